@@ -1,0 +1,158 @@
+/*
+ * mbls.h -- C ABI of libmbls_hip.so: MI355X (gfx950) batch BLS12-381 signature verification.
+ *
+ * This is the drop-in boundary for the verification path of sigp/milagro_bls. The reference has no FFI of
+ * its own (it is a Rust library over the `amcl` crate); these entry points are what a Rust shim re-creating
+ * reference src/lib.rs:17-22 would bind. Each entry cites the reference interface it
+ * replaces. Plain pointers and sizes only; the caller owns every buffer.
+ *
+ * Wire formats (ZCash BLS12-381 serialization, as in the reference):
+ *   signature / aggregate signature : 96 bytes, compressed G2      (Signature::as_bytes, src/signature.rs:49-51)
+ *   public key, compressed          : 48 bytes                      (PublicKey::as_bytes, src/keys.rs:158-160)
+ *   public key, uncompressed        : 96 bytes x||y                 (PublicKey::as_uncompressed_bytes, src/keys.rs:163-165)
+ *   secret key                      : 32 bytes big-endian           (SecretKey::as_bytes, src/keys.rs:85-87)
+ * A decoded PublicKey / AggregatePublicKey object is represented by its 96-byte uncompressed form, a decoded
+ * Signature / AggregateSignature by its 96-byte compressed form (amcl's in-memory layout is private).
+ *
+ * There is NO CPU fallback: every function runs HIP kernels and returns MBLS_ERR_DEVICE if the GPU is
+ * unavailable. `*_device` variants take device pointers (inputs already resident in HBM) and a hipStream_t
+ * (passed as void*); the others take host pointers and stage through the context's device buffers.
+ */
+#ifndef MBLS_H
+#define MBLS_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* error codes: the AmclError variants the reference uses (src/amcl_utils.rs:55,71; src/keys.rs:47,143,293;
+   src/aggregates.rs:31) plus device errors */
+#define MBLS_OK 0
+#define MBLS_ERR_INVALID_G1_SIZE 1          /* AmclError::InvalidG1Size */
+#define MBLS_ERR_INVALID_G2_SIZE 2          /* AmclError::InvalidG2Size */
+#define MBLS_ERR_INVALID_POINT 3            /* AmclError::InvalidPoint */
+#define MBLS_ERR_AGGREGATE_EMPTY_POINTS 4   /* AmclError::AggregateEmptyPoints */
+#define MBLS_ERR_INVALID_SECRET_KEY_SIZE 5  /* AmclError::InvalidSecretKeySize */
+#define MBLS_ERR_INVALID_SECRET_KEY_RANGE 6 /* AmclError::InvalidSecretKeyRange */
+#define MBLS_ERR_DEVICE 100                 /* HIP failure / no GPU */
+#define MBLS_ERR_ARGUMENT 101
+
+#define MBLS_G1_BYTES 48                    /* reference src/lib.rs:20 G1_BYTES */
+#define MBLS_G2_BYTES 96                    /* reference src/lib.rs:20 G2_BYTES */
+#define MBLS_SECRET_KEY_BYTES 32            /* reference src/lib.rs:20 SECRET_KEY_BYTES */
+#define MBLS_PK_COMPRESSED 0
+#define MBLS_PK_UNCOMPRESSED 1
+
+/* per-item status bits reported by the batch verifiers (why an item was rejected) */
+#define MBLS_ST_BAD_SIG_ENCODING 0x01u
+#define MBLS_ST_SIG_NOT_IN_G2 0x02u
+#define MBLS_ST_BAD_PK_ENCODING 0x04u
+#define MBLS_ST_APK_INFINITY 0x08u
+#define MBLS_ST_NO_KEYS 0x10u
+#define MBLS_ST_PK_INFINITY 0x20u
+#define MBLS_ST_PAIRING_FAILED 0x40u
+
+typedef struct mbls_ctx mbls_ctx;
+
+/* ---- context: one per GPU (one process per GPU in multi-GPU runs) ---- */
+int mbls_ctx_create(mbls_ctx** out, int device_id);
+void mbls_ctx_destroy(mbls_ctx* ctx);
+/* pre-allocate the HBM workspace for batches of up to max_items items (avoids allocation in timed regions) */
+int mbls_ctx_reserve(mbls_ctx* ctx, uint64_t max_items);
+const char* mbls_last_error(mbls_ctx* ctx);
+
+/* ---- the hot path -------------------------------------------------------------------------------------
+ * Batch of n independent AggregateSignature::fast_aggregate_verify calls (reference src/aggregates.rs:177-215):
+ * item i = (sigs[96 i..], msgs[msg_len i..], its public keys). Keys are either k per item, contiguous
+ * (pk_offsets == NULL), or ragged: item i owns keys [pk_offsets[i], pk_offsets[i+1]) of `pks`.
+ * results[i] = 1/0 exactly as the reference function returns true/false, including its check order:
+ * empty key list -> 0, signature outside G2 -> 0, aggregate key = infinity -> 0, pairing check.
+ * bitmap (optional, ceil(n/64) words): bit (i%64) of word i/64 = results[i]. status (optional): MBLS_ST_* bits. */
+int mbls_fast_aggregate_verify_batch_device(mbls_ctx* ctx, const uint8_t* d_sigs, const uint8_t* d_msgs, uint32_t msg_len,
+                                            const uint8_t* d_pks, int pk_format, const uint32_t* d_pk_offsets,
+                                            uint64_t n, uint32_t k, uint8_t* d_results, uint64_t* d_bitmap,
+                                            uint32_t* d_status, void* stream);
+int mbls_fast_aggregate_verify_batch(mbls_ctx* ctx, const uint8_t* sigs, const uint8_t* msgs, uint32_t msg_len,
+                                     const uint8_t* pks, int pk_format, const uint32_t* pk_offsets,
+                                     uint64_t n, uint32_t k, uint8_t* results, uint32_t* status);
+/* Batch of n Signature::verify calls (reference src/signature.rs:27-40): one key per item, no infinity check. */
+int mbls_verify_batch_device(mbls_ctx* ctx, const uint8_t* d_sigs, const uint8_t* d_msgs, uint32_t msg_len,
+                             const uint8_t* d_pks, int pk_format, uint64_t n, uint8_t* d_results, uint64_t* d_bitmap,
+                             uint32_t* d_status, void* stream);
+int mbls_verify_batch(mbls_ctx* ctx, const uint8_t* sigs, const uint8_t* msgs, uint32_t msg_len,
+                      const uint8_t* pks, int pk_format, uint64_t n, uint8_t* results, uint32_t* status);
+
+/* ---- scalar API, 1:1 with the reference's methods (each runs the batch kernels with n = 1) ---- */
+/* PublicKey::from_bytes (src/keys.rs:140-147): compressed decode + KeyValidate -> 96-byte decoded key */
+int mbls_pk_from_bytes(mbls_ctx* ctx, const uint8_t* bytes, size_t len, uint8_t pk_out[96]);
+/* PublicKey::from_bytes_unchecked (src/keys.rs:150-155) */
+int mbls_pk_from_bytes_unchecked(mbls_ctx* ctx, const uint8_t* bytes, size_t len, uint8_t pk_out[96]);
+/* PublicKey::from_uncompressed_bytes (src/keys.rs:170-175) */
+int mbls_pk_from_uncompressed_bytes(mbls_ctx* ctx, const uint8_t* bytes, size_t len, uint8_t pk_out[96]);
+/* PublicKey::as_bytes (src/keys.rs:158-160) */
+int mbls_pk_as_bytes(mbls_ctx* ctx, const uint8_t pk[96], uint8_t out[48]);
+/* PublicKey::key_validate (src/keys.rs:181-186) -> 1/0 */
+int mbls_pk_key_validate(mbls_ctx* ctx, const uint8_t pk[96]);
+/* PublicKey::from_secret_key (src/keys.rs:124-137); sk range is checked like SecretKey::from_bytes (src/keys.rs:80-82) */
+int mbls_pk_from_secret_key(mbls_ctx* ctx, const uint8_t* sk, size_t sk_len, uint8_t pk_out[96]);
+/* Signature::from_bytes / AggregateSignature::from_bytes (src/signature.rs:43-46, src/aggregates.rs:319-322) */
+int mbls_sig_from_bytes(mbls_ctx* ctx, const uint8_t* bytes, size_t len, uint8_t sig_out[96]);
+/* Signature::new (src/signature.rs:17-21) */
+int mbls_sign(mbls_ctx* ctx, const uint8_t* msg, size_t msg_len, const uint8_t* sk, size_t sk_len, uint8_t sig_out[96]);
+/* Signature::verify (src/signature.rs:27-40) -> 1/0 */
+int mbls_verify(mbls_ctx* ctx, const uint8_t sig[96], const uint8_t* msg, size_t msg_len, const uint8_t pk[96]);
+/* AggregatePublicKey::aggregate / into_aggregate (src/aggregates.rs:29-56): n decoded keys -> decoded aggregate */
+int mbls_aggregate_public_keys(mbls_ctx* ctx, const uint8_t* pks96, size_t n, uint8_t apk_out[96]);
+/* AggregatePublicKey::add / add_aggregate (src/aggregates.rs:68-77) */
+int mbls_aggregate_public_key_add(mbls_ctx* ctx, const uint8_t a[96], const uint8_t b[96], uint8_t out[96]);
+/* AggregateSignature::add / add_aggregate (src/aggregates.rs:114-124); AggregateSignature::new() is 0xC0||0.. */
+int mbls_aggregate_signature_add(mbls_ctx* ctx, const uint8_t a[96], const uint8_t b[96], uint8_t out[96]);
+/* AggregateSignature::fast_aggregate_verify (src/aggregates.rs:177-215) -> 1/0 */
+int mbls_fast_aggregate_verify(mbls_ctx* ctx, const uint8_t sig[96], const uint8_t* msg, size_t msg_len,
+                               const uint8_t* pks96, size_t n_pks);
+/* AggregateSignature::fast_aggregate_verify_pre_aggregated (src/aggregates.rs:223-253) -> 1/0 */
+int mbls_fast_aggregate_verify_pre_aggregated(mbls_ctx* ctx, const uint8_t sig[96], const uint8_t* msg, size_t msg_len,
+                                              const uint8_t apk[96]);
+/* AggregateSignature::aggregate_verify (src/aggregates.rs:130-170): n messages of msg_lens[i] bytes, concatenated */
+int mbls_aggregate_verify(mbls_ctx* ctx, const uint8_t sig[96], const uint8_t* msgs, const size_t* msg_lens, size_t n_msgs,
+                          const uint8_t* pks96, size_t n_pks);
+/* AggregateSignature::verify_multiple_aggregate_signatures (src/aggregates.rs:261-316): n sets of
+ * (aggregate signature, aggregate public key, message); rands[i] = the nonzero 63-bit blinding scalars drawn
+ * from the caller's RNG exactly as at src/aggregates.rs:280-287. One bool for the whole batch. */
+int mbls_verify_multiple_aggregate_signatures(mbls_ctx* ctx, const uint8_t* sigs96, const uint8_t* apks96,
+                                              const uint8_t* msgs, uint32_t msg_len, const uint64_t* rands, size_t n);
+int mbls_verify_multiple_aggregate_signatures_device(mbls_ctx* ctx, const uint8_t* d_sigs96, const uint8_t* d_apks96,
+                                              const uint8_t* d_msgs, uint32_t msg_len, const uint64_t* d_rands, uint64_t n,
+                                              int* result, void* stream);
+
+/* ---- batch helpers used to build inputs and caches on the device ---- */
+/* n x PublicKey::from_bytes[_unchecked] / from_uncompressed_bytes: errs[i] = MBLS_OK / MBLS_ERR_* per key */
+int mbls_pk_decode_batch(mbls_ctx* ctx, const uint8_t* in, int in_format, int validate, uint64_t n, uint8_t* out96, uint8_t* errs);
+int mbls_pk_compress_batch(mbls_ctx* ctx, const uint8_t* in96, uint64_t n, uint8_t* out48, uint8_t* errs);
+/* n x Signature::from_bytes: errs[i]; in_g2 (optional) = subgroup_check_g2 per signature */
+int mbls_sig_check_batch(mbls_ctx* ctx, const uint8_t* in96, uint64_t n, uint8_t* errs, uint8_t* in_g2);
+/* n x Signature::new / PublicKey::from_secret_key (secret keys are NOT range-checked here) */
+int mbls_sign_batch(mbls_ctx* ctx, const uint8_t* sks32, const uint8_t* msgs, uint32_t msg_len, uint64_t n, uint8_t* sigs96);
+int mbls_sign_batch_device(mbls_ctx* ctx, const uint8_t* d_sks32, const uint8_t* d_msgs, uint32_t msg_len, uint64_t n, uint8_t* d_sigs96, void* stream);
+int mbls_sk_to_pk_batch(mbls_ctx* ctx, const uint8_t* sks32, int out_format, uint64_t n, uint8_t* pks);
+int mbls_sk_to_pk_batch_device(mbls_ctx* ctx, const uint8_t* d_sks32, int out_format, uint64_t n, uint8_t* d_pks, void* stream);
+/* n x hash_to_curve_g2 (src/amcl_utils.rs:33-35), compressed output */
+int mbls_hash_to_g2_batch(mbls_ctx* ctx, const uint8_t* msgs, uint32_t msg_len, uint64_t n, uint8_t* out96);
+/* n x AggregatePublicKey::aggregate over wire-format keys -> decoded aggregate keys */
+int mbls_aggregate_public_keys_batch(mbls_ctx* ctx, const uint8_t* pks, int pk_format, const uint32_t* pk_offsets,
+                                     uint64_t n, uint32_t k, uint8_t* apks96, uint32_t* status);
+/* field probe for parity tests and the ALU microbenchmark: out = a*b (or a^2) mod p on 48-byte big-endian values */
+int mbls_fp_mul_batch(mbls_ctx* ctx, const uint8_t* a48, const uint8_t* b48, uint64_t n, uint8_t* out48, int square);
+/* integer-ALU calibration: runs `iters` dependent Fp multiplications per lane on n lanes, returns elapsed ms */
+int mbls_fp_mul_bench(mbls_ctx* ctx, uint64_t n_lanes, uint32_t iters, float* ms_out);
+
+/* ---- instrumentation: per-kernel HIP-event timing of the last *_device verify call (ms), for bench.py ---- */
+#define MBLS_N_PHASES 6
+int mbls_enable_phase_timing(mbls_ctx* ctx, int on);
+int mbls_last_phase_ms(mbls_ctx* ctx, float ms[MBLS_N_PHASES]);   /* aggregate, sig, hash, miller, final, pack */
+
+#ifdef __cplusplus
+}
+#endif
+#endif

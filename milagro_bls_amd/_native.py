@@ -1,0 +1,153 @@
+"""ctypes loader for libmbls_hip.so. There is no CPU fallback: if the HIP library is missing, or no GPU
+is present when a context is created, this raises."""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libmbls_hip.so")
+
+# error codes (include/mbls.h)
+OK = 0
+ERR_INVALID_G1_SIZE = 1
+ERR_INVALID_G2_SIZE = 2
+ERR_INVALID_POINT = 3
+ERR_AGGREGATE_EMPTY_POINTS = 4
+ERR_INVALID_SECRET_KEY_SIZE = 5
+ERR_INVALID_SECRET_KEY_RANGE = 6
+ERR_DEVICE = 100
+ERR_ARGUMENT = 101
+PK_COMPRESSED, PK_UNCOMPRESSED = 0, 1
+N_PHASES = 6
+PHASE_NAMES = ("aggregate", "sig", "hash", "miller", "final", "pack")
+
+_lib = None
+
+u8p = C.POINTER(C.c_uint8)
+u32p = C.POINTER(C.c_uint32)
+u64p = C.POINTER(C.c_uint64)
+vp = C.c_void_p
+SIGNATURES = {
+    "mbls_ctx_create": (C.c_int, [C.POINTER(vp), C.c_int]),
+    "mbls_ctx_destroy": (None, [vp]),
+    "mbls_ctx_reserve": (C.c_int, [vp, C.c_uint64]),
+    "mbls_last_error": (C.c_char_p, [vp]),
+    "mbls_fast_aggregate_verify_batch_device": (C.c_int, [vp, vp, vp, C.c_uint32, vp, C.c_int, vp, C.c_uint64, C.c_uint32, vp, vp, vp, vp]),
+    "mbls_fast_aggregate_verify_batch": (C.c_int, [vp, vp, vp, C.c_uint32, vp, C.c_int, vp, C.c_uint64, C.c_uint32, vp, vp]),
+    "mbls_verify_batch_device": (C.c_int, [vp, vp, vp, C.c_uint32, vp, C.c_int, C.c_uint64, vp, vp, vp, vp]),
+    "mbls_verify_batch": (C.c_int, [vp, vp, vp, C.c_uint32, vp, C.c_int, C.c_uint64, vp, vp]),
+    "mbls_pk_from_bytes": (C.c_int, [vp, vp, C.c_size_t, vp]),
+    "mbls_pk_from_bytes_unchecked": (C.c_int, [vp, vp, C.c_size_t, vp]),
+    "mbls_pk_from_uncompressed_bytes": (C.c_int, [vp, vp, C.c_size_t, vp]),
+    "mbls_pk_as_bytes": (C.c_int, [vp, vp, vp]),
+    "mbls_pk_key_validate": (C.c_int, [vp, vp]),
+    "mbls_pk_from_secret_key": (C.c_int, [vp, vp, C.c_size_t, vp]),
+    "mbls_sig_from_bytes": (C.c_int, [vp, vp, C.c_size_t, vp]),
+    "mbls_sign": (C.c_int, [vp, vp, C.c_size_t, vp, C.c_size_t, vp]),
+    "mbls_verify": (C.c_int, [vp, vp, vp, C.c_size_t, vp]),
+    "mbls_aggregate_public_keys": (C.c_int, [vp, vp, C.c_size_t, vp]),
+    "mbls_aggregate_public_key_add": (C.c_int, [vp, vp, vp, vp]),
+    "mbls_aggregate_signature_add": (C.c_int, [vp, vp, vp, vp]),
+    "mbls_fast_aggregate_verify": (C.c_int, [vp, vp, vp, C.c_size_t, vp, C.c_size_t]),
+    "mbls_fast_aggregate_verify_pre_aggregated": (C.c_int, [vp, vp, vp, C.c_size_t, vp]),
+    "mbls_aggregate_verify": (C.c_int, [vp, vp, vp, vp, C.c_size_t, vp, C.c_size_t]),
+    "mbls_verify_multiple_aggregate_signatures": (C.c_int, [vp, vp, vp, vp, C.c_uint32, vp, C.c_size_t]),
+    "mbls_verify_multiple_aggregate_signatures_device": (C.c_int, [vp, vp, vp, vp, C.c_uint32, vp, C.c_uint64, C.POINTER(C.c_int), vp]),
+    "mbls_pk_decode_batch": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_uint64, vp, vp]),
+    "mbls_pk_compress_batch": (C.c_int, [vp, vp, C.c_uint64, vp, vp]),
+    "mbls_sig_check_batch": (C.c_int, [vp, vp, C.c_uint64, vp, vp]),
+    "mbls_sign_batch": (C.c_int, [vp, vp, vp, C.c_uint32, C.c_uint64, vp]),
+    "mbls_sign_batch_device": (C.c_int, [vp, vp, vp, C.c_uint32, C.c_uint64, vp, vp]),
+    "mbls_sk_to_pk_batch": (C.c_int, [vp, vp, C.c_int, C.c_uint64, vp]),
+    "mbls_sk_to_pk_batch_device": (C.c_int, [vp, vp, C.c_int, C.c_uint64, vp, vp]),
+    "mbls_hash_to_g2_batch": (C.c_int, [vp, vp, C.c_uint32, C.c_uint64, vp]),
+    "mbls_aggregate_public_keys_batch": (C.c_int, [vp, vp, C.c_int, vp, C.c_uint64, C.c_uint32, vp, vp]),
+    "mbls_fp_mul_batch": (C.c_int, [vp, vp, vp, C.c_uint64, vp, C.c_int]),
+    "mbls_fp_mul_bench": (C.c_int, [vp, C.c_uint64, C.c_uint32, C.POINTER(C.c_float)]),
+    "mbls_enable_phase_timing": (C.c_int, [vp, C.c_int]),
+    "mbls_last_phase_ms": (C.c_int, [vp, C.POINTER(C.c_float)]),
+}
+
+
+class MblsError(RuntimeError):
+    def __init__(self, code, what=""):
+        super().__init__("mbls error %d %s" % (code, what))
+        self.code = code
+
+
+def lib():
+    """Load libmbls_hip.so (raises if it has not been built: there is no fallback)."""
+    global _lib
+    if _lib is None:
+        # PyTorch-ROCm wheels bundle their own libamdhip64.so.7 / HSA runtime. Two HIP runtimes in one process
+        # do not coexist (the second one finds no GPU), so when torch is installed it is imported first: our
+        # library's NEEDED libamdhip64.so.7 then resolves to the copy torch already loaded. Set MBLS_STANDALONE=1
+        # to skip this and run against /opt/rocm's runtime alone.
+        if os.environ.get("MBLS_STANDALONE", "0") != "1":
+            try:
+                import torch  # noqa: F401
+            except ImportError:
+                pass
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError("libmbls_hip.so not built: run `python -m milagro_bls_amd.build` (HIP extension is mandatory)")
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            f = getattr(l, name)
+            f.restype = res
+            f.argtypes = args
+        _lib = l
+    return _lib
+
+
+class Context:
+    """One mbls_ctx per GPU."""
+
+    def __init__(self, device_id=0):
+        self._h = vp()
+        rc = lib().mbls_ctx_create(C.byref(self._h), device_id)
+        if rc != OK:
+            raise MblsError(rc, "mbls_ctx_create failed (no MI355X / HIP device available?)")
+
+    def close(self):
+        if self._h:
+            lib().mbls_ctx_destroy(self._h)
+            self._h = vp()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def handle(self):
+        return self._h
+
+    def last_error(self):
+        return lib().mbls_last_error(self._h).decode()
+
+    def check(self, rc):
+        if rc != OK:
+            raise MblsError(rc, self.last_error())
+
+    def reserve(self, n):
+        self.check(lib().mbls_ctx_reserve(self._h, n))
+
+
+_default_ctx = None
+
+
+def default_context():
+    global _default_ctx
+    if _default_ctx is None:
+        _default_ctx = Context(int(os.environ.get("MBLS_DEVICE", "0")))
+    return _default_ctx
+
+
+def cbuf(data):
+    """bytes -> ctypes buffer (kept alive by the caller)."""
+    data = bytes(data)
+    return (C.c_uint8 * max(1, len(data))).from_buffer_copy(data if data else b"\0")
+
+
+def outbuf(n):
+    return (C.c_uint8 * max(1, n))()

@@ -1,0 +1,313 @@
+"""Host-side mirror of the reference's public API (reference src/lib.rs:17-22) over the C ABI of
+libmbls_hip.so: same type and method names, argument meaning and error behaviour, so that the parity tests
+read like the reference's own tests. Every numeric operation runs in the HIP kernels (no CPU arithmetic
+here apart from SecretKey's HKDF key derivation, which the reference also does on the host, src/keys.rs:45-77).
+
+    reference                                   here
+    ---------                                   ----
+    SecretKey / PublicKey / Keypair             src/keys.rs:28-204
+    Signature                                   src/signature.rs:9-51
+    AggregatePublicKey / AggregateSignature     src/aggregates.rs:17-334
+    AmclError                                   amcl::errors::AmclError (src/amcl_utils.rs:11)
+"""
+import ctypes as C
+import hashlib
+import hmac
+import os
+
+from . import _native as N
+
+G1_BYTES = 48            # reference src/lib.rs:20
+G2_BYTES = 96
+SECRET_KEY_BYTES = 32
+CURVE_ORDER = 0x73eda753299d7d483339d80809a1d80553bda402fffe5bfeffffffff00000001
+KEY_SALT = b"BLS-SIG-KEYGEN-SALT-"   # reference src/keys.rs:24
+L = 48                                # reference src/keys.rs:26
+_G2_INFINITY = bytes([0xC0]) + bytes(95)
+
+
+class AmclError(Exception):
+    """Mirror of the AmclError variants the reference uses."""
+    InvalidG1Size = N.ERR_INVALID_G1_SIZE
+    InvalidG2Size = N.ERR_INVALID_G2_SIZE
+    InvalidPoint = N.ERR_INVALID_POINT
+    AggregateEmptyPoints = N.ERR_AGGREGATE_EMPTY_POINTS
+    InvalidSecretKeySize = N.ERR_INVALID_SECRET_KEY_SIZE
+    InvalidSecretKeyRange = N.ERR_INVALID_SECRET_KEY_RANGE
+    _NAMES = {1: "InvalidG1Size", 2: "InvalidG2Size", 3: "InvalidPoint", 4: "AggregateEmptyPoints",
+              5: "InvalidSecretKeySize", 6: "InvalidSecretKeyRange"}
+
+    def __init__(self, code):
+        super().__init__(self._NAMES.get(code, "DeviceError(%d)" % code))
+        self.code = code
+
+    def __eq__(self, other):
+        return isinstance(other, AmclError) and other.code == self.code
+
+    def __hash__(self):
+        return hash(self.code)
+
+
+def _ctx():
+    return N.default_context()
+
+
+def _raise(rc):
+    if rc != N.OK:
+        if rc >= N.ERR_DEVICE:
+            raise N.MblsError(rc, _ctx().last_error())
+        raise AmclError(rc)
+
+
+class SecretKey:
+    """reference src/keys.rs:28-113. Host-only object; the scalar is sent to the GPU only for signing."""
+
+    def __init__(self, x):
+        self._x = int(x)
+
+    @classmethod
+    def random(cls, rng=None):
+        ikm = os.urandom(32) if rng is None else bytes(rng.getrandbits(8) for _ in range(32))
+        return cls.key_generate(ikm, b"")
+
+    @classmethod
+    def key_generate(cls, ikm, key_info=b""):
+        """KeyGenerate, reference src/keys.rs:45-77 (HKDF-SHA256 with the salt-rehash loop)."""
+        if len(ikm) < 32:
+            raise AmclError(AmclError.InvalidSecretKeySize)
+        sk, salt = 0, KEY_SALT
+        while sk == 0:
+            salt = hashlib.sha256(salt).digest()
+            prk = hmac.new(salt, bytes(ikm) + b"\x00", hashlib.sha256).digest()
+            info = bytes(key_info) + bytes([0, L])
+            okm, t, i = b"", b"", 1
+            while len(okm) < L:
+                t = hmac.new(prk, t + info + bytes([i]), hashlib.sha256).digest()
+                okm += t
+                i += 1
+            sk = int.from_bytes(okm[:L], "big") % CURVE_ORDER
+        return cls(sk)
+
+    @classmethod
+    def from_bytes(cls, data):
+        """reference src/keys.rs:80-82, error cases pinned by tests at src/keys.rs:285-297."""
+        data = bytes(data)
+        if len(data) != SECRET_KEY_BYTES:
+            raise AmclError(AmclError.InvalidSecretKeySize)
+        x = int.from_bytes(data, "big")
+        if x == 0 or x >= CURVE_ORDER:
+            raise AmclError(AmclError.InvalidSecretKeyRange)
+        return cls(x)
+
+    def as_bytes(self):
+        return self._x.to_bytes(SECRET_KEY_BYTES, "big")
+
+    def as_raw(self):
+        return self._x
+
+    def __eq__(self, other):
+        return isinstance(other, SecretKey) and self.as_bytes() == other.as_bytes()
+
+
+class PublicKey:
+    """reference src/keys.rs:116-187. `point` is the 96-byte uncompressed form (amcl's layout is private)."""
+
+    def __init__(self, point):
+        self.point = bytes(point)
+
+    @classmethod
+    def from_secret_key(cls, sk):
+        out = N.outbuf(96)
+        _raise(N.lib().mbls_pk_from_secret_key(_ctx().handle, N.cbuf(sk.as_bytes()), 32, out))
+        return cls(bytes(out))
+
+    @classmethod
+    def from_bytes(cls, data):
+        out = N.outbuf(96)
+        _raise(N.lib().mbls_pk_from_bytes(_ctx().handle, N.cbuf(data), len(data), out))
+        return cls(bytes(out))
+
+    @classmethod
+    def from_bytes_unchecked(cls, data):
+        out = N.outbuf(96)
+        _raise(N.lib().mbls_pk_from_bytes_unchecked(_ctx().handle, N.cbuf(data), len(data), out))
+        return cls(bytes(out))
+
+    @classmethod
+    def from_uncompressed_bytes(cls, data):
+        out = N.outbuf(96)
+        _raise(N.lib().mbls_pk_from_uncompressed_bytes(_ctx().handle, N.cbuf(data), len(data), out))
+        return cls(bytes(out))
+
+    def as_bytes(self):
+        out = N.outbuf(48)
+        _raise(N.lib().mbls_pk_as_bytes(_ctx().handle, N.cbuf(self.point), out))
+        return bytes(out)
+
+    def as_uncompressed_bytes(self):
+        return self.point
+
+    def key_validate(self):
+        return bool(N.lib().mbls_pk_key_validate(_ctx().handle, N.cbuf(self.point)))
+
+    def is_infinity(self):
+        return self.point[0] == 0x40
+
+    def __eq__(self, other):
+        return isinstance(other, PublicKey) and self.point == other.point
+
+
+class Keypair:
+    """reference src/keys.rs:189-204."""
+
+    def __init__(self, sk, pk):
+        self.sk, self.pk = sk, pk
+
+    @classmethod
+    def random(cls, rng=None):
+        sk = SecretKey.random(rng)
+        return cls(sk, PublicKey.from_secret_key(sk))
+
+
+class Signature:
+    """reference src/signature.rs:9-51. `point` is the 96-byte compressed form."""
+
+    def __init__(self, point):
+        self.point = bytes(point)
+
+    @classmethod
+    def new(cls, msg, sk):
+        out = N.outbuf(96)
+        _raise(N.lib().mbls_sign(_ctx().handle, N.cbuf(msg), len(msg), N.cbuf(sk.as_bytes()), 32, out))
+        return cls(bytes(out))
+
+    def verify(self, msg, pk):
+        return bool(N.lib().mbls_verify(_ctx().handle, N.cbuf(self.point), N.cbuf(msg), len(msg), N.cbuf(pk.point)))
+
+    @classmethod
+    def from_bytes(cls, data):
+        out = N.outbuf(96)
+        _raise(N.lib().mbls_sig_from_bytes(_ctx().handle, N.cbuf(data), len(data), out))
+        return cls(bytes(out))
+
+    def as_bytes(self):
+        return self.point
+
+    def __eq__(self, other):
+        return isinstance(other, Signature) and self.point == other.point
+
+
+class AggregatePublicKey:
+    """reference src/aggregates.rs:17-78."""
+
+    def __init__(self, point):
+        self.point = bytes(point)
+
+    @classmethod
+    def aggregate(cls, keys):
+        if len(keys) == 0:
+            raise AmclError(AmclError.AggregateEmptyPoints)
+        out = N.outbuf(96)
+        _raise(N.lib().mbls_aggregate_public_keys(_ctx().handle, N.cbuf(b"".join(k.point for k in keys)), len(keys), out))
+        return cls(bytes(out))
+
+    into_aggregate = aggregate
+
+    @classmethod
+    def from_public_key(cls, key):
+        return cls(key.point)
+
+    def add(self, public_key):
+        out = N.outbuf(96)
+        _raise(N.lib().mbls_aggregate_public_key_add(_ctx().handle, N.cbuf(self.point), N.cbuf(public_key.point), out))
+        self.point = bytes(out)
+
+    def add_aggregate(self, other):
+        self.add(other)
+
+    def is_infinity(self):
+        return self.point[0] == 0x40
+
+    def __eq__(self, other):
+        return isinstance(other, AggregatePublicKey) and self.point == other.point
+
+
+class AggregateSignature:
+    """reference src/aggregates.rs:83-334."""
+
+    def __init__(self, point=_G2_INFINITY):
+        self.point = bytes(point)
+
+    @classmethod
+    def new(cls):
+        return cls(_G2_INFINITY)
+
+    @classmethod
+    def aggregate(cls, signatures):
+        agg = cls.new()
+        for s in signatures:
+            agg.add(s)
+        return agg
+
+    @classmethod
+    def from_signature(cls, signature):
+        return cls(signature.point)
+
+    def clone(self):
+        return AggregateSignature(self.point)
+
+    def add(self, signature):
+        out = N.outbuf(96)
+        _raise(N.lib().mbls_aggregate_signature_add(_ctx().handle, N.cbuf(self.point), N.cbuf(signature.point), out))
+        self.point = bytes(out)
+
+    def add_aggregate(self, other):
+        self.add(other)
+
+    def aggregate_verify(self, msgs, public_keys):
+        lens = (C.c_size_t * max(1, len(msgs)))(*[len(m) for m in msgs])
+        return bool(N.lib().mbls_aggregate_verify(_ctx().handle, N.cbuf(self.point), N.cbuf(b"".join(msgs)), lens, len(msgs),
+                                                   N.cbuf(b"".join(k.point for k in public_keys)), len(public_keys)))
+
+    def fast_aggregate_verify(self, msg, public_keys):
+        return bool(N.lib().mbls_fast_aggregate_verify(_ctx().handle, N.cbuf(self.point), N.cbuf(msg), len(msg),
+                                                        N.cbuf(b"".join(k.point for k in public_keys)), len(public_keys)))
+
+    def fast_aggregate_verify_pre_aggregated(self, msg, aggregate_public_key):
+        return bool(N.lib().mbls_fast_aggregate_verify_pre_aggregated(_ctx().handle, N.cbuf(self.point), N.cbuf(msg), len(msg),
+                                                                       N.cbuf(aggregate_public_key.point)))
+
+    @staticmethod
+    def verify_multiple_aggregate_signatures(rng, signature_sets):
+        """reference src/aggregates.rs:261-316. `rng` must offer getrandbits (random.Random); the blinding scalars
+        are drawn exactly as at :280-287: 8 random bytes, big-endian i64, absolute value, retry on zero.
+        All messages must have the same length (the batch kernel's layout); 32 bytes in the Eth2 use."""
+        sets = list(signature_sets)
+        rands = []
+        for _ in sets:
+            r = 0
+            while r == 0:
+                v = int.from_bytes(bytes(rng.getrandbits(8) for _ in range(8)), "big", signed=True)
+                r = abs(v) & 0xFFFFFFFFFFFFFFFF
+            rands.append(r)
+        if not sets:
+            return bool(N.lib().mbls_verify_multiple_aggregate_signatures(_ctx().handle, None, None, None, 0, None, 0))
+        mlen = len(sets[0][2])
+        if any(len(s[2]) != mlen for s in sets):
+            raise ValueError("verify_multiple_aggregate_signatures: messages must have equal length")
+        rr = (C.c_uint64 * len(sets))(*rands)
+        return bool(N.lib().mbls_verify_multiple_aggregate_signatures(
+            _ctx().handle, N.cbuf(b"".join(s[0].point for s in sets)), N.cbuf(b"".join(s[1].point for s in sets)),
+            N.cbuf(b"".join(bytes(s[2]) for s in sets)), mlen, rr, len(sets)))
+
+    @classmethod
+    def from_bytes(cls, data):
+        out = N.outbuf(96)
+        _raise(N.lib().mbls_sig_from_bytes(_ctx().handle, N.cbuf(data), len(data), out))
+        return cls(bytes(out))
+
+    def as_bytes(self):
+        return self.point
+
+    def __eq__(self, other):
+        return isinstance(other, AggregateSignature) and self.point == other.point

@@ -1,0 +1,103 @@
+"""Batch entry points (host buffers in, results out) and device-pointer entry points for callers that keep
+their inputs resident in HBM (bench.py uses torch tensors only as device memory + stream plumbing)."""
+import ctypes as C
+
+from . import _native as N
+
+
+def _c():
+    return N.default_context()
+
+
+def fast_aggregate_verify_batch(sigs, msgs, pks, n, k=None, pk_format=N.PK_COMPRESSED, msg_len=32, pk_offsets=None, ctx=None):
+    """n x AggregateSignature::fast_aggregate_verify (reference src/aggregates.rs:177-215).
+    Returns (results: list[bool], status: list[int])."""
+    ctx = ctx or _c()
+    res = N.outbuf(n)
+    st = (C.c_uint32 * max(1, n))()
+    off = None
+    if pk_offsets is not None:
+        off = (C.c_uint32 * len(pk_offsets))(*pk_offsets)
+        k = 0
+    ctx.check(N.lib().mbls_fast_aggregate_verify_batch(ctx.handle, N.cbuf(sigs), N.cbuf(msgs), msg_len, N.cbuf(pks), pk_format,
+                                                       off, n, k, res, st))
+    return [bool(x) for x in bytes(res)[:n]], list(st)[:n]
+
+
+def verify_batch(sigs, msgs, pks, n, pk_format=N.PK_COMPRESSED, msg_len=32, ctx=None):
+    """n x Signature::verify (reference src/signature.rs:27-40)."""
+    ctx = ctx or _c()
+    res = N.outbuf(n)
+    st = (C.c_uint32 * max(1, n))()
+    ctx.check(N.lib().mbls_verify_batch(ctx.handle, N.cbuf(sigs), N.cbuf(msgs), msg_len, N.cbuf(pks), pk_format, n, res, st))
+    return [bool(x) for x in bytes(res)[:n]], list(st)[:n]
+
+
+def pk_decode_batch(data, n, in_format=N.PK_COMPRESSED, validate=True, ctx=None):
+    ctx = ctx or _c()
+    out, errs = N.outbuf(96 * n), N.outbuf(n)
+    ctx.check(N.lib().mbls_pk_decode_batch(ctx.handle, N.cbuf(data), in_format, int(validate), n, out, errs))
+    return bytes(out)[:96 * n], list(bytes(errs)[:n])
+
+
+def pk_compress_batch(data96, n, ctx=None):
+    ctx = ctx or _c()
+    out, errs = N.outbuf(48 * n), N.outbuf(n)
+    ctx.check(N.lib().mbls_pk_compress_batch(ctx.handle, N.cbuf(data96), n, out, errs))
+    return bytes(out)[:48 * n], list(bytes(errs)[:n])
+
+
+def sig_check_batch(data96, n, ctx=None):
+    ctx = ctx or _c()
+    errs, g2 = N.outbuf(n), N.outbuf(n)
+    ctx.check(N.lib().mbls_sig_check_batch(ctx.handle, N.cbuf(data96), n, errs, g2))
+    return list(bytes(errs)[:n]), [bool(x) for x in bytes(g2)[:n]]
+
+
+def sign_batch(sks32, msgs, n, msg_len=32, ctx=None):
+    ctx = ctx or _c()
+    out = N.outbuf(96 * n)
+    ctx.check(N.lib().mbls_sign_batch(ctx.handle, N.cbuf(sks32), N.cbuf(msgs), msg_len, n, out))
+    return bytes(out)[:96 * n]
+
+
+def sk_to_pk_batch(sks32, n, out_format=N.PK_COMPRESSED, ctx=None):
+    ctx = ctx or _c()
+    sz = 48 if out_format == N.PK_COMPRESSED else 96
+    out = N.outbuf(sz * n)
+    ctx.check(N.lib().mbls_sk_to_pk_batch(ctx.handle, N.cbuf(sks32), out_format, n, out))
+    return bytes(out)[:sz * n]
+
+
+def hash_to_g2_batch(msgs, n, msg_len=32, ctx=None):
+    ctx = ctx or _c()
+    out = N.outbuf(96 * n)
+    ctx.check(N.lib().mbls_hash_to_g2_batch(ctx.handle, N.cbuf(msgs), msg_len, n, out))
+    return bytes(out)[:96 * n]
+
+
+def aggregate_public_keys_batch(pks, n, k=None, pk_format=N.PK_COMPRESSED, pk_offsets=None, ctx=None):
+    ctx = ctx or _c()
+    out = N.outbuf(96 * n)
+    st = (C.c_uint32 * max(1, n))()
+    off = None
+    if pk_offsets is not None:
+        off = (C.c_uint32 * len(pk_offsets))(*pk_offsets)
+        k = 0
+    ctx.check(N.lib().mbls_aggregate_public_keys_batch(ctx.handle, N.cbuf(pks), pk_format, off, n, k, out, st))
+    return bytes(out)[:96 * n], list(st)[:n]
+
+
+def fp_mul_batch(a48, b48, n, square=False, ctx=None):
+    ctx = ctx or _c()
+    out = N.outbuf(48 * n)
+    ctx.check(N.lib().mbls_fp_mul_batch(ctx.handle, N.cbuf(a48), N.cbuf(b48), n, out, int(square)))
+    return bytes(out)[:48 * n]
+
+
+def fp_mul_bench(n_lanes, iters, ctx=None):
+    """Integer-ALU calibration: `iters` dependent Fp multiplications on each of n_lanes lanes -> elapsed ms."""
+    ctx = ctx or _c()
+    ms = C.c_float()
+    ctx.check(N.lib().mbls_fp_mul_bench(ctx.handle, n_lanes, iters, C.byref(ms)))
+    return ms.value

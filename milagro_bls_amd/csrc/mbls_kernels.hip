@@ -1,0 +1,573 @@
+// mbls_kernels.hip -- gfx950 kernels and the C ABI of libmbls_hip.so (see include/mbls.h).
+//
+// One item per lane, one wave (64 lanes) per workgroup: the kernels are long integer carry-chain programs
+// with no intra-workgroup cooperation, so single-wave workgroups give the dispatcher the finest granularity
+// to fill 256 CUs x 4 SIMDs. The pipeline is split into phase kernels that hand their state over through a
+// limb-major struct-of-arrays workspace in HBM (mbls_lanes.h); each phase is thousands of Fp
+// multiplications per lane, so the hand-over traffic (<= 1.2 KB per item per phase) and the launch gaps are
+// noise. No MFMA, no LDS tiling: there is no data reuse across lanes to tile for.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <string.h>
+#include <stdlib.h>
+#include <new>
+#include "mbls_ops.h"
+#include "../../include/mbls.h"
+
+#define MBLS_SLOT_S 25            // 6 Fp: Jacobian G2 accumulator for verify_multiple
+#define MBLS_SLOT_TOTAL 31
+#define WG 64
+
+static __device__ __forceinline__ uint64_t gid() { return (uint64_t)blockIdx.x * WG + threadIdx.x; }
+
+// ------------------------------------------------------------------------------------------------ pipeline kernels
+__global__ void __launch_bounds__(WG) k_aggregate(mbls_ws ws, const uint8_t* pks, const uint32_t* offsets, uint32_t k, int fmt, int mode,
+                                                   uint32_t* status, uint64_t n) {
+    uint64_t i = gid(); if (i >= n) return;
+    const uint32_t pkb = fmt == MBLS_PK_COMPRESSED ? 48u : 96u;
+    uint64_t first = offsets ? offsets[i] : (uint64_t)k * i; uint32_t cnt = offsets ? offsets[i + 1] - offsets[i] : k;
+    uint32_t st; lane_aggregate(ws, i, pks + pkb * first, cnt, fmt, mode, &st); status[i] = st;
+}
+__global__ void __launch_bounds__(WG) k_sig(mbls_ws ws, const uint8_t* sigs, uint32_t* status, uint64_t n) {
+    uint64_t i = gid(); if (i >= n) return;
+    uint32_t st = status[i]; lane_sig(ws, i, sigs + 96 * i, &st); status[i] = st;
+}
+__global__ void __launch_bounds__(WG) k_hash(mbls_ws ws, const uint8_t* msgs, uint32_t mlen, const uint64_t* moff, const uint32_t* mlens, uint64_t n) {
+    uint64_t i = gid(); if (i >= n) return;
+    if (moff) lane_hash(ws, i, msgs + moff[i], mlens[i]); else lane_hash(ws, i, msgs + (uint64_t)mlen * i, mlen);
+}
+__global__ void __launch_bounds__(WG) k_miller(mbls_ws ws, uint64_t n) {
+    uint64_t i = gid(); if (i >= n) return;
+    lane_miller(ws, i);
+}
+__global__ void __launch_bounds__(WG) k_final(mbls_ws ws, uint32_t* status, uint8_t* results, uint64_t n) {
+    uint64_t i = gid(); if (i >= n) return;
+    uint32_t st = status[i]; uint8_t r; lane_final(ws, i, &st, &r); status[i] = st; results[i] = r;
+}
+// accept bitmap: one 64-bit word per wave via ballot
+__global__ void __launch_bounds__(WG) k_pack(const uint8_t* results, uint64_t* bitmap, uint64_t n) {
+    uint64_t i = gid();
+    bool bit = (i < n) && results[i];
+    uint64_t m = __ballot(bit);
+    if (threadIdx.x == 0) bitmap[blockIdx.x] = m;
+}
+
+// ------------------------------------------------------------------------------------------------ n-pairing kernels
+// (aggregate_verify, reference src/aggregates.rs:130-170; verify_multiple, src/aggregates.rs:261-316)
+// item i: f_i = Miller(H_i, P_i) with P_i = [r_i] pk_i (r_i = 1 when rands == NULL); optional S_i = [r_i] sig_i
+__global__ void __launch_bounds__(WG) k_blind_pair(mbls_ws ws, const uint8_t* pks96, const uint8_t* sigs96, const uint64_t* rands,
+                                                    uint32_t* status, uint64_t n) {
+    uint64_t i = gid(); if (i >= n) return;
+    uint32_t st = 0;
+    fp x, y; bool inf; int e = g1_decode_uncompressed(&x, &y, &inf, pks96 + 96 * i);
+    if (e) { st |= MBLS_ST_BAD_PK_ENCODING; inf = true; }
+    g1j p; p.x = x; p.y = y; p.z = fp_one(); if (inf) g1_set_inf(&p);
+    uint32_t k[2] = {1, 0};
+    if (rands) { k[0] = (uint32_t)rands[i]; k[1] = (uint32_t)(rands[i] >> 32); g1_mul(&p, &p, k, 64); }
+    ws_st(ws, MBLS_SLOT_APK, i, p.x); ws_st(ws, MBLS_SLOT_APK + 1, i, p.y); ws_st(ws, MBLS_SLOT_APK + 2, i, p.z);
+    if (sigs96) {
+        fp2 sx, sy; bool sinf; int e2 = g2_decode_compressed(&sx, &sy, &sinf, sigs96 + 96 * i);
+        if (e2) { st |= MBLS_ST_BAD_SIG_ENCODING; sinf = true; }
+        g2j s; s.x = sx; s.y = sy; s.z = fp2_one(); if (sinf) g2_set_inf(&s);
+        if (!g2_in_subgroup(&s)) st |= MBLS_ST_SIG_NOT_IN_G2;
+        g2_mul(&s, &s, k, 64);
+        ws_st2(ws, MBLS_SLOT_S, i, s.x); ws_st2(ws, MBLS_SLOT_S + 2, i, s.y); ws_st2(ws, MBLS_SLOT_S + 4, i, s.z);
+    }
+    status[i] = st;
+}
+// f_i = Miller(H_i, P_i) for i < n; lane n (if sig_slot_valid) computes Miller(S, -G1) with S read from slot S of item `s_item`
+__global__ void __launch_bounds__(WG) k_miller_single(mbls_ws ws, uint64_t n, int with_sig, uint64_t s_item) {
+    uint64_t i = gid(); if (i > n || (i == n && !with_sig)) return;
+    mbls_pair pr;
+    if (i < n) {
+        g2j h; h.x = ws_ld2(ws, MBLS_SLOT_H, i); h.y = ws_ld2(ws, MBLS_SLOT_H + 2, i); h.z = ws_ld2(ws, MBLS_SLOT_H + 4, i);
+        g1j a; a.x = ws_ld(ws, MBLS_SLOT_APK, i); a.y = ws_ld(ws, MBLS_SLOT_APK + 1, i); a.z = ws_ld(ws, MBLS_SLOT_APK + 2, i);
+        pr.skip = g2_is_inf(&h) | g1_is_inf(&a);
+        g2h_from_jacobian(&pr.q, &h); g1arg_from_jacobian(&pr.p, &a);
+    } else {
+        g2j s; s.x = ws_ld2(ws, MBLS_SLOT_S, s_item); s.y = ws_ld2(ws, MBLS_SLOT_S + 2, s_item); s.z = ws_ld2(ws, MBLS_SLOT_S + 4, s_item);
+        pr.skip = g2_is_inf(&s);
+        g2h_from_jacobian(&pr.q, &s);
+        g1arg_from_affine(&pr.p, fp_load_const(MBLS_G1_X), fp_load_const(MBLS_G1_NEG_Y));
+    }
+    pr.t = pr.q;
+    fp12 f; miller_loop(&f, &pr, 1);
+    const fp2* c = &f.c0.c0;
+    for (int s = 0; s < 6; s++) ws_st2(ws, MBLS_SLOT_F + 2 * s, i, c[s]);
+}
+// tree steps: item i <- item i (op) item i + half, for i + half < m
+__global__ void __launch_bounds__(WG) k_f12_tree(mbls_ws ws, uint64_t m, uint64_t half) {
+    uint64_t i = gid(); if (i + half >= m || i >= half) return;
+    fp12 a, b; fp2* ca = &a.c0.c0; fp2* cb = &b.c0.c0;
+    for (int s = 0; s < 6; s++) { ca[s] = ws_ld2(ws, MBLS_SLOT_F + 2 * s, i); cb[s] = ws_ld2(ws, MBLS_SLOT_F + 2 * s, i + half); }
+    fp12_mul(&a, &a, &b);
+    for (int s = 0; s < 6; s++) ws_st2(ws, MBLS_SLOT_F + 2 * s, i, ca[s]);
+}
+__global__ void __launch_bounds__(WG) k_g2_tree(mbls_ws ws, uint64_t m, uint64_t half) {
+    uint64_t i = gid(); if (i + half >= m || i >= half) return;
+    g2j a, b;
+    a.x = ws_ld2(ws, MBLS_SLOT_S, i); a.y = ws_ld2(ws, MBLS_SLOT_S + 2, i); a.z = ws_ld2(ws, MBLS_SLOT_S + 4, i);
+    b.x = ws_ld2(ws, MBLS_SLOT_S, i + half); b.y = ws_ld2(ws, MBLS_SLOT_S + 2, i + half); b.z = ws_ld2(ws, MBLS_SLOT_S + 4, i + half);
+    g2_add(&a, &a, &b);
+    ws_st2(ws, MBLS_SLOT_S, i, a.x); ws_st2(ws, MBLS_SLOT_S + 2, i, a.y); ws_st2(ws, MBLS_SLOT_S + 4, i, a.z);
+}
+__global__ void __launch_bounds__(WG) k_status_or(const uint32_t* status, uint64_t n, uint32_t* out) {
+    uint64_t i = gid(); uint32_t v = (i < n) ? status[i] : 0;
+    if (__ballot(v != 0)) { if (v) atomicOr(out, v); }
+}
+// decoded signature (compressed bytes) -> slot S of item `item` (for aggregate_verify's (sig, -G1) pair)
+__global__ void __launch_bounds__(WG) k_sig_to_slot(mbls_ws ws, const uint8_t* sig96, uint64_t item, uint32_t* status_out) {
+    if (gid() != 0) return;
+    fp2 x, y; bool inf; uint32_t st = 0;
+    int e = g2_decode_compressed(&x, &y, &inf, sig96);
+    if (e) { st |= MBLS_ST_BAD_SIG_ENCODING; inf = true; }
+    g2j s; s.x = x; s.y = y; s.z = fp2_one(); if (inf) g2_set_inf(&s);
+    if (!g2_in_subgroup(&s)) st |= MBLS_ST_SIG_NOT_IN_G2;
+    ws_st2(ws, MBLS_SLOT_S, item, s.x); ws_st2(ws, MBLS_SLOT_S + 2, item, s.y); ws_st2(ws, MBLS_SLOT_S + 4, item, s.z);
+    atomicOr(status_out, st);
+}
+
+// ------------------------------------------------------------------------------------------------ auxiliary kernels
+__global__ void __launch_bounds__(WG) k_g1_decode(const uint8_t* in, int fmt, int validate, uint64_t n, uint8_t* out96, uint8_t* err) { uint64_t i = gid(); if (i < n) op_g1_decode(i, in, fmt, validate, out96, err); }
+__global__ void __launch_bounds__(WG) k_g1_key_validate(const uint8_t* in96, uint64_t n, uint8_t* ok) { uint64_t i = gid(); if (i < n) op_g1_key_validate(i, in96, ok); }
+__global__ void __launch_bounds__(WG) k_g1_compress(const uint8_t* in96, uint64_t n, uint8_t* out48, uint8_t* err) { uint64_t i = gid(); if (i < n) op_g1_compress(i, in96, out48, err); }
+__global__ void __launch_bounds__(WG) k_g2_check(const uint8_t* in96, uint64_t n, uint8_t* err, uint8_t* in_g2) { uint64_t i = gid(); if (i < n) op_g2_check(i, in96, err, in_g2); }
+__global__ void __launch_bounds__(WG) k_g2_add(const uint8_t* a, const uint8_t* b, uint64_t n, uint8_t* out, uint8_t* err) { uint64_t i = gid(); if (i < n) op_g2_add(i, a, b, out, err); }
+__global__ void __launch_bounds__(WG) k_g1_add(const uint8_t* a, const uint8_t* b, uint64_t n, uint8_t* out, uint8_t* err) { uint64_t i = gid(); if (i < n) op_g1_add(i, a, b, out, err); }
+__global__ void __launch_bounds__(WG) k_sign(const uint8_t* sks, const uint8_t* msgs, uint32_t mlen, uint64_t n, uint8_t* out96) { uint64_t i = gid(); if (i < n) op_sign(i, sks, msgs, mlen, out96); }
+__global__ void __launch_bounds__(WG) k_sk_to_pk(const uint8_t* sks, int fmt, uint64_t n, uint8_t* out) { uint64_t i = gid(); if (i < n) op_sk_to_pk(i, sks, fmt, out); }
+__global__ void __launch_bounds__(WG) k_hash_to_g2(const uint8_t* msgs, uint32_t mlen, uint64_t n, uint8_t* out96) { uint64_t i = gid(); if (i < n) op_hash_to_g2(i, msgs, mlen, out96); }
+__global__ void __launch_bounds__(WG) k_fp_mul(const uint8_t* a, const uint8_t* b, uint64_t n, uint8_t* out, int sq) { uint64_t i = gid(); if (i < n) op_fp_mul(i, a, b, out, sq); }
+__global__ void __launch_bounds__(WG) k_apk_export(mbls_ws ws, uint64_t n, uint8_t* out96) { uint64_t i = gid(); if (i < n) op_apk_export(ws, i, out96); }
+__global__ void __launch_bounds__(WG) k_fp_mul_bench(uint32_t* sink, uint32_t iters, uint64_t n) {
+    uint64_t i = gid(); if (i >= n) return;
+    fp a = fp_load_const(MBLS_G1_X), b = fp_load_const(MBLS_G1_Y);
+    a[0] ^= (uint32_t)i;
+    for (uint32_t it = 0; it < iters; it++) a = fp_mul(a, b);
+    uint32_t acc = 0;
+    for (int j = 0; j < 12; j++) acc ^= a[j];
+    sink[i] = acc;
+}
+
+// ------------------------------------------------------------------------------------------------ host side
+struct mbls_ctx {
+    int device;
+    uint64_t cap;            // items the workspace can hold
+    uint32_t* d_w;           // workspace limbs
+    uint32_t* d_status;      // per-item status (when the caller passes none)
+    uint8_t* d_results;
+    uint32_t* d_scalar;      // small scratch words
+    bool timing;
+    hipEvent_t ev[MBLS_N_PHASES + 1];
+    float phase_ms[MBLS_N_PHASES];
+    char err[256];
+};
+
+#define HIPCHK(ctx, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { \
+    snprintf((ctx)->err, sizeof((ctx)->err), "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); return MBLS_ERR_DEVICE; } } while (0)
+
+static inline unsigned nblk(uint64_t n) { return (unsigned)((n + WG - 1) / WG); }
+
+extern "C" int mbls_ctx_create(mbls_ctx** out, int device_id) {
+    if (!out) return MBLS_ERR_ARGUMENT;
+    int cnt = 0;
+    if (hipGetDeviceCount(&cnt) != hipSuccess || cnt <= 0 || device_id < 0 || device_id >= cnt) return MBLS_ERR_DEVICE;
+    if (hipSetDevice(device_id) != hipSuccess) return MBLS_ERR_DEVICE;
+    mbls_ctx* c = new (std::nothrow) mbls_ctx();
+    if (!c) return MBLS_ERR_DEVICE;
+    memset(c, 0, sizeof(*c)); c->device = device_id;
+    for (int i = 0; i <= MBLS_N_PHASES; i++) if (hipEventCreate(&c->ev[i]) != hipSuccess) { delete c; return MBLS_ERR_DEVICE; }
+    if (hipMalloc(&c->d_scalar, 64) != hipSuccess) { delete c; return MBLS_ERR_DEVICE; }
+    *out = c; return MBLS_OK;
+}
+extern "C" void mbls_ctx_destroy(mbls_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->d_w) (void)hipFree(c->d_w);
+    if (c->d_status) (void)hipFree(c->d_status);
+    if (c->d_results) (void)hipFree(c->d_results);
+    if (c->d_scalar) (void)hipFree(c->d_scalar);
+    for (int i = 0; i <= MBLS_N_PHASES; i++) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+    delete c;
+}
+extern "C" const char* mbls_last_error(mbls_ctx* c) { return c ? c->err : "null context"; }
+extern "C" int mbls_ctx_reserve(mbls_ctx* c, uint64_t max_items) {
+    if (!c) return MBLS_ERR_ARGUMENT;
+    HIPCHK(c, hipSetDevice(c->device));
+    uint64_t want = ((max_items + 1 + WG - 1) / WG) * WG;     // +1: the extra (sig, -G1) lane of the n-pairing paths
+    if (want <= c->cap) return MBLS_OK;
+    if (c->d_w) { (void)hipFree(c->d_w); (void)hipFree(c->d_status); (void)hipFree(c->d_results); c->d_w = nullptr; c->cap = 0; }
+    HIPCHK(c, hipMalloc(&c->d_w, (size_t)MBLS_SLOT_TOTAL * 12 * want * 4));
+    HIPCHK(c, hipMalloc(&c->d_status, want * 4));
+    HIPCHK(c, hipMalloc(&c->d_results, want));
+    c->cap = want; return MBLS_OK;
+}
+extern "C" int mbls_enable_phase_timing(mbls_ctx* c, int on) { if (!c) return MBLS_ERR_ARGUMENT; c->timing = on != 0; return MBLS_OK; }
+extern "C" int mbls_last_phase_ms(mbls_ctx* c, float ms[MBLS_N_PHASES]) {
+    if (!c) return MBLS_ERR_ARGUMENT;
+    for (int i = 0; i < MBLS_N_PHASES; i++) ms[i] = c->phase_ms[i];
+    return MBLS_OK;
+}
+
+static int verify_pipeline(mbls_ctx* c, const uint8_t* d_sigs, const uint8_t* d_msgs, uint32_t msg_len, const uint8_t* d_pks, int fmt,
+                           const uint32_t* d_off, uint64_t n, uint32_t k, int mode, uint8_t* d_results, uint64_t* d_bitmap,
+                           uint32_t* d_status, hipStream_t s) {
+    if (!c || (fmt != MBLS_PK_COMPRESSED && fmt != MBLS_PK_UNCOMPRESSED)) return MBLS_ERR_ARGUMENT;
+    if (n == 0) return MBLS_OK;
+    if (!d_sigs || !d_msgs || !d_results || (!d_pks && (k || d_off))) return MBLS_ERR_ARGUMENT;
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = mbls_ctx_reserve(c, n); if (rc) return rc;
+    mbls_ws ws; ws.w = c->d_w; ws.stride = c->cap;
+    uint32_t* st = d_status ? d_status : c->d_status;
+    unsigned g = nblk(n);
+    bool tm = c->timing;
+    if (tm) HIPCHK(c, hipEventRecord(c->ev[0], s));
+    hipLaunchKernelGGL(k_aggregate, dim3(g), dim3(WG), 0, s, ws, d_pks, d_off, k, fmt, mode, st, n);
+    if (tm) HIPCHK(c, hipEventRecord(c->ev[1], s));
+    hipLaunchKernelGGL(k_sig, dim3(g), dim3(WG), 0, s, ws, d_sigs, st, n);
+    if (tm) HIPCHK(c, hipEventRecord(c->ev[2], s));
+    hipLaunchKernelGGL(k_hash, dim3(g), dim3(WG), 0, s, ws, d_msgs, msg_len, (const uint64_t*)nullptr, (const uint32_t*)nullptr, n);
+    if (tm) HIPCHK(c, hipEventRecord(c->ev[3], s));
+    hipLaunchKernelGGL(k_miller, dim3(g), dim3(WG), 0, s, ws, n);
+    if (tm) HIPCHK(c, hipEventRecord(c->ev[4], s));
+    hipLaunchKernelGGL(k_final, dim3(g), dim3(WG), 0, s, ws, st, d_results, n);
+    if (tm) HIPCHK(c, hipEventRecord(c->ev[5], s));
+    if (d_bitmap) hipLaunchKernelGGL(k_pack, dim3(g), dim3(WG), 0, s, d_results, d_bitmap, n);
+    if (tm) {
+        HIPCHK(c, hipEventRecord(c->ev[6], s));
+        HIPCHK(c, hipEventSynchronize(c->ev[6]));
+        for (int i = 0; i < MBLS_N_PHASES; i++) HIPCHK(c, hipEventElapsedTime(&c->phase_ms[i], c->ev[i], c->ev[i + 1]));
+    }
+    HIPCHK(c, hipGetLastError());
+    return MBLS_OK;
+}
+extern "C" int mbls_fast_aggregate_verify_batch_device(mbls_ctx* c, const uint8_t* d_sigs, const uint8_t* d_msgs, uint32_t msg_len,
+        const uint8_t* d_pks, int fmt, const uint32_t* d_off, uint64_t n, uint32_t k, uint8_t* d_results, uint64_t* d_bitmap,
+        uint32_t* d_status, void* stream) {
+    return verify_pipeline(c, d_sigs, d_msgs, msg_len, d_pks, fmt, d_off, n, k, MBLS_MODE_FAST_AGGREGATE, d_results, d_bitmap, d_status, (hipStream_t)stream);
+}
+extern "C" int mbls_verify_batch_device(mbls_ctx* c, const uint8_t* d_sigs, const uint8_t* d_msgs, uint32_t msg_len,
+        const uint8_t* d_pks, int fmt, uint64_t n, uint8_t* d_results, uint64_t* d_bitmap, uint32_t* d_status, void* stream) {
+    return verify_pipeline(c, d_sigs, d_msgs, msg_len, d_pks, fmt, nullptr, n, 1, MBLS_MODE_VERIFY, d_results, d_bitmap, d_status, (hipStream_t)stream);
+}
+
+// ---- small RAII helper for host-pointer entry points
+struct dbuf {
+    void* p = nullptr; size_t n = 0;
+    ~dbuf() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t bytes) { n = bytes ? bytes : 1; return hipMalloc(&p, n); }
+    hipError_t up(const void* h, size_t bytes) { hipError_t e = alloc(bytes); if (e != hipSuccess || !bytes) return e; return hipMemcpy(p, h, bytes, hipMemcpyHostToDevice); }
+    hipError_t down(void* h, size_t bytes) { return bytes ? hipMemcpy(h, p, bytes, hipMemcpyDeviceToHost) : hipSuccess; }
+    template <typename T> T* as() { return (T*)p; }
+};
+
+static int verify_host(mbls_ctx* c, const uint8_t* sigs, const uint8_t* msgs, uint32_t msg_len, const uint8_t* pks, int fmt,
+                       const uint32_t* off, uint64_t n, uint32_t k, int mode, uint8_t* results, uint32_t* status) {
+    if (!c) return MBLS_ERR_ARGUMENT;
+    if (n == 0) return MBLS_OK;
+    if (!sigs || (!msgs && msg_len) || !results) return MBLS_ERR_ARGUMENT;
+    if (fmt != MBLS_PK_COMPRESSED && fmt != MBLS_PK_UNCOMPRESSED) return MBLS_ERR_ARGUMENT;
+    HIPCHK(c, hipSetDevice(c->device));
+    uint64_t total_keys = off ? off[n] : (uint64_t)k * n;
+    size_t pkb = fmt == MBLS_PK_COMPRESSED ? 48 : 96;
+    dbuf ds, dm, dp, doff, dr, dst;
+    HIPCHK(c, ds.up(sigs, 96 * n)); HIPCHK(c, dm.up(msgs, (size_t)msg_len * n)); HIPCHK(c, dp.up(pks, pkb * total_keys));
+    if (off) HIPCHK(c, doff.up(off, 4 * (n + 1)));
+    HIPCHK(c, dr.alloc(n)); HIPCHK(c, dst.alloc(4 * n));
+    int rc = verify_pipeline(c, ds.as<uint8_t>(), dm.as<uint8_t>(), msg_len, dp.as<uint8_t>(), fmt, off ? doff.as<uint32_t>() : nullptr,
+                             n, k, mode, dr.as<uint8_t>(), nullptr, dst.as<uint32_t>(), 0);
+    if (rc) return rc;
+    HIPCHK(c, hipDeviceSynchronize());
+    HIPCHK(c, dr.down(results, n));
+    if (status) HIPCHK(c, dst.down(status, 4 * n));
+    return MBLS_OK;
+}
+extern "C" int mbls_fast_aggregate_verify_batch(mbls_ctx* c, const uint8_t* sigs, const uint8_t* msgs, uint32_t msg_len, const uint8_t* pks,
+        int fmt, const uint32_t* off, uint64_t n, uint32_t k, uint8_t* results, uint32_t* status) {
+    return verify_host(c, sigs, msgs, msg_len, pks, fmt, off, n, k, MBLS_MODE_FAST_AGGREGATE, results, status);
+}
+extern "C" int mbls_verify_batch(mbls_ctx* c, const uint8_t* sigs, const uint8_t* msgs, uint32_t msg_len, const uint8_t* pks, int fmt,
+        uint64_t n, uint8_t* results, uint32_t* status) {
+    return verify_host(c, sigs, msgs, msg_len, pks, fmt, nullptr, n, 1, MBLS_MODE_VERIFY, results, status);
+}
+
+// ---- batch helpers
+static int map_dec_err_g1(int e) { return e == MBLS_DEC_OK ? MBLS_OK : (e == MBLS_DEC_SIZE ? MBLS_ERR_INVALID_G1_SIZE : MBLS_ERR_INVALID_POINT); }
+static int map_dec_err_g2(int e) { return e == MBLS_DEC_OK ? MBLS_OK : (e == MBLS_DEC_SIZE ? MBLS_ERR_INVALID_G2_SIZE : MBLS_ERR_INVALID_POINT); }
+
+extern "C" int mbls_pk_decode_batch(mbls_ctx* c, const uint8_t* in, int fmt, int validate, uint64_t n, uint8_t* out96, uint8_t* errs) {
+    if (!c || !in || !out96 || !errs || (fmt != 0 && fmt != 1)) return MBLS_ERR_ARGUMENT;
+    if (!n) return MBLS_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    dbuf di, dout, de; HIPCHK(c, di.up(in, (fmt ? 96 : 48) * n)); HIPCHK(c, dout.alloc(96 * n)); HIPCHK(c, de.alloc(n));
+    hipLaunchKernelGGL(k_g1_decode, dim3(nblk(n)), dim3(WG), 0, 0, di.as<uint8_t>(), fmt, validate, n, dout.as<uint8_t>(), de.as<uint8_t>());
+    HIPCHK(c, hipDeviceSynchronize()); HIPCHK(c, dout.down(out96, 96 * n)); HIPCHK(c, de.down(errs, n));
+    for (uint64_t i = 0; i < n; i++) errs[i] = (uint8_t)map_dec_err_g1(errs[i]);
+    return MBLS_OK;
+}
+extern "C" int mbls_pk_compress_batch(mbls_ctx* c, const uint8_t* in96, uint64_t n, uint8_t* out48, uint8_t* errs) {
+    if (!c || !in96 || !out48 || !errs) return MBLS_ERR_ARGUMENT;
+    if (!n) return MBLS_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    dbuf di, dout, de; HIPCHK(c, di.up(in96, 96 * n)); HIPCHK(c, dout.alloc(48 * n)); HIPCHK(c, de.alloc(n));
+    hipLaunchKernelGGL(k_g1_compress, dim3(nblk(n)), dim3(WG), 0, 0, di.as<uint8_t>(), n, dout.as<uint8_t>(), de.as<uint8_t>());
+    HIPCHK(c, hipDeviceSynchronize()); HIPCHK(c, dout.down(out48, 48 * n)); HIPCHK(c, de.down(errs, n));
+    for (uint64_t i = 0; i < n; i++) errs[i] = (uint8_t)map_dec_err_g1(errs[i]);
+    return MBLS_OK;
+}
+extern "C" int mbls_sig_check_batch(mbls_ctx* c, const uint8_t* in96, uint64_t n, uint8_t* errs, uint8_t* in_g2) {
+    if (!c || !in96 || !errs) return MBLS_ERR_ARGUMENT;
+    if (!n) return MBLS_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    dbuf di, de, dg; HIPCHK(c, di.up(in96, 96 * n)); HIPCHK(c, de.alloc(n)); if (in_g2) HIPCHK(c, dg.alloc(n));
+    hipLaunchKernelGGL(k_g2_check, dim3(nblk(n)), dim3(WG), 0, 0, di.as<uint8_t>(), n, de.as<uint8_t>(), in_g2 ? dg.as<uint8_t>() : (uint8_t*)nullptr);
+    HIPCHK(c, hipDeviceSynchronize()); HIPCHK(c, de.down(errs, n)); if (in_g2) HIPCHK(c, dg.down(in_g2, n));
+    for (uint64_t i = 0; i < n; i++) errs[i] = (uint8_t)map_dec_err_g2(errs[i]);
+    return MBLS_OK;
+}
+extern "C" int mbls_sign_batch_device(mbls_ctx* c, const uint8_t* d_sks, const uint8_t* d_msgs, uint32_t msg_len, uint64_t n, uint8_t* d_sigs, void* stream) {
+    if (!c || !d_sks || !d_sigs || (!d_msgs && msg_len)) return MBLS_ERR_ARGUMENT;
+    if (!n) return MBLS_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    hipLaunchKernelGGL(k_sign, dim3(nblk(n)), dim3(WG), 0, (hipStream_t)stream, d_sks, d_msgs, msg_len, n, d_sigs);
+    HIPCHK(c, hipGetLastError()); return MBLS_OK;
+}
+extern "C" int mbls_sign_batch(mbls_ctx* c, const uint8_t* sks, const uint8_t* msgs, uint32_t msg_len, uint64_t n, uint8_t* sigs) {
+    if (!c || !sks || !sigs || (!msgs && msg_len)) return MBLS_ERR_ARGUMENT;
+    if (!n) return MBLS_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    dbuf dk, dm, dout; HIPCHK(c, dk.up(sks, 32 * n)); HIPCHK(c, dm.up(msgs, (size_t)msg_len * n)); HIPCHK(c, dout.alloc(96 * n));
+    int rc = mbls_sign_batch_device(c, dk.as<uint8_t>(), dm.as<uint8_t>(), msg_len, n, dout.as<uint8_t>(), nullptr); if (rc) return rc;
+    HIPCHK(c, hipDeviceSynchronize()); HIPCHK(c, dout.down(sigs, 96 * n)); return MBLS_OK;
+}
+extern "C" int mbls_sk_to_pk_batch_device(mbls_ctx* c, const uint8_t* d_sks, int fmt, uint64_t n, uint8_t* d_pks, void* stream) {
+    if (!c || !d_sks || !d_pks || (fmt != 0 && fmt != 1)) return MBLS_ERR_ARGUMENT;
+    if (!n) return MBLS_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    hipLaunchKernelGGL(k_sk_to_pk, dim3(nblk(n)), dim3(WG), 0, (hipStream_t)stream, d_sks, fmt, n, d_pks);
+    HIPCHK(c, hipGetLastError()); return MBLS_OK;
+}
+extern "C" int mbls_sk_to_pk_batch(mbls_ctx* c, const uint8_t* sks, int fmt, uint64_t n, uint8_t* pks) {
+    if (!c || !sks || !pks || (fmt != 0 && fmt != 1)) return MBLS_ERR_ARGUMENT;
+    if (!n) return MBLS_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    dbuf dk, dout; HIPCHK(c, dk.up(sks, 32 * n)); HIPCHK(c, dout.alloc((fmt ? 96 : 48) * n));
+    int rc = mbls_sk_to_pk_batch_device(c, dk.as<uint8_t>(), fmt, n, dout.as<uint8_t>(), nullptr); if (rc) return rc;
+    HIPCHK(c, hipDeviceSynchronize()); HIPCHK(c, dout.down(pks, (fmt ? 96 : 48) * n)); return MBLS_OK;
+}
+extern "C" int mbls_hash_to_g2_batch(mbls_ctx* c, const uint8_t* msgs, uint32_t msg_len, uint64_t n, uint8_t* out96) {
+    if (!c || !out96 || (!msgs && msg_len)) return MBLS_ERR_ARGUMENT;
+    if (!n) return MBLS_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    dbuf dm, dout; HIPCHK(c, dm.up(msgs, (size_t)msg_len * n)); HIPCHK(c, dout.alloc(96 * n));
+    hipLaunchKernelGGL(k_hash_to_g2, dim3(nblk(n)), dim3(WG), 0, 0, dm.as<uint8_t>(), msg_len, n, dout.as<uint8_t>());
+    HIPCHK(c, hipDeviceSynchronize()); HIPCHK(c, dout.down(out96, 96 * n)); return MBLS_OK;
+}
+extern "C" int mbls_aggregate_public_keys_batch(mbls_ctx* c, const uint8_t* pks, int fmt, const uint32_t* off, uint64_t n, uint32_t k,
+                                                uint8_t* apks96, uint32_t* status) {
+    if (!c || !apks96 || (fmt != 0 && fmt != 1)) return MBLS_ERR_ARGUMENT;
+    if (!n) return MBLS_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = mbls_ctx_reserve(c, n); if (rc) return rc;
+    uint64_t total = off ? off[n] : (uint64_t)k * n;
+    dbuf dp, doff, dout; HIPCHK(c, dp.up(pks, (fmt ? 96 : 48) * total)); if (off) HIPCHK(c, doff.up(off, 4 * (n + 1))); HIPCHK(c, dout.alloc(96 * n));
+    mbls_ws ws; ws.w = c->d_w; ws.stride = c->cap;
+    hipLaunchKernelGGL(k_aggregate, dim3(nblk(n)), dim3(WG), 0, 0, ws, dp.as<uint8_t>(), off ? doff.as<uint32_t>() : (const uint32_t*)nullptr, k, fmt,
+                       MBLS_MODE_FAST_AGGREGATE, c->d_status, n);
+    hipLaunchKernelGGL(k_apk_export, dim3(nblk(n)), dim3(WG), 0, 0, ws, n, dout.as<uint8_t>());
+    HIPCHK(c, hipDeviceSynchronize()); HIPCHK(c, dout.down(apks96, 96 * n));
+    if (status) HIPCHK(c, hipMemcpy(status, c->d_status, 4 * n, hipMemcpyDeviceToHost));
+    return MBLS_OK;
+}
+extern "C" int mbls_fp_mul_batch(mbls_ctx* c, const uint8_t* a, const uint8_t* b, uint64_t n, uint8_t* out, int square) {
+    if (!c || !a || !b || !out) return MBLS_ERR_ARGUMENT;
+    if (!n) return MBLS_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    dbuf da, db, dout; HIPCHK(c, da.up(a, 48 * n)); HIPCHK(c, db.up(b, 48 * n)); HIPCHK(c, dout.alloc(48 * n));
+    hipLaunchKernelGGL(k_fp_mul, dim3(nblk(n)), dim3(WG), 0, 0, da.as<uint8_t>(), db.as<uint8_t>(), n, dout.as<uint8_t>(), square);
+    HIPCHK(c, hipDeviceSynchronize()); HIPCHK(c, dout.down(out, 48 * n)); return MBLS_OK;
+}
+extern "C" int mbls_fp_mul_bench(mbls_ctx* c, uint64_t n_lanes, uint32_t iters, float* ms_out) {
+    if (!c || !ms_out || !n_lanes) return MBLS_ERR_ARGUMENT;
+    HIPCHK(c, hipSetDevice(c->device));
+    dbuf sink; HIPCHK(c, sink.alloc(4 * n_lanes));
+    hipLaunchKernelGGL(k_fp_mul_bench, dim3(nblk(n_lanes)), dim3(WG), 0, 0, sink.as<uint32_t>(), 16u, n_lanes);   // warm-up
+    HIPCHK(c, hipEventRecord(c->ev[0], 0));
+    hipLaunchKernelGGL(k_fp_mul_bench, dim3(nblk(n_lanes)), dim3(WG), 0, 0, sink.as<uint32_t>(), iters, n_lanes);
+    HIPCHK(c, hipEventRecord(c->ev[1], 0)); HIPCHK(c, hipEventSynchronize(c->ev[1]));
+    HIPCHK(c, hipEventElapsedTime(ms_out, c->ev[0], c->ev[1]));
+    return MBLS_OK;
+}
+
+// ---- scalar API (n = 1 batches)
+static int sk_check(const uint8_t* sk, size_t len) {     // SecretKey::from_bytes, reference src/keys.rs:80-82 and tests :285-297
+    static const uint8_t R_BE[32] = {0x73,0xed,0xa7,0x53,0x29,0x9d,0x7d,0x48,0x33,0x39,0xd8,0x08,0x09,0xa1,0xd8,0x05,0x53,0xbd,0xa4,0x02,0xff,0xfe,0x5b,0xfe,0xff,0xff,0xff,0xff,0x00,0x00,0x00,0x01};
+    if (!sk || len != 32) return MBLS_ERR_INVALID_SECRET_KEY_SIZE;
+    bool zero = true; for (int i = 0; i < 32; i++) if (sk[i]) zero = false;
+    if (zero || memcmp(sk, R_BE, 32) >= 0) return MBLS_ERR_INVALID_SECRET_KEY_RANGE;
+    return MBLS_OK;
+}
+extern "C" int mbls_pk_from_bytes(mbls_ctx* c, const uint8_t* bytes, size_t len, uint8_t pk_out[96]) {
+    if (!c || !pk_out) return MBLS_ERR_ARGUMENT;
+    if (!bytes || len != 48) return MBLS_ERR_INVALID_G1_SIZE;         // decompress_g1, reference src/amcl_utils.rs:54-56
+    uint8_t e; int rc = mbls_pk_decode_batch(c, bytes, MBLS_PK_COMPRESSED, 1, 1, pk_out, &e); return rc ? rc : e;
+}
+extern "C" int mbls_pk_from_bytes_unchecked(mbls_ctx* c, const uint8_t* bytes, size_t len, uint8_t pk_out[96]) {
+    if (!c || !pk_out) return MBLS_ERR_ARGUMENT;
+    if (!bytes || len != 48) return MBLS_ERR_INVALID_G1_SIZE;
+    uint8_t e; int rc = mbls_pk_decode_batch(c, bytes, MBLS_PK_COMPRESSED, 0, 1, pk_out, &e); return rc ? rc : e;
+}
+extern "C" int mbls_pk_from_uncompressed_bytes(mbls_ctx* c, const uint8_t* bytes, size_t len, uint8_t pk_out[96]) {
+    if (!c || !pk_out) return MBLS_ERR_ARGUMENT;
+    if (!bytes || len != 96) return MBLS_ERR_INVALID_G1_SIZE;         // reference src/keys.rs:171-173
+    uint8_t e; int rc = mbls_pk_decode_batch(c, bytes, MBLS_PK_UNCOMPRESSED, 0, 1, pk_out, &e); return rc ? rc : e;
+}
+extern "C" int mbls_pk_as_bytes(mbls_ctx* c, const uint8_t pk[96], uint8_t out[48]) {
+    if (!c || !pk || !out) return MBLS_ERR_ARGUMENT;
+    uint8_t e; int rc = mbls_pk_compress_batch(c, pk, 1, out, &e); return rc ? rc : e;
+}
+extern "C" int mbls_pk_key_validate(mbls_ctx* c, const uint8_t pk[96]) {
+    if (!c || !pk) return 0;
+    if (hipSetDevice(c->device) != hipSuccess) return 0;
+    dbuf di, dk; if (di.up(pk, 96) != hipSuccess || dk.alloc(1) != hipSuccess) return 0;
+    hipLaunchKernelGGL(k_g1_key_validate, dim3(1), dim3(WG), 0, 0, di.as<uint8_t>(), (uint64_t)1, dk.as<uint8_t>());
+    uint8_t ok = 0; if (hipDeviceSynchronize() != hipSuccess || dk.down(&ok, 1) != hipSuccess) return 0;
+    return ok;
+}
+extern "C" int mbls_pk_from_secret_key(mbls_ctx* c, const uint8_t* sk, size_t sk_len, uint8_t pk_out[96]) {
+    if (!c || !pk_out) return MBLS_ERR_ARGUMENT;
+    int e = sk_check(sk, sk_len); if (e) return e;
+    return mbls_sk_to_pk_batch(c, sk, MBLS_PK_UNCOMPRESSED, 1, pk_out);
+}
+extern "C" int mbls_sig_from_bytes(mbls_ctx* c, const uint8_t* bytes, size_t len, uint8_t sig_out[96]) {
+    if (!c || !sig_out) return MBLS_ERR_ARGUMENT;
+    if (!bytes || len != 96) return MBLS_ERR_INVALID_G2_SIZE;         // decompress_g2, reference src/amcl_utils.rs:70-72
+    uint8_t e; int rc = mbls_sig_check_batch(c, bytes, 1, &e, nullptr); if (rc) return rc;
+    if (e) return e;
+    memcpy(sig_out, bytes, 96); return MBLS_OK;
+}
+extern "C" int mbls_sign(mbls_ctx* c, const uint8_t* msg, size_t msg_len, const uint8_t* sk, size_t sk_len, uint8_t sig_out[96]) {
+    if (!c || !sig_out) return MBLS_ERR_ARGUMENT;
+    int e = sk_check(sk, sk_len); if (e) return e;
+    return mbls_sign_batch(c, sk, msg, (uint32_t)msg_len, 1, sig_out);
+}
+extern "C" int mbls_verify(mbls_ctx* c, const uint8_t sig[96], const uint8_t* msg, size_t msg_len, const uint8_t pk[96]) {
+    uint8_t r = 0; if (!c || !sig || !pk) return 0;
+    if (mbls_verify_batch(c, sig, msg, (uint32_t)msg_len, pk, MBLS_PK_UNCOMPRESSED, 1, &r, nullptr)) return 0;
+    return r;
+}
+extern "C" int mbls_aggregate_public_keys(mbls_ctx* c, const uint8_t* pks96, size_t n, uint8_t apk_out[96]) {
+    if (!c || !apk_out) return MBLS_ERR_ARGUMENT;
+    if (n == 0) return MBLS_ERR_AGGREGATE_EMPTY_POINTS;               // reference src/aggregates.rs:30-32
+    uint32_t st = 0; int rc = mbls_aggregate_public_keys_batch(c, pks96, MBLS_PK_UNCOMPRESSED, nullptr, 1, (uint32_t)n, apk_out, &st);
+    if (rc) return rc;
+    return (st & MBLS_ST_BAD_PK_ENCODING) ? MBLS_ERR_INVALID_POINT : MBLS_OK;
+}
+extern "C" int mbls_aggregate_public_key_add(mbls_ctx* c, const uint8_t a[96], const uint8_t b[96], uint8_t out[96]) {
+    if (!c || !a || !b || !out) return MBLS_ERR_ARGUMENT;
+    HIPCHK(c, hipSetDevice(c->device));
+    dbuf da, db, dout, de; HIPCHK(c, da.up(a, 96)); HIPCHK(c, db.up(b, 96)); HIPCHK(c, dout.alloc(96)); HIPCHK(c, de.alloc(1));
+    hipLaunchKernelGGL(k_g1_add, dim3(1), dim3(WG), 0, 0, da.as<uint8_t>(), db.as<uint8_t>(), (uint64_t)1, dout.as<uint8_t>(), de.as<uint8_t>());
+    uint8_t e; HIPCHK(c, hipDeviceSynchronize()); HIPCHK(c, dout.down(out, 96)); HIPCHK(c, de.down(&e, 1));
+    return map_dec_err_g1(e);
+}
+extern "C" int mbls_aggregate_signature_add(mbls_ctx* c, const uint8_t a[96], const uint8_t b[96], uint8_t out[96]) {
+    if (!c || !a || !b || !out) return MBLS_ERR_ARGUMENT;
+    HIPCHK(c, hipSetDevice(c->device));
+    dbuf da, db, dout, de; HIPCHK(c, da.up(a, 96)); HIPCHK(c, db.up(b, 96)); HIPCHK(c, dout.alloc(96)); HIPCHK(c, de.alloc(1));
+    hipLaunchKernelGGL(k_g2_add, dim3(1), dim3(WG), 0, 0, da.as<uint8_t>(), db.as<uint8_t>(), (uint64_t)1, dout.as<uint8_t>(), de.as<uint8_t>());
+    uint8_t e; HIPCHK(c, hipDeviceSynchronize()); HIPCHK(c, dout.down(out, 96)); HIPCHK(c, de.down(&e, 1));
+    return map_dec_err_g2(e);
+}
+extern "C" int mbls_fast_aggregate_verify(mbls_ctx* c, const uint8_t sig[96], const uint8_t* msg, size_t msg_len, const uint8_t* pks96, size_t n_pks) {
+    uint8_t r = 0; if (!c || !sig) return 0;
+    if (n_pks == 0) return 0;                                         // reference src/aggregates.rs:179-181
+    if (mbls_fast_aggregate_verify_batch(c, sig, msg, (uint32_t)msg_len, pks96, MBLS_PK_UNCOMPRESSED, nullptr, 1, (uint32_t)n_pks, &r, nullptr)) return 0;
+    return r;
+}
+extern "C" int mbls_fast_aggregate_verify_pre_aggregated(mbls_ctx* c, const uint8_t sig[96], const uint8_t* msg, size_t msg_len, const uint8_t apk[96]) {
+    uint8_t r = 0; if (!c || !sig || !apk) return 0;
+    // identical checks with a one-key set: sig in G2, key != infinity, pairing (reference src/aggregates.rs:223-253)
+    if (mbls_fast_aggregate_verify_batch(c, sig, msg, (uint32_t)msg_len, apk, MBLS_PK_UNCOMPRESSED, nullptr, 1, 1, &r, nullptr)) return 0;
+    return r;
+}
+
+// n-pairing product check shared by aggregate_verify and verify_multiple. On entry the workspace holds, for
+// items 0..n-1, H_i (slot H) and P_i (slot APK); the (S, -G1) pair takes S from slot S of item 0.
+static int npairing_finish(mbls_ctx* c, uint64_t n, hipStream_t s, int* result) {
+    mbls_ws ws; ws.w = c->d_w; ws.stride = c->cap;
+    hipLaunchKernelGGL(k_miller_single, dim3(nblk(n + 1)), dim3(WG), 0, s, ws, n, 1, (uint64_t)0);
+    uint64_t m = n + 1;
+    while (m > 1) { uint64_t half = (m + 1) / 2; hipLaunchKernelGGL(k_f12_tree, dim3(nblk(half)), dim3(WG), 0, s, ws, m, half); m = half; }
+    hipLaunchKernelGGL(k_final, dim3(1), dim3(WG), 0, s, ws, c->d_scalar, c->d_results, (uint64_t)1);
+    uint8_t r = 0; uint32_t st = 0;
+    HIPCHK(c, hipStreamSynchronize(s));
+    HIPCHK(c, hipMemcpy(&r, c->d_results, 1, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(&st, c->d_scalar, 4, hipMemcpyDeviceToHost));
+    *result = r; (void)st; return MBLS_OK;
+}
+extern "C" int mbls_aggregate_verify(mbls_ctx* c, const uint8_t sig[96], const uint8_t* msgs, const size_t* msg_lens, size_t n_msgs,
+                                     const uint8_t* pks96, size_t n_pks) {
+    if (!c || !sig) return 0;
+    if (n_msgs != n_pks || n_pks == 0) return 0;                      // reference src/aggregates.rs:132-134
+    if (hipSetDevice(c->device) != hipSuccess) return 0;
+    uint64_t n = n_pks;
+    if (mbls_ctx_reserve(c, n)) return 0;
+    size_t total = 0; uint64_t* off = (uint64_t*)malloc(8 * n); uint32_t* lens = (uint32_t*)malloc(4 * n);
+    for (size_t i = 0; i < n; i++) { off[i] = total; lens[i] = (uint32_t)msg_lens[i]; total += msg_lens[i]; }
+    dbuf dm, doff, dl, dp, dsig; int result = 0; bool ok = true;
+    ok = ok && dm.up(msgs, total) == hipSuccess && doff.up(off, 8 * n) == hipSuccess && dl.up(lens, 4 * n) == hipSuccess &&
+         dp.up(pks96, 96 * n) == hipSuccess && dsig.up(sig, 96) == hipSuccess;
+    free(off); free(lens);
+    if (!ok) return 0;
+    mbls_ws ws; ws.w = c->d_w; ws.stride = c->cap;
+    (void)hipMemsetAsync(c->d_scalar, 0, 64, 0);
+    hipLaunchKernelGGL(k_sig_to_slot, dim3(1), dim3(WG), 0, 0, ws, dsig.as<uint8_t>(), (uint64_t)0, c->d_scalar);
+    hipLaunchKernelGGL(k_blind_pair, dim3(nblk(n)), dim3(WG), 0, 0, ws, dp.as<uint8_t>(), (const uint8_t*)nullptr, (const uint64_t*)nullptr, c->d_status, n);
+    hipLaunchKernelGGL(k_status_or, dim3(nblk(n)), dim3(WG), 0, 0, c->d_status, n, c->d_scalar);
+    hipLaunchKernelGGL(k_hash, dim3(nblk(n)), dim3(WG), 0, 0, ws, dm.as<uint8_t>(), 0u, doff.as<uint64_t>(), dl.as<uint32_t>(), n);
+    uint32_t st = 0;
+    if (hipMemcpy(&st, c->d_scalar, 4, hipMemcpyDeviceToHost) != hipSuccess) return 0;
+    if (st & (MBLS_ST_BAD_SIG_ENCODING | MBLS_ST_SIG_NOT_IN_G2 | MBLS_ST_BAD_PK_ENCODING)) return 0;   // reference src/aggregates.rs:137-139
+    (void)hipMemsetAsync(c->d_scalar, 0, 64, 0);
+    if (npairing_finish(c, n, 0, &result)) return 0;
+    return result;
+}
+extern "C" int mbls_verify_multiple_aggregate_signatures_device(mbls_ctx* c, const uint8_t* d_sigs, const uint8_t* d_apks, const uint8_t* d_msgs,
+        uint32_t msg_len, const uint64_t* d_rands, uint64_t n, int* result, void* stream) {
+    if (!c || !result) return MBLS_ERR_ARGUMENT;
+    hipStream_t s = (hipStream_t)stream;
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = mbls_ctx_reserve(c, n ? n : 1); if (rc) return rc;
+    mbls_ws ws; ws.w = c->d_w; ws.stride = c->cap;
+    HIPCHK(c, hipMemsetAsync(c->d_scalar, 0, 64, s));
+    if (n) {
+        hipLaunchKernelGGL(k_blind_pair, dim3(nblk(n)), dim3(WG), 0, s, ws, d_apks, d_sigs, d_rands, c->d_status, n);
+        hipLaunchKernelGGL(k_status_or, dim3(nblk(n)), dim3(WG), 0, s, c->d_status, n, c->d_scalar);
+        hipLaunchKernelGGL(k_hash, dim3(nblk(n)), dim3(WG), 0, s, ws, d_msgs, msg_len, (const uint64_t*)nullptr, (const uint32_t*)nullptr, n);
+        uint64_t m = n;
+        while (m > 1) { uint64_t half = (m + 1) / 2; hipLaunchKernelGGL(k_g2_tree, dim3(nblk(half)), dim3(WG), 0, s, ws, m, half); m = half; }
+    } else {
+        // empty iterator: S' = infinity, product of no pairings = 1 -> e(inf, -G1) = 1 -> true (mathematical convention)
+        *result = 1; return MBLS_OK;
+    }
+    uint32_t st = 0;
+    HIPCHK(c, hipStreamSynchronize(s));
+    HIPCHK(c, hipMemcpy(&st, c->d_scalar, 4, hipMemcpyDeviceToHost));
+    if (st & (MBLS_ST_BAD_SIG_ENCODING | MBLS_ST_SIG_NOT_IN_G2 | MBLS_ST_BAD_PK_ENCODING)) { *result = 0; return MBLS_OK; }   // reference src/aggregates.rs:274-276
+    HIPCHK(c, hipMemsetAsync(c->d_scalar, 0, 64, s));
+    return npairing_finish(c, n, s, result);
+}
+extern "C" int mbls_verify_multiple_aggregate_signatures(mbls_ctx* c, const uint8_t* sigs96, const uint8_t* apks96, const uint8_t* msgs,
+        uint32_t msg_len, const uint64_t* rands, size_t n) {
+    if (!c) return 0;
+    if (n == 0) return 1;
+    if (!sigs96 || !apks96 || !rands || (!msgs && msg_len)) return 0;
+    if (hipSetDevice(c->device) != hipSuccess) return 0;
+    dbuf ds, da, dm, dr;
+    if (ds.up(sigs96, 96 * n) != hipSuccess || da.up(apks96, 96 * n) != hipSuccess || dm.up(msgs, (size_t)msg_len * n) != hipSuccess ||
+        dr.up(rands, 8 * n) != hipSuccess) return 0;
+    int result = 0;
+    if (mbls_verify_multiple_aggregate_signatures_device(c, ds.as<uint8_t>(), da.as<uint8_t>(), dm.as<uint8_t>(), msg_len, dr.as<uint64_t>(), n, &result, nullptr)) return 0;
+    return result;
+}

@@ -1,0 +1,113 @@
+// mbls_lanes.h -- the per-lane bodies of the pipeline kernels and the HBM workspace layout between them.
+//
+// Pipeline for one (sig, msg, pubkey-set) item per lane -- the data-parallel restatement of
+// AggregateSignature::fast_aggregate_verify (reference src/aggregates.rs:177-215), Signature::verify
+// (src/signature.rs:27-40) and fast_aggregate_verify_pre_aggregated (src/aggregates.rs:223-253):
+//   lane_aggregate   decode + sum the item's public keys            (src/aggregates.rs:29-39, :189-198)
+//   lane_sig         decode the signature, G2 subgroup check         (src/signature.rs:43-46, aggregates.rs:184)
+//   lane_hash        hash_to_curve_g2(msg)                           (src/amcl_utils.rs:33-35)
+//   lane_miller      2-pair Miller loop e(sig,-G1) e(H,apk)          (src/amcl_utils.rs:38-39)
+//   lane_final       final exponentiation, == 1, fold status         (src/amcl_utils.rs:40-41)
+// Rejections are carried as status bits (mbls_curve.h), never as early exits of the whole pipeline.
+//
+// Workspace (HBM): struct-of-arrays of 32-bit limbs, limb-major: limb j of Fp slot s of item i lives at
+// w[(s*12 + j) * stride + i], so every load/store instruction of a wave touches 64 consecutive dwords.
+#pragma once
+#include "mbls_hash.h"
+#include "mbls_pairing.h"
+
+#define MBLS_PK_COMPRESSED 0
+#define MBLS_PK_UNCOMPRESSED 1
+
+// verification flavours (which checks the reference function performs)
+#define MBLS_MODE_FAST_AGGREGATE 0   // empty-set + apk-infinity checks (src/aggregates.rs:179-198)
+#define MBLS_MODE_VERIFY 1           // Signature::verify: one key, no infinity check (src/signature.rs:27-40)
+
+enum {
+    MBLS_SLOT_APK = 0,      // 3 Fp: Jacobian X, Y, Z
+    MBLS_SLOT_SIG = 3,      // 4 Fp: affine x.c0, x.c1, y.c0, y.c1
+    MBLS_SLOT_H = 7,        // 6 Fp: Jacobian
+    MBLS_SLOT_F = 13,       // 12 Fp: Miller value
+    MBLS_SLOT_COUNT = 25
+};
+struct mbls_ws { uint32_t* w; uint64_t stride; };
+
+MBLS_FN fp ws_ld(const mbls_ws& ws, int slot, uint64_t i) {
+    fp r; const uint32_t* p = ws.w + (uint64_t)slot * 12 * ws.stride + i;
+#pragma unroll
+    for (int j = 0; j < 12; j++) r[j] = p[(uint64_t)j * ws.stride];
+    return r;
+}
+MBLS_FN void ws_st(const mbls_ws& ws, int slot, uint64_t i, fp v) {
+    uint32_t* p = ws.w + (uint64_t)slot * 12 * ws.stride + i;
+#pragma unroll
+    for (int j = 0; j < 12; j++) p[(uint64_t)j * ws.stride] = v[j];
+}
+MBLS_FN fp2 ws_ld2(const mbls_ws& ws, int slot, uint64_t i) { fp2 r; r.c0 = ws_ld(ws, slot, i); r.c1 = ws_ld(ws, slot + 1, i); return r; }
+MBLS_FN void ws_st2(const mbls_ws& ws, int slot, uint64_t i, const fp2& v) { ws_st(ws, slot, i, v.c0); ws_st(ws, slot + 1, i, v.c1); }
+
+// ---------------------------------------------------------------------------------------------- phases
+// Sum of the item's k public keys (wire bytes), starting from infinity like AggregatePublicKey::aggregate.
+MBLS_FN void lane_aggregate(const mbls_ws& ws, uint64_t i, const uint8_t* pks, uint32_t k, int fmt, int mode, uint32_t* status) {
+    uint32_t st = 0;
+    g1j acc; g1_set_inf(&acc);
+    const uint32_t pkb = (fmt == MBLS_PK_COMPRESSED) ? 48u : 96u;
+    for (uint32_t j = 0; j < k; j++) {
+        fp x, y; bool inf;
+        int e = (fmt == MBLS_PK_COMPRESSED) ? g1_decode_compressed(&x, &y, &inf, pks + (uint64_t)pkb * j)
+                                           : g1_decode_uncompressed(&x, &y, &inf, pks + (uint64_t)pkb * j);
+        if (e) { st |= MBLS_ST_BAD_PK_ENCODING; inf = true; }
+        if (inf) st |= MBLS_ST_PK_INFINITY;
+        g1_madd(&acc, &acc, x, y, inf);
+    }
+    if (mode == MBLS_MODE_FAST_AGGREGATE) {
+        if (k == 0) st |= MBLS_ST_NO_KEYS;
+        if (g1_is_inf(&acc)) st |= MBLS_ST_APK_INFINITY;
+    }
+    ws_st(ws, MBLS_SLOT_APK, i, acc.x); ws_st(ws, MBLS_SLOT_APK + 1, i, acc.y); ws_st(ws, MBLS_SLOT_APK + 2, i, acc.z);
+    *status = st;
+}
+MBLS_FN void lane_sig(const mbls_ws& ws, uint64_t i, const uint8_t* sig96, uint32_t* status) {
+    fp2 x, y; bool inf; uint32_t st = 0;
+    int e = g2_decode_compressed(&x, &y, &inf, sig96);
+    if (e) { st |= MBLS_ST_BAD_SIG_ENCODING; inf = true; }
+    g2j p; p.x = x; p.y = y; p.z = fp2_one();
+    if (inf) g2_set_inf(&p);
+    if (!g2_in_subgroup(&p)) st |= MBLS_ST_SIG_NOT_IN_G2;
+    // infinity is stored as y = 0 (no curve point has y = 0: there is no 2-torsion)
+    if (inf) { x = fp2_zero(); y = fp2_zero(); }
+    ws_st2(ws, MBLS_SLOT_SIG, i, x); ws_st2(ws, MBLS_SLOT_SIG + 2, i, y);
+    *status |= st;
+}
+MBLS_FN void lane_hash(const mbls_ws& ws, uint64_t i, const uint8_t* msg, uint32_t mlen) {
+    g2j h; hash_to_g2(&h, msg, mlen, MBLS_DST_POP, MBLS_DST_POP_LEN);
+    ws_st2(ws, MBLS_SLOT_H, i, h.x); ws_st2(ws, MBLS_SLOT_H + 2, i, h.y); ws_st2(ws, MBLS_SLOT_H + 4, i, h.z);
+}
+MBLS_FN void lane_miller(const mbls_ws& ws, uint64_t i) {
+    mbls_pair pr[2];
+    // pair 0: (sig, -G1)
+    fp2 sx = ws_ld2(ws, MBLS_SLOT_SIG, i), sy = ws_ld2(ws, MBLS_SLOT_SIG + 2, i);
+    pr[0].skip = fp2_is_zero(sy);
+    g2h_from_affine(&pr[0].q, sx, sy); pr[0].t = pr[0].q;
+    g1arg_from_affine(&pr[0].p, fp_load_const(MBLS_G1_X), fp_load_const(MBLS_G1_NEG_Y));
+    // pair 1: (H(msg), apk)
+    g2j h; h.x = ws_ld2(ws, MBLS_SLOT_H, i); h.y = ws_ld2(ws, MBLS_SLOT_H + 2, i); h.z = ws_ld2(ws, MBLS_SLOT_H + 4, i);
+    g1j a; a.x = ws_ld(ws, MBLS_SLOT_APK, i); a.y = ws_ld(ws, MBLS_SLOT_APK + 1, i); a.z = ws_ld(ws, MBLS_SLOT_APK + 2, i);
+    pr[1].skip = g2_is_inf(&h) | g1_is_inf(&a);
+    g2h_from_jacobian(&pr[1].q, &h); pr[1].t = pr[1].q;
+    g1arg_from_jacobian(&pr[1].p, &a);
+    fp12 f; miller_loop(&f, pr, 2);
+    const fp2* c = &f.c0.c0;
+    for (int s = 0; s < 6; s++) ws_st2(ws, MBLS_SLOT_F + 2 * s, i, c[s]);
+}
+MBLS_FN void lane_final(const mbls_ws& ws, uint64_t i, uint32_t* status, uint8_t* result) {
+    fp12 f; fp2* c = &f.c0.c0;
+    for (int s = 0; s < 6; s++) c[s] = ws_ld2(ws, MBLS_SLOT_F + 2 * s, i);
+    final_exp(&f, &f);
+    uint32_t st = *status;
+    if (!fp12_is_one(&f)) st |= MBLS_ST_PAIRING_FAILED;
+    *status = st;
+    const uint32_t reject = MBLS_ST_BAD_SIG_ENCODING | MBLS_ST_SIG_NOT_IN_G2 | MBLS_ST_BAD_PK_ENCODING |
+                            MBLS_ST_APK_INFINITY | MBLS_ST_NO_KEYS | MBLS_ST_PAIRING_FAILED;
+    *result = (st & reject) ? 0 : 1;
+}

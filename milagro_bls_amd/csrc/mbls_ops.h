@@ -1,0 +1,103 @@
+// mbls_ops.h -- per-item bodies of the auxiliary kernels (codec, key validation, signing, aggregation
+// outputs, field probes). Each op_* processes item i; mbls_kernels.hip wraps them in __global__ kernels.
+#pragma once
+#include "mbls_lanes.h"
+
+// PublicKey::from_bytes / from_bytes_unchecked / from_uncompressed_bytes (reference src/keys.rs:140-175):
+// in: wire bytes (48 or 96 per item), out: 96-byte uncompressed form + AmclError-style code per item.
+// validate != 0 adds KeyValidate (reject infinity and points outside G1, reference src/keys.rs:181-186).
+MBLS_FN void op_g1_decode(uint64_t i, const uint8_t* in, int fmt, int validate, uint8_t* out96, uint8_t* err) {
+    fp x, y; bool inf;
+    int e = (fmt == MBLS_PK_COMPRESSED) ? g1_decode_compressed(&x, &y, &inf, in + 48 * i) : g1_decode_uncompressed(&x, &y, &inf, in + 96 * i);
+    if (!e && validate) {
+        g1j p; p.x = x; p.y = y; p.z = fp_one();
+        if (inf) e = MBLS_DEC_POINT;
+        else if (!g1_in_subgroup(&p)) e = MBLS_DEC_POINT;
+    }
+    if (e) { for (int j = 0; j < 96; j++) out96[96 * i + j] = 0; }
+    else g1_encode_uncompressed(out96 + 96 * i, x, y, inf);
+    err[i] = (uint8_t)e;
+}
+// PublicKey::key_validate on decoded (uncompressed) keys -> 1/0
+MBLS_FN void op_g1_key_validate(uint64_t i, const uint8_t* in96, uint8_t* ok) {
+    fp x, y; bool inf; int e = g1_decode_uncompressed(&x, &y, &inf, in96 + 96 * i);
+    g1j p; p.x = x; p.y = y; p.z = fp_one();
+    ok[i] = (!e && !inf && g1_in_subgroup(&p)) ? 1 : 0;
+}
+// PublicKey::as_bytes (reference src/keys.rs:158-160): uncompressed -> compressed
+MBLS_FN void op_g1_compress(uint64_t i, const uint8_t* in96, uint8_t* out48, uint8_t* err) {
+    fp x, y; bool inf; int e = g1_decode_uncompressed(&x, &y, &inf, in96 + 96 * i);
+    if (e) { for (int j = 0; j < 48; j++) out48[48 * i + j] = 0; } else g1_encode_compressed(out48 + 48 * i, x, y, inf);
+    err[i] = (uint8_t)e;
+}
+// Signature::from_bytes validity (reference src/signature.rs:43-46): err code per item; optional subgroup flag
+MBLS_FN void op_g2_check(uint64_t i, const uint8_t* in96, uint8_t* err, uint8_t* in_g2) {
+    fp2 x, y; bool inf; int e = g2_decode_compressed(&x, &y, &inf, in96 + 96 * i);
+    err[i] = (uint8_t)e;
+    if (in_g2) {
+        g2j p; p.x = x; p.y = y; p.z = fp2_one(); if (inf || e) g2_set_inf(&p);
+        in_g2[i] = (!e && g2_in_subgroup(&p)) ? 1 : 0;
+    }
+}
+MBLS_FN void g2_encode_jacobian(uint8_t* out96, const g2j* p) {
+    fp2 x, y; bool inf; g2_to_affine(&x, &y, &inf, p); g2_encode_compressed(out96, x, y, inf);
+}
+// AggregateSignature::add (reference src/aggregates.rs:114-116): out = a + b on compressed signatures
+MBLS_FN void op_g2_add(uint64_t i, const uint8_t* a96, const uint8_t* b96, uint8_t* out96, uint8_t* err) {
+    fp2 x, y; bool inf; g2j p, q;
+    int e = g2_decode_compressed(&x, &y, &inf, a96 + 96 * i);
+    p.x = x; p.y = y; p.z = fp2_one(); if (inf) g2_set_inf(&p);
+    int e2 = g2_decode_compressed(&x, &y, &inf, b96 + 96 * i);
+    q.x = x; q.y = y; q.z = fp2_one(); if (inf) g2_set_inf(&q);
+    if (!e) e = e2;
+    if (e) { for (int j = 0; j < 96; j++) out96[96 * i + j] = 0; }
+    else { g2_add(&p, &p, &q); g2_encode_jacobian(out96 + 96 * i, &p); }
+    err[i] = (uint8_t)e;
+}
+// AggregatePublicKey::add (reference src/aggregates.rs:68-77) on decoded keys
+MBLS_FN void op_g1_add(uint64_t i, const uint8_t* a96, const uint8_t* b96, uint8_t* out96, uint8_t* err) {
+    fp x, y, x2, y2; bool inf, inf2;
+    int e = g1_decode_uncompressed(&x, &y, &inf, a96 + 96 * i), e2 = g1_decode_uncompressed(&x2, &y2, &inf2, b96 + 96 * i);
+    if (!e) e = e2;
+    if (e) { for (int j = 0; j < 96; j++) out96[96 * i + j] = 0; }
+    else {
+        g1j p; p.x = x; p.y = y; p.z = fp_one(); if (inf) g1_set_inf(&p);
+        g1_madd(&p, &p, x2, y2, inf2);
+        g1_to_affine(&x, &y, &inf, &p); g1_encode_uncompressed(out96 + 96 * i, x, y, inf);
+    }
+    err[i] = (uint8_t)e;
+}
+// the aggregate key of item i (left in the workspace by lane_aggregate) as 96 uncompressed bytes
+MBLS_FN void op_apk_export(const mbls_ws& ws, uint64_t i, uint8_t* out96) {
+    g1j a; a.x = ws_ld(ws, MBLS_SLOT_APK, i); a.y = ws_ld(ws, MBLS_SLOT_APK + 1, i); a.z = ws_ld(ws, MBLS_SLOT_APK + 2, i);
+    fp x, y; bool inf; g1_to_affine(&x, &y, &inf, &a); g1_encode_uncompressed(out96 + 96 * i, x, y, inf);
+}
+MBLS_FN void scalar_from_be32(uint32_t* k, const uint8_t* b) {
+    for (int j = 0; j < 8; j++) { const uint8_t* q = b + 28 - 4 * j; k[j] = ((uint32_t)q[0] << 24) | ((uint32_t)q[1] << 16) | ((uint32_t)q[2] << 8) | q[3]; }
+}
+// Signature::new (reference src/signature.rs:17-21): sig = [sk] H(msg), compressed
+MBLS_FN void op_sign(uint64_t i, const uint8_t* sks32, const uint8_t* msgs, uint32_t mlen, uint8_t* out96) {
+    uint32_t k[8]; scalar_from_be32(k, sks32 + 32 * i);
+    g2j h; hash_to_g2(&h, msgs + (uint64_t)mlen * i, mlen, MBLS_DST_POP, MBLS_DST_POP_LEN);
+    g2_mul(&h, &h, k, 255);
+    g2_encode_jacobian(out96 + 96 * i, &h);
+}
+// PublicKey::from_secret_key (reference src/keys.rs:124-137): pk = [sk] G1
+MBLS_FN void op_sk_to_pk(uint64_t i, const uint8_t* sks32, int fmt, uint8_t* out) {
+    uint32_t k[8]; scalar_from_be32(k, sks32 + 32 * i);
+    g1j g; g.x = fp_load_const(MBLS_G1_X); g.y = fp_load_const(MBLS_G1_Y); g.z = fp_one();
+    g1_mul(&g, &g, k, 255);
+    fp x, y; bool inf; g1_to_affine(&x, &y, &inf, &g);
+    if (fmt == MBLS_PK_COMPRESSED) g1_encode_compressed(out + 48 * i, x, y, inf); else g1_encode_uncompressed(out + 96 * i, x, y, inf);
+}
+// hash_to_curve_g2 (reference src/amcl_utils.rs:33-35), compressed output
+MBLS_FN void op_hash_to_g2(uint64_t i, const uint8_t* msgs, uint32_t mlen, uint8_t* out96) {
+    g2j h; hash_to_g2(&h, msgs + (uint64_t)mlen * i, mlen, MBLS_DST_POP, MBLS_DST_POP_LEN);
+    g2_encode_jacobian(out96 + 96 * i, &h);
+}
+// field probe: out = a*b mod p on canonical 48-byte big-endian values (parity test of the multiplier)
+MBLS_FN void op_fp_mul(uint64_t i, const uint8_t* a48, const uint8_t* b48, uint8_t* out48, int use_sqr) {
+    fp a = fp_to_mont(fp_raw_from_be(a48 + 48 * i)), b = fp_to_mont(fp_raw_from_be(b48 + 48 * i));
+    fp r = use_sqr ? fp_sqr(a) : fp_mul(a, b);
+    fp_raw_to_be(out48 + 48 * i, fp_from_mont(r));
+}

@@ -1,0 +1,88 @@
+// mbls_pairing.h -- optimal-ate Miller loop (shared squaring over the pairs of one lane) and final
+// exponentiation. Replaces amcl's pair::{ate2, initmp/another/miller, fexp} behind reference
+// src/amcl_utils.rs:38-42 and src/aggregates.rs:142-169,270-315.
+//
+// Everything projective, no field inversion inside the loop:
+//   * T and Q in homogeneous coordinates on the twist E': y^2 = x^3 + 4(1+i);
+//   * the G1 argument P = (X:Y:Z) Jacobian enters only through PX = X*Z, PY = Y, PZ3 = Z^3: the line
+//     (c0 + c2 xP w^2 + c3 yP w^3) is scaled by Z^3 in Fp, which the final exponentiation kills, like every
+//     other factor from a proper subfield of Fp12 that these formulas drop.
+// Lines: doubling  (Y^2 - 3b'Z^2) + (-3X^2 xP) w^2 + (2YZ yP) w^3
+//        addition  (u X2 - v Y2) + (-u Z2 xP) w^2 + (v Z2 yP) w^3,  u = Y2 Z1 - Y1 Z2, v = X2 Z1 - X1 Z2
+// The loop runs over |x| = 0xd201000000010000 (63 doublings, 5 additions; the bit pattern is a
+// compile-time constant, so no lane ever diverges) and conjugates at the end because x < 0.
+#pragma once
+#include "mbls_curve.h"
+
+struct g2h { fp2 x, y, z; };                 // homogeneous projective point on the twist
+struct g1arg { fp px, py, pz3; };            // scaled G1 argument (see above)
+struct mbls_pair { g2h q; g2h t; g1arg p; bool skip; };   // skip: a member is infinity -> contributes 1
+
+MBLS_FN void g1arg_from_affine(g1arg* a, fp x, fp y) { a->px = x; a->py = y; a->pz3 = fp_one(); }
+MBLS_FN void g1arg_from_jacobian(g1arg* a, const g1j* p) {
+    a->px = fp_mul(p->x, p->z); a->py = p->y; a->pz3 = fp_mul(fp_sqr(p->z), p->z);
+}
+MBLS_FN void g2h_from_affine(g2h* h, const fp2& x, const fp2& y) { h->x = x; h->y = y; h->z = fp2_one(); }
+MBLS_FN void g2h_from_jacobian(g2h* h, const g2j* p) {   // (X/Z^2, Y/Z^3) = (XZ : Y : Z^3)
+    h->x = fp2_mul(p->x, p->z); h->y = p->y; h->z = fp2_mul(fp2_sqr(p->z), p->z);
+}
+
+MBLS_NOINLINE void miller_dbl_step(fp12* f, mbls_pair* pr) {
+    g2h* T = &pr->t;
+    fp2 B = fp2_sqr(T->y), C = fp2_sqr(T->z);
+    fp2 E = fp2_mul12(fp2_mul_xi(C));                 // 3b' Z^2, b' = 4(1+i)
+    fp2 F = fp2_mul3(E);
+    fp2 X2 = fp2_sqr(T->x);
+    fp2 YZ = fp2_mul(T->y, T->z);
+    fp2 c0 = fp2_mul_fp(fp2_sub(B, E), pr->p.pz3);
+    fp2 c2 = fp2_mul_fp(fp2_neg(fp2_mul3(X2)), pr->p.px);
+    fp2 c3 = fp2_mul_fp(fp2_dbl(YZ), pr->p.py);
+    fp2 x3 = fp2_dbl(fp2_mul(fp2_mul(T->x, T->y), fp2_sub(B, F)));
+    fp2 y3 = fp2_sub(fp2_sqr(fp2_add(B, F)), fp2_mul12(fp2_sqr(E)));
+    fp2 z3 = fp2_mul8(fp2_mul(B, YZ));
+    T->x = x3; T->y = y3; T->z = z3;
+    bool sk = pr->skip;
+    c0 = fp2_select(sk, fp2_one(), c0); c2 = fp2_select(sk, fp2_zero(), c2); c3 = fp2_select(sk, fp2_zero(), c3);
+    fp12_mul_line(f, f, &c0, &c2, &c3);
+}
+MBLS_NOINLINE void miller_add_step(fp12* f, mbls_pair* pr) {
+    g2h* T = &pr->t; const g2h* Q = &pr->q;
+    fp2 y1z2 = fp2_mul(T->y, Q->z), x1z2 = fp2_mul(T->x, Q->z), z1z2 = fp2_mul(T->z, Q->z);
+    fp2 u = fp2_sub(fp2_mul(Q->y, T->z), y1z2), v = fp2_sub(fp2_mul(Q->x, T->z), x1z2);
+    fp2 c0 = fp2_mul_fp(fp2_sub(fp2_mul(u, Q->x), fp2_mul(v, Q->y)), pr->p.pz3);
+    fp2 c2 = fp2_mul_fp(fp2_neg(fp2_mul(u, Q->z)), pr->p.px);
+    fp2 c3 = fp2_mul_fp(fp2_mul(v, Q->z), pr->p.py);
+    fp2 uu = fp2_sqr(u), vv = fp2_sqr(v), vvv = fp2_mul(v, vv), R = fp2_mul(vv, x1z2);
+    fp2 A = fp2_sub(fp2_sub(fp2_mul(uu, z1z2), vvv), fp2_dbl(R));
+    fp2 x3 = fp2_mul(v, A);
+    fp2 y3 = fp2_sub(fp2_mul(u, fp2_sub(R, A)), fp2_mul(vvv, y1z2));
+    fp2 z3 = fp2_mul(vvv, z1z2);
+    T->x = x3; T->y = y3; T->z = z3;
+    bool sk = pr->skip;
+    c0 = fp2_select(sk, fp2_one(), c0); c2 = fp2_select(sk, fp2_zero(), c2); c3 = fp2_select(sk, fp2_zero(), c3);
+    fp12_mul_line(f, f, &c0, &c2, &c3);
+}
+// f = prod_k f_{x,Q_k}(P_k) up to subfield factors; pairs[k].t must equal pairs[k].q on entry
+MBLS_NOINLINE void miller_loop(fp12* f, mbls_pair* pairs, int npairs) {
+    fp12_set_one(f);
+    for (int i = 62; i >= 0; i--) {
+        if (i != 62) fp12_sqr(f, f);
+        for (int k = 0; k < npairs; k++) miller_dbl_step(f, &pairs[k]);
+        if ((MBLS_X_ABS >> i) & 1) for (int k = 0; k < npairs; k++) miller_add_step(f, &pairs[k]);
+    }
+    fp12_conj(f, f);
+}
+// f^(3 (p^12-1)/r). Hard part: 3 (p^4-p^2+1)/r = (x-1)^2 (x+p) (x^2+p^2-1) + 3 (Hayashida-Hayasaka-Teruya);
+// gcd(3, r) = 1, so comparing with 1 gives the same boolean as amcl's fexp (reference src/amcl_utils.rs:40-41).
+MBLS_NOINLINE void final_exp(fp12* r, const fp12* f) {
+    fp12 t, u, a, b, c, m;
+    fp12_conj(&t, f); fp12_inv(&u, f); fp12_mul(&t, &t, &u);              // f^(p^6-1)
+    fp12_frob(&u, &t); fp12_frob(&u, &u); fp12_mul(&m, &u, &t);            // ^(p^2+1): now cyclotomic
+    fp12_cyc_exp_x(&a, &m); fp12_conj(&u, &m); fp12_mul(&a, &a, &u);       // m^(x-1)
+    fp12_cyc_exp_x(&t, &a); fp12_conj(&u, &a); fp12_mul(&a, &t, &u);       // m^((x-1)^2)
+    fp12_cyc_exp_x(&b, &a); fp12_frob(&u, &a); fp12_mul(&b, &b, &u);       // a^(x+p)
+    fp12_cyc_exp_x(&c, &b); fp12_cyc_exp_x(&c, &c);                        // b^(x^2)
+    fp12_frob(&u, &b); fp12_frob(&u, &u); fp12_mul(&c, &c, &u);            // * b^(p^2)
+    fp12_conj(&u, &b); fp12_mul(&c, &c, &u);                               // * b^-1
+    fp12_cyc_sqr(&u, &m); fp12_mul(&u, &u, &m); fp12_mul(r, &c, &u);       // * m^3
+}

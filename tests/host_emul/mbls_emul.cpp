@@ -1,0 +1,46 @@
+// mbls_emul.cpp -- TEST INFRASTRUCTURE: compiles the lane bodies of the HIP kernels
+// (milagro_bls_amd/csrc/mbls_*.h) as plain C++ and runs them one "lane" at a time on the CPU, so the
+// CPU-only test suite can check every phase against the oracle before a GPU is involved. It is not a
+// fallback: the product library (libmbls_hip.so) contains no CPU path and never loads this file.
+#define MBLS_HOST_EMUL 1
+#include <stdlib.h>
+#include <string.h>
+#include "../../milagro_bls_amd/csrc/mbls_ops.h"
+
+extern "C" {
+// the full fast_aggregate_verify / verify pipeline over n items, same phases and workspace layout as the GPU
+void emul_verify_batch(const uint8_t* sigs, const uint8_t* msgs, uint32_t mlen, const uint8_t* pks, int fmt,
+                       const uint32_t* offsets, uint64_t n, uint32_t k, int mode, uint8_t* results, uint32_t* status) {
+    mbls_ws ws; ws.stride = n ? n : 1; ws.w = (uint32_t*)calloc((size_t)MBLS_SLOT_COUNT * 12 * ws.stride, 4);
+    const uint32_t pkb = fmt == MBLS_PK_COMPRESSED ? 48 : 96;
+    for (uint64_t i = 0; i < n; i++) {
+        uint64_t first = offsets ? offsets[i] : (uint64_t)k * i; uint32_t cnt = offsets ? offsets[i + 1] - offsets[i] : k;
+        lane_aggregate(ws, i, pks + pkb * first, cnt, fmt, mode, &status[i]);
+    }
+    for (uint64_t i = 0; i < n; i++) lane_sig(ws, i, sigs + 96 * i, &status[i]);
+    for (uint64_t i = 0; i < n; i++) lane_hash(ws, i, msgs + (uint64_t)mlen * i, mlen);
+    for (uint64_t i = 0; i < n; i++) lane_miller(ws, i);
+    for (uint64_t i = 0; i < n; i++) lane_final(ws, i, &status[i], &results[i]);
+    free(ws.w);
+}
+void emul_g1_decode(const uint8_t* in, int fmt, int validate, uint64_t n, uint8_t* out96, uint8_t* err) { for (uint64_t i = 0; i < n; i++) op_g1_decode(i, in, fmt, validate, out96, err); }
+void emul_g1_key_validate(const uint8_t* in96, uint64_t n, uint8_t* ok) { for (uint64_t i = 0; i < n; i++) op_g1_key_validate(i, in96, ok); }
+void emul_g1_compress(const uint8_t* in96, uint64_t n, uint8_t* out48, uint8_t* err) { for (uint64_t i = 0; i < n; i++) op_g1_compress(i, in96, out48, err); }
+void emul_g2_check(const uint8_t* in96, uint64_t n, uint8_t* err, uint8_t* in_g2) { for (uint64_t i = 0; i < n; i++) op_g2_check(i, in96, err, in_g2); }
+void emul_g2_add(const uint8_t* a, const uint8_t* b, uint64_t n, uint8_t* out, uint8_t* err) { for (uint64_t i = 0; i < n; i++) op_g2_add(i, a, b, out, err); }
+void emul_g1_add(const uint8_t* a, const uint8_t* b, uint64_t n, uint8_t* out, uint8_t* err) { for (uint64_t i = 0; i < n; i++) op_g1_add(i, a, b, out, err); }
+void emul_sign(const uint8_t* sks, const uint8_t* msgs, uint32_t mlen, uint64_t n, uint8_t* out96) { for (uint64_t i = 0; i < n; i++) op_sign(i, sks, msgs, mlen, out96); }
+void emul_sk_to_pk(const uint8_t* sks, int fmt, uint64_t n, uint8_t* out) { for (uint64_t i = 0; i < n; i++) op_sk_to_pk(i, sks, fmt, out); }
+void emul_hash_to_g2(const uint8_t* msgs, uint32_t mlen, uint64_t n, uint8_t* out96) { for (uint64_t i = 0; i < n; i++) op_hash_to_g2(i, msgs, mlen, out96); }
+void emul_fp_mul(const uint8_t* a, const uint8_t* b, uint64_t n, uint8_t* out, int use_sqr) { for (uint64_t i = 0; i < n; i++) op_fp_mul(i, a, b, out, use_sqr); }
+void emul_aggregate(const uint8_t* pks, int fmt, const uint32_t* offsets, uint64_t n, uint32_t k, uint8_t* out96, uint32_t* status) {
+    mbls_ws ws; ws.stride = n ? n : 1; ws.w = (uint32_t*)calloc((size_t)MBLS_SLOT_COUNT * 12 * ws.stride, 4);
+    const uint32_t pkb = fmt == MBLS_PK_COMPRESSED ? 48 : 96;
+    for (uint64_t i = 0; i < n; i++) {
+        uint64_t first = offsets ? offsets[i] : (uint64_t)k * i; uint32_t cnt = offsets ? offsets[i + 1] - offsets[i] : k;
+        lane_aggregate(ws, i, pks + pkb * first, cnt, fmt, MBLS_MODE_FAST_AGGREGATE, &status[i]);
+        op_apk_export(ws, i, out96);
+    }
+    free(ws.w);
+}
+}
