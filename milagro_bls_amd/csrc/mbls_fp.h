@@ -132,6 +132,14 @@ MBLS_FN fp fp_half(fp a) {
 
 // ------------------------------------------------------------------------------------------------
 // Montgomery multiplication r = a*b/2^384 mod p, product scanning over a 96-bit column accumulator.
+#if defined(MBLS_HOST_EMUL)
+static thread_local uint64_t mbls_cnt_mul = 0, mbls_cnt_sqr = 0;     // op census (host emulation only)
+#define MBLS_COUNT_MUL() (mbls_cnt_mul++)
+#define MBLS_COUNT_SQR() (mbls_cnt_sqr++)
+#else
+#define MBLS_COUNT_MUL()
+#define MBLS_COUNT_SQR()
+#endif
 struct mbls_acc { uint64_t lo; uint32_t hi; };
 MBLS_FN void mbls_mac(mbls_acc& s, uint32_t a, uint32_t b) {
 #if MBLS_DEVICE_ASM
@@ -153,6 +161,7 @@ MBLS_FN void mbls_acc_shift(mbls_acc& s) { s.lo = (s.lo >> 32) | ((uint64_t)s.hi
 
 MBLS_NOINLINE fp fp_mul(fp a, fp b) {
     uint32_t m[12]; fp t; mbls_acc s = {0, 0};
+    MBLS_COUNT_MUL();
 #pragma unroll
     for (int k = 0; k < 12; k++) {
 #pragma unroll
@@ -177,6 +186,7 @@ MBLS_NOINLINE fp fp_mul(fp a, fp b) {
 // Squaring: off-diagonal products once, doubled, plus the diagonal.
 MBLS_NOINLINE fp fp_sqr(fp a) {
     uint32_t m[12]; fp t; mbls_acc s = {0, 0};
+    MBLS_COUNT_SQR();
 #pragma unroll
     for (int k = 0; k < 24; k++) {
         mbls_acc d = {0, 0};

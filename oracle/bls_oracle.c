@@ -701,7 +701,8 @@ int orc_g1_from_uncompressed(const uint8_t *in, size_t len, uint8_t out[96]) {  
 }
 int orc_g1_key_validate(const uint8_t pk[96]) {                                    /* src/keys.rs:181-186 */
     orc_init(); g1p p; if (g1_from_unc(&p, pk)) return 0;
-    if (g1_is_inf(&p) || !g1_in_subgroup(&p)) return 0; return 1;
+    if (g1_is_inf(&p) || !g1_in_subgroup(&p)) return 0;
+    return 1;
 }
 int orc_pk_from_bytes(const uint8_t *in, size_t len, uint8_t out[96]) {            /* PublicKey::from_bytes, src/keys.rs:140-147 */
     int e = orc_g1_from_compressed(in, len, out); if (e) return e;

@@ -8,6 +8,7 @@
 #include "../../milagro_bls_amd/csrc/mbls_ops.h"
 
 extern "C" {
+void emul_op_counts(uint64_t* mul, uint64_t* sqr, int reset) { *mul = mbls_cnt_mul; *sqr = mbls_cnt_sqr; if (reset) mbls_cnt_mul = mbls_cnt_sqr = 0; }
 // the full fast_aggregate_verify / verify pipeline over n items, same phases and workspace layout as the GPU
 void emul_verify_batch(const uint8_t* sigs, const uint8_t* msgs, uint32_t mlen, const uint8_t* pks, int fmt,
                        const uint32_t* offsets, uint64_t n, uint32_t k, int mode, uint8_t* results, uint32_t* status) {

@@ -1,0 +1,84 @@
+"""CPU-only checks of the built product library: it loads, exports every symbol include/mbls.h declares, carries a
+gfx950 code object without the base-pointer hazard (see mbls_fp.h), and has no path into the oracle."""
+import ctypes
+import os
+import re
+import shutil
+import subprocess
+import tempfile
+
+import pytest
+
+import helpers
+
+LIB = os.path.join(helpers.ROOT, "milagro_bls_amd", "libmbls_hip.so")
+HDR = os.path.join(helpers.ROOT, "include", "mbls.h")
+LLVM = "/opt/rocm/lib/llvm/bin"
+
+
+@pytest.fixture(scope="module")
+def lib_path():
+    from milagro_bls_amd import build
+    return build.build()
+
+
+def declared_symbols():
+    txt = open(HDR).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(mbls_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_header_declares_the_path():
+    syms = declared_symbols()
+    for must in ("mbls_fast_aggregate_verify_batch_device", "mbls_verify_batch_device", "mbls_verify_multiple_aggregate_signatures",
+                 "mbls_aggregate_verify", "mbls_pk_from_bytes", "mbls_sig_from_bytes", "mbls_ctx_create"):
+        assert must in syms
+
+
+def test_library_exports_every_declared_symbol(lib_path):
+    l = ctypes.CDLL(lib_path)
+    missing = [s for s in declared_symbols() if not hasattr(l, s)]
+    assert not missing, missing
+    # and the ctypes binding table covers the header 1:1
+    from milagro_bls_amd import _native
+    assert sorted(_native.SIGNATURES) == declared_symbols()
+
+
+def test_no_oracle_in_product(lib_path):
+    out = subprocess.check_output(["nm", "-D", lib_path], text=True)
+    assert "orc_" not in out
+    needed = subprocess.check_output([LLVM + "/llvm-readelf", "-d", lib_path], text=True)
+    assert "bls_oracle" not in needed and "mbls_emul" not in needed
+    pkg = os.path.join(helpers.ROOT, "milagro_bls_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".h", ".hip", ".inc")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "import orc" not in src and "bls_oracle" not in src and "pymodel" not in src, f
+
+
+def test_context_creation_fails_loudly_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from milagro_bls_amd import _native
+    with pytest.raises(_native.MblsError):
+        _native.Context(0)
+    from milagro_bls_amd import PublicKey
+    with pytest.raises(_native.MblsError):
+        PublicKey.from_bytes(bytes(48))       # no CPU fallback behind the API
+
+
+def test_code_object_has_no_base_pointer_frames(lib_path):
+    # hipcc 7.2 IPRA clobbers the base pointer s34 across calls; mbls_fp.h avoids realigned frames altogether.
+    with tempfile.TemporaryDirectory() as d:
+        so = os.path.join(d, "lib.so")
+        shutil.copy(lib_path, so)
+        subprocess.check_call([LLVM + "/llvm-objdump", "--offloading", so], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        co = [f for f in os.listdir(d) if "gfx950" in f]
+        assert co, os.listdir(d)
+        dis = subprocess.check_output([LLVM + "/llvm-objdump", "-d", "--mcpu=gfx950", os.path.join(d, co[0])], text=True)
+    assert "v_mad_u64_u32" in dis                      # the hand-written multiplier is there
+    assert "v_mfma" not in dis                         # carry-chain integer work, no MFMA
+    assert not re.search(r"s_andn2_b32 s33, s33", dis), "a function realigns its stack (base pointer hazard)"
+    assert not re.search(r"s_mov_b32 s32, s34", dis), "a function restores SP from the base pointer s34"

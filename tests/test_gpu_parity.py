@@ -1,0 +1,186 @@
+"""GPU parity tests proper: the HIP path, called through the C ABI of libmbls_hip.so, against the oracle on the same
+seeded inputs, against the committed golden vectors, and -- at sizes the oracle cannot cover in seconds -- through
+size-independent properties. Bit-exact: accept bits, status classes, serialized bytes, error codes."""
+import ctypes as C
+import random
+
+import pytest
+
+import helpers
+import orc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def mb():
+    import milagro_bls_amd
+    from milagro_bls_amd import batch, _native
+    _native.default_context()          # raises if the HIP library or the GPU is missing: no fallback
+    return batch
+
+
+def test_native_library_is_loaded(mb):
+    from milagro_bls_amd import _native
+    assert _native.lib() is not None
+    with open("/proc/self/maps") as f:
+        assert "libmbls_hip.so" in f.read()
+
+
+def test_fp_mul_sqr_parity(mb):
+    rnd = random.Random(1)
+    n = 4096
+    A = [rnd.randrange(helpers.P) for _ in range(n)]; B = [rnd.randrange(helpers.P) for _ in range(n)]
+    A[:4] = [0, 1, helpers.P - 1, helpers.P - 1]; B[:4] = [5, helpers.P - 1, helpers.P - 1, 2]
+    a = b"".join(x.to_bytes(48, "big") for x in A); b = b"".join(x.to_bytes(48, "big") for x in B)
+    o = mb.fp_mul_batch(a, b, n)
+    assert all(int.from_bytes(o[48 * i:48 * i + 48], "big") == A[i] * B[i] % helpers.P for i in range(n))
+    o = mb.fp_mul_batch(a, b, n, square=True)
+    assert all(int.from_bytes(o[48 * i:48 * i + 48], "big") == A[i] * A[i] % helpers.P for i in range(n))
+    # spot-check the oracle's own multiplier on the same inputs
+    assert orc.fp_mul(a[:48 * 5][-48:], b[:48 * 5][-48:]) == o[:0] + mb.fp_mul_batch(a[48 * 4:48 * 5], b[48 * 4:48 * 5], 1)
+
+
+def test_hash_to_g2_golden_and_oracle(mb, vectors):
+    for v in vectors["model"]["hash_to_g2"]:
+        m = helpers.expand_msg(v["msg"])
+        assert mb.hash_to_g2_batch(m, 1, msg_len=len(m)).hex() == v["compressed"], v["msg"][:16]
+    rnd = random.Random(2)
+    msgs = rnd.randbytes(32 * 256)
+    assert mb.hash_to_g2_batch(msgs, 256) == orc.batch_hash_to_g2(msgs, 256)
+
+
+def test_sign_and_keys_external_vectors(mb, vectors):
+    e = vectors["external"]["eth2_sign"]
+    assert mb.sign_batch(bytes.fromhex(e["sk"]), bytes.fromhex(e["msg"]), 1).hex() == e["sig"]
+    sks = b"".join(bytes.fromhex(kp["sk"]) for kp in vectors["external"]["eth2_sk_to_pk"])
+    got = mb.sk_to_pk_batch(sks, 3)
+    assert [got[48 * i:48 * i + 48].hex() for i in range(3)] == [kp["pk"] for kp in vectors["external"]["eth2_sk_to_pk"]]
+    rnd = random.Random(3)
+    n = 64
+    sk = b"".join(rnd.randrange(1, helpers.R).to_bytes(32, "big") for _ in range(n)); msgs = rnd.randbytes(32 * n)
+    assert mb.sign_batch(sk, msgs, n) == orc.batch_sign(sk, msgs, n, nthreads=8)
+    assert mb.sk_to_pk_batch(sk, n, out_format=1) == orc.batch_sk_to_pk(sk, n, 1, nthreads=8)
+
+
+def test_codec_parity(mb, vectors):
+    ref = vectors["reference"]
+    g1 = [bytes.fromhex(h) for h in ref["g1_compressed_round_trip"]["hex"]]
+    out, errs = mb.pk_decode_batch(b"".join(g1), 3, validate=True)
+    assert errs == [0, 0, 0] and [out[96 * i:96 * i + 96] for i in range(3)] == [orc.g1_from_compressed(b)[1] for b in g1]
+    back, errs = mb.pk_compress_batch(out, 3)
+    assert errs == [0, 0, 0] and back == b"".join(g1)                      # reference src/amcl_utils.rs:81-99
+    g2 = [bytes.fromhex(h) for h in ref["g2_compressed_round_trip"]["hex"]]
+    errs, in_g2 = mb.sig_check_batch(b"".join(g2), 3)
+    assert errs == [0, 0, 0] and in_g2 == [True, True, True]
+    probes = vectors["model"]["g2_subgroup_probes"]
+    errs, in_g2 = mb.sig_check_batch(b"".join(bytes.fromhex(p["compressed"]) for p in probes), len(probes))
+    assert errs == [0] * len(probes) and in_g2 == [p["in_g2"] for p in probes]
+    p1 = vectors["model"]["g1_subgroup_probes"]
+    out, errs = mb.pk_decode_batch(b"".join(bytes.fromhex(p["compressed"]) for p in p1), len(p1), validate=True)
+    assert [e == 0 for e in errs] == [p["key_validate"] for p in p1]
+    out, errs = mb.pk_decode_batch(b"".join(bytes.fromhex(p["compressed"]) for p in p1), len(p1), validate=False)
+    assert errs == [0] * len(p1) and out == b"".join(bytes.fromhex(p["uncompressed"]) for p in p1)
+    bad = [bytes.fromhex(h) for h in vectors["model"]["g1_bad_compressed"]]
+    assert mb.pk_decode_batch(b"".join(bad), len(bad), validate=False)[1] == [3] * len(bad)
+    # random garbage: identical error classes as the oracle (differential decode test, cf. reference fuzz/ targets)
+    rnd = random.Random(4)
+    blobs = [bytes([rnd.choice([0x80, 0xA0, 0xC0, 0x00, 0xE0, 0x9f]) | rnd.getrandbits(5)]) + rnd.randbytes(47) for _ in range(256)]
+    out, errs = mb.pk_decode_batch(b"".join(blobs), 256, validate=False)
+    for i, bl in enumerate(blobs):
+        e, pt = orc.g1_from_compressed(bl)
+        assert errs[i] == e and (e != 0 or out[96 * i:96 * i + 96] == pt)
+    blobs2 = [bytes([rnd.choice([0x80, 0xA0, 0xC0, 0x00, 0xE0]) | rnd.getrandbits(5)]) + rnd.randbytes(95) for _ in range(128)]
+    errs, in_g2 = mb.sig_check_batch(b"".join(blobs2), 128)
+    for i, bl in enumerate(blobs2):
+        e, pt = orc.g2_from_compressed(bl)
+        assert errs[i] == e and (e != 0 or in_g2[i] == orc.g2_subgroup_check(pt))
+
+
+@pytest.mark.parametrize("fmt", [0, 1])
+def test_fast_aggregate_verify_batch_vs_oracle(mb, fmt):
+    b = helpers.make_batch(96, 8, fmt=fmt, seed=40 + fmt)
+    got, st = mb.fast_aggregate_verify_batch(b.sigs, b.msgs, b.pks, b.n, b.k, pk_format=fmt)
+    want = orc.batch_fast_aggregate_verify(b.sigs, b.msgs, b.pks, b.n, b.k, fmt, nthreads=8)
+    assert got == want == b.expect
+    flag = {"sig_not_in_g2": 0x02, "apk_infinity": 0x08, "bad_sig_bytes": 0x01, "bad_pk_bytes": 0x04, "flip_msg": 0x40, "wrong_key": 0x40}
+    for kind, s in zip(b.kinds, st):
+        if kind in flag:
+            assert s & flag[kind], (kind, s)
+
+
+def test_fast_aggregate_verify_128_keys_vs_oracle(mb):
+    b = helpers.make_batch(192, 128, fmt=1, seed=50, pool_n=256)
+    got, _ = mb.fast_aggregate_verify_batch(b.sigs, b.msgs, b.pks, b.n, b.k, pk_format=1)
+    assert got == orc.batch_fast_aggregate_verify(b.sigs, b.msgs, b.pks, b.n, b.k, 1, nthreads=8) == b.expect
+    b = helpers.make_batch(96, 128, fmt=0, seed=51, pool_n=256)
+    got, _ = mb.fast_aggregate_verify_batch(b.sigs, b.msgs, b.pks, b.n, b.k, pk_format=0)
+    assert got == orc.batch_fast_aggregate_verify(b.sigs, b.msgs, b.pks, b.n, b.k, 0, nthreads=8) == b.expect
+
+
+def test_golden_batch_and_edge_cases(mb, vectors):
+    fb = vectors["model"]["fast_aggregate_verify_batch"]
+    items = fb["items"]
+    sigs = b"".join(bytes.fromhex(i["sig"]) for i in items); msgs = b"".join(bytes.fromhex(i["msg"]) for i in items)
+    for fmt, key in ((0, "pks_compressed"), (1, "pks_uncompressed")):
+        pks = b"".join(bytes.fromhex(h) for i in items for h in i[key])
+        assert mb.fast_aggregate_verify_batch(sigs, msgs, pks, len(items), fb["k"], pk_format=fmt)[0] == [i["result"] for i in items]
+    # ragged key sets incl. an empty one (reference src/aggregates.rs:179-181, :384-389)
+    b = helpers.make_batch(6, 3, fmt=0, seed=21, negatives=False)
+    counts = [3, 3, 0, 3, 2, 3]
+    pks = b"".join(b.pks[48 * 3 * i:48 * 3 * i + 48 * c] for i, c in enumerate(counts))
+    offs = [0]
+    for c in counts:
+        offs.append(offs[-1] + c)
+    got, st = mb.fast_aggregate_verify_batch(b.sigs, b.msgs, pks, 6, pk_offsets=offs)
+    assert got == [True, True, False, True, False, True] and st[2] & 0x10
+    # empty batch
+    assert mb.fast_aggregate_verify_batch(b"", b"", b"", 0, 3) == ([], [])
+    # n not a multiple of the wave size, k = 1
+    b = helpers.make_batch(67, 1, fmt=0, seed=22)
+    assert mb.fast_aggregate_verify_batch(b.sigs, b.msgs, b.pks, b.n, b.k)[0] == b.expect
+
+
+def test_verify_batch_vs_oracle(mb):
+    b = helpers.make_batch(128, 1, fmt=0, seed=60)
+    got, _ = mb.verify_batch(b.sigs, b.msgs, b.pks, b.n)
+    assert got == orc.batch_verify(b.sigs, b.msgs, b.pks, b.n, nthreads=8)
+
+
+def test_aggregate_public_keys_vs_oracle(mb):
+    b = helpers.make_batch(32, 16, fmt=0, seed=70, negatives=False)
+    apks, st = mb.aggregate_public_keys_batch(b.pks, b.n, b.k, pk_format=0)
+    for i in range(b.n):
+        keys = [orc.g1_from_compressed(b.pks[48 * (16 * i + j):48 * (16 * i + j + 1)])[1] for j in range(16)]
+        assert apks[96 * i:96 * i + 96] == orc.aggregate_pks(keys)[1]
+
+
+def test_device_entry_point_bitmap_and_large_batch_properties(mb):
+    """Config-2-sized property test (2^16 x Signature::verify): sign on the device, corrupt a known subset, check the
+    accept bitmap by construction, and pin a 64-item subsample against the oracle."""
+    import torch
+    from milagro_bls_amd import _native as N
+    ctx = N.default_context()
+    dev = torch.device("cuda:0")
+    n = 1 << 16
+    g = torch.Generator(device="cpu"); g.manual_seed(0x6d626c73)
+    sks = torch.randint(0, 256, (n, 32), dtype=torch.uint8, generator=g); sks[:, 0] &= 0x3F; sks[:, 31] |= 1   # nonzero, < r
+    msgs = torch.randint(0, 256, (n, 32), dtype=torch.uint8, generator=g)
+    d_sk, d_msg = sks.to(dev), msgs.to(dev)
+    d_sig = torch.empty((n, 96), dtype=torch.uint8, device=dev); d_pk = torch.empty((n, 48), dtype=torch.uint8, device=dev)
+    ctx.check(N.lib().mbls_sign_batch_device(ctx.handle, d_sk.data_ptr(), d_msg.data_ptr(), 32, n, d_sig.data_ptr(), None))
+    ctx.check(N.lib().mbls_sk_to_pk_batch_device(ctx.handle, d_sk.data_ptr(), 0, n, d_pk.data_ptr(), None))
+    bad = torch.arange(7, n, 16, device=dev)
+    d_msg[bad, 0] ^= 1
+    d_res = torch.empty(n, dtype=torch.uint8, device=dev); d_bm = torch.zeros(n // 64, dtype=torch.int64, device=dev)
+    ctx.check(N.lib().mbls_verify_batch_device(ctx.handle, d_sig.data_ptr(), d_msg.data_ptr(), 32, d_pk.data_ptr(), 0, n,
+                                               d_res.data_ptr(), d_bm.data_ptr(), None, None))
+    torch.cuda.synchronize()
+    res = d_res.cpu()
+    expect = torch.ones(n, dtype=torch.uint8); expect[7::16] = 0
+    assert torch.equal(res, expect)
+    bits = torch.tensor([(int(w) >> b) & 1 for w in d_bm.cpu().tolist()[:4] for b in range(64)], dtype=torch.uint8)
+    assert torch.equal(bits, expect[:256])
+    idx = list(range(0, 64))
+    sub = lambda t, w: bytes(t[idx].cpu().numpy().tobytes())
+    assert orc.batch_verify(sub(d_sig, 96), sub(d_msg, 32), sub(d_pk, 48), 64, nthreads=8) == [bool(x) for x in expect[:64].tolist()]
