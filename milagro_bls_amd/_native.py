@@ -4,7 +4,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libmbls_hip.so")
+LIB_PATH = os.environ.get("MBLS_LIB", os.path.join(HERE, "libmbls_hip.so"))
 
 # error codes (include/mbls.h)
 OK = 0

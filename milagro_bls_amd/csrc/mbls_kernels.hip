@@ -17,35 +17,39 @@
 #define MBLS_SLOT_S 25            // 6 Fp: Jacobian G2 accumulator for verify_multiple
 #define MBLS_SLOT_TOTAL 31
 #define WG 64
+#ifndef MBLS_WAVES_PER_SIMD
+#define MBLS_WAVES_PER_SIMD 1
+#endif
+#define MBLS_LB __launch_bounds__(WG, MBLS_WAVES_PER_SIMD)
 
 static __device__ __forceinline__ uint64_t gid() { return (uint64_t)blockIdx.x * WG + threadIdx.x; }
 
 // ------------------------------------------------------------------------------------------------ pipeline kernels
-__global__ void __launch_bounds__(WG) k_aggregate(mbls_ws ws, const uint8_t* pks, const uint32_t* offsets, uint32_t k, int fmt, int mode,
+__global__ void MBLS_LB k_aggregate(mbls_ws ws, const uint8_t* pks, const uint32_t* offsets, uint32_t k, int fmt, int mode,
                                                    uint32_t* status, uint64_t n) {
     uint64_t i = gid(); if (i >= n) return;
     const uint32_t pkb = fmt == MBLS_PK_COMPRESSED ? 48u : 96u;
     uint64_t first = offsets ? offsets[i] : (uint64_t)k * i; uint32_t cnt = offsets ? offsets[i + 1] - offsets[i] : k;
     uint32_t st; lane_aggregate(ws, i, pks + pkb * first, cnt, fmt, mode, &st); status[i] = st;
 }
-__global__ void __launch_bounds__(WG) k_sig(mbls_ws ws, const uint8_t* sigs, uint32_t* status, uint64_t n) {
+__global__ void MBLS_LB k_sig(mbls_ws ws, const uint8_t* sigs, uint32_t* status, uint64_t n) {
     uint64_t i = gid(); if (i >= n) return;
     uint32_t st = status[i]; lane_sig(ws, i, sigs + 96 * i, &st); status[i] = st;
 }
-__global__ void __launch_bounds__(WG) k_hash(mbls_ws ws, const uint8_t* msgs, uint32_t mlen, const uint64_t* moff, const uint32_t* mlens, uint64_t n) {
+__global__ void MBLS_LB k_hash(mbls_ws ws, const uint8_t* msgs, uint32_t mlen, const uint64_t* moff, const uint32_t* mlens, uint64_t n) {
     uint64_t i = gid(); if (i >= n) return;
     if (moff) lane_hash(ws, i, msgs + moff[i], mlens[i]); else lane_hash(ws, i, msgs + (uint64_t)mlen * i, mlen);
 }
-__global__ void __launch_bounds__(WG) k_miller(mbls_ws ws, uint64_t n) {
+__global__ void MBLS_LB k_miller(mbls_ws ws, uint64_t n) {
     uint64_t i = gid(); if (i >= n) return;
     lane_miller(ws, i);
 }
-__global__ void __launch_bounds__(WG) k_final(mbls_ws ws, uint32_t* status, uint8_t* results, uint64_t n) {
+__global__ void MBLS_LB k_final(mbls_ws ws, uint32_t* status, uint8_t* results, uint64_t n) {
     uint64_t i = gid(); if (i >= n) return;
     uint32_t st = status[i]; uint8_t r; lane_final(ws, i, &st, &r); status[i] = st; results[i] = r;
 }
 // accept bitmap: one 64-bit word per wave via ballot
-__global__ void __launch_bounds__(WG) k_pack(const uint8_t* results, uint64_t* bitmap, uint64_t n) {
+__global__ void MBLS_LB k_pack(const uint8_t* results, uint64_t* bitmap, uint64_t n) {
     uint64_t i = gid();
     bool bit = (i < n) && results[i];
     uint64_t m = __ballot(bit);
@@ -55,7 +59,7 @@ __global__ void __launch_bounds__(WG) k_pack(const uint8_t* results, uint64_t* b
 // ------------------------------------------------------------------------------------------------ n-pairing kernels
 // (aggregate_verify, reference src/aggregates.rs:130-170; verify_multiple, src/aggregates.rs:261-316)
 // item i: f_i = Miller(H_i, P_i) with P_i = [r_i] pk_i (r_i = 1 when rands == NULL); optional S_i = [r_i] sig_i
-__global__ void __launch_bounds__(WG) k_blind_pair(mbls_ws ws, const uint8_t* pks96, const uint8_t* sigs96, const uint64_t* rands,
+__global__ void MBLS_LB k_blind_pair(mbls_ws ws, const uint8_t* pks96, const uint8_t* sigs96, const uint64_t* rands,
                                                     uint32_t* status, uint64_t n) {
     uint64_t i = gid(); if (i >= n) return;
     uint32_t st = 0;
@@ -76,7 +80,7 @@ __global__ void __launch_bounds__(WG) k_blind_pair(mbls_ws ws, const uint8_t* pk
     status[i] = st;
 }
 // f_i = Miller(H_i, P_i) for i < n; lane n (if sig_slot_valid) computes Miller(S, -G1) with S read from slot S of item `s_item`
-__global__ void __launch_bounds__(WG) k_miller_single(mbls_ws ws, uint64_t n, int with_sig, uint64_t s_item) {
+__global__ void MBLS_LB k_miller_single(mbls_ws ws, uint64_t n, int with_sig, uint64_t s_item) {
     uint64_t i = gid(); if (i > n || (i == n && !with_sig)) return;
     mbls_pair pr;
     if (i < n) {
@@ -96,14 +100,14 @@ __global__ void __launch_bounds__(WG) k_miller_single(mbls_ws ws, uint64_t n, in
     for (int s = 0; s < 6; s++) ws_st2(ws, MBLS_SLOT_F + 2 * s, i, c[s]);
 }
 // tree steps: item i <- item i (op) item i + half, for i + half < m
-__global__ void __launch_bounds__(WG) k_f12_tree(mbls_ws ws, uint64_t m, uint64_t half) {
+__global__ void MBLS_LB k_f12_tree(mbls_ws ws, uint64_t m, uint64_t half) {
     uint64_t i = gid(); if (i + half >= m || i >= half) return;
     fp12 a, b; fp2* ca = &a.c0.c0; fp2* cb = &b.c0.c0;
     for (int s = 0; s < 6; s++) { ca[s] = ws_ld2(ws, MBLS_SLOT_F + 2 * s, i); cb[s] = ws_ld2(ws, MBLS_SLOT_F + 2 * s, i + half); }
     fp12_mul(&a, &a, &b);
     for (int s = 0; s < 6; s++) ws_st2(ws, MBLS_SLOT_F + 2 * s, i, ca[s]);
 }
-__global__ void __launch_bounds__(WG) k_g2_tree(mbls_ws ws, uint64_t m, uint64_t half) {
+__global__ void MBLS_LB k_g2_tree(mbls_ws ws, uint64_t m, uint64_t half) {
     uint64_t i = gid(); if (i + half >= m || i >= half) return;
     g2j a, b;
     a.x = ws_ld2(ws, MBLS_SLOT_S, i); a.y = ws_ld2(ws, MBLS_SLOT_S + 2, i); a.z = ws_ld2(ws, MBLS_SLOT_S + 4, i);
@@ -111,12 +115,12 @@ __global__ void __launch_bounds__(WG) k_g2_tree(mbls_ws ws, uint64_t m, uint64_t
     g2_add(&a, &a, &b);
     ws_st2(ws, MBLS_SLOT_S, i, a.x); ws_st2(ws, MBLS_SLOT_S + 2, i, a.y); ws_st2(ws, MBLS_SLOT_S + 4, i, a.z);
 }
-__global__ void __launch_bounds__(WG) k_status_or(const uint32_t* status, uint64_t n, uint32_t* out) {
+__global__ void MBLS_LB k_status_or(const uint32_t* status, uint64_t n, uint32_t* out) {
     uint64_t i = gid(); uint32_t v = (i < n) ? status[i] : 0;
     if (__ballot(v != 0)) { if (v) atomicOr(out, v); }
 }
 // decoded signature (compressed bytes) -> slot S of item `item` (for aggregate_verify's (sig, -G1) pair)
-__global__ void __launch_bounds__(WG) k_sig_to_slot(mbls_ws ws, const uint8_t* sig96, uint64_t item, uint32_t* status_out) {
+__global__ void MBLS_LB k_sig_to_slot(mbls_ws ws, const uint8_t* sig96, uint64_t item, uint32_t* status_out) {
     if (gid() != 0) return;
     fp2 x, y; bool inf; uint32_t st = 0;
     int e = g2_decode_compressed(&x, &y, &inf, sig96);
@@ -128,18 +132,18 @@ __global__ void __launch_bounds__(WG) k_sig_to_slot(mbls_ws ws, const uint8_t* s
 }
 
 // ------------------------------------------------------------------------------------------------ auxiliary kernels
-__global__ void __launch_bounds__(WG) k_g1_decode(const uint8_t* in, int fmt, int validate, uint64_t n, uint8_t* out96, uint8_t* err) { uint64_t i = gid(); if (i < n) op_g1_decode(i, in, fmt, validate, out96, err); }
-__global__ void __launch_bounds__(WG) k_g1_key_validate(const uint8_t* in96, uint64_t n, uint8_t* ok) { uint64_t i = gid(); if (i < n) op_g1_key_validate(i, in96, ok); }
-__global__ void __launch_bounds__(WG) k_g1_compress(const uint8_t* in96, uint64_t n, uint8_t* out48, uint8_t* err) { uint64_t i = gid(); if (i < n) op_g1_compress(i, in96, out48, err); }
-__global__ void __launch_bounds__(WG) k_g2_check(const uint8_t* in96, uint64_t n, uint8_t* err, uint8_t* in_g2) { uint64_t i = gid(); if (i < n) op_g2_check(i, in96, err, in_g2); }
-__global__ void __launch_bounds__(WG) k_g2_add(const uint8_t* a, const uint8_t* b, uint64_t n, uint8_t* out, uint8_t* err) { uint64_t i = gid(); if (i < n) op_g2_add(i, a, b, out, err); }
-__global__ void __launch_bounds__(WG) k_g1_add(const uint8_t* a, const uint8_t* b, uint64_t n, uint8_t* out, uint8_t* err) { uint64_t i = gid(); if (i < n) op_g1_add(i, a, b, out, err); }
-__global__ void __launch_bounds__(WG) k_sign(const uint8_t* sks, const uint8_t* msgs, uint32_t mlen, uint64_t n, uint8_t* out96) { uint64_t i = gid(); if (i < n) op_sign(i, sks, msgs, mlen, out96); }
-__global__ void __launch_bounds__(WG) k_sk_to_pk(const uint8_t* sks, int fmt, uint64_t n, uint8_t* out) { uint64_t i = gid(); if (i < n) op_sk_to_pk(i, sks, fmt, out); }
-__global__ void __launch_bounds__(WG) k_hash_to_g2(const uint8_t* msgs, uint32_t mlen, uint64_t n, uint8_t* out96) { uint64_t i = gid(); if (i < n) op_hash_to_g2(i, msgs, mlen, out96); }
-__global__ void __launch_bounds__(WG) k_fp_mul(const uint8_t* a, const uint8_t* b, uint64_t n, uint8_t* out, int sq) { uint64_t i = gid(); if (i < n) op_fp_mul(i, a, b, out, sq); }
-__global__ void __launch_bounds__(WG) k_apk_export(mbls_ws ws, uint64_t n, uint8_t* out96) { uint64_t i = gid(); if (i < n) op_apk_export(ws, i, out96); }
-__global__ void __launch_bounds__(WG) k_fp_mul_bench(uint32_t* sink, uint32_t iters, uint64_t n) {
+__global__ void MBLS_LB k_g1_decode(const uint8_t* in, int fmt, int validate, uint64_t n, uint8_t* out96, uint8_t* err) { uint64_t i = gid(); if (i < n) op_g1_decode(i, in, fmt, validate, out96, err); }
+__global__ void MBLS_LB k_g1_key_validate(const uint8_t* in96, uint64_t n, uint8_t* ok) { uint64_t i = gid(); if (i < n) op_g1_key_validate(i, in96, ok); }
+__global__ void MBLS_LB k_g1_compress(const uint8_t* in96, uint64_t n, uint8_t* out48, uint8_t* err) { uint64_t i = gid(); if (i < n) op_g1_compress(i, in96, out48, err); }
+__global__ void MBLS_LB k_g2_check(const uint8_t* in96, uint64_t n, uint8_t* err, uint8_t* in_g2) { uint64_t i = gid(); if (i < n) op_g2_check(i, in96, err, in_g2); }
+__global__ void MBLS_LB k_g2_add(const uint8_t* a, const uint8_t* b, uint64_t n, uint8_t* out, uint8_t* err) { uint64_t i = gid(); if (i < n) op_g2_add(i, a, b, out, err); }
+__global__ void MBLS_LB k_g1_add(const uint8_t* a, const uint8_t* b, uint64_t n, uint8_t* out, uint8_t* err) { uint64_t i = gid(); if (i < n) op_g1_add(i, a, b, out, err); }
+__global__ void MBLS_LB k_sign(const uint8_t* sks, const uint8_t* msgs, uint32_t mlen, uint64_t n, uint8_t* out96) { uint64_t i = gid(); if (i < n) op_sign(i, sks, msgs, mlen, out96); }
+__global__ void MBLS_LB k_sk_to_pk(const uint8_t* sks, int fmt, uint64_t n, uint8_t* out) { uint64_t i = gid(); if (i < n) op_sk_to_pk(i, sks, fmt, out); }
+__global__ void MBLS_LB k_hash_to_g2(const uint8_t* msgs, uint32_t mlen, uint64_t n, uint8_t* out96) { uint64_t i = gid(); if (i < n) op_hash_to_g2(i, msgs, mlen, out96); }
+__global__ void MBLS_LB k_fp_mul(const uint8_t* a, const uint8_t* b, uint64_t n, uint8_t* out, int sq) { uint64_t i = gid(); if (i < n) op_fp_mul(i, a, b, out, sq); }
+__global__ void MBLS_LB k_apk_export(mbls_ws ws, uint64_t n, uint8_t* out96) { uint64_t i = gid(); if (i < n) op_apk_export(ws, i, out96); }
+__global__ void MBLS_LB k_fp_mul_bench(uint32_t* sink, uint32_t iters, uint64_t n) {
     uint64_t i = gid(); if (i >= n) return;
     fp a = fp_load_const(MBLS_G1_X), b = fp_load_const(MBLS_G1_Y);
     a[0] ^= (uint32_t)i;

@@ -14,8 +14,11 @@ for k, fmt, name in ((128, 1, "k128_uncompressed"), (128, 0, "k128_compressed"),
     E.emul_op_counts(C.byref(m), C.byref(s), 1)
     res = helpers.ob(n); st = (C.c_uint32 * n)()
     E.emul_verify_batch(helpers.cb(b.sigs), helpers.cb(b.msgs), 32, helpers.cb(b.pks), fmt, None, C.c_uint64(n), k, 0 if k > 1 else 1, res, st)
+    ph = (C.c_uint64 * 5)(); E.emul_phase_counts(ph)
     E.emul_op_counts(C.byref(m), C.byref(s), 1)
     assert all(bytes(res)[:n])
+    cum = [0] + list(ph)
+    out[name + "_per_phase"] = {nm: (cum[i + 1] - cum[i]) / n for i, nm in enumerate(("aggregate", "sig", "hash", "miller", "final"))}
     out[name] = (m.value + s.value) / n
     out[name + "_detail"] = {"fp_mul": m.value / n, "fp_sqr": s.value / n}
     print(name, out[name], out[name + "_detail"])

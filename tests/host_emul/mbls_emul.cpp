@@ -7,6 +7,7 @@
 #include <string.h>
 #include "../../milagro_bls_amd/csrc/mbls_ops.h"
 
+static uint64_t emul_phase_ops[5];
 extern "C" {
 void emul_op_counts(uint64_t* mul, uint64_t* sqr, int reset) { *mul = mbls_cnt_mul; *sqr = mbls_cnt_sqr; if (reset) mbls_cnt_mul = mbls_cnt_sqr = 0; }
 // the full fast_aggregate_verify / verify pipeline over n items, same phases and workspace layout as the GPU
@@ -18,12 +19,18 @@ void emul_verify_batch(const uint8_t* sigs, const uint8_t* msgs, uint32_t mlen, 
         uint64_t first = offsets ? offsets[i] : (uint64_t)k * i; uint32_t cnt = offsets ? offsets[i + 1] - offsets[i] : k;
         lane_aggregate(ws, i, pks + pkb * first, cnt, fmt, mode, &status[i]);
     }
+    emul_phase_ops[0] = mbls_cnt_mul + mbls_cnt_sqr;
     for (uint64_t i = 0; i < n; i++) lane_sig(ws, i, sigs + 96 * i, &status[i]);
+    emul_phase_ops[1] = mbls_cnt_mul + mbls_cnt_sqr;
     for (uint64_t i = 0; i < n; i++) lane_hash(ws, i, msgs + (uint64_t)mlen * i, mlen);
+    emul_phase_ops[2] = mbls_cnt_mul + mbls_cnt_sqr;
     for (uint64_t i = 0; i < n; i++) lane_miller(ws, i);
+    emul_phase_ops[3] = mbls_cnt_mul + mbls_cnt_sqr;
     for (uint64_t i = 0; i < n; i++) lane_final(ws, i, &status[i], &results[i]);
+    emul_phase_ops[4] = mbls_cnt_mul + mbls_cnt_sqr;
     free(ws.w);
 }
+void emul_phase_counts(uint64_t out[5]) { for (int i = 0; i < 5; i++) out[i] = emul_phase_ops[i]; }
 void emul_g1_decode(const uint8_t* in, int fmt, int validate, uint64_t n, uint8_t* out96, uint8_t* err) { for (uint64_t i = 0; i < n; i++) op_g1_decode(i, in, fmt, validate, out96, err); }
 void emul_g1_key_validate(const uint8_t* in96, uint64_t n, uint8_t* ok) { for (uint64_t i = 0; i < n; i++) op_g1_key_validate(i, in96, ok); }
 void emul_g1_compress(const uint8_t* in96, uint64_t n, uint8_t* out48, uint8_t* err) { for (uint64_t i = 0; i < n; i++) op_g1_compress(i, in96, out48, err); }
