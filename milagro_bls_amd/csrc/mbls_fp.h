@@ -28,6 +28,13 @@
 #endif
 #endif
 
+// Fp6/Fp12-level operations: real functions by default; -DMBLS_INLINE_TOWER inlines them into their callers
+#if defined(MBLS_INLINE_TOWER)
+#define MBLS_TOWER_FN MBLS_FN
+#else
+#define MBLS_TOWER_FN MBLS_NOINLINE
+#endif
+
 #include "mbls_constants.inc"
 
 // An Fp element is a 12-lane-private-dword vector so that it is passed to and returned from
@@ -90,39 +97,48 @@ MBLS_FN fp fp_select(bool c, fp a, fp b) {   // c ? a : b, branch-free
     return r;
 }
 
-// r = a - p if a >= p else a   (a < 2p)
+// Carry chains are written with __builtin_addc / __builtin_subc: they lower to v_add_co_u32 / v_addc_co_u32 /
+// v_subb_co_u32 chains (36-48 VALU instructions per modular add). The obvious uint64_t formulation compiles to
+// ~155 instructions per add on gfx950 (v_lshl_add_u64 with zero-extension moves), which made the additions of the
+// Karatsuba tower cost as much as the multiplications.
+// r = a - p if a >= p else a   (a < 2p; top = carry word above the 12 limbs)
 MBLS_FN fp fp_reduce_once(fp a, uint32_t top) {
-    fp d; uint64_t br = 0;
+    fp d; unsigned br = 0;
 #pragma unroll
-    for (int i = 0; i < 12; i++) {
-        uint64_t x = (uint64_t)a[i] - fp_plimb(i) - br;
-        d[i] = (uint32_t)x; br = (x >> 32) & 1;
-    }
-    bool ge = (top != 0) || (br == 0);
+    for (int i = 0; i < 12; i++) { unsigned bo; d[i] = __builtin_subc(a[i], fp_plimb(i), br, &bo); br = bo; }
+    bool ge = (top != 0) | (br == 0);
     return fp_select(ge, d, a);
 }
 MBLS_FN fp fp_add(fp a, fp b) {
-    fp t; uint64_t c = 0;
+    fp t; unsigned c = 0;
 #pragma unroll
-    for (int i = 0; i < 12; i++) { c += (uint64_t)a[i] + b[i]; t[i] = (uint32_t)c; c >>= 32; }
+    for (int i = 0; i < 12; i++) { unsigned co; t[i] = __builtin_addc(a[i], b[i], c, &co); c = co; }
     return fp_reduce_once(t, 0);      // a + b < 2p < 2^384: no carry out of the top limb
 }
 MBLS_FN fp fp_sub(fp a, fp b) {
-    fp t; uint64_t br = 0;
+    fp t; unsigned br = 0;
 #pragma unroll
-    for (int i = 0; i < 12; i++) { uint64_t x = (uint64_t)a[i] - b[i] - br; t[i] = (uint32_t)x; br = (x >> 32) & 1; }
-    fp u; uint64_t c = 0;
+    for (int i = 0; i < 12; i++) { unsigned bo; t[i] = __builtin_subc(a[i], b[i], br, &bo); br = bo; }
+    uint32_t m = 0u - br; unsigned c = 0; fp r;      // add p back iff the subtraction borrowed
 #pragma unroll
-    for (int i = 0; i < 12; i++) { c += (uint64_t)t[i] + fp_plimb(i); u[i] = (uint32_t)c; c >>= 32; }
-    return fp_select(br != 0, u, t);
+    for (int i = 0; i < 12; i++) { unsigned co; r[i] = __builtin_addc(t[i], fp_plimb(i) & m, c, &co); c = co; }
+    return r;
 }
-MBLS_FN fp fp_neg(fp a) { return fp_sub(fp_zero(), a); }
+MBLS_FN fp fp_neg(fp a) {             // p - a, and 0 stays 0
+    fp t; unsigned br = 0; uint32_t nz = 0;
+#pragma unroll
+    for (int i = 0; i < 12; i++) { unsigned bo; t[i] = __builtin_subc(fp_plimb(i), a[i], br, &bo); br = bo; nz |= a[i]; }
+    uint32_t m = nz ? 0xFFFFFFFFu : 0u;
+#pragma unroll
+    for (int i = 0; i < 12; i++) t[i] &= m;
+    return t;
+}
 MBLS_FN fp fp_dbl(fp a) { return fp_add(a, a); }
 // a/2: (a + (a odd ? p : 0)) >> 1 -- valid on Montgomery representatives as well
 MBLS_FN fp fp_half(fp a) {
-    uint32_t odd = a[0] & 1u; fp t; uint64_t c = 0;
+    uint32_t m = 0u - (a[0] & 1u); fp t; unsigned c = 0;
 #pragma unroll
-    for (int i = 0; i < 12; i++) { c += (uint64_t)a[i] + (odd ? fp_plimb(i) : 0u); t[i] = (uint32_t)c; c >>= 32; }
+    for (int i = 0; i < 12; i++) { unsigned co; t[i] = __builtin_addc(a[i], fp_plimb(i) & m, c, &co); c = co; }
     fp r;
 #pragma unroll
     for (int i = 0; i < 11; i++) r[i] = (t[i] >> 1) | (t[i + 1] << 31);
@@ -221,15 +237,15 @@ MBLS_FN fp fp_from_mont(fp a) { fp one = 0; one[0] = 1; return fp_mul(a, one); }
 
 // raw (non-Montgomery) comparisons
 MBLS_FN bool fp_raw_geq_p(fp raw) {
-    uint64_t br = 0;
+    unsigned br = 0;
 #pragma unroll
-    for (int i = 0; i < 12; i++) { uint64_t x = (uint64_t)raw[i] - fp_plimb(i) - br; br = (x >> 32) & 1; }
+    for (int i = 0; i < 12; i++) { unsigned bo; (void)__builtin_subc(raw[i], fp_plimb(i), br, &bo); br = bo; }
     return br == 0;
 }
 MBLS_FN bool fp_raw_gt_half(fp raw) {   // raw > (p-1)/2
-    uint64_t br = 0;
+    unsigned br = 0;
 #pragma unroll
-    for (int i = 0; i < 12; i++) { uint64_t x = (uint64_t)MBLS_P_MINUS_1_DIV_2[i] - raw[i] - br; br = (x >> 32) & 1; }
+    for (int i = 0; i < 12; i++) { unsigned bo; (void)__builtin_subc(MBLS_P_MINUS_1_DIV_2[i], raw[i], br, &bo); br = bo; }
     return br != 0;
 }
 MBLS_FN bool fp_lex_largest(fp a) { return fp_raw_gt_half(fp_from_mont(a)); }

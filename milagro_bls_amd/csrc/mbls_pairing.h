@@ -27,7 +27,7 @@ MBLS_FN void g2h_from_jacobian(g2h* h, const g2j* p) {   // (X/Z^2, Y/Z^3) = (XZ
     h->x = fp2_mul(p->x, p->z); h->y = p->y; h->z = fp2_mul(fp2_sqr(p->z), p->z);
 }
 
-MBLS_NOINLINE void miller_dbl_step(fp12* f, mbls_pair* pr) {
+MBLS_TOWER_FN void miller_dbl_step(fp12* f, mbls_pair* pr) {
     g2h* T = &pr->t;
     fp2 B = fp2_sqr(T->y), C = fp2_sqr(T->z);
     fp2 E = fp2_mul12(fp2_mul_xi(C));                 // 3b' Z^2, b' = 4(1+i)
@@ -45,7 +45,7 @@ MBLS_NOINLINE void miller_dbl_step(fp12* f, mbls_pair* pr) {
     c0 = fp2_select(sk, fp2_one(), c0); c2 = fp2_select(sk, fp2_zero(), c2); c3 = fp2_select(sk, fp2_zero(), c3);
     fp12_mul_line(f, f, &c0, &c2, &c3);
 }
-MBLS_NOINLINE void miller_add_step(fp12* f, mbls_pair* pr) {
+MBLS_TOWER_FN void miller_add_step(fp12* f, mbls_pair* pr) {
     g2h* T = &pr->t; const g2h* Q = &pr->q;
     fp2 y1z2 = fp2_mul(T->y, Q->z), x1z2 = fp2_mul(T->x, Q->z), z1z2 = fp2_mul(T->z, Q->z);
     fp2 u = fp2_sub(fp2_mul(Q->y, T->z), y1z2), v = fp2_sub(fp2_mul(Q->x, T->z), x1z2);

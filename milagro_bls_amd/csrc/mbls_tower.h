@@ -85,7 +85,7 @@ MBLS_FN void fp6_add(fp6* r, const fp6* a, const fp6* b) { r->c0 = fp2_add(a->c0
 MBLS_FN void fp6_sub(fp6* r, const fp6* a, const fp6* b) { r->c0 = fp2_sub(a->c0, b->c0); r->c1 = fp2_sub(a->c1, b->c1); r->c2 = fp2_sub(a->c2, b->c2); }
 MBLS_FN void fp6_neg(fp6* r, const fp6* a) { r->c0 = fp2_neg(a->c0); r->c1 = fp2_neg(a->c1); r->c2 = fp2_neg(a->c2); }
 MBLS_FN void fp6_mul_v(fp6* r, const fp6* a) { fp2 t = fp2_mul_xi(a->c2); r->c2 = a->c1; r->c1 = a->c0; r->c0 = t; }
-MBLS_NOINLINE void fp6_mul(fp6* r, const fp6* a, const fp6* b) {
+MBLS_TOWER_FN void fp6_mul(fp6* r, const fp6* a, const fp6* b) {
     fp2 t0 = fp2_mul(a->c0, b->c0), t1 = fp2_mul(a->c1, b->c1), t2 = fp2_mul(a->c2, b->c2);
     fp2 c0 = fp2_mul(fp2_add(a->c1, a->c2), fp2_add(b->c1, b->c2));
     c0 = fp2_add(fp2_mul_xi(fp2_sub(fp2_sub(c0, t1), t2)), t0);
@@ -96,7 +96,7 @@ MBLS_NOINLINE void fp6_mul(fp6* r, const fp6* a, const fp6* b) {
     r->c0 = c0; r->c1 = c1; r->c2 = c2;
 }
 // a * (x + y v)
-MBLS_NOINLINE void fp6_mul_01(fp6* r, const fp6* a, const fp2* x, const fp2* y) {
+MBLS_TOWER_FN void fp6_mul_01(fp6* r, const fp6* a, const fp2* x, const fp2* y) {
     fp2 t0 = fp2_mul(a->c0, *x), t1 = fp2_mul(a->c1, *y);
     fp2 c1 = fp2_sub(fp2_sub(fp2_mul(fp2_add(a->c0, a->c1), fp2_add(*x, *y)), t0), t1);
     fp2 c0 = fp2_add(fp2_mul_xi(fp2_mul(a->c2, *y)), t0);
@@ -104,7 +104,7 @@ MBLS_NOINLINE void fp6_mul_01(fp6* r, const fp6* a, const fp2* x, const fp2* y) 
     r->c0 = c0; r->c1 = c1; r->c2 = c2;
 }
 // a * (y v)
-MBLS_NOINLINE void fp6_mul_1(fp6* r, const fp6* a, const fp2* y) {
+MBLS_TOWER_FN void fp6_mul_1(fp6* r, const fp6* a, const fp2* y) {
     fp2 c0 = fp2_mul_xi(fp2_mul(a->c2, *y)), c1 = fp2_mul(a->c0, *y), c2 = fp2_mul(a->c1, *y);
     r->c0 = c0; r->c1 = c1; r->c2 = c2;
 }
@@ -122,14 +122,14 @@ MBLS_FN void fp12_set_one(fp12* r) {
     r->c0.c0 = fp2_one(); r->c0.c1 = fp2_zero(); r->c0.c2 = fp2_zero();
     r->c1.c0 = fp2_zero(); r->c1.c1 = fp2_zero(); r->c1.c2 = fp2_zero();
 }
-MBLS_NOINLINE void fp12_mul(fp12* r, const fp12* a, const fp12* b) {
+MBLS_TOWER_FN void fp12_mul(fp12* r, const fp12* a, const fp12* b) {
     fp6 t0, t1, s, u, c1;
     fp6_mul(&t0, &a->c0, &b->c0); fp6_mul(&t1, &a->c1, &b->c1);
     fp6_add(&s, &a->c0, &a->c1); fp6_add(&u, &b->c0, &b->c1); fp6_mul(&c1, &s, &u);
     fp6_sub(&c1, &c1, &t0); fp6_sub(&c1, &c1, &t1);
     fp6_mul_v(&s, &t1); fp6_add(&r->c0, &t0, &s); r->c1 = c1;
 }
-MBLS_NOINLINE void fp12_sqr(fp12* r, const fp12* a) {
+MBLS_TOWER_FN void fp12_sqr(fp12* r, const fp12* a) {
     fp6 ab, s, t, va;
     fp6_mul(&ab, &a->c0, &a->c1);
     fp6_add(&s, &a->c0, &a->c1); fp6_mul_v(&va, &a->c1); fp6_add(&t, &a->c0, &va);
@@ -137,7 +137,7 @@ MBLS_NOINLINE void fp12_sqr(fp12* r, const fp12* a) {
     fp6_add(&r->c1, &ab, &ab);
 }
 // f * (c0 + c2 w^2 + c3 w^3): tower positions c0.c0 = c0, c0.c1 = c2, c1.c1 = c3
-MBLS_NOINLINE void fp12_mul_line(fp12* r, const fp12* f, const fp2* c0, const fp2* c2, const fp2* c3) {
+MBLS_TOWER_FN void fp12_mul_line(fp12* r, const fp12* f, const fp2* c0, const fp2* c2, const fp2* c3) {
     fp6 t0, t1, s, c1; fp2 y;
     fp6_mul_01(&t0, &f->c0, c0, c2); fp6_mul_1(&t1, &f->c1, c3);
     fp6_add(&s, &f->c0, &f->c1); y = fp2_add(*c2, *c3); fp6_mul_01(&c1, &s, c0, &y);
@@ -169,7 +169,7 @@ MBLS_FN void fp4_sqr(fp2* c0, fp2* c1, const fp2& a, const fp2& b) {
     *c0 = fp2_add(fp2_mul_xi(t1), t0);
     *c1 = fp2_sub(fp2_sub(fp2_sqr(fp2_add(a, b)), t0), t1);
 }
-MBLS_NOINLINE void fp12_cyc_sqr(fp12* r, const fp12* f) {
+MBLS_TOWER_FN void fp12_cyc_sqr(fp12* r, const fp12* f) {
     fp2 z0 = f->c0.c0, z4 = f->c0.c1, z3 = f->c0.c2, z2 = f->c1.c0, z1 = f->c1.c1, z5 = f->c1.c2;
     fp2 t0, t1, t2, t3;
     fp4_sqr(&t0, &t1, z0, z1);
