@@ -126,6 +126,12 @@ int mbls_verify_multiple_aggregate_signatures_device(mbls_ctx* ctx, const uint8_
                                               const uint8_t* d_msgs, uint32_t msg_len, const uint64_t* d_rands, uint64_t n,
                                               int* result, void* stream);
 
+/* The same for sets given by their keys in wire format (BASELINE configs[3]: 2^14 sets x 128 keys): set i owns k keys
+ * (or [pk_offsets[i], pk_offsets[i+1])), AggregatePublicKey::aggregate (src/aggregates.rs:29-39) runs on the device first. */
+int mbls_verify_multiple_sets_device(mbls_ctx* ctx, const uint8_t* d_sigs96, const uint8_t* d_pks, int pk_format,
+                                     const uint32_t* d_pk_offsets, uint32_t k, const uint8_t* d_msgs, uint32_t msg_len,
+                                     const uint64_t* d_rands, uint64_t n, int* result, void* stream);
+
 /* ---- batch helpers used to build inputs and caches on the device ---- */
 /* n x PublicKey::from_bytes[_unchecked] / from_uncompressed_bytes: errs[i] = MBLS_OK / MBLS_ERR_* per key */
 int mbls_pk_decode_batch(mbls_ctx* ctx, const uint8_t* in, int in_format, int validate, uint64_t n, uint8_t* out96, uint8_t* errs);

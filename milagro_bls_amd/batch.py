@@ -101,3 +101,13 @@ def fp_mul_bench(n_lanes, iters, ctx=None):
     ms = C.c_float()
     ctx.check(N.lib().mbls_fp_mul_bench(ctx.handle, n_lanes, iters, C.byref(ms)))
     return ms.value
+
+
+def verify_multiple_sets_device(d_sigs, d_pks, d_msgs, d_rands, n, k, pk_format=N.PK_COMPRESSED, msg_len=32, stream=None, ctx=None):
+    """AggregateSignature::verify_multiple_aggregate_signatures (reference src/aggregates.rs:261-316) over n sets given by
+    their k wire-format keys each, everything resident on the device (raw device pointers / ints). One bool."""
+    ctx = ctx or _c()
+    res = C.c_int(0)
+    ctx.check(N.lib().mbls_verify_multiple_sets_device(ctx.handle, d_sigs, d_pks, pk_format, None, k, d_msgs, msg_len, d_rands, n,
+                                                       C.byref(res), stream))
+    return bool(res.value)

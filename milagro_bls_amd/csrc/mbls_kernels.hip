@@ -63,9 +63,15 @@ __global__ void MBLS_LB k_blind_pair(mbls_ws ws, const uint8_t* pks96, const uin
                                                     uint32_t* status, uint64_t n) {
     uint64_t i = gid(); if (i >= n) return;
     uint32_t st = 0;
-    fp x, y; bool inf; int e = g1_decode_uncompressed(&x, &y, &inf, pks96 + 96 * i);
-    if (e) { st |= MBLS_ST_BAD_PK_ENCODING; inf = true; }
-    g1j p; p.x = x; p.y = y; p.z = fp_one(); if (inf) g1_set_inf(&p);
+    g1j p;
+    if (pks96) {
+        fp x, y; bool inf; int e = g1_decode_uncompressed(&x, &y, &inf, pks96 + 96 * i);
+        if (e) { st |= MBLS_ST_BAD_PK_ENCODING; inf = true; }
+        p.x = x; p.y = y; p.z = fp_one(); if (inf) g1_set_inf(&p);
+    } else {          // aggregate key left in the workspace by k_aggregate
+        st = status[i] & MBLS_ST_BAD_PK_ENCODING;
+        p.x = ws_ld(ws, MBLS_SLOT_APK, i); p.y = ws_ld(ws, MBLS_SLOT_APK + 1, i); p.z = ws_ld(ws, MBLS_SLOT_APK + 2, i);
+    }
     uint32_t k[2] = {1, 0};
     if (rands) { k[0] = (uint32_t)rands[i]; k[1] = (uint32_t)(rands[i] >> 32); g1_mul(&p, &p, k, 64); }
     ws_st(ws, MBLS_SLOT_APK, i, p.x); ws_st(ws, MBLS_SLOT_APK + 1, i, p.y); ws_st(ws, MBLS_SLOT_APK + 2, i, p.z);
@@ -537,8 +543,8 @@ extern "C" int mbls_aggregate_verify(mbls_ctx* c, const uint8_t sig[96], const u
     if (npairing_finish(c, n, 0, &result)) return 0;
     return result;
 }
-extern "C" int mbls_verify_multiple_aggregate_signatures_device(mbls_ctx* c, const uint8_t* d_sigs, const uint8_t* d_apks, const uint8_t* d_msgs,
-        uint32_t msg_len, const uint64_t* d_rands, uint64_t n, int* result, void* stream) {
+static int verify_multiple_impl(mbls_ctx* c, const uint8_t* d_sigs, const uint8_t* d_apks, const uint8_t* d_pks, int pk_format,
+        const uint32_t* d_pk_offsets, uint32_t k, const uint8_t* d_msgs, uint32_t msg_len, const uint64_t* d_rands, uint64_t n, int* result, void* stream) {
     if (!c || !result) return MBLS_ERR_ARGUMENT;
     hipStream_t s = (hipStream_t)stream;
     HIPCHK(c, hipSetDevice(c->device));
@@ -546,6 +552,8 @@ extern "C" int mbls_verify_multiple_aggregate_signatures_device(mbls_ctx* c, con
     mbls_ws ws; ws.w = c->d_w; ws.stride = c->cap;
     HIPCHK(c, hipMemsetAsync(c->d_scalar, 0, 64, s));
     if (n) {
+        if (!d_apks)   // sets given by their wire-format keys: AggregatePublicKey::aggregate on the device first (src/aggregates.rs:29-39)
+            hipLaunchKernelGGL(k_aggregate, dim3(nblk(n)), dim3(WG), 0, s, ws, d_pks, d_pk_offsets, k, pk_format, MBLS_MODE_VERIFY, c->d_status, n);
         hipLaunchKernelGGL(k_blind_pair, dim3(nblk(n)), dim3(WG), 0, s, ws, d_apks, d_sigs, d_rands, c->d_status, n);
         hipLaunchKernelGGL(k_status_or, dim3(nblk(n)), dim3(WG), 0, s, c->d_status, n, c->d_scalar);
         hipLaunchKernelGGL(k_hash, dim3(nblk(n)), dim3(WG), 0, s, ws, d_msgs, msg_len, (const uint64_t*)nullptr, (const uint32_t*)nullptr, n);
@@ -561,6 +569,17 @@ extern "C" int mbls_verify_multiple_aggregate_signatures_device(mbls_ctx* c, con
     if (st & (MBLS_ST_BAD_SIG_ENCODING | MBLS_ST_SIG_NOT_IN_G2 | MBLS_ST_BAD_PK_ENCODING)) { *result = 0; return MBLS_OK; }   // reference src/aggregates.rs:274-276
     HIPCHK(c, hipMemsetAsync(c->d_scalar, 0, 64, s));
     return npairing_finish(c, n, s, result);
+}
+extern "C" int mbls_verify_multiple_aggregate_signatures_device(mbls_ctx* c, const uint8_t* d_sigs, const uint8_t* d_apks, const uint8_t* d_msgs,
+        uint32_t msg_len, const uint64_t* d_rands, uint64_t n, int* result, void* stream) {
+    if (n && !d_apks) return MBLS_ERR_ARGUMENT;
+    return verify_multiple_impl(c, d_sigs, d_apks, nullptr, 0, nullptr, 0, d_msgs, msg_len, d_rands, n, result, stream);
+}
+extern "C" int mbls_verify_multiple_sets_device(mbls_ctx* c, const uint8_t* d_sigs, const uint8_t* d_pks, int pk_format, const uint32_t* d_pk_offsets,
+        uint32_t k, const uint8_t* d_msgs, uint32_t msg_len, const uint64_t* d_rands, uint64_t n, int* result, void* stream) {
+    if (pk_format != MBLS_PK_COMPRESSED && pk_format != MBLS_PK_UNCOMPRESSED) return MBLS_ERR_ARGUMENT;
+    if (n && !d_pks) return MBLS_ERR_ARGUMENT;
+    return verify_multiple_impl(c, d_sigs, nullptr, d_pks, pk_format, d_pk_offsets, k, d_msgs, msg_len, d_rands, n, result, stream);
 }
 extern "C" int mbls_verify_multiple_aggregate_signatures(mbls_ctx* c, const uint8_t* sigs96, const uint8_t* apks96, const uint8_t* msgs,
         uint32_t msg_len, const uint64_t* rands, size_t n) {

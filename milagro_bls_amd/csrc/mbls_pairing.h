@@ -45,7 +45,7 @@ MBLS_TOWER_FN void miller_dbl_step(fp12* f, mbls_pair* pr) {
     c0 = fp2_select(sk, fp2_one(), c0); c2 = fp2_select(sk, fp2_zero(), c2); c3 = fp2_select(sk, fp2_zero(), c3);
     fp12_mul_line(f, f, &c0, &c2, &c3);
 }
-MBLS_TOWER_FN void miller_add_step(fp12* f, mbls_pair* pr) {
+MBLS_TOWER_COLD_FN void miller_add_step(fp12* f, mbls_pair* pr) {
     g2h* T = &pr->t; const g2h* Q = &pr->q;
     fp2 y1z2 = fp2_mul(T->y, Q->z), x1z2 = fp2_mul(T->x, Q->z), z1z2 = fp2_mul(T->z, Q->z);
     fp2 u = fp2_sub(fp2_mul(Q->y, T->z), y1z2), v = fp2_sub(fp2_mul(Q->x, T->z), x1z2);

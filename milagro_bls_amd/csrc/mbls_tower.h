@@ -122,7 +122,7 @@ MBLS_FN void fp12_set_one(fp12* r) {
     r->c0.c0 = fp2_one(); r->c0.c1 = fp2_zero(); r->c0.c2 = fp2_zero();
     r->c1.c0 = fp2_zero(); r->c1.c1 = fp2_zero(); r->c1.c2 = fp2_zero();
 }
-MBLS_TOWER_FN void fp12_mul(fp12* r, const fp12* a, const fp12* b) {
+MBLS_TOWER_COLD_FN void fp12_mul(fp12* r, const fp12* a, const fp12* b) {
     fp6 t0, t1, s, u, c1;
     fp6_mul(&t0, &a->c0, &b->c0); fp6_mul(&t1, &a->c1, &b->c1);
     fp6_add(&s, &a->c0, &a->c1); fp6_add(&u, &b->c0, &b->c1); fp6_mul(&c1, &s, &u);

@@ -44,6 +44,13 @@ def test_library_exports_every_declared_symbol(lib_path):
     assert sorted(_native.SIGNATURES) == declared_symbols()
 
 
+def test_generated_asm_is_up_to_date():
+    inc = os.path.join(helpers.ROOT, "milagro_bls_amd", "csrc", "mbls_fp_asm.inc")
+    before = open(inc).read()
+    subprocess.check_call([__import__("sys").executable, os.path.join(helpers.ROOT, "tools", "gen_fp_asm.py")], stdout=subprocess.DEVNULL)
+    assert open(inc).read() == before
+
+
 def test_no_oracle_in_product(lib_path):
     out = subprocess.check_output(["nm", "-D", lib_path], text=True)
     assert "orc_" not in out

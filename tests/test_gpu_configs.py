@@ -1,0 +1,79 @@
+"""BASELINE.json configs at (or near) their stated sizes on the GPU, through size-independent properties: inputs are
+signed on the device by the product's own kernels (bench.build_inputs), so every accepted item is a
+sign -> aggregate -> verify round trip, every corrupted item must be rejected, and a subsample is pinned to the oracle."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import helpers
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def env():
+    import torch
+    import bench
+    from milagro_bls_amd import _native as N
+    ctx = N.default_context()
+    return torch, bench, N, ctx
+
+
+def test_config3_fast_aggregate_verify_128_keys_both_formats(env):
+    # configs[2]: fast_aggregate_verify with 128 public keys per item (2^13 items per format here; bench.py runs 2^16)
+    torch, bench, N, ctx = env
+    import orc
+    dev = torch.device("cuda:0")
+    for fmt in (N.PK_UNCOMPRESSED, N.PK_COMPRESSED):
+        n, k = 1 << 13, 128
+        d_sigs, d_msgs, d_pks, expect = bench.build_inputs(ctx, dev, n, k, fmt, rank=3)
+        d_res = torch.zeros(n, dtype=torch.uint8, device=dev); d_bm = torch.zeros(n // 64, dtype=torch.int64, device=dev)
+        d_st = torch.zeros(n, dtype=torch.int32, device=dev)
+        ctx.check(N.lib().mbls_fast_aggregate_verify_batch_device(ctx.handle, d_sigs.data_ptr(), d_msgs.data_ptr(), 32, d_pks.data_ptr(), fmt, None,
+                                                                  n, k, d_res.data_ptr(), d_bm.data_ptr(), d_st.data_ptr(), None))
+        torch.cuda.synchronize()
+        assert torch.equal(d_res.cpu(), expect)
+        st = d_st.cpu().numpy()
+        bad = np.arange(7, n, 16)
+        want_flag = [0x40, 0x40, 0x02, 0x40, 0x08]     # msg bit, wrong key, sig not in G2, infinity sig (pairing fails), apk = infinity
+        for j, i in enumerate(bad[:40]):
+            assert st[i] & want_flag[j % 5], (i, j % 5, st[i])
+        m = 48
+        pkb = 96 if fmt == N.PK_UNCOMPRESSED else 48
+        got = orc.batch_fast_aggregate_verify(d_sigs[:m].cpu().numpy().tobytes(), d_msgs[:m].cpu().numpy().tobytes(),
+                                              d_pks[:m].cpu().numpy().tobytes(), m, k, fmt, nthreads=8)
+        assert got == [bool(x) for x in expect[:m].tolist()]
+
+
+def test_config4_verify_multiple_2_14_sets_128_keys(env):
+    # configs[3]: verify_multiple_aggregate_signatures, 2^14 sets x 128 keys: all valid -> true, one corrupted set -> false
+    torch, bench, N, ctx = env
+    from milagro_bls_amd import batch
+    dev = torch.device("cuda:0")
+    n, k = 1 << 14, 128
+    d_sigs, d_msgs, d_pks, expect = bench.build_inputs(ctx, dev, n, k, N.PK_UNCOMPRESSED, rank=4, negatives=False)
+    g = torch.Generator(device="cpu"); g.manual_seed(7)
+    rands = torch.randint(1, (1 << 62), (n,), dtype=torch.int64, generator=g).to(dev)
+    args = (d_sigs.data_ptr(), d_pks.data_ptr(), d_msgs.data_ptr(), rands.data_ptr(), n, k)
+    assert batch.verify_multiple_sets_device(*args, pk_format=N.PK_UNCOMPRESSED) is True
+    d_msgs[n // 3, 5] ^= 0x10
+    assert batch.verify_multiple_sets_device(*args, pk_format=N.PK_UNCOMPRESSED) is False
+    d_msgs[n // 3, 5] ^= 0x10
+    assert batch.verify_multiple_sets_device(*args, pk_format=N.PK_UNCOMPRESSED) is True
+    # a signature outside G2 anywhere in the batch -> false (reference src/aggregates.rs:274-276)
+    probe = bytes.fromhex(helpers.load_vectors()["model"]["g2_subgroup_probes"][1]["compressed"])
+    keep = d_sigs[n - 1].clone()
+    d_sigs[n - 1] = torch.frombuffer(bytearray(probe), dtype=torch.uint8).to(dev)
+    assert batch.verify_multiple_sets_device(*args, pk_format=N.PK_UNCOMPRESSED) is False
+    d_sigs[n - 1] = keep
+    # small case against the oracle with the same blinding scalars
+    import orc
+    m = 6
+    sets = []
+    apks, _ = batch.aggregate_public_keys_batch(d_pks[:m].cpu().numpy().tobytes(), m, k, pk_format=N.PK_UNCOMPRESSED)
+    for i in range(m):
+        sets.append((orc.g2_from_compressed(d_sigs[i].cpu().numpy().tobytes())[1], apks[96 * i:96 * i + 96], d_msgs[i].cpu().numpy().tobytes()))
+    rr = [int(x) for x in rands[:m].cpu().tolist()]
+    assert orc.verify_multiple(sets, rr) is True
+    assert batch.verify_multiple_sets_device(d_sigs.data_ptr(), d_pks.data_ptr(), d_msgs.data_ptr(), rands.data_ptr(), m, k, pk_format=N.PK_UNCOMPRESSED) is True
