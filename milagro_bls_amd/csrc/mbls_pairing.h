@@ -27,8 +27,9 @@ MBLS_FN void g2h_from_jacobian(g2h* h, const g2j* p) {   // (X/Z^2, Y/Z^3) = (XZ
     h->x = fp2_mul(p->x, p->z); h->y = p->y; h->z = fp2_mul(fp2_sqr(p->z), p->z);
 }
 
-MBLS_TOWER_FN void miller_dbl_step(fp12* f, mbls_pair* pr) {
-    g2h* T = &pr->t;
+// One doubling step for the pair (T, P): T <- 2T, f <- f * line. T and f are the caller's loop-carried values; the G1
+// argument and the skip flag are read from the pair record in lane-private memory when needed.
+MBLS_TOWER_FN void miller_dbl_step(fp12* f, g2h* T, const mbls_pair* pr) {
     fp2 B = fp2_sqr(T->y), C = fp2_sqr(T->z);
     fp2 E = fp2_mul12(fp2_mul_xi(C));                 // 3b' Z^2, b' = 4(1+i)
     fp2 F = fp2_mul3(E);
@@ -45,8 +46,9 @@ MBLS_TOWER_FN void miller_dbl_step(fp12* f, mbls_pair* pr) {
     c0 = fp2_select(sk, fp2_one(), c0); c2 = fp2_select(sk, fp2_zero(), c2); c3 = fp2_select(sk, fp2_zero(), c3);
     fp12_mul_line(f, f, &c0, &c2, &c3);
 }
-MBLS_TOWER_COLD_FN void miller_add_step(fp12* f, mbls_pair* pr) {
-    g2h* T = &pr->t; const g2h* Q = &pr->q;
+// Addition step T <- T + Q (5 of the 63 iterations): out of line, on memory operands.
+MBLS_TOWER_COLD_FN void miller_add_step(fp12* f, g2h* T, const mbls_pair* pr) {
+    const g2h* Q = &pr->q;
     fp2 y1z2 = fp2_mul(T->y, Q->z), x1z2 = fp2_mul(T->x, Q->z), z1z2 = fp2_mul(T->z, Q->z);
     fp2 u = fp2_sub(fp2_mul(Q->y, T->z), y1z2), v = fp2_sub(fp2_mul(Q->x, T->z), x1z2);
     fp2 c0 = fp2_mul_fp(fp2_sub(fp2_mul(u, Q->x), fp2_mul(v, Q->y)), pr->p.pz3);
@@ -62,15 +64,28 @@ MBLS_TOWER_COLD_FN void miller_add_step(fp12* f, mbls_pair* pr) {
     c0 = fp2_select(sk, fp2_one(), c0); c2 = fp2_select(sk, fp2_zero(), c2); c3 = fp2_select(sk, fp2_zero(), c3);
     fp12_mul_line(f, f, &c0, &c2, &c3);
 }
-// f = prod_k f_{x,Q_k}(P_k) up to subfield factors; pairs[k].t must equal pairs[k].q on entry
-MBLS_NOINLINE void miller_loop(fp12* f, mbls_pair* pairs, int npairs) {
-    fp12_set_one(f);
+// f = prod_k f_{x,Q_k}(P_k) up to subfield factors; pairs[k].t must equal pairs[k].q on entry.
+// The loop-carried state (f and the running points T_k) is held in locals whose address never leaves this function
+// except through short-lived copies around the rare addition steps, so it can stay in VGPRs/AGPRs across iterations.
+template <int NP>
+MBLS_FN void miller_loop_n(fp12* f_out, mbls_pair* pairs) {
+    fp12 f; fp12_set_one(&f);
+    g2h T0 = pairs[0].t, T1 = pairs[NP - 1].t;
     for (int i = 62; i >= 0; i--) {
-        if (i != 62) fp12_sqr(f, f);
-        for (int k = 0; k < npairs; k++) miller_dbl_step(f, &pairs[k]);
-        if ((MBLS_X_ABS >> i) & 1) for (int k = 0; k < npairs; k++) miller_add_step(f, &pairs[k]);
+        if (i != 62) fp12_sqr(&f, &f);
+        miller_dbl_step(&f, &T0, &pairs[0]);
+        if (NP > 1) miller_dbl_step(&f, &T1, &pairs[NP - 1]);
+        if ((MBLS_X_ABS >> i) & 1) {
+            fp12 ft = f; g2h tt = T0;
+            miller_add_step(&ft, &tt, &pairs[0]); T0 = tt;
+            if (NP > 1) { tt = T1; miller_add_step(&ft, &tt, &pairs[NP - 1]); T1 = tt; }
+            f = ft;
+        }
     }
-    fp12_conj(f, f);
+    fp12_conj(f_out, &f);
+}
+MBLS_NOINLINE void miller_loop(fp12* f, mbls_pair* pairs, int npairs) {
+    if (npairs == 2) miller_loop_n<2>(f, pairs); else miller_loop_n<1>(f, pairs);
 }
 // f^(3 (p^12-1)/r). Hard part: 3 (p^4-p^2+1)/r = (x-1)^2 (x+p) (x^2+p^2-1) + 3 (Hayashida-Hayasaka-Teruya);
 // gcd(3, r) = 1, so comparing with 1 gives the same boolean as amcl's fexp (reference src/amcl_utils.rs:40-41).

@@ -185,10 +185,11 @@ MBLS_TOWER_FN void fp12_cyc_sqr(fp12* r, const fp12* f) {
 }
 // f^x, x = -0xd201000000010000, f in the cyclotomic subgroup
 MBLS_NOINLINE void fp12_cyc_exp_x(fp12* r, const fp12* f) {
+    // acc never escapes (the 5 multiplications go through a short-lived copy), so the 63 squarings keep it in registers
     fp12 acc = *f;
     for (int i = 62; i >= 0; i--) {
         fp12_cyc_sqr(&acc, &acc);
-        if ((MBLS_X_ABS >> i) & 1) fp12_mul(&acc, &acc, f);
+        if ((MBLS_X_ABS >> i) & 1) { fp12 t = acc; fp12_mul(&t, &t, f); acc = t; }
     }
     fp12_conj(r, &acc);
 }
