@@ -194,6 +194,8 @@ def main():
     d_bm = torch.zeros(words, dtype=torch.int64, device=dev)
     d_all = torch.zeros(words * world, dtype=torch.int64, device=dev) if world > 1 else None
     ctx.reserve(n)
+    if fmt == N.PK_COMPRESSED:
+        ctx.check(lib.mbls_ctx_reserve_keys(ctx.handle, n * k))
     stream = torch.cuda.current_stream(dev)
 
     def step():

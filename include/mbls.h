@@ -60,6 +60,8 @@ int mbls_ctx_create(mbls_ctx** out, int device_id);
 void mbls_ctx_destroy(mbls_ctx* ctx);
 /* pre-allocate the HBM workspace for batches of up to max_items items (avoids allocation in timed regions) */
 int mbls_ctx_reserve(mbls_ctx* ctx, uint64_t max_items);
+/* pre-allocate the staging area for max_keys decompressed public keys (compressed wire format, 96 bytes per key) */
+int mbls_ctx_reserve_keys(mbls_ctx* ctx, uint64_t max_keys);
 const char* mbls_last_error(mbls_ctx* ctx);
 
 /* ---- the hot path -------------------------------------------------------------------------------------

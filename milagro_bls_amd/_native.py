@@ -30,6 +30,7 @@ SIGNATURES = {
     "mbls_ctx_create": (C.c_int, [C.POINTER(vp), C.c_int]),
     "mbls_ctx_destroy": (None, [vp]),
     "mbls_ctx_reserve": (C.c_int, [vp, C.c_uint64]),
+    "mbls_ctx_reserve_keys": (C.c_int, [vp, C.c_uint64]),
     "mbls_last_error": (C.c_char_p, [vp]),
     "mbls_fast_aggregate_verify_batch_device": (C.c_int, [vp, vp, vp, C.c_uint32, vp, C.c_int, vp, C.c_uint64, C.c_uint32, vp, vp, vp, vp]),
     "mbls_fast_aggregate_verify_batch": (C.c_int, [vp, vp, vp, C.c_uint32, vp, C.c_int, vp, C.c_uint64, C.c_uint32, vp, vp]),

@@ -32,6 +32,14 @@ __global__ void MBLS_LB k_aggregate(mbls_ws ws, const uint8_t* pks, const uint32
     uint64_t first = offsets ? offsets[i] : (uint64_t)k * i; uint32_t cnt = offsets ? offsets[i + 1] - offsets[i] : k;
     uint32_t st; lane_aggregate(ws, i, pks + pkb * first, cnt, fmt, mode, &st); status[i] = st;
 }
+__global__ void __launch_bounds__(WG, 4) k_pk_decompress(const uint8_t* pks48, uint64_t nkeys, uint32_t* keys_xy, uint8_t* flags) {
+    uint64_t j = gid(); if (j >= nkeys) return;
+    lane_pk_decompress(j, pks48, keys_xy, flags);
+}
+__global__ void MBLS_LB k_aggregate_decoded(mbls_ws ws, const uint32_t* keys_xy, const uint8_t* flags, uint32_t k, int mode, uint32_t* status, uint64_t n) {
+    uint64_t i = gid(); if (i >= n) return;
+    uint32_t st; lane_aggregate_decoded(ws, i, keys_xy + 24 * (uint64_t)k * i, flags + (uint64_t)k * i, k, mode, &st); status[i] = st;
+}
 __global__ void MBLS_LB k_sig(mbls_ws ws, const uint8_t* sigs, uint32_t* status, uint64_t n) {
     uint64_t i = gid(); if (i >= n) return;
     uint32_t st = status[i]; lane_sig(ws, i, sigs + 96 * i, &st); status[i] = st;
@@ -167,6 +175,9 @@ struct mbls_ctx {
     uint32_t* d_status;      // per-item status (when the caller passes none)
     uint8_t* d_results;
     uint32_t* d_scalar;      // small scratch words
+    uint64_t key_cap;        // decompressed-key staging (compressed wire format): capacity in keys
+    uint32_t* d_keys_xy;     // [key_cap][24] affine Montgomery coordinates
+    uint8_t* d_key_flags;
     bool timing;
     hipEvent_t ev[MBLS_N_PHASES + 1];
     float phase_ms[MBLS_N_PHASES];
@@ -197,6 +208,8 @@ extern "C" void mbls_ctx_destroy(mbls_ctx* c) {
     if (c->d_status) (void)hipFree(c->d_status);
     if (c->d_results) (void)hipFree(c->d_results);
     if (c->d_scalar) (void)hipFree(c->d_scalar);
+    if (c->d_keys_xy) (void)hipFree(c->d_keys_xy);
+    if (c->d_key_flags) (void)hipFree(c->d_key_flags);
     for (int i = 0; i <= MBLS_N_PHASES; i++) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
     delete c;
 }
@@ -211,6 +224,19 @@ extern "C" int mbls_ctx_reserve(mbls_ctx* c, uint64_t max_items) {
     HIPCHK(c, hipMalloc(&c->d_status, want * 4));
     HIPCHK(c, hipMalloc(&c->d_results, want));
     c->cap = want; return MBLS_OK;
+}
+// staging for decompressed keys (compressed wire format with a uniform key count)
+static int reserve_keys(mbls_ctx* c, uint64_t nkeys) {
+    if (nkeys <= c->key_cap) return MBLS_OK;
+    if (c->d_keys_xy) { (void)hipFree(c->d_keys_xy); (void)hipFree(c->d_key_flags); c->d_keys_xy = nullptr; c->d_key_flags = nullptr; c->key_cap = 0; }
+    HIPCHK(c, hipMalloc(&c->d_keys_xy, nkeys * 96));
+    HIPCHK(c, hipMalloc(&c->d_key_flags, nkeys));
+    c->key_cap = nkeys; return MBLS_OK;
+}
+extern "C" int mbls_ctx_reserve_keys(mbls_ctx* c, uint64_t max_keys) {
+    if (!c) return MBLS_ERR_ARGUMENT;
+    HIPCHK(c, hipSetDevice(c->device));
+    return reserve_keys(c, max_keys);
 }
 extern "C" int mbls_enable_phase_timing(mbls_ctx* c, int on) { if (!c) return MBLS_ERR_ARGUMENT; c->timing = on != 0; return MBLS_OK; }
 extern "C" int mbls_last_phase_ms(mbls_ctx* c, float ms[MBLS_N_PHASES]) {
@@ -231,8 +257,14 @@ static int verify_pipeline(mbls_ctx* c, const uint8_t* d_sigs, const uint8_t* d_
     uint32_t* st = d_status ? d_status : c->d_status;
     unsigned g = nblk(n);
     bool tm = c->timing;
+    bool staged = (fmt == MBLS_PK_COMPRESSED) && !d_off && k > 1;   // lane-per-key decompression, then the per-item sums
+    if (staged) { rc = reserve_keys(c, n * (uint64_t)k); if (rc) return rc; }
     if (tm) HIPCHK(c, hipEventRecord(c->ev[0], s));
-    hipLaunchKernelGGL(k_aggregate, dim3(g), dim3(WG), 0, s, ws, d_pks, d_off, k, fmt, mode, st, n);
+    if (staged) {
+        hipLaunchKernelGGL(k_pk_decompress, dim3(nblk(n * (uint64_t)k)), dim3(WG), 0, s, d_pks, n * (uint64_t)k, c->d_keys_xy, c->d_key_flags);
+        hipLaunchKernelGGL(k_aggregate_decoded, dim3(g), dim3(WG), 0, s, ws, (const uint32_t*)c->d_keys_xy, (const uint8_t*)c->d_key_flags, k, mode, st, n);
+    } else
+        hipLaunchKernelGGL(k_aggregate, dim3(g), dim3(WG), 0, s, ws, d_pks, d_off, k, fmt, mode, st, n);
     if (tm) HIPCHK(c, hipEventRecord(c->ev[1], s));
     hipLaunchKernelGGL(k_sig, dim3(g), dim3(WG), 0, s, ws, d_sigs, st, n);
     if (tm) HIPCHK(c, hipEventRecord(c->ev[2], s));

@@ -67,6 +67,39 @@ MBLS_FN void lane_aggregate(const mbls_ws& ws, uint64_t i, const uint8_t* pks, u
     ws_st(ws, MBLS_SLOT_APK, i, acc.x); ws_st(ws, MBLS_SLOT_APK + 1, i, acc.y); ws_st(ws, MBLS_SLOT_APK + 2, i, acc.z);
     *status = st;
 }
+// Compressed keys are decompressed one key per lane first (one Fp square root each: the dominant cost of the 48-byte
+// format, and with n*k lanes the kernel runs at full occupancy), into an array of affine Montgomery coordinates
+// (24 dwords per key); the per-item sum then only does the mixed additions.
+#define MBLS_KEYFLAG_INF 1u
+#define MBLS_KEYFLAG_BAD 2u
+MBLS_FN void lane_pk_decompress(uint64_t j, const uint8_t* pks48, uint32_t* keys_xy, uint8_t* flags) {
+    fp x, y; bool inf;
+    int e = g1_decode_compressed(&x, &y, &inf, pks48 + 48 * j);
+    uint32_t* o = keys_xy + 24 * j;
+#pragma unroll
+    for (int t = 0; t < 12; t++) { o[t] = x[t]; o[12 + t] = y[t]; }
+    flags[j] = (uint8_t)((e ? MBLS_KEYFLAG_BAD : 0u) | ((inf || e) ? MBLS_KEYFLAG_INF : 0u));
+}
+MBLS_FN void lane_aggregate_decoded(const mbls_ws& ws, uint64_t i, const uint32_t* keys_xy, const uint8_t* flags, uint32_t k, int mode, uint32_t* status) {
+    uint32_t st = 0;
+    g1j acc; g1_set_inf(&acc);
+    for (uint32_t j = 0; j < k; j++) {
+        const uint32_t* o = keys_xy + 24 * (uint64_t)j;
+        fp x, y;
+#pragma unroll
+        for (int t = 0; t < 12; t++) { x[t] = o[t]; y[t] = o[12 + t]; }
+        uint32_t f = flags[j];
+        if (f & MBLS_KEYFLAG_BAD) st |= MBLS_ST_BAD_PK_ENCODING;
+        if (f & MBLS_KEYFLAG_INF) st |= MBLS_ST_PK_INFINITY;
+        g1_madd(&acc, &acc, x, y, (f & MBLS_KEYFLAG_INF) != 0);
+    }
+    if (mode == MBLS_MODE_FAST_AGGREGATE) {
+        if (k == 0) st |= MBLS_ST_NO_KEYS;
+        if (g1_is_inf(&acc)) st |= MBLS_ST_APK_INFINITY;
+    }
+    ws_st(ws, MBLS_SLOT_APK, i, acc.x); ws_st(ws, MBLS_SLOT_APK + 1, i, acc.y); ws_st(ws, MBLS_SLOT_APK + 2, i, acc.z);
+    *status = st;
+}
 MBLS_FN void lane_sig(const mbls_ws& ws, uint64_t i, const uint8_t* sig96, uint32_t* status) {
     fp2 x, y; bool inf; uint32_t st = 0;
     int e = g2_decode_compressed(&x, &y, &inf, sig96);

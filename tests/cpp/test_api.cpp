@@ -1,0 +1,73 @@
+// The reference's unit tests restated against the C++ mirror include/milagro_bls.hpp (runs on the GPU through the C ABI).
+// Each block names the reference test it mirrors. Exit code 0 = all passed.
+#include <cstdio>
+#include <cstdlib>
+#include <random>
+#include "milagro_bls.hpp"
+using namespace milagro_bls;
+static int fails = 0;
+#define CHECK(x) do { if (!(x)) { std::printf("FAIL %s:%d %s\n", __FILE__, __LINE__, #x); fails++; } } while (0)
+static Bytes hex(const char* s) { Bytes b; for (size_t i = 0; s[i] && s[i + 1]; i += 2) { unsigned v; std::sscanf(s + i, "%2x", &v); b.push_back(uint8_t(v)); } return b; }
+static Bytes str(const char* s) { return Bytes(s, s + std::strlen(s)); }
+template <typename F> static int err_of(F f) { try { f(); } catch (const AmclError& e) { return e.kind; } return 0; }
+
+int main() {
+    // src/amcl_utils.rs:81-99: compressed G1 round trip
+    const char* g1[] = {"b53d21a4cfd562c469cc81514d4ce5a6b577d8403d32a394dc265dd190b47fa9f829fdd7963afdf972e5e77854051f6f",
+                        "b301803f8b5ac4a1133581fc676dfedc60d891dd5fa99028805e5ea5b08d3491af75d0707adab3b70c6a6a580217bf81",
+                        "a491d1b0ecd9bb917989f0e74f0dea0422eac4a873e5e2644f368dffb9a6e20fd6e10c1b77654d067c0618f6e5a7f79a"};
+    for (auto h : g1) { Bytes b = hex(h); auto pk = PublicKey::from_bytes(b); auto o = pk.as_bytes(); CHECK(Bytes(o.begin(), o.end()) == b); CHECK(pk.key_validate()); }
+    // src/signature.rs:103-125 (README): fixed secret key, message "cats"
+    Bytes skb = {78, 252, 122, 126, 32, 0, 75, 89, 252, 31, 42, 130, 254, 88, 6, 90, 138, 202, 135, 194, 233, 117, 181, 75, 96, 238, 79, 100, 237, 59, 140, 111};
+    SecretKey sk = SecretKey::from_bytes(skb);
+    CHECK(sk.as_bytes() == skb);
+    PublicKey pk = PublicKey::from_secret_key(sk);
+    Signature sig = Signature::new_(str("cats"), sk);
+    CHECK(sig.verify(str("cats"), pk));
+    auto pkb = pk.as_bytes();
+    CHECK(sig.verify(str("cats"), PublicKey::from_bytes(Bytes(pkb.begin(), pkb.end()))));
+    CHECK(!sig.verify(str("dogs"), pk));                                   // src/signature.rs:89-100
+    auto sb = sig.as_bytes();
+    CHECK(Signature::from_bytes(Bytes(sb.begin(), sb.end())) == sig);
+    // src/keys.rs:261-297, :334-350: error variants
+    CHECK(err_of([] { PublicKey::from_uncompressed_bytes(Bytes(95, 1)); }) == AmclError::InvalidG1Size);
+    { Bytes b(96, 0); b[47] = 1; b[95] = 1; CHECK(err_of([&] { PublicKey::from_uncompressed_bytes(b); }) == AmclError::InvalidPoint); }
+    { Bytes b(48, 0); b[0] = 128; CHECK(err_of([&] { PublicKey::from_bytes(b); }) == AmclError::InvalidPoint); CHECK(!PublicKey::from_bytes_unchecked(b).key_validate()); }
+    { Bytes b(48, 0); b[0] = 196; CHECK(err_of([&] { PublicKey::from_bytes(b); }) == AmclError::InvalidPoint); }
+    CHECK(err_of([] { SecretKey::from_bytes(Bytes(32, 0)); }) == AmclError::InvalidSecretKeyRange);
+    CHECK(err_of([] { SecretKey::from_bytes(Bytes(32, 255)); }) == AmclError::InvalidSecretKeyRange);
+    CHECK(err_of([] { SecretKey::from_bytes(Bytes(33, 1)); }) == AmclError::InvalidSecretKeySize);
+    CHECK(err_of([] { Signature::from_bytes(Bytes(95, 0)); }) == AmclError::InvalidG2Size);
+    // src/aggregates.rs:384-410: empty key list, keys summing to infinity
+    AggregateSignature inf;
+    CHECK(!inf.fast_aggregate_verify(Bytes(32, 0), {}));
+    { Bytes one(32, 0); one[31] = 1; PublicKey p1 = PublicKey::from_secret_key(SecretKey::from_bytes(one));
+      PublicKey pm = PublicKey::from_secret_key(SecretKey::from_bytes(hex("73eda753299d7d483339d80809a1d80553bda402fffe5bfeffffffff00000000")));
+      CHECK(!inf.fast_aggregate_verify(Bytes(32, 0), {&p1, &pm})); }
+    CHECK(err_of([] { AggregatePublicKey::aggregate({}); }) == AmclError::AggregateEmptyPoints);
+    // src/aggregates.rs:423-530 (shortened): aggregate of 4 signers, subset and superset must fail
+    std::mt19937 gen(7);
+    auto rand_sk = [&] { Bytes b(32); for (auto& v : b) v = uint8_t(gen()); b[0] &= 0x3f; b[31] |= 1; return SecretKey::from_bytes(b); };
+    std::vector<Keypair> kps; for (int i = 0; i < 4; i++) { SecretKey s = rand_sk(); kps.push_back(Keypair{s, PublicKey::from_secret_key(s)}); }
+    Bytes msg = str("Small msg");
+    AggregateSignature agg; std::vector<const PublicKey*> pks; std::vector<PublicKey> pkv;
+    for (auto& kp : kps) { agg.add(Signature::new_(msg, kp.sk)); pks.push_back(&kp.pk); pkv.push_back(kp.pk); }
+    AggregatePublicKey apk = AggregatePublicKey::into_aggregate(pkv);
+    CHECK(agg.fast_aggregate_verify_pre_aggregated(msg, apk));
+    CHECK(agg.fast_aggregate_verify(msg, pks));
+    { auto sub = pks; sub.pop_back(); CHECK(!agg.fast_aggregate_verify(msg, sub)); }
+    { AggregateSignature dbl = agg; dbl.add(Signature::new_(msg, kps[0].sk)); CHECK(!dbl.fast_aggregate_verify_pre_aggregated(msg, apk)); }
+    // src/aggregates.rs:808-929: aggregate_verify, distinct messages; length mismatch -> false
+    { std::vector<Bytes> msgs; AggregateSignature a; for (int i = 0; i < 4; i++) { msgs.push_back(Bytes(32, uint8_t(i))); a.add(Signature::new_(msgs[i], kps[i].sk)); }
+      CHECK(a.aggregate_verify(msgs, pks)); msgs.pop_back(); CHECK(!a.aggregate_verify(msgs, pks)); }
+    // src/aggregates.rs:688-805: verify_multiple_aggregate_signatures, valid then one set signed with the wrong key
+    { std::vector<AggregateSignature> sigs(3); std::vector<AggregatePublicKey> apks; std::vector<std::tuple<const AggregateSignature*, const AggregatePublicKey*, Bytes>> sets;
+      for (int i = 0; i < 3; i++) { Bytes m(32, uint8_t(i)); sigs[i].add(Signature::new_(m, kps[i].sk)); apks.push_back(AggregatePublicKey::from_public_key(kps[i].pk)); }
+      for (int i = 0; i < 3; i++) sets.emplace_back(&sigs[i], &apks[i], Bytes(32, uint8_t(i)));
+      auto rng = [&] { return uint8_t(gen()); };
+      CHECK(AggregateSignature::verify_multiple_aggregate_signatures(rng, sets));
+      AggregateSignature wrong; wrong.add(Signature::new_(Bytes(32, 1), kps[3].sk)); std::get<0>(sets[1]) = &wrong;
+      CHECK(!AggregateSignature::verify_multiple_aggregate_signatures(rng, sets)); }
+    std::printf(fails ? "%d checks failed\n" : "all C++ API checks passed\n", fails);
+    return fails ? 1 : 0;
+}

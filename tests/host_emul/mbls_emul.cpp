@@ -15,6 +15,12 @@ void emul_verify_batch(const uint8_t* sigs, const uint8_t* msgs, uint32_t mlen, 
                        const uint32_t* offsets, uint64_t n, uint32_t k, int mode, uint8_t* results, uint32_t* status) {
     mbls_ws ws; ws.stride = n ? n : 1; ws.w = (uint32_t*)calloc((size_t)MBLS_SLOT_COUNT * 12 * ws.stride, 4);
     const uint32_t pkb = fmt == MBLS_PK_COMPRESSED ? 48 : 96;
+    if (fmt == MBLS_PK_COMPRESSED && !offsets && k > 1) {   // staged path: lane per key, then per-item sums (as on the GPU)
+        uint32_t* xy = (uint32_t*)malloc((size_t)n * k * 96); uint8_t* fl = (uint8_t*)malloc((size_t)n * k);
+        for (uint64_t j = 0; j < n * k; j++) lane_pk_decompress(j, pks, xy, fl);
+        for (uint64_t i = 0; i < n; i++) lane_aggregate_decoded(ws, i, xy + 24 * (uint64_t)k * i, fl + (uint64_t)k * i, k, mode, &status[i]);
+        free(xy); free(fl);
+    } else
     for (uint64_t i = 0; i < n; i++) {
         uint64_t first = offsets ? offsets[i] : (uint64_t)k * i; uint32_t cnt = offsets ? offsets[i + 1] - offsets[i] : k;
         lane_aggregate(ws, i, pks + pkb * first, cnt, fmt, mode, &status[i]);
