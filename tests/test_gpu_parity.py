@@ -41,6 +41,23 @@ def test_fp_mul_sqr_parity(mb):
     assert orc.fp_mul(a[:48 * 5][-48:], b[:48 * 5][-48:]) == o[:0] + mb.fp_mul_batch(a[48 * 4:48 * 5], b[48 * 4:48 * 5], 1)
 
 
+def test_fp_mul_bulk_and_structured_operands(mb):
+    """2^18 random pairs plus structured limb patterns (carry-chain corner cases of the hand-written multiplier)."""
+    rnd = random.Random(123)
+    P = helpers.P
+    special = [0, 1, 2, P - 1, P - 2, (P - 1) // 2, (P + 1) // 2, 2**380, 2**380 - 1, 2**352 - 1, 2**32 - 1, 2**32, 2**64 - 1, 2**96,
+               int("ffffffff" * 11, 16), int("00000000ffffffff" * 5, 16), int("ffffffff00000000" * 5, 16) % P, int("80000000" * 11, 16),
+               0x1a0111ea397fe69a4b1ba7b6434bacd764774b84f38512bf6730d2a0f6b0f6241eabfffeb153ffffb9feffff00000000 % P]
+    pairs = [(a, b) for a in special for b in special]
+    n = 1 << 18
+    while len(pairs) < n:
+        pairs.append((rnd.randrange(P), rnd.randrange(P)))
+    a = b"".join(x.to_bytes(48, "big") for x, _ in pairs); b = b"".join(y.to_bytes(48, "big") for _, y in pairs)
+    o = mb.fp_mul_batch(a, b, n)
+    bad = [i for i in range(n) if int.from_bytes(o[48 * i:48 * i + 48], "big") != pairs[i][0] * pairs[i][1] % P]
+    assert not bad, bad[:5]
+
+
 def test_hash_to_g2_golden_and_oracle(mb, vectors):
     for v in vectors["model"]["hash_to_g2"]:
         m = helpers.expand_msg(v["msg"])
