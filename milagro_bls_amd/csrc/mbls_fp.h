@@ -135,6 +135,23 @@ MBLS_FN fp fp_sub(fp a, fp b) {
     for (int i = 0; i < 12; i++) { unsigned co; r[i] = __builtin_addc(t[i], fp_plimb(i) & m, c, &co); c = co; }
     return r;
 }
+// Unreduced variants for operands that feed a Montgomery multiplication directly: with R = 2^384 > 9.8 p the multiplier
+// accepts factors below 2p (a b / R + p < 1.41 p, brought below p by its one conditional subtraction), so the sum of two
+// reduced values, or a difference lifted by p, needs no reduction of its own (12 / 24 instructions instead of 36).
+MBLS_FN fp fp_add_nr(fp a, fp b) {     // a + b in [0, 2p)
+    fp t; unsigned c = 0;
+#pragma unroll
+    for (int i = 0; i < 12; i++) { unsigned co; t[i] = __builtin_addc(a[i], b[i], c, &co); c = co; }
+    return t;
+}
+MBLS_FN fp fp_sub_nr(fp a, fp b) {     // a - b + p in (0, 2p)
+    fp t; unsigned c = 0, br = 0;
+#pragma unroll
+    for (int i = 0; i < 12; i++) { unsigned co; t[i] = __builtin_addc(a[i], fp_plimb(i), c, &co); c = co; }
+#pragma unroll
+    for (int i = 0; i < 12; i++) { unsigned bo; t[i] = __builtin_subc(t[i], b[i], br, &bo); br = bo; }
+    return t;
+}
 MBLS_FN fp fp_neg(fp a) {             // p - a, and 0 stays 0
     fp t; unsigned br = 0; uint32_t nz = 0;
 #pragma unroll

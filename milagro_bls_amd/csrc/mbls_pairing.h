@@ -29,13 +29,16 @@ MBLS_FN void g2h_from_jacobian(g2h* h, const g2j* p) {   // (X/Z^2, Y/Z^3) = (XZ
 
 // One doubling step for the pair (T, P): T <- 2T, f <- f * line. T and f are the caller's loop-carried values; the G1
 // argument and the skip flag are read from the pair record in lane-private memory when needed.
+// AFFINE: the G1 argument is affine (pz3 = 1), so the Z^3 scaling of the constant coefficient is skipped.
+template <bool AFFINE>
 MBLS_TOWER_FN void miller_dbl_step(fp12* f, g2h* T, const mbls_pair* pr) {
     fp2 B = fp2_sqr(T->y), C = fp2_sqr(T->z);
     fp2 E = fp2_mul12(fp2_mul_xi(C));                 // 3b' Z^2, b' = 4(1+i)
     fp2 F = fp2_mul3(E);
     fp2 X2 = fp2_sqr(T->x);
     fp2 YZ = fp2_mul(T->y, T->z);
-    fp2 c0 = fp2_mul_fp(fp2_sub(B, E), pr->p.pz3);
+    fp2 c0 = fp2_sub(B, E);
+    if (!AFFINE) c0 = fp2_mul_fp(c0, pr->p.pz3);
     fp2 c2 = fp2_mul_fp(fp2_neg(fp2_mul3(X2)), pr->p.px);
     fp2 c3 = fp2_mul_fp(fp2_dbl(YZ), pr->p.py);
     fp2 x3 = fp2_dbl(fp2_mul(fp2_mul(T->x, T->y), fp2_sub(B, F)));
@@ -67,14 +70,14 @@ MBLS_TOWER_COLD_FN void miller_add_step(fp12* f, g2h* T, const mbls_pair* pr) {
 // f = prod_k f_{x,Q_k}(P_k) up to subfield factors; pairs[k].t must equal pairs[k].q on entry.
 // The loop-carried state (f and the running points T_k) is held in locals whose address never leaves this function
 // except through short-lived copies around the rare addition steps, so it can stay in VGPRs/AGPRs across iterations.
-template <int NP>
+template <int NP, bool AFFINE0>
 MBLS_FN void miller_loop_n(fp12* f_out, mbls_pair* pairs) {
     fp12 f; fp12_set_one(&f);
     g2h T0 = pairs[0].t, T1 = pairs[NP - 1].t;
     for (int i = 62; i >= 0; i--) {
         if (i != 62) fp12_sqr(&f, &f);
-        miller_dbl_step(&f, &T0, &pairs[0]);
-        if (NP > 1) miller_dbl_step(&f, &T1, &pairs[NP - 1]);
+        miller_dbl_step<AFFINE0>(&f, &T0, &pairs[0]);
+        if (NP > 1) miller_dbl_step<false>(&f, &T1, &pairs[NP - 1]);
         if ((MBLS_X_ABS >> i) & 1) {
             fp12 ft = f; g2h tt = T0;
             miller_add_step(&ft, &tt, &pairs[0]); T0 = tt;
@@ -84,8 +87,9 @@ MBLS_FN void miller_loop_n(fp12* f_out, mbls_pair* pairs) {
     }
     fp12_conj(f_out, &f);
 }
+// npairs = 2 is the verification shape: pair 0 = (signature, -G1) with an affine G1 argument, pair 1 = (H(msg), apk)
 MBLS_NOINLINE void miller_loop(fp12* f, mbls_pair* pairs, int npairs) {
-    if (npairs == 2) miller_loop_n<2>(f, pairs); else miller_loop_n<1>(f, pairs);
+    if (npairs == 2) miller_loop_n<2, true>(f, pairs); else miller_loop_n<1, false>(f, pairs);
 }
 // f^(3 (p^12-1)/r). Hard part: 3 (p^4-p^2+1)/r = (x-1)^2 (x+p) (x^2+p^2-1) + 3 (Hayashida-Hayasaka-Teruya);
 // gcd(3, r) = 1, so comparing with 1 gives the same boolean as amcl's fexp (reference src/amcl_utils.rs:40-41).

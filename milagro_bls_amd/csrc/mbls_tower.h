@@ -25,12 +25,12 @@ MBLS_FN fp2 fp2_dbl(const fp2& a) { return fp2_add(a, a); }
 MBLS_FN fp2 fp2_conj(const fp2& a) { fp2 r; r.c0 = a.c0; r.c1 = fp_neg(a.c1); return r; }
 MBLS_FN fp2 fp2_mul(const fp2& a, const fp2& b) {
     fp t0 = fp_mul(a.c0, b.c0), t1 = fp_mul(a.c1, b.c1);
-    fp t2 = fp_mul(fp_add(a.c0, a.c1), fp_add(b.c0, b.c1));
+    fp t2 = fp_mul(fp_add_nr(a.c0, a.c1), fp_add_nr(b.c0, b.c1));     // factors < 2p: see fp_add_nr
     fp2 r; r.c0 = fp_sub(t0, t1); r.c1 = fp_sub(fp_sub(t2, t0), t1); return r;
 }
 MBLS_FN fp2 fp2_sqr(const fp2& a) {
     fp m = fp_mul(a.c0, a.c1);
-    fp2 r; r.c0 = fp_mul(fp_add(a.c0, a.c1), fp_sub(a.c0, a.c1)); r.c1 = fp_dbl(m); return r;
+    fp2 r; r.c0 = fp_mul(fp_add_nr(a.c0, a.c1), fp_sub_nr(a.c0, a.c1)); r.c1 = fp_dbl(m); return r;
 }
 MBLS_FN fp2 fp2_mul_fp(const fp2& a, fp k) { fp2 r; r.c0 = fp_mul(a.c0, k); r.c1 = fp_mul(a.c1, k); return r; }
 MBLS_FN fp2 fp2_mul_xi(const fp2& a) { fp2 r; r.c0 = fp_sub(a.c0, a.c1); r.c1 = fp_add(a.c0, a.c1); return r; }
