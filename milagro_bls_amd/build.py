@@ -6,7 +6,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmbls_hip.so")
-SOURCES = ["mbls_kernels.hip"]
+SOURCES = ["mbls_kernels.hip", "mbls_kernels_w2.hip"]
 DEPS = ["mbls_fp.h", "mbls_fp_asm.inc", "mbls_tower.h", "mbls_curve.h", "mbls_hash.h", "mbls_pairing.h", "mbls_lanes.h", "mbls_ops.h",
         "mbls_constants.inc", os.path.join("..", "..", "include", "mbls.h")]
 
@@ -22,13 +22,25 @@ def build(force=False, verbose=False):
     if not force and not needs_build():
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-o", LIB + ".tmp"]
-    cmd += [os.path.join(CSRC, s) for s in SOURCES]
-    cmd += os.environ.get("MBLS_EXTRA_HIPCC_FLAGS", "").split()
+    extra = os.environ.get("MBLS_EXTRA_HIPCC_FLAGS", "").split()
+    objs, procs = [], []
+    for src in SOURCES:          # the two translation units compile in parallel
+        obj = os.path.join(HERE, "_" + src.replace(".hip", ".o"))
+        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", os.path.join(CSRC, src), "-o", obj] + extra
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        procs.append((subprocess.Popen(cmd), cmd))
+        objs.append(obj)
+    for p, cmd in procs:
+        if p.wait() != 0:
+            raise subprocess.CalledProcessError(p.returncode, cmd)
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB + ".tmp"] + objs
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
     os.replace(LIB + ".tmp", LIB)
+    for o in objs:
+        os.remove(o)
     return LIB
 
 

@@ -172,6 +172,20 @@ def test_aggregate_public_keys_vs_oracle(mb):
         assert apks[96 * i:96 * i + 96] == orc.aggregate_pks(keys)[1]
 
 
+def test_aggregation_with_repeated_inverse_and_infinite_keys(mb):
+    # complete-addition semantics of AggregatePublicKey::aggregate (reference src/aggregates.rs:34-37, :74-75): the running sum meets
+    # doubling (same key twice), inverse pairs (sum passes through infinity) and explicit infinity keys
+    g = orc.sk_to_pk(1); g2 = orc.sk_to_pk(2); mg = orc.sk_to_pk(helpers.R - 1); inf = bytes([0x40]) + bytes(95); q = orc.sk_to_pk(0xABCDEF)
+    sets = [[g, g, mg, g2, g2, g2], [g, mg, q, q, inf, q], [inf, inf, g, mg, inf, inf], [q, q, q, q, q, q], [mg, g, mg, g, g2, inf], [g2, g, g, inf, mg, mg]]
+    for fmt in (1, 0):
+        enc = (lambda p: p) if fmt == 1 else orc.g1_compress
+        flat = b"".join(enc(p) for s_ in sets for p in s_)
+        apks, st = mb.aggregate_public_keys_batch(flat, len(sets), 6, pk_format=fmt)
+        for i, s_ in enumerate(sets):
+            assert apks[96 * i:96 * i + 96] == orc.aggregate_pks(s_)[1], (fmt, i)
+        assert st[2] & 0x08 and not st[0] & 0x08        # set 2 sums to infinity
+
+
 def test_device_entry_point_bitmap_and_large_batch_properties(mb):
     """Config-2-sized property test (2^16 x Signature::verify): sign on the device, corrupt a known subset, check the
     accept bitmap by construction, and pin a 64-item subsample against the oracle."""
