@@ -23,11 +23,33 @@ MBLS_FN fp2 fp2_sub(const fp2& a, const fp2& b) { fp2 r; r.c0 = fp_sub(a.c0, b.c
 MBLS_FN fp2 fp2_neg(const fp2& a) { fp2 r; r.c0 = fp_neg(a.c0); r.c1 = fp_neg(a.c1); return r; }
 MBLS_FN fp2 fp2_dbl(const fp2& a) { return fp2_add(a, a); }
 MBLS_FN fp2 fp2_conj(const fp2& a) { fp2 r; r.c0 = a.c0; r.c1 = fp_neg(a.c1); return r; }
+#if MBLS_DEVICE_ASM && !defined(MBLS_NO_FP2_ASM)
+// Fp2 multiplication as one hand-written routine with a private calling convention (tools/gen_fp_asm.py, fp2_mul_body):
+// operands a0,a1,b0,b1 in v[0:47], results in v[48:71]. It computes c0 = a0 b0 + a1 (p - b1) and c1 = a0 b1 + a1 b0 as two
+// sum-of-two-products scans with one Montgomery reduction each: 864 multiply-accumulates and no modular additions, against
+// 900 + five modular additions + three calls for Karatsuba. The routine is reached by an s_swappc inside an asm statement,
+// so the 32-VGPR argument limit of the regular calling convention does not apply; the statement's clobber list is the contract.
+extern "C" __device__ __attribute__((noinline, used)) void mbls_fp2_mul_asm_fn() {
+    asm volatile(MBLS_FP2_MUL_ASM);
+}
+MBLS_FN fp2 fp2_mul(const fp2& a, const fp2& b) {
+    fp c0, c1;
+    asm volatile("s_getpc_b64 s[40:41]\n\t"
+                 "s_add_u32 s40, s40, mbls_fp2_mul_asm_fn@rel32@lo+4\n\t"
+                 "s_addc_u32 s41, s41, mbls_fp2_mul_asm_fn@rel32@hi+12\n\t"
+                 "s_swappc_b64 s[30:31], s[40:41]"
+                 : "={v[48:59]}"(c0), "={v[60:71]}"(c1)
+                 : "{v[0:11]}"(a.c0), "{v[12:23]}"(a.c1), "{v[24:35]}"(b.c0), "{v[36:47]}"(b.c1)
+                 : MBLS_FP2_MUL_CLOBBERS, "s30", "s31");
+    fp2 r; r.c0 = c0; r.c1 = c1; return r;
+}
+#else
 MBLS_FN fp2 fp2_mul(const fp2& a, const fp2& b) {
     fp t0 = fp_mul(a.c0, b.c0), t1 = fp_mul(a.c1, b.c1);
     fp t2 = fp_mul(fp_add_nr(a.c0, a.c1), fp_add_nr(b.c0, b.c1));     // factors < 2p: see fp_add_nr
     fp2 r; r.c0 = fp_sub(t0, t1); r.c1 = fp_sub(fp_sub(t2, t0), t1); return r;
 }
+#endif
 MBLS_FN fp2 fp2_sqr(const fp2& a) {
     fp m = fp_mul(a.c0, a.c1);
     fp2 r; r.c0 = fp_mul(fp_add_nr(a.c0, a.c1), fp_sub_nr(a.c0, a.c1)); r.c1 = fp_dbl(m); return r;

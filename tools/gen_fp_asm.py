@@ -63,6 +63,65 @@ def body(square=False):
     return L
 
 
+def fp2_mul_body():
+    """c0 = a0 b0 - a1 b1, c1 = a0 b1 + a1 b0 as two sum-of-two-products scans with ONE Montgomery reduction each
+    (864 multiply-accumulates instead of 3 x 300 for Karatsuba, no modular additions besides the negation of b1).
+    Private calling convention (see fp2_mul in mbls_tower.h): a0 v[0:11], a1 v[12:23], b0 v[24:35], b1 v[36:47] (all preserved);
+    c0 -> v[48:59], c1 -> v[60:71]; scratch v72-v99."""
+    A0 = lambda i: "v%d" % i
+    A1 = lambda i: "v%d" % (12 + i)
+    B0 = lambda i: "v%d" % (24 + i)
+    B1 = lambda i: "v%d" % (36 + i)
+    C0 = lambda i: "v%d" % (48 + i)
+    C1 = lambda i: "v%d" % (60 + i)
+    NB = lambda i: "v%d" % (72 + i)       # p - b1
+    MM = lambda i: "v%d" % (84 + i)       # Montgomery quotients, then t - p
+    acc, lo, mid, hi = "v[96:97]", "v96", "v97", "v98"
+
+    def mac2(x, y):
+        return ["v_mad_u64_u32 %s, vcc, %s, %s, %s" % (acc, x, y, acc), "v_addc_co_u32_e32 %s, vcc, 0, %s, vcc" % (hi, hi)]
+    L = []
+    for i in range(12):
+        L.append("s_mov_b32 %s, 0x%08x" % (SP(i), PL[i]))
+    L.append("s_mov_b32 %s, 0x%08x" % (SNP, NP0))
+    # nb1 = p - b1 (b1 < p; b1 = 0 gives p, which is fine as a factor)
+    for i in range(12):
+        L.append("v_mov_b32_e32 %s, %s" % (MM(i), SP(i)))
+    L.append("v_sub_co_u32_e32 %s, vcc, %s, %s" % (NB(0), MM(0), B1(0)))
+    for i in range(1, 12):
+        L.append("v_subb_co_u32_e32 %s, vcc, %s, %s, vcc" % (NB(i), MM(i), B1(i)))
+
+    def scan(X0, Y0, X1, Y1, OUT):
+        S = ["v_mov_b32_e32 %s, 0" % lo, "v_mov_b32_e32 %s, 0" % mid, "v_mov_b32_e32 %s, 0" % hi]
+        for k in range(24):
+            for i in range(max(0, k - 11), min(k, 11) + 1):
+                S += mac2(X0(i), Y0(k - i))
+                S += mac2(X1(i), Y1(k - i))
+            if k < 12:
+                for i in range(0, k):
+                    S += mac2(SP(k - i), MM(i))
+                S.append("v_mul_lo_u32 %s, %s, %s" % (MM(k), SNP, lo))
+                S += mac2(SP(0), MM(k))
+                S += ["v_mov_b32_e32 %s, %s" % (lo, mid), "v_mov_b32_e32 %s, %s" % (mid, hi), "v_mov_b32_e32 %s, 0" % hi]
+            else:
+                for i in range(k - 11, 12):
+                    S += mac2(SP(k - i), MM(i))
+                S += ["v_mov_b32_e32 %s, %s" % (OUT(k - 12), lo), "v_mov_b32_e32 %s, %s" % (lo, mid), "v_mov_b32_e32 %s, %s" % (mid, hi),
+                      "v_mov_b32_e32 %s, 0" % hi]
+        # t < 1.2 p: one conditional subtraction (the 13th limb is always zero here); p goes through v99 limb by limb
+        S.append("v_mov_b32_e32 v99, %s" % SP(0))
+        S.append("v_sub_co_u32_e32 %s, vcc, %s, v99" % (MM(0), OUT(0)))
+        for i in range(1, 12):
+            S.append("v_mov_b32_e32 v99, %s" % SP(i))
+            S.append("v_subb_co_u32_e32 %s, vcc, %s, v99, vcc" % (MM(i), OUT(i)))
+        for i in range(12):
+            S.append("v_cndmask_b32_e32 %s, %s, %s, vcc" % (OUT(i), MM(i), OUT(i)))     # borrow ? t : t - p
+        return S
+    L += scan(A0, B0, A1, NB, C0)
+    L += scan(A0, B1, A1, B0, C1)
+    return L
+
+
 def emit(name, lines):
     out = ["#define %s \\" % name]
     for l in lines:
@@ -85,9 +144,12 @@ def main():
     txt += emit("MBLS_FP_MUL_ASM", body()) + "\n"
     txt += '#define MBLS_FP_MUL_CLOBBERS "v24","v25","v26","v27","v28","v29","v30","v31","v32","v33","v34","v35","v36","v37","v38", \\\n'
     txt += '    "s40","s41","s42","s43","s44","s45","s46","s47","s56","s57","s58","s59","s60","s62","s63","vcc","scc"\n'
+    txt += emit("MBLS_FP2_MUL_ASM", fp2_mul_body()) + "\n"
+    txt += '#define MBLS_FP2_MUL_CLOBBERS "v72","v73","v74","v75","v76","v77","v78","v79","v80","v81","v82","v83","v84","v85","v86","v87","v88","v89","v90", \\\n'
+    txt += '    "v91","v92","v93","v94","v95","v96","v97","v98","v99","s40","s41","s42","s43","s44","s45","s46","s47","s56","s57","s58","s59","s60","vcc","scc"\n'
     with open(path, "w") as f:
         f.write(txt)
-    print("wrote", path, "(%d instructions)" % len(body()))
+    print("wrote", path, "(%d + %d instructions)" % (len(body()), len(fp2_mul_body())))
 
 
 if __name__ == "__main__":
