@@ -12,12 +12,14 @@
 #include <stdint.h>
 
 #if defined(MBLS_HOST_EMUL)
+#define MBLS_LDS
 #define MBLS_FN static inline
 #define MBLS_NOINLINE static __attribute__((noinline))
 #define MBLS_CONST static const
 #define MBLS_DEVICE_ASM 0
 #else
 #include <hip/hip_runtime.h>
+#define MBLS_LDS __attribute__((address_space(3)))      // pointers into the workgroup's LDS (ds_* instructions, not flat)
 #define MBLS_FN static __device__ __forceinline__
 #define MBLS_NOINLINE static __device__ __noinline__
 #define MBLS_CONST static __device__ __constant__ const
@@ -207,7 +209,7 @@ MBLS_FN void mbls_acc_shift(mbls_acc& s) { s.lo = (s.lo >> 32) | ((uint64_t)s.hi
 #include "mbls_fp_asm.inc"
 // Hand-scheduled body (tools/gen_fp_asm.py): one asm statement, operands pinned to the registers the calling convention
 // already uses (a: v[0:11], b: v[12:23], result: v[0:11]); 288 v_mad_u64_u32 + 288 v_addc_co_u32, no compiler padding.
-MBLS_NOINLINE fp fp_mul(fp a, fp b) {
+__attribute__((aligned(64))) MBLS_NOINLINE fp fp_mul(fp a, fp b) {
     fp r;
     asm volatile(MBLS_FP_MUL_ASM : "={v[0:11]}"(r), "+{v[12:23]}"(b) : "{v[0:11]}"(a) : MBLS_FP_MUL_CLOBBERS);
     return r;

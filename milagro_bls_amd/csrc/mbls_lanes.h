@@ -116,7 +116,7 @@ MBLS_FN void lane_hash(const mbls_ws& ws, uint64_t i, const uint8_t* msg, uint32
     g2j h; hash_to_g2(&h, msg, mlen, MBLS_DST_POP, MBLS_DST_POP_LEN);
     ws_st2(ws, MBLS_SLOT_H, i, h.x); ws_st2(ws, MBLS_SLOT_H + 2, i, h.y); ws_st2(ws, MBLS_SLOT_H + 4, i, h.z);
 }
-MBLS_FN void lane_miller(const mbls_ws& ws, uint64_t i) {
+MBLS_FN void lane_miller(const mbls_ws& ws, uint64_t i, MBLS_LDS uint32_t* tstore = nullptr, uint32_t lane = 0) {
     mbls_pair pr[2];
     // pair 0: (sig, -G1)
     fp2 sx = ws_ld2(ws, MBLS_SLOT_SIG, i), sy = ws_ld2(ws, MBLS_SLOT_SIG + 2, i);
@@ -129,14 +129,15 @@ MBLS_FN void lane_miller(const mbls_ws& ws, uint64_t i) {
     pr[1].skip = g2_is_inf(&h) | g1_is_inf(&a);
     g2h_from_jacobian(&pr[1].q, &h); pr[1].t = pr[1].q;
     g1arg_from_jacobian(&pr[1].p, &a);
-    fp12 f; miller_loop(&f, pr, 2);
+    fp12 f;
+    if (tstore) miller_loop_verify_lds(&f, pr, tstore, lane); else miller_loop(&f, pr, 2);
     const fp2* c = &f.c0.c0;
     for (int s = 0; s < 6; s++) ws_st2(ws, MBLS_SLOT_F + 2 * s, i, c[s]);
 }
-MBLS_FN void lane_final(const mbls_ws& ws, uint64_t i, uint32_t* status, uint8_t* result) {
+MBLS_FN void lane_final(const mbls_ws& ws, uint64_t i, uint32_t* status, uint8_t* result, MBLS_LDS uint32_t* ls = nullptr, uint32_t lane = 0) {
     fp12 f; fp2* c = &f.c0.c0;
     for (int s = 0; s < 6; s++) c[s] = ws_ld2(ws, MBLS_SLOT_F + 2 * s, i);
-    final_exp(&f, &f);
+    final_exp(&f, &f, ls, lane);
     uint32_t st = *status;
     if (!fp12_is_one(&f)) st |= MBLS_ST_PAIRING_FAILED;
     *status = st;

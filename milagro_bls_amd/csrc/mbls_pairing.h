@@ -70,18 +70,53 @@ MBLS_TOWER_COLD_FN void miller_add_step(fp12* f, g2h* T, const mbls_pair* pr) {
 // f = prod_k f_{x,Q_k}(P_k) up to subfield factors; pairs[k].t must equal pairs[k].q on entry.
 // The loop-carried state (f and the running points T_k) is held in locals whose address never leaves this function
 // except through short-lived copies around the rare addition steps, so it can stay in VGPRs/AGPRs across iterations.
+// Optional LDS home for the running points T_k: element e of point k of lane l at tstore[(k*72 + e)*64 + l] (conflict-free:
+// consecutive lanes hit consecutive banks). Between doubling steps the points then occupy no registers, which leaves the
+// register file to f and the line evaluation; tstore == nullptr keeps them in locals.
+MBLS_FN void g2h_lds_load(g2h* T, const MBLS_LDS uint32_t* ts, int k, uint32_t lane) {
+    const MBLS_LDS uint32_t* p = ts + (uint32_t)k * 72 * 64 + lane;
+    fp* c = &T->x.c0;
+    for (int e = 0; e < 6; e++) {
+        fp v;
+#pragma unroll
+        for (int j = 0; j < 12; j++) v[j] = p[(e * 12 + j) * 64];
+        c[e] = v;
+    }
+}
+MBLS_FN void g2h_lds_store(MBLS_LDS uint32_t* ts, int k, uint32_t lane, const g2h* T) {
+    MBLS_LDS uint32_t* p = ts + (uint32_t)k * 72 * 64 + lane;
+    const fp* c = &T->x.c0;
+    for (int e = 0; e < 6; e++) {
+        fp v = c[e];
+#pragma unroll
+        for (int j = 0; j < 12; j++) p[(e * 12 + j) * 64] = v[j];
+    }
+}
 template <int NP, bool AFFINE0>
-MBLS_FN void miller_loop_n(fp12* f_out, mbls_pair* pairs) {
+MBLS_FN void miller_loop_n(fp12* f_out, mbls_pair* pairs, MBLS_LDS uint32_t* tstore, uint32_t lane) {
     fp12 f; fp12_set_one(&f);
     g2h T0 = pairs[0].t, T1 = pairs[NP - 1].t;
+    if (tstore) { g2h_lds_store(tstore, 0, lane, &T0); if (NP > 1) g2h_lds_store(tstore, 1, lane, &T1); }
     for (int i = 62; i >= 0; i--) {
         if (i != 62) fp12_sqr(&f, &f);
+        if (tstore) g2h_lds_load(&T0, tstore, 0, lane);
         miller_dbl_step<AFFINE0>(&f, &T0, &pairs[0]);
-        if (NP > 1) miller_dbl_step<false>(&f, &T1, &pairs[NP - 1]);
+        if (tstore) g2h_lds_store(tstore, 0, lane, &T0);
+        if (NP > 1) {
+            if (tstore) g2h_lds_load(&T1, tstore, 1, lane);
+            miller_dbl_step<false>(&f, &T1, &pairs[NP - 1]);
+            if (tstore) g2h_lds_store(tstore, 1, lane, &T1);
+        }
         if ((MBLS_X_ABS >> i) & 1) {
-            fp12 ft = f; g2h tt = T0;
-            miller_add_step(&ft, &tt, &pairs[0]); T0 = tt;
-            if (NP > 1) { tt = T1; miller_add_step(&ft, &tt, &pairs[NP - 1]); T1 = tt; }
+            fp12 ft = f; g2h tt;
+            if (tstore) g2h_lds_load(&tt, tstore, 0, lane); else tt = T0;
+            miller_add_step(&ft, &tt, &pairs[0]);
+            if (tstore) g2h_lds_store(tstore, 0, lane, &tt); else T0 = tt;
+            if (NP > 1) {
+                if (tstore) g2h_lds_load(&tt, tstore, 1, lane); else tt = T1;
+                miller_add_step(&ft, &tt, &pairs[NP - 1]);
+                if (tstore) g2h_lds_store(tstore, 1, lane, &tt); else T1 = tt;
+            }
             f = ft;
         }
     }
@@ -89,18 +124,22 @@ MBLS_FN void miller_loop_n(fp12* f_out, mbls_pair* pairs) {
 }
 // npairs = 2 is the verification shape: pair 0 = (signature, -G1) with an affine G1 argument, pair 1 = (H(msg), apk)
 MBLS_NOINLINE void miller_loop(fp12* f, mbls_pair* pairs, int npairs) {
-    if (npairs == 2) miller_loop_n<2, true>(f, pairs); else miller_loop_n<1, false>(f, pairs);
+    if (npairs == 2) miller_loop_n<2, true>(f, pairs, nullptr, 0); else miller_loop_n<1, false>(f, pairs, nullptr, 0);
+}
+// the verification shape with the running points in LDS (inlined into k_miller so that the LDS accesses are ds_* instructions)
+MBLS_FN void miller_loop_verify_lds(fp12* f, mbls_pair* pairs, MBLS_LDS uint32_t* tstore, uint32_t lane) {
+    miller_loop_n<2, true>(f, pairs, tstore, lane);
 }
 // f^(3 (p^12-1)/r). Hard part: 3 (p^4-p^2+1)/r = (x-1)^2 (x+p) (x^2+p^2-1) + 3 (Hayashida-Hayasaka-Teruya);
 // gcd(3, r) = 1, so comparing with 1 gives the same boolean as amcl's fexp (reference src/amcl_utils.rs:40-41).
-MBLS_NOINLINE void final_exp(fp12* r, const fp12* f) {
+MBLS_NOINLINE void final_exp(fp12* r, const fp12* f, MBLS_LDS uint32_t* ls = nullptr, uint32_t lane = 0) {
     fp12 t, u, a, b, c, m;
     fp12_conj(&t, f); fp12_inv(&u, f); fp12_mul(&t, &t, &u);              // f^(p^6-1)
     fp12_frob(&u, &t); fp12_frob(&u, &u); fp12_mul(&m, &u, &t);            // ^(p^2+1): now cyclotomic
-    fp12_cyc_exp_x(&a, &m); fp12_conj(&u, &m); fp12_mul(&a, &a, &u);       // m^(x-1)
-    fp12_cyc_exp_x(&t, &a); fp12_conj(&u, &a); fp12_mul(&a, &t, &u);       // m^((x-1)^2)
-    fp12_cyc_exp_x(&b, &a); fp12_frob(&u, &a); fp12_mul(&b, &b, &u);       // a^(x+p)
-    fp12_cyc_exp_x(&c, &b); fp12_cyc_exp_x(&c, &c);                        // b^(x^2)
+    fp12_cyc_exp_x(&a, &m, ls, lane); fp12_conj(&u, &m); fp12_mul(&a, &a, &u);       // m^(x-1)
+    fp12_cyc_exp_x(&t, &a, ls, lane); fp12_conj(&u, &a); fp12_mul(&a, &t, &u);       // m^((x-1)^2)
+    fp12_cyc_exp_x(&b, &a, ls, lane); fp12_frob(&u, &a); fp12_mul(&b, &b, &u);       // a^(x+p)
+    fp12_cyc_exp_x(&c, &b, ls, lane); fp12_cyc_exp_x(&c, &c, ls, lane);                        // b^(x^2)
     fp12_frob(&u, &b); fp12_frob(&u, &u); fp12_mul(&c, &c, &u);            // * b^(p^2)
     fp12_conj(&u, &b); fp12_mul(&c, &c, &u);                               // * b^-1
     fp12_cyc_sqr(&u, &m); fp12_mul(&u, &u, &m); fp12_mul(r, &c, &u);       // * m^3

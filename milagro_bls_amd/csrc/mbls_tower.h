@@ -29,7 +29,7 @@ MBLS_FN fp2 fp2_conj(const fp2& a) { fp2 r; r.c0 = a.c0; r.c1 = fp_neg(a.c1); re
 // sum-of-two-products scans with one Montgomery reduction each: 864 multiply-accumulates and no modular additions, against
 // 900 + five modular additions + three calls for Karatsuba. The routine is reached by an s_swappc inside an asm statement,
 // so the 32-VGPR argument limit of the regular calling convention does not apply; the statement's clobber list is the contract.
-extern "C" __device__ __attribute__((noinline, used)) void mbls_fp2_mul_asm_fn() {
+extern "C" __device__ __attribute__((noinline, used, aligned(64))) void mbls_fp2_mul_asm_fn() {
     asm volatile(MBLS_FP2_MUL_ASM);
 }
 MBLS_FN fp2 fp2_mul(const fp2& a, const fp2& b) {
@@ -206,12 +206,36 @@ MBLS_TOWER_FN void fp12_cyc_sqr(fp12* r, const fp12* f) {
     r->c0.c0 = z0; r->c0.c1 = z4; r->c0.c2 = z3; r->c1.c0 = z2; r->c1.c1 = z1; r->c1.c2 = z5;
 }
 // f^x, x = -0xd201000000010000, f in the cyclotomic subgroup
-MBLS_NOINLINE void fp12_cyc_exp_x(fp12* r, const fp12* f) {
+// An Fp12 parked in LDS between uses: coefficient dword e of lane l at ls[e*64 + l] (conflict-free across the wave).
+MBLS_FN void fp12_lds_load(fp12* a, const MBLS_LDS uint32_t* ls, uint32_t lane) {
+    fp* c = &a->c0.c0.c0;
+    for (int e = 0; e < 12; e++) {
+        fp v;
+#pragma unroll
+        for (int j = 0; j < 12; j++) v[j] = ls[(e * 12 + j) * 64 + lane];
+        c[e] = v;
+    }
+}
+MBLS_FN void fp12_lds_store(MBLS_LDS uint32_t* ls, uint32_t lane, const fp12* a) {
+    const fp* c = &a->c0.c0.c0;
+    for (int e = 0; e < 12; e++) {
+        fp v = c[e];
+#pragma unroll
+        for (int j = 0; j < 12; j++) ls[(e * 12 + j) * 64 + lane] = v[j];
+    }
+}
+// f^x, x = -0xd201000000010000, f in the cyclotomic subgroup. With ls != nullptr the running power lives in LDS between
+// squarings (it would otherwise pin 144 registers for 63 iterations while each squaring needs the register file itself).
+MBLS_NOINLINE void fp12_cyc_exp_x(fp12* r, const fp12* f, MBLS_LDS uint32_t* ls, uint32_t lane) {
     // acc never escapes (the 5 multiplications go through a short-lived copy), so the 63 squarings keep it in registers
     fp12 acc = *f;
+    if (ls) fp12_lds_store(ls, lane, &acc);
     for (int i = 62; i >= 0; i--) {
+        if (ls) fp12_lds_load(&acc, ls, lane);
         fp12_cyc_sqr(&acc, &acc);
         if ((MBLS_X_ABS >> i) & 1) { fp12 t = acc; fp12_mul(&t, &t, f); acc = t; }
+        if (ls) fp12_lds_store(ls, lane, &acc);
     }
+    if (ls) fp12_lds_load(&acc, ls, lane);
     fp12_conj(r, &acc);
 }
