@@ -209,6 +209,11 @@ MBLS_FN void mbls_acc_shift(mbls_acc& s) { s.lo = (s.lo >> 32) | ((uint64_t)s.hi
 #include "mbls_fp_asm.inc"
 // Hand-scheduled body (tools/gen_fp_asm.py): one asm statement, operands pinned to the registers the calling convention
 // already uses (a: v[0:11], b: v[12:23], result: v[0:11]); 288 v_mad_u64_u32 + 288 v_addc_co_u32, no compiler padding.
+// Private-convention routines (mbls_fp2_mul_asm_fn in mbls_tower.h) are ordinary device functions whose whole body is the asm
+// text, reached through an s_swappc inside an asm statement: the statement's constraints and clobbers are the contract.
+// (Entering 4 bytes past the symbol to skip hipcc's entry `s_waitcnt vmcnt(0)` was measured: no gain, not kept.)
+#define MBLS_ASM_CALL(sym) "s_getpc_b64 s[40:41]\n\ts_add_u32 s40, s40, " sym "@rel32@lo+4\n\ts_addc_u32 s41, s41, " sym "@rel32@hi+12\n\ts_swappc_b64 s[30:31], s[40:41]"
+// (fp_mul itself stays a regular function: routing its thousands of call sites through asm statements overwhelms hipcc.)
 __attribute__((aligned(64))) MBLS_NOINLINE fp fp_mul(fp a, fp b) {
     fp r;
     asm volatile(MBLS_FP_MUL_ASM : "={v[0:11]}"(r), "+{v[12:23]}"(b) : "{v[0:11]}"(a) : MBLS_FP_MUL_CLOBBERS);

@@ -34,10 +34,7 @@ extern "C" __device__ __attribute__((noinline, used, aligned(64))) void mbls_fp2
 }
 MBLS_FN fp2 fp2_mul(const fp2& a, const fp2& b) {
     fp c0, c1;
-    asm volatile("s_getpc_b64 s[40:41]\n\t"
-                 "s_add_u32 s40, s40, mbls_fp2_mul_asm_fn@rel32@lo+4\n\t"
-                 "s_addc_u32 s41, s41, mbls_fp2_mul_asm_fn@rel32@hi+12\n\t"
-                 "s_swappc_b64 s[30:31], s[40:41]"
+    asm volatile(MBLS_ASM_CALL("mbls_fp2_mul_asm_fn")
                  : "={v[48:59]}"(c0), "={v[60:71]}"(c1)
                  : "{v[0:11]}"(a.c0), "{v[12:23]}"(a.c1), "{v[24:35]}"(b.c0), "{v[36:47]}"(b.c1)
                  : MBLS_FP2_MUL_CLOBBERS, "s30", "s31");
