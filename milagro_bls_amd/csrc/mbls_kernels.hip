@@ -5,7 +5,9 @@
 // to fill 256 CUs x 4 SIMDs. The pipeline is split into phase kernels that hand their state over through a
 // limb-major struct-of-arrays workspace in HBM (mbls_lanes.h); each phase is thousands of Fp
 // multiplications per lane, so the hand-over traffic (<= 1.2 KB per item per phase) and the launch gaps are
-// noise. No MFMA, no LDS tiling: there is no data reuse across lanes to tile for.
+// noise. No MFMA (carry-chain integer work). LDS is not used for tiling (no data is shared between lanes) but as the
+// home of each lane's loop-carried state in k_miller / k_final (36 KB per wave, lane-interleaved so that a wave's access is
+// conflict-free), which keeps that state out of the register file between uses and off the HBM-backed stack.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <string.h>
