@@ -47,10 +47,25 @@ MBLS_FN fp2 fp2_mul(const fp2& a, const fp2& b) {
     fp2 r; r.c0 = fp_sub(t0, t1); r.c1 = fp_sub(fp_sub(t2, t0), t1); return r;
 }
 #endif
+#if MBLS_DEVICE_ASM && !defined(MBLS_NO_FP2_ASM)
+// Fp2 squaring, same private-convention scheme: c0 = (a0+a1)(a0-a1+p), c1 = a0 (2 a1) on unreduced operands, two scans.
+extern "C" __device__ __attribute__((noinline, used, aligned(64))) void mbls_fp2_sqr_asm_fn() {
+    asm volatile(MBLS_FP2_SQR_ASM);
+}
+MBLS_FN fp2 fp2_sqr(const fp2& a) {
+    fp c0, c1;
+    asm volatile(MBLS_ASM_CALL("mbls_fp2_sqr_asm_fn")
+                 : "={v[24:35]}"(c0), "={v[36:47]}"(c1)
+                 : "{v[0:11]}"(a.c0), "{v[12:23]}"(a.c1)
+                 : MBLS_FP2_SQR_CLOBBERS, "s30", "s31");
+    fp2 r; r.c0 = c0; r.c1 = c1; return r;
+}
+#else
 MBLS_FN fp2 fp2_sqr(const fp2& a) {
     fp m = fp_mul(a.c0, a.c1);
     fp2 r; r.c0 = fp_mul(fp_add_nr(a.c0, a.c1), fp_sub_nr(a.c0, a.c1)); r.c1 = fp_dbl(m); return r;
 }
+#endif
 MBLS_FN fp2 fp2_mul_fp(const fp2& a, fp k) { fp2 r; r.c0 = fp_mul(a.c0, k); r.c1 = fp_mul(a.c1, k); return r; }
 MBLS_FN fp2 fp2_mul_xi(const fp2& a) { fp2 r; r.c0 = fp_sub(a.c0, a.c1); r.c1 = fp_add(a.c0, a.c1); return r; }
 MBLS_FN fp2 fp2_mul_i(const fp2& a) { fp2 r; r.c0 = fp_neg(a.c1); r.c1 = a.c0; return r; }

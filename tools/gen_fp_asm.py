@@ -122,6 +122,70 @@ def fp2_mul_body():
     return L
 
 
+def fp2_sqr_body():
+    """c0 = (a0 + a1)(a0 - a1 + p), c1 = a0 (2 a1): two single-product scans on unreduced operands (all < 2p, so the product
+    is < 1.41 p after reduction and one conditional subtraction finishes it); 600 multiply-accumulates, no modular additions.
+    Private convention: a0 v[0:11], a1 v[12:23] (preserved); c0 -> v[24:35], c1 -> v[36:47]; scratch v48-v99."""
+    A0 = lambda i: "v%d" % i
+    A1 = lambda i: "v%d" % (12 + i)
+    C0 = lambda i: "v%d" % (24 + i)
+    C1 = lambda i: "v%d" % (36 + i)
+    S = lambda i: "v%d" % (48 + i)
+    D = lambda i: "v%d" % (60 + i)
+    A1D = lambda i: "v%d" % (72 + i)
+    MM = lambda i: "v%d" % (84 + i)
+    acc, lo, mid, hi = "v[96:97]", "v96", "v97", "v98"
+
+    def mac2(x, y):
+        return ["v_mad_u64_u32 %s, vcc, %s, %s, %s" % (acc, x, y, acc), "v_addc_co_u32_e32 %s, vcc, 0, %s, vcc" % (hi, hi)]
+    L = []
+    for i in range(12):
+        L.append("s_mov_b32 %s, 0x%08x" % (SP(i), PL[i]))
+    L.append("s_mov_b32 %s, 0x%08x" % (SNP, NP0))
+    L.append("v_add_co_u32_e32 %s, vcc, %s, %s" % (S(0), A0(0), A1(0)))
+    for i in range(1, 12):
+        L.append("v_addc_co_u32_e32 %s, vcc, %s, %s, vcc" % (S(i), A0(i), A1(i)))
+    for i in range(12):
+        L.append("v_mov_b32_e32 %s, %s" % (MM(i), SP(i)))
+    L.append("v_add_co_u32_e32 %s, vcc, %s, %s" % (D(0), A0(0), MM(0)))
+    for i in range(1, 12):
+        L.append("v_addc_co_u32_e32 %s, vcc, %s, %s, vcc" % (D(i), A0(i), MM(i)))
+    L.append("v_sub_co_u32_e32 %s, vcc, %s, %s" % (D(0), D(0), A1(0)))
+    for i in range(1, 12):
+        L.append("v_subb_co_u32_e32 %s, vcc, %s, %s, vcc" % (D(i), D(i), A1(i)))
+    L.append("v_lshlrev_b32_e32 %s, 1, %s" % (A1D(0), A1(0)))
+    for i in range(1, 12):
+        L.append("v_alignbit_b32 %s, %s, %s, 31" % (A1D(i), A1(i), A1(i - 1)))
+
+    def scan(X, Y, OUT):
+        Sx = ["v_mov_b32_e32 %s, 0" % lo, "v_mov_b32_e32 %s, 0" % mid, "v_mov_b32_e32 %s, 0" % hi]
+        for k in range(24):
+            for i in range(max(0, k - 11), min(k, 11) + 1):
+                Sx += mac2(X(i), Y(k - i))
+            if k < 12:
+                for i in range(0, k):
+                    Sx += mac2(SP(k - i), MM(i))
+                Sx.append("v_mul_lo_u32 %s, %s, %s" % (MM(k), SNP, lo))
+                Sx += mac2(SP(0), MM(k))
+                Sx += ["v_mov_b32_e32 %s, %s" % (lo, mid), "v_mov_b32_e32 %s, %s" % (mid, hi), "v_mov_b32_e32 %s, 0" % hi]
+            else:
+                for i in range(k - 11, 12):
+                    Sx += mac2(SP(k - i), MM(i))
+                Sx += ["v_mov_b32_e32 %s, %s" % (OUT(k - 12), lo), "v_mov_b32_e32 %s, %s" % (lo, mid), "v_mov_b32_e32 %s, %s" % (mid, hi),
+                       "v_mov_b32_e32 %s, 0" % hi]
+        Sx.append("v_mov_b32_e32 v99, %s" % SP(0))
+        Sx.append("v_sub_co_u32_e32 %s, vcc, %s, v99" % (MM(0), OUT(0)))
+        for i in range(1, 12):
+            Sx.append("v_mov_b32_e32 v99, %s" % SP(i))
+            Sx.append("v_subb_co_u32_e32 %s, vcc, %s, v99, vcc" % (MM(i), OUT(i)))
+        for i in range(12):
+            Sx.append("v_cndmask_b32_e32 %s, %s, %s, vcc" % (OUT(i), MM(i), OUT(i)))
+        return Sx
+    L += scan(S, D, C0)
+    L += scan(A0, A1D, C1)
+    return L
+
+
 def emit(name, lines):
     out = ["#define %s \\" % name]
     for l in lines:
@@ -147,9 +211,12 @@ def main():
     txt += emit("MBLS_FP2_MUL_ASM", fp2_mul_body()) + "\n"
     txt += '#define MBLS_FP2_MUL_CLOBBERS "v72","v73","v74","v75","v76","v77","v78","v79","v80","v81","v82","v83","v84","v85","v86","v87","v88","v89","v90", \\\n'
     txt += '    "v91","v92","v93","v94","v95","v96","v97","v98","v99","s40","s41","s42","s43","s44","s45","s46","s47","s56","s57","s58","s59","s60","vcc","scc"\n'
+    txt += emit("MBLS_FP2_SQR_ASM", fp2_sqr_body()) + "\n"
+    txt += '#define MBLS_FP2_SQR_CLOBBERS "v48","v49","v50","v51","v52","v53","v54","v55","v56","v57","v58","v59","v60","v61","v62","v63","v64","v65","v66","v67", \\\n'
+    txt += '    "v68","v69","v70","v71", MBLS_FP2_MUL_CLOBBERS\n'
     with open(path, "w") as f:
         f.write(txt)
-    print("wrote", path, "(%d + %d instructions)" % (len(body()), len(fp2_mul_body())))
+    print("wrote", path, "(%d + %d + %d instructions)" % (len(body()), len(fp2_mul_body()), len(fp2_sqr_body())))
 
 
 if __name__ == "__main__":
