@@ -7,15 +7,30 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmbls_hip.so")
 SOURCES = ["mbls_kernels.hip", "mbls_kernels_w2.hip"]
-DEPS = ["mbls_fp.h", "mbls_fp_asm.inc", "mbls_tower.h", "mbls_curve.h", "mbls_hash.h", "mbls_pairing.h", "mbls_lanes.h", "mbls_ops.h",
+DEPS = ["mbls_fp.h", "mbls_fp_asm.inc", "mbls_tower_asm.inc", "mbls_tower.h", "mbls_curve.h", "mbls_hash.h", "mbls_pairing.h", "mbls_lanes.h", "mbls_ops.h",
         "mbls_constants.inc", os.path.join("..", "..", "include", "mbls.h")]
 
 
+STAMP = LIB + ".srchash"
+
+
+def source_hash():
+    """content hash of everything the library is built from (file times do not survive the copy to the GPU box)"""
+    import hashlib
+    h = hashlib.sha256(os.environ.get("MBLS_EXTRA_HIPCC_FLAGS", "").encode())
+    for f in SOURCES + DEPS:
+        with open(os.path.join(CSRC, f), "rb") as fh:
+            h.update(f.encode() + b"\0" + fh.read())
+    return h.hexdigest()
+
+
 def needs_build():
-    if not os.path.exists(LIB):
+    if not os.path.exists(LIB) or not os.path.exists(STAMP):
         return True
-    t = os.path.getmtime(LIB)
-    return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in SOURCES + DEPS)
+    if os.environ.get("MBLS_TRUST_PREBUILT") == "1":
+        return False
+    with open(STAMP) as fh:
+        return fh.read().strip() != source_hash()
 
 
 def build(force=False, verbose=False):
@@ -39,6 +54,8 @@ def build(force=False, verbose=False):
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
     os.replace(LIB + ".tmp", LIB)
+    with open(STAMP, "w") as fh:
+        fh.write(source_hash() + "\n")
     for o in objs:
         os.remove(o)
     return LIB

@@ -65,7 +65,7 @@ __global__ void MBLS_LB MBLS_KSUF(k_miller)(mbls_ws ws, uint64_t n) {
     // one wave per SIMD = 4 waves per CU: each wave can park 36 KB of loop state in LDS (144 of the 160 KB)
     __shared__ uint32_t tstore[2 * 72 * 64];      // the two running points of each lane
     uint64_t i = gid(); if (i >= n) return;
-    lane_miller(ws, i, (MBLS_LDS uint32_t*)tstore, threadIdx.x);
+    lane_miller(ws, i, (MBLS_LDS uint32_t*)tstore, threadIdx.x, true);
 #else
     uint64_t i = gid(); if (i >= n) return;
     lane_miller(ws, i);
@@ -75,7 +75,7 @@ __global__ void MBLS_LB MBLS_KSUF(k_final)(mbls_ws ws, uint32_t* status, uint8_t
 #if MBLS_WAVES_PER_SIMD == 1 && !defined(MBLS_NO_LDS_STATE)
     __shared__ uint32_t accstore[144 * 64];       // the running power of the cyclotomic exponentiations
     uint64_t i = gid(); if (i >= n) return;
-    uint32_t st = status[i]; uint8_t r; lane_final(ws, i, &st, &r, (MBLS_LDS uint32_t*)accstore, threadIdx.x); status[i] = st; results[i] = r;
+    uint32_t st = status[i]; uint8_t r; lane_final(ws, i, &st, &r, (MBLS_LDS uint32_t*)accstore, threadIdx.x, true); status[i] = st; results[i] = r;
 #else
     uint64_t i = gid(); if (i >= n) return;
     uint32_t st = status[i]; uint8_t r; lane_final(ws, i, &st, &r); status[i] = st; results[i] = r;

@@ -116,7 +116,9 @@ MBLS_FN void lane_hash(const mbls_ws& ws, uint64_t i, const uint8_t* msg, uint32
     g2j h; hash_to_g2(&h, msg, mlen, MBLS_DST_POP, MBLS_DST_POP_LEN);
     ws_st2(ws, MBLS_SLOT_H, i, h.x); ws_st2(ws, MBLS_SLOT_H + 2, i, h.y); ws_st2(ws, MBLS_SLOT_H + 4, i, h.z);
 }
-MBLS_FN void lane_miller(const mbls_ws& ws, uint64_t i, MBLS_LDS uint32_t* tstore = nullptr, uint32_t lane = 0) {
+// use_lds: the kernel provides an LDS home for the running points (an explicit flag: a __shared__ array may sit at LDS
+// address 0, so the pointer itself cannot say whether it is there)
+MBLS_FN void lane_miller(const mbls_ws& ws, uint64_t i, MBLS_LDS uint32_t* tstore = nullptr, uint32_t lane = 0, bool use_lds = false) {
     mbls_pair pr[2];
     // pair 0: (sig, -G1)
     fp2 sx = ws_ld2(ws, MBLS_SLOT_SIG, i), sy = ws_ld2(ws, MBLS_SLOT_SIG + 2, i);
@@ -130,14 +132,14 @@ MBLS_FN void lane_miller(const mbls_ws& ws, uint64_t i, MBLS_LDS uint32_t* tstor
     g2h_from_jacobian(&pr[1].q, &h); pr[1].t = pr[1].q;
     g1arg_from_jacobian(&pr[1].p, &a);
     fp12 f;
-    if (tstore) miller_loop_verify_lds(&f, pr, tstore, lane); else miller_loop(&f, pr, 2);
+    if (use_lds) miller_loop_verify_lds(&f, pr, tstore, lane); else miller_loop(&f, pr, 2);
     const fp2* c = &f.c0.c0;
     for (int s = 0; s < 6; s++) ws_st2(ws, MBLS_SLOT_F + 2 * s, i, c[s]);
 }
-MBLS_FN void lane_final(const mbls_ws& ws, uint64_t i, uint32_t* status, uint8_t* result, MBLS_LDS uint32_t* ls = nullptr, uint32_t lane = 0) {
+MBLS_FN void lane_final(const mbls_ws& ws, uint64_t i, uint32_t* status, uint8_t* result, MBLS_LDS uint32_t* ls = nullptr, uint32_t lane = 0, bool use_lds = false) {
     fp12 f; fp2* c = &f.c0.c0;
     for (int s = 0; s < 6; s++) c[s] = ws_ld2(ws, MBLS_SLOT_F + 2 * s, i);
-    final_exp(&f, &f, ls, lane);
+    final_exp(&f, &f, ls, lane, use_lds);
     uint32_t st = *status;
     if (!fp12_is_one(&f)) st |= MBLS_ST_PAIRING_FAILED;
     *status = st;

@@ -93,29 +93,29 @@ MBLS_FN void g2h_lds_store(MBLS_LDS uint32_t* ts, int k, uint32_t lane, const g2
     }
 }
 template <int NP, bool AFFINE0>
-MBLS_FN void miller_loop_n(fp12* f_out, mbls_pair* pairs, MBLS_LDS uint32_t* tstore, uint32_t lane) {
+MBLS_FN void miller_loop_n(fp12* f_out, mbls_pair* pairs, MBLS_LDS uint32_t* tstore, uint32_t lane, bool use_lds) {
     fp12 f; fp12_set_one(&f);
     g2h T0 = pairs[0].t, T1 = pairs[NP - 1].t;
-    if (tstore) { g2h_lds_store(tstore, 0, lane, &T0); if (NP > 1) g2h_lds_store(tstore, 1, lane, &T1); }
+    if (use_lds) { g2h_lds_store(tstore, 0, lane, &T0); if (NP > 1) g2h_lds_store(tstore, 1, lane, &T1); }
     for (int i = 62; i >= 0; i--) {
         if (i != 62) fp12_sqr(&f, &f);
-        if (tstore) g2h_lds_load(&T0, tstore, 0, lane);
+        if (use_lds) g2h_lds_load(&T0, tstore, 0, lane);
         miller_dbl_step<AFFINE0>(&f, &T0, &pairs[0]);
-        if (tstore) g2h_lds_store(tstore, 0, lane, &T0);
+        if (use_lds) g2h_lds_store(tstore, 0, lane, &T0);
         if (NP > 1) {
-            if (tstore) g2h_lds_load(&T1, tstore, 1, lane);
+            if (use_lds) g2h_lds_load(&T1, tstore, 1, lane);
             miller_dbl_step<false>(&f, &T1, &pairs[NP - 1]);
-            if (tstore) g2h_lds_store(tstore, 1, lane, &T1);
+            if (use_lds) g2h_lds_store(tstore, 1, lane, &T1);
         }
         if ((MBLS_X_ABS >> i) & 1) {
             fp12 ft = f; g2h tt;
-            if (tstore) g2h_lds_load(&tt, tstore, 0, lane); else tt = T0;
+            if (use_lds) g2h_lds_load(&tt, tstore, 0, lane); else tt = T0;
             miller_add_step(&ft, &tt, &pairs[0]);
-            if (tstore) g2h_lds_store(tstore, 0, lane, &tt); else T0 = tt;
+            if (use_lds) g2h_lds_store(tstore, 0, lane, &tt); else T0 = tt;
             if (NP > 1) {
-                if (tstore) g2h_lds_load(&tt, tstore, 1, lane); else tt = T1;
+                if (use_lds) g2h_lds_load(&tt, tstore, 1, lane); else tt = T1;
                 miller_add_step(&ft, &tt, &pairs[NP - 1]);
-                if (tstore) g2h_lds_store(tstore, 1, lane, &tt); else T1 = tt;
+                if (use_lds) g2h_lds_store(tstore, 1, lane, &tt); else T1 = tt;
             }
             f = ft;
         }
@@ -124,22 +124,66 @@ MBLS_FN void miller_loop_n(fp12* f_out, mbls_pair* pairs, MBLS_LDS uint32_t* tst
 }
 // npairs = 2 is the verification shape: pair 0 = (signature, -G1) with an affine G1 argument, pair 1 = (H(msg), apk)
 MBLS_NOINLINE void miller_loop(fp12* f, mbls_pair* pairs, int npairs) {
-    if (npairs == 2) miller_loop_n<2, true>(f, pairs, nullptr, 0); else miller_loop_n<1, false>(f, pairs, nullptr, 0);
+    if (npairs == 2) miller_loop_n<2, true>(f, pairs, nullptr, 0, false); else miller_loop_n<1, false>(f, pairs, nullptr, 0, false);
 }
 // the verification shape with the running points in LDS (inlined into k_miller so that the LDS accesses are ds_* instructions)
-MBLS_FN void miller_loop_verify_lds(fp12* f, mbls_pair* pairs, MBLS_LDS uint32_t* tstore, uint32_t lane) {
-    miller_loop_n<2, true>(f, pairs, tstore, lane);
+#if MBLS_DEVICE_ASM && !defined(MBLS_NO_FP2_ASM)
+// Doubling iterations as one generated straight-line routine (tools/gen_tower_asm.py, prog_miller_dbl): f^2 and both
+// doubling steps with explicit VGPR/AGPR placement, interleaved carry chains and no scratch memory. It is specific to the
+// verification shape: pair 0's G1 argument is the constant -G1 (folded into the code), pair 1's arrives as (-px, py, pz^3).
+extern "C" __device__ __attribute__((noinline, used, aligned(64))) void mbls_fp2_mulfp_asm_fn() {
+    asm volatile(MBLS_FP2_MULFP_ASM);
 }
+extern "C" __device__ __attribute__((noinline, used, aligned(64))) void mbls_miller_dbl_asm_fn() {
+    asm volatile(MBLS_MILLER_DBL_ASM);
+}
+MBLS_FN void miller_dbl_n_asm(fp12* f, fp npx1, fp py1, fp pz3, uint32_t flags, MBLS_LDS uint32_t* ts, uint32_t lane, uint32_t n) {
+    uint32_t addr = (uint32_t)(uintptr_t)(ts + lane);
+    fp* c = &f->c0.c0.c0;
+    fp f0 = c[0], f1 = c[1], f2 = c[2], f3 = c[3], f4 = c[4], f5 = c[5], f6 = c[6], f7 = c[7], f8 = c[8], f9 = c[9], f10 = c[10], f11 = c[11];
+    fp d0 = npx1, d1 = py1, d2 = pz3;      // the operand registers are overwritten by the routine
+    asm volatile(MBLS_ASM_CALL("mbls_miller_dbl_asm_fn")
+                 : "+{v[96:107]}"(f0), "+{v[108:119]}"(f1), "+{v[120:131]}"(f2), "+{v[132:143]}"(f3), "+{v[144:155]}"(f4), "+{v[156:167]}"(f5),
+                   "+{v[168:179]}"(f6), "+{v[180:191]}"(f7), "+{v[192:203]}"(f8), "+{v[204:215]}"(f9), "+{v[216:227]}"(f10), "+{v[228:239]}"(f11),
+                   "+{v[0:11]}"(d0), "+{v[12:23]}"(d1), "+{v[24:35]}"(d2)
+                 : "{v252}"(addr), "{v253}"(flags), "{s38}"(n)
+                 : MBLS_MILLER_ASM_CLOBBERS);
+    c[0] = f0; c[1] = f1; c[2] = f2; c[3] = f3; c[4] = f4; c[5] = f5; c[6] = f6; c[7] = f7; c[8] = f8; c[9] = f9; c[10] = f10; c[11] = f11;
+}
+MBLS_FN void miller_loop_verify_lds(fp12* f_out, mbls_pair* pairs, MBLS_LDS uint32_t* tstore, uint32_t lane) {
+    fp12 f; fp12_set_one(&f);
+    g2h_lds_store(tstore, 0, lane, &pairs[0].t); g2h_lds_store(tstore, 1, lane, &pairs[1].t);
+    const fp npx1 = fp_neg(pairs[1].p.px), py1 = pairs[1].p.py, pz3 = pairs[1].p.pz3;
+    const uint32_t flags = (pairs[0].skip ? 1u : 0u) | (pairs[1].skip ? 2u : 0u);
+    int i = 62;
+    while (i >= 0) {
+        int j = i;                                       // doubling iterations for bits i..j, j = next set bit of |x| (or 0)
+        while (j > 0 && !((MBLS_X_ABS >> j) & 1)) j--;
+        miller_dbl_n_asm(&f, npx1, py1, pz3, flags, tstore, lane, (uint32_t)(i - j + 1));
+        if ((MBLS_X_ABS >> j) & 1) {
+            g2h tt;
+            g2h_lds_load(&tt, tstore, 0, lane); miller_add_step(&f, &tt, &pairs[0]); g2h_lds_store(tstore, 0, lane, &tt);
+            g2h_lds_load(&tt, tstore, 1, lane); miller_add_step(&f, &tt, &pairs[1]); g2h_lds_store(tstore, 1, lane, &tt);
+        }
+        i = j - 1;
+    }
+    fp12_conj(f_out, &f);
+}
+#else
+MBLS_FN void miller_loop_verify_lds(fp12* f, mbls_pair* pairs, MBLS_LDS uint32_t* tstore, uint32_t lane) {
+    miller_loop_n<2, true>(f, pairs, tstore, lane, true);
+}
+#endif
 // f^(3 (p^12-1)/r). Hard part: 3 (p^4-p^2+1)/r = (x-1)^2 (x+p) (x^2+p^2-1) + 3 (Hayashida-Hayasaka-Teruya);
 // gcd(3, r) = 1, so comparing with 1 gives the same boolean as amcl's fexp (reference src/amcl_utils.rs:40-41).
-MBLS_NOINLINE void final_exp(fp12* r, const fp12* f, MBLS_LDS uint32_t* ls = nullptr, uint32_t lane = 0) {
+MBLS_NOINLINE void final_exp(fp12* r, const fp12* f, MBLS_LDS uint32_t* ls = nullptr, uint32_t lane = 0, bool use_lds = false) {
     fp12 t, u, a, b, c, m;
     fp12_conj(&t, f); fp12_inv(&u, f); fp12_mul(&t, &t, &u);              // f^(p^6-1)
     fp12_frob(&u, &t); fp12_frob(&u, &u); fp12_mul(&m, &u, &t);            // ^(p^2+1): now cyclotomic
-    fp12_cyc_exp_x(&a, &m, ls, lane); fp12_conj(&u, &m); fp12_mul(&a, &a, &u);       // m^(x-1)
-    fp12_cyc_exp_x(&t, &a, ls, lane); fp12_conj(&u, &a); fp12_mul(&a, &t, &u);       // m^((x-1)^2)
-    fp12_cyc_exp_x(&b, &a, ls, lane); fp12_frob(&u, &a); fp12_mul(&b, &b, &u);       // a^(x+p)
-    fp12_cyc_exp_x(&c, &b, ls, lane); fp12_cyc_exp_x(&c, &c, ls, lane);                        // b^(x^2)
+    fp12_cyc_exp_x(&a, &m, ls, lane, use_lds); fp12_conj(&u, &m); fp12_mul(&a, &a, &u);       // m^(x-1)
+    fp12_cyc_exp_x(&t, &a, ls, lane, use_lds); fp12_conj(&u, &a); fp12_mul(&a, &t, &u);       // m^((x-1)^2)
+    fp12_cyc_exp_x(&b, &a, ls, lane, use_lds); fp12_frob(&u, &a); fp12_mul(&b, &b, &u);       // a^(x+p)
+    fp12_cyc_exp_x(&c, &b, ls, lane, use_lds); fp12_cyc_exp_x(&c, &c, ls, lane, use_lds);                        // b^(x^2)
     fp12_frob(&u, &b); fp12_frob(&u, &u); fp12_mul(&c, &c, &u);            // * b^(p^2)
     fp12_conj(&u, &b); fp12_mul(&c, &c, &u);                               // * b^-1
     fp12_cyc_sqr(&u, &m); fp12_mul(&u, &u, &m); fp12_mul(r, &c, &u);       // * m^3

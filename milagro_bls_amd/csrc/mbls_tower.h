@@ -236,18 +236,47 @@ MBLS_FN void fp12_lds_store(MBLS_LDS uint32_t* ls, uint32_t lane, const fp12* a)
         for (int j = 0; j < 12; j++) ls[(e * 12 + j) * 64 + lane] = v[j];
     }
 }
-// f^x, x = -0xd201000000010000, f in the cyclotomic subgroup. With ls != nullptr the running power lives in LDS between
-// squarings (it would otherwise pin 144 registers for 63 iterations while each squaring needs the register file itself).
-MBLS_NOINLINE void fp12_cyc_exp_x(fp12* r, const fp12* f, MBLS_LDS uint32_t* ls, uint32_t lane) {
-    // acc never escapes (the 5 multiplications go through a short-lived copy), so the 63 squarings keep it in registers
+#if MBLS_DEVICE_ASM && !defined(MBLS_NO_FP2_ASM)
+// n >= 1 Granger-Scott squarings of the Fp12 parked in LDS, in place, as one generated straight-line routine
+// (tools/gen_tower_asm.py: explicit VGPR/AGPR placement, no scratch memory; the compiler-scheduled fp12_cyc_sqr spills and,
+// with one wave per SIMD, waits a full memory round trip for every reload).
+#include "mbls_tower_asm.inc"
+extern "C" __device__ __attribute__((noinline, used, aligned(64))) void mbls_cyc_sqr_asm_fn() {
+    asm volatile(MBLS_CYC_SQR_ASM);
+}
+MBLS_FN void fp12_cyc_sqr_n_lds(MBLS_LDS uint32_t* ls, uint32_t lane, uint32_t n) {
+    uint32_t addr = (uint32_t)(uintptr_t)(ls + lane);
+    asm volatile(MBLS_ASM_CALL("mbls_cyc_sqr_asm_fn") : "+{s38}"(n) : "{v252}"(addr) : MBLS_TOWER_ASM_CLOBBERS);
+}
+#else
+MBLS_FN void fp12_cyc_sqr_n_lds(MBLS_LDS uint32_t* ls, uint32_t lane, uint32_t n) {
+    fp12 acc; fp12_lds_load(&acc, ls, lane);
+    for (uint32_t i = 0; i < n; i++) fp12_cyc_sqr(&acc, &acc);
+    fp12_lds_store(ls, lane, &acc);
+}
+#endif
+// f^x, x = -0xd201000000010000, f in the cyclotomic subgroup. With ls != nullptr the running power lives in LDS (it would
+// otherwise pin 144 registers for 63 iterations while each squaring needs the register file itself) and is squared in place,
+// run by run between the 5 multiplications.
+MBLS_NOINLINE void fp12_cyc_exp_x(fp12* r, const fp12* f, MBLS_LDS uint32_t* ls, uint32_t lane, bool use_lds) {
     fp12 acc = *f;
-    if (ls) fp12_lds_store(ls, lane, &acc);
-    for (int i = 62; i >= 0; i--) {
-        if (ls) fp12_lds_load(&acc, ls, lane);
-        fp12_cyc_sqr(&acc, &acc);
-        if ((MBLS_X_ABS >> i) & 1) { fp12 t = acc; fp12_mul(&t, &t, f); acc = t; }
-        if (ls) fp12_lds_store(ls, lane, &acc);
+    if (use_lds) {
+        fp12_lds_store(ls, lane, &acc);
+        int i = 62;
+        while (i >= 0) {
+            int j = i;                                   // squarings for bits i..j, j = next set bit (or 0)
+            while (j > 0 && !((MBLS_X_ABS >> j) & 1)) j--;
+            fp12_cyc_sqr_n_lds(ls, lane, (uint32_t)(i - j + 1));
+            if ((MBLS_X_ABS >> j) & 1) { fp12 t; fp12_lds_load(&t, ls, lane); fp12_mul(&t, &t, f); fp12_lds_store(ls, lane, &t); }
+            i = j - 1;
+        }
+        fp12_lds_load(&acc, ls, lane);
+    } else {
+        // acc never escapes (the 5 multiplications go through a short-lived copy), so the 63 squarings keep it in registers
+        for (int i = 62; i >= 0; i--) {
+            fp12_cyc_sqr(&acc, &acc);
+            if ((MBLS_X_ABS >> i) & 1) { fp12 t = acc; fp12_mul(&t, &t, f); acc = t; }
+        }
     }
-    if (ls) fp12_lds_load(&acc, ls, lane);
     fp12_conj(r, &acc);
 }

@@ -1,0 +1,183 @@
+#!/usr/bin/env python3
+"""Single-lane interpreter for the small gfx950 instruction subset that tools/gen_fp_asm.py and tools/gen_tower_asm.py emit.
+
+Development/test infrastructure only (tests/test_asm_sim_cpu.py): it lets the generated routines be checked against the
+big-integer model on the CPU before they ever run on a GPU. One lane is simulated, so VCC and the SGPR-pair carry registers
+are single bits and an LDS address is just a key. Unknown instructions raise.
+"""
+import re
+
+M32 = 0xFFFFFFFF
+
+
+class Machine:
+    def __init__(self, routines=None):
+        self.v = [0] * 256
+        self.a = [0] * 256
+        self.s = {}
+        self.vcc = 0
+        self.lds = {}
+        self.mem = {}
+        self.routines = routines or {}
+        self.count = 0
+        self.calls = 0
+
+    # ---- operand helpers
+    def rd(self, tok):
+        tok = tok.strip()
+        if tok == "vcc":
+            return self.vcc
+        m = re.fullmatch(r"v(\d+)", tok)
+        if m:
+            return self.v[int(m.group(1))]
+        m = re.fullmatch(r"s(\d+)", tok)
+        if m:
+            return self.s[int(m.group(1))]
+        m = re.fullmatch(r"a(\d+)", tok)
+        if m:
+            return self.a[int(m.group(1))]
+        m = re.fullmatch(r"s\[(\d+):(\d+)\]", tok)
+        if m:
+            return self.s.get(("pair", int(m.group(1))), 0)
+        m = re.fullmatch(r"v\[(\d+):(\d+)\]", tok)
+        if m:
+            lo = int(m.group(1))
+            return self.v[lo] | (self.v[lo + 1] << 32)
+        if tok.startswith("0x"):
+            return int(tok, 16)
+        return int(tok) & M32
+
+    def wr_carry(self, tok, val):
+        tok = tok.strip()
+        if tok == "vcc":
+            self.vcc = val
+        else:
+            m = re.fullmatch(r"s\[(\d+):(\d+)\]", tok)
+            self.s[("pair", int(m.group(1)))] = val
+
+    def wr(self, tok, val):
+        tok = tok.strip()
+        m = re.fullmatch(r"v(\d+)", tok)
+        if m:
+            self.v[int(m.group(1))] = val & M32
+            return
+        m = re.fullmatch(r"a(\d+)", tok)
+        if m:
+            self.a[int(m.group(1))] = val & M32
+            return
+        m = re.fullmatch(r"s(\d+)", tok)
+        if m:
+            self.s[int(m.group(1))] = val & M32
+            return
+        m = re.fullmatch(r"v\[(\d+):(\d+)\]", tok)
+        if m:
+            lo = int(m.group(1))
+            assert lo % 2 == 0, "64-bit VGPR operands must be even-aligned: " + tok
+            self.v[lo] = val & M32
+            self.v[lo + 1] = (val >> 32) & M32
+            return
+        m = re.fullmatch(r"s\[(\d+):(\d+)\]", tok)
+        if m:
+            self.s[("pair", int(m.group(1)))] = val
+            return
+        raise ValueError("bad destination " + tok)
+
+    # ---- execution
+    def run(self, lines):
+        pending_call = None
+        for line in lines:
+            line = line.split("//")[0].strip()
+            if not line:
+                continue
+            self.count += 1
+            op, _, rest = line.partition(" ")
+            args = [x.strip() for x in self._split(rest)]
+            if op == "CALL":                      # pseudo-instruction of the generator: s_getpc/s_add/s_addc/s_swappc to a routine
+                self.calls += 1
+                self.run(self.routines[args[0]])
+            elif op in ("s_mov_b32",):
+                self.wr(args[0], self.rd(args[1]))
+            elif op == "s_mov_b64":
+                self.wr_carry(args[0], self.rd(args[1])) if args[0] == "vcc" else self.wr(args[0], self.rd(args[1]))
+            elif op in ("v_mov_b32_e32",):
+                self.wr(args[0], self.rd(args[1]))
+            elif op == "v_mov_b64_e32":
+                self.wr(args[0], self.rd(args[1]))
+            elif op in ("v_accvgpr_write_b32", "v_accvgpr_read_b32"):
+                self.wr(args[0], self.rd(args[1]))
+            elif op in ("v_add_co_u32_e32", "v_add_co_u32_e64"):
+                t = self.rd(args[2]) + self.rd(args[3])
+                self.wr(args[0], t); self.wr_carry(args[1], t >> 32)
+            elif op in ("v_addc_co_u32_e32", "v_addc_co_u32_e64"):
+                t = self.rd(args[2]) + self.rd(args[3]) + self.rd(args[4])
+                self.wr(args[0], t); self.wr_carry(args[1], t >> 32)
+            elif op in ("v_sub_co_u32_e32", "v_sub_co_u32_e64"):
+                t = self.rd(args[2]) - self.rd(args[3])
+                self.wr(args[0], t); self.wr_carry(args[1], 1 if t < 0 else 0)
+            elif op in ("v_subb_co_u32_e32", "v_subb_co_u32_e64"):
+                t = self.rd(args[2]) - self.rd(args[3]) - self.rd(args[4])
+                self.wr(args[0], t); self.wr_carry(args[1], 1 if t < 0 else 0)
+            elif op == "v_mad_u64_u32":
+                t = self.rd(args[2]) * self.rd(args[3]) + self.rd(args[4])
+                self.wr(args[0], t & 0xFFFFFFFFFFFFFFFF); self.wr_carry(args[1], t >> 64)
+            elif op == "v_mul_lo_u32":
+                self.wr(args[0], self.rd(args[1]) * self.rd(args[2]))
+            elif op in ("v_cndmask_b32_e32", "v_cndmask_b32_e64"):
+                self.wr(args[0], self.rd(args[2]) if self.rd(args[3]) else self.rd(args[1]))
+            elif op == "v_lshlrev_b32_e32":
+                self.wr(args[0], self.rd(args[2]) << self.rd(args[1]))
+            elif op == "v_alignbit_b32":
+                t = (self.rd(args[1]) << 32) | self.rd(args[2])
+                self.wr(args[0], t >> self.rd(args[3]))
+            elif op == "v_or_b32_e32":
+                self.wr(args[0], self.rd(args[1]) | self.rd(args[2]))
+            elif op == "v_cmp_eq_u32_e64":
+                self.wr_carry(args[0], 1 if self.rd(args[1]) == self.rd(args[2]) else 0)
+            elif op == "v_cmp_ne_u32_e64":
+                self.wr_carry(args[0], 1 if self.rd(args[1]) != self.rd(args[2]) else 0)
+            elif op == "s_not_b64":
+                self.wr_carry(args[0], 1 - self.rd(args[1]))
+            elif op == "s_or_b64":
+                self.wr_carry(args[0], self.rd(args[1]) | self.rd(args[2]))
+            elif op == "s_and_b64":
+                self.wr_carry(args[0], self.rd(args[1]) & self.rd(args[2]))
+            elif op == "ds_read2st64_b32":       # ds_read2st64_b32 v[d:d+1], vaddr offset0:x offset1:y
+                m = re.fullmatch(r"(v\[\d+:\d+\]|a\[\d+:\d+\]), (v\d+)(?: offset0:(\d+))?(?: offset1:(\d+))?", rest.strip())
+                dst, addr = m.group(1), self.rd(m.group(2))
+                o0, o1 = int(m.group(3) or 0), int(m.group(4) or 0)
+                lo = int(re.match(r"[va]\[(\d+)", dst).group(1))
+                bank = self.v if dst[0] == "v" else self.a
+                bank[lo] = self.lds[addr + o0 * 256]; bank[lo + 1] = self.lds[addr + o1 * 256]
+            elif op == "ds_write2st64_b32":      # ds_write2st64_b32 vaddr, vd0, vd1 offset0:x offset1:y
+                m = re.fullmatch(r"(v\d+), ([va]\d+), ([va]\d+)(?: offset0:(\d+))?(?: offset1:(\d+))?", rest.strip())
+                addr = self.rd(m.group(1))
+                o0, o1 = int(m.group(4) or 0), int(m.group(5) or 0)
+                self.lds[addr + o0 * 256] = self.rd(m.group(2)); self.lds[addr + o1 * 256] = self.rd(m.group(3))
+            elif op in ("s_waitcnt", "s_nop"):
+                pass
+            else:
+                raise NotImplementedError(line)
+
+    @staticmethod
+    def _split(rest):
+        out, depth, cur = [], 0, ""
+        for ch in rest:
+            if ch == "[":
+                depth += 1
+            if ch == "]":
+                depth -= 1
+            if ch == "," and depth == 0:
+                out.append(cur); cur = ""
+            else:
+                cur += ch
+        if cur.strip():
+            out.append(cur)
+        return out
+
+
+def limbs(x):
+    return [(x >> (32 * i)) & M32 for i in range(12)]
+
+
+def from_limbs(l):
+    return sum(int(w) << (32 * i) for i, w in enumerate(l))

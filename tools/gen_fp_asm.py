@@ -63,126 +63,144 @@ def body(square=False):
     return L
 
 
-def fp2_mul_body():
-    """c0 = a0 b0 - a1 b1, c1 = a0 b1 + a1 b0 as two sum-of-two-products scans with ONE Montgomery reduction each
-    (864 multiply-accumulates instead of 3 x 300 for Karatsuba, no modular additions besides the negation of b1).
-    Private calling convention (see fp2_mul in mbls_tower.h): a0 v[0:11], a1 v[12:23], b0 v[24:35], b1 v[36:47] (all preserved);
-    c0 -> v[48:59], c1 -> v[60:71]; scratch v72-v99."""
-    A0 = lambda i: "v%d" % i
-    A1 = lambda i: "v%d" % (12 + i)
-    B0 = lambda i: "v%d" % (24 + i)
-    B1 = lambda i: "v%d" % (36 + i)
-    C0 = lambda i: "v%d" % (48 + i)
-    C1 = lambda i: "v%d" % (60 + i)
-    NB = lambda i: "v%d" % (72 + i)       # p - b1
-    MM = lambda i: "v%d" % (84 + i)       # Montgomery quotients, then t - p
-    acc, lo, mid, hi = "v[96:97]", "v96", "v97", "v98"
+class Chain:
+    """One product-scanning Montgomery chain: sum of the listed operand products, one reduction, result (< 2p before the final
+    conditional subtraction) left in `out`. The Montgomery quotients live in the `out` registers too (m[j] is dead after column
+    j+11, out[j] is written in column j+12). The 96-bit column accumulator alternates between two aligned register pairs
+    r[0:1] / r[2:3] with the third word in the other pair's high register, so a column boundary costs one move (two when a
+    result limb is emitted) and the third word is initialised by the first carry of the column instead of a move."""
 
-    def mac2(x, y):
-        return ["v_mad_u64_u32 %s, vcc, %s, %s, %s" % (acc, x, y, acc), "v_addc_co_u32_e32 %s, vcc, 0, %s, vcc" % (hi, hi)]
-    L = []
-    for i in range(12):
-        L.append("s_mov_b32 %s, 0x%08x" % (SP(i), PL[i]))
-    L.append("s_mov_b32 %s, 0x%08x" % (SNP, NP0))
-    # nb1 = p - b1 (b1 < p; b1 = 0 gives p, which is fine as a factor)
-    for i in range(12):
-        L.append("v_mov_b32_e32 %s, %s" % (MM(i), SP(i)))
-    L.append("v_sub_co_u32_e32 %s, vcc, %s, %s" % (NB(0), MM(0), B1(0)))
-    for i in range(1, 12):
-        L.append("v_subb_co_u32_e32 %s, vcc, %s, %s, vcc" % (NB(i), MM(i), B1(i)))
+    def __init__(self, pairs, out, r, carry):
+        self.pairs, self.out, self.r, self.carry = pairs, out, r, carry
 
-    def scan(X0, Y0, X1, Y1, OUT):
-        S = ["v_mov_b32_e32 %s, 0" % lo, "v_mov_b32_e32 %s, 0" % mid, "v_mov_b32_e32 %s, 0" % hi]
-        for k in range(24):
+    def stream(self):
+        r, cy, out = self.r, self.carry, self.out
+        S = []
+        for k in range(23):
+            lo, mid = (r, r + 1) if k % 2 == 0 else (r + 2, r + 3)
+            hi = r + 3 if k % 2 == 0 else r + 1
+            nlo = r + 2 if k % 2 == 0 else r
+            acc = "v[%d:%d]" % (lo, mid)
+            macs = []
             for i in range(max(0, k - 11), min(k, 11) + 1):
-                S += mac2(X0(i), Y0(k - i))
-                S += mac2(X1(i), Y1(k - i))
+                for (X, Y) in self.pairs:
+                    macs.append((X(i), Y(k - i)))
             if k < 12:
                 for i in range(0, k):
-                    S += mac2(SP(k - i), MM(i))
-                S.append("v_mul_lo_u32 %s, %s, %s" % (MM(k), SNP, lo))
-                S += mac2(SP(0), MM(k))
-                S += ["v_mov_b32_e32 %s, %s" % (lo, mid), "v_mov_b32_e32 %s, %s" % (mid, hi), "v_mov_b32_e32 %s, 0" % hi]
+                    macs.append((SP(k - i), out(i)))
             else:
                 for i in range(k - 11, 12):
-                    S += mac2(SP(k - i), MM(i))
-                S += ["v_mov_b32_e32 %s, %s" % (OUT(k - 12), lo), "v_mov_b32_e32 %s, %s" % (lo, mid), "v_mov_b32_e32 %s, %s" % (mid, hi),
-                      "v_mov_b32_e32 %s, 0" % hi]
-        # t < 1.2 p: one conditional subtraction (the 13th limb is always zero here); p goes through v99 limb by limb
-        S.append("v_mov_b32_e32 v99, %s" % SP(0))
-        S.append("v_sub_co_u32_e32 %s, vcc, %s, v99" % (MM(0), OUT(0)))
-        for i in range(1, 12):
-            S.append("v_mov_b32_e32 v99, %s" % SP(i))
-            S.append("v_subb_co_u32_e32 %s, vcc, %s, v99, vcc" % (MM(i), OUT(i)))
-        for i in range(12):
-            S.append("v_cndmask_b32_e32 %s, %s, %s, vcc" % (OUT(i), MM(i), OUT(i)))     # borrow ? t : t - p
+                    macs.append((SP(k - i), out(i)))
+            first = True
+            for (x, y) in macs:
+                src2 = "0" if (k == 0 and first) else acc
+                S.append("v_mad_u64_u32 %s, %s, %s, %s, %s" % (acc, cy, x, y, src2))
+                S.append("v_addc_co_u32_e64 v%d, %s, 0, %s, %s" % (hi, cy, "0" if first else "v%d" % hi, cy))
+                first = False
+            if k < 12:
+                S.append("v_mul_lo_u32 %s, %s, v%d" % (out(k), SNP, lo))
+                S.append("v_mad_u64_u32 %s, %s, %s, %s, %s" % (acc, cy, SP(0), out(k), acc))
+                S.append("v_addc_co_u32_e64 v%d, %s, 0, v%d, %s" % (hi, cy, hi, cy))
+                S.append("v_mov_b32_e32 v%d, v%d" % (nlo, mid))
+            elif k < 22:
+                S.append("v_mov_b32_e32 %s, v%d" % (out(k - 12), lo))
+                S.append("v_mov_b32_e32 v%d, v%d" % (nlo, mid))
+            else:
+                # the result is < 2p < 2^384: the third word is zero, column 23 is the middle word
+                S.append("v_mov_b32_e32 %s, v%d" % (out(10), lo))
+                S.append("v_mov_b32_e32 %s, v%d" % (out(11), mid))
         return S
-    L += scan(A0, B0, A1, NB, C0)
-    L += scan(A0, B1, A1, B0, C1)
+
+
+def cond_sub(out, diff, tmp):
+    """out = out - p if that does not borrow (one conditional subtraction; p goes through a VGPR because an SGPR source next to
+    the VCC carry-in would be two constant-bus reads)"""
+    S = ["v_mov_b32_e32 %s, %s" % (tmp, SP(0)), "v_sub_co_u32_e32 %s, vcc, %s, %s" % (diff(0), out(0), tmp)]
+    for i in range(1, 12):
+        S.append("v_mov_b32_e32 %s, %s" % (tmp, SP(i)))
+        S.append("v_subb_co_u32_e32 %s, vcc, %s, %s, vcc" % (diff(i), out(i), tmp))
+    for i in range(12):
+        S.append("v_cndmask_b32_e32 %s, %s, %s, vcc" % (out(i), diff(i), out(i)))     # borrow ? t : t - p
+    return S
+
+
+def zip2(sa, sb):
+    assert len(sa) == len(sb)
+    L = []
+    for x, y in zip(sa, sb):
+        L += [x, y]
+    return L
+
+
+def load_modulus():
+    L = ["s_mov_b32 %s, 0x%08x" % (SP(i), PL[i]) for i in range(12)]
+    L.append("s_mov_b32 %s, 0x%08x" % (SNP, NP0))
+    return L
+
+
+CARRY_B = "s[62:63]"
+VR = lambda base: (lambda i: "v%d" % (base + i))
+
+
+def fp2_mul_body():
+    """c0 = a0 b0 + a1 (p - b1), c1 = a0 b1 + a1 b0 as two sum-of-two-products scans with ONE Montgomery reduction each
+    (864 multiply-accumulates instead of 3 x 300 for Karatsuba, no modular additions besides the negation of b1). The two
+    scans are independent and are interleaved instruction by instruction (carries in vcc and s[62:63]) so that a wave that is
+    alone on its SIMD always has an independent instruction to issue.
+    Private calling convention (see fp2_mul in mbls_tower.h): a0 v[0:11], a1 v[12:23], b0 v[24:35], b1 v[36:47] (all preserved);
+    c0 -> v[48:59], c1 -> v[60:71]; scratch v72-v92."""
+    A0, A1, B0, B1, C0, C1, NB = VR(0), VR(12), VR(24), VR(36), VR(48), VR(60), VR(72)
+    tmp = "v92"
+    L = load_modulus()
+    # nb1 = p - b1 (b1 < p; b1 = 0 gives p, which is fine as a factor)
+    L.append("v_mov_b32_e32 %s, %s" % (tmp, SP(0)))
+    L.append("v_sub_co_u32_e32 %s, vcc, %s, %s" % (NB(0), tmp, B1(0)))
+    for i in range(1, 12):
+        L.append("v_mov_b32_e32 %s, %s" % (tmp, SP(i)))
+        L.append("v_subb_co_u32_e32 %s, vcc, %s, %s, vcc" % (NB(i), tmp, B1(i)))
+    L += zip2(Chain([(A0, B0), (A1, NB)], C0, 84, "vcc").stream(), Chain([(A0, B1), (A1, B0)], C1, 88, CARRY_B).stream())
+    L += cond_sub(C0, NB, tmp)
+    L += cond_sub(C1, NB, tmp)
     return L
 
 
 def fp2_sqr_body():
     """c0 = (a0 + a1)(a0 - a1 + p), c1 = a0 (2 a1): two single-product scans on unreduced operands (all < 2p, so the product
-    is < 1.41 p after reduction and one conditional subtraction finishes it); 600 multiply-accumulates, no modular additions.
-    Private convention: a0 v[0:11], a1 v[12:23] (preserved); c0 -> v[24:35], c1 -> v[36:47]; scratch v48-v99."""
-    A0 = lambda i: "v%d" % i
-    A1 = lambda i: "v%d" % (12 + i)
-    C0 = lambda i: "v%d" % (24 + i)
-    C1 = lambda i: "v%d" % (36 + i)
-    S = lambda i: "v%d" % (48 + i)
-    D = lambda i: "v%d" % (60 + i)
-    A1D = lambda i: "v%d" % (72 + i)
-    MM = lambda i: "v%d" % (84 + i)
-    acc, lo, mid, hi = "v[96:97]", "v96", "v97", "v98"
-
-    def mac2(x, y):
-        return ["v_mad_u64_u32 %s, vcc, %s, %s, %s" % (acc, x, y, acc), "v_addc_co_u32_e32 %s, vcc, 0, %s, vcc" % (hi, hi)]
-    L = []
-    for i in range(12):
-        L.append("s_mov_b32 %s, 0x%08x" % (SP(i), PL[i]))
-    L.append("s_mov_b32 %s, 0x%08x" % (SNP, NP0))
+    is < 1.41 p after reduction and one conditional subtraction finishes it); 600 multiply-accumulates, no modular additions;
+    the two scans interleaved like in fp2_mul.
+    Private convention: a0 v[0:11], a1 v[12:23] (preserved); c0 -> v[24:35], c1 -> v[36:47]; scratch v48-v92."""
+    A0, A1, C0, C1, S, D, A1D = VR(0), VR(12), VR(24), VR(36), VR(48), VR(60), VR(72)
+    tmp = "v92"
+    L = load_modulus()
     L.append("v_add_co_u32_e32 %s, vcc, %s, %s" % (S(0), A0(0), A1(0)))
     for i in range(1, 12):
         L.append("v_addc_co_u32_e32 %s, vcc, %s, %s, vcc" % (S(i), A0(i), A1(i)))
-    for i in range(12):
-        L.append("v_mov_b32_e32 %s, %s" % (MM(i), SP(i)))
-    L.append("v_add_co_u32_e32 %s, vcc, %s, %s" % (D(0), A0(0), MM(0)))
+    L.append("v_mov_b32_e32 %s, %s" % (tmp, SP(0)))
+    L.append("v_add_co_u32_e32 %s, vcc, %s, %s" % (D(0), A0(0), tmp))
     for i in range(1, 12):
-        L.append("v_addc_co_u32_e32 %s, vcc, %s, %s, vcc" % (D(i), A0(i), MM(i)))
+        L.append("v_mov_b32_e32 %s, %s" % (tmp, SP(i)))
+        L.append("v_addc_co_u32_e32 %s, vcc, %s, %s, vcc" % (D(i), A0(i), tmp))
     L.append("v_sub_co_u32_e32 %s, vcc, %s, %s" % (D(0), D(0), A1(0)))
     for i in range(1, 12):
         L.append("v_subb_co_u32_e32 %s, vcc, %s, %s, vcc" % (D(i), D(i), A1(i)))
     L.append("v_lshlrev_b32_e32 %s, 1, %s" % (A1D(0), A1(0)))
     for i in range(1, 12):
         L.append("v_alignbit_b32 %s, %s, %s, 31" % (A1D(i), A1(i), A1(i - 1)))
+    L += zip2(Chain([(S, D)], C0, 84, "vcc").stream(), Chain([(A0, A1D)], C1, 88, CARRY_B).stream())
+    L += cond_sub(C0, S, tmp)
+    L += cond_sub(C1, S, tmp)
+    return L
 
-    def scan(X, Y, OUT):
-        Sx = ["v_mov_b32_e32 %s, 0" % lo, "v_mov_b32_e32 %s, 0" % mid, "v_mov_b32_e32 %s, 0" % hi]
-        for k in range(24):
-            for i in range(max(0, k - 11), min(k, 11) + 1):
-                Sx += mac2(X(i), Y(k - i))
-            if k < 12:
-                for i in range(0, k):
-                    Sx += mac2(SP(k - i), MM(i))
-                Sx.append("v_mul_lo_u32 %s, %s, %s" % (MM(k), SNP, lo))
-                Sx += mac2(SP(0), MM(k))
-                Sx += ["v_mov_b32_e32 %s, %s" % (lo, mid), "v_mov_b32_e32 %s, %s" % (mid, hi), "v_mov_b32_e32 %s, 0" % hi]
-            else:
-                for i in range(k - 11, 12):
-                    Sx += mac2(SP(k - i), MM(i))
-                Sx += ["v_mov_b32_e32 %s, %s" % (OUT(k - 12), lo), "v_mov_b32_e32 %s, %s" % (lo, mid), "v_mov_b32_e32 %s, %s" % (mid, hi),
-                       "v_mov_b32_e32 %s, 0" % hi]
-        Sx.append("v_mov_b32_e32 v99, %s" % SP(0))
-        Sx.append("v_sub_co_u32_e32 %s, vcc, %s, v99" % (MM(0), OUT(0)))
-        for i in range(1, 12):
-            Sx.append("v_mov_b32_e32 v99, %s" % SP(i))
-            Sx.append("v_subb_co_u32_e32 %s, vcc, %s, v99, vcc" % (MM(i), OUT(i)))
-        for i in range(12):
-            Sx.append("v_cndmask_b32_e32 %s, %s, %s, vcc" % (OUT(i), MM(i), OUT(i)))
-        return Sx
-    L += scan(S, D, C0)
-    L += scan(A0, A1D, C1)
+
+def fp2_mulfp_body():
+    """c0 = a0 s, c1 = a1 s (an Fp2 element times an Fp element) as two interleaved single-product scans.
+    Private convention: a0 v[0:11], a1 v[12:23], s v[24:35] (preserved); c0 -> v[36:47], c1 -> v[48:59]; scratch v60-v92."""
+    A0, A1, S, C0, C1, DF = VR(0), VR(12), VR(24), VR(36), VR(48), VR(60)
+    tmp = "v92"
+    L = load_modulus()
+    L += zip2(Chain([(A0, S)], C0, 84, "vcc").stream(), Chain([(A1, S)], C1, 88, CARRY_B).stream())
+    L += cond_sub(C0, DF, tmp)
+    L += cond_sub(C1, DF, tmp)
     return L
 
 
@@ -209,14 +227,16 @@ def main():
     txt += '#define MBLS_FP_MUL_CLOBBERS "v24","v25","v26","v27","v28","v29","v30","v31","v32","v33","v34","v35","v36","v37","v38", \\\n'
     txt += '    "s40","s41","s42","s43","s44","s45","s46","s47","s56","s57","s58","s59","s60","s62","s63","vcc","scc"\n'
     txt += emit("MBLS_FP2_MUL_ASM", fp2_mul_body()) + "\n"
-    txt += '#define MBLS_FP2_MUL_CLOBBERS "v72","v73","v74","v75","v76","v77","v78","v79","v80","v81","v82","v83","v84","v85","v86","v87","v88","v89","v90", \\\n'
-    txt += '    "v91","v92","v93","v94","v95","v96","v97","v98","v99","s40","s41","s42","s43","s44","s45","s46","s47","s56","s57","s58","s59","s60","vcc","scc"\n'
+    vl = lambda a, b: ",".join('"v%d"' % i for i in range(a, b + 1))
+    sg = '"s40","s41","s42","s43","s44","s45","s46","s47","s56","s57","s58","s59","s60","s62","s63","vcc","scc"'
+    txt += "#define MBLS_FP2_MUL_CLOBBERS %s, %s\n" % (vl(72, 92), sg)
     txt += emit("MBLS_FP2_SQR_ASM", fp2_sqr_body()) + "\n"
-    txt += '#define MBLS_FP2_SQR_CLOBBERS "v48","v49","v50","v51","v52","v53","v54","v55","v56","v57","v58","v59","v60","v61","v62","v63","v64","v65","v66","v67", \\\n'
-    txt += '    "v68","v69","v70","v71", MBLS_FP2_MUL_CLOBBERS\n'
+    txt += "#define MBLS_FP2_SQR_CLOBBERS %s, %s\n" % (vl(48, 92), sg)
+    txt += emit("MBLS_FP2_MULFP_ASM", fp2_mulfp_body()) + "\n"
+    txt += "#define MBLS_FP2_MULFP_CLOBBERS %s, %s\n" % (vl(60, 92), sg)
     with open(path, "w") as f:
         f.write(txt)
-    print("wrote", path, "(%d + %d + %d instructions)" % (len(body()), len(fp2_mul_body()), len(fp2_sqr_body())))
+    print("wrote", path, "(%d + %d + %d + %d instructions)" % (len(body()), len(fp2_mul_body()), len(fp2_sqr_body()), len(fp2_mulfp_body())))
 
 
 if __name__ == "__main__":

@@ -1,0 +1,607 @@
+#!/usr/bin/env python3
+"""Generate milagro_bls_amd/csrc/mbls_tower_asm.inc: straight-line gfx950 routines for the two hot loop bodies
+(Granger-Scott cyclotomic squaring of the final exponentiation, doubling iteration of the Miller loop).
+
+Why: inside these loops hipcc cannot keep the working set (an Fp12 = 144 registers, plus Fp6 temporaries, plus the fixed
+register window of the Fp2 multiplication routines) in registers; it spills to lane-private scratch memory, and with one wave
+per SIMD every reload is an exposed HBM round trip (measured: 23-27 % of k_final / k_miller wave cycles waiting). Here the
+program is known in full, so values are placed by hand-rolled allocation with exact next-use knowledge (Belady eviction):
+VGPR blocks first, AGPRs as the spill space (one v_accvgpr move per limb instead of a memory round trip), LDS for state that
+crosses the routine boundary. No scratch memory is touched.
+
+Structure:  Prog  -- records a straight-line program over Fp values (add, sub, select, Fp2 mul/sqr/mul-by-Fp calls, LDS moves)
+            Alloc -- walks it, assigns 12-register blocks, emits instructions
+The emitted text is checked on the CPU by tools/asm_sim.py against the big-integer model (tests/test_asm_sim_cpu.py).
+Run:  python3 tools/gen_tower_asm.py    (output committed; tests check it is up to date)
+"""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from gen_fp_asm import P, PL, emit  # noqa: E402
+
+INF = 1 << 60
+WIN = [0, 12, 24, 36, 48, 60]                      # blocks inside the register window of the multiplication routines
+FREE_V = [96 + 12 * i for i in range(12)]          # v96..v239
+ALL_V = FREE_V + [36, 24, 12, 0, 60, 48]           # preference order for fresh values
+PB = 240                                           # v240..v251: the modulus
+U = 72                                             # v72..v83: scratch of the modular add/sub (dead between calls)
+LADDR = "v252"                                     # byte address of this lane's column in the LDS state
+AG = [12 * i for i in range(21)]                   # a0..a251
+NLDS = 13                                          # 13 Fp slots of 64 x 12 dwords in a 160-dword-per-lane LDS budget
+CARRY_B = "s[62:63]"
+CARRY_C, CARRY_D = "s[50:51]", "s[52:53]"          # carries of the second chain of an interleaved pair
+U2 = 84                                            # v84..v95: scratch of that second chain
+
+ROUTINES = {
+    "mul": dict(name="mbls_fp2_mul_asm_fn", ins=[0, 12, 24, 36], outs=[48, 60], clob=[48, 60]),
+    "sqr": dict(name="mbls_fp2_sqr_asm_fn", ins=[0, 12], outs=[24, 36], clob=[24, 36, 48, 60]),
+    "mulfp": dict(name="mbls_fp2_mulfp_asm_fn", ins=[0, 12, 24], outs=[36, 48], clob=[36, 48, 60]),
+}
+
+
+class Prog:
+    def __init__(self):
+        self.ops = []
+        self.nval = 0
+        self.init_loc = {}
+
+    def new(self):
+        self.nval += 1
+        return self.nval - 1
+
+    def live_in(self, loc):
+        v = self.new()
+        self.init_loc[v] = loc
+        return v
+
+    def add(self, a, b):
+        d = self.new(); self.ops.append(("add", [d], [a, b], None)); return d
+
+    def sub(self, a, b):
+        d = self.new(); self.ops.append(("sub", [d], [a, b], None)); return d
+
+    def const(self, value):
+        d = self.new(); self.ops.append(("const", [d], [], value)); return d
+
+    def sel(self, mask, a, b):                 # mask (an SGPR pair, one bit per lane) ? b : a
+        d = self.new(); self.ops.append(("sel", [d], [a, b], mask)); return d
+
+    def call(self, kind, ins):
+        outs = [self.new(), self.new()]
+        assert len(set(ins)) == len(ins)
+        self.ops.append((kind, outs, list(ins), None))
+        return tuple(outs)
+
+    def store(self, a, loc):
+        self.ops.append(("store", [], [a], loc))
+
+    def keep(self, vals):
+        """values that stay in their live-in homes for the next round of the loop (never moved, only copied)"""
+        self.ops.append(("keep", [], list(vals), None))
+
+    # ---- Fp2 layer (an Fp2 is a pair of values)
+    def pair(self, k0, a0, b0, k1, a1, b1):
+        """two independent Fp additions/subtractions, emitted as interleaved carry chains (a lone wave issues a dependent
+        v_addc chain at ~6.8 clk per instruction, two interleaved chains at ~4.5)"""
+        d0, d1 = self.new(), self.new()
+        self.ops.append(("pair", [d0, d1], [a0, b0, a1, b1], (k0, k1)))
+        return (d0, d1)
+
+    def add2(self, a, b): return self.pair("add", a[0], b[0], "add", a[1], b[1])
+    def sub2(self, a, b): return self.pair("sub", a[0], b[0], "sub", a[1], b[1])
+    def dbl2(self, a): return self.add2(a, a)
+    def mul2(self, a, b): return self.call("mul", [a[0], a[1], b[0], b[1]])
+    def sqr2(self, a): return self.call("sqr", [a[0], a[1]])
+    def mulfp2(self, a, s): return self.call("mulfp", [a[0], a[1], s])
+    def mul_xi2(self, a): return self.pair("sub", a[0], a[1], "add", a[0], a[1])    # (1 + i) a
+    def sel2(self, mask, a, b): return (self.sel(mask, a[0], b[0]), self.sel(mask, a[1], b[1]))
+    def store2(self, a, slot2): self.store(a[0], ("l", 2 * slot2)); self.store(a[1], ("l", 2 * slot2 + 1))
+    def mul3_2(self, a): return self.add2(self.dbl2(a), a)
+    def mul4_2(self, a): return self.dbl2(self.dbl2(a))
+    def mul8_2(self, a): return self.dbl2(self.mul4_2(a))
+    def mul12_2(self, a): return self.add2(self.mul8_2(a), self.mul4_2(a))
+
+    # ---- Fp6 layer (lists of three Fp2), same formulas as mbls_tower.h
+    def add6(self, a, b): return [self.add2(a[i], b[i]) for i in range(3)]
+    def sub6(self, a, b): return [self.sub2(a[i], b[i]) for i in range(3)]
+    def mul_v6(self, a): return [self.mul_xi2(a[2]), a[0], a[1]]
+
+    def mul6(self, a, b):
+        t0, t1, t2 = self.mul2(a[0], b[0]), self.mul2(a[1], b[1]), self.mul2(a[2], b[2])
+        c0 = self.mul2(self.add2(a[1], a[2]), self.add2(b[1], b[2]))
+        c0 = self.add2(self.mul_xi2(self.sub2(self.sub2(c0, t1), t2)), t0)
+        c1 = self.mul2(self.add2(a[0], a[1]), self.add2(b[0], b[1]))
+        c1 = self.add2(self.sub2(self.sub2(c1, t0), t1), self.mul_xi2(t2))
+        c2 = self.mul2(self.add2(a[0], a[2]), self.add2(b[0], b[2]))
+        c2 = self.add2(self.sub2(self.sub2(c2, t0), t2), t1)
+        return [c0, c1, c2]
+
+    def mul6_01(self, a, x, y):            # a (x + y v)
+        t0, t1 = self.mul2(a[0], x), self.mul2(a[1], y)
+        c1 = self.sub2(self.sub2(self.mul2(self.add2(a[0], a[1]), self.add2(x, y)), t0), t1)
+        c0 = self.add2(self.mul_xi2(self.mul2(a[2], y)), t0)
+        c2 = self.add2(self.mul2(a[2], x), t1)
+        return [c0, c1, c2]
+
+    def mul6_1(self, a, y):                # a (y v)
+        return [self.mul_xi2(self.mul2(a[2], y)), self.mul2(a[0], y), self.mul2(a[1], y)]
+
+    # ---- Fp12 layer: (c0, c1) of Fp6
+    def sqr12(self, f):
+        a, b = f
+        ab = self.mul6(a, b)
+        s = self.add6(a, b)
+        t = self.add6(a, self.mul_v6(b))
+        st = self.sub6(self.mul6(s, t), ab)
+        return (self.sub6(st, self.mul_v6(ab)), self.add6(ab, ab))
+
+    def mul12_line(self, f, c0, c2, c3):   # f (c0 + c2 w^2 + c3 w^3)
+        a, b = f
+        t0 = self.mul6_01(a, c0, c2)
+        t1 = self.mul6_1(b, c3)
+        c1 = self.mul6_01(self.add6(a, b), c0, self.add2(c2, c3))
+        c1 = self.sub6(self.sub6(c1, t0), t1)
+        return (self.add6(t0, self.mul_v6(t1)), c1)
+
+
+class Alloc:
+    def __init__(self, prog):
+        self.p = prog
+        self.uses = {}
+        for k, (kind, outs, ins, aux) in enumerate(prog.ops):
+            for v in ins:
+                self.uses.setdefault(v, []).append(k)
+        self.loc = dict(prog.init_loc)
+        self.at = {l: v for v, l in self.loc.items()}
+        self.out = []
+        self.pending_lds = False
+        self.stats = dict(vmov=0, acc=0, lds=0, arith=0, calls=0)
+
+    # ---- liveness
+    def next_use(self, v, k):
+        for u in self.uses.get(v, ()):
+            if u >= k:
+                return u
+        return INF
+
+    # ---- location bookkeeping
+    def place(self, v, l):
+        old = self.loc.get(v)
+        if old is not None and self.at.get(old) == v:
+            del self.at[old]
+        self.loc[v] = l
+        self.at[l] = v
+
+    def release(self, v):
+        l = self.loc.pop(v, None)
+        if l is not None and self.at.get(l) == v:
+            del self.at[l]
+
+    def free_block(self, kind, pool, avoid=()):
+        for b in pool:
+            if (kind, b) not in self.at and b not in avoid:
+                return b
+        return None
+
+    # ---- instruction emission
+    def e(self, s):
+        self.out.append(s)
+
+    def wait_lds(self):
+        if self.pending_lds:
+            self.e("s_waitcnt lgkmcnt(0)")
+            self.pending_lds = False
+
+    def copy(self, src, dst):
+        """copy one Fp between locations; dst is ('v', b), ('a', b) or ('l', slot)"""
+        (sk, sb), (dk, db) = src, dst
+        if sk == "v" and dk == "v":
+            for j in range(0, 12, 2):
+                self.e("v_mov_b64_e32 v[%d:%d], v[%d:%d]" % (db + j, db + j + 1, sb + j, sb + j + 1))
+            self.stats["vmov"] += 6
+        elif sk == "v" and dk == "a":
+            for j in range(12):
+                self.e("v_accvgpr_write_b32 a%d, v%d" % (db + j, sb + j))
+            self.stats["acc"] += 12
+        elif sk == "a" and dk == "v":
+            for j in range(12):
+                self.e("v_accvgpr_read_b32 v%d, a%d" % (db + j, sb + j))
+            self.stats["acc"] += 12
+        elif sk == "l" and dk == "v":
+            for j in range(0, 12, 2):
+                o = sb * 12 + j
+                self.e("ds_read2st64_b32 v[%d:%d], %s offset0:%d offset1:%d" % (db + j, db + j + 1, LADDR, o, o + 1))
+            self.pending_lds = True
+            self.stats["lds"] += 6
+        elif sk == "v" and dk == "l":
+            for j in range(0, 12, 2):
+                o = db * 12 + j
+                self.e("ds_write2st64_b32 %s, v%d, v%d offset0:%d offset1:%d" % (LADDR, sb + j, sb + j + 1, o, o + 1))
+            self.stats["lds"] += 6
+        else:
+            raise ValueError((src, dst))
+
+    # ---- getting a VGPR block
+    def alloc_v(self, k, avoid=(), hint=None):
+        if hint is not None and ("v", hint) not in self.at and hint not in avoid:
+            return hint
+        b = self.free_block("v", ALL_V, avoid)
+        if b is not None:
+            return b
+        # evict the VGPR-resident value whose next use is farthest away
+        best, bu = None, -1
+        for blk in ALL_V:
+            if blk in avoid:
+                continue
+            w = self.at[("v", blk)]
+            u = self.next_use(w, k)
+            if u > bu:
+                best, bu = blk, u
+        w = self.at[("v", best)]
+        if bu == INF:
+            self.release(w)
+            return best
+        self.spill(w)
+        return best
+
+    def spill(self, w):
+        """move a VGPR-resident value out of the VGPR file (AGPR first, LDS if the AGPRs are full)"""
+        src = self.loc[w]
+        ab = self.free_block("a", AG)
+        if ab is not None:
+            self.copy(src, ("a", ab)); self.place(w, ("a", ab)); return
+        ls = self.free_block("l", range(NLDS))
+        if ls is None:
+            raise RuntimeError("out of storage")
+        self.copy(src, ("l", ls)); self.place(w, ("l", ls))
+
+    def to_vgpr(self, v, k, avoid=()):
+        l = self.loc[v]
+        if l[0] == "v":
+            return l[1]
+        b = self.alloc_v(k, avoid)
+        self.copy(l, ("v", b))
+        self.place(v, ("v", b))
+        return b
+
+    def hint_for(self, d, k):
+        """if the next use of d is an operand slot of the very next call, compute it there"""
+        u = self.next_use(d, k + 1)
+        if u == INF:
+            return None
+        for j in range(k + 1, u):
+            if self.p.ops[j][0] in ROUTINES:
+                return None
+        kind, outs, ins, aux = self.p.ops[u]
+        if kind in ROUTINES:
+            return ROUTINES[kind]["ins"][ins.index(d)]
+        return None
+
+    # ---- the walk
+    def run(self):
+        for j in range(12):
+            self.e("v_mov_b32_e32 v%d, 0x%08x" % (PB + j, PL[j]))
+        for k, (kind, outs, ins, aux) in enumerate(self.p.ops):
+            if kind in ("add", "sub", "sel"):
+                self.do_arith(k, kind, outs[0], ins, aux)
+            elif kind == "pair":
+                self.do_pair(k, outs, ins, aux)
+            elif kind == "const":
+                b = self.alloc_v(k, hint=self.hint_for(outs[0], k))
+                for j in range(12):
+                    self.e("v_mov_b32_e32 v%d, 0x%08x" % (b + j, (aux >> (32 * j)) & 0xFFFFFFFF))
+                self.place(outs[0], ("v", b))
+            elif kind in ROUTINES:
+                self.do_call(k, kind, outs, ins)
+            elif kind == "store":
+                self.do_store(k, ins[0], aux)
+            elif kind == "keep":
+                for v in ins:
+                    assert self.loc[v] == self.p.init_loc[v], "pinned value moved"
+                continue
+            for v in set(ins):
+                if self.next_use(v, k + 1) == INF:
+                    self.release(v)
+        self.wait_lds()
+        self.e("s_waitcnt lgkmcnt(0)")
+        return self.out
+
+    def pick_dst(self, k, d, a, b, ba, bb, avoid):
+        """destination block of d = a op b: the operand slot of the next call if d goes straight there, else in place over an
+        operand that dies here, else None (a fresh block)"""
+        hint = self.hint_for(d, k)
+        if hint is not None and hint not in (ba, bb) and hint not in avoid and ("v", hint) not in self.at:
+            return hint
+        for v, blk in ((a, ba), (b, bb)):
+            if self.next_use(v, k + 1) == INF and blk not in avoid:
+                return blk
+        return None
+
+    @staticmethod
+    def gen_arith(kind, D, A, B, Ub, c1, c2, aux=None):
+        """instruction list of one modular operation on 12-register blocks; c1/c2: carry registers (vcc or an SGPR pair)"""
+        def co(op, d, x, y, c):
+            return ("%s_e32 v%d, vcc, v%d, v%d" if c == "vcc" else "%s_e64 v%d, " + c + ", v%d, v%d") % (op, d, x, y)
+
+        def cc(op, d, x, y, c):
+            return ("%s_e32 v%d, vcc, v%d, v%d, vcc" if c == "vcc" else "%s_e64 v%d, " + c + ", v%d, v%d, " + c) % (op, d, x, y)
+
+        def cm(d, x, y, c):
+            return ("v_cndmask_b32_e32 v%d, v%d, v%d, vcc" if c == "vcc" else "v_cndmask_b32_e64 v%d, v%d, v%d, " + c) % (d, x, y)
+        L = []
+        if kind == "add":
+            L.append(co("v_add_co_u32", D, A, B, c1))
+            L += [cc("v_addc_co_u32", D + j, A + j, B + j, c1) for j in range(1, 12)]
+            L.append(co("v_sub_co_u32", Ub, D, PB, c1))
+            L += [cc("v_subb_co_u32", Ub + j, D + j, PB + j, c1) for j in range(1, 12)]
+            L += [cm(D + j, Ub + j, D + j, c1) for j in range(12)]            # borrow ? sum : sum - p
+        elif kind == "sub":
+            L.append(co("v_sub_co_u32", D, A, B, c1))
+            L += [cc("v_subb_co_u32", D + j, A + j, B + j, c1) for j in range(1, 12)]
+            L.append(co("v_add_co_u32", Ub, D, PB, c2))                          # the borrow stays in c1
+            L += [cc("v_addc_co_u32", Ub + j, D + j, PB + j, c2) for j in range(1, 12)]
+            L += [cm(D + j, D + j, Ub + j, c1) for j in range(12)]            # borrow ? diff + p : diff
+        else:                                                                    # sel: mask ? b : a
+            L += ["v_cndmask_b32_e64 v%d, v%d, v%d, %s" % (D + j, A + j, B + j, aux) for j in range(12)]
+        return L
+
+    def finish_arith(self, d, bd, operands):
+        # d may have been written over a dying operand's block: drop that operand first
+        for v in operands:
+            if self.loc.get(v) == ("v", bd):
+                self.release(v)
+        self.place(d, ("v", bd))
+
+    def do_arith(self, k, kind, d, ins, aux):
+        a, b = ins
+        self.to_vgpr(a, k)
+        if b != a:
+            self.to_vgpr(b, k, avoid=(self.loc[a][1],))
+        ba, bb = self.loc[a][1], self.loc[b][1]
+        self.wait_lds()
+        bd = self.pick_dst(k, d, a, b, ba, bb, ())
+        if bd is None:
+            bd = self.alloc_v(k, avoid=(ba, bb))
+        for l in self.gen_arith(kind, bd, ba, bb, U, "vcc", CARRY_B, aux):
+            self.e(l)
+        self.stats["arith"] += 12 if kind == "sel" else 36
+        self.finish_arith(d, bd, (a, b))
+
+    def do_pair(self, k, outs, ins, kinds):
+        a0, b0, a1, b1 = ins
+        got = []
+        for v in (a0, b0, a1, b1):
+            if v not in got:
+                self.to_vgpr(v, k, avoid=tuple(self.loc[w][1] for w in got))
+                got.append(v)
+        blk = {v: self.loc[v][1] for v in got}
+        assert all(self.loc[v][0] == "v" for v in got)
+        self.wait_lds()
+        # an operand of one operation must not be overwritten by the other one's result (the chains run interleaved)
+        d0 = self.pick_dst(k, outs[0], a0, b0, blk[a0], blk[b0], avoid=(blk[a1], blk[b1]))
+        if d0 is None:
+            d0 = self.alloc_v(k, avoid=tuple(blk.values()))
+        d1 = self.pick_dst(k, outs[1], a1, b1, blk[a1], blk[b1], avoid=(blk[a0], blk[b0], d0))
+        if d1 is None:
+            d1 = self.alloc_v(k, avoid=tuple(blk.values()) + (d0,))
+        L0 = self.gen_arith(kinds[0], d0, blk[a0], blk[b0], U, "vcc", CARRY_B)
+        L1 = self.gen_arith(kinds[1], d1, blk[a1], blk[b1], U2, CARRY_C, CARRY_D)
+        for x, y in zip(L0, L1):
+            self.e(x); self.e(y)
+        self.stats["arith"] += 72
+        for bd in (d0, d1):
+            for v in got:
+                if self.loc.get(v) == ("v", bd):
+                    self.release(v)
+        self.place(outs[0], ("v", d0)); self.place(outs[1], ("v", d1))
+
+    def do_call(self, k, kind, outs, ins):
+        R = ROUTINES[kind]
+        slots = R["ins"]
+        touched = set(slots) | set(R["clob"])
+        want = {slots[i]: ins[i] for i in range(len(ins))}
+        # 1. move out whatever sits in a slot that will be overwritten and is still needed
+        for s in sorted(touched):
+            w = self.at.get(("v", s))
+            if w is None or want.get(s) == w:
+                continue
+            is_operand = w in ins
+            if is_operand or self.next_use(w, k + 1) != INF:
+                u = self.next_use(w, k if is_operand else k + 1)
+                nk = self.p.ops[u][0] if u != INF else None
+                # a value that is next consumed as an operand of a call loses nothing by waiting in an AGPR
+                if not is_operand and nk in ROUTINES and self.free_block("a", AG) is not None:
+                    self.spill(w)
+                else:
+                    b = self.alloc_v(k, avoid=touched)
+                    self.copy(("v", s), ("v", b)); self.place(w, ("v", b))
+            else:
+                self.release(w)
+        # 2. operands into their slots
+        for s, v in want.items():
+            l = self.loc[v]
+            if l == ("v", s):
+                continue
+            self.copy(l, ("v", s))
+            dies = self.next_use(v, k + 1) == INF
+            if dies or l[0] == "v" and l[1] in R["clob"]:
+                self.place(v, ("v", s))
+            # otherwise the value keeps its old home; the slot holds an untracked copy that dies with the call
+        self.wait_lds()
+        self.e("CALL " + R["name"])
+        self.stats["calls"] += 1
+        # operands that were tracked in a slot and are still live stay there (input slots are preserved by the routines)
+        for s in R["clob"]:
+            w = self.at.get(("v", s))
+            if w is not None:
+                assert self.next_use(w, k + 1) == INF, "live value in a clobbered slot"
+                self.release(w)
+        for i, o in enumerate(outs):
+            self.place(o, ("v", R["outs"][i]))
+
+    def do_store(self, k, a, dst):
+        w = self.at.get(dst)
+        if w is not None and w != a:
+            if self.next_use(w, k + 1) != INF:
+                b = self.alloc_v(k, avoid=(self.loc[a][1],) if self.loc[a][0] == "v" else ())
+                self.copy(dst, ("v", b)); self.place(w, ("v", b))
+                self.wait_lds()
+            else:
+                self.release(w)
+        if self.loc[a] != dst:
+            b = self.to_vgpr(a, k)
+            self.wait_lds()
+            self.copy(("v", b), dst)
+        if self.next_use(a, k + 1) == INF:
+            self.release(a)
+        self.at[dst] = ("stored", a)  # the slot now holds a result: never reused as spill space
+
+
+# ------------------------------------------------------------------------------------------ the programs
+# Fp2 coefficient e2 of an Fp12 in tower order: 0 c0.c0, 1 c0.c1, 2 c0.c2, 3 c1.c0, 4 c1.c1, 5 c1.c2  (LDS slots 2*e2, 2*e2+1)
+def prog_cyc_sqr():
+    """Granger-Scott squaring in the cyclotomic subgroup, state in LDS slots 0..11, in place
+    (same formulas as fp12_cyc_sqr in mbls_tower.h)."""
+    p = Prog()
+    z = [(p.live_in(("l", 2 * e)), p.live_in(("l", 2 * e + 1))) for e in range(6)]
+    z0, z4, z3, z2, z1, z5 = z
+
+    def fp4_sqr(a, b):
+        t0 = p.sqr2(a); t1 = p.sqr2(b)
+        c0 = p.add2(p.mul_xi2(t1), t0)
+        s = p.sqr2(p.add2(a, b))
+        c1 = p.sub2(p.sub2(s, t0), t1)
+        return c0, c1
+    t0, t1 = fp4_sqr(z0, z1)
+    p.store2(p.add2(p.dbl2(p.sub2(t0, z0)), t0), 0)
+    p.store2(p.add2(p.dbl2(p.add2(t1, z1)), t1), 4)
+    t0, t1 = fp4_sqr(z2, z3)
+    t2, t3 = fp4_sqr(z4, z5)
+    p.store2(p.add2(p.dbl2(p.sub2(t0, z4)), t0), 1)
+    p.store2(p.add2(p.dbl2(p.add2(t1, z5)), t1), 5)
+    x = p.mul_xi2(t3)
+    p.store2(p.add2(p.dbl2(p.add2(x, z2)), x), 3)
+    p.store2(p.add2(p.dbl2(p.sub2(t2, z3)), t2), 2)
+    return p
+
+
+R384 = 1 << 384
+G1_X = 0x17f1d3a73197d7942695638c4fa9ac0fc3688c4f9774b905a14e3a3f171bac586c55e83ff97a1aeffb3af00adb22c6bb
+G1_Y = 0x08b3f481e3aaa0f1a09e30ed741d8ae4fcf5e095d5d00af600db18cb2c04b3edd03cc744a2888ae40caa232946c5e7e1
+ONE_M = R384 % P                                  # Montgomery form of 1
+# pair 0 of a verification is (signature, -G1): the G1 argument is the constant (G1_X, -G1_Y); the line needs -px and py
+NPX0_M = (P - G1_X) * R384 % P
+PY0_M = (P - G1_Y) * R384 % P
+F_HOME = [("a", 12 * i) for i in range(12)]        # the Miller value between iterations, tower order
+P1_HOME = [("a", 144 + 12 * i) for i in range(3)]  # -px, py, pz^3 of the second pair's G1 argument
+SKIP_MASK = ["s[48:49]", "s[54:55]"]               # lanes whose pair contributes 1 (a member is infinity)
+
+
+def prog_miller_dbl():
+    """One doubling iteration of the two-pair (verification-shape) Miller loop: f <- f^2, then for each pair T <- 2T and
+    f <- f * line (formulas of miller_dbl_step / fp12_sqr / fp12_mul_line in mbls_pairing.h / mbls_tower.h).
+    State: f in AGPR homes, running points T0/T1 in LDS slots 0..5 / 6..11 (x, y, z as Fp2), second G1 argument in AGPR homes."""
+    p = Prog()
+    fl = [p.live_in(h) for h in F_HOME]
+    f = ([(fl[0], fl[1]), (fl[2], fl[3]), (fl[4], fl[5])], [(fl[6], fl[7]), (fl[8], fl[9]), (fl[10], fl[11])])
+    p1 = [p.live_in(h) for h in P1_HOME]
+    f = p.sqr12(f)
+    for k in range(2):
+        T = [(p.live_in(("l", 6 * k + 2 * e)), p.live_in(("l", 6 * k + 2 * e + 1))) for e in range(3)]
+        Tx, Ty, Tz = T
+        B = p.sqr2(Ty); C = p.sqr2(Tz)
+        E = p.mul12_2(p.mul_xi2(C))
+        F = p.mul3_2(E)
+        X2 = p.sqr2(Tx)
+        YZ = p.mul2(Ty, Tz)
+        c0 = p.sub2(B, E)
+        if k == 0:
+            npx, py = p.const(NPX0_M), None
+            c2 = p.mulfp2(p.mul3_2(X2), npx)
+            c3 = p.mulfp2(p.dbl2(YZ), p.const(PY0_M))
+        else:
+            c0 = p.mulfp2(c0, p1[2])
+            c2 = p.mulfp2(p.mul3_2(X2), p1[0])
+            c3 = p.mulfp2(p.dbl2(YZ), p1[1])
+        x3 = p.dbl2(p.mul2(p.mul2(Tx, Ty), p.sub2(B, F)))
+        y3 = p.sub2(p.sqr2(p.add2(B, F)), p.mul12_2(p.sqr2(E)))
+        z3 = p.mul8_2(p.mul2(B, YZ))
+        for e, v in enumerate((x3, y3, z3)):
+            p.store2(v, 3 * k + e)
+        m = SKIP_MASK[k]
+        c0 = (p.sel(m, c0[0], p.const(ONE_M)), p.sel(m, c0[1], p.const(0)))
+        c2 = (p.sel(m, c2[0], p.const(0)), p.sel(m, c2[1], p.const(0)))
+        c3 = (p.sel(m, c3[0], p.const(0)), p.sel(m, c3[1], p.const(0)))
+        f = p.mul12_line(f, c0, c2, c3)
+    flat = [x for h in f for c in h for x in c]
+    for v, h in zip(flat, F_HOME):
+        p.store(v, h)
+    p.keep(p1)
+    return p
+
+
+def miller_dbl_shell(body):
+    """f arrives in v96..v239 and the second G1 argument in v0..v35 (asm operands of the call site); both move to their AGPR
+    homes around the loop. v253 carries the per-lane skip flags (bit 0: pair 0, bit 1: pair 1), s38 the number of iterations."""
+    pro = ["v_and_b32_e32 v254, 1, v253", "v_cmp_ne_u32_e64 %s, 0, v254" % SKIP_MASK[0],
+           "v_and_b32_e32 v254, 2, v253", "v_cmp_ne_u32_e64 %s, 0, v254" % SKIP_MASK[1], "s_mov_b32 s39, s38"]
+    epi = []
+    for i in range(12):
+        for j in range(12):
+            pro.append("v_accvgpr_write_b32 a%d, v%d" % (12 * i + j, 96 + 12 * i + j))
+            epi.append("v_accvgpr_read_b32 v%d, a%d" % (96 + 12 * i + j, 12 * i + j))
+    for i in range(3):
+        for j in range(12):
+            pro.append("v_accvgpr_write_b32 a%d, v%d" % (144 + 12 * i + j, 12 * i + j))
+    return wrap_loop(body, count_sgpr="s39", prologue=pro, epilogue=epi)
+
+
+def expand_calls(lines):
+    out = []
+    for l in lines:
+        if l.startswith("CALL "):
+            sym = l.split()[1]
+            out += ["s_getpc_b64 s[40:41]", "s_add_u32 s40, s40, %s@rel32@lo+4" % sym, "s_addc_u32 s41, s41, %s@rel32@hi+12" % sym,
+                    "s_swappc_b64 s[30:31], s[40:41]"]
+        else:
+            out.append(l)
+    return out
+
+
+def wrap_loop(lines, count_sgpr="s38", prologue=(), epilogue=()):
+    """routine shell: save the return address (nested calls overwrite s[30:31]) and repeat the body count_sgpr times (>= 1)"""
+    return (["s_mov_b64 s[36:37], s[30:31]"] + list(prologue) + ["1:"] + lines +
+            ["s_sub_u32 %s, %s, 1" % (count_sgpr, count_sgpr), "s_cmp_lg_u32 %s, 0" % count_sgpr, "s_cbranch_scc1 1b"] +
+            list(epilogue) + ["s_mov_b64 s[30:31], s[36:37]"])
+
+
+def build(name):
+    prog = {"cyc_sqr": prog_cyc_sqr, "miller_dbl": prog_miller_dbl}[name]()
+    al = Alloc(prog)
+    lines = al.run()
+    return lines, al.stats
+
+
+def main():
+    here = os.path.dirname(os.path.abspath(__file__))
+    path = os.path.join(os.path.dirname(here), "milagro_bls_amd", "csrc", "mbls_tower_asm.inc")
+    txt = "// GENERATED by tools/gen_tower_asm.py -- do not edit.\n"
+    for name, macro, shell in (("cyc_sqr", "MBLS_CYC_SQR_ASM", wrap_loop), ("miller_dbl", "MBLS_MILLER_DBL_ASM", miller_dbl_shell)):
+        lines, stats = build(name)
+        txt += emit(macro, shell(expand_calls(lines))) + "\n"
+        print(name, len(lines), "lines", stats)
+    sg = '"s30","s31","s36","s37","s39","s40","s41","s42","s43","s44","s45","s46","s47","s48","s49","s50","s51","s52","s53","s54","s55","s56","s57","s58","s59","s60","s62","s63","vcc","scc","memory"'
+    vr = ",".join('"v%d"' % i for i in list(range(252)) + [254])
+    txt += "// everything a tower routine may overwrite (v252 carries the LDS address and is preserved)\n"
+    txt += "#define MBLS_TOWER_ASM_CLOBBERS %s,%s, \\\n    %s\n" % (vr, ",".join('"a%d"' % i for i in range(252)), sg)
+    txt += "// the Miller routine takes the G1 argument in v0..v35 and f in v96..v239 as operands\n"
+    txt += "#define MBLS_MILLER_ASM_CLOBBERS %s,%s, \\\n    %s\n" % (
+        ",".join('"v%d"' % i for i in list(range(36, 96)) + list(range(240, 252)) + [254]), ",".join('"a%d"' % i for i in range(252)), sg)
+    with open(path, "w") as f:
+        f.write(txt)
+    print("wrote", path)
+
+
+if __name__ == "__main__":
+    main()
