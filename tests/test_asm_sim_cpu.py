@@ -63,7 +63,7 @@ def test_fp_routines():
         m.run(g.fp2_mulfp_body())
         assert (from_limbs(m.v[36:48]), from_limbs(m.v[48:60])) == (mm(a0, b0), mm(a1, b0))
         m = Machine(); m.v[0:12] = limbs(a0); m.v[12:24] = limbs(b0)
-        m.run(g.body())
+        m.run(g.fp_mul_body())
         assert from_limbs(m.v[0:12]) == mm(a0, b0)
 
 

@@ -87,7 +87,7 @@ class Machine:
         pending_call = None
         for line in lines:
             line = line.split("//")[0].strip()
-            if not line:
+            if not line or line.startswith("."):      # assembler directives (.p2align)
                 continue
             self.count += 1
             op, _, rest = line.partition(" ")
@@ -99,9 +99,9 @@ class Machine:
                 self.wr(args[0], self.rd(args[1]))
             elif op == "s_mov_b64":
                 self.wr_carry(args[0], self.rd(args[1])) if args[0] == "vcc" else self.wr(args[0], self.rd(args[1]))
-            elif op in ("v_mov_b32_e32",):
+            elif op in ("v_mov_b32_e32", "v_mov_b32_e64"):
                 self.wr(args[0], self.rd(args[1]))
-            elif op == "v_mov_b64_e32":
+            elif op in ("v_mov_b64_e32", "v_mov_b64_e64"):
                 self.wr(args[0], self.rd(args[1]))
             elif op in ("v_accvgpr_write_b32", "v_accvgpr_read_b32"):
                 self.wr(args[0], self.rd(args[1]))

@@ -191,6 +191,7 @@ class Alloc:
     def wait_lds(self):
         if self.pending_lds:
             self.e("s_waitcnt lgkmcnt(0)")
+            self.e("s_nop 0")                 # keeps the 8-byte instructions that follow 8-byte aligned
             self.pending_lds = False
 
     def copy(self, src, dst):
@@ -198,7 +199,7 @@ class Alloc:
         (sk, sb), (dk, db) = src, dst
         if sk == "v" and dk == "v":
             for j in range(0, 12, 2):
-                self.e("v_mov_b64_e32 v[%d:%d], v[%d:%d]" % (db + j, db + j + 1, sb + j, sb + j + 1))
+                self.e("v_mov_b64_e64 v[%d:%d], v[%d:%d]" % (db + j, db + j + 1, sb + j, sb + j + 1))
             self.stats["vmov"] += 6
         elif sk == "v" and dk == "a":
             for j in range(12):
@@ -290,7 +291,7 @@ class Alloc:
             elif kind == "const":
                 b = self.alloc_v(k, hint=self.hint_for(outs[0], k))
                 for j in range(12):
-                    self.e("v_mov_b32_e32 v%d, 0x%08x" % (b + j, (aux >> (32 * j)) & 0xFFFFFFFF))
+                    self.e("v_mov_b32_e32 v%d, 0x%08x" % (b + j, (aux >> (32 * j)) & 0xFFFFFFFF))    # 4 + 4 bytes with the literal
                 self.place(outs[0], ("v", b))
             elif kind in ROUTINES:
                 self.do_call(k, kind, outs, ins)
@@ -305,6 +306,7 @@ class Alloc:
                     self.release(v)
         self.wait_lds()
         self.e("s_waitcnt lgkmcnt(0)")
+        self.e("s_nop 0")
         return self.out
 
     def pick_dst(self, k, d, a, b, ba, bb, avoid):
@@ -321,14 +323,16 @@ class Alloc:
     @staticmethod
     def gen_arith(kind, D, A, B, Ub, c1, c2, aux=None):
         """instruction list of one modular operation on 12-register blocks; c1/c2: carry registers (vcc or an SGPR pair)"""
+        # 8-byte (VOP3) encodings throughout: a lone wave fetches 8-byte instructions that sit at 4 mod 8 markedly slower,
+        # and with no 4-byte instructions in the stream nothing ever does
         def co(op, d, x, y, c):
-            return ("%s_e32 v%d, vcc, v%d, v%d" if c == "vcc" else "%s_e64 v%d, " + c + ", v%d, v%d") % (op, d, x, y)
+            return ("%s_e64 v%d, " + c + ", v%d, v%d") % (op, d, x, y)
 
         def cc(op, d, x, y, c):
-            return ("%s_e32 v%d, vcc, v%d, v%d, vcc" if c == "vcc" else "%s_e64 v%d, " + c + ", v%d, v%d, " + c) % (op, d, x, y)
+            return ("%s_e64 v%d, " + c + ", v%d, v%d, " + c) % (op, d, x, y)
 
         def cm(d, x, y, c):
-            return ("v_cndmask_b32_e32 v%d, v%d, v%d, vcc" if c == "vcc" else "v_cndmask_b32_e64 v%d, v%d, v%d, " + c) % (d, x, y)
+            return ("v_cndmask_b32_e64 v%d, v%d, v%d, " + c) % (d, x, y)
         L = []
         if kind == "add":
             L.append(co("v_add_co_u32", D, A, B, c1))
@@ -570,10 +574,11 @@ def expand_calls(lines):
 
 
 def wrap_loop(lines, count_sgpr="s38", prologue=(), epilogue=()):
-    """routine shell: save the return address (nested calls overwrite s[30:31]) and repeat the body count_sgpr times (>= 1)"""
-    return (["s_mov_b64 s[36:37], s[30:31]"] + list(prologue) + ["1:"] + lines +
-            ["s_sub_u32 %s, %s, 1" % (count_sgpr, count_sgpr), "s_cmp_lg_u32 %s, 0" % count_sgpr, "s_cbranch_scc1 1b"] +
-            list(epilogue) + ["s_mov_b64 s[30:31], s[36:37]"])
+    """routine shell: save the return address (nested calls overwrite s[30:31]) and repeat the body count_sgpr times (>= 1).
+    The body can exceed the +-128 KB reach of s_cbranch, so the back edge is a computed jump."""
+    back = ["s_sub_u32 %s, %s, 1" % (count_sgpr, count_sgpr), "s_cmp_lg_u32 %s, 0" % count_sgpr, "s_cbranch_scc0 2f",
+            "s_getpc_b64 s[40:41]", "3:", "s_sub_u32 s40, s40, 3b-1b", "s_subb_u32 s41, s41, 0", "s_setpc_b64 s[40:41]", "2:"]
+    return ["s_mov_b64 s[36:37], s[30:31]"] + list(prologue) + [".p2align 6", "1:"] + lines + back + list(epilogue) + ["s_mov_b64 s[30:31], s[36:37]"]
 
 
 def build(name):
