@@ -178,13 +178,15 @@ MBLS_FN void miller_loop_verify_lds(fp12* f, mbls_pair* pairs, MBLS_LDS uint32_t
 // gcd(3, r) = 1, so comparing with 1 gives the same boolean as amcl's fexp (reference src/amcl_utils.rs:40-41).
 MBLS_NOINLINE void final_exp(fp12* r, const fp12* f, MBLS_LDS uint32_t* ls = nullptr, uint32_t lane = 0, bool use_lds = false) {
     fp12 t, u, a, b, c, m;
-    fp12_conj(&t, f); fp12_inv(&u, f); fp12_mul(&t, &t, &u);              // f^(p^6-1)
-    fp12_frob(&u, &t); fp12_frob(&u, &u); fp12_mul(&m, &u, &t);            // ^(p^2+1): now cyclotomic
-    fp12_cyc_exp_x(&a, &m, ls, lane, use_lds); fp12_conj(&u, &m); fp12_mul(&a, &a, &u);       // m^(x-1)
-    fp12_cyc_exp_x(&t, &a, ls, lane, use_lds); fp12_conj(&u, &a); fp12_mul(&a, &t, &u);       // m^((x-1)^2)
-    fp12_cyc_exp_x(&b, &a, ls, lane, use_lds); fp12_frob(&u, &a); fp12_mul(&b, &b, &u);       // a^(x+p)
+#define MBLS_F12MUL(r, x, y) do { if (use_lds) fp12_mul_via_lds(r, x, y, ls, lane); else fp12_mul(r, x, y); } while (0)
+    fp12_conj(&t, f); fp12_inv(&u, f); MBLS_F12MUL(&t, &t, &u);              // f^(p^6-1)
+    fp12_frob(&u, &t); fp12_frob(&u, &u); MBLS_F12MUL(&m, &u, &t);            // ^(p^2+1): now cyclotomic
+    fp12_cyc_exp_x(&a, &m, ls, lane, use_lds); fp12_conj(&u, &m); MBLS_F12MUL(&a, &a, &u);       // m^(x-1)
+    fp12_cyc_exp_x(&t, &a, ls, lane, use_lds); fp12_conj(&u, &a); MBLS_F12MUL(&a, &t, &u);       // m^((x-1)^2)
+    fp12_cyc_exp_x(&b, &a, ls, lane, use_lds); fp12_frob(&u, &a); MBLS_F12MUL(&b, &b, &u);       // a^(x+p)
     fp12_cyc_exp_x(&c, &b, ls, lane, use_lds); fp12_cyc_exp_x(&c, &c, ls, lane, use_lds);                        // b^(x^2)
-    fp12_frob(&u, &b); fp12_frob(&u, &u); fp12_mul(&c, &c, &u);            // * b^(p^2)
-    fp12_conj(&u, &b); fp12_mul(&c, &c, &u);                               // * b^-1
-    fp12_cyc_sqr(&u, &m); fp12_mul(&u, &u, &m); fp12_mul(r, &c, &u);       // * m^3
+    fp12_frob(&u, &b); fp12_frob(&u, &u); MBLS_F12MUL(&c, &c, &u);            // * b^(p^2)
+    fp12_conj(&u, &b); MBLS_F12MUL(&c, &c, &u);                               // * b^-1
+    fp12_cyc_sqr(&u, &m); MBLS_F12MUL(&u, &u, &m); MBLS_F12MUL(r, &c, &u);       // * m^3
+#undef MBLS_F12MUL
 }

@@ -248,12 +248,34 @@ MBLS_FN void fp12_cyc_sqr_n_lds(MBLS_LDS uint32_t* ls, uint32_t lane, uint32_t n
     uint32_t addr = (uint32_t)(uintptr_t)(ls + lane);
     asm volatile(MBLS_ASM_CALL("mbls_cyc_sqr_asm_fn") : "+{s38}"(n) : "{v252}"(addr) : MBLS_TOWER_ASM_CLOBBERS);
 }
+// The Fp12 parked in LDS times g, in place (generated routine, prog_fp12_mul).
+extern "C" __device__ __attribute__((noinline, used, aligned(64))) void mbls_fp12_mul_asm_fn() {
+    asm volatile(MBLS_FP12_MUL_ASM);
+}
+MBLS_FN void fp12_mul_lds(MBLS_LDS uint32_t* ls, uint32_t lane, const fp12* g) {
+    uint32_t addr = (uint32_t)(uintptr_t)(ls + lane);
+    const fp* c = &g->c0.c0.c0;
+    fp g0 = c[0], g1 = c[1], g2 = c[2], g3 = c[3], g4 = c[4], g5 = c[5], g6 = c[6], g7 = c[7], g8 = c[8], g9 = c[9], g10 = c[10], g11 = c[11];
+    asm volatile(MBLS_ASM_CALL("mbls_fp12_mul_asm_fn")          // the operand registers are overwritten: read-write operands
+                 : "+{v[96:107]}"(g0), "+{v[108:119]}"(g1), "+{v[120:131]}"(g2), "+{v[132:143]}"(g3), "+{v[144:155]}"(g4), "+{v[156:167]}"(g5),
+                   "+{v[168:179]}"(g6), "+{v[180:191]}"(g7), "+{v[192:203]}"(g8), "+{v[204:215]}"(g9), "+{v[216:227]}"(g10), "+{v[228:239]}"(g11)
+                 : "{v252}"(addr)
+                 : MBLS_FP12_ARG_ASM_CLOBBERS);
+}
+// r = a * b through the LDS home (a is parked, multiplied in place, read back)
+MBLS_FN void fp12_mul_via_lds(fp12* r, const fp12* a, const fp12* b, MBLS_LDS uint32_t* ls, uint32_t lane) {
+    fp12_lds_store(ls, lane, a); fp12_mul_lds(ls, lane, b); fp12_lds_load(r, ls, lane);
+}
 #else
 MBLS_FN void fp12_cyc_sqr_n_lds(MBLS_LDS uint32_t* ls, uint32_t lane, uint32_t n) {
     fp12 acc; fp12_lds_load(&acc, ls, lane);
     for (uint32_t i = 0; i < n; i++) fp12_cyc_sqr(&acc, &acc);
     fp12_lds_store(ls, lane, &acc);
 }
+MBLS_FN void fp12_mul_lds(MBLS_LDS uint32_t* ls, uint32_t lane, const fp12* g) {
+    fp12 acc; fp12_lds_load(&acc, ls, lane); fp12_mul(&acc, &acc, g); fp12_lds_store(ls, lane, &acc);
+}
+MBLS_FN void fp12_mul_via_lds(fp12* r, const fp12* a, const fp12* b, MBLS_LDS uint32_t* ls, uint32_t lane) { fp12_mul(r, a, b); }
 #endif
 // f^x, x = -0xd201000000010000, f in the cyclotomic subgroup. With ls != nullptr the running power lives in LDS (it would
 // otherwise pin 144 registers for 63 iterations while each squaring needs the register file itself) and is squared in place,
@@ -267,7 +289,7 @@ MBLS_NOINLINE void fp12_cyc_exp_x(fp12* r, const fp12* f, MBLS_LDS uint32_t* ls,
             int j = i;                                   // squarings for bits i..j, j = next set bit (or 0)
             while (j > 0 && !((MBLS_X_ABS >> j) & 1)) j--;
             fp12_cyc_sqr_n_lds(ls, lane, (uint32_t)(i - j + 1));
-            if ((MBLS_X_ABS >> j) & 1) { fp12 t; fp12_lds_load(&t, ls, lane); fp12_mul(&t, &t, f); fp12_lds_store(ls, lane, &t); }
+            if ((MBLS_X_ABS >> j) & 1) fp12_mul_lds(ls, lane, f);
             i = j - 1;
         }
         fp12_lds_load(&acc, ls, lane);

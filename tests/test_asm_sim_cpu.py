@@ -212,3 +212,28 @@ def test_miller_dbl_routine(skips):
         for e in range(3):
             assert (lds_get(m, 8192, 6 * k + 2 * e), lds_get(m, 8192, 6 * k + 2 * e + 1)) == Tn[e], (k, e)
     assert [from_limbs(m.a[144 + 12 * i:144 + 12 * i + 12]) for i in range(3)] == p1      # the G1 argument stays in its home
+
+
+def test_fp12_mul_routine():
+    lines, stats = t.build("fp12_mul")
+    assert not any("scratch" in l for l in lines)
+    rng = random.Random(21)
+    r2 = lambda: (rng.randrange(P), rng.randrange(P))
+    for trial in range(3):
+        a = ([r2(), r2(), r2()], [r2(), r2(), r2()])
+        b = ([r2(), r2(), r2()], [r2(), r2(), r2()])
+        if trial == 0:
+            b = ([(t.ONE_M, 0), (0, 0), (0, 0)], [(0, 0), (0, 0), (0, 0)])
+        m = Machine(ROUTINES); m.v[252] = 512
+        for i, x in enumerate([x for h in a for c in h for x in c]):
+            lds_put(m, 512, i, x)
+        for i, x in enumerate([x for h in b for c in h for x in c]):
+            m.v[96 + 12 * i:96 + 12 * i + 12] = limbs(x)
+        m.run(lines)
+        t0, t1 = f6mul(a[0], b[0]), f6mul(a[1], b[1])
+        c1 = f6sub(f6sub(f6mul(f6add(a[0], a[1]), f6add(b[0], b[1])), t0), t1)
+        c0 = f6add(t0, f6mulv(t1))
+        exp = [x for h in (c0, c1) for c in h for x in c]
+        assert [lds_get(m, 512, i) for i in range(12)] == exp
+        if trial == 0:
+            assert exp == [x for h in a for c in h for x in c]

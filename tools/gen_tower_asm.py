@@ -545,6 +545,28 @@ def prog_miller_dbl():
     return p
 
 
+def prog_fp12_mul():
+    """acc <- acc * g: acc in LDS slots 0..11 (tower order), g arriving in the twelve blocks v96..v239 (asm operands)."""
+    p = Prog()
+    al = [p.live_in(("l", i)) for i in range(12)]
+    gl = [p.live_in(("v", 96 + 12 * i)) for i in range(12)]
+    six = lambda l: ([(l[0], l[1]), (l[2], l[3]), (l[4], l[5])], [(l[6], l[7]), (l[8], l[9]), (l[10], l[11])])
+    a, g = six(al), six(gl)
+    t0 = p.mul6(a[0], g[0])
+    t1 = p.mul6(a[1], g[1])
+    c1 = p.mul6(p.add6(a[0], a[1]), p.add6(g[0], g[1]))
+    c1 = p.sub6(p.sub6(c1, t0), t1)
+    c0 = p.add6(t0, p.mul_v6(t1))
+    for i, v in enumerate([x for h in (c0, c1) for c in h for x in c]):
+        p.store(v, ("l", i))
+    return p
+
+
+def plain_shell(body):
+    """a routine without a loop: only the return address needs saving around the nested calls"""
+    return ["s_mov_b64 s[36:37], s[30:31]", ".p2align 6"] + body + ["s_mov_b64 s[30:31], s[36:37]"]
+
+
 def miller_dbl_shell(body):
     """f arrives in v96..v239 and the second G1 argument in v0..v35 (asm operands of the call site); both move to their AGPR
     homes around the loop. v253 carries the per-lane skip flags (bit 0: pair 0, bit 1: pair 1), s38 the number of iterations."""
@@ -582,7 +604,7 @@ def wrap_loop(lines, count_sgpr="s38", prologue=(), epilogue=()):
 
 
 def build(name):
-    prog = {"cyc_sqr": prog_cyc_sqr, "miller_dbl": prog_miller_dbl}[name]()
+    prog = {"cyc_sqr": prog_cyc_sqr, "miller_dbl": prog_miller_dbl, "fp12_mul": prog_fp12_mul}[name]()
     al = Alloc(prog)
     lines = al.run()
     return lines, al.stats
@@ -592,7 +614,8 @@ def main():
     here = os.path.dirname(os.path.abspath(__file__))
     path = os.path.join(os.path.dirname(here), "milagro_bls_amd", "csrc", "mbls_tower_asm.inc")
     txt = "// GENERATED by tools/gen_tower_asm.py -- do not edit.\n"
-    for name, macro, shell in (("cyc_sqr", "MBLS_CYC_SQR_ASM", wrap_loop), ("miller_dbl", "MBLS_MILLER_DBL_ASM", miller_dbl_shell)):
+    for name, macro, shell in (("cyc_sqr", "MBLS_CYC_SQR_ASM", wrap_loop), ("miller_dbl", "MBLS_MILLER_DBL_ASM", miller_dbl_shell),
+                               ("fp12_mul", "MBLS_FP12_MUL_ASM", plain_shell)):
         lines, stats = build(name)
         txt += emit(macro, shell(expand_calls(lines))) + "\n"
         print(name, len(lines), "lines", stats)
@@ -600,6 +623,9 @@ def main():
     vr = ",".join('"v%d"' % i for i in list(range(252)) + [254])
     txt += "// everything a tower routine may overwrite (v252 carries the LDS address and is preserved)\n"
     txt += "#define MBLS_TOWER_ASM_CLOBBERS %s,%s, \\\n    %s\n" % (vr, ",".join('"a%d"' % i for i in range(252)), sg)
+    txt += "// routines that take an Fp12 in v96..v239 as operands\n"
+    txt += "#define MBLS_FP12_ARG_ASM_CLOBBERS %s,%s, \\\n    %s\n" % (
+        ",".join('"v%d"' % i for i in list(range(0, 96)) + list(range(240, 252)) + [254]), ",".join('"a%d"' % i for i in range(252)), sg)
     txt += "// the Miller routine takes the G1 argument in v0..v35 and f in v96..v239 as operands\n"
     txt += "#define MBLS_MILLER_ASM_CLOBBERS %s,%s, \\\n    %s\n" % (
         ",".join('"v%d"' % i for i in list(range(36, 96)) + list(range(240, 252)) + [254]), ",".join('"a%d"' % i for i in range(252)), sg)
