@@ -6,7 +6,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmbls_hip.so")
-SOURCES = ["mbls_kernels.hip", "mbls_kernels_w2.hip"]
+SOURCES = ["mbls_kernels.hip"]
 DEPS = ["mbls_fp.h", "mbls_fp_asm.inc", "mbls_tower_asm.inc", "mbls_tower.h", "mbls_curve.h", "mbls_hash.h", "mbls_pairing.h", "mbls_lanes.h", "mbls_ops.h",
         "mbls_constants.inc", os.path.join("..", "..", "include", "mbls.h")]
 
@@ -39,7 +39,7 @@ def build(force=False, verbose=False):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     extra = os.environ.get("MBLS_EXTRA_HIPCC_FLAGS", "").split()
     objs, procs = [], []
-    for src in SOURCES:          # the two translation units compile in parallel
+    for src in SOURCES:
         obj = os.path.join(HERE, "_" + src.replace(".hip", ".o"))
         cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", os.path.join(CSRC, src), "-o", obj] + extra
         if verbose:

@@ -19,49 +19,40 @@
 #define MBLS_SLOT_S 25            // 6 Fp: Jacobian G2 accumulator for verify_multiple
 #define MBLS_SLOT_TOTAL 31
 #define WG 64
-// The five pipeline kernels exist in two register budgets, compiled as two translation units of this file:
-//   default (this TU)          512 registers per lane, 1 wave per SIMD -- fastest per wave; a batch of up to 2^16 items is
-//                              exactly one wave per SIMD on 256 CUs, so nothing is gained by allowing more;
-//   mbls_kernels_w2.hip (_w2)  256 registers, 2 waves per SIMD -- used for batches above 2^16 items, where the second
-//                              resident wave hides the first one's issue gaps (+8 % at 2^17, +12 % at 2^18 items measured).
-#ifndef MBLS_WAVES_PER_SIMD
-#define MBLS_WAVES_PER_SIMD 1
-#endif
-#ifndef MBLS_KSUF
-#define MBLS_KSUF(x) x
-#endif
-#define MBLS_LB __launch_bounds__(WG, MBLS_WAVES_PER_SIMD)
+// The pipeline kernels are built for one wave per SIMD (512 registers per lane): a batch of 2^16 items is exactly one wave
+// per SIMD on 256 CUs, and the hot loops are generated straight-line routines that already issue at the VALU rate with a
+// single wave, so a 256-register / two-wave variant is slower at every batch size (larger batches
+// simply run as successive rounds of workgroups).
+#define MBLS_LB __launch_bounds__(WG, 1)
 
 static __device__ __forceinline__ uint64_t gid() { return (uint64_t)blockIdx.x * WG + threadIdx.x; }
 
 // ------------------------------------------------------------------------------------------------ pipeline kernels
-__global__ void MBLS_LB MBLS_KSUF(k_aggregate)(mbls_ws ws, const uint8_t* pks, const uint32_t* offsets, uint32_t k, int fmt, int mode,
+__global__ void MBLS_LB k_aggregate(mbls_ws ws, const uint8_t* pks, const uint32_t* offsets, uint32_t k, int fmt, int mode,
                                                    uint32_t* status, uint64_t n) {
     uint64_t i = gid(); if (i >= n) return;
     const uint32_t pkb = fmt == MBLS_PK_COMPRESSED ? 48u : 96u;
     uint64_t first = offsets ? offsets[i] : (uint64_t)k * i; uint32_t cnt = offsets ? offsets[i + 1] - offsets[i] : k;
     uint32_t st; lane_aggregate(ws, i, pks + pkb * first, cnt, fmt, mode, &st); status[i] = st;
 }
-#ifndef MBLS_KERNELS_ONLY
 __global__ void __launch_bounds__(WG, 4) k_pk_decompress(const uint8_t* pks48, uint64_t nkeys, uint32_t* keys_xy, uint8_t* flags) {
     uint64_t j = gid(); if (j >= nkeys) return;
     lane_pk_decompress(j, pks48, keys_xy, flags);
 }
-#endif
-__global__ void MBLS_LB MBLS_KSUF(k_aggregate_decoded)(mbls_ws ws, const uint32_t* keys_xy, const uint8_t* flags, uint32_t k, int mode, uint32_t* status, uint64_t n) {
+__global__ void MBLS_LB k_aggregate_decoded(mbls_ws ws, const uint32_t* keys_xy, const uint8_t* flags, uint32_t k, int mode, uint32_t* status, uint64_t n) {
     uint64_t i = gid(); if (i >= n) return;
     uint32_t st; lane_aggregate_decoded(ws, i, keys_xy + 24 * (uint64_t)k * i, flags + (uint64_t)k * i, k, mode, &st); status[i] = st;
 }
-__global__ void MBLS_LB MBLS_KSUF(k_sig)(mbls_ws ws, const uint8_t* sigs, uint32_t* status, uint64_t n) {
+__global__ void MBLS_LB k_sig(mbls_ws ws, const uint8_t* sigs, uint32_t* status, uint64_t n) {
     uint64_t i = gid(); if (i >= n) return;
     uint32_t st = status[i]; lane_sig(ws, i, sigs + 96 * i, &st); status[i] = st;
 }
-__global__ void MBLS_LB MBLS_KSUF(k_hash)(mbls_ws ws, const uint8_t* msgs, uint32_t mlen, const uint64_t* moff, const uint32_t* mlens, uint64_t n) {
+__global__ void MBLS_LB k_hash(mbls_ws ws, const uint8_t* msgs, uint32_t mlen, const uint64_t* moff, const uint32_t* mlens, uint64_t n) {
     uint64_t i = gid(); if (i >= n) return;
     if (moff) lane_hash(ws, i, msgs + moff[i], mlens[i]); else lane_hash(ws, i, msgs + (uint64_t)mlen * i, mlen);
 }
-__global__ void MBLS_LB MBLS_KSUF(k_miller)(mbls_ws ws, uint64_t n) {
-#if MBLS_WAVES_PER_SIMD == 1 && !defined(MBLS_NO_LDS_STATE)
+__global__ void MBLS_LB k_miller(mbls_ws ws, uint64_t n) {
+#if !defined(MBLS_NO_LDS_STATE)
     // one wave per SIMD = 4 waves per CU: each wave can park 36 KB of loop state in LDS (144 of the 160 KB)
     __shared__ uint32_t tstore[2 * 72 * 64];      // the two running points of each lane
     uint64_t i = gid(); if (i >= n) return;
@@ -71,8 +62,8 @@ __global__ void MBLS_LB MBLS_KSUF(k_miller)(mbls_ws ws, uint64_t n) {
     lane_miller(ws, i);
 #endif
 }
-__global__ void MBLS_LB MBLS_KSUF(k_final)(mbls_ws ws, uint32_t* status, uint8_t* results, uint64_t n) {
-#if MBLS_WAVES_PER_SIMD == 1 && !defined(MBLS_NO_LDS_STATE)
+__global__ void MBLS_LB k_final(mbls_ws ws, uint32_t* status, uint8_t* results, uint64_t n) {
+#if !defined(MBLS_NO_LDS_STATE)
     __shared__ uint32_t accstore[144 * 64];       // the running power of the cyclotomic exponentiations
     uint64_t i = gid(); if (i >= n) return;
     uint32_t st = status[i]; uint8_t r; lane_final(ws, i, &st, &r, (MBLS_LDS uint32_t*)accstore, threadIdx.x, true); status[i] = st; results[i] = r;
@@ -81,14 +72,6 @@ __global__ void MBLS_LB MBLS_KSUF(k_final)(mbls_ws ws, uint32_t* status, uint8_t
     uint32_t st = status[i]; uint8_t r; lane_final(ws, i, &st, &r); status[i] = st; results[i] = r;
 #endif
 }
-#ifndef MBLS_KERNELS_ONLY
-// the 256-register variants (mbls_kernels_w2.hip)
-__global__ void k_aggregate_w2(mbls_ws ws, const uint8_t* pks, const uint32_t* offsets, uint32_t k, int fmt, int mode, uint32_t* status, uint64_t n);
-__global__ void k_aggregate_decoded_w2(mbls_ws ws, const uint32_t* keys_xy, const uint8_t* flags, uint32_t k, int mode, uint32_t* status, uint64_t n);
-__global__ void k_sig_w2(mbls_ws ws, const uint8_t* sigs, uint32_t* status, uint64_t n);
-__global__ void k_hash_w2(mbls_ws ws, const uint8_t* msgs, uint32_t mlen, const uint64_t* moff, const uint32_t* mlens, uint64_t n);
-__global__ void k_miller_w2(mbls_ws ws, uint64_t n);
-__global__ void k_final_w2(mbls_ws ws, uint32_t* status, uint8_t* results, uint64_t n);
 
 // accept bitmap: one 64-bit word per wave via ballot
 __global__ void MBLS_LB k_pack(const uint8_t* results, uint64_t* bitmap, uint64_t n) {
@@ -293,24 +276,21 @@ static int verify_pipeline(mbls_ctx* c, const uint8_t* d_sigs, const uint8_t* d_
     bool tm = c->timing;
     bool staged = (fmt == MBLS_PK_COMPRESSED) && !d_off && k > 1;   // lane-per-key decompression, then the per-item sums
     if (staged) { rc = reserve_keys(c, n * (uint64_t)k); if (rc) return rc; }
-    const bool big = n > (1u << 16);      // more than one wave per SIMD worth of items: 256-register variants
-#define MBLS_PICK(kern) (big ? kern##_w2 : kern)
     if (tm) HIPCHK(c, hipEventRecord(c->ev[0], s));
     if (staged) {
         hipLaunchKernelGGL(k_pk_decompress, dim3(nblk(n * (uint64_t)k)), dim3(WG), 0, s, d_pks, n * (uint64_t)k, c->d_keys_xy, c->d_key_flags);
-        hipLaunchKernelGGL(MBLS_PICK(k_aggregate_decoded), dim3(g), dim3(WG), 0, s, ws, (const uint32_t*)c->d_keys_xy, (const uint8_t*)c->d_key_flags, k, mode, st, n);
+        hipLaunchKernelGGL(k_aggregate_decoded, dim3(g), dim3(WG), 0, s, ws, (const uint32_t*)c->d_keys_xy, (const uint8_t*)c->d_key_flags, k, mode, st, n);
     } else
-        hipLaunchKernelGGL(MBLS_PICK(k_aggregate), dim3(g), dim3(WG), 0, s, ws, d_pks, d_off, k, fmt, mode, st, n);
+        hipLaunchKernelGGL(k_aggregate, dim3(g), dim3(WG), 0, s, ws, d_pks, d_off, k, fmt, mode, st, n);
     if (tm) HIPCHK(c, hipEventRecord(c->ev[1], s));
-    hipLaunchKernelGGL(MBLS_PICK(k_sig), dim3(g), dim3(WG), 0, s, ws, d_sigs, st, n);
+    hipLaunchKernelGGL(k_sig, dim3(g), dim3(WG), 0, s, ws, d_sigs, st, n);
     if (tm) HIPCHK(c, hipEventRecord(c->ev[2], s));
-    hipLaunchKernelGGL(MBLS_PICK(k_hash), dim3(g), dim3(WG), 0, s, ws, d_msgs, msg_len, (const uint64_t*)nullptr, (const uint32_t*)nullptr, n);
+    hipLaunchKernelGGL(k_hash, dim3(g), dim3(WG), 0, s, ws, d_msgs, msg_len, (const uint64_t*)nullptr, (const uint32_t*)nullptr, n);
     if (tm) HIPCHK(c, hipEventRecord(c->ev[3], s));
-    hipLaunchKernelGGL(MBLS_PICK(k_miller), dim3(g), dim3(WG), 0, s, ws, n);
+    hipLaunchKernelGGL(k_miller, dim3(g), dim3(WG), 0, s, ws, n);
     if (tm) HIPCHK(c, hipEventRecord(c->ev[4], s));
-    hipLaunchKernelGGL(MBLS_PICK(k_final), dim3(g), dim3(WG), 0, s, ws, st, d_results, n);
+    hipLaunchKernelGGL(k_final, dim3(g), dim3(WG), 0, s, ws, st, d_results, n);
     if (tm) HIPCHK(c, hipEventRecord(c->ev[5], s));
-#undef MBLS_PICK
     if (d_bitmap) hipLaunchKernelGGL(k_pack, dim3(g), dim3(WG), 0, s, d_results, d_bitmap, n);
     if (tm) {
         HIPCHK(c, hipEventRecord(c->ev[6], s));
@@ -663,4 +643,3 @@ extern "C" int mbls_verify_multiple_aggregate_signatures(mbls_ctx* c, const uint
     if (mbls_verify_multiple_aggregate_signatures_device(c, ds.as<uint8_t>(), da.as<uint8_t>(), dm.as<uint8_t>(), msg_len, dr.as<uint64_t>(), n, &result, nullptr)) return 0;
     return result;
 }
-#endif  // MBLS_KERNELS_ONLY
