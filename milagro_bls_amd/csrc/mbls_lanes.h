@@ -51,14 +51,29 @@ MBLS_FN void ws_st2(const mbls_ws& ws, int slot, uint64_t i, const fp2& v) { ws_
 MBLS_FN void lane_aggregate(const mbls_ws& ws, uint64_t i, const uint8_t* pks, uint32_t k, int fmt, int mode, uint32_t* status) {
     uint32_t st = 0;
     g1j acc; g1_set_inf(&acc);
-    const uint32_t pkb = (fmt == MBLS_PK_COMPRESSED) ? 48u : 96u;
-    for (uint32_t j = 0; j < k; j++) {
-        fp x, y; bool inf;
-        int e = (fmt == MBLS_PK_COMPRESSED) ? g1_decode_compressed(&x, &y, &inf, pks + (uint64_t)pkb * j)
-                                           : g1_decode_uncompressed(&x, &y, &inf, pks + (uint64_t)pkb * j);
-        if (e) { st |= MBLS_ST_BAD_PK_ENCODING; inf = true; }
-        if (inf) st |= MBLS_ST_PK_INFINITY;
-        g1_madd(&acc, &acc, x, y, inf);
+    if (fmt == MBLS_PK_COMPRESSED) {
+        for (uint32_t j = 0; j < k; j++) {
+            fp x, y; bool inf;
+            int e = g1_decode_compressed(&x, &y, &inf, pks + (uint64_t)48 * j);
+            if (e) { st |= MBLS_ST_BAD_PK_ENCODING; inf = true; }
+            if (inf) st |= MBLS_ST_PK_INFINITY;
+            g1_madd(&acc, &acc, x, y, inf);
+        }
+    } else {
+        // 96-byte keys: dword loads when the buffer allows, and the next key is requested before the current one is used
+        // (with one wave per SIMD nothing else hides the memory latency)
+        const bool al = (((uintptr_t)pks) & 15u) == 0;
+        fp nwx = fp_zero(), nwy = fp_zero();
+        if (k) g1_load_words96(&nwx, &nwy, pks, al);
+        for (uint32_t j = 0; j < k; j++) {
+            fp wx = nwx, wy = nwy;
+            if (j + 1 < k) g1_load_words96(&nwx, &nwy, pks + (uint64_t)96 * (j + 1), al);
+            fp x, y; bool inf;
+            int e = g1_decode_uncompressed_w(&x, &y, &inf, wx, wy);
+            if (e) { st |= MBLS_ST_BAD_PK_ENCODING; inf = true; }
+            if (inf) st |= MBLS_ST_PK_INFINITY;
+            g1_madd(&acc, &acc, x, y, inf);
+        }
     }
     if (mode == MBLS_MODE_FAST_AGGREGATE) {
         if (k == 0) st |= MBLS_ST_NO_KEYS;
