@@ -28,7 +28,7 @@ PB = 240                                           # v240..v251: the modulus
 U = 72                                             # v72..v83: scratch of the modular add/sub (dead between calls)
 LADDR = "v252"                                     # byte address of this lane's column in the LDS state
 AG = [12 * i for i in range(21)]                   # a0..a251
-NLDS = 13                                          # 13 Fp slots of 64 x 12 dwords in a 160-dword-per-lane LDS budget
+NLDS = 12                                          # Fp slots of the LDS state (the kernels allocate 144 dwords per lane)
 CARRY_B = "s[62:63]"
 CARRY_C, CARRY_D = "s[50:51]", "s[52:53]"          # carries of the second chain of an interleaved pair
 U2 = 84                                            # v84..v95: scratch of that second chain
