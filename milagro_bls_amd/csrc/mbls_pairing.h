@@ -143,8 +143,7 @@ MBLS_FN void miller_dbl_n_asm(fp12* f, fp npx1, fp py1, fp pz3, uint32_t flags, 
     fp f0 = c[0], f1 = c[1], f2 = c[2], f3 = c[3], f4 = c[4], f5 = c[5], f6 = c[6], f7 = c[7], f8 = c[8], f9 = c[9], f10 = c[10], f11 = c[11];
     fp d0 = npx1, d1 = py1, d2 = pz3;      // the operand registers are overwritten by the routine
     asm volatile(MBLS_ASM_CALL("mbls_miller_dbl_asm_fn")
-                 : "+{v[96:107]}"(f0), "+{v[108:119]}"(f1), "+{v[120:131]}"(f2), "+{v[132:143]}"(f3), "+{v[144:155]}"(f4), "+{v[156:167]}"(f5),
-                   "+{v[168:179]}"(f6), "+{v[180:191]}"(f7), "+{v[192:203]}"(f8), "+{v[204:215]}"(f9), "+{v[216:227]}"(f10), "+{v[228:239]}"(f11),
+                 : MBLS_F12_ARG_REGS(f),
                    "+{v[0:11]}"(d0), "+{v[12:23]}"(d1), "+{v[24:35]}"(d2)
                  : "{v252}"(addr), "{v253}"(flags), "{s38}"(n)
                  : MBLS_MILLER_ASM_CLOBBERS);

@@ -25,18 +25,20 @@ MBLS_FN fp2 fp2_dbl(const fp2& a) { return fp2_add(a, a); }
 MBLS_FN fp2 fp2_conj(const fp2& a) { fp2 r; r.c0 = a.c0; r.c1 = fp_neg(a.c1); return r; }
 #if MBLS_DEVICE_ASM && !defined(MBLS_NO_FP2_ASM)
 // Fp2 multiplication as one hand-written routine with a private calling convention (tools/gen_fp_asm.py, fp2_mul_body):
-// operands a0,a1,b0,b1 in v[0:47], results in v[48:71]. It computes c0 = a0 b0 + a1 (p - b1) and c1 = a0 b1 + a1 b0 as two
-// sum-of-two-products scans with one Montgomery reduction each: 864 multiply-accumulates and no modular additions, against
-// 900 + five modular additions + three calls for Karatsuba. The routine is reached by an s_swappc inside an asm statement,
-// so the 32-VGPR argument limit of the regular calling convention does not apply; the statement's clobber list is the contract.
+// operands a0,a1,b0,b1 in v[0:47] (overwritten), results in v[48:71]. It computes c0 = a0 b0 + a1 (2p - b1) and
+// c1 = a0 b1 + a1 b0 as two sum-of-two-products scans with one Montgomery reduction each and no modular additions, on 14
+// digits of 28 bits so that a multiply-accumulate is a single v_mad_u64_u32 (1176 of them, against 900 x 2 instructions +
+// five modular additions + three calls for Karatsuba on 32-bit limbs). The routine is reached by an s_swappc inside an asm
+// statement, so the 32-VGPR argument limit of the regular calling convention does not apply; the statement's operand and
+// clobber lists are the contract.
 extern "C" __device__ __attribute__((noinline, used, aligned(64))) void mbls_fp2_mul_asm_fn() {
     asm volatile(MBLS_FP2_MUL_ASM);
 }
 MBLS_FN fp2 fp2_mul(const fp2& a, const fp2& b) {
-    fp c0, c1;
+    fp c0, c1, a0 = a.c0, a1 = a.c1, b0 = b.c0, b1 = b.c1;          // the routine overwrites its operand registers
     asm volatile(MBLS_ASM_CALL("mbls_fp2_mul_asm_fn")
-                 : "={v[48:59]}"(c0), "={v[60:71]}"(c1)
-                 : "{v[0:11]}"(a.c0), "{v[12:23]}"(a.c1), "{v[24:35]}"(b.c0), "{v[36:47]}"(b.c1)
+                 : "={v[48:59]}"(c0), "={v[60:71]}"(c1), "+{v[0:11]}"(a0), "+{v[12:23]}"(a1), "+{v[24:35]}"(b0), "+{v[36:47]}"(b1)
+                 :
                  : MBLS_FP2_MUL_CLOBBERS, "s30", "s31");
     fp2 r; r.c0 = c0; r.c1 = c1; return r;
 }
@@ -53,10 +55,10 @@ extern "C" __device__ __attribute__((noinline, used, aligned(64))) void mbls_fp2
     asm volatile(MBLS_FP2_SQR_ASM);
 }
 MBLS_FN fp2 fp2_sqr(const fp2& a) {
-    fp c0, c1;
+    fp c0, c1, a0 = a.c0, a1 = a.c1;
     asm volatile(MBLS_ASM_CALL("mbls_fp2_sqr_asm_fn")
-                 : "={v[24:35]}"(c0), "={v[36:47]}"(c1)
-                 : "{v[0:11]}"(a.c0), "{v[12:23]}"(a.c1)
+                 : "={v[24:35]}"(c0), "={v[36:47]}"(c1), "+{v[0:11]}"(a0), "+{v[12:23]}"(a1)
+                 :
                  : MBLS_FP2_SQR_CLOBBERS, "s30", "s31");
     fp2 r; r.c0 = c0; r.c1 = c1; return r;
 }
@@ -257,8 +259,7 @@ MBLS_FN void fp12_mul_lds(MBLS_LDS uint32_t* ls, uint32_t lane, const fp12* g) {
     const fp* c = &g->c0.c0.c0;
     fp g0 = c[0], g1 = c[1], g2 = c[2], g3 = c[3], g4 = c[4], g5 = c[5], g6 = c[6], g7 = c[7], g8 = c[8], g9 = c[9], g10 = c[10], g11 = c[11];
     asm volatile(MBLS_ASM_CALL("mbls_fp12_mul_asm_fn")          // the operand registers are overwritten: read-write operands
-                 : "+{v[96:107]}"(g0), "+{v[108:119]}"(g1), "+{v[120:131]}"(g2), "+{v[132:143]}"(g3), "+{v[144:155]}"(g4), "+{v[156:167]}"(g5),
-                   "+{v[168:179]}"(g6), "+{v[180:191]}"(g7), "+{v[192:203]}"(g8), "+{v[204:215]}"(g9), "+{v[216:227]}"(g10), "+{v[228:239]}"(g11)
+                 : MBLS_F12_ARG_REGS(g)
                  : "{v252}"(addr)
                  : MBLS_FP12_ARG_ASM_CLOBBERS);
 }

@@ -124,6 +124,20 @@ class Machine:
                 self.wr(args[0], self.rd(args[1]) * self.rd(args[2]))
             elif op in ("v_cndmask_b32_e32", "v_cndmask_b32_e64"):
                 self.wr(args[0], self.rd(args[2]) if self.rd(args[3]) else self.rd(args[1]))
+            elif op == "v_bfe_u32":
+                self.wr(args[0], (self.rd(args[1]) >> self.rd(args[2])) & ((1 << self.rd(args[3])) - 1))
+            elif op in ("v_and_b32_e32", "v_and_b32_e64"):
+                self.wr(args[0], self.rd(args[1]) & self.rd(args[2]))
+            elif op == "v_lshrrev_b32_e64":
+                self.wr(args[0], self.rd(args[2]) >> self.rd(args[1]))
+            elif op == "v_lshlrev_b32_e64":
+                self.wr(args[0], self.rd(args[2]) << self.rd(args[1]))
+            elif op == "v_lshrrev_b64":
+                self.wr(args[0], self.rd(args[2]) >> self.rd(args[1]))
+            elif op == "v_lshl_or_b32":
+                self.wr(args[0], (self.rd(args[1]) << self.rd(args[2])) | self.rd(args[3]))
+            elif op == "v_sub_u32_e32":
+                self.wr(args[0], self.rd(args[1]) - self.rd(args[2]))
             elif op == "v_lshlrev_b32_e32":
                 self.wr(args[0], self.rd(args[2]) << self.rd(args[1]))
             elif op == "v_alignbit_b32":

@@ -1,66 +1,23 @@
 #!/usr/bin/env python3
-"""Generate milagro_bls_amd/csrc/mbls_fp_asm.inc: the hand-scheduled gfx950 body of the Montgomery multiplication.
+"""Generate milagro_bls_amd/csrc/mbls_fp_asm.inc: the hand-scheduled gfx950 multiplication routines.
 
-One asm statement per multiplication, physical registers chosen to coincide with the AMDGPU calling convention
-(a in v[0:11], b in v[12:23], result in v[0:11]), so a call costs no argument shuffling and hipcc cannot interleave
-its own s_nop padding (it pads every inline-asm boundary, which costs an issue slot per multiply-accumulate when only
-one wave lives on the SIMD). Product scanning over a 96-bit column accumulator v[36:37], v38:
-    v_mad_u64_u32 v[36:37], vcc, x, y, v[36:37] ; v_addc_co_u32 v38, vcc, 0, v38, vcc
-Run:  python3 tools/gen_fp_asm.py   (output is committed; tests/test_build_cpu.py checks it is up to date)
+* fp_mul_body      -- one Montgomery product in the regular calling convention (a v[0:11], b v[12:23] -> v[0:11]), one asm
+                      statement: a call moves no arguments and hipcc cannot pad the stream (it pads every inline-asm
+                      boundary). Product scanning over 12 x 32-bit limbs, v_mad_u64_u32 + v_addc_co_u32 per product (Chain).
+* fp2_mul_body, fp2_sqr_body, fp2_mulfp_body -- Fp2 product / square / Fp2 x Fp with a private calling convention (operands in
+                      fixed blocks of v0..v47, reached by s_swappc). Sum-of-products scans with one Montgomery reduction per
+                      output coefficient, on 14 digits of 28 bits so that a multiply-accumulate is a single v_mad_u64_u32
+                      (Chain28), two independent scans interleaved instruction by instruction.
+Run:  python3 tools/gen_fp_asm.py   (output is committed; tests/test_asm_sim_cpu.py interprets every routine on the CPU and
+checks that the committed file is up to date)
 """
 import os
 P = 0x1a0111ea397fe69a4b1ba7b6434bacd764774b84f38512bf6730d2a0f6b0f6241eabfffeb153ffffb9feffffffffaaab
 NP0 = (-pow(P, -1, 1 << 32)) % (1 << 32)
 PL = [(P >> (32 * i)) & 0xFFFFFFFF for i in range(12)]
-A = lambda i: "v%d" % i            # a[i], later t[i]
-B = lambda i: "v%d" % (12 + i)
-M = lambda i: "v%d" % (24 + i)     # m[i], later d[i]
 # scalar registers that the calling convention leaves to the callee (s40-s47, s56-s63): no save/restore code is generated
 SP = lambda i: "s%d" % (40 + i if i < 8 else 56 + i - 8)    # modulus limbs
 SNP = "s60"
-ACC, ACC_HI, LO, MID = "v[36:37]", "v38", "v36", "v37"
-
-
-def mac(x, y):
-    return ["v_mad_u64_u32 %s, vcc, %s, %s, %s" % (ACC, x, y, ACC), "v_addc_co_u32_e32 %s, vcc, 0, %s, vcc" % (ACC_HI, ACC_HI)]
-
-
-def body(square=False):
-    L = []
-    for i in range(12):
-        L.append("s_mov_b32 %s, 0x%08x" % (SP(i), PL[i]))
-    L.append("s_mov_b32 %s, 0x%08x" % (SNP, NP0))
-    L += ["v_mov_b32_e32 %s, 0" % LO, "v_mov_b32_e32 %s, 0" % MID, "v_mov_b32_e32 %s, 0" % ACC_HI]
-    bb = (lambda i: A(i)) if square else B
-    for k in range(24):
-        lo, hi = max(0, k - 11), min(k, 11)
-        for i in range(lo, hi + 1):
-            L += mac(A(i), bb(k - i))
-        if k < 12:
-            for i in range(0, k):
-                L += mac(SP(k - i), M(i))
-            L.append("v_mul_lo_u32 %s, %s, %s" % (M(k), SNP, LO))
-            L += mac(SP(0), M(k))
-            # shift the accumulator by one limb (low word is now zero)
-            L += ["v_mov_b32_e32 %s, %s" % (LO, MID), "v_mov_b32_e32 %s, %s" % (MID, ACC_HI), "v_mov_b32_e32 %s, 0" % ACC_HI]
-        else:
-            for i in range(k - 11, 12):
-                L += mac(SP(k - i), M(i))
-            # a[k-12] is dead from column k-1 on (its last use is column k-1): the result limb goes there
-            L += ["v_mov_b32_e32 %s, %s" % (A(k - 12), LO), "v_mov_b32_e32 %s, %s" % (LO, MID), "v_mov_b32_e32 %s, %s" % (MID, ACC_HI),
-                  "v_mov_b32_e32 %s, 0" % ACC_HI]
-    # conditional subtraction of p: d = t - p in the m registers
-    # (an SGPR source plus the VCC carry-in would be two constant-bus reads: the modulus goes through the dead b registers)
-    for i in range(12):
-        L.append("v_mov_b32_e32 %s, %s" % (B(i), SP(i)))
-    L.append("v_sub_co_u32_e32 %s, vcc, %s, %s" % (M(0), A(0), B(0)))
-    for i in range(1, 12):
-        L.append("v_subb_co_u32_e32 %s, vcc, %s, %s, vcc" % (M(i), A(i), B(i)))
-    # take d when there was no borrow or the 13th limb is set
-    L += ["v_cmp_ne_u32_e64 s[62:63], 0, %s" % LO, "s_not_b64 vcc, vcc", "s_nop 1", "s_or_b64 vcc, vcc, s[62:63]", "s_nop 1"]
-    for i in range(12):
-        L.append("v_cndmask_b32_e32 %s, %s, %s, vcc" % (A(i), A(i), M(i)))
-    return L
 
 
 class Chain:
@@ -144,68 +101,6 @@ CARRY_B = "s[62:63]"
 VR = lambda base: (lambda i: "v%d" % (base + i))
 
 
-def fp2_mul_body():
-    """c0 = a0 b0 + a1 (p - b1), c1 = a0 b1 + a1 b0 as two sum-of-two-products scans with ONE Montgomery reduction each
-    (864 multiply-accumulates instead of 3 x 300 for Karatsuba, no modular additions besides the negation of b1). The two
-    scans are independent and are interleaved instruction by instruction (carries in vcc and s[62:63]) so that a wave that is
-    alone on its SIMD always has an independent instruction to issue.
-    Private calling convention (see fp2_mul in mbls_tower.h): a0 v[0:11], a1 v[12:23], b0 v[24:35], b1 v[36:47] (all preserved);
-    c0 -> v[48:59], c1 -> v[60:71]; scratch v72-v92."""
-    A0, A1, B0, B1, C0, C1, NB = VR(0), VR(12), VR(24), VR(36), VR(48), VR(60), VR(72)
-    tmp = "v92"
-    L = load_modulus()
-    # nb1 = p - b1 (b1 < p; b1 = 0 gives p, which is fine as a factor)
-    L.append("v_mov_b32_e32 %s, %s" % (tmp, SP(0)))
-    L.append("v_sub_co_u32_e32 %s, vcc, %s, %s" % (NB(0), tmp, B1(0)))
-    for i in range(1, 12):
-        L.append("v_mov_b32_e32 %s, %s" % (tmp, SP(i)))
-        L.append("v_subb_co_u32_e32 %s, vcc, %s, %s, vcc" % (NB(i), tmp, B1(i)))
-    L += zip2(Chain([(A0, B0), (A1, NB)], C0, 84, "vcc").stream(), Chain([(A0, B1), (A1, B0)], C1, 88, CARRY_B).stream())
-    L += cond_sub(C0, NB, tmp)
-    L += cond_sub(C1, NB, tmp)
-    return L
-
-
-def fp2_sqr_body():
-    """c0 = (a0 + a1)(a0 - a1 + p), c1 = a0 (2 a1): two single-product scans on unreduced operands (all < 2p, so the product
-    is < 1.41 p after reduction and one conditional subtraction finishes it); 600 multiply-accumulates, no modular additions;
-    the two scans interleaved like in fp2_mul.
-    Private convention: a0 v[0:11], a1 v[12:23] (preserved); c0 -> v[24:35], c1 -> v[36:47]; scratch v48-v92."""
-    A0, A1, C0, C1, S, D, A1D = VR(0), VR(12), VR(24), VR(36), VR(48), VR(60), VR(72)
-    tmp = "v92"
-    L = load_modulus()
-    L.append("v_add_co_u32_e32 %s, vcc, %s, %s" % (S(0), A0(0), A1(0)))
-    for i in range(1, 12):
-        L.append("v_addc_co_u32_e32 %s, vcc, %s, %s, vcc" % (S(i), A0(i), A1(i)))
-    L.append("v_mov_b32_e32 %s, %s" % (tmp, SP(0)))
-    L.append("v_add_co_u32_e32 %s, vcc, %s, %s" % (D(0), A0(0), tmp))
-    for i in range(1, 12):
-        L.append("v_mov_b32_e32 %s, %s" % (tmp, SP(i)))
-        L.append("v_addc_co_u32_e32 %s, vcc, %s, %s, vcc" % (D(i), A0(i), tmp))
-    L.append("v_sub_co_u32_e32 %s, vcc, %s, %s" % (D(0), D(0), A1(0)))
-    for i in range(1, 12):
-        L.append("v_subb_co_u32_e32 %s, vcc, %s, %s, vcc" % (D(i), D(i), A1(i)))
-    L.append("v_lshlrev_b32_e32 %s, 1, %s" % (A1D(0), A1(0)))
-    for i in range(1, 12):
-        L.append("v_alignbit_b32 %s, %s, %s, 31" % (A1D(i), A1(i), A1(i - 1)))
-    L += zip2(Chain([(S, D)], C0, 84, "vcc").stream(), Chain([(A0, A1D)], C1, 88, CARRY_B).stream())
-    L += cond_sub(C0, S, tmp)
-    L += cond_sub(C1, S, tmp)
-    return L
-
-
-def fp2_mulfp_body():
-    """c0 = a0 s, c1 = a1 s (an Fp2 element times an Fp element) as two interleaved single-product scans.
-    Private convention: a0 v[0:11], a1 v[12:23], s v[24:35] (preserved); c0 -> v[36:47], c1 -> v[48:59]; scratch v60-v92."""
-    A0, A1, S, C0, C1, DF = VR(0), VR(12), VR(24), VR(36), VR(48), VR(60)
-    tmp = "v92"
-    L = load_modulus()
-    L += zip2(Chain([(A0, S)], C0, 84, "vcc").stream(), Chain([(A1, S)], C1, 88, CARRY_B).stream())
-    L += cond_sub(C0, DF, tmp)
-    L += cond_sub(C1, DF, tmp)
-    return L
-
-
 def fp_mul_body():
     """Single Montgomery product in the regular calling convention (a v[0:11], b v[12:23], result v[0:11]; v24-v39 scratch):
     one product-scanning chain, every instruction 8 bytes long and 8-byte aligned."""
@@ -222,19 +117,181 @@ def fp_mul_body():
     return L
 
 
+# ----------------------------------------------------------------------------------------------------------------------
+# 28-bit-digit multiplication core. Inside a routine the operands are re-cut into 14 digits of 28 bits, so that a whole column
+# of the product scan (up to 28 products of 56/57 bits plus 14 reduction products) accumulates in ONE 64-bit register pair
+# without carries: a multiply-accumulate is a single v_mad_u64_u32 instead of v_mad_u64_u32 + v_addc_co_u32. The Montgomery
+# radix of 14 digits is 2^392; the first factor of every product is converted as a * 2^8 (digit j = bits [28j-8, 28j+20)),
+# so the routine still returns a b 2^-384 and the Montgomery domain of the rest of the library (R = 2^384, 12 x 32-bit
+# limbs between routines) is unchanged.
+M28 = (1 << 28) - 1
+P28 = [(P >> (28 * i)) & M28 for i in range(14)]
+NP28 = (-pow(P, -1, 1 << 28)) % (1 << 28)
+SP28 = lambda i: "s%d" % (40 + i if i < 8 else 56 + i - 8)      # 14 digits of p: s40-s47, s56-s61
+SNP28, SMASK28 = "s64", "s65"
+# digits of 2p, each raised above 2^28 by borrowing from the next one, so that digit-wise subtraction of a value < 2p never
+# underflows: NEG2P[j] - b[j] are the (29-bit) digits of 2p - b
+_d2p = [((2 * P) >> (28 * i)) & M28 for i in range(14)]
+NEG2P = [_d2p[0] + (1 << 28)] + [_d2p[i] + (1 << 28) - 1 for i in range(1, 13)] + [_d2p[13] - 1]
+assert sum(d << (28 * i) for i, d in enumerate(NEG2P)) == 2 * P and NEG2P[13] > (P >> 364)     # fine for any b <= p
+
+
+def load_modulus28():
+    L = ["s_mov_b32 %s, 0x%08x" % (SP28(i), P28[i]) for i in range(14)]
+    L += ["s_mov_b32 %s, 0x%08x" % (SNP28, NP28), "s_mov_b32 %s, 0x%08x" % (SMASK28, M28)]
+    return L
+
+
+def conv28(dst, src, aform):
+    """14 digits of 28 bits from 12 x 32-bit words; aform: digits of src * 2^8"""
+    L = []
+    for j in range(14):
+        o = 28 * j - (8 if aform else 0)
+        d = dst(j)
+        if o < 0:
+            L += ["v_lshlrev_b32_e64 %s, 8, %s" % (d, src(0)), "v_and_b32_e64 %s, %s, %s" % (d, d, SMASK28)]
+            continue
+        q, r = o >> 5, o & 31
+        if o + 28 > 384:
+            assert q == 11
+            L.append("v_lshrrev_b32_e64 %s, %d, %s" % (d, r, src(11)))
+        elif r == 0:
+            L.append("v_and_b32_e64 %s, %s, %s" % (d, src(q), SMASK28))
+        elif r + 28 == 32:
+            L.append("v_lshrrev_b32_e64 %s, %d, %s" % (d, r, src(q)))
+        elif r + 28 < 32:
+            L.append("v_bfe_u32 %s, %s, %d, 28" % (d, src(q), r))
+        else:
+            L += ["v_alignbit_b32 %s, %s, %s, %d" % (d, src(q + 1), src(q), r), "v_and_b32_e64 %s, %s, %s" % (d, d, SMASK28)]
+    return L
+
+
+def to32(dst, t):
+    """12 x 32-bit words from 14 digits of exactly 28 bits"""
+    L = []
+    for q in range(12):
+        j, off = (32 * q) // 28, (32 * q) % 28
+        if off == 0:
+            L.append("v_lshl_or_b32 %s, %s, 28, %s" % (dst(q), t(j + 1), t(j)))
+        else:
+            L.append("v_lshrrev_b32_e64 %s, %d, %s" % (dst(q), off, t(j)))
+            L.append("v_lshl_or_b32 %s, %s, %d, %s" % (dst(q), t(j + 1), 28 - off, dst(q)))
+            assert 56 - off >= 32
+    return L
+
+
+class Chain28:
+    """product scan over 28-bit digits: sum of the listed operand products (first factors in a*2^8 form), Montgomery-reduced by
+    2^392; the quotient digits and then the result digits live in `out` (14 registers); acc: an aligned register pair"""
+
+    def __init__(self, pairs, out, acc, carry):
+        self.pairs, self.out, self.acc, self.carry = pairs, out, acc, carry
+
+    def stream(self):
+        out, cy = self.out, self.carry
+        acc, lo = "v[%d:%d]" % (self.acc, self.acc + 1), "v%d" % self.acc
+        S = []
+        first = True
+        for k in range(28):
+            macs = []
+            for i in range(max(0, k - 13), min(k, 13) + 1):
+                for (X, Y) in self.pairs:
+                    macs.append((X(i), Y(k - i)))
+            if k < 14:
+                macs += [(SP28(k - i), out(i)) for i in range(k)]
+            else:
+                macs += [(SP28(k - i), out(i)) for i in range(k - 13, 14)]
+            for (x, y) in macs:
+                S.append("v_mad_u64_u32 %s, %s, %s, %s, %s" % (acc, cy, x, y, "0" if first else acc))
+                first = False
+            if k < 14:
+                S.append("v_mul_lo_u32 %s, %s, %s" % (out(k), lo, SNP28))
+                S.append("v_and_b32_e64 %s, %s, %s" % (out(k), out(k), SMASK28))
+                S.append("v_mad_u64_u32 %s, %s, %s, %s, %s" % (acc, cy, SP28(0), out(k), acc))
+                S.append("v_lshrrev_b64 %s, 28, %s" % (acc, acc))
+            else:
+                S.append("v_and_b32_e64 %s, %s, %s" % (out(k - 14), lo, SMASK28))
+                if k < 27:
+                    S.append("v_lshrrev_b64 %s, 28, %s" % (acc, acc))
+        return S
+
+
+def cond_sub32(out, diff, tmp):
+    """out = out - p if that does not borrow; p as literals (the SGPRs hold the 28-bit digits)"""
+    S = ["v_mov_b32_e32 %s, 0x%08x" % (tmp, PL[0]), "v_sub_co_u32_e64 %s, vcc, %s, %s" % (diff(0), out(0), tmp)]
+    for i in range(1, 12):
+        S.append("v_mov_b32_e32 %s, 0x%08x" % (tmp, PL[i]))
+        S.append("v_subb_co_u32_e64 %s, vcc, %s, %s, vcc" % (diff(i), out(i), tmp))
+    for i in range(12):
+        S.append("v_cndmask_b32_e64 %s, %s, %s, vcc" % (out(i), diff(i), out(i)))     # borrow ? t : t - p
+    return S
+
+
+def fp2_mul_body():
+    """Fp2 product on the 28-bit core. a0 v[0:11], a1 v[12:23], b0 v[24:35], b1 v[36:47] (all OVERWRITTEN);
+    c0 -> v[48:59], c1 -> v[60:71]; scratch up to v117."""
+    A0w, A1w, B0w, B1w = VR(0), VR(12), VR(24), VR(36)
+    A0, A1, B0, B1, NB = VR(48), VR(62), VR(76), VR(90), VR(104)
+    TA, TB = VR(0), VR(14)
+    C0, C1, DF = VR(48), VR(60), VR(72)
+    L = load_modulus28()
+    L += conv28(A0, A0w, True) + conv28(A1, A1w, True) + conv28(B0, B0w, False) + conv28(B1, B1w, False)
+    L += ["v_sub_u32_e32 %s, 0x%08x, %s" % (NB(j), NEG2P[j], B1(j)) for j in range(14)]        # digits of 2p - b1
+    L += zip2(Chain28([(A0, B0), (A1, NB)], TA, 28, "vcc").stream(), Chain28([(A0, B1), (A1, B0)], TB, 30, CARRY_B).stream())
+    L += to32(C0, TA) + to32(C1, TB)
+    L += cond_sub32(C0, DF, "v84") + cond_sub32(C1, DF, "v84")
+    return L
+
+
+def fp2_sqr_body():
+    """Fp2 square on the 28-bit core: c0 = (a0 + a1)(a0 - a1 + p), c1 = a0 (2 a1). a0 v[0:11], a1 v[12:23] (OVERWRITTEN);
+    c0 -> v[24:35], c1 -> v[36:47]; scratch up to v103."""
+    A0w, A1w, Sw, Dw = VR(0), VR(12), VR(24), VR(36)
+    SA, DB, A0A, A1D = VR(48), VR(62), VR(76), VR(90)
+    TA, TB = VR(0), VR(14)
+    C0, C1, DF = VR(24), VR(36), VR(48)
+    tmp = "v104"
+    L = load_modulus28()
+    L.append("v_add_co_u32_e64 %s, vcc, %s, %s" % (Sw(0), A0w(0), A1w(0)))
+    for i in range(1, 12):
+        L.append("v_addc_co_u32_e64 %s, vcc, %s, %s, vcc" % (Sw(i), A0w(i), A1w(i)))
+    L.append("v_mov_b32_e32 %s, 0x%08x" % (tmp, PL[0]))
+    L.append("v_add_co_u32_e64 %s, vcc, %s, %s" % (Dw(0), A0w(0), tmp))
+    for i in range(1, 12):
+        L.append("v_mov_b32_e32 %s, 0x%08x" % (tmp, PL[i]))
+        L.append("v_addc_co_u32_e64 %s, vcc, %s, %s, vcc" % (Dw(i), A0w(i), tmp))
+    L.append("v_sub_co_u32_e64 %s, vcc, %s, %s" % (Dw(0), Dw(0), A1w(0)))
+    for i in range(1, 12):
+        L.append("v_subb_co_u32_e64 %s, vcc, %s, %s, vcc" % (Dw(i), Dw(i), A1w(i)))
+    L += conv28(SA, Sw, True) + conv28(DB, Dw, False) + conv28(A0A, A0w, True) + conv28(A1D, A1w, False)
+    L += ["v_lshlrev_b32_e64 %s, 1, %s" % (A1D(j), A1D(j)) for j in range(14)]                   # digits of 2 a1 (29 bits)
+    L += zip2(Chain28([(SA, DB)], TA, 28, "vcc").stream(), Chain28([(A0A, A1D)], TB, 30, CARRY_B).stream())
+    L += to32(C1, TB) + to32(C0, TA)          # in this order: c0's registers overlap the digits of the second chain
+    L += cond_sub32(C0, DF, tmp) + cond_sub32(C1, DF, tmp)
+    return L
+
+
+def fp2_mulfp_body():
+    """c0 = a0 s, c1 = a1 s on the 28-bit core. a0 v[0:11], a1 v[12:23], s v[24:35] (OVERWRITTEN); c0 -> v[36:47],
+    c1 -> v[48:59]; scratch up to v89."""
+    A0w, A1w, Sw = VR(0), VR(12), VR(24)
+    A0, A1, SB = VR(48), VR(62), VR(76)
+    TA, TB = VR(0), VR(14)
+    C0, C1, DF = VR(36), VR(48), VR(60)
+    L = load_modulus28()
+    L += conv28(A0, A0w, True) + conv28(A1, A1w, True) + conv28(SB, Sw, False)
+    L += zip2(Chain28([(A0, SB)], TA, 28, "vcc").stream(), Chain28([(A1, SB)], TB, 30, CARRY_B).stream())
+    L += to32(C0, TA) + to32(C1, TB)
+    L += cond_sub32(C0, DF, "v72") + cond_sub32(C1, DF, "v72")
+    return L
+
+
 def emit(name, lines):
     out = ["#define %s \\" % name]
     for l in lines:
         out.append('    "%s\\n\\t" \\' % l)
     out.append('    ""')
     return "\n".join(out)
-
-
-def square_body():
-    # squaring in a square-only call: b is not an argument, so a[k-12] may not be overwritten while a[j] (j = k - i) is still
-    # needed as the second factor: a[j] with j up to 11 is needed until column 22, so the result goes to v[12:23] instead.
-    L = body(square=True)
-    return L
 
 
 def main():
@@ -246,12 +303,13 @@ def main():
     txt += '    "s40","s41","s42","s43","s44","s45","s46","s47","s56","s57","s58","s59","s60","s62","s63","vcc","scc"\n'
     txt += emit("MBLS_FP2_MUL_ASM", fp2_mul_body()) + "\n"
     vl = lambda a, b: ",".join('"v%d"' % i for i in range(a, b + 1))
-    sg = '"s40","s41","s42","s43","s44","s45","s46","s47","s56","s57","s58","s59","s60","s62","s63","vcc","scc"'
-    txt += "#define MBLS_FP2_MUL_CLOBBERS %s, %s\n" % (vl(72, 92), sg)
+    sg = '"s40","s41","s42","s43","s44","s45","s46","s47","s56","s57","s58","s59","s60","s61","s62","s63","s64","s65","vcc","scc"'
+    txt += "// the Fp2 routines overwrite their operand registers (v0..v47 / v0..v23): call sites pass them as read-write operands\n"
+    txt += "#define MBLS_FP2_MUL_CLOBBERS %s, %s\n" % (vl(72, 117), sg)
     txt += emit("MBLS_FP2_SQR_ASM", fp2_sqr_body()) + "\n"
-    txt += "#define MBLS_FP2_SQR_CLOBBERS %s, %s\n" % (vl(48, 92), sg)
+    txt += "#define MBLS_FP2_SQR_CLOBBERS %s, %s\n" % (vl(48, 104), sg)
     txt += emit("MBLS_FP2_MULFP_ASM", fp2_mulfp_body()) + "\n"
-    txt += "#define MBLS_FP2_MULFP_CLOBBERS %s, %s\n" % (vl(60, 92), sg)
+    txt += "#define MBLS_FP2_MULFP_CLOBBERS %s, %s\n" % (vl(60, 89), sg)
     with open(path, "w") as f:
         f.write(txt)
     print("wrote", path, "(%d + %d + %d + %d instructions)" % (len(fp_mul_body()), len(fp2_mul_body()), len(fp2_sqr_body()), len(fp2_mulfp_body())))

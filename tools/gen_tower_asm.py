@@ -21,22 +21,27 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from gen_fp_asm import P, PL, emit  # noqa: E402
 
 INF = 1 << 60
-WIN = [0, 12, 24, 36, 48, 60]                      # blocks inside the register window of the multiplication routines
-FREE_V = [96 + 12 * i for i in range(12)]          # v96..v239
-ALL_V = FREE_V + [36, 24, 12, 0, 60, 48]           # preference order for fresh values
+# Register map (12-register blocks). v0..v119 is the window of the multiplication routines (they overwrite all of it except
+# their result blocks, operands included); between calls its first eight blocks are ordinary storage and v96..v119 is the
+# scratch of the modular additions.
+WIN = [0, 12, 24, 36, 48, 60, 72, 84]
+FREE_V = [120 + 12 * i for i in range(10)]         # v120..v239: survive calls
+ALL_V = FREE_V + [84, 72, 36, 24, 12, 0, 60, 48]   # preference order for fresh values
 PB = 240                                           # v240..v251: the modulus
-U = 72                                             # v72..v83: scratch of the modular add/sub (dead between calls)
+U = 96                                             # v96..v107: scratch of the modular add/sub (dead between calls)
+U2 = 108                                           # v108..v119: scratch of the second chain of an interleaved pair
 LADDR = "v252"                                     # byte address of this lane's column in the LDS state
 AG = [12 * i for i in range(21)]                   # a0..a251
 NLDS = 12                                          # Fp slots of the LDS state (the kernels allocate 144 dwords per lane)
 CARRY_B = "s[62:63]"
 CARRY_C, CARRY_D = "s[50:51]", "s[52:53]"          # carries of the second chain of an interleaved pair
-U2 = 84                                            # v84..v95: scratch of that second chain
+
+F12_ARG = FREE_V + [72, 84]                         # the twelve blocks in which a routine receives / returns an Fp12 operand
 
 ROUTINES = {
-    "mul": dict(name="mbls_fp2_mul_asm_fn", ins=[0, 12, 24, 36], outs=[48, 60], clob=[48, 60]),
-    "sqr": dict(name="mbls_fp2_sqr_asm_fn", ins=[0, 12], outs=[24, 36], clob=[24, 36, 48, 60]),
-    "mulfp": dict(name="mbls_fp2_mulfp_asm_fn", ins=[0, 12, 24], outs=[36, 48], clob=[36, 48, 60]),
+    "mul": dict(name="mbls_fp2_mul_asm_fn", ins=[0, 12, 24, 36], outs=[48, 60], clob=WIN),
+    "sqr": dict(name="mbls_fp2_sqr_asm_fn", ins=[0, 12], outs=[24, 36], clob=WIN),
+    "mulfp": dict(name="mbls_fp2_mulfp_asm_fn", ins=[0, 12, 24], outs=[36, 48], clob=WIN),
 }
 
 
@@ -405,13 +410,22 @@ class Alloc:
         slots = R["ins"]
         touched = set(slots) | set(R["clob"])
         want = {slots[i]: ins[i] for i in range(len(ins))}
-        # 1. move out whatever sits in a slot that will be overwritten and is still needed
+        ready = set()
+        # 1. everything in the window is overwritten by the routine (its operands too): move out what is still needed
         for s in sorted(touched):
             w = self.at.get(("v", s))
-            if w is None or want.get(s) == w:
+            if w is None:
                 continue
+            in_place = want.get(s) == w
             is_operand = w in ins
-            if is_operand or self.next_use(w, k + 1) != INF:
+            live_after = self.next_use(w, k + 1) != INF
+            if in_place:
+                ready.add(s)
+                if live_after:                      # the slot keeps the operand copy; the value itself continues elsewhere
+                    b = self.alloc_v(k, avoid=touched)
+                    self.copy(("v", s), ("v", b)); self.place(w, ("v", b))
+                continue
+            if is_operand or live_after:
                 u = self.next_use(w, k if is_operand else k + 1)
                 nk = self.p.ops[u][0] if u != INF else None
                 # a value that is next consumed as an operand of a call loses nothing by waiting in an AGPR
@@ -422,24 +436,18 @@ class Alloc:
                     self.copy(("v", s), ("v", b)); self.place(w, ("v", b))
             else:
                 self.release(w)
-        # 2. operands into their slots
+        # 2. operands into their slots (untracked copies: they die with the call)
         for s, v in want.items():
-            l = self.loc[v]
-            if l == ("v", s):
+            if s in ready:
                 continue
-            self.copy(l, ("v", s))
-            dies = self.next_use(v, k + 1) == INF
-            if dies or l[0] == "v" and l[1] in R["clob"]:
-                self.place(v, ("v", s))
-            # otherwise the value keeps its old home; the slot holds an untracked copy that dies with the call
+            self.copy(self.loc[v], ("v", s))
         self.wait_lds()
         self.e("CALL " + R["name"])
         self.stats["calls"] += 1
-        # operands that were tracked in a slot and are still live stay there (input slots are preserved by the routines)
-        for s in R["clob"]:
+        for s in touched:
             w = self.at.get(("v", s))
             if w is not None:
-                assert self.next_use(w, k + 1) == INF, "live value in a clobbered slot"
+                assert self.next_use(w, k + 1) == INF, "live value in the window across a call"
                 self.release(w)
         for i, o in enumerate(outs):
             self.place(o, ("v", R["outs"][i]))
@@ -546,10 +554,10 @@ def prog_miller_dbl():
 
 
 def prog_fp12_mul():
-    """acc <- acc * g: acc in LDS slots 0..11 (tower order), g arriving in the twelve blocks v96..v239 (asm operands)."""
+    """acc <- acc * g: acc in LDS slots 0..11 (tower order), g arriving in the twelve blocks F12_ARG (asm operands)."""
     p = Prog()
     al = [p.live_in(("l", i)) for i in range(12)]
-    gl = [p.live_in(("v", 96 + 12 * i)) for i in range(12)]
+    gl = [p.live_in(("v", b)) for b in F12_ARG]
     six = lambda l: ([(l[0], l[1]), (l[2], l[3]), (l[4], l[5])], [(l[6], l[7]), (l[8], l[9]), (l[10], l[11])])
     a, g = six(al), six(gl)
     t0 = p.mul6(a[0], g[0])
@@ -568,15 +576,15 @@ def plain_shell(body):
 
 
 def miller_dbl_shell(body):
-    """f arrives in v96..v239 and the second G1 argument in v0..v35 (asm operands of the call site); both move to their AGPR
+    """f arrives in the blocks F12_ARG and the second G1 argument in v0..v35 (asm operands of the call site); both move to their AGPR
     homes around the loop. v253 carries the per-lane skip flags (bit 0: pair 0, bit 1: pair 1), s38 the number of iterations."""
     pro = ["v_and_b32_e32 v254, 1, v253", "v_cmp_ne_u32_e64 %s, 0, v254" % SKIP_MASK[0],
            "v_and_b32_e32 v254, 2, v253", "v_cmp_ne_u32_e64 %s, 0, v254" % SKIP_MASK[1], "s_mov_b32 s39, s38"]
     epi = []
     for i in range(12):
         for j in range(12):
-            pro.append("v_accvgpr_write_b32 a%d, v%d" % (12 * i + j, 96 + 12 * i + j))
-            epi.append("v_accvgpr_read_b32 v%d, a%d" % (96 + 12 * i + j, 12 * i + j))
+            pro.append("v_accvgpr_write_b32 a%d, v%d" % (12 * i + j, F12_ARG[i] + j))
+            epi.append("v_accvgpr_read_b32 v%d, a%d" % (F12_ARG[i] + j, 12 * i + j))
     for i in range(3):
         for j in range(12):
             pro.append("v_accvgpr_write_b32 a%d, v%d" % (144 + 12 * i + j, 12 * i + j))
@@ -619,16 +627,19 @@ def main():
         lines, stats = build(name)
         txt += emit(macro, shell(expand_calls(lines))) + "\n"
         print(name, len(lines), "lines", stats)
-    sg = '"s30","s31","s36","s37","s39","s40","s41","s42","s43","s44","s45","s46","s47","s48","s49","s50","s51","s52","s53","s54","s55","s56","s57","s58","s59","s60","s62","s63","vcc","scc","memory"'
+    sg = '"s30","s31","s36","s37","s39","s40","s41","s42","s43","s44","s45","s46","s47","s48","s49","s50","s51","s52","s53","s54","s55","s56","s57","s58","s59","s60","s61","s62","s63","s64","s65","vcc","scc","memory"'
     vr = ",".join('"v%d"' % i for i in list(range(252)) + [254])
     txt += "// everything a tower routine may overwrite (v252 carries the LDS address and is preserved)\n"
     txt += "#define MBLS_TOWER_ASM_CLOBBERS %s,%s, \\\n    %s\n" % (vr, ",".join('"a%d"' % i for i in range(252)), sg)
-    txt += "// routines that take an Fp12 in v96..v239 as operands\n"
+    argregs = set(r for b in F12_ARG for r in range(b, b + 12))
+    other = [i for i in list(range(0, 120)) + list(range(240, 252)) + [254] if i not in argregs]
+    txt += "// routines that take an Fp12 as twelve operands; its register blocks, in tower order:\n"
+    txt += "#define MBLS_F12_ARG_REGS(x) " + ", ".join('"+{v[%d:%d]}"(x##%d)' % (b, b + 11, i) for i, b in enumerate(F12_ARG)) + "\n"
     txt += "#define MBLS_FP12_ARG_ASM_CLOBBERS %s,%s, \\\n    %s\n" % (
-        ",".join('"v%d"' % i for i in list(range(0, 96)) + list(range(240, 252)) + [254]), ",".join('"a%d"' % i for i in range(252)), sg)
-    txt += "// the Miller routine takes the G1 argument in v0..v35 and f in v96..v239 as operands\n"
+        ",".join('"v%d"' % i for i in other), ",".join('"a%d"' % i for i in range(252)), sg)
+    txt += "// the Miller routine additionally takes the G1 argument in v0..v35\n"
     txt += "#define MBLS_MILLER_ASM_CLOBBERS %s,%s, \\\n    %s\n" % (
-        ",".join('"v%d"' % i for i in list(range(36, 96)) + list(range(240, 252)) + [254]), ",".join('"a%d"' % i for i in range(252)), sg)
+        ",".join('"v%d"' % i for i in other if i >= 36), ",".join('"a%d"' % i for i in range(252)), sg)
     with open(path, "w") as f:
         f.write(txt)
     print("wrote", path)
