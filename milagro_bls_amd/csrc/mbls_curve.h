@@ -219,12 +219,29 @@ MBLS_NOINLINE void g2_psi(g2j* r, const g2j* p) {
 MBLS_FN void g2_psi2(g2j* r, const g2j* p) {
     r->x = fp2_mul_fp(p->x, fp_load_const(MBLS_PSI2_CX)); r->y = fp2_neg(p->y); r->z = p->z;
 }
-// [x]P, x = -0xd201000000010000 (uniform bit pattern: no lane divergence)
+#if MBLS_DEVICE_ASM && !defined(MBLS_NO_FP2_ASM)
+// n >= 1 doublings in place as one generated straight-line routine (tools/gen_tower_asm.py, prog_g2_dbl)
+extern "C" __device__ __attribute__((noinline, used, aligned(64))) void mbls_g2_dbl_asm_fn() {
+    asm volatile(MBLS_G2_DBL_ASM);
+}
+MBLS_FN void g2_dbl_n(g2j* p, uint32_t n) {
+    fp p0 = p->x.c0, p1 = p->x.c1, p2 = p->y.c0, p3 = p->y.c1, p4 = p->z.c0, p5 = p->z.c1;
+    asm volatile(MBLS_ASM_CALL("mbls_g2_dbl_asm_fn") : MBLS_G2_ARG_REGS(p) : "{s38}"(n) : MBLS_G2_ARG_ASM_CLOBBERS);
+    p->x.c0 = p0; p->x.c1 = p1; p->y.c0 = p2; p->y.c1 = p3; p->z.c0 = p4; p->z.c1 = p5;
+}
+#else
+MBLS_FN void g2_dbl_n(g2j* p, uint32_t n) { for (uint32_t i = 0; i < n; i++) g2_dbl(p, p); }
+#endif
+// [x]P, x = -0xd201000000010000 (uniform bit pattern: no lane divergence): runs of doublings between the set bits
 MBLS_NOINLINE void g2_mul_x(g2j* r, const g2j* p) {
     g2j acc = *p;
-    for (int i = 62; i >= 0; i--) {
-        g2_dbl(&acc, &acc);
-        if ((MBLS_X_ABS >> i) & 1) g2_add(&acc, &acc, p);
+    int i = 62;
+    while (i >= 0) {
+        int j = i;
+        while (j > 0 && !((MBLS_X_ABS >> j) & 1)) j--;
+        g2_dbl_n(&acc, (uint32_t)(i - j + 1));
+        if ((MBLS_X_ABS >> j) & 1) g2_add(&acc, &acc, p);
+        i = j - 1;
     }
     g2_neg(r, &acc);
 }

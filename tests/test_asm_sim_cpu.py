@@ -239,3 +239,27 @@ def test_fp12_mul_routine():
         assert [lds_get(m, 512, i) for i in range(12)] == exp
         if trial == 0:
             assert exp == [x for h in a for c in h for x in c]
+
+
+def test_g2_dbl_routine():
+    lines, stats = t.build("g2_dbl")
+    rng = random.Random(31)
+    r2 = lambda: (rng.randrange(P), rng.randrange(P))
+    for trial in range(3):
+        X, Y, Z = r2(), r2(), r2()
+        if trial == 0:
+            Z = (0, 0)
+        m = Machine(ROUTINES)
+        for i, x in enumerate([X[0], X[1], Y[0], Y[1], Z[0], Z[1]]):
+            m.a[12 * i:12 * i + 12] = limbs(x)
+        m.run(lines)
+        sq = lambda a: f2mul(a, a)
+        A, B = sq(X), sq(Y)
+        C = sq(B)
+        D = f2k(f2sub(f2sub(sq(f2add(X, B)), A), C), 2)
+        E = f2k(A, 3); F = sq(E)
+        Z3 = f2k(f2mul(Y, Z), 2)
+        X3 = f2sub(F, f2k(D, 2))
+        Y3 = f2sub(f2mul(E, f2sub(D, X3)), f2k(C, 8))
+        got = [from_limbs(m.a[12 * i:12 * i + 12]) for i in range(6)]
+        assert got == [X3[0], X3[1], Y3[0], Y3[1], Z3[0], Z3[1]]

@@ -570,6 +570,37 @@ def prog_fp12_mul():
     return p
 
 
+G2_HOME = [("a", 12 * i) for i in range(6)]
+G2_ARG = FREE_V[:6]
+
+
+def prog_g2_dbl():
+    """Jacobian doubling of a point of E'(Fp2) (formulas of g2_dbl in mbls_curve.h; valid for every curve point including
+    infinity, the curve has no 2-torsion). X, Y, Z in AGPR homes."""
+    p = Prog()
+    l = [p.live_in(h) for h in G2_HOME]
+    X, Y, Z = (l[0], l[1]), (l[2], l[3]), (l[4], l[5])
+    A = p.sqr2(X); B = p.sqr2(Y); C = p.sqr2(B)
+    D = p.dbl2(p.sub2(p.sub2(p.sqr2(p.add2(X, B)), A), C))
+    E = p.mul3_2(A); F = p.sqr2(E)
+    Z3 = p.dbl2(p.mul2(Y, Z))
+    X3 = p.sub2(F, p.dbl2(D))
+    Y3 = p.sub2(p.mul2(E, p.sub2(D, X3)), p.mul8_2(C))
+    for v, h in zip((X3[0], X3[1], Y3[0], Y3[1], Z3[0], Z3[1]), G2_HOME):
+        p.store(v, h)
+    return p
+
+
+def g2_dbl_shell(body):
+    """the point arrives in the six blocks G2_ARG (asm operands) and is doubled s38 times"""
+    pro = ["s_mov_b32 s39, s38"]
+    epi = []
+    for i in range(6):
+        pro += ["v_accvgpr_write_b32 a%d, v%d" % (12 * i + j, G2_ARG[i] + j) for j in range(12)]
+        epi += ["v_accvgpr_read_b32 v%d, a%d" % (G2_ARG[i] + j, 12 * i + j) for j in range(12)]
+    return wrap_loop(body, count_sgpr="s39", prologue=pro, epilogue=epi)
+
+
 def plain_shell(body):
     """a routine without a loop: only the return address needs saving around the nested calls"""
     return ["s_mov_b64 s[36:37], s[30:31]", ".p2align 6"] + body + ["s_mov_b64 s[30:31], s[36:37]"]
@@ -612,7 +643,7 @@ def wrap_loop(lines, count_sgpr="s38", prologue=(), epilogue=()):
 
 
 def build(name):
-    prog = {"cyc_sqr": prog_cyc_sqr, "miller_dbl": prog_miller_dbl, "fp12_mul": prog_fp12_mul}[name]()
+    prog = {"cyc_sqr": prog_cyc_sqr, "miller_dbl": prog_miller_dbl, "fp12_mul": prog_fp12_mul, "g2_dbl": prog_g2_dbl}[name]()
     al = Alloc(prog)
     lines = al.run()
     return lines, al.stats
@@ -623,7 +654,7 @@ def main():
     path = os.path.join(os.path.dirname(here), "milagro_bls_amd", "csrc", "mbls_tower_asm.inc")
     txt = "// GENERATED by tools/gen_tower_asm.py -- do not edit.\n"
     for name, macro, shell in (("cyc_sqr", "MBLS_CYC_SQR_ASM", wrap_loop), ("miller_dbl", "MBLS_MILLER_DBL_ASM", miller_dbl_shell),
-                               ("fp12_mul", "MBLS_FP12_MUL_ASM", plain_shell)):
+                               ("fp12_mul", "MBLS_FP12_MUL_ASM", plain_shell), ("g2_dbl", "MBLS_G2_DBL_ASM", g2_dbl_shell)):
         lines, stats = build(name)
         txt += emit(macro, shell(expand_calls(lines))) + "\n"
         print(name, len(lines), "lines", stats)
@@ -637,6 +668,11 @@ def main():
     txt += "#define MBLS_F12_ARG_REGS(x) " + ", ".join('"+{v[%d:%d]}"(x##%d)' % (b, b + 11, i) for i, b in enumerate(F12_ARG)) + "\n"
     txt += "#define MBLS_FP12_ARG_ASM_CLOBBERS %s,%s, \\\n    %s\n" % (
         ",".join('"v%d"' % i for i in other), ",".join('"a%d"' % i for i in range(252)), sg)
+    g2regs = set(r for b in G2_ARG for r in range(b, b + 12))
+    txt += "// the G2 doubling routine takes X, Y, Z as six operands\n"
+    txt += "#define MBLS_G2_ARG_REGS(x) " + ", ".join('"+{v[%d:%d]}"(x##%d)' % (b, b + 11, i) for i, b in enumerate(G2_ARG)) + "\n"
+    txt += "#define MBLS_G2_ARG_ASM_CLOBBERS %s,%s, \\\n    %s\n" % (
+        ",".join('"v%d"' % i for i in list(range(0, 252)) + [254] if i not in g2regs), ",".join('"a%d"' % i for i in range(252)), sg)
     txt += "// the Miller routine additionally takes the G1 argument in v0..v35\n"
     txt += "#define MBLS_MILLER_ASM_CLOBBERS %s,%s, \\\n    %s\n" % (
         ",".join('"v%d"' % i for i in other if i >= 36), ",".join('"a%d"' % i for i in range(252)), sg)
