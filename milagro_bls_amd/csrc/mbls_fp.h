@@ -330,9 +330,29 @@ MBLS_NOINLINE fp fp_pow_const(fp a, const uint32_t* e) {
     }
     return acc;
 }
+#if MBLS_DEVICE_ASM
+// The two exponentiations of the hot path (square roots: (p-3)/4, inversion: p-2) as generated routines that work on 14
+// unsaturated 28-bit digits from start to end (tools/gen_fp_asm.py, pow_body): no conversions or carries between the ~480
+// dependent multiplications, squarings with half the cross products; the 4-bit-window table lives in AGPRs.
+extern "C" __device__ __attribute__((noinline, used, aligned(64))) void mbls_pow_sqr_xy_asm_fn() { asm volatile(MBLS_POW_SQR_XY_ASM); }
+extern "C" __device__ __attribute__((noinline, used, aligned(64))) void mbls_pow_sqr_yx_asm_fn() { asm volatile(MBLS_POW_SQR_YX_ASM); }
+extern "C" __device__ __attribute__((noinline, used, aligned(64))) void mbls_pow_mul_xb_asm_fn() { asm volatile(MBLS_POW_MUL_XB_ASM); }
+extern "C" __device__ __attribute__((noinline, used, aligned(64))) void mbls_fp_pow_pm3d4_asm_fn() { asm volatile(MBLS_FP_POW_PM3D4_ASM); }
+extern "C" __device__ __attribute__((noinline, used, aligned(64))) void mbls_fp_pow_pm2_asm_fn() { asm volatile(MBLS_FP_POW_PM2_ASM); }
+MBLS_FN fp fp_inv(fp a) {                                                          // 0 -> 0
+    asm volatile(MBLS_ASM_CALL("mbls_fp_pow_pm2_asm_fn") : "+{v[0:11]}"(a) : : MBLS_FP_POW_CLOBBERS);
+    return a;
+}
+// w = a^((p-3)/4): sqrt candidate = w*a, 1/a = chi * w^2 with chi = (w*a)^2 / a = +-1
+MBLS_FN fp fp_pow_pm3d4(fp a) {
+    asm volatile(MBLS_ASM_CALL("mbls_fp_pow_pm3d4_asm_fn") : "+{v[0:11]}"(a) : : MBLS_FP_POW_CLOBBERS);
+    return a;
+}
+#else
 MBLS_FN fp fp_inv(fp a) { return fp_pow_const(a, MBLS_EXP_P_MINUS_2); }            // 0 -> 0
 // w = a^((p-3)/4): sqrt candidate = w*a, 1/a = chi * w^2 with chi = (w*a)^2 / a = +-1
 MBLS_FN fp fp_pow_pm3d4(fp a) { return fp_pow_const(a, MBLS_EXP_P_MINUS_3_DIV_4); }
+#endif
 // returns true and a root in *r if a is a square (0 -> 0)
 MBLS_FN bool fp_sqrt(fp* r, fp a) {
     fp s = fp_mul(fp_pow_pm3d4(a), a);

@@ -263,3 +263,18 @@ def test_g2_dbl_routine():
         Y3 = f2sub(f2mul(E, f2sub(D, X3)), f2k(C, 8))
         got = [from_limbs(m.a[12 * i:12 * i + 12]) for i in range(6)]
         assert got == [X3[0], X3[1], Y3[0], Y3[1], Z3[0], Z3[1]]
+
+
+@pytest.mark.parametrize("which", ["pm3d4", "pm2"])
+def test_fp_pow_routines(which):
+    e = g.EXP_PM3D4 if which == "pm3d4" else g.EXP_PM2
+    body = g.pow_body(e)
+    subs = g.pow_subroutines()
+    rng = random.Random(41)
+    R = 1 << 384
+    for a in (0, 1, P - 1, rng.randrange(P), rng.randrange(P)):
+        am = a * R % P
+        m = Machine(subs); m.s[("pair", 30)] = 5
+        m.v[0:12] = limbs(am)
+        m.run(body)
+        assert from_limbs(m.v[0:12]) == pow(a, e, P) * R % P, (which, a)

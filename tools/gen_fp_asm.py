@@ -286,6 +286,127 @@ def fp2_mulfp_body():
     return L
 
 
+# ----------------------------------------------------------------------------------------------------------------------
+# Fixed-exponent Fp exponentiation entirely on 28-bit digits (domain 2^392 inside the routine): the square roots and the
+# inversion are ~480 dependent Fp multiplications each, 6-7 per verified item. Inside, a value is 14 unsaturated digits and
+# never converted: a squaring uses the symmetry (cross products once, with a doubled digit vector -- exact because digits
+# carry no carries), 105 + 196 multiply-accumulates instead of 2 x 300 on saturated limbs.
+def digit_column_scan(terms, out, acc, acc2, cy="vcc"):
+    """product scan with explicit per-column product lists; products alternate between two 64-bit accumulators (a single
+    dependent v_mad_u64_u32 chain stalls); digits of the Montgomery quotient / result in `out`"""
+    A, A2, lo = "v[%d:%d]" % (acc, acc + 1), "v[%d:%d]" % (acc2, acc2 + 1), "v%d" % acc
+    S, first = [], True
+    for k in range(28):
+        macs = list(terms(k))
+        if k < 14:
+            macs += [(SP28(k - i), out(i)) for i in range(k)]
+        else:
+            macs += [(SP28(k - i), out(i)) for i in range(k - 13, 14)]
+        used2 = False
+        for n, (x, y) in enumerate(macs):
+            if n % 2 == 1:
+                S.append("v_mad_u64_u32 %s, %s, %s, %s, %s" % (A2, cy, x, y, A2 if used2 else "0")); used2 = True
+            else:
+                S.append("v_mad_u64_u32 %s, %s, %s, %s, %s" % (A, cy, x, y, "0" if first else A)); first = False
+        if used2:
+            S.append("v_lshl_add_u64 %s, %s, 0, %s" % (A, A2, A))
+        if k < 14:
+            S += ["v_mul_lo_u32 %s, %s, %s" % (out(k), lo, SNP28), "v_and_b32_e64 %s, %s, %s" % (out(k), out(k), SMASK28),
+                  "v_mad_u64_u32 %s, %s, %s, %s, %s" % (A, cy, SP28(0), out(k), A), "v_lshrrev_b64 %s, 28, %s" % (A, A)]
+        elif k < 27:
+            S += ["v_and_b32_e64 %s, %s, %s" % (out(k - 14), lo, SMASK28), "v_lshrrev_b64 %s, 28, %s" % (A, A)]
+        else:
+            S.append("v_mov_b32_e64 %s, %s" % (out(13), lo))          # top digit: whatever is left (the value is < 2^392 + 2p)
+    return S
+
+
+def sqr_digits(X, D, out, acc, acc2):
+    """out = X^2 / 2^392 on digit vectors (D: scratch for the doubled digits)"""
+    L = ["v_lshlrev_b32_e64 %s, 1, %s" % (D(j), X(j)) for j in range(14)]
+
+    def terms(k):
+        for i in range(max(0, k - 13), min(k, 13) + 1):
+            j = k - i
+            if i < j:
+                yield (X(i), D(j))
+            elif i == j:
+                yield (X(i), X(i))
+    return L + digit_column_scan(terms, out, acc, acc2)
+
+
+def mul_digits(X, Y, out, acc, acc2):
+    def terms(k):
+        for i in range(max(0, k - 13), min(k, 13) + 1):
+            yield (X(i), Y(k - i))
+    return digit_column_scan(terms, out, acc, acc2)
+
+
+POW_X, POW_Y, POW_D, POW_B = VR(0), VR(14), VR(28), VR(42)      # value (ping), value (pong), doubled digits, table entry
+POW_ACC, POW_ACC2 = 56, 58
+R384_DIGITS = [(((1 << 384) % P) >> (28 * i)) & M28 for i in range(14)]
+
+
+def pow_subroutines():
+    """the four leaf routines of an exponentiation: X -> Y squaring, Y -> X squaring, X <- X * B (through Y)"""
+    return {
+        "mbls_pow_sqr_xy_asm_fn": [".p2align 6"] + sqr_digits(POW_X, POW_D, POW_Y, POW_ACC, POW_ACC2),
+        "mbls_pow_sqr_yx_asm_fn": [".p2align 6"] + sqr_digits(POW_Y, POW_D, POW_X, POW_ACC, POW_ACC2),
+        "mbls_pow_mul_xb_asm_fn": [".p2align 6"] + mul_digits(POW_X, POW_B, POW_Y, POW_ACC, POW_ACC2) +
+                                  ["v_mov_b32_e64 %s, %s" % (POW_X(j), POW_Y(j)) for j in range(14)],
+    }
+
+
+def pow_body(e):
+    """a^e for a in v[0:11] (Montgomery form, R = 2^384), result in v[0:11]; fixed 4-bit windows, the table a^1..a^15 in
+    a0..a209 as digit vectors. Pseudo-instruction CALL name = s_getpc/s_add/s_addc/s_swappc."""
+    nibs = [(e >> (4 * w)) & 15 for w in range(96)]
+    L = ["s_mov_b64 s[36:37], s[30:31]"] + load_modulus28()
+    L += conv28(VR(60), VR(0), True)                              # digits of a * 2^8: the value in the 2^392 domain
+    L += ["v_mov_b32_e64 %s, %s" % (POW_X(j), "v%d" % (60 + j)) for j in range(14)]
+    tab = lambda n, j: "a%d" % (14 * (n - 1) + j)
+    L += ["v_accvgpr_write_b32 %s, %s" % (tab(1, j), POW_X(j)) for j in range(14)]
+    L += ["v_mov_b32_e64 %s, %s" % (POW_B(j), POW_X(j)) for j in range(14)]
+    for n in range(2, 16):                                        # a^n = a^(n-1) * a
+        L.append("CALL mbls_pow_mul_xb_asm_fn")
+        L += ["v_accvgpr_write_b32 %s, %s" % (tab(n, j), POW_X(j)) for j in range(14)]
+    started = False
+    for w in range(95, -1, -1):
+        if started:
+            L += ["CALL mbls_pow_sqr_xy_asm_fn", "CALL mbls_pow_sqr_yx_asm_fn"] * 2
+        if nibs[w]:
+            if started:
+                L += ["v_accvgpr_read_b32 %s, %s" % (POW_B(j), tab(nibs[w], j)) for j in range(14)]
+                L.append("CALL mbls_pow_mul_xb_asm_fn")
+            else:
+                L += ["v_accvgpr_read_b32 %s, %s" % (POW_X(j), tab(nibs[w], j)) for j in range(14)]
+                started = True
+    # leave the 2^392 domain: X * (2^384 mod p) / 2^392, then 12 x 32-bit words and the final conditional subtraction
+    L += ["v_mov_b32_e32 %s, 0x%08x" % (POW_B(j), R384_DIGITS[j]) for j in range(14)]
+    L.append("CALL mbls_pow_mul_xb_asm_fn")
+    L += to32(VR(60), POW_X)
+    L += cond_sub32(VR(60), VR(72), "v84")
+    L += ["v_mov_b32_e64 v%d, v%d" % (j, 60 + j) for j in range(12)]
+    L.append("s_mov_b64 s[30:31], s[36:37]")
+    return L
+
+
+def expand_pow_calls(lines):
+    """the leaf routines use s40.. (modulus digits) themselves, so the call address goes through s[66:67]"""
+    out = []
+    for l in lines:
+        if l.startswith("CALL "):
+            sym = l.split()[1]
+            out += ["s_getpc_b64 s[66:67]", "s_add_u32 s66, s66, %s@rel32@lo+4" % sym, "s_addc_u32 s67, s67, %s@rel32@hi+12" % sym,
+                    "s_swappc_b64 s[30:31], s[66:67]"]
+        else:
+            out.append(l)
+    return out
+
+
+EXP_PM3D4 = (P - 3) // 4
+EXP_PM2 = P - 2
+
+
 def emit(name, lines):
     out = ["#define %s \\" % name]
     for l in lines:
@@ -310,6 +431,12 @@ def main():
     txt += "#define MBLS_FP2_SQR_CLOBBERS %s, %s\n" % (vl(48, 104), sg)
     txt += emit("MBLS_FP2_MULFP_ASM", fp2_mulfp_body()) + "\n"
     txt += "#define MBLS_FP2_MULFP_CLOBBERS %s, %s\n" % (vl(60, 89), sg)
+    for sym, body in pow_subroutines().items():
+        txt += emit("MBLS_" + sym.upper()[5:-7] + "_ASM", body) + "\n"
+    txt += emit("MBLS_FP_POW_PM3D4_ASM", expand_pow_calls(pow_body(EXP_PM3D4))) + "\n"
+    txt += emit("MBLS_FP_POW_PM2_ASM", expand_pow_calls(pow_body(EXP_PM2))) + "\n"
+    txt += "#define MBLS_FP_POW_CLOBBERS %s,%s, \\\n" % (vl(12, 84), ",".join('"a%d"' % i for i in range(210)))
+    txt += '    "s30","s31","s36","s37","s66","s67", %s\n' % sg
     with open(path, "w") as f:
         f.write(txt)
     print("wrote", path, "(%d + %d + %d + %d instructions)" % (len(fp_mul_body()), len(fp2_mul_body()), len(fp2_sqr_body()), len(fp2_mulfp_body())))
