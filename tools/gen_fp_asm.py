@@ -180,40 +180,52 @@ def to32(dst, t):
     return L
 
 
+def digit_column_scan(terms, out, acc, acc2, cy="vcc", last_masked=False):
+    """product scan with explicit per-column product lists; products alternate between two 64-bit accumulators (a single
+    dependent v_mad_u64_u32 chain stalls); digits of the Montgomery quotient / result in `out`"""
+    A, lo = "v[%d:%d]" % (acc, acc + 1), "v%d" % acc
+    A2 = "v[%d:%d]" % (acc2, acc2 + 1) if acc2 is not None else None
+    S, first = [], True
+    for k in range(28):
+        macs = list(terms(k))
+        if k < 14:
+            macs += [(SP28(k - i), out(i)) for i in range(k)]
+        else:
+            macs += [(SP28(k - i), out(i)) for i in range(k - 13, 14)]
+        used2 = False
+        for n, (x, y) in enumerate(macs):
+            if A2 is not None and n % 2 == 1:
+                S.append("v_mad_u64_u32 %s, %s, %s, %s, %s" % (A2, cy, x, y, A2 if used2 else "0")); used2 = True
+            else:
+                S.append("v_mad_u64_u32 %s, %s, %s, %s, %s" % (A, cy, x, y, "0" if first else A)); first = False
+        if used2:
+            S.append("v_lshl_add_u64 %s, %s, 0, %s" % (A, A2, A))
+        if k < 14:
+            S += ["v_mul_lo_u32 %s, %s, %s" % (out(k), lo, SNP28), "v_and_b32_e64 %s, %s, %s" % (out(k), out(k), SMASK28),
+                  "v_mad_u64_u32 %s, %s, %s, %s, %s" % (A, cy, SP28(0), out(k), A), "v_lshrrev_b64 %s, 28, %s" % (A, A)]
+        elif k < 27:
+            S += ["v_and_b32_e64 %s, %s, %s" % (out(k - 14), lo, SMASK28), "v_lshrrev_b64 %s, 28, %s" % (A, A)]
+        elif last_masked:
+            S.append("v_and_b32_e64 %s, %s, %s" % (out(13), lo, SMASK28))
+        else:
+            S.append("v_mov_b32_e64 %s, %s" % (out(13), lo))          # top digit: whatever is left (the value is < 2^392 + 2p)
+    return S
+
+
 class Chain28:
     """product scan over 28-bit digits: sum of the listed operand products (first factors in a*2^8 form), Montgomery-reduced by
-    2^392; the quotient digits and then the result digits live in `out` (14 registers); acc: an aligned register pair"""
+    2^392; the quotient digits and then the result digits live in `out` (14 registers); acc: an aligned register pair;
+    acc2: optional second pair, the products of a column then alternate between two accumulators"""
 
-    def __init__(self, pairs, out, acc, carry):
-        self.pairs, self.out, self.acc, self.carry = pairs, out, acc, carry
+    def __init__(self, pairs, out, acc, carry, acc2=None):
+        self.pairs, self.out, self.acc, self.carry, self.acc2 = pairs, out, acc, carry, acc2
 
     def stream(self):
-        out, cy = self.out, self.carry
-        acc, lo = "v[%d:%d]" % (self.acc, self.acc + 1), "v%d" % self.acc
-        S = []
-        first = True
-        for k in range(28):
-            macs = []
+        def terms(k):
             for i in range(max(0, k - 13), min(k, 13) + 1):
                 for (X, Y) in self.pairs:
-                    macs.append((X(i), Y(k - i)))
-            if k < 14:
-                macs += [(SP28(k - i), out(i)) for i in range(k)]
-            else:
-                macs += [(SP28(k - i), out(i)) for i in range(k - 13, 14)]
-            for (x, y) in macs:
-                S.append("v_mad_u64_u32 %s, %s, %s, %s, %s" % (acc, cy, x, y, "0" if first else acc))
-                first = False
-            if k < 14:
-                S.append("v_mul_lo_u32 %s, %s, %s" % (out(k), lo, SNP28))
-                S.append("v_and_b32_e64 %s, %s, %s" % (out(k), out(k), SMASK28))
-                S.append("v_mad_u64_u32 %s, %s, %s, %s, %s" % (acc, cy, SP28(0), out(k), acc))
-                S.append("v_lshrrev_b64 %s, 28, %s" % (acc, acc))
-            else:
-                S.append("v_and_b32_e64 %s, %s, %s" % (out(k - 14), lo, SMASK28))
-                if k < 27:
-                    S.append("v_lshrrev_b64 %s, 28, %s" % (acc, acc))
-        return S
+                    yield (X(i), Y(k - i))
+        return digit_column_scan(terms, self.out, self.acc, self.acc2, self.carry, last_masked=True)
 
 
 def cond_sub32(out, diff, tmp):
@@ -227,6 +239,9 @@ def cond_sub32(out, diff, tmp):
     return S
 
 
+ACC2A, ACC2B = None, None      # a second accumulator per scan was measured slower (6802 vs 6604 clocks per Fp2 multiplication)
+
+
 def fp2_mul_body():
     """Fp2 product on the 28-bit core. a0 v[0:11], a1 v[12:23], b0 v[24:35], b1 v[36:47] (all OVERWRITTEN);
     c0 -> v[48:59], c1 -> v[60:71]; scratch up to v117."""
@@ -237,7 +252,7 @@ def fp2_mul_body():
     L = load_modulus28()
     L += conv28(A0, A0w, True) + conv28(A1, A1w, True) + conv28(B0, B0w, False) + conv28(B1, B1w, False)
     L += ["v_sub_u32_e32 %s, 0x%08x, %s" % (NB(j), NEG2P[j], B1(j)) for j in range(14)]        # digits of 2p - b1
-    L += zip2(Chain28([(A0, B0), (A1, NB)], TA, 28, "vcc").stream(), Chain28([(A0, B1), (A1, B0)], TB, 30, CARRY_B).stream())
+    L += zip2(Chain28([(A0, B0), (A1, NB)], TA, 28, "vcc", ACC2A).stream(), Chain28([(A0, B1), (A1, B0)], TB, 30, CARRY_B, ACC2B).stream())
     L += to32(C0, TA) + to32(C1, TB)
     L += cond_sub32(C0, DF, "v84") + cond_sub32(C1, DF, "v84")
     return L
@@ -265,7 +280,7 @@ def fp2_sqr_body():
         L.append("v_subb_co_u32_e64 %s, vcc, %s, %s, vcc" % (Dw(i), Dw(i), A1w(i)))
     L += conv28(SA, Sw, True) + conv28(DB, Dw, False) + conv28(A0A, A0w, True) + conv28(A1D, A1w, False)
     L += ["v_lshlrev_b32_e64 %s, 1, %s" % (A1D(j), A1D(j)) for j in range(14)]                   # digits of 2 a1 (29 bits)
-    L += zip2(Chain28([(SA, DB)], TA, 28, "vcc").stream(), Chain28([(A0A, A1D)], TB, 30, CARRY_B).stream())
+    L += zip2(Chain28([(SA, DB)], TA, 28, "vcc", ACC2A).stream(), Chain28([(A0A, A1D)], TB, 30, CARRY_B, ACC2B).stream())
     L += to32(C1, TB) + to32(C0, TA)          # in this order: c0's registers overlap the digits of the second chain
     L += cond_sub32(C0, DF, tmp) + cond_sub32(C1, DF, tmp)
     return L
@@ -280,7 +295,7 @@ def fp2_mulfp_body():
     C0, C1, DF = VR(36), VR(48), VR(60)
     L = load_modulus28()
     L += conv28(A0, A0w, True) + conv28(A1, A1w, True) + conv28(SB, Sw, False)
-    L += zip2(Chain28([(A0, SB)], TA, 28, "vcc").stream(), Chain28([(A1, SB)], TB, 30, CARRY_B).stream())
+    L += zip2(Chain28([(A0, SB)], TA, 28, "vcc", ACC2A).stream(), Chain28([(A1, SB)], TB, 30, CARRY_B, ACC2B).stream())
     L += to32(C0, TA) + to32(C1, TB)
     L += cond_sub32(C0, DF, "v72") + cond_sub32(C1, DF, "v72")
     return L
@@ -291,35 +306,6 @@ def fp2_mulfp_body():
 # inversion are ~480 dependent Fp multiplications each, 6-7 per verified item. Inside, a value is 14 unsaturated digits and
 # never converted: a squaring uses the symmetry (cross products once, with a doubled digit vector -- exact because digits
 # carry no carries), 105 + 196 multiply-accumulates instead of 2 x 300 on saturated limbs.
-def digit_column_scan(terms, out, acc, acc2, cy="vcc"):
-    """product scan with explicit per-column product lists; products alternate between two 64-bit accumulators (a single
-    dependent v_mad_u64_u32 chain stalls); digits of the Montgomery quotient / result in `out`"""
-    A, A2, lo = "v[%d:%d]" % (acc, acc + 1), "v[%d:%d]" % (acc2, acc2 + 1), "v%d" % acc
-    S, first = [], True
-    for k in range(28):
-        macs = list(terms(k))
-        if k < 14:
-            macs += [(SP28(k - i), out(i)) for i in range(k)]
-        else:
-            macs += [(SP28(k - i), out(i)) for i in range(k - 13, 14)]
-        used2 = False
-        for n, (x, y) in enumerate(macs):
-            if n % 2 == 1:
-                S.append("v_mad_u64_u32 %s, %s, %s, %s, %s" % (A2, cy, x, y, A2 if used2 else "0")); used2 = True
-            else:
-                S.append("v_mad_u64_u32 %s, %s, %s, %s, %s" % (A, cy, x, y, "0" if first else A)); first = False
-        if used2:
-            S.append("v_lshl_add_u64 %s, %s, 0, %s" % (A, A2, A))
-        if k < 14:
-            S += ["v_mul_lo_u32 %s, %s, %s" % (out(k), lo, SNP28), "v_and_b32_e64 %s, %s, %s" % (out(k), out(k), SMASK28),
-                  "v_mad_u64_u32 %s, %s, %s, %s, %s" % (A, cy, SP28(0), out(k), A), "v_lshrrev_b64 %s, 28, %s" % (A, A)]
-        elif k < 27:
-            S += ["v_and_b32_e64 %s, %s, %s" % (out(k - 14), lo, SMASK28), "v_lshrrev_b64 %s, 28, %s" % (A, A)]
-        else:
-            S.append("v_mov_b32_e64 %s, %s" % (out(13), lo))          # top digit: whatever is left (the value is < 2^392 + 2p)
-    return S
-
-
 def sqr_digits(X, D, out, acc, acc2):
     """out = X^2 / 2^392 on digit vectors (D: scratch for the doubled digits)"""
     L = ["v_lshlrev_b32_e64 %s, 1, %s" % (D(j), X(j)) for j in range(14)]
