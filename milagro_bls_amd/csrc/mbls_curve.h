@@ -34,13 +34,18 @@ MBLS_NOINLINE void g1_dbl(g1j* r, const g1j* p) {
 // r = p + (x2, y2) affine; inf2 marks the affine operand as the point at infinity
 MBLS_NOINLINE void g1_madd(g1j* r, const g1j* p, fp x2, fp y2, bool inf2) {
     bool inf1 = g1_is_inf(p);
-    fp z1z1 = fp_sqr(p->z);
-    fp u2 = fp_mul(x2, z1z1), s2 = fp_mul(fp_mul(y2, p->z), z1z1);
+    // the 11 multiplications as five independent pairs (fp_mul_pair) and one single
+    fp z1z1, t, u2, s2, hh, rr2, j, v, m0, m1;
+    fp_mul_pair(&z1z1, &t, p->z, p->z, y2, p->z);
+    fp_mul_pair(&u2, &s2, x2, z1z1, t, z1z1);
     fp h = fp_sub(u2, p->x), rr = fp_dbl(fp_sub(s2, p->y));
     bool h0 = fp_is_zero(h), r0 = fp_is_zero(rr);
-    fp hh = fp_sqr(h), i4 = fp_dbl(fp_dbl(hh)), j = fp_mul(h, i4), v = fp_mul(p->x, i4);
-    fp x3 = fp_sub(fp_sub(fp_sqr(rr), j), fp_dbl(v));
-    fp y3 = fp_sub(fp_mul(rr, fp_sub(v, x3)), fp_dbl(fp_mul(p->y, j)));
+    fp_mul_pair(&hh, &rr2, h, h, rr, rr);
+    fp i4 = fp_dbl(fp_dbl(hh));
+    fp_mul_pair(&j, &v, h, i4, p->x, i4);
+    fp x3 = fp_sub(fp_sub(rr2, j), fp_dbl(v));
+    fp_mul_pair(&m0, &m1, rr, fp_sub(v, x3), p->y, j);
+    fp y3 = fp_sub(m0, fp_dbl(m1));
     fp z3 = fp_sub(fp_sub(fp_sqr(fp_add(p->z, h)), z1z1), hh);
     g1j out; out.x = x3; out.y = y3; out.z = z3;
     if (h0 & !inf1 & !inf2) {                 // same x: doubling or inverse points (rare, divergent)
@@ -162,8 +167,11 @@ MBLS_NOINLINE int g1_decode_uncompressed_w(fp* x, fp* y, bool* inf, fp wx, fp wy
     if (b0 & 0x20) return MBLS_DEC_POINT;
     fp rx = fp_raw_from_be_words(wx), ry = fp_raw_from_be_words(wy);
     if (fp_raw_geq_p(rx) | fp_raw_geq_p(ry)) return MBLS_DEC_POINT;
-    fp xm = fp_to_mont(rx), ym = fp_to_mont(ry);
-    if (!g1_on_curve(xm, ym)) return MBLS_DEC_POINT;
+    fp xm, ym, xx, yy;
+    fp_mul_pair(&xm, &ym, rx, fp_load_const(MBLS_R2), ry, fp_load_const(MBLS_R2));     // to Montgomery form
+    fp_mul_pair(&xx, &yy, xm, xm, ym, ym);
+    fp four = fp_dbl(fp_dbl(fp_one()));
+    if (!fp_eq(yy, fp_add(fp_mul(xx, xm), four))) return MBLS_DEC_POINT;                 // y^2 = x^3 + 4
     *x = xm; *y = ym; return MBLS_DEC_OK;
 }
 MBLS_FN int g1_decode_uncompressed(fp* x, fp* y, bool* inf, const uint8_t* b) {

@@ -220,6 +220,18 @@ __attribute__((aligned(64))) MBLS_NOINLINE fp fp_mul(fp a, fp b) {
     return r;
 }
 MBLS_FN fp fp_sqr(fp a) { return fp_mul(a, a); }
+// Two independent products at once (generated routine, two interleaved scans on the 28-bit core): ~4.4 k clocks for the
+// pair against ~3.1 k for one fp_mul, whose single dependent multiply-accumulate chain cannot be overlapped with anything
+// when the wave is alone on its SIMD.
+extern "C" __device__ __attribute__((noinline, used, aligned(64))) void mbls_fp_mulpair_asm_fn() { asm volatile(MBLS_FP_MULPAIR_ASM); }
+MBLS_FN void fp_mul_pair(fp* c0, fp* c1, fp a0, fp b0, fp a1, fp b1) {
+    fp r0, r1;
+    asm volatile(MBLS_ASM_CALL("mbls_fp_mulpair_asm_fn")
+                 : "={v[48:59]}"(r0), "={v[60:71]}"(r1), "+{v[0:11]}"(a0), "+{v[12:23]}"(b0), "+{v[24:35]}"(a1), "+{v[36:47]}"(b1)
+                 :
+                 : MBLS_FP_MULPAIR_CLOBBERS, "s30", "s31");
+    *c0 = r0; *c1 = r1;
+}
 #else
 MBLS_NOINLINE fp fp_mul(fp a, fp b) {
     uint32_t m[12]; fp t; mbls_acc s = {0, 0};
@@ -277,6 +289,7 @@ MBLS_NOINLINE fp fp_sqr(fp a) {
     }
     return fp_reduce_once(t, (uint32_t)s.lo);
 }
+MBLS_FN void fp_mul_pair(fp* c0, fp* c1, fp a0, fp b0, fp a1, fp b1) { *c0 = fp_mul(a0, b0); *c1 = fp_mul(a1, b1); }
 #endif
 
 MBLS_FN fp fp_to_mont(fp raw) { return fp_mul(raw, fp_load_const(MBLS_R2)); }

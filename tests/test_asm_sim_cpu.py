@@ -64,6 +64,11 @@ def test_fp_routines():
         m = Machine(); m.v[0:12] = limbs(a0); m.v[12:24] = limbs(a1); m.v[24:36] = limbs(b0)
         m.run(g.fp2_mulfp_body())
         assert (from_limbs(m.v[36:48]), from_limbs(m.v[48:60])) == (mm(a0, b0), mm(a1, b0))
+        m = Machine()
+        for i, x in enumerate([a0, b0, a1, b1]):
+            m.v[12 * i:12 * i + 12] = limbs(x)
+        m.run(g.fp_mulpair_body())
+        assert (from_limbs(m.v[48:60]), from_limbs(m.v[60:72])) == (mm(a0, b0), mm(a1, b1))
         m = Machine(); m.v[0:12] = limbs(a0); m.v[12:24] = limbs(b0)
         m.run(g.fp_mul_body())
         assert from_limbs(m.v[0:12]) == mm(a0, b0)

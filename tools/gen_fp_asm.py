@@ -393,6 +393,22 @@ EXP_PM3D4 = (P - 3) // 4
 EXP_PM2 = P - 2
 
 
+def fp_mulpair_body():
+    """two independent Fp products, interleaved: c0 = a0 b0, c1 = a1 b1. a0 v[0:11], b0 v[12:23], a1 v[24:35], b1 v[36:47]
+    (OVERWRITTEN); c0 -> v[48:59], c1 -> v[60:71]; scratch up to v103. For code that has independent multiplications in
+    pairs (G1 point addition): a lone Fp product is one dependent chain and issues ~15 % slower per multiply-accumulate."""
+    A0w, B0w, A1w, B1w = VR(0), VR(12), VR(24), VR(36)
+    A0, B0, A1, B1 = VR(48), VR(62), VR(76), VR(90)
+    TA, TB = VR(0), VR(14)
+    C0, C1, DF = VR(48), VR(60), VR(72)
+    L = load_modulus28()
+    L += conv28(A0, A0w, True) + conv28(B0, B0w, False) + conv28(A1, A1w, True) + conv28(B1, B1w, False)
+    L += zip2(Chain28([(A0, B0)], TA, 28, "vcc").stream(), Chain28([(A1, B1)], TB, 30, CARRY_B).stream())
+    L += to32(C0, TA) + to32(C1, TB)
+    L += cond_sub32(C0, DF, "v84") + cond_sub32(C1, DF, "v84")
+    return L
+
+
 def emit(name, lines):
     out = ["#define %s \\" % name]
     for l in lines:
@@ -417,6 +433,8 @@ def main():
     txt += "#define MBLS_FP2_SQR_CLOBBERS %s, %s\n" % (vl(48, 104), sg)
     txt += emit("MBLS_FP2_MULFP_ASM", fp2_mulfp_body()) + "\n"
     txt += "#define MBLS_FP2_MULFP_CLOBBERS %s, %s\n" % (vl(60, 89), sg)
+    txt += emit("MBLS_FP_MULPAIR_ASM", fp_mulpair_body()) + "\n"
+    txt += "#define MBLS_FP_MULPAIR_CLOBBERS %s, %s\n" % (vl(72, 103), sg)
     for sym, body in pow_subroutines().items():
         txt += emit("MBLS_" + sym.upper()[5:-7] + "_ASM", body) + "\n"
     txt += emit("MBLS_FP_POW_PM3D4_ASM", expand_pow_calls(pow_body(EXP_PM3D4))) + "\n"
