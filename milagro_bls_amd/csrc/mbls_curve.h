@@ -32,7 +32,7 @@ MBLS_NOINLINE void g1_dbl(g1j* r, const g1j* p) {
     r->y = fp_sub(fp_mul(E, fp_sub(D, x3)), c8); r->x = x3; r->z = z3;
 }
 // r = p + (x2, y2) affine; inf2 marks the affine operand as the point at infinity
-MBLS_NOINLINE void g1_madd(g1j* r, const g1j* p, fp x2, fp y2, bool inf2) {
+MBLS_FN void g1_madd_inl(g1j* r, const g1j* p, fp x2, fp y2, bool inf2) {
     bool inf1 = g1_is_inf(p);
     // the 11 multiplications as five independent pairs (fp_mul_pair) and one single
     fp z1z1, t, u2, s2, hh, rr2, j, v, m0, m1;
@@ -57,6 +57,7 @@ MBLS_NOINLINE void g1_madd(g1j* r, const g1j* p, fp x2, fp y2, bool inf2) {
     out.x = fp_select(inf2, p->x, out.x); out.y = fp_select(inf2, p->y, out.y); out.z = fp_select(inf2, p->z, out.z);
     *r = out;
 }
+MBLS_NOINLINE void g1_madd(g1j* r, const g1j* p, fp x2, fp y2, bool inf2) { g1_madd_inl(r, p, x2, y2, inf2); }
 MBLS_NOINLINE void g1_add(g1j* r, const g1j* p, const g1j* q) {
     bool inf1 = g1_is_inf(p), inf2 = g1_is_inf(q);
     fp z1z1 = fp_sqr(p->z), z2z2 = fp_sqr(q->z);
@@ -151,7 +152,7 @@ MBLS_FN fp fp_raw_from_be_words(fp w) {          // big-endian byte string held 
     for (int i = 0; i < 12; i++) r[i] = mbls_bswap32(w[11 - i]);
     return r;
 }
-MBLS_NOINLINE int g1_decode_uncompressed_w(fp* x, fp* y, bool* inf, fp wx, fp wy) {
+MBLS_FN int g1_decode_uncompressed_w(fp* x, fp* y, bool* inf, fp wx, fp wy) {
     uint32_t b0 = wx[0] & 0xFFu;
     *inf = false; *x = fp_zero(); *y = fp_zero();
     if (b0 & 0x80) return MBLS_DEC_SIZE;
@@ -174,7 +175,7 @@ MBLS_NOINLINE int g1_decode_uncompressed_w(fp* x, fp* y, bool* inf, fp wx, fp wy
     if (!fp_eq(yy, fp_add(fp_mul(xx, xm), four))) return MBLS_DEC_POINT;                 // y^2 = x^3 + 4
     *x = xm; *y = ym; return MBLS_DEC_OK;
 }
-MBLS_FN int g1_decode_uncompressed(fp* x, fp* y, bool* inf, const uint8_t* b) {
+MBLS_NOINLINE int g1_decode_uncompressed(fp* x, fp* y, bool* inf, const uint8_t* b) {
     fp wx, wy; g1_load_words96(&wx, &wy, b, false);
     return g1_decode_uncompressed_w(x, y, inf, wx, wy);
 }

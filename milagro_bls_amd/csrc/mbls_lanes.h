@@ -72,7 +72,7 @@ MBLS_FN void lane_aggregate(const mbls_ws& ws, uint64_t i, const uint8_t* pks, u
             int e = g1_decode_uncompressed_w(&x, &y, &inf, wx, wy);
             if (e) { st |= MBLS_ST_BAD_PK_ENCODING; inf = true; }
             if (inf) st |= MBLS_ST_PK_INFINITY;
-            g1_madd(&acc, &acc, x, y, inf);
+            g1_madd_inl(&acc, &acc, x, y, inf);
         }
     }
     if (mode == MBLS_MODE_FAST_AGGREGATE) {
