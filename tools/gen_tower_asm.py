@@ -157,6 +157,25 @@ class Alloc:
         for k, (kind, outs, ins, aux) in enumerate(prog.ops):
             for v in ins:
                 self.uses.setdefault(v, []).append(k)
+        # sums that only ever enter a multiplication as a first factor stay unreduced (< 2p): the routines convert first factors
+        # as a * 2^8 < 2^392 and their results stay below 2p for first factors up to 8p
+        self.unreduced = set()
+        first_factor = {"mul": (0, 1), "mulfp": (0, 1)}
+        for k, (kind, outs, ins, aux) in enumerate(prog.ops):
+            cands = []
+            if kind == "add":
+                cands = [outs[0]]
+            elif kind == "pair":
+                cands = [outs[i] for i in range(2) if aux[i] == "add"]
+            for d in cands:
+                us = self.uses.get(d, [])
+                ok = bool(us)
+                for u in us:
+                    uk, uo, ui, ua = prog.ops[u]
+                    if uk not in first_factor or any(ui[j] == d for j in range(len(ui)) if j not in first_factor[uk]):
+                        ok = False
+                if ok:
+                    self.unreduced.add(d)
         self.loc = dict(prog.init_loc)
         self.at = {l: v for v, l in self.loc.items()}
         self.out = []
@@ -339,7 +358,10 @@ class Alloc:
         def cm(d, x, y, c):
             return ("v_cndmask_b32_e64 v%d, v%d, v%d, " + c) % (d, x, y)
         L = []
-        if kind == "add":
+        if kind == "addnr":                                                      # plain sum, no reduction
+            L.append(co("v_add_co_u32", D, A, B, c1))
+            L += [cc("v_addc_co_u32", D + j, A + j, B + j, c1) for j in range(1, 12)]
+        elif kind == "add":
             L.append(co("v_add_co_u32", D, A, B, c1))
             L += [cc("v_addc_co_u32", D + j, A + j, B + j, c1) for j in range(1, 12)]
             L.append(co("v_sub_co_u32", Ub, D, PB, c1))
@@ -372,9 +394,11 @@ class Alloc:
         bd = self.pick_dst(k, d, a, b, ba, bb, ())
         if bd is None:
             bd = self.alloc_v(k, avoid=(ba, bb))
+        if kind == "add" and d in self.unreduced:
+            kind = "addnr"
         for l in self.gen_arith(kind, bd, ba, bb, U, "vcc", CARRY_B, aux):
             self.e(l)
-        self.stats["arith"] += 12 if kind == "sel" else 36
+        self.stats["arith"] += 12 if kind in ("sel", "addnr") else 36
         self.finish_arith(d, bd, (a, b))
 
     def do_pair(self, k, outs, ins, kinds):
@@ -394,11 +418,15 @@ class Alloc:
         d1 = self.pick_dst(k, outs[1], a1, b1, blk[a1], blk[b1], avoid=(blk[a0], blk[b0], d0))
         if d1 is None:
             d1 = self.alloc_v(k, avoid=tuple(blk.values()) + (d0,))
+        kinds = tuple("addnr" if kinds[i] == "add" and outs[i] in self.unreduced else kinds[i] for i in range(2))
         L0 = self.gen_arith(kinds[0], d0, blk[a0], blk[b0], U, "vcc", CARRY_B)
         L1 = self.gen_arith(kinds[1], d1, blk[a1], blk[b1], U2, CARRY_C, CARRY_D)
-        for x, y in zip(L0, L1):
-            self.e(x); self.e(y)
-        self.stats["arith"] += 72
+        for i in range(max(len(L0), len(L1))):
+            if i < len(L0):
+                self.e(L0[i])
+            if i < len(L1):
+                self.e(L1[i])
+        self.stats["arith"] += len(L0) + len(L1)
         for bd in (d0, d1):
             for v in got:
                 if self.loc.get(v) == ("v", bd):
