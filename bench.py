@@ -279,7 +279,7 @@ def main():
         out = {
             "metric": "fast_aggregate_verify/sec (128 pubkeys, 32B msg)", "value": value, "unit": "fast_aggregate_verify/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "u32 limbs (12 x 32-bit Montgomery, integer)", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": "u32 (12 x 32-bit Montgomery limbs; 14 x 28-bit digits with 64-bit column sums inside the multiplication routines)", "data": "synthetic",
             "config": {"workload": "configs[2]: batch 2^%d fast_aggregate_verify, %d pubkeys each, per GPU" % (int(np.log2(n)), k),
                        "items_per_gpu": n, "keys_per_item": k, "msg_bytes": 32, "pk_format": args.pk_format,
                        "negatives": "every 16th item corrupted (msg bit / wrong key / sig not in G2 / infinity sig / apk = infinity)",
