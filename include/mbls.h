@@ -150,8 +150,10 @@ int mbls_hash_to_g2_batch(mbls_ctx* ctx, const uint8_t* msgs, uint32_t msg_len, 
 /* n x AggregatePublicKey::aggregate over wire-format keys -> decoded aggregate keys */
 int mbls_aggregate_public_keys_batch(mbls_ctx* ctx, const uint8_t* pks, int pk_format, const uint32_t* pk_offsets,
                                      uint64_t n, uint32_t k, uint8_t* apks96, uint32_t* status);
-/* field probe for parity tests and the ALU microbenchmark: out = a*b (or a^2) mod p on 48-byte big-endian values */
-int mbls_fp_mul_batch(mbls_ctx* ctx, const uint8_t* a48, const uint8_t* b48, uint64_t n, uint8_t* out48, int square);
+/* field probe for the parity tests of the hand-written routines, on canonical 48-byte big-endian values. op: 0 out = a*b,
+ * 1 a^2, 2 Fp2 product and 3 Fp2 square over element pairs (2i, 2i+1) = (real, imaginary), 4 a^-1 (0 -> 0),
+ * 5 a^((p-3)/4), 6 the paired-product routine on elements 2i and 2i+1 */
+int mbls_fp_mul_batch(mbls_ctx* ctx, const uint8_t* a48, const uint8_t* b48, uint64_t n, uint8_t* out48, int op);
 /* integer-ALU calibration: runs `iters` dependent Fp multiplications per lane on n lanes, returns elapsed ms */
 int mbls_fp_mul_bench(mbls_ctx* ctx, uint64_t n_lanes, uint32_t iters, float* ms_out);
 

@@ -88,10 +88,11 @@ def aggregate_public_keys_batch(pks, n, k=None, pk_format=N.PK_COMPRESSED, pk_of
     return bytes(out)[:96 * n], list(st)[:n]
 
 
-def fp_mul_batch(a48, b48, n, square=False, ctx=None):
+def fp_mul_batch(a48, b48, n, square=False, ctx=None, op=None):
+    """field probe; op as in include/mbls.h (default: 1 if square else 0)"""
     ctx = ctx or _c()
     out = N.outbuf(48 * n)
-    ctx.check(N.lib().mbls_fp_mul_batch(ctx.handle, N.cbuf(a48), N.cbuf(b48), n, out, int(square)))
+    ctx.check(N.lib().mbls_fp_mul_batch(ctx.handle, N.cbuf(a48), N.cbuf(b48), n, out, int(square) if op is None else op))
     return bytes(out)[:48 * n]
 
 

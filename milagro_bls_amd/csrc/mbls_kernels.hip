@@ -172,7 +172,7 @@ __global__ void MBLS_LB k_g1_add(const uint8_t* a, const uint8_t* b, uint64_t n,
 __global__ void MBLS_LB k_sign(const uint8_t* sks, const uint8_t* msgs, uint32_t mlen, uint64_t n, uint8_t* out96) { uint64_t i = gid(); if (i < n) op_sign(i, sks, msgs, mlen, out96); }
 __global__ void MBLS_LB k_sk_to_pk(const uint8_t* sks, int fmt, uint64_t n, uint8_t* out) { uint64_t i = gid(); if (i < n) op_sk_to_pk(i, sks, fmt, out); }
 __global__ void MBLS_LB k_hash_to_g2(const uint8_t* msgs, uint32_t mlen, uint64_t n, uint8_t* out96) { uint64_t i = gid(); if (i < n) op_hash_to_g2(i, msgs, mlen, out96); }
-__global__ void MBLS_LB k_fp_mul(const uint8_t* a, const uint8_t* b, uint64_t n, uint8_t* out, int sq) { uint64_t i = gid(); if (i < n) op_fp_mul(i, a, b, out, sq); }
+__global__ void MBLS_LB k_fp_mul(const uint8_t* a, const uint8_t* b, uint64_t n, uint8_t* out, int op) { uint64_t i = gid(); if (i < n) op_fp_mul(i, n, a, b, out, op); }
 __global__ void MBLS_LB k_apk_export(mbls_ws ws, uint64_t n, uint8_t* out96) { uint64_t i = gid(); if (i < n) op_apk_export(ws, i, out96); }
 __global__ void MBLS_LB k_fp_mul_bench(uint32_t* sink, uint32_t iters, uint64_t n) {
     uint64_t i = gid(); if (i >= n) return;

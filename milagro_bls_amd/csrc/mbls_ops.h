@@ -95,9 +95,25 @@ MBLS_FN void op_hash_to_g2(uint64_t i, const uint8_t* msgs, uint32_t mlen, uint8
     g2j h; hash_to_g2(&h, msgs + (uint64_t)mlen * i, mlen, MBLS_DST_POP, MBLS_DST_POP_LEN);
     g2_encode_jacobian(out96 + 96 * i, &h);
 }
-// field probe: out = a*b mod p on canonical 48-byte big-endian values (parity test of the multiplier)
-MBLS_FN void op_fp_mul(uint64_t i, const uint8_t* a48, const uint8_t* b48, uint8_t* out48, int use_sqr) {
+// field probe on canonical 48-byte big-endian values (parity tests of the hand-written routines). op: 0 a*b, 1 a^2,
+// 2 Fp2 product and 3 Fp2 square over element pairs (2i, 2i+1) = (real, imaginary), 4 a^-1 (0 -> 0), 5 a^((p-3)/4),
+// 6 the paired-product routine on elements 2i and 2i+1
+MBLS_FN void op_fp_mul(uint64_t i, uint64_t n, const uint8_t* a48, const uint8_t* b48, uint8_t* out48, int op) {
+    if (op == 2 || op == 3 || op == 6) {
+        if ((i & 1) || i + 1 >= n) return;
+        fp a0 = fp_to_mont(fp_raw_from_be(a48 + 48 * i)), a1 = fp_to_mont(fp_raw_from_be(a48 + 48 * (i + 1)));
+        fp b0 = fp_to_mont(fp_raw_from_be(b48 + 48 * i)), b1 = fp_to_mont(fp_raw_from_be(b48 + 48 * (i + 1)));
+        fp r0, r1;
+        if (op == 6) fp_mul_pair(&r0, &r1, a0, b0, a1, b1);
+        else {
+            fp2 a, b; a.c0 = a0; a.c1 = a1; b.c0 = b0; b.c1 = b1;
+            fp2 r = op == 2 ? fp2_mul(a, b) : fp2_sqr(a);
+            r0 = r.c0; r1 = r.c1;
+        }
+        fp_raw_to_be(out48 + 48 * i, fp_from_mont(r0)); fp_raw_to_be(out48 + 48 * (i + 1), fp_from_mont(r1));
+        return;
+    }
     fp a = fp_to_mont(fp_raw_from_be(a48 + 48 * i)), b = fp_to_mont(fp_raw_from_be(b48 + 48 * i));
-    fp r = use_sqr ? fp_sqr(a) : fp_mul(a, b);
+    fp r = op == 1 ? fp_sqr(a) : op == 4 ? fp_inv(a) : op == 5 ? fp_pow_pm3d4(a) : fp_mul(a, b);
     fp_raw_to_be(out48 + 48 * i, fp_from_mont(r));
 }

@@ -46,7 +46,7 @@ void emul_g1_add(const uint8_t* a, const uint8_t* b, uint64_t n, uint8_t* out, u
 void emul_sign(const uint8_t* sks, const uint8_t* msgs, uint32_t mlen, uint64_t n, uint8_t* out96) { for (uint64_t i = 0; i < n; i++) op_sign(i, sks, msgs, mlen, out96); }
 void emul_sk_to_pk(const uint8_t* sks, int fmt, uint64_t n, uint8_t* out) { for (uint64_t i = 0; i < n; i++) op_sk_to_pk(i, sks, fmt, out); }
 void emul_hash_to_g2(const uint8_t* msgs, uint32_t mlen, uint64_t n, uint8_t* out96) { for (uint64_t i = 0; i < n; i++) op_hash_to_g2(i, msgs, mlen, out96); }
-void emul_fp_mul(const uint8_t* a, const uint8_t* b, uint64_t n, uint8_t* out, int use_sqr) { for (uint64_t i = 0; i < n; i++) op_fp_mul(i, a, b, out, use_sqr); }
+void emul_fp_mul(const uint8_t* a, const uint8_t* b, uint64_t n, uint8_t* out, int op) { for (uint64_t i = 0; i < n; i++) op_fp_mul(i, n, a, b, out, op); }
 void emul_aggregate(const uint8_t* pks, int fmt, const uint32_t* offsets, uint64_t n, uint32_t k, uint8_t* out96, uint32_t* status) {
     mbls_ws ws; ws.stride = n ? n : 1; ws.w = (uint32_t*)calloc((size_t)MBLS_SLOT_COUNT * 12 * ws.stride, 4);
     const uint32_t pkb = fmt == MBLS_PK_COMPRESSED ? 48 : 96;

@@ -58,6 +58,36 @@ def test_fp_mul_bulk_and_structured_operands(mb):
     assert not bad, bad[:5]
 
 
+def test_field_routines_structured_operands(mb):
+    """The hand-written Fp2 product / square, paired product and the two exponentiation routines (28-bit digit core) on
+    structured and random operands, against big-integer arithmetic."""
+    rnd = random.Random(77)
+    P = helpers.P
+    special = [0, 1, 2, P - 1, P - 2, (P - 1) // 2, 2**380, 2**364, 2**364 - 1, 2**28 - 1, 2**28, 2**56 - 1, int("0fffffff" * 11, 16),
+               int("ffffffff" * 11, 16), int("f0000000" * 11, 16) % P, 2**383 % P]
+    vals = [(a, b) for a in special for b in special]
+    while len(vals) < 2048:
+        vals.append((rnd.randrange(P), rnd.randrange(P)))
+    n = len(vals)
+    a = b"".join(x.to_bytes(48, "big") for x, _ in vals); b = b"".join(y.to_bytes(48, "big") for _, y in vals)
+    get = lambda o, i: int.from_bytes(o[48 * i:48 * i + 48], "big")
+    o = mb.fp_mul_batch(a, b, n, op=2)
+    for i in range(0, n, 2):
+        (a0, b0), (a1, b1) = vals[i], vals[i + 1]
+        assert (get(o, i), get(o, i + 1)) == ((a0 * b0 - a1 * b1) % P, (a0 * b1 + a1 * b0) % P), i
+    o = mb.fp_mul_batch(a, b, n, op=3)
+    for i in range(0, n, 2):
+        a0, a1 = vals[i][0], vals[i + 1][0]
+        assert (get(o, i), get(o, i + 1)) == ((a0 * a0 - a1 * a1) % P, 2 * a0 * a1 % P), i
+    o = mb.fp_mul_batch(a, b, n, op=6)
+    assert all(get(o, i) == vals[i][0] * vals[i][1] % P for i in range(n))
+    m = 256                                   # the exponentiations are ~480 multiplications each
+    o = mb.fp_mul_batch(a[:48 * m], b[:48 * m], m, op=4)
+    assert all(get(o, i) == pow(vals[i][0], P - 2, P) for i in range(m))
+    o = mb.fp_mul_batch(b[:48 * m], a[:48 * m], m, op=5)
+    assert all(get(o, i) == pow(vals[i][1], (P - 3) // 4, P) for i in range(m))
+
+
 def test_hash_to_g2_golden_and_oracle(mb, vectors):
     for v in vectors["model"]["hash_to_g2"]:
         m = helpers.expand_msg(v["msg"])
