@@ -1,8 +1,9 @@
 // mbls_fp.h -- Fp arithmetic for BLS12-381 on gfx950: 12 x 32-bit limbs in VGPRs, Montgomery form.
 //
-// One field element per lane. The multiplier is a product-scanning Montgomery multiplication whose
-// inner step is one v_mad_u64_u32 (32x32+64 -> 64, carry-out in VCC) plus one v_addc_co_u32 into the
-// third accumulator word: 288 + 12 multiplies per Fp multiplication, no MFMA (carry-chain integer work).
+// One field element per lane. fp_mul is a product-scanning Montgomery multiplication whose inner step is one
+// v_mad_u64_u32 (32x32+64 -> 64, carry-out in VCC) plus one v_addc_co_u32 into the third accumulator word; the Fp2-level
+// routines (mbls_tower.h), the paired product and the fixed-exponent exponentiations below re-cut their operands into 14
+// unsaturated 28-bit digits, where a product is a single v_mad_u64_u32 (tools/gen_fp_asm.py). No MFMA (integer carry work).
 //
 // Replaces amcl's `fp`/`big` modules that the reference reaches through BLSCurve::* (reference
 // src/amcl_utils.rs:6-21). The same header compiles as plain C++ (MBLS_HOST_EMUL) so that the CPU-only
@@ -30,9 +31,10 @@
 #endif
 #endif
 
-// Fp6/Fp12-level operations are inlined into the functions that own the hot loops (miller_loop, fp12_cyc_exp_x): their
-// Fp6 temporaries then live in VGPRs/AGPRs instead of lane-private memory (measured: k_miller 32.9 -> 26.9 ms, scratch
-// 7.5 -> 2.7 KB per lane). -DMBLS_OUTLINE_TOWER restores real functions on memory operands (smaller code, slower).
+// In the compiler-scheduled code (generic n-pair Miller loop, cold paths) Fp6/Fp12-level operations are inlined into the
+// functions that own the loops: their Fp6 temporaries then live in VGPRs/AGPRs instead of lane-private memory.
+// -DMBLS_OUTLINE_TOWER restores real functions on memory operands (smaller code, slower). The hot loops of the verification
+// path do not go through this code at all: they are generated routines (mbls_tower_asm.inc).
 #if !defined(MBLS_OUTLINE_TOWER)
 #define MBLS_INLINE_TOWER 1
 #endif
