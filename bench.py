@@ -266,8 +266,19 @@ def main():
         valu = {"unit": "Fp mul/s", "peak_measured": fpmul_peak, "fp_mul_per_item": census,
                 "achieved": (value / world) * census if census else None,
                 "frac": (value / world) * census / fpmul_peak if census else None,
-                "note": "peak = k_fp_mul_bench (dependent Montgomery multiplications, 2^19 lanes) measured in this run; "
-                        "fp_mul_per_item from profiles/fpmul_census.json (emulator census of fp_mul+fp_sqr calls)"}
+                "note": "peak = k_fp_mul_bench (dependent Montgomery multiplications with the 32-bit-limb fp_mul, 2^19 lanes) "
+                        "measured in this run; fp_mul_per_item from profiles/fpmul_census.json (emulator census of fp_mul+fp_sqr "
+                        "calls, Karatsuba equivalents). The Fp2 routines use fewer instructions per product than that reference "
+                        "multiplier (28-bit digits), so this is a progress gauge; issue_utilisation is the hardware-side figure"}
+        # VALU issue utilisation of the dominant kernel from the committed SQ counters (SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES)
+        sqf = os.path.join(ROOT, "profiles", "r01_sq_counters.json")
+        if os.path.exists(sqf):
+            try:
+                with open(sqf) as f:
+                    sq = json.load(f).get("k_" + N.PHASE_NAMES[dom])
+                valu["issue_utilisation"] = sq["SQ_ACTIVE_INST_VALU"] / sq["SQ_WAVE_CYCLES"]
+            except Exception:
+                pass
         traffic = None
         tf = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(tf):
