@@ -33,7 +33,7 @@ __global__ void MBLS_LB k_aggregate(mbls_ws ws, const uint8_t* pks, const uint32
     uint64_t i = gid(); if (i >= n) return;
     const uint32_t pkb = fmt == MBLS_PK_COMPRESSED ? 48u : 96u;
     uint64_t first = offsets ? offsets[i] : (uint64_t)k * i; uint32_t cnt = offsets ? offsets[i + 1] - offsets[i] : k;
-    uint32_t st; lane_aggregate(ws, i, pks + pkb * first, cnt, fmt, mode, &st); status[i] = st;
+    uint32_t st; lane_aggregate(ws, i, pks + pkb * first, cnt, fmt, mode, &st); status[i] |= st;
 }
 __global__ void __launch_bounds__(WG, 4) k_pk_decompress(const uint8_t* pks48, uint64_t nkeys, uint32_t* keys_xy, uint8_t* flags) {
     uint64_t j = gid(); if (j >= nkeys) return;
@@ -41,7 +41,7 @@ __global__ void __launch_bounds__(WG, 4) k_pk_decompress(const uint8_t* pks48, u
 }
 __global__ void MBLS_LB k_aggregate_decoded(mbls_ws ws, const uint32_t* keys_xy, const uint8_t* flags, uint32_t k, int mode, uint32_t* status, uint64_t n) {
     uint64_t i = gid(); if (i >= n) return;
-    uint32_t st; lane_aggregate_decoded(ws, i, keys_xy + 24 * (uint64_t)k * i, flags + (uint64_t)k * i, k, mode, &st); status[i] = st;
+    uint32_t st; lane_aggregate_decoded(ws, i, keys_xy + 24 * (uint64_t)k * i, flags + (uint64_t)k * i, k, mode, &st); status[i] |= st;
 }
 __global__ void MBLS_LB k_sig(mbls_ws ws, const uint8_t* sigs, uint32_t* status, uint64_t n) {
     uint64_t i = gid(); if (i >= n) return;
@@ -264,10 +264,10 @@ extern "C" int mbls_last_phase_ms(mbls_ctx* c, float ms[MBLS_N_PHASES]) {
 
 static int verify_pipeline(mbls_ctx* c, const uint8_t* d_sigs, const uint8_t* d_msgs, uint32_t msg_len, const uint8_t* d_pks, int fmt,
                            const uint32_t* d_off, uint64_t n, uint32_t k, int mode, uint8_t* d_results, uint64_t* d_bitmap,
-                           uint32_t* d_status, hipStream_t s) {
+                           uint32_t* d_status, hipStream_t s, int part = 0) {
     if (!c || (fmt != MBLS_PK_COMPRESSED && fmt != MBLS_PK_UNCOMPRESSED)) return MBLS_ERR_ARGUMENT;
     if (n == 0) return MBLS_OK;
-    if (!d_sigs || !d_msgs || !d_results || (!d_pks && (k || d_off))) return MBLS_ERR_ARGUMENT;
+    if (!d_sigs || !d_msgs || !d_results || (!d_pks && (k || d_off) && part != 1)) return MBLS_ERR_ARGUMENT;
     HIPCHK(c, hipSetDevice(c->device));
     int rc = mbls_ctx_reserve(c, n); if (rc) return rc;
     mbls_ws ws; ws.w = c->d_w; ws.stride = c->cap;
@@ -276,6 +276,17 @@ static int verify_pipeline(mbls_ctx* c, const uint8_t* d_sigs, const uint8_t* d_
     bool tm = c->timing;
     bool staged = (fmt == MBLS_PK_COMPRESSED) && !d_off && k > 1;   // lane-per-key decompression, then the per-item sums
     if (staged) { rc = reserve_keys(c, n * (uint64_t)k); if (rc) return rc; }
+    // The status words are zeroed and every phase ORs its bits in, so the phases before the Miller loop can run in any order.
+    // part 1 / part 2 (host-buffer entry points): the signature and message phases are queued first (part 1, the keys may be
+    // null), the caller then uploads the keys on another stream and makes this one wait, and part 2 queues the rest.
+    const bool keys_later = part != 0;
+    if (part != 2) HIPCHK(c, hipMemsetAsync(st, 0, 4 * n, s));
+    if (part == 1) {
+        hipLaunchKernelGGL(k_sig, dim3(g), dim3(WG), 0, s, ws, d_sigs, st, n);
+        hipLaunchKernelGGL(k_hash, dim3(g), dim3(WG), 0, s, ws, d_msgs, msg_len, (const uint64_t*)nullptr, (const uint32_t*)nullptr, n);
+        HIPCHK(c, hipGetLastError());
+        return MBLS_OK;
+    }
     if (tm) HIPCHK(c, hipEventRecord(c->ev[0], s));
     if (staged) {
         hipLaunchKernelGGL(k_pk_decompress, dim3(nblk(n * (uint64_t)k)), dim3(WG), 0, s, d_pks, n * (uint64_t)k, c->d_keys_xy, c->d_key_flags);
@@ -283,9 +294,9 @@ static int verify_pipeline(mbls_ctx* c, const uint8_t* d_sigs, const uint8_t* d_
     } else
         hipLaunchKernelGGL(k_aggregate, dim3(g), dim3(WG), 0, s, ws, d_pks, d_off, k, fmt, mode, st, n);
     if (tm) HIPCHK(c, hipEventRecord(c->ev[1], s));
-    hipLaunchKernelGGL(k_sig, dim3(g), dim3(WG), 0, s, ws, d_sigs, st, n);
+    if (!keys_later) hipLaunchKernelGGL(k_sig, dim3(g), dim3(WG), 0, s, ws, d_sigs, st, n);
     if (tm) HIPCHK(c, hipEventRecord(c->ev[2], s));
-    hipLaunchKernelGGL(k_hash, dim3(g), dim3(WG), 0, s, ws, d_msgs, msg_len, (const uint64_t*)nullptr, (const uint32_t*)nullptr, n);
+    if (!keys_later) hipLaunchKernelGGL(k_hash, dim3(g), dim3(WG), 0, s, ws, d_msgs, msg_len, (const uint64_t*)nullptr, (const uint32_t*)nullptr, n);
     if (tm) HIPCHK(c, hipEventRecord(c->ev[3], s));
     hipLaunchKernelGGL(k_miller, dim3(g), dim3(WG), 0, s, ws, n);
     if (tm) HIPCHK(c, hipEventRecord(c->ev[4], s));
@@ -330,11 +341,30 @@ static int verify_host(mbls_ctx* c, const uint8_t* sigs, const uint8_t* msgs, ui
     uint64_t total_keys = off ? off[n] : (uint64_t)k * n;
     size_t pkb = fmt == MBLS_PK_COMPRESSED ? 48 : 96;
     dbuf ds, dm, dp, doff, dr, dst;
-    HIPCHK(c, ds.up(sigs, 96 * n)); HIPCHK(c, dm.up(msgs, (size_t)msg_len * n)); HIPCHK(c, dp.up(pks, pkb * total_keys));
+    HIPCHK(c, ds.up(sigs, 96 * n)); HIPCHK(c, dm.up(msgs, (size_t)msg_len * n));
     if (off) HIPCHK(c, doff.up(off, 4 * (n + 1)));
-    HIPCHK(c, dr.alloc(n)); HIPCHK(c, dst.alloc(4 * n));
-    int rc = verify_pipeline(c, ds.as<uint8_t>(), dm.as<uint8_t>(), msg_len, dp.as<uint8_t>(), fmt, off ? doff.as<uint32_t>() : nullptr,
-                             n, k, mode, dr.as<uint8_t>(), nullptr, dst.as<uint32_t>(), 0);
+    HIPCHK(c, dr.alloc(n)); HIPCHK(c, dst.alloc(4 * n)); HIPCHK(c, dp.alloc(pkb * total_keys));
+    // the keys are 99 % of the bytes: they are uploaded on a second stream while the signature and message phases run
+    struct two_streams {
+        hipStream_t a = nullptr, b = nullptr; hipEvent_t e = nullptr;
+        ~two_streams() { if (e) (void)hipEventDestroy(e); if (a) (void)hipStreamDestroy(a); if (b) (void)hipStreamDestroy(b); }
+    } ts;
+    HIPCHK(c, hipStreamCreateWithFlags(&ts.a, hipStreamNonBlocking)); HIPCHK(c, hipStreamCreateWithFlags(&ts.b, hipStreamNonBlocking));
+    HIPCHK(c, hipEventCreateWithFlags(&ts.e, hipEventDisableTiming));
+    bool tm = c->timing; c->timing = false;              // the phase timers assume the plain order
+    const uint32_t* doffp = off ? doff.as<uint32_t>() : nullptr;
+    int rc = verify_pipeline(c, ds.as<uint8_t>(), dm.as<uint8_t>(), msg_len, nullptr, fmt, doffp, n, k, mode, dr.as<uint8_t>(), nullptr,
+                             dst.as<uint32_t>(), ts.a, 1);
+    if (!rc) {
+        hipError_t e1 = hipSuccess;      // issued after the first two phases were queued: a copy from pageable memory may block the host
+        if (total_keys) e1 = hipMemcpyAsync(dp.p, pks, pkb * total_keys, hipMemcpyHostToDevice, ts.b);
+        if (e1 == hipSuccess) e1 = hipEventRecord(ts.e, ts.b);
+        if (e1 == hipSuccess) e1 = hipStreamWaitEvent(ts.a, ts.e, 0);
+        if (e1 != hipSuccess) { c->timing = tm; HIPCHK(c, e1); }
+        rc = verify_pipeline(c, ds.as<uint8_t>(), dm.as<uint8_t>(), msg_len, dp.as<uint8_t>(), fmt, doffp, n, k, mode, dr.as<uint8_t>(), nullptr,
+                             dst.as<uint32_t>(), ts.a, 2);
+    }
+    c->timing = tm;
     if (rc) return rc;
     HIPCHK(c, hipDeviceSynchronize());
     HIPCHK(c, dr.down(results, n));
@@ -431,6 +461,7 @@ extern "C" int mbls_aggregate_public_keys_batch(mbls_ctx* c, const uint8_t* pks,
     uint64_t total = off ? off[n] : (uint64_t)k * n;
     dbuf dp, doff, dout; HIPCHK(c, dp.up(pks, (fmt ? 96 : 48) * total)); if (off) HIPCHK(c, doff.up(off, 4 * (n + 1))); HIPCHK(c, dout.alloc(96 * n));
     mbls_ws ws; ws.w = c->d_w; ws.stride = c->cap;
+    HIPCHK(c, hipMemsetAsync(c->d_status, 0, 4 * n, 0));      // k_aggregate ORs its bits in
     hipLaunchKernelGGL(k_aggregate, dim3(nblk(n)), dim3(WG), 0, 0, ws, dp.as<uint8_t>(), off ? doff.as<uint32_t>() : (const uint32_t*)nullptr, k, fmt,
                        MBLS_MODE_FAST_AGGREGATE, c->d_status, n);
     hipLaunchKernelGGL(k_apk_export, dim3(nblk(n)), dim3(WG), 0, 0, ws, n, dout.as<uint8_t>());
@@ -601,8 +632,10 @@ static int verify_multiple_impl(mbls_ctx* c, const uint8_t* d_sigs, const uint8_
     mbls_ws ws; ws.w = c->d_w; ws.stride = c->cap;
     HIPCHK(c, hipMemsetAsync(c->d_scalar, 0, 64, s));
     if (n) {
-        if (!d_apks)   // sets given by their wire-format keys: AggregatePublicKey::aggregate on the device first (src/aggregates.rs:29-39)
+        if (!d_apks) {  // sets given by their wire-format keys: AggregatePublicKey::aggregate on the device first (src/aggregates.rs:29-39)
+            HIPCHK(c, hipMemsetAsync(c->d_status, 0, 4 * n, s));
             hipLaunchKernelGGL(k_aggregate, dim3(nblk(n)), dim3(WG), 0, s, ws, d_pks, d_pk_offsets, k, pk_format, MBLS_MODE_VERIFY, c->d_status, n);
+        }
         hipLaunchKernelGGL(k_blind_pair, dim3(nblk(n)), dim3(WG), 0, s, ws, d_apks, d_sigs, d_rands, c->d_status, n);
         hipLaunchKernelGGL(k_status_or, dim3(nblk(n)), dim3(WG), 0, s, c->d_status, n, c->d_scalar);
         hipLaunchKernelGGL(k_hash, dim3(nblk(n)), dim3(WG), 0, s, ws, d_msgs, msg_len, (const uint64_t*)nullptr, (const uint32_t*)nullptr, n);
