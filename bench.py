@@ -9,12 +9,16 @@ final exponentiation -> bitmap) over one batch of 2^16 synthetic (signature, mes
 (BASELINE.json configs[2]), inputs resident in HBM, followed -- for N > 1 -- by the RCCL all-gather of the accept
 bitmap. Weak scaling: every rank verifies its own 2^16 items, no data-path collective.
 Inputs are produced on the device by the product's own signing / key kernels (the oracle is used only for the
-cpu_baseline leg and a small cross-check of the bitmap). PyTorch is plumbing: device buffers, stream, RCCL.
+cpu_baseline leg). PyTorch is plumbing: device buffers, stream, RCCL.
+
+Every figure in the JSON line is measured by THIS run unless its key says otherwise (`*_from_profile` objects carry the
+file and commit they were read from and are never part of `roofline` / `valu_issue` proper).
 """
 import argparse
 import ctypes as C
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -28,11 +32,11 @@ from milagro_bls_amd import _native as N  # noqa: E402
 from milagro_bls_amd import shard  # noqa: E402
 
 R = 0x73eda753299d7d483339d80809a1d80553bda402fffe5bfeffffffff00000001
+P = 0x1a0111ea397fe69a4b1ba7b6434bacd764774b84f38512bf6730d2a0f6b0f6241eabfffeb153ffffb9feffffffffaaab
 SEED = 0x6D626C73          # "mbls" 
 POOL = 4096
 HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s peak
-# a point of E'(Fp2) outside G2 (tests/golden/vectors.json model.g2_subgroup_probes[0]) for the "sig not in G2" negatives
-NOT_IN_G2_HEX = None
+N_SIMD = 256 * 4           # 256 CUs x 4 SIMDs
 
 
 def splitmix64(state):
@@ -55,9 +59,11 @@ def make_pool(seed):
     return sks
 
 
-def build_inputs(ctx, dev, n, k, fmt, rank, negatives=True):
+def build_inputs(ctx, dev, n, k, fmt, rank, negatives=True, return_indices=False):
     """Synthetic batch on the device. Item i uses the k pool keys {(a_i + j*s_i) mod POOL}, s_i odd (distinct keys);
-    sig_i = [sum sk mod r] H(msg_i). Every 16th item (i % 16 == 7) is corrupted, cycling over five rejection classes."""
+    sig_i = [sum sk mod r] H(msg_i). Every 16th item (i % 16 == 7) is corrupted, cycling over five rejection classes.
+    return_indices: additionally a resident key table holding the pool (+ the crafted keys of the apk = infinity items) and the
+    [n, k] uint32 table indices of every item's keys -- the same batch in the indexed representation."""
     lib = N.lib()
     pool = make_pool(SEED)
     pool_b = np.frombuffer(b"".join(s.to_bytes(32, "big") for s in pool), dtype=np.uint8).reshape(POOL, 32)
@@ -89,6 +95,13 @@ def build_inputs(ctx, dev, n, k, fmt, rank, negatives=True):
     ctx.check(lib.mbls_sign_batch_device(ctx.handle, d_agg.data_ptr(), d_msgs.data_ptr(), 32, n, d_sigs.data_ptr(), None))
     d_pks = d_pool_pk[d_idx.reshape(-1)].reshape(n, k, pkb).contiguous()
     expect = torch.ones(n, dtype=torch.uint8)
+    table = None
+    if return_indices:
+        table = N.KeyTable(ctx, capacity_hint=POOL + n // 64)
+        d_errs = torch.zeros(POOL, dtype=torch.uint8, device=dev)
+        table.append_device(d_pool_pk.data_ptr(), POOL, d_errs.data_ptr(), pk_format=fmt, validate=False)
+        torch.cuda.synchronize()
+        assert int(d_errs.max().item()) == 0
     if negatives:
         bad = np.arange(7, n, 16)
         kinds = np.arange(len(bad)) % 5
@@ -99,6 +112,7 @@ def build_inputs(ctx, dev, n, k, fmt, rank, negatives=True):
         if len(b1):
             other = (idx[b1, 0] + 1) % POOL
             d_pks[torch.from_numpy(b1).to(dev), 0] = d_pool_pk[torch.from_numpy(other).to(dev)]
+            idx[b1, 0] = other
         b2 = torch.from_numpy(bad[kinds == 2]).to(dev)                     # signature on the curve but outside G2
         if len(b2):
             with open(os.path.join(ROOT, "tests", "golden", "vectors.json")) as f:
@@ -115,11 +129,14 @@ def build_inputs(ctx, dev, n, k, fmt, rank, negatives=True):
             apk = np.zeros((len(b4), 96), dtype=np.uint8)
             ctx.check(lib.mbls_aggregate_public_keys_batch(ctx.handle, N.cbuf(part.cpu().numpy().tobytes()), fmt, None, len(b4), k - 1,
                                                            apk.ctypes.data_as(C.c_void_p), None))
-            P = 0x1a0111ea397fe69a4b1ba7b6434bacd764774b84f38512bf6730d2a0f6b0f6241eabfffeb153ffffb9feffffffffaaab
             neg = np.zeros((len(b4), 96), dtype=np.uint8)
             for r in range(len(b4)):
                 y = int.from_bytes(apk[r, 48:].tobytes(), "big")
                 neg[r] = np.frombuffer(apk[r, :48].tobytes() + ((P - y) % P).to_bytes(48, "big"), dtype=np.uint8)
+            if table is not None:
+                first, errs = table.append(neg.tobytes(), len(b4), pk_format=N.PK_UNCOMPRESSED, validate=False)
+                assert not any(errs)
+                idx[b4, k - 1] = first + np.arange(len(b4))
             if fmt == N.PK_COMPRESSED:
                 comp = np.zeros((len(b4), 48), dtype=np.uint8); errs = np.zeros(len(b4), dtype=np.uint8)
                 ctx.check(lib.mbls_pk_compress_batch(ctx.handle, neg.ctypes.data_as(C.c_void_p), len(b4), comp.ctypes.data_as(C.c_void_p),
@@ -129,33 +146,211 @@ def build_inputs(ctx, dev, n, k, fmt, rank, negatives=True):
         elif len(b4):
             expect[b4] = 1
     torch.cuda.synchronize()
+    if return_indices:
+        return d_sigs, d_msgs, d_pks, expect, torch.from_numpy(idx.astype(np.uint32).view(np.int32)).to(dev).contiguous(), table
     return d_sigs, d_msgs, d_pks, expect
 
 
-def cpu_baseline(d_sigs, d_msgs, d_pks, expect, k, fmt, seconds_target=12.0):
-    """The oracle (CPU port, not Milagro itself -- the reference cannot be built here) on a bounded sample of the same
-    batch, all host cores."""
+# ---------------------------------------------------------------------------------------------- the timed region
+def timed_steps(step, steps, warmup, world, sync):
+    """W untimed warm-up steps, then exactly K timed steps bracketed by barrier + device synchronisation on both sides; the
+    elapsed time is the MAX over ranks. `sync` synchronises the device (a no-op in the CPU test of this function)."""
+    def fence():
+        sync()
+        if world > 1:
+            dist.barrier()
+            sync()
+    for _ in range(warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    fence()
+    return reduce_max(time.perf_counter() - t0, world)
+
+
+def _reduce_device():
+    return torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+
+
+def reduce_max(x, world):
+    if world == 1:
+        return float(x)
+    t = torch.tensor([x], dtype=torch.float64, device=_reduce_device())
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def reduce_all_ok(ok, world):
+    if world == 1:
+        return bool(ok)
+    t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=_reduce_device())
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return bool(t.item())
+
+
+def check_bitmap(results_u8, bitmap_words, expect_u8):
+    """results and the packed bitmap must both equal the expectation known by construction"""
+    n = expect_u8.numel()
+    ok = bool(torch.equal(results_u8.cpu(), expect_u8))
+    return ok and bool(torch.equal(shard.unpack_bits(bitmap_words.cpu(), n), expect_u8))
+
+
+def check_gathered(all_words, world, words_per_rank, own_words, rank):
+    """the gathered bitmap holds this rank's words at its slot"""
+    mine = all_words[rank * words_per_rank:(rank + 1) * words_per_rank]
+    return bool(torch.equal(mine.cpu(), own_words.cpu()))
+
+
+# ---------------------------------------------------------------------------------------------- CPU baseline (the oracle)
+def _oracle_native():
+    """oracle/bls_oracle.c built -O3 -march=native for THIS host (the shipped oracle/_build library is a portable build)"""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import orc
-    cores = os.cpu_count() or 1
-    threads = min(cores, 256)
-    probe = min(4 * threads, d_sigs.shape[0])
-    pkb = d_pks.shape[2]
+    out = os.path.join(ROOT, "oracle", "_build", "libbls_oracle_native.so")
+    try:
+        os.makedirs(os.path.dirname(out), exist_ok=True)
+        subprocess.check_call(["gcc", "-O3", "-march=native", "-fPIC", "-std=gnu11", "-w", "-shared", "-o", out, os.path.join(ROOT, "oracle", "bls_oracle.c"), "-lpthread"])
+        orc.LIB_PATH = out
+        orc._lib = None
+        flags = "-O3 -march=native"
+    except Exception:
+        flags = "portable build (native rebuild failed)"
+    return orc, flags
 
-    def run(m):
+
+def usable_cores():
+    """threads the CPU leg can really run at once: the affinity set, capped by the cgroup CPU quota when the container has one (a
+    256-thread affinity mask over an 8-CPU quota runs 8 threads' worth of work, however many are started)"""
+    n = len(os.sched_getaffinity(0))
+    quota = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:                       # cgroup v2: "<quota|max> <period>"
+            q, p = f.read().split()
+            if q != "max":
+                quota = float(q) / float(p)
+    except (OSError, ValueError):
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f:        # cgroup v1
+                q = float(f.read())
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                p = float(f.read())
+            if q > 0:
+                quota = q / p
+        except (OSError, ValueError):
+            pass
+    if quota is not None:
+        n = max(1, min(n, int(quota + 0.5)))
+    return n, quota
+
+
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(d_sigs, d_msgs, d_pks, expect, k, fmt, seconds_target=10.0):
+    """The oracle (a CPU restatement -- "port" -- NOT Milagro/amcl: the reference cannot be built here, and amcl is several times
+    faster per core than this plain C) on a bounded sample of the same batch: all cores of this process's affinity set, one thread,
+    and BASELINE config 1 (single Signature::verify, one thread)."""
+    orc, flags = _oracle_native()
+    threads, quota = usable_cores()
+
+    def run(m, nthreads):
         sg = d_sigs[:m].cpu().numpy().tobytes(); ms = d_msgs[:m].cpu().numpy().tobytes(); pk = d_pks[:m].cpu().numpy().tobytes()
         t = time.perf_counter()
-        got = orc.batch_fast_aggregate_verify(sg, ms, pk, m, k, fmt, nthreads=threads)
+        got = orc.batch_fast_aggregate_verify(sg, ms, pk, m, k, fmt, nthreads=nthreads)
         dt = time.perf_counter() - t
         assert got == [bool(x) for x in expect[:m].tolist()], "oracle disagrees with the constructed expectation"
         return dt
-    dt = run(probe)
+    fmt_name = "compressed" if fmt == N.PK_COMPRESSED else "uncompressed"
+    # one thread
+    dt = run(8, 1)
+    m1 = int(max(8, min(d_sigs.shape[0], 8 * 4.0 / max(dt, 1e-3))))
+    dt1 = run(m1, 1)
+    one = {"value": m1 / dt1, "unit": "fast_aggregate_verify/s", "cores": 1, "kind": "port",
+           "sample": "%d items (k=%d, %s keys) of the GPU batch, oracle/bls_oracle.c %s, 1 thread, %.1f s" % (m1, k, fmt_name, flags, dt1)}
+    # all cores
+    probe = min(2 * threads, d_sigs.shape[0])
+    dt = run(probe, threads)
     m = int(min(d_sigs.shape[0], max(probe, probe * seconds_target / max(dt, 1e-3))))
     m = max(threads, (m // threads) * threads)
-    dt = run(m)
-    return {"value": m / dt, "unit": "fast_aggregate_verify/s", "cores": threads, "kind": "port",
-            "sample": "%d items (k=%d, %s keys) of the GPU batch, oracle/bls_oracle.c, %d threads, %.1f s" % (
-                m, k, "compressed" if fmt == N.PK_COMPRESSED else "uncompressed", threads, dt)}
+    dt = run(m, threads)
+    allc = {"value": m / dt, "unit": "fast_aggregate_verify/s", "cores": threads, "kind": "port", "cpu": cpu_model(),
+            "sample": "%d items (k=%d, %s keys) of the GPU batch, oracle/bls_oracle.c %s (CPU restatement, not Milagro), %d threads "
+                      "= this process's affinity set (os.cpu_count() = %d), %.1f s" % (m, k, fmt_name, flags, threads, os.cpu_count() or 0, dt)}
+    # BASELINE config 1: single Signature::verify, msg "Some msg", one thread (reference benches/bls381_benches.rs:104-112)
+    sk = 0x263dbd792f5b1be47ed85f8938c0f29586af0d3ac7b977f21c278fe1462040e3
+    msg = b"Some msg"
+    sig = orc.sign(msg, sk); pk = orc.sk_to_pk(sk)
+    reps, t = 0, time.perf_counter()
+    while time.perf_counter() - t < 2.0:
+        assert orc.verify(sig, msg, pk)
+        reps += 1
+    cfg1 = {"value": reps / (time.perf_counter() - t), "unit": "Signature::verify/s", "cores": 1, "kind": "port",
+            "sample": "configs[0]: %d x verify of one (sig, 'Some msg', pk), 1 thread" % reps}
+    return allc, one, cfg1
+
+
+# ---------------------------------------------------------------------------------------------- instruction-level figure
+def valu_issue_figure(lib, ctx, phase_ms, n_items):
+    """Hardware-side efficiency of the two dominant kernels from numbers this run measures plus the generators' exact instruction
+    counts (profiles/instr_census.json, written by tools/instr_census.py from the same generators that emit the routines):
+    achieved = wave-instructions per item x items / 64 lanes / kernel time / 1024 SIMDs;
+    ceiling  = the rate one SIMD issues this instruction mix at, measured live by mbls_valu_bench (8 waves per SIMD): v_mad_u64_u32
+    and plain 32-bit VALU timed separately and blended by the routines' mix. Only the generated straight-line routines are counted
+    (the cold compiler-scheduled paths -- 10 addition steps, one Fp12 inversion, Frobenius maps -- are not), so `frac` is a lower bound."""
+    cf = os.path.join(ROOT, "profiles", "instr_census.json")
+    if not os.path.exists(cf):
+        return None
+    with open(cf) as f:
+        census = json.load(f)
+    rate = {}
+    for mode, name in ((0, "v_mad_u64_u32"), (1, "plain_valu")):
+        ms = C.c_float()
+        ctx.check(lib.mbls_valu_bench(ctx.handle, mode, 8, 4000, C.byref(ms)))
+        rate[name] = 8 * 4000 * 128 / (ms.value * 1e-3)            # wave-instructions per second per SIMD
+    out = {"unit": "wave-instructions/s/SIMD", "ceiling_measured": rate, "kernels": {},
+           "note": "ceiling = live mbls_valu_bench at 8 waves/SIMD; instruction counts = generated routines only (exact), cold paths excluded: frac is a lower bound"}
+    for kern, phase in (("k_miller", "miller"), ("k_final", "final")):
+        c = census["per_item"].get(kern)
+        if not c or phase_ms.get(phase, 0) <= 0:
+            continue
+        total, mad = c["valu"], c["mad_u64_u32"]
+        ach = total * n_items / 64.0 / (phase_ms[phase] * 1e-3) / N_SIMD
+        ceil = total / (mad / rate["v_mad_u64_u32"] + (total - mad) / rate["plain_valu"])
+        out["kernels"][kern] = {"valu_wave_instr_per_item": total, "of_which_v_mad_u64_u32": mad, "achieved": ach, "ceiling": ceil, "frac": ach / ceil}
+    return out
+
+
+def git_head():
+    try:
+        return subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], text=True, stderr=subprocess.DEVNULL).strip()
+    except Exception:
+        return None
+
+
+def from_profile(fname, key):
+    """a figure that was NOT measured by this run: read from a committed profile, labelled with its source"""
+    p = os.path.join(ROOT, "profiles", fname)
+    if not os.path.exists(p):
+        return None
+    try:
+        with open(p) as f:
+            d = json.load(f)
+        v = d.get(key)
+        if v is None:
+            return None
+        return {"value": v, "source": "profiles/%s (%s)" % (fname, d.get("_collected", "collected in an earlier run")), "measured_by_this_run": False}
+    except Exception:
+        return None
 
 
 def main():
@@ -163,10 +358,13 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--items", type=int, default=1 << 16, help="items per GPU per step (default 2^16, BASELINE configs[2])")
+    ap.add_argument("--items", type=int, default=1 << 16, help="items per GPU per step (default 2^16, BASELINE configs[2]; 131072 = the config-5 shard)")
     ap.add_argument("--keys", type=int, default=128)
-    ap.add_argument("--pk-format", choices=["uncompressed", "compressed"], default="uncompressed")
+    ap.add_argument("--pk-format", choices=["uncompressed", "compressed", "indexed"], default="uncompressed",
+                    help="how the timed path receives the keys: 96-byte decoded form (default: what the reference's fast_aggregate_verify takes), "
+                         "48-byte wire form, or indices into a resident key table")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-variants", action="store_true", help="skip the compressed-key and indexed-key legs")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -182,130 +380,123 @@ def main():
     ctx = N.Context(dev.index)
     lib = N.lib()
     n, k = args.items, args.keys
-    fmt = N.PK_UNCOMPRESSED if args.pk_format == "uncompressed" else N.PK_COMPRESSED
-    pkb = 96 if fmt == N.PK_UNCOMPRESSED else 48
-    bytes_per_item = k * pkb + 96 + 32 + 1          # algorithmic bytes in + 1 out
+    words = (n + 63) // 64
+    stream = torch.cuda.current_stream(dev)
+    sptr = C.c_void_p(stream.cuda_stream)
 
     t_in = time.perf_counter()
-    d_sigs, d_msgs, d_pks, expect = build_inputs(ctx, dev, n, k, fmt, rank)
+    d_sigs, d_msgs, d_pks, expect, d_idx, table = build_inputs(ctx, dev, n, k, N.PK_UNCOMPRESSED, rank, return_indices=True)
     t_in = time.perf_counter() - t_in
-    d_res = torch.zeros(n, dtype=torch.uint8, device=dev)
-    words = (n + 63) // 64
-    d_bm = torch.zeros(words, dtype=torch.int64, device=dev)
-    d_all = torch.zeros(words * world, dtype=torch.int64, device=dev) if world > 1 else None
     ctx.reserve(n)
-    if fmt == N.PK_COMPRESSED:
-        ctx.check(lib.mbls_ctx_reserve_keys(ctx.handle, n * k))
-    stream = torch.cuda.current_stream(dev)
 
-    def step():
-        ctx.check(lib.mbls_fast_aggregate_verify_batch_device(ctx.handle, d_sigs.data_ptr(), d_msgs.data_ptr(), 32, d_pks.data_ptr(), fmt, None,
-                                                              n, k, d_res.data_ptr(), d_bm.data_ptr(), None, C.c_void_p(stream.cuda_stream)))
+    def make_step(kind, d_res, d_bm, d_all, d_pk_c=None):
+        if kind == "indexed":
+            def verify():
+                ctx.check(lib.mbls_fast_aggregate_verify_batch_indexed_device(ctx.handle, table.handle, d_sigs.data_ptr(), d_msgs.data_ptr(), 32, d_idx.data_ptr(),
+                                                                              None, n, k, d_res.data_ptr(), d_bm.data_ptr(), None, sptr))
+        else:
+            fmt = N.PK_UNCOMPRESSED if kind == "uncompressed" else N.PK_COMPRESSED
+            pk = d_pks if kind == "uncompressed" else d_pk_c
+
+            def verify():
+                ctx.check(lib.mbls_fast_aggregate_verify_batch_device(ctx.handle, d_sigs.data_ptr(), d_msgs.data_ptr(), 32, pk.data_ptr(), fmt, None,
+                                                                      n, k, d_res.data_ptr(), d_bm.data_ptr(), None, sptr))
+
+        def step():
+            verify()
+            if world > 1:
+                shard.all_gather_bitmap(d_bm, world, out=d_all)  # the only collective: RCCL gather of the accept bitmap
+        return step, verify
+
+    def compressed_keys():
+        flat = d_pks.reshape(-1, 96)
+        out = torch.empty((flat.shape[0], 48), dtype=torch.uint8, device=dev)
+        # compress on the device in slices through the host-buffer helper (input generation, untimed)
+        sl = 1 << 18
+        for c0 in range(0, flat.shape[0], sl):
+            part = flat[c0:c0 + sl].cpu().numpy()
+            comp = np.zeros((part.shape[0], 48), dtype=np.uint8); errs = np.zeros(part.shape[0], dtype=np.uint8)
+            ctx.check(lib.mbls_pk_compress_batch(ctx.handle, part.ctypes.data_as(C.c_void_p), part.shape[0], comp.ctypes.data_as(C.c_void_p), errs.ctypes.data_as(C.c_void_p)))
+            assert not errs.any()
+            out[c0:c0 + sl] = torch.from_numpy(comp).to(dev)
+        return out.reshape(n, k, 48).contiguous()
+
+    def run_leg(kind, steps, warmup):
+        d_res = torch.zeros(n, dtype=torch.uint8, device=dev)
+        d_bm = torch.zeros(words, dtype=torch.int64, device=dev)
+        d_all = torch.zeros(words * world, dtype=torch.int64, device=dev) if world > 1 else None
+        d_pk_c = None
+        if kind == "compressed":
+            d_pk_c = compressed_keys()
+            ctx.check(lib.mbls_ctx_reserve_keys(ctx.handle, n * k))
+        step, verify = make_step(kind, d_res, d_bm, d_all, d_pk_c)
+        lib.mbls_enable_phase_timing(ctx.handle, 0)
+        elapsed = timed_steps(step, steps, warmup, world, torch.cuda.synchronize)
+        ok = check_bitmap(d_res, d_bm, expect)
         if world > 1:
-            shard.all_gather_bitmap(d_bm, world, out=d_all)  # the only collective: RCCL gather of the accept bitmap
+            ok = ok and check_gathered(d_all, world, words, d_bm, rank)
+        ok = reduce_all_ok(ok, world)
+        # per-kernel timing with HIP events on the launch stream (separate, untimed pass)
+        lib.mbls_enable_phase_timing(ctx.handle, 1)
+        phase = np.zeros(N.N_PHASES, dtype=np.float64)
+        reps = max(1, min(3, steps))
+        for _ in range(reps):
+            verify()
+            ms = (C.c_float * N.N_PHASES)()
+            lib.mbls_last_phase_ms(ctx.handle, ms)
+            phase += np.array(list(ms))
+        phase /= reps
+        lib.mbls_enable_phase_timing(ctx.handle, 0)
+        return elapsed, ok, {nm: float(v) for nm, v in zip(N.PHASE_NAMES, phase)}
 
-    def fence():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-            torch.cuda.synchronize()
-
-    lib.mbls_enable_phase_timing(ctx.handle, 0)
-    for _ in range(args.warmup):
-        step()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-
-    # correctness of what was timed: the accept bitmap must equal the expectation known by construction
-    got = d_res.cpu()
-    ok = bool(torch.equal(got, expect))
-    bits = d_bm.cpu().numpy().view(np.uint64)
-    unpacked = ((bits[:, None] >> np.arange(64, dtype=np.uint64)[None, :]) & 1).reshape(-1)[:n].astype(np.uint8)
-    ok = ok and bool((unpacked == expect.numpy()).all())
-    if world > 1:
-        okt = torch.tensor([1 if ok else 0], device=dev)
-        dist.all_reduce(okt, op=dist.ReduceOp.MIN)
-        ok = bool(okt.item())
-
-    # per-kernel timing with HIP events on the launch stream (separate, untimed pass) -> roofline of the dominant kernel
-    lib.mbls_enable_phase_timing(ctx.handle, 1)
-    phase = np.zeros(N.N_PHASES, dtype=np.float64)
-    reps = max(1, min(3, args.steps))
-    for _ in range(reps):
-        ctx.check(lib.mbls_fast_aggregate_verify_batch_device(ctx.handle, d_sigs.data_ptr(), d_msgs.data_ptr(), 32, d_pks.data_ptr(), fmt, None,
-                                                              n, k, d_res.data_ptr(), d_bm.data_ptr(), None, C.c_void_p(stream.cuda_stream)))
-        ms = (C.c_float * N.N_PHASES)()
-        lib.mbls_last_phase_ms(ctx.handle, ms)
-        phase += np.array(list(ms))
-    phase /= reps
-    lib.mbls_enable_phase_timing(ctx.handle, 0)
-    dom = int(np.argmax(phase))
+    elapsed, ok, phase_ms = run_leg(args.pk_format, args.steps, args.warmup)
+    variants = {}
+    if not args.no_variants and world == 1:
+        for kind in ("compressed", "indexed", "uncompressed"):
+            if kind == args.pk_format:
+                continue
+            e2, ok2, ph2 = run_leg(kind, max(2, min(3, args.steps)), 1)
+            st2 = max(2, min(3, args.steps))
+            pkb2 = {"compressed": 48 * k, "uncompressed": 96 * k, "indexed": 4 * k}[kind]
+            variants[kind] = {"value": n * st2 / e2, "unit": "fast_aggregate_verify/s", "ms_per_step": e2 / st2 * 1e3, "bitmap_matches_expectation": ok2,
+                              "algorithmic_bytes_per_item": pkb2 + 96 + 32 + 1, "phase_ms": ph2}
+            ok = ok and ok2
 
     if rank == 0:
+        pkb = {"compressed": 48 * k, "uncompressed": 96 * k, "indexed": 4 * k}[args.pk_format]
+        bytes_per_item = pkb + 96 + 32 + 1          # algorithmic bytes in + 1 out
         ms_per_step = elapsed / args.steps * 1e3
         value = n * world * args.steps / elapsed
-        achieved = n * bytes_per_item / (phase[dom] * 1e-3) / 1e9          # algorithmic GB/s through the dominant kernel
-        # integer-ALU calibration (the bound that actually applies): dependent Fp multiplications, all lanes busy
-        cal_ms = C.c_float()
-        ctx.check(lib.mbls_fp_mul_bench(ctx.handle, 1 << 19, 2000, C.byref(cal_ms)))
-        fpmul_peak = (1 << 19) * 2000 / (cal_ms.value * 1e-3)
-        # Fp multiplications per item: census of the lane bodies (tests/host_emul counts fp_mul + fp_sqr calls), committed
-        census = None
-        cf = os.path.join(ROOT, "profiles", "fpmul_census.json")
-        if os.path.exists(cf):
-            with open(cf) as f:
-                census = json.load(f).get("k%d_%s" % (k, args.pk_format))
-        valu = {"unit": "Fp mul/s", "peak_measured": fpmul_peak, "fp_mul_per_item": census,
-                "achieved": (value / world) * census if census else None,
-                "frac": (value / world) * census / fpmul_peak if census else None,
-                "note": "peak = k_fp_mul_bench (dependent Montgomery multiplications with the 32-bit-limb fp_mul, 2^19 lanes) "
-                        "measured in this run; fp_mul_per_item from profiles/fpmul_census.json (emulator census of fp_mul+fp_sqr "
-                        "calls, Karatsuba equivalents). The Fp2 routines use fewer instructions per product than that reference "
-                        "multiplier (28-bit digits), so this is a progress gauge; issue_utilisation is the hardware-side figure"}
-        # VALU issue utilisation of the dominant kernel from the committed SQ counters (SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES)
-        sqf = os.path.join(ROOT, "profiles", "r01_sq_counters.json")
-        if os.path.exists(sqf):
-            try:
-                with open(sqf) as f:
-                    sq = json.load(f).get("k_" + N.PHASE_NAMES[dom])
-                valu["issue_utilisation"] = sq["SQ_ACTIVE_INST_VALU"] / sq["SQ_WAVE_CYCLES"]
-            except Exception:
-                pass
-        traffic = None
-        tf = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if os.path.exists(tf):
-            try:
-                with open(tf) as f:
-                    traffic = json.load(f).get(N.PHASE_NAMES[dom])
-            except Exception:
-                traffic = None
+        dom = max((nm for nm in phase_ms), key=lambda nm: phase_ms[nm])
+        achieved = n * bytes_per_item / (phase_ms[dom] * 1e-3) / 1e9          # algorithmic GB/s through the dominant kernel
+        cfg_name = "configs[2]" if n == (1 << 16) else ("the configs[4] shard (2^20 items / 8 GPUs)" if n == (1 << 17) else "custom size")
         out = {
             "metric": "fast_aggregate_verify/sec (128 pubkeys, 32B msg)", "value": value, "unit": "fast_aggregate_verify/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "u32 (12 x 32-bit Montgomery limbs; 14 x 28-bit digits with 64-bit column sums inside the multiplication routines)", "data": "synthetic",
-            "config": {"workload": "configs[2]: batch 2^%d fast_aggregate_verify, %d pubkeys each, per GPU" % (int(np.log2(n)), k),
+            "scaling": "weak", "vs_baseline": None,
+            "dtype": "u32 (12 x 32-bit Montgomery limbs; 14 x 28-bit digits with 64-bit column sums inside the multiplication routines)", "data": "synthetic",
+            "config": {"workload": "%s: batch of %d fast_aggregate_verify, %d pubkeys each, per GPU" % (cfg_name, n, k),
                        "items_per_gpu": n, "keys_per_item": k, "msg_bytes": 32, "pk_format": args.pk_format,
                        "negatives": "every 16th item corrupted (msg bit / wrong key / sig not in G2 / infinity sig / apk = infinity)",
                        "parallelism": "items sharded over %d GPU(s), RCCL all-gather of the accept bitmap" % world},
             "bitmap_matches_expectation": ok,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "kernel": "k_" + N.PHASE_NAMES[dom], "kernel_ms": float(phase[dom]),
+                         "traffic": None, "kernel": "k_" + dom, "kernel_ms": phase_ms[dom],
                          "algorithmic_bytes_per_item": bytes_per_item,
-                         "note": "integer-ALU bound path: HBM fraction is reported as measured, see valu_roofline"},
-            "valu_roofline": valu,
-            "phase_ms": {nm: float(v) for nm, v in zip(N.PHASE_NAMES, phase)},
+                         "note": "VALU-issue-bound path (see valu_issue): the HBM fraction is reported as measured; traffic (PMC counters) cannot "
+                                 "be collected inside a timed run, see traffic_from_profile"},
+            "traffic_from_profile": from_profile("hbm_traffic.json", dom),
+            "valu_issue": valu_issue_figure(lib, ctx, phase_ms, n),
+            "phase_ms": phase_ms,
+            "variants": variants,
             "input_build_s": t_in,
+            "head": git_head(),
         }
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(d_sigs, d_msgs, d_pks, expect, k, fmt)
+            allc, one, cfg1 = cpu_baseline(d_sigs, d_msgs, d_pks, expect, k, N.PK_UNCOMPRESSED)
+            out["cpu_baseline"] = allc
+            out["cpu_baseline_1t"] = one
+            out["cpu_config1"] = cfg1
         elif not args.no_cpu_baseline:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)

@@ -52,10 +52,15 @@ extern "C" {
 #define MBLS_ST_NO_KEYS 0x10u
 #define MBLS_ST_PK_INFINITY 0x20u
 #define MBLS_ST_PAIRING_FAILED 0x40u
+#define MBLS_ST_BAD_SCALAR 0x80u            /* verify_multiple: a zero blinding scalar */
 
 typedef struct mbls_ctx mbls_ctx;
 
-/* ---- context: one per GPU (one process per GPU in multi-GPU runs) ---- */
+/* ---- context: one per GPU (one process per GPU in multi-GPU runs) ----
+ * Thread safety: every entry point takes the context's lock, so a context may be shared by any number of threads (the
+ * reference's functions are pure and re-entrant); calls on one context run one after the other.
+ * Device-pointer entries only enqueue work: a later call on another stream waits (on the device) for the workspace of
+ * the earlier one. For concurrent streams of work create one context per stream. */
 int mbls_ctx_create(mbls_ctx** out, int device_id);
 void mbls_ctx_destroy(mbls_ctx* ctx);
 /* pre-allocate the HBM workspace for batches of up to max_items items (avoids allocation in timed regions) */
@@ -84,6 +89,37 @@ int mbls_verify_batch_device(mbls_ctx* ctx, const uint8_t* d_sigs, const uint8_t
                              uint32_t* d_status, void* stream);
 int mbls_verify_batch(mbls_ctx* ctx, const uint8_t* sigs, const uint8_t* msgs, uint32_t msg_len,
                       const uint8_t* pks, int pk_format, uint64_t n, uint8_t* results, uint32_t* status);
+
+/* ---- resident key table ---------------------------------------------------------------------------------
+ * The on-device analogue of the decoded PublicKey objects a reference caller keeps (src/keys.rs:116-120; callers cache
+ * decoded keys through as_uncompressed_bytes / from_uncompressed_bytes, src/keys.rs:163-175): keys are decoded (and
+ * optionally KeyValidate'd) ONCE into HBM as affine Montgomery limbs, and a verification names its keys by table index --
+ * what `&[&PublicKey]` is in the reference's fast_aggregate_verify (src/aggregates.rs:177). Per use this removes the byte
+ * decoding, the Montgomery conversion and the on-curve check (5 of 16 multiplications per key), makes the compressed
+ * 48-byte wire format a one-time cost, and cuts the per-item input to 96 + msg_len + 4 k bytes.
+ * A table belongs to the context it was created with (same GPU, same lock). Entries are never removed; indices are stable. */
+typedef struct mbls_keytable mbls_keytable;
+int mbls_keytable_create(mbls_ctx* ctx, uint64_t capacity_hint, mbls_keytable** out);
+void mbls_keytable_destroy(mbls_keytable* t);
+uint64_t mbls_keytable_size(const mbls_keytable* t);
+/* n x PublicKey::from_bytes (pk_format compressed, validate = 1), from_bytes_unchecked (compressed, 0) or
+ * from_uncompressed_bytes (uncompressed, 0): entry first_index + i holds key i; errs[i] = MBLS_OK / MBLS_ERR_* exactly as
+ * the reference constructor would return. A key that failed is stored as an invalid entry: every item that names it is
+ * rejected with MBLS_ST_BAD_PK_ENCODING (the reference caller would hold no PublicKey to pass). */
+int mbls_keytable_append(mbls_keytable* t, const uint8_t* pks, int pk_format, int validate, uint64_t n, uint64_t* first_index, uint8_t* errs);
+int mbls_keytable_append_device(mbls_keytable* t, const uint8_t* d_pks, int pk_format, int validate, uint64_t n, uint64_t* first_index,
+                                uint8_t* d_errs, void* stream);
+/* PublicKey::as_uncompressed_bytes of n consecutive entries (src/keys.rs:163-165); errs[i] = MBLS_ERR_INVALID_POINT for invalid entries */
+int mbls_keytable_get(mbls_keytable* t, uint64_t first_index, uint64_t n, uint8_t* pks96, uint8_t* errs);
+/* The hot path over table indices: item i uses entries key_idx[k i .. k i + k) (offsets == NULL) or
+ * key_idx[offsets[i] .. offsets[i+1]). An index >= mbls_keytable_size counts as an undecodable key. Same results, bitmap and
+ * status words as mbls_fast_aggregate_verify_batch over the same keys in wire format. */
+int mbls_fast_aggregate_verify_batch_indexed_device(mbls_ctx* ctx, const mbls_keytable* t, const uint8_t* d_sigs, const uint8_t* d_msgs,
+                                                    uint32_t msg_len, const uint32_t* d_key_idx, const uint32_t* d_offsets, uint64_t n, uint32_t k,
+                                                    uint8_t* d_results, uint64_t* d_bitmap, uint32_t* d_status, void* stream);
+int mbls_fast_aggregate_verify_batch_indexed(mbls_ctx* ctx, const mbls_keytable* t, const uint8_t* sigs, const uint8_t* msgs, uint32_t msg_len,
+                                             const uint32_t* key_idx, const uint32_t* offsets, uint64_t n, uint32_t k, uint8_t* results,
+                                             uint32_t* status);
 
 /* ---- scalar API, 1:1 with the reference's methods (each runs the batch kernels with n = 1) ---- */
 /* PublicKey::from_bytes (src/keys.rs:140-147): compressed decode + KeyValidate -> 96-byte decoded key */
@@ -120,8 +156,11 @@ int mbls_fast_aggregate_verify_pre_aggregated(mbls_ctx* ctx, const uint8_t sig[9
 int mbls_aggregate_verify(mbls_ctx* ctx, const uint8_t sig[96], const uint8_t* msgs, const size_t* msg_lens, size_t n_msgs,
                           const uint8_t* pks96, size_t n_pks);
 /* AggregateSignature::verify_multiple_aggregate_signatures (src/aggregates.rs:261-316): n sets of
- * (aggregate signature, aggregate public key, message); rands[i] = the nonzero 63-bit blinding scalars drawn
- * from the caller's RNG exactly as at src/aggregates.rs:280-287. One bool for the whole batch. */
+ * (aggregate signature, aggregate public key, message); rands[i] = the NONZERO blinding scalars (63 bits in the
+ * reference) drawn from the caller's RNG exactly as at src/aggregates.rs:280-287 -- the reference owns that loop, here
+ * the caller does. The scalars are the security of the batch check: rands == NULL is MBLS_ERR_ARGUMENT, and a zero
+ * scalar (which would drop its set from the check) makes the call fail: result 0 and MBLS_ERR_ARGUMENT from the
+ * *_device forms, 0 from the bool form. One bool for the whole batch. */
 int mbls_verify_multiple_aggregate_signatures(mbls_ctx* ctx, const uint8_t* sigs96, const uint8_t* apks96,
                                               const uint8_t* msgs, uint32_t msg_len, const uint64_t* rands, size_t n);
 int mbls_verify_multiple_aggregate_signatures_device(mbls_ctx* ctx, const uint8_t* d_sigs96, const uint8_t* d_apks96,
@@ -147,6 +186,12 @@ int mbls_sk_to_pk_batch(mbls_ctx* ctx, const uint8_t* sks32, int out_format, uin
 int mbls_sk_to_pk_batch_device(mbls_ctx* ctx, const uint8_t* d_sks32, int out_format, uint64_t n, uint8_t* d_pks, void* stream);
 /* n x hash_to_curve_g2 (src/amcl_utils.rs:33-35), compressed output */
 int mbls_hash_to_g2_batch(mbls_ctx* ctx, const uint8_t* msgs, uint32_t msg_len, uint64_t n, uint8_t* out96);
+/* n x AggregateSignature::aggregate (src/aggregates.rs:100-106): set i sums its k signatures (or the signatures
+ * [offsets[i], offsets[i+1]) of sigs96), starting from infinity (an empty set gives 0xC0 || 0..). errs[i] = MBLS_OK or the
+ * Signature::from_bytes error of the first member that does not decode. No subgroup check, like the reference. */
+int mbls_aggregate_signatures_batch(mbls_ctx* ctx, const uint8_t* sigs96, const uint32_t* offsets, uint64_t n, uint32_t k, uint8_t* out96, uint8_t* errs);
+int mbls_aggregate_signatures_batch_device(mbls_ctx* ctx, const uint8_t* d_sigs96, const uint32_t* d_offsets, uint64_t n_sets, uint32_t k,
+                                           uint64_t total_sigs, uint8_t* d_out96, uint8_t* d_errs, void* stream);
 /* n x AggregatePublicKey::aggregate over wire-format keys -> decoded aggregate keys */
 int mbls_aggregate_public_keys_batch(mbls_ctx* ctx, const uint8_t* pks, int pk_format, const uint32_t* pk_offsets,
                                      uint64_t n, uint32_t k, uint8_t* apks96, uint32_t* status);
@@ -156,6 +201,10 @@ int mbls_aggregate_public_keys_batch(mbls_ctx* ctx, const uint8_t* pks, int pk_f
 int mbls_fp_mul_batch(mbls_ctx* ctx, const uint8_t* a48, const uint8_t* b48, uint64_t n, uint8_t* out48, int op);
 /* integer-ALU calibration: runs `iters` dependent Fp multiplications per lane on n lanes, returns elapsed ms */
 int mbls_fp_mul_bench(mbls_ctx* ctx, uint64_t n_lanes, uint32_t iters, float* ms_out);
+
+/* VALU issue-rate calibration for bench.py: every SIMD runs waves_per_simd (1..8) waves of `iters` x 128 instructions; mode 0:
+ * v_mad_u64_u32, mode 1: v_add_co/v_addc chains. Returns elapsed ms (rate = waves_per_simd * iters * 128 / ms per SIMD). */
+int mbls_valu_bench(mbls_ctx* ctx, int mode, uint32_t waves_per_simd, uint32_t iters, float* ms_out);
 
 /* ---- instrumentation: per-kernel HIP-event timing of the last *_device verify call (ms), for bench.py ---- */
 #define MBLS_N_PHASES 6

@@ -9,12 +9,17 @@
 //     AggregateSignature::fast_aggregate_verify(..)      same
 //     AggregateSignature::verify_multiple_aggregate_signatures(rng, iter)   same, rng = any callable returning uint8_t
 //
-// Every numeric operation runs in the HIP kernels; there is no CPU arithmetic here and no fallback: constructing the
-// first object without a GPU throws DeviceError.
+// Every curve / pairing operation runs in the HIP kernels; there is no CPU fallback: constructing the first object without a
+// GPU throws DeviceError. The only host arithmetic is SecretKey::key_generate (HKDF-SHA-256 + one reduction mod r), which the
+// reference also does on the host (src/keys.rs:45-77).
+// Threads: all objects go through one process-wide mbls_ctx; every C ABI entry takes that context's lock, so the types can be used
+// from any number of threads like the reference's -- calls are serialised on the one GPU.
 #pragma once
+#include <algorithm>
 #include <array>
 #include <cstdint>
 #include <cstring>
+#include <random>
 #include <stdexcept>
 #include <string>
 #include <tuple>
@@ -52,10 +57,93 @@ inline void check(int rc) {
 }
 }  // namespace detail
 
-// reference src/keys.rs:28-113 (host-only; HKDF key generation is out of this library's scope)
+// ---- host-side SHA-256 / HMAC / HKDF for KeyGenerate (reference src/keys.rs:45-77 uses amcl's HASH256::hkdf_extract / hkdf_extend)
+namespace detail {
+struct Sha256 {
+    uint32_t h[8]; uint8_t buf[64]; uint64_t len = 0; size_t fill = 0;
+    Sha256() { static const uint32_t iv[8] = {0x6a09e667,0xbb67ae85,0x3c6ef372,0xa54ff53a,0x510e527f,0x9b05688c,0x1f83d9ab,0x5be0cd19}; std::memcpy(h, iv, 32); }
+    static uint32_t ror(uint32_t x, int n) { return (x >> n) | (x << (32 - n)); }
+    void block(const uint8_t* p) {
+        static const uint32_t K[64] = {
+            0x428a2f98,0x71374491,0xb5c0fbcf,0xe9b5dba5,0x3956c25b,0x59f111f1,0x923f82a4,0xab1c5ed5,0xd807aa98,0x12835b01,0x243185be,0x550c7dc3,0x72be5d74,0x80deb1fe,0x9bdc06a7,0xc19bf174,
+            0xe49b69c1,0xefbe4786,0x0fc19dc6,0x240ca1cc,0x2de92c6f,0x4a7484aa,0x5cb0a9dc,0x76f988da,0x983e5152,0xa831c66d,0xb00327c8,0xbf597fc7,0xc6e00bf3,0xd5a79147,0x06ca6351,0x14292967,
+            0x27b70a85,0x2e1b2138,0x4d2c6dfc,0x53380d13,0x650a7354,0x766a0abb,0x81c2c92e,0x92722c85,0xa2bfe8a1,0xa81a664b,0xc24b8b70,0xc76c51a3,0xd192e819,0xd6990624,0xf40e3585,0x106aa070,
+            0x19a4c116,0x1e376c08,0x2748774c,0x34b0bcb5,0x391c0cb3,0x4ed8aa4a,0x5b9cca4f,0x682e6ff3,0x748f82ee,0x78a5636f,0x84c87814,0x8cc70208,0x90befffa,0xa4506ceb,0xbef9a3f7,0xc67178f2};
+        uint32_t w[64];
+        for (int i = 0; i < 16; i++) w[i] = (uint32_t(p[4 * i]) << 24) | (uint32_t(p[4 * i + 1]) << 16) | (uint32_t(p[4 * i + 2]) << 8) | p[4 * i + 3];
+        for (int i = 16; i < 64; i++) w[i] = w[i - 16] + (ror(w[i - 15], 7) ^ ror(w[i - 15], 18) ^ (w[i - 15] >> 3)) + w[i - 7] + (ror(w[i - 2], 17) ^ ror(w[i - 2], 19) ^ (w[i - 2] >> 10));
+        uint32_t a = h[0], b = h[1], c = h[2], d = h[3], e = h[4], f = h[5], g = h[6], hh = h[7];
+        for (int i = 0; i < 64; i++) {
+            uint32_t t1 = hh + (ror(e, 6) ^ ror(e, 11) ^ ror(e, 25)) + ((e & f) ^ (~e & g)) + K[i] + w[i];
+            uint32_t t2 = (ror(a, 2) ^ ror(a, 13) ^ ror(a, 22)) + ((a & b) ^ (a & c) ^ (b & c));
+            hh = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + t2;
+        }
+        h[0] += a; h[1] += b; h[2] += c; h[3] += d; h[4] += e; h[5] += f; h[6] += g; h[7] += hh;
+    }
+    void update(const uint8_t* p, size_t n) {
+        len += n;
+        while (n) { size_t t = std::min(n, size_t(64) - fill); std::memcpy(buf + fill, p, t); fill += t; p += t; n -= t; if (fill == 64) { block(buf); fill = 0; } }
+    }
+    std::array<uint8_t, 32> finish() {
+        uint64_t bits = len * 8; uint8_t pad = 0x80; update(&pad, 1);
+        uint8_t z = 0; while (fill != 56) update(&z, 1);
+        uint8_t lb[8]; for (int i = 0; i < 8; i++) lb[i] = uint8_t(bits >> (56 - 8 * i)); update(lb, 8);
+        std::array<uint8_t, 32> o; for (int i = 0; i < 8; i++) { o[4 * i] = uint8_t(h[i] >> 24); o[4 * i + 1] = uint8_t(h[i] >> 16); o[4 * i + 2] = uint8_t(h[i] >> 8); o[4 * i + 3] = uint8_t(h[i]); }
+        return o;
+    }
+};
+inline std::array<uint8_t, 32> sha256(const Bytes& m) { Sha256 s; s.update(m.data(), m.size()); return s.finish(); }
+inline std::array<uint8_t, 32> hmac_sha256(const Bytes& key, const Bytes& msg) {
+    Bytes k = key; if (k.size() > 64) { auto d = sha256(k); k.assign(d.begin(), d.end()); } k.resize(64, 0);
+    Bytes i(64), o(64); for (int j = 0; j < 64; j++) { i[j] = k[j] ^ 0x36; o[j] = k[j] ^ 0x5c; }
+    i.insert(i.end(), msg.begin(), msg.end()); auto inner = sha256(i);
+    o.insert(o.end(), inner.begin(), inner.end()); return sha256(o);
+}
+// OS2IP(48 bytes) mod r -> 32 bytes big-endian (bitwise long division on 32-bit limbs; host-only, once per key)
+inline std::array<uint8_t, 32> mod_r(const uint8_t okm[48]) {
+    static const uint32_t R[9] = {0x00000001, 0xffffffff, 0xfffe5bfe, 0x53bda402, 0x09a1d805, 0x3339d808, 0x299d7d48, 0x73eda753, 0};
+    uint32_t a[9] = {0};
+    for (int bit = 0; bit < 384; bit++) {
+        for (int j = 8; j > 0; j--) a[j] = (a[j] << 1) | (a[j - 1] >> 31);
+        a[0] = (a[0] << 1) | ((okm[bit >> 3] >> (7 - (bit & 7))) & 1u);
+        bool ge = true; for (int j = 8; j >= 0; j--) { if (a[j] != R[j]) { ge = a[j] > R[j]; break; } }
+        if (ge) { uint64_t br = 0; for (int j = 0; j < 9; j++) { uint64_t d = uint64_t(a[j]) - R[j] - br; a[j] = uint32_t(d); br = (d >> 63) & 1; } }
+    }
+    std::array<uint8_t, 32> o; for (int j = 0; j < 8; j++) { uint32_t v = a[7 - j]; o[4 * j] = uint8_t(v >> 24); o[4 * j + 1] = uint8_t(v >> 16); o[4 * j + 2] = uint8_t(v >> 8); o[4 * j + 3] = uint8_t(v); }
+    return o;
+}
+}  // namespace detail
+
+// reference src/keys.rs:28-113 (host-only object; the scalar goes to the GPU only for signing)
 class SecretKey {
     std::array<uint8_t, 32> x_{};
 public:
+    // KeyGenerate, reference src/keys.rs:45-77: HKDF-SHA-256 with the salt-rehash loop (KEY_SALT :24, L = 48 :26)
+    static SecretKey key_generate(const Bytes& ikm, const Bytes& key_info = {}) {
+        if (ikm.size() < 32) throw AmclError(AmclError::InvalidSecretKeySize);
+        const char* ks = "BLS-SIG-KEYGEN-SALT-";
+        Bytes salt(ks, ks + 20);
+        SecretKey s;
+        bool zero = true;
+        while (zero) {
+            auto hs = detail::sha256(salt); salt.assign(hs.begin(), hs.end());                          // salt = H(salt)
+            Bytes ikm0 = ikm; ikm0.push_back(0);
+            auto prk = detail::hmac_sha256(salt, ikm0);                                                 // PRK = HKDF-Extract(salt, IKM || 0)
+            Bytes info = key_info; info.push_back(0); info.push_back(48);                               // key_info || I2OSP(L, 2)
+            Bytes okm, t; uint8_t ctr = 1;                                                              // OKM = HKDF-Expand(PRK, info, L)
+            while (okm.size() < 48) {
+                Bytes m = t; m.insert(m.end(), info.begin(), info.end()); m.push_back(ctr++);
+                auto d = detail::hmac_sha256(Bytes(prk.begin(), prk.end()), m); t.assign(d.begin(), d.end());
+                okm.insert(okm.end(), t.begin(), t.end());
+            }
+            s.x_ = detail::mod_r(okm.data());                                                           // SK = OS2IP(OKM) mod r
+            for (uint8_t v : s.x_) if (v) zero = false;
+        }
+        return s;
+    }
+    // SecretKey::random (src/keys.rs:36-39): 32 bytes of IKM from the caller's byte source (rng() returns one random byte)
+    template <typename Rng> static SecretKey random(Rng&& rng) { Bytes ikm(32); for (auto& b : ikm) b = uint8_t(rng()); return key_generate(ikm); }
+    static SecretKey random() { std::random_device rd; return random([&] { return uint8_t(rd()); }); }
     static SecretKey from_bytes(const Bytes& b) {                          // src/keys.rs:80-82, error cases :285-297
         static const uint8_t R[32] = {0x73,0xed,0xa7,0x53,0x29,0x9d,0x7d,0x48,0x33,0x39,0xd8,0x08,0x09,0xa1,0xd8,0x05,0x53,0xbd,0xa4,0x02,0xff,0xfe,0x5b,0xfe,0xff,0xff,0xff,0xff,0x00,0x00,0x00,0x01};
         if (b.size() != 32) throw AmclError(AmclError::InvalidSecretKeySize);
@@ -81,7 +169,11 @@ struct PublicKey {
     bool operator==(const PublicKey& o) const { return point == o.point; }
 };
 
-struct Keypair { SecretKey sk; PublicKey pk; };                              // reference src/keys.rs:189-204
+struct Keypair {                                                             // reference src/keys.rs:189-204
+    SecretKey sk; PublicKey pk;
+    template <typename Rng> static Keypair random(Rng&& rng) { SecretKey s = SecretKey::random(rng); PublicKey p = PublicKey::from_secret_key(s); return Keypair{s, p}; }
+    static Keypair random() { SecretKey s = SecretKey::random(); PublicKey p = PublicKey::from_secret_key(s); return Keypair{s, p}; }
+};
 
 // reference src/signature.rs:9-51; `point` is the 96-byte compressed form
 struct Signature {
@@ -116,7 +208,12 @@ struct AggregatePublicKey {
 struct AggregateSignature {
     std::array<uint8_t, 96> point{};
     AggregateSignature() { point[0] = 0xC0; }                                // AggregateSignature::new(): the point at infinity
-    static AggregateSignature aggregate(const std::vector<const Signature*>& sigs) { AggregateSignature a; for (auto* s : sigs) a.add(*s); return a; }
+    static AggregateSignature aggregate(const std::vector<const Signature*>& sigs) {      // src/aggregates.rs:100-106: one batched launch
+        AggregateSignature a; if (sigs.empty()) return a;
+        Bytes flat; for (auto* s : sigs) flat.insert(flat.end(), s->point.begin(), s->point.end());
+        uint8_t e = 0; detail::check(mbls_aggregate_signatures_batch(detail::ctx(), flat.data(), nullptr, 1, uint32_t(sigs.size()), a.point.data(), &e)); detail::check(e);
+        return a;
+    }
     static AggregateSignature from_signature(const Signature& s) { AggregateSignature a; a.point = s.point; return a; }
     void add(const Signature& s) { detail::check(mbls_aggregate_signature_add(detail::ctx(), point.data(), s.point.data(), point.data())); }
     void add_aggregate(const AggregateSignature& o) { detail::check(mbls_aggregate_signature_add(detail::ctx(), point.data(), o.point.data(), point.data())); }
@@ -141,7 +238,7 @@ struct AggregateSignature {
         const size_t mlen = std::get<2>(sets[0]).size();
         for (auto& s : sets) {
             uint64_t r = 0;
-            while (r == 0) { uint64_t v = 0; for (int i = 0; i < 8; i++) v = (v << 8) | uint8_t(rng()); int64_t sv = int64_t(v); r = uint64_t(sv < 0 ? -sv : sv); }
+            while (r == 0) { uint64_t v = 0; for (int i = 0; i < 8; i++) v = (v << 8) | uint8_t(rng()); r = (v >> 63) ? (uint64_t(0) - v) : v; }      // i64::from_be_bytes(..).abs() as the release build wraps it
             rands.push_back(r);
             sigs.insert(sigs.end(), std::get<0>(s)->point.begin(), std::get<0>(s)->point.end());
             apks.insert(apks.end(), std::get<1>(s)->point.begin(), std::get<1>(s)->point.end());

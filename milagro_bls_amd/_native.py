@@ -36,6 +36,16 @@ SIGNATURES = {
     "mbls_fast_aggregate_verify_batch": (C.c_int, [vp, vp, vp, C.c_uint32, vp, C.c_int, vp, C.c_uint64, C.c_uint32, vp, vp]),
     "mbls_verify_batch_device": (C.c_int, [vp, vp, vp, C.c_uint32, vp, C.c_int, C.c_uint64, vp, vp, vp, vp]),
     "mbls_verify_batch": (C.c_int, [vp, vp, vp, C.c_uint32, vp, C.c_int, C.c_uint64, vp, vp]),
+    "mbls_keytable_create": (C.c_int, [vp, C.c_uint64, C.POINTER(vp)]),
+    "mbls_keytable_destroy": (None, [vp]),
+    "mbls_keytable_size": (C.c_uint64, [vp]),
+    "mbls_keytable_append": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_uint64, C.POINTER(C.c_uint64), vp]),
+    "mbls_keytable_append_device": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_uint64, C.POINTER(C.c_uint64), vp, vp]),
+    "mbls_keytable_get": (C.c_int, [vp, C.c_uint64, C.c_uint64, vp, vp]),
+    "mbls_fast_aggregate_verify_batch_indexed_device": (C.c_int, [vp, vp, vp, vp, C.c_uint32, vp, vp, C.c_uint64, C.c_uint32, vp, vp, vp, vp]),
+    "mbls_fast_aggregate_verify_batch_indexed": (C.c_int, [vp, vp, vp, vp, C.c_uint32, vp, vp, C.c_uint64, C.c_uint32, vp, vp]),
+    "mbls_aggregate_signatures_batch": (C.c_int, [vp, vp, vp, C.c_uint64, C.c_uint32, vp, vp]),
+    "mbls_aggregate_signatures_batch_device": (C.c_int, [vp, vp, vp, C.c_uint64, C.c_uint32, C.c_uint64, vp, vp, vp]),
     "mbls_pk_from_bytes": (C.c_int, [vp, vp, C.c_size_t, vp]),
     "mbls_pk_from_bytes_unchecked": (C.c_int, [vp, vp, C.c_size_t, vp]),
     "mbls_pk_from_uncompressed_bytes": (C.c_int, [vp, vp, C.c_size_t, vp]),
@@ -65,6 +75,7 @@ SIGNATURES = {
     "mbls_aggregate_public_keys_batch": (C.c_int, [vp, vp, C.c_int, vp, C.c_uint64, C.c_uint32, vp, vp]),
     "mbls_fp_mul_batch": (C.c_int, [vp, vp, vp, C.c_uint64, vp, C.c_int]),
     "mbls_fp_mul_bench": (C.c_int, [vp, C.c_uint64, C.c_uint32, C.POINTER(C.c_float)]),
+    "mbls_valu_bench": (C.c_int, [vp, C.c_int, C.c_uint32, C.c_uint32, C.POINTER(C.c_float)]),
     "mbls_enable_phase_timing": (C.c_int, [vp, C.c_int]),
     "mbls_last_phase_ms": (C.c_int, [vp, C.POINTER(C.c_float)]),
 }
@@ -133,6 +144,50 @@ class Context:
 
     def reserve(self, n):
         self.check(lib().mbls_ctx_reserve(self._h, n))
+
+
+class KeyTable:
+    """Resident table of decoded public keys in HBM (include/mbls.h, mbls_keytable_*): decode once, verify by index."""
+
+    def __init__(self, ctx=None, capacity_hint=0):
+        self.ctx = ctx or default_context()
+        self._h = vp()
+        self.ctx.check(lib().mbls_keytable_create(self.ctx.handle, capacity_hint, C.byref(self._h)))
+
+    def close(self):
+        if self._h:
+            lib().mbls_keytable_destroy(self._h)
+            self._h = vp()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def handle(self):
+        return self._h
+
+    def __len__(self):
+        return int(lib().mbls_keytable_size(self._h))
+
+    def append(self, pks, n, pk_format=PK_COMPRESSED, validate=True):
+        """-> (first_index, errs): errs[i] = OK / ERR_* as PublicKey::from_bytes[_unchecked] / from_uncompressed_bytes would return"""
+        first = C.c_uint64(0)
+        errs = outbuf(n)
+        self.ctx.check(lib().mbls_keytable_append(self._h, cbuf(pks), pk_format, int(validate), n, C.byref(first), errs))
+        return int(first.value), list(bytes(errs)[:n])
+
+    def append_device(self, d_pks, n, d_errs, pk_format=PK_COMPRESSED, validate=True, stream=None):
+        first = C.c_uint64(0)
+        self.ctx.check(lib().mbls_keytable_append_device(self._h, d_pks, pk_format, int(validate), n, C.byref(first), d_errs, stream))
+        return int(first.value)
+
+    def get(self, first, n=1):
+        out, errs = outbuf(96 * n), outbuf(n)
+        self.ctx.check(lib().mbls_keytable_get(self._h, first, n, out, errs))
+        return bytes(out)[:96 * n], list(bytes(errs)[:n])
 
 
 _default_ctx = None

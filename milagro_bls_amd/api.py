@@ -244,10 +244,14 @@ class AggregateSignature:
 
     @classmethod
     def aggregate(cls, signatures):
-        agg = cls.new()
-        for s in signatures:
-            agg.add(s)
-        return agg
+        """reference src/aggregates.rs:100-106: one batched launch (segmented G2 sum) instead of one addition per call"""
+        signatures = list(signatures)
+        if not signatures:
+            return cls.new()
+        out, errs = N.outbuf(96), N.outbuf(1)
+        _raise(N.lib().mbls_aggregate_signatures_batch(_ctx().handle, N.cbuf(b"".join(s.point for s in signatures)), None, 1, len(signatures), out, errs))
+        _raise(bytes(errs)[0])
+        return cls(bytes(out))
 
     @classmethod
     def from_signature(cls, signature):

@@ -24,6 +24,32 @@ def fast_aggregate_verify_batch(sigs, msgs, pks, n, k=None, pk_format=N.PK_COMPR
     return [bool(x) for x in bytes(res)[:n]], list(st)[:n]
 
 
+def fast_aggregate_verify_batch_indexed(table, sigs, msgs, key_idx, n, k=None, msg_len=32, offsets=None, ctx=None):
+    """The same over a resident key table: item i uses table entries key_idx[k*i : k*i+k] (or key_idx[offsets[i]:offsets[i+1]])."""
+    ctx = ctx or table.ctx
+    res = N.outbuf(n)
+    st = (C.c_uint32 * max(1, n))()
+    idx = (C.c_uint32 * max(1, len(key_idx)))(*key_idx)
+    off = None
+    if offsets is not None:
+        off = (C.c_uint32 * len(offsets))(*offsets)
+        k = 0
+    ctx.check(N.lib().mbls_fast_aggregate_verify_batch_indexed(ctx.handle, table.handle, N.cbuf(sigs), N.cbuf(msgs), msg_len, idx, off, n, k, res, st))
+    return [bool(x) for x in bytes(res)[:n]], list(st)[:n]
+
+
+def aggregate_signatures_batch(sigs96, n, k=None, offsets=None, ctx=None):
+    """n x AggregateSignature::aggregate (reference src/aggregates.rs:100-106) -> (compressed sums, errs)"""
+    ctx = ctx or _c()
+    out, errs = N.outbuf(96 * n), N.outbuf(n)
+    off = None
+    if offsets is not None:
+        off = (C.c_uint32 * len(offsets))(*offsets)
+        k = 0
+    ctx.check(N.lib().mbls_aggregate_signatures_batch(ctx.handle, N.cbuf(sigs96), off, n, k, out, errs))
+    return bytes(out)[:96 * n], list(bytes(errs)[:n])
+
+
 def verify_batch(sigs, msgs, pks, n, pk_format=N.PK_COMPRESSED, msg_len=32, ctx=None):
     """n x Signature::verify (reference src/signature.rs:27-40)."""
     ctx = ctx or _c()

@@ -13,6 +13,8 @@
 #include <string.h>
 #include <stdlib.h>
 #include <new>
+#include <mutex>
+#include <vector>
 #include "mbls_ops.h"
 #include "../../include/mbls.h"
 
@@ -33,15 +35,45 @@ __global__ void MBLS_LB k_aggregate(mbls_ws ws, const uint8_t* pks, const uint32
     uint64_t i = gid(); if (i >= n) return;
     const uint32_t pkb = fmt == MBLS_PK_COMPRESSED ? 48u : 96u;
     uint64_t first = offsets ? offsets[i] : (uint64_t)k * i; uint32_t cnt = offsets ? offsets[i + 1] - offsets[i] : k;
-    uint32_t st; lane_aggregate(ws, i, pks + pkb * first, cnt, fmt, mode, &st); status[i] |= st;
+    uint32_t bad = 0;
+    if (offsets && offsets[i + 1] < offsets[i]) { cnt = 0; bad = MBLS_ST_BAD_PK_ENCODING; }     // a non-monotonic offset table never becomes a read
+    uint32_t st; lane_aggregate(ws, i, pks + pkb * first, cnt, fmt, mode, &st); st |= bad; if (st) atomicOr(status + i, st);
 }
-__global__ void __launch_bounds__(WG, 4) k_pk_decompress(const uint8_t* pks48, uint64_t nkeys, uint32_t* keys_xy, uint8_t* flags) {
+// one key per lane; the square-root routine keeps its window table in 210 AGPRs, so this kernel too runs one wave per SIMD
+__global__ void MBLS_LB k_pk_decompress(const uint8_t* pks48, uint64_t nkeys, uint32_t* keys_xy, uint8_t* flags) {
     uint64_t j = gid(); if (j >= nkeys) return;
     lane_pk_decompress(j, pks48, keys_xy, flags);
 }
 __global__ void MBLS_LB k_aggregate_decoded(mbls_ws ws, const uint32_t* keys_xy, const uint8_t* flags, uint32_t k, int mode, uint32_t* status, uint64_t n) {
     uint64_t i = gid(); if (i >= n) return;
-    uint32_t st; lane_aggregate_decoded(ws, i, keys_xy + 24 * (uint64_t)k * i, flags + (uint64_t)k * i, k, mode, &st); status[i] |= st;
+    uint32_t st; lane_aggregate_decoded(ws, i, keys_xy + 24 * (uint64_t)k * i, flags + (uint64_t)k * i, k, mode, &st); if (st) atomicOr(status + i, st);
+}
+// Resident key table (the on-device analogue of the decoded PublicKey objects a reference caller holds, src/keys.rs:116-120):
+// item i sums the table entries idx[k*i .. k*i+k) (or idx[offsets[i] .. offsets[i+1])).
+__global__ void MBLS_LB k_aggregate_indexed(mbls_ws ws, const uint32_t* recs, uint64_t tsize, const uint32_t* idx, const uint32_t* offsets, uint32_t k,
+                                            int mode, uint32_t* status, uint64_t n) {
+    uint64_t i = gid(); if (i >= n) return;
+    uint64_t first = offsets ? offsets[i] : (uint64_t)k * i; uint32_t cnt = offsets ? offsets[i + 1] - offsets[i] : k;
+    uint32_t bad = 0;
+    if (offsets && offsets[i + 1] < offsets[i]) { cnt = 0; bad = MBLS_ST_BAD_PK_ENCODING; }
+    uint32_t st; lane_aggregate_indexed(ws, i, recs, tsize, idx + first, cnt, mode, &st); st |= bad; if (st) atomicOr(status + i, st);
+}
+// n x PublicKey::from_bytes[_unchecked] / from_uncompressed_bytes into table records (affine Montgomery limbs + flags)
+__global__ void MBLS_LB k_keytable_append(const uint8_t* in, int fmt, int validate, uint64_t n, uint32_t* recs, uint8_t* errs) {
+    uint64_t i = gid(); if (i < n) op_keytable_append(i, in, fmt, validate, recs, errs);
+}
+__global__ void MBLS_LB k_keytable_export(const uint32_t* recs, uint64_t first, uint64_t n, uint8_t* out96, uint8_t* errs) {
+    uint64_t i = gid(); if (i < n) op_keytable_export(i, recs + 32 * first, out96, errs);
+}
+// batched AggregateSignature::aggregate (src/aggregates.rs:100-106): decode one signature per lane, then one set per lane
+__global__ void MBLS_LB k_g2_decode_affine(const uint8_t* sigs96, uint64_t n, uint32_t* xy, uint8_t* flags) {
+    uint64_t i = gid(); if (i < n) op_g2_decode_affine(i, sigs96, xy, flags);
+}
+__global__ void MBLS_LB k_g2_sum(const uint32_t* xy, const uint8_t* flags, const uint32_t* offsets, uint32_t k, uint64_t n, uint8_t* out96, uint8_t* errs) {
+    uint64_t i = gid(); if (i >= n) return;
+    uint64_t first = offsets ? offsets[i] : (uint64_t)k * i; uint32_t cnt = offsets ? offsets[i + 1] - offsets[i] : k;
+    if (offsets && offsets[i + 1] < offsets[i]) cnt = 0;
+    op_g2_sum(i, xy + 48 * first, flags + first, cnt, out96, errs);
 }
 __global__ void MBLS_LB k_sig(mbls_ws ws, const uint8_t* sigs, uint32_t* status, uint64_t n) {
     uint64_t i = gid(); if (i >= n) return;
@@ -83,9 +115,10 @@ __global__ void MBLS_LB k_pack(const uint8_t* results, uint64_t* bitmap, uint64_
 
 // ------------------------------------------------------------------------------------------------ n-pairing kernels
 // (aggregate_verify, reference src/aggregates.rs:130-170; verify_multiple, src/aggregates.rs:261-316)
-// item i: f_i = Miller(H_i, P_i) with P_i = [r_i] pk_i (r_i = 1 when rands == NULL); optional S_i = [r_i] sig_i
-__global__ void MBLS_LB k_blind_pair(mbls_ws ws, const uint8_t* pks96, const uint8_t* sigs96, const uint64_t* rands,
-                                                    uint32_t* status, uint64_t n) {
+// item i: f_i = Miller(H_i, P_i) with P_i = [r_i] pk_i (r_i = 1 when rands == NULL: aggregate_verify only); S_i = [r_i] sig_i.
+// Two kernels so that the G1 and the G2 halves can run side by side on two streams (sets below 2^14 leave most SIMDs idle);
+// both OR their bits into status[i] atomically. A zero scalar would drop set i from the check: it is flagged, never used.
+__global__ void MBLS_LB k_blind_g1(mbls_ws ws, const uint8_t* pks96, const uint64_t* rands, uint32_t* status, uint64_t n) {
     uint64_t i = gid(); if (i >= n) return;
     uint32_t st = 0;
     g1j p;
@@ -93,22 +126,28 @@ __global__ void MBLS_LB k_blind_pair(mbls_ws ws, const uint8_t* pks96, const uin
         fp x, y; bool inf; int e = g1_decode_uncompressed(&x, &y, &inf, pks96 + 96 * i);
         if (e) { st |= MBLS_ST_BAD_PK_ENCODING; inf = true; }
         p.x = x; p.y = y; p.z = fp_one(); if (inf) g1_set_inf(&p);
-    } else {          // aggregate key left in the workspace by k_aggregate
-        st = status[i] & MBLS_ST_BAD_PK_ENCODING;
+    } else {          // aggregate key left in the workspace by k_aggregate (which already set the status bits)
         p.x = ws_ld(ws, MBLS_SLOT_APK, i); p.y = ws_ld(ws, MBLS_SLOT_APK + 1, i); p.z = ws_ld(ws, MBLS_SLOT_APK + 2, i);
     }
-    uint32_t k[2] = {1, 0};
-    if (rands) { k[0] = (uint32_t)rands[i]; k[1] = (uint32_t)(rands[i] >> 32); g1_mul(&p, &p, k, 64); }
-    ws_st(ws, MBLS_SLOT_APK, i, p.x); ws_st(ws, MBLS_SLOT_APK + 1, i, p.y); ws_st(ws, MBLS_SLOT_APK + 2, i, p.z);
-    if (sigs96) {
-        fp2 sx, sy; bool sinf; int e2 = g2_decode_compressed(&sx, &sy, &sinf, sigs96 + 96 * i);
-        if (e2) { st |= MBLS_ST_BAD_SIG_ENCODING; sinf = true; }
-        g2j s; s.x = sx; s.y = sy; s.z = fp2_one(); if (sinf) g2_set_inf(&s);
-        if (!g2_in_subgroup(&s)) st |= MBLS_ST_SIG_NOT_IN_G2;
-        g2_mul(&s, &s, k, 64);
-        ws_st2(ws, MBLS_SLOT_S, i, s.x); ws_st2(ws, MBLS_SLOT_S + 2, i, s.y); ws_st2(ws, MBLS_SLOT_S + 4, i, s.z);
+    if (rands) {
+        uint32_t k[2] = {(uint32_t)rands[i], (uint32_t)(rands[i] >> 32)};
+        if ((k[0] | k[1]) == 0) st |= MBLS_ST_BAD_SCALAR;
+        g1_mul(&p, &p, k, 64);
     }
-    status[i] = st;
+    ws_st(ws, MBLS_SLOT_APK, i, p.x); ws_st(ws, MBLS_SLOT_APK + 1, i, p.y); ws_st(ws, MBLS_SLOT_APK + 2, i, p.z);
+    if (st) atomicOr(status + i, st);
+}
+__global__ void MBLS_LB k_blind_sig(mbls_ws ws, const uint8_t* sigs96, const uint64_t* rands, uint32_t* status, uint64_t n) {
+    uint64_t i = gid(); if (i >= n) return;
+    uint32_t st = 0;
+    fp2 sx, sy; bool sinf; int e2 = g2_decode_compressed(&sx, &sy, &sinf, sigs96 + 96 * i);
+    if (e2) { st |= MBLS_ST_BAD_SIG_ENCODING; sinf = true; }
+    g2j s; s.x = sx; s.y = sy; s.z = fp2_one(); if (sinf) g2_set_inf(&s);
+    if (!g2_in_subgroup(&s)) st |= MBLS_ST_SIG_NOT_IN_G2;
+    uint32_t k[2] = {(uint32_t)rands[i], (uint32_t)(rands[i] >> 32)};
+    g2_mul(&s, &s, k, 64);
+    ws_st2(ws, MBLS_SLOT_S, i, s.x); ws_st2(ws, MBLS_SLOT_S + 2, i, s.y); ws_st2(ws, MBLS_SLOT_S + 4, i, s.z);
+    if (st) atomicOr(status + i, st);
 }
 // f_i = Miller(H_i, P_i) for i < n; lane n (if sig_slot_valid) computes Miller(S, -G1) with S read from slot S of item `s_item`
 __global__ void MBLS_LB k_miller_single(mbls_ws ws, uint64_t n, int with_sig, uint64_t s_item) {
@@ -184,42 +223,69 @@ __global__ void MBLS_LB k_fp_mul_bench(uint32_t* sink, uint32_t iters, uint64_t 
     sink[i] = acc;
 }
 
+// VALU issue-rate calibration (bench.py, valu_issue): 128 instructions per iteration, 8 independent chains per lane.
+// mode 0: v_mad_u64_u32 with the carry-out alternating between VCC and SGPR pairs (what the multiplication routines issue);
+// mode 1: v_add_co / v_addc chains (the class every other integer instruction of the routines issues at).
+#define MBLS_REP4(x) x x x x
+#define MBLS_REP16(x) MBLS_REP4(MBLS_REP4(x))
+__global__ void __launch_bounds__(WG) k_valu_bench(uint32_t* sink, uint32_t iters, int mode) {
+    uint32_t a = (threadIdx.x * 2654435761u + blockIdx.x) | 1u, b = a ^ 0x9e3779b9u;
+    uint64_t c0 = a, c1 = b, c2 = a + 1, c3 = b + 1, c4 = a + 2, c5 = b + 2, c6 = a + 3, c7 = b + 3;
+    uint32_t h0 = a, h1 = b, h2 = a + 5, h3 = b + 7;
+    for (uint32_t i = 0; i < iters; i++) {
+        if (mode == 0) {
+            MBLS_REP16(asm volatile("v_mad_u64_u32 %0, vcc, %8, %9, %0\n v_mad_u64_u32 %1, s[20:21], %8, %9, %1\n v_mad_u64_u32 %2, vcc, %8, %9, %2\n v_mad_u64_u32 %3, s[22:23], %8, %9, %3\n"
+                                    "v_mad_u64_u32 %4, vcc, %8, %9, %4\n v_mad_u64_u32 %5, s[20:21], %8, %9, %5\n v_mad_u64_u32 %6, vcc, %8, %9, %6\n v_mad_u64_u32 %7, s[22:23], %8, %9, %7\n"
+                                    : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3), "+v"(c4), "+v"(c5), "+v"(c6), "+v"(c7) : "v"(a), "v"(b) : "vcc", "s20", "s21", "s22", "s23");)
+        } else {
+            MBLS_REP16(asm volatile("v_add_co_u32_e64 %0, vcc, %4, %0\n v_add_co_u32_e64 %2, s[20:21], %5, %2\n v_addc_co_u32_e64 %1, vcc, %5, %1, vcc\n v_addc_co_u32_e64 %3, s[20:21], %4, %3, s[20:21]\n"
+                                    "v_add_co_u32_e64 %0, vcc, %5, %0\n v_add_co_u32_e64 %2, s[20:21], %4, %2\n v_addc_co_u32_e64 %1, vcc, %4, %1, vcc\n v_addc_co_u32_e64 %3, s[20:21], %5, %3, s[20:21]\n"
+                                    : "+v"(h0), "+v"(h1), "+v"(h2), "+v"(h3) : "v"(a), "v"(b) : "vcc", "s20", "s21");)
+        }
+    }
+    sink[(uint64_t)blockIdx.x * WG + threadIdx.x] = (uint32_t)(c0 ^ c1 ^ c2 ^ c3 ^ c4 ^ c5 ^ c6 ^ c7) ^ h0 ^ h1 ^ h2 ^ h3;
+}
+
 // ------------------------------------------------------------------------------------------------ host side
+// Every extern "C" entry takes the context's (recursive) lock: a context may be shared between threads, calls are serialised.
+// Host-buffer entries stage through grow-only device buffers and two streams that the context owns (no allocation or stream
+// creation per call once the sizes have been seen); device-pointer entries only enqueue, and order their use of the
+// workspace against earlier calls on other streams with an event.
+#define MBLS_N_STAGE 8
 struct mbls_ctx {
-    int device;
-    uint64_t cap;            // items the workspace can hold
-    uint32_t* d_w;           // workspace limbs
-    uint32_t* d_status;      // per-item status (when the caller passes none)
-    uint8_t* d_results;
-    uint32_t* d_scalar;      // small scratch words
-    uint64_t key_cap;        // decompressed-key staging (compressed wire format): capacity in keys
-    uint32_t* d_keys_xy;     // [key_cap][24] affine Montgomery coordinates
-    uint8_t* d_key_flags;
-    bool timing;
-    hipEvent_t ev[MBLS_N_PHASES + 1];
-    float phase_ms[MBLS_N_PHASES];
-    char err[256];
+    std::recursive_mutex mu;
+    int device = 0;
+    uint64_t cap = 0;                  // items the workspace can hold
+    uint32_t* d_w = nullptr;           // workspace limbs
+    uint32_t* d_status = nullptr;      // per-item status (when the caller passes none)
+    uint8_t* d_results = nullptr;
+    uint32_t* d_scalar = nullptr;      // small scratch words
+    uint64_t key_cap = 0;              // decompressed-key staging (compressed wire format): capacity in keys
+    uint32_t* d_keys_xy = nullptr;     // [key_cap][24] affine Montgomery coordinates
+    uint8_t* d_key_flags = nullptr;
+    struct { void* p; size_t cap; } stage[MBLS_N_STAGE] = {};
+    hipStream_t hs_a = nullptr, hs_b = nullptr, hs_c = nullptr;      // streams of the host-buffer entry points
+    hipEvent_t hs_ev = nullptr, hs_ev2 = nullptr, hs_ev3 = nullptr;
+    hipEvent_t ws_ev = nullptr; hipStream_t ws_stream = nullptr; bool ws_pending = false;   // last asynchronous user of the workspace
+    bool timing = false;
+    hipEvent_t ev[MBLS_N_PHASES + 1] = {};
+    float phase_ms[MBLS_N_PHASES] = {};
+    char err[256] = {};
 };
+struct mbls_keytable {
+    mbls_ctx* c = nullptr;
+    uint32_t* d_recs = nullptr;        // [cap][MBLS_KEYREC_DWORDS]
+    uint64_t size = 0, cap = 0;
+};
+typedef std::lock_guard<std::recursive_mutex> mbls_lock;
 
 #define HIPCHK(ctx, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { \
     snprintf((ctx)->err, sizeof((ctx)->err), "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); return MBLS_ERR_DEVICE; } } while (0)
+#define ARGFAIL(ctx, what) do { snprintf((ctx)->err, sizeof((ctx)->err), "invalid argument: %s", what); return MBLS_ERR_ARGUMENT; } while (0)
 
 static inline unsigned nblk(uint64_t n) { return (unsigned)((n + WG - 1) / WG); }
 
-extern "C" int mbls_ctx_create(mbls_ctx** out, int device_id) {
-    if (!out) return MBLS_ERR_ARGUMENT;
-    int cnt = 0;
-    if (hipGetDeviceCount(&cnt) != hipSuccess || cnt <= 0 || device_id < 0 || device_id >= cnt) return MBLS_ERR_DEVICE;
-    if (hipSetDevice(device_id) != hipSuccess) return MBLS_ERR_DEVICE;
-    mbls_ctx* c = new (std::nothrow) mbls_ctx();
-    if (!c) return MBLS_ERR_DEVICE;
-    memset(c, 0, sizeof(*c)); c->device = device_id;
-    for (int i = 0; i <= MBLS_N_PHASES; i++) if (hipEventCreate(&c->ev[i]) != hipSuccess) { delete c; return MBLS_ERR_DEVICE; }
-    if (hipMalloc(&c->d_scalar, 64) != hipSuccess) { delete c; return MBLS_ERR_DEVICE; }
-    *out = c; return MBLS_OK;
-}
-extern "C" void mbls_ctx_destroy(mbls_ctx* c) {
-    if (!c) return;
+static void ctx_free(mbls_ctx* c) {
     (void)hipSetDevice(c->device);
     if (c->d_w) (void)hipFree(c->d_w);
     if (c->d_status) (void)hipFree(c->d_status);
@@ -227,16 +293,48 @@ extern "C" void mbls_ctx_destroy(mbls_ctx* c) {
     if (c->d_scalar) (void)hipFree(c->d_scalar);
     if (c->d_keys_xy) (void)hipFree(c->d_keys_xy);
     if (c->d_key_flags) (void)hipFree(c->d_key_flags);
+    for (int i = 0; i < MBLS_N_STAGE; i++) if (c->stage[i].p) (void)hipFree(c->stage[i].p);
     for (int i = 0; i <= MBLS_N_PHASES; i++) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+    if (c->hs_ev) (void)hipEventDestroy(c->hs_ev);
+    if (c->hs_ev2) (void)hipEventDestroy(c->hs_ev2);
+    if (c->hs_ev3) (void)hipEventDestroy(c->hs_ev3);
+    if (c->ws_ev) (void)hipEventDestroy(c->ws_ev);
+    if (c->hs_a) (void)hipStreamDestroy(c->hs_a);
+    if (c->hs_b) (void)hipStreamDestroy(c->hs_b);
+    if (c->hs_c) (void)hipStreamDestroy(c->hs_c);
     delete c;
+}
+extern "C" int mbls_ctx_create(mbls_ctx** out, int device_id) {
+    if (!out) return MBLS_ERR_ARGUMENT;
+    int cnt = 0;
+    if (hipGetDeviceCount(&cnt) != hipSuccess || cnt <= 0 || device_id < 0 || device_id >= cnt) return MBLS_ERR_DEVICE;
+    if (hipSetDevice(device_id) != hipSuccess) return MBLS_ERR_DEVICE;
+    mbls_ctx* c = new (std::nothrow) mbls_ctx();
+    if (!c) return MBLS_ERR_DEVICE;
+    c->device = device_id;
+    bool ok = true;
+    for (int i = 0; i <= MBLS_N_PHASES; i++) ok = ok && hipEventCreate(&c->ev[i]) == hipSuccess;
+    ok = ok && hipMalloc(&c->d_scalar, 64) == hipSuccess;
+    ok = ok && hipStreamCreateWithFlags(&c->hs_a, hipStreamNonBlocking) == hipSuccess && hipStreamCreateWithFlags(&c->hs_b, hipStreamNonBlocking) == hipSuccess &&
+         hipStreamCreateWithFlags(&c->hs_c, hipStreamNonBlocking) == hipSuccess;
+    ok = ok && hipEventCreateWithFlags(&c->hs_ev, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&c->hs_ev2, hipEventDisableTiming) == hipSuccess &&
+         hipEventCreateWithFlags(&c->hs_ev3, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&c->ws_ev, hipEventDisableTiming) == hipSuccess;
+    if (!ok) { ctx_free(c); return MBLS_ERR_DEVICE; }
+    *out = c; return MBLS_OK;
+}
+extern "C" void mbls_ctx_destroy(mbls_ctx* c) {
+    if (!c) return;
+    { mbls_lock lk(c->mu); (void)hipSetDevice(c->device); (void)hipDeviceSynchronize(); }
+    ctx_free(c);
 }
 extern "C" const char* mbls_last_error(mbls_ctx* c) { return c ? c->err : "null context"; }
 extern "C" int mbls_ctx_reserve(mbls_ctx* c, uint64_t max_items) {
     if (!c) return MBLS_ERR_ARGUMENT;
+    mbls_lock lk(c->mu);
     HIPCHK(c, hipSetDevice(c->device));
     uint64_t want = ((max_items + 1 + WG - 1) / WG) * WG;     // +1: the extra (sig, -G1) lane of the n-pairing paths
     if (want <= c->cap) return MBLS_OK;
-    if (c->d_w) { (void)hipFree(c->d_w); (void)hipFree(c->d_status); (void)hipFree(c->d_results); c->d_w = nullptr; c->cap = 0; }
+    if (c->d_w) { (void)hipFree(c->d_w); (void)hipFree(c->d_status); (void)hipFree(c->d_results); c->d_w = nullptr; c->d_status = nullptr; c->d_results = nullptr; c->cap = 0; }
     HIPCHK(c, hipMalloc(&c->d_w, (size_t)MBLS_SLOT_TOTAL * 12 * want * 4));
     HIPCHK(c, hipMalloc(&c->d_status, want * 4));
     HIPCHK(c, hipMalloc(&c->d_results, want));
@@ -252,35 +350,74 @@ static int reserve_keys(mbls_ctx* c, uint64_t nkeys) {
 }
 extern "C" int mbls_ctx_reserve_keys(mbls_ctx* c, uint64_t max_keys) {
     if (!c) return MBLS_ERR_ARGUMENT;
+    mbls_lock lk(c->mu);
     HIPCHK(c, hipSetDevice(c->device));
     return reserve_keys(c, max_keys);
 }
-extern "C" int mbls_enable_phase_timing(mbls_ctx* c, int on) { if (!c) return MBLS_ERR_ARGUMENT; c->timing = on != 0; return MBLS_OK; }
+extern "C" int mbls_enable_phase_timing(mbls_ctx* c, int on) { if (!c) return MBLS_ERR_ARGUMENT; mbls_lock lk(c->mu); c->timing = on != 0; return MBLS_OK; }
 extern "C" int mbls_last_phase_ms(mbls_ctx* c, float ms[MBLS_N_PHASES]) {
     if (!c) return MBLS_ERR_ARGUMENT;
+    mbls_lock lk(c->mu);
     for (int i = 0; i < MBLS_N_PHASES; i++) ms[i] = c->phase_ms[i];
     return MBLS_OK;
 }
 
-static int verify_pipeline(mbls_ctx* c, const uint8_t* d_sigs, const uint8_t* d_msgs, uint32_t msg_len, const uint8_t* d_pks, int fmt,
-                           const uint32_t* d_off, uint64_t n, uint32_t k, int mode, uint8_t* d_results, uint64_t* d_bitmap,
+// a view of one of the context's grow-only staging buffers (host-buffer entry points; the lock makes the reuse safe)
+struct sbuf {
+    mbls_ctx* c; int slot; void* p = nullptr;
+    sbuf(mbls_ctx* c_, int slot_) : c(c_), slot(slot_) {}
+    hipError_t alloc(size_t bytes) {
+        if (!bytes) bytes = 1;
+        auto& s = c->stage[slot];
+        if (s.cap < bytes) {
+            if (s.p) { (void)hipFree(s.p); s.p = nullptr; s.cap = 0; }
+            size_t want = bytes < 4096 ? 4096 : bytes + bytes / 8;
+            hipError_t e = hipMalloc(&s.p, want); if (e != hipSuccess) return e;
+            s.cap = want;
+        }
+        p = s.p; return hipSuccess;
+    }
+    hipError_t up(const void* h, size_t bytes) { hipError_t e = alloc(bytes); if (e != hipSuccess || !bytes) return e; return hipMemcpy(p, h, bytes, hipMemcpyHostToDevice); }
+    hipError_t down(void* h, size_t bytes) { return bytes ? hipMemcpy(h, p, bytes, hipMemcpyDeviceToHost) : hipSuccess; }
+    template <typename T> T* as() { return (T*)p; }
+};
+
+// cross-stream ordering of the shared workspace: a call on stream s first waits for the last asynchronous user on another stream
+static int ws_acquire(mbls_ctx* c, hipStream_t s) {
+    if (c->ws_pending && c->ws_stream != s) HIPCHK(c, hipStreamWaitEvent(s, c->ws_ev, 0));
+    return MBLS_OK;
+}
+static int ws_release(mbls_ctx* c, hipStream_t s) {
+    HIPCHK(c, hipEventRecord(c->ws_ev, s)); c->ws_stream = s; c->ws_pending = true; return MBLS_OK;
+}
+
+// where an item's public keys come from
+struct keysrc {
+    const uint8_t* d_pks = nullptr; int fmt = MBLS_PK_UNCOMPRESSED; const uint32_t* d_off = nullptr;      // wire bytes
+    const uint32_t* d_recs = nullptr; uint64_t tsize = 0; const uint32_t* d_idx = nullptr; bool indexed = false;   // key table
+};
+
+static int verify_pipeline(mbls_ctx* c, const uint8_t* d_sigs, const uint8_t* d_msgs, uint32_t msg_len, const keysrc& ks,
+                           uint64_t n, uint32_t k, int mode, uint8_t* d_results, uint64_t* d_bitmap,
                            uint32_t* d_status, hipStream_t s, int part = 0) {
+    const int fmt = ks.fmt; const uint32_t* d_off = ks.d_off;
     if (!c || (fmt != MBLS_PK_COMPRESSED && fmt != MBLS_PK_UNCOMPRESSED)) return MBLS_ERR_ARGUMENT;
     if (n == 0) return MBLS_OK;
-    if (!d_sigs || !d_msgs || !d_results || (!d_pks && (k || d_off) && part != 1)) return MBLS_ERR_ARGUMENT;
+    const bool have_keys = ks.indexed ? (ks.d_idx != nullptr) : (ks.d_pks != nullptr);
+    if (!d_sigs || !d_msgs || !d_results || (!have_keys && (k || d_off) && part != 1)) ARGFAIL(c, "null buffer");
     HIPCHK(c, hipSetDevice(c->device));
     int rc = mbls_ctx_reserve(c, n); if (rc) return rc;
     mbls_ws ws; ws.w = c->d_w; ws.stride = c->cap;
     uint32_t* st = d_status ? d_status : c->d_status;
     unsigned g = nblk(n);
     bool tm = c->timing;
-    bool staged = (fmt == MBLS_PK_COMPRESSED) && !d_off && k > 1;   // lane-per-key decompression, then the per-item sums
+    bool staged = !ks.indexed && (fmt == MBLS_PK_COMPRESSED) && !d_off && k > 1;   // lane-per-key decompression, then the per-item sums
     if (staged) { rc = reserve_keys(c, n * (uint64_t)k); if (rc) return rc; }
     // The status words are zeroed and every phase ORs its bits in, so the phases before the Miller loop can run in any order.
     // part 1 / part 2 (host-buffer entry points): the signature and message phases are queued first (part 1, the keys may be
     // null), the caller then uploads the keys on another stream and makes this one wait, and part 2 queues the rest.
     const bool keys_later = part != 0;
-    if (part != 2) HIPCHK(c, hipMemsetAsync(st, 0, 4 * n, s));
+    if (part != 2) { rc = ws_acquire(c, s); if (rc) return rc; HIPCHK(c, hipMemsetAsync(st, 0, 4 * n, s)); }
     if (part == 1) {
         hipLaunchKernelGGL(k_sig, dim3(g), dim3(WG), 0, s, ws, d_sigs, st, n);
         hipLaunchKernelGGL(k_hash, dim3(g), dim3(WG), 0, s, ws, d_msgs, msg_len, (const uint64_t*)nullptr, (const uint32_t*)nullptr, n);
@@ -288,11 +425,13 @@ static int verify_pipeline(mbls_ctx* c, const uint8_t* d_sigs, const uint8_t* d_
         return MBLS_OK;
     }
     if (tm) HIPCHK(c, hipEventRecord(c->ev[0], s));
-    if (staged) {
-        hipLaunchKernelGGL(k_pk_decompress, dim3(nblk(n * (uint64_t)k)), dim3(WG), 0, s, d_pks, n * (uint64_t)k, c->d_keys_xy, c->d_key_flags);
+    if (ks.indexed)
+        hipLaunchKernelGGL(k_aggregate_indexed, dim3(g), dim3(WG), 0, s, ws, ks.d_recs, ks.tsize, ks.d_idx, d_off, k, mode, st, n);
+    else if (staged) {
+        hipLaunchKernelGGL(k_pk_decompress, dim3(nblk(n * (uint64_t)k)), dim3(WG), 0, s, ks.d_pks, n * (uint64_t)k, c->d_keys_xy, c->d_key_flags);
         hipLaunchKernelGGL(k_aggregate_decoded, dim3(g), dim3(WG), 0, s, ws, (const uint32_t*)c->d_keys_xy, (const uint8_t*)c->d_key_flags, k, mode, st, n);
     } else
-        hipLaunchKernelGGL(k_aggregate, dim3(g), dim3(WG), 0, s, ws, d_pks, d_off, k, fmt, mode, st, n);
+        hipLaunchKernelGGL(k_aggregate, dim3(g), dim3(WG), 0, s, ws, ks.d_pks, d_off, k, fmt, mode, st, n);
     if (tm) HIPCHK(c, hipEventRecord(c->ev[1], s));
     if (!keys_later) hipLaunchKernelGGL(k_sig, dim3(g), dim3(WG), 0, s, ws, d_sigs, st, n);
     if (tm) HIPCHK(c, hipEventRecord(c->ev[2], s));
@@ -309,113 +448,209 @@ static int verify_pipeline(mbls_ctx* c, const uint8_t* d_sigs, const uint8_t* d_
         for (int i = 0; i < MBLS_N_PHASES; i++) HIPCHK(c, hipEventElapsedTime(&c->phase_ms[i], c->ev[i], c->ev[i + 1]));
     }
     HIPCHK(c, hipGetLastError());
-    return MBLS_OK;
+    return ws_release(c, s);
 }
 extern "C" int mbls_fast_aggregate_verify_batch_device(mbls_ctx* c, const uint8_t* d_sigs, const uint8_t* d_msgs, uint32_t msg_len,
         const uint8_t* d_pks, int fmt, const uint32_t* d_off, uint64_t n, uint32_t k, uint8_t* d_results, uint64_t* d_bitmap,
         uint32_t* d_status, void* stream) {
-    return verify_pipeline(c, d_sigs, d_msgs, msg_len, d_pks, fmt, d_off, n, k, MBLS_MODE_FAST_AGGREGATE, d_results, d_bitmap, d_status, (hipStream_t)stream);
+    if (!c) return MBLS_ERR_ARGUMENT;
+    mbls_lock lk(c->mu);
+    keysrc ks; ks.d_pks = d_pks; ks.fmt = fmt; ks.d_off = d_off;
+    return verify_pipeline(c, d_sigs, d_msgs, msg_len, ks, n, k, MBLS_MODE_FAST_AGGREGATE, d_results, d_bitmap, d_status, (hipStream_t)stream);
 }
 extern "C" int mbls_verify_batch_device(mbls_ctx* c, const uint8_t* d_sigs, const uint8_t* d_msgs, uint32_t msg_len,
         const uint8_t* d_pks, int fmt, uint64_t n, uint8_t* d_results, uint64_t* d_bitmap, uint32_t* d_status, void* stream) {
-    return verify_pipeline(c, d_sigs, d_msgs, msg_len, d_pks, fmt, nullptr, n, 1, MBLS_MODE_VERIFY, d_results, d_bitmap, d_status, (hipStream_t)stream);
+    if (!c) return MBLS_ERR_ARGUMENT;
+    mbls_lock lk(c->mu);
+    keysrc ks; ks.d_pks = d_pks; ks.fmt = fmt;
+    return verify_pipeline(c, d_sigs, d_msgs, msg_len, ks, n, 1, MBLS_MODE_VERIFY, d_results, d_bitmap, d_status, (hipStream_t)stream);
 }
 
-// ---- small RAII helper for host-pointer entry points
-struct dbuf {
-    void* p = nullptr; size_t n = 0;
-    ~dbuf() { if (p) (void)hipFree(p); }
-    hipError_t alloc(size_t bytes) { n = bytes ? bytes : 1; return hipMalloc(&p, n); }
-    hipError_t up(const void* h, size_t bytes) { hipError_t e = alloc(bytes); if (e != hipSuccess || !bytes) return e; return hipMemcpy(p, h, bytes, hipMemcpyHostToDevice); }
-    hipError_t down(void* h, size_t bytes) { return bytes ? hipMemcpy(h, p, bytes, hipMemcpyDeviceToHost) : hipSuccess; }
-    template <typename T> T* as() { return (T*)p; }
-};
+// offsets of a ragged key / signature table handed over in host memory: non-decreasing, and the total fits the index type
+static bool offsets_ok(const uint32_t* off, uint64_t n) {
+    for (uint64_t i = 0; i < n; i++) if (off[i + 1] < off[i]) return false;
+    return true;
+}
 
+// Host buffers in, results out. The keys (or key indices) are 99 % of the bytes: they are uploaded on a second stream while the
+// signature and message phases run.
 static int verify_host(mbls_ctx* c, const uint8_t* sigs, const uint8_t* msgs, uint32_t msg_len, const uint8_t* pks, int fmt,
-                       const uint32_t* off, uint64_t n, uint32_t k, int mode, uint8_t* results, uint32_t* status) {
+                       const mbls_keytable* tab, const uint32_t* idx, const uint32_t* off, uint64_t n, uint32_t k, int mode,
+                       uint8_t* results, uint32_t* status) {
     if (!c) return MBLS_ERR_ARGUMENT;
+    mbls_lock lk(c->mu);
     if (n == 0) return MBLS_OK;
-    if (!sigs || (!msgs && msg_len) || !results) return MBLS_ERR_ARGUMENT;
-    if (fmt != MBLS_PK_COMPRESSED && fmt != MBLS_PK_UNCOMPRESSED) return MBLS_ERR_ARGUMENT;
+    if (!sigs || (!msgs && msg_len) || !results) ARGFAIL(c, "null buffer");
+    if (fmt != MBLS_PK_COMPRESSED && fmt != MBLS_PK_UNCOMPRESSED) ARGFAIL(c, "pk_format");
+    if (tab && tab->c != c) ARGFAIL(c, "key table belongs to another context");
+    if (off && !offsets_ok(off, n)) ARGFAIL(c, "offsets must be non-decreasing");
     HIPCHK(c, hipSetDevice(c->device));
     uint64_t total_keys = off ? off[n] : (uint64_t)k * n;
-    size_t pkb = fmt == MBLS_PK_COMPRESSED ? 48 : 96;
-    dbuf ds, dm, dp, doff, dr, dst;
+    const bool indexed = tab != nullptr;
+    if (total_keys && !(indexed ? (const void*)idx : (const void*)pks)) ARGFAIL(c, "null key buffer");
+    size_t unit = indexed ? 4 : (fmt == MBLS_PK_COMPRESSED ? 48 : 96);
+    sbuf ds(c, 0), dm(c, 1), dp(c, 2), doff(c, 3), dr(c, 4), dst(c, 5);
     HIPCHK(c, ds.up(sigs, 96 * n)); HIPCHK(c, dm.up(msgs, (size_t)msg_len * n));
     if (off) HIPCHK(c, doff.up(off, 4 * (n + 1)));
-    HIPCHK(c, dr.alloc(n)); HIPCHK(c, dst.alloc(4 * n)); HIPCHK(c, dp.alloc(pkb * total_keys));
-    // the keys are 99 % of the bytes: they are uploaded on a second stream while the signature and message phases run
-    struct two_streams {
-        hipStream_t a = nullptr, b = nullptr; hipEvent_t e = nullptr;
-        ~two_streams() { if (e) (void)hipEventDestroy(e); if (a) (void)hipStreamDestroy(a); if (b) (void)hipStreamDestroy(b); }
-    } ts;
-    HIPCHK(c, hipStreamCreateWithFlags(&ts.a, hipStreamNonBlocking)); HIPCHK(c, hipStreamCreateWithFlags(&ts.b, hipStreamNonBlocking));
-    HIPCHK(c, hipEventCreateWithFlags(&ts.e, hipEventDisableTiming));
+    HIPCHK(c, dr.alloc(n)); HIPCHK(c, dst.alloc(4 * n)); HIPCHK(c, dp.alloc(unit * total_keys));
     bool tm = c->timing; c->timing = false;              // the phase timers assume the plain order
-    const uint32_t* doffp = off ? doff.as<uint32_t>() : nullptr;
-    int rc = verify_pipeline(c, ds.as<uint8_t>(), dm.as<uint8_t>(), msg_len, nullptr, fmt, doffp, n, k, mode, dr.as<uint8_t>(), nullptr,
-                             dst.as<uint32_t>(), ts.a, 1);
+    keysrc ks; ks.fmt = fmt; ks.d_off = off ? doff.as<uint32_t>() : nullptr; ks.indexed = indexed;
+    if (indexed) { ks.d_recs = tab->d_recs; ks.tsize = tab->size; }
+    int rc = verify_pipeline(c, ds.as<uint8_t>(), dm.as<uint8_t>(), msg_len, ks, n, k, mode, dr.as<uint8_t>(), nullptr, dst.as<uint32_t>(), c->hs_a, 1);
     if (!rc) {
         hipError_t e1 = hipSuccess;      // issued after the first two phases were queued: a copy from pageable memory may block the host
-        if (total_keys) e1 = hipMemcpyAsync(dp.p, pks, pkb * total_keys, hipMemcpyHostToDevice, ts.b);
-        if (e1 == hipSuccess) e1 = hipEventRecord(ts.e, ts.b);
-        if (e1 == hipSuccess) e1 = hipStreamWaitEvent(ts.a, ts.e, 0);
+        if (total_keys) e1 = hipMemcpyAsync(dp.p, indexed ? (const void*)idx : (const void*)pks, unit * total_keys, hipMemcpyHostToDevice, c->hs_b);
+        if (e1 == hipSuccess) e1 = hipEventRecord(c->hs_ev, c->hs_b);
+        if (e1 == hipSuccess) e1 = hipStreamWaitEvent(c->hs_a, c->hs_ev, 0);
         if (e1 != hipSuccess) { c->timing = tm; HIPCHK(c, e1); }
-        rc = verify_pipeline(c, ds.as<uint8_t>(), dm.as<uint8_t>(), msg_len, dp.as<uint8_t>(), fmt, doffp, n, k, mode, dr.as<uint8_t>(), nullptr,
-                             dst.as<uint32_t>(), ts.a, 2);
+        if (indexed) ks.d_idx = dp.as<uint32_t>(); else ks.d_pks = dp.as<uint8_t>();
+        rc = verify_pipeline(c, ds.as<uint8_t>(), dm.as<uint8_t>(), msg_len, ks, n, k, mode, dr.as<uint8_t>(), nullptr, dst.as<uint32_t>(), c->hs_a, 2);
     }
     c->timing = tm;
     if (rc) return rc;
-    HIPCHK(c, hipDeviceSynchronize());
+    HIPCHK(c, hipStreamSynchronize(c->hs_a));
+    c->ws_pending = false;
     HIPCHK(c, dr.down(results, n));
     if (status) HIPCHK(c, dst.down(status, 4 * n));
     return MBLS_OK;
 }
 extern "C" int mbls_fast_aggregate_verify_batch(mbls_ctx* c, const uint8_t* sigs, const uint8_t* msgs, uint32_t msg_len, const uint8_t* pks,
         int fmt, const uint32_t* off, uint64_t n, uint32_t k, uint8_t* results, uint32_t* status) {
-    return verify_host(c, sigs, msgs, msg_len, pks, fmt, off, n, k, MBLS_MODE_FAST_AGGREGATE, results, status);
+    return verify_host(c, sigs, msgs, msg_len, pks, fmt, nullptr, nullptr, off, n, k, MBLS_MODE_FAST_AGGREGATE, results, status);
 }
 extern "C" int mbls_verify_batch(mbls_ctx* c, const uint8_t* sigs, const uint8_t* msgs, uint32_t msg_len, const uint8_t* pks, int fmt,
         uint64_t n, uint8_t* results, uint32_t* status) {
-    return verify_host(c, sigs, msgs, msg_len, pks, fmt, nullptr, n, 1, MBLS_MODE_VERIFY, results, status);
+    return verify_host(c, sigs, msgs, msg_len, pks, fmt, nullptr, nullptr, nullptr, n, 1, MBLS_MODE_VERIFY, results, status);
+}
+
+// ---- resident key table
+extern "C" int mbls_keytable_create(mbls_ctx* c, uint64_t capacity_hint, mbls_keytable** out) {
+    if (!c || !out) return MBLS_ERR_ARGUMENT;
+    mbls_lock lk(c->mu);
+    HIPCHK(c, hipSetDevice(c->device));
+    mbls_keytable* t = new (std::nothrow) mbls_keytable();
+    if (!t) return MBLS_ERR_DEVICE;
+    t->c = c; t->cap = capacity_hint ? capacity_hint : 1024;
+    hipError_t e = hipMalloc(&t->d_recs, t->cap * MBLS_KEYREC_DWORDS * 4);
+    if (e != hipSuccess) { delete t; HIPCHK(c, e); }
+    *out = t; return MBLS_OK;
+}
+extern "C" void mbls_keytable_destroy(mbls_keytable* t) {
+    if (!t) return;
+    { mbls_lock lk(t->c->mu); (void)hipSetDevice(t->c->device); (void)hipDeviceSynchronize(); if (t->d_recs) (void)hipFree(t->d_recs); }
+    delete t;
+}
+extern "C" uint64_t mbls_keytable_size(const mbls_keytable* t) { if (!t) return 0; mbls_lock lk(t->c->mu); return t->size; }
+static int keytable_grow(mbls_keytable* t, uint64_t need, hipStream_t s) {
+    mbls_ctx* c = t->c;
+    if (need <= t->cap) return MBLS_OK;
+    uint64_t ncap = t->cap * 2 > need ? t->cap * 2 : need;
+    uint32_t* nr = nullptr;
+    HIPCHK(c, hipMalloc(&nr, ncap * MBLS_KEYREC_DWORDS * 4));
+    hipError_t e = hipSuccess;
+    if (t->size) e = hipMemcpyAsync(nr, t->d_recs, t->size * MBLS_KEYREC_DWORDS * 4, hipMemcpyDeviceToDevice, s);
+    if (e == hipSuccess) e = hipDeviceSynchronize();      // verifications in flight on other streams may still read the old records
+    if (e != hipSuccess) { (void)hipFree(nr); HIPCHK(c, e); }
+    (void)hipFree(t->d_recs); t->d_recs = nr; t->cap = ncap;
+    return MBLS_OK;
+}
+extern "C" int mbls_keytable_append_device(mbls_keytable* t, const uint8_t* d_pks, int fmt, int validate, uint64_t n, uint64_t* first_index,
+                                           uint8_t* d_errs, void* stream) {
+    if (!t) return MBLS_ERR_ARGUMENT;
+    mbls_ctx* c = t->c;
+    mbls_lock lk(c->mu);
+    if ((fmt != MBLS_PK_COMPRESSED && fmt != MBLS_PK_UNCOMPRESSED) || (n && (!d_pks || !d_errs))) ARGFAIL(c, "keytable_append");
+    if (t->size + n > 0xFFFFFFFFull) ARGFAIL(c, "key table indices are 32-bit");
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t s = (hipStream_t)stream;
+    int rc = keytable_grow(t, t->size + n, s); if (rc) return rc;
+    if (first_index) *first_index = t->size;
+    if (n) {
+        hipLaunchKernelGGL(k_keytable_append, dim3(nblk(n)), dim3(WG), 0, s, d_pks, fmt, validate, n, t->d_recs + t->size * MBLS_KEYREC_DWORDS, d_errs);
+        HIPCHK(c, hipGetLastError());
+    }
+    t->size += n; return MBLS_OK;
+}
+static int map_dec_err_g1(int e) { return e == MBLS_DEC_OK ? MBLS_OK : (e == MBLS_DEC_SIZE ? MBLS_ERR_INVALID_G1_SIZE : MBLS_ERR_INVALID_POINT); }
+static int map_dec_err_g2(int e) { return e == MBLS_DEC_OK ? MBLS_OK : (e == MBLS_DEC_SIZE ? MBLS_ERR_INVALID_G2_SIZE : MBLS_ERR_INVALID_POINT); }
+extern "C" int mbls_keytable_append(mbls_keytable* t, const uint8_t* pks, int fmt, int validate, uint64_t n, uint64_t* first_index, uint8_t* errs) {
+    if (!t) return MBLS_ERR_ARGUMENT;
+    mbls_ctx* c = t->c;
+    mbls_lock lk(c->mu);
+    if ((fmt != MBLS_PK_COMPRESSED && fmt != MBLS_PK_UNCOMPRESSED) || (n && (!pks || !errs))) ARGFAIL(c, "keytable_append");
+    HIPCHK(c, hipSetDevice(c->device));
+    sbuf di(c, 0), de(c, 1);
+    HIPCHK(c, di.up(pks, (fmt ? 96 : 48) * n)); HIPCHK(c, de.alloc(n));
+    int rc = mbls_keytable_append_device(t, di.as<uint8_t>(), fmt, validate, n, first_index, de.as<uint8_t>(), c->hs_a); if (rc) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->hs_a)); HIPCHK(c, de.down(errs, n));
+    for (uint64_t i = 0; i < n; i++) errs[i] = (uint8_t)map_dec_err_g1(errs[i]);
+    return MBLS_OK;
+}
+extern "C" int mbls_keytable_get(mbls_keytable* t, uint64_t first, uint64_t n, uint8_t* pks96, uint8_t* errs) {
+    if (!t) return MBLS_ERR_ARGUMENT;
+    mbls_ctx* c = t->c;
+    mbls_lock lk(c->mu);
+    if (first + n > t->size || (n && (!pks96 || !errs))) ARGFAIL(c, "keytable_get range");
+    if (!n) return MBLS_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    sbuf dout(c, 0), de(c, 1); HIPCHK(c, dout.alloc(96 * n)); HIPCHK(c, de.alloc(n));
+    hipLaunchKernelGGL(k_keytable_export, dim3(nblk(n)), dim3(WG), 0, c->hs_a, (const uint32_t*)t->d_recs, first, n, dout.as<uint8_t>(), de.as<uint8_t>());
+    HIPCHK(c, hipStreamSynchronize(c->hs_a)); HIPCHK(c, dout.down(pks96, 96 * n)); HIPCHK(c, de.down(errs, n));
+    for (uint64_t i = 0; i < n; i++) errs[i] = (uint8_t)map_dec_err_g1(errs[i]);
+    return MBLS_OK;
+}
+extern "C" int mbls_fast_aggregate_verify_batch_indexed_device(mbls_ctx* c, const mbls_keytable* t, const uint8_t* d_sigs, const uint8_t* d_msgs,
+        uint32_t msg_len, const uint32_t* d_idx, const uint32_t* d_off, uint64_t n, uint32_t k, uint8_t* d_results, uint64_t* d_bitmap,
+        uint32_t* d_status, void* stream) {
+    if (!c || !t) return MBLS_ERR_ARGUMENT;
+    mbls_lock lk(c->mu);
+    if (t->c != c) ARGFAIL(c, "key table belongs to another context");
+    keysrc ks; ks.indexed = true; ks.d_recs = t->d_recs; ks.tsize = t->size; ks.d_idx = d_idx; ks.d_off = d_off;
+    return verify_pipeline(c, d_sigs, d_msgs, msg_len, ks, n, k, MBLS_MODE_FAST_AGGREGATE, d_results, d_bitmap, d_status, (hipStream_t)stream);
+}
+extern "C" int mbls_fast_aggregate_verify_batch_indexed(mbls_ctx* c, const mbls_keytable* t, const uint8_t* sigs, const uint8_t* msgs, uint32_t msg_len,
+        const uint32_t* idx, const uint32_t* off, uint64_t n, uint32_t k, uint8_t* results, uint32_t* status) {
+    if (!c || !t) return MBLS_ERR_ARGUMENT;
+    return verify_host(c, sigs, msgs, msg_len, nullptr, MBLS_PK_UNCOMPRESSED, t, idx, off, n, k, MBLS_MODE_FAST_AGGREGATE, results, status);
 }
 
 // ---- batch helpers
-static int map_dec_err_g1(int e) { return e == MBLS_DEC_OK ? MBLS_OK : (e == MBLS_DEC_SIZE ? MBLS_ERR_INVALID_G1_SIZE : MBLS_ERR_INVALID_POINT); }
-static int map_dec_err_g2(int e) { return e == MBLS_DEC_OK ? MBLS_OK : (e == MBLS_DEC_SIZE ? MBLS_ERR_INVALID_G2_SIZE : MBLS_ERR_INVALID_POINT); }
-
 extern "C" int mbls_pk_decode_batch(mbls_ctx* c, const uint8_t* in, int fmt, int validate, uint64_t n, uint8_t* out96, uint8_t* errs) {
     if (!c || !in || !out96 || !errs || (fmt != 0 && fmt != 1)) return MBLS_ERR_ARGUMENT;
+    mbls_lock lk(c->mu);
     if (!n) return MBLS_OK;
     HIPCHK(c, hipSetDevice(c->device));
-    dbuf di, dout, de; HIPCHK(c, di.up(in, (fmt ? 96 : 48) * n)); HIPCHK(c, dout.alloc(96 * n)); HIPCHK(c, de.alloc(n));
-    hipLaunchKernelGGL(k_g1_decode, dim3(nblk(n)), dim3(WG), 0, 0, di.as<uint8_t>(), fmt, validate, n, dout.as<uint8_t>(), de.as<uint8_t>());
-    HIPCHK(c, hipDeviceSynchronize()); HIPCHK(c, dout.down(out96, 96 * n)); HIPCHK(c, de.down(errs, n));
+    sbuf di(c, 0), dout(c, 1), de(c, 2); HIPCHK(c, di.up(in, (fmt ? 96 : 48) * n)); HIPCHK(c, dout.alloc(96 * n)); HIPCHK(c, de.alloc(n));
+    hipLaunchKernelGGL(k_g1_decode, dim3(nblk(n)), dim3(WG), 0, c->hs_a, di.as<uint8_t>(), fmt, validate, n, dout.as<uint8_t>(), de.as<uint8_t>());
+    HIPCHK(c, hipStreamSynchronize(c->hs_a)); HIPCHK(c, dout.down(out96, 96 * n)); HIPCHK(c, de.down(errs, n));
     for (uint64_t i = 0; i < n; i++) errs[i] = (uint8_t)map_dec_err_g1(errs[i]);
     return MBLS_OK;
 }
 extern "C" int mbls_pk_compress_batch(mbls_ctx* c, const uint8_t* in96, uint64_t n, uint8_t* out48, uint8_t* errs) {
     if (!c || !in96 || !out48 || !errs) return MBLS_ERR_ARGUMENT;
+    mbls_lock lk(c->mu);
     if (!n) return MBLS_OK;
     HIPCHK(c, hipSetDevice(c->device));
-    dbuf di, dout, de; HIPCHK(c, di.up(in96, 96 * n)); HIPCHK(c, dout.alloc(48 * n)); HIPCHK(c, de.alloc(n));
-    hipLaunchKernelGGL(k_g1_compress, dim3(nblk(n)), dim3(WG), 0, 0, di.as<uint8_t>(), n, dout.as<uint8_t>(), de.as<uint8_t>());
-    HIPCHK(c, hipDeviceSynchronize()); HIPCHK(c, dout.down(out48, 48 * n)); HIPCHK(c, de.down(errs, n));
+    sbuf di(c, 0), dout(c, 1), de(c, 2); HIPCHK(c, di.up(in96, 96 * n)); HIPCHK(c, dout.alloc(48 * n)); HIPCHK(c, de.alloc(n));
+    hipLaunchKernelGGL(k_g1_compress, dim3(nblk(n)), dim3(WG), 0, c->hs_a, di.as<uint8_t>(), n, dout.as<uint8_t>(), de.as<uint8_t>());
+    HIPCHK(c, hipStreamSynchronize(c->hs_a)); HIPCHK(c, dout.down(out48, 48 * n)); HIPCHK(c, de.down(errs, n));
     for (uint64_t i = 0; i < n; i++) errs[i] = (uint8_t)map_dec_err_g1(errs[i]);
     return MBLS_OK;
 }
 extern "C" int mbls_sig_check_batch(mbls_ctx* c, const uint8_t* in96, uint64_t n, uint8_t* errs, uint8_t* in_g2) {
     if (!c || !in96 || !errs) return MBLS_ERR_ARGUMENT;
+    mbls_lock lk(c->mu);
     if (!n) return MBLS_OK;
     HIPCHK(c, hipSetDevice(c->device));
-    dbuf di, de, dg; HIPCHK(c, di.up(in96, 96 * n)); HIPCHK(c, de.alloc(n)); if (in_g2) HIPCHK(c, dg.alloc(n));
-    hipLaunchKernelGGL(k_g2_check, dim3(nblk(n)), dim3(WG), 0, 0, di.as<uint8_t>(), n, de.as<uint8_t>(), in_g2 ? dg.as<uint8_t>() : (uint8_t*)nullptr);
-    HIPCHK(c, hipDeviceSynchronize()); HIPCHK(c, de.down(errs, n)); if (in_g2) HIPCHK(c, dg.down(in_g2, n));
+    sbuf di(c, 0), de(c, 1), dg(c, 2); HIPCHK(c, di.up(in96, 96 * n)); HIPCHK(c, de.alloc(n)); if (in_g2) HIPCHK(c, dg.alloc(n));
+    hipLaunchKernelGGL(k_g2_check, dim3(nblk(n)), dim3(WG), 0, c->hs_a, di.as<uint8_t>(), n, de.as<uint8_t>(), in_g2 ? dg.as<uint8_t>() : (uint8_t*)nullptr);
+    HIPCHK(c, hipStreamSynchronize(c->hs_a)); HIPCHK(c, de.down(errs, n)); if (in_g2) HIPCHK(c, dg.down(in_g2, n));
     for (uint64_t i = 0; i < n; i++) errs[i] = (uint8_t)map_dec_err_g2(errs[i]);
     return MBLS_OK;
 }
 extern "C" int mbls_sign_batch_device(mbls_ctx* c, const uint8_t* d_sks, const uint8_t* d_msgs, uint32_t msg_len, uint64_t n, uint8_t* d_sigs, void* stream) {
     if (!c || !d_sks || !d_sigs || (!d_msgs && msg_len)) return MBLS_ERR_ARGUMENT;
+    mbls_lock lk(c->mu);
     if (!n) return MBLS_OK;
     HIPCHK(c, hipSetDevice(c->device));
     hipLaunchKernelGGL(k_sign, dim3(nblk(n)), dim3(WG), 0, (hipStream_t)stream, d_sks, d_msgs, msg_len, n, d_sigs);
@@ -423,14 +658,16 @@ extern "C" int mbls_sign_batch_device(mbls_ctx* c, const uint8_t* d_sks, const u
 }
 extern "C" int mbls_sign_batch(mbls_ctx* c, const uint8_t* sks, const uint8_t* msgs, uint32_t msg_len, uint64_t n, uint8_t* sigs) {
     if (!c || !sks || !sigs || (!msgs && msg_len)) return MBLS_ERR_ARGUMENT;
+    mbls_lock lk(c->mu);
     if (!n) return MBLS_OK;
     HIPCHK(c, hipSetDevice(c->device));
-    dbuf dk, dm, dout; HIPCHK(c, dk.up(sks, 32 * n)); HIPCHK(c, dm.up(msgs, (size_t)msg_len * n)); HIPCHK(c, dout.alloc(96 * n));
-    int rc = mbls_sign_batch_device(c, dk.as<uint8_t>(), dm.as<uint8_t>(), msg_len, n, dout.as<uint8_t>(), nullptr); if (rc) return rc;
-    HIPCHK(c, hipDeviceSynchronize()); HIPCHK(c, dout.down(sigs, 96 * n)); return MBLS_OK;
+    sbuf dk(c, 0), dm(c, 1), dout(c, 2); HIPCHK(c, dk.up(sks, 32 * n)); HIPCHK(c, dm.up(msgs, (size_t)msg_len * n)); HIPCHK(c, dout.alloc(96 * n));
+    int rc = mbls_sign_batch_device(c, dk.as<uint8_t>(), dm.as<uint8_t>(), msg_len, n, dout.as<uint8_t>(), c->hs_a); if (rc) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->hs_a)); HIPCHK(c, dout.down(sigs, 96 * n)); return MBLS_OK;
 }
 extern "C" int mbls_sk_to_pk_batch_device(mbls_ctx* c, const uint8_t* d_sks, int fmt, uint64_t n, uint8_t* d_pks, void* stream) {
     if (!c || !d_sks || !d_pks || (fmt != 0 && fmt != 1)) return MBLS_ERR_ARGUMENT;
+    mbls_lock lk(c->mu);
     if (!n) return MBLS_OK;
     HIPCHK(c, hipSetDevice(c->device));
     hipLaunchKernelGGL(k_sk_to_pk, dim3(nblk(n)), dim3(WG), 0, (hipStream_t)stream, d_sks, fmt, n, d_pks);
@@ -438,53 +675,109 @@ extern "C" int mbls_sk_to_pk_batch_device(mbls_ctx* c, const uint8_t* d_sks, int
 }
 extern "C" int mbls_sk_to_pk_batch(mbls_ctx* c, const uint8_t* sks, int fmt, uint64_t n, uint8_t* pks) {
     if (!c || !sks || !pks || (fmt != 0 && fmt != 1)) return MBLS_ERR_ARGUMENT;
+    mbls_lock lk(c->mu);
     if (!n) return MBLS_OK;
     HIPCHK(c, hipSetDevice(c->device));
-    dbuf dk, dout; HIPCHK(c, dk.up(sks, 32 * n)); HIPCHK(c, dout.alloc((fmt ? 96 : 48) * n));
-    int rc = mbls_sk_to_pk_batch_device(c, dk.as<uint8_t>(), fmt, n, dout.as<uint8_t>(), nullptr); if (rc) return rc;
-    HIPCHK(c, hipDeviceSynchronize()); HIPCHK(c, dout.down(pks, (fmt ? 96 : 48) * n)); return MBLS_OK;
+    sbuf dk(c, 0), dout(c, 1); HIPCHK(c, dk.up(sks, 32 * n)); HIPCHK(c, dout.alloc((fmt ? 96 : 48) * n));
+    int rc = mbls_sk_to_pk_batch_device(c, dk.as<uint8_t>(), fmt, n, dout.as<uint8_t>(), c->hs_a); if (rc) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->hs_a)); HIPCHK(c, dout.down(pks, (fmt ? 96 : 48) * n)); return MBLS_OK;
 }
 extern "C" int mbls_hash_to_g2_batch(mbls_ctx* c, const uint8_t* msgs, uint32_t msg_len, uint64_t n, uint8_t* out96) {
     if (!c || !out96 || (!msgs && msg_len)) return MBLS_ERR_ARGUMENT;
+    mbls_lock lk(c->mu);
     if (!n) return MBLS_OK;
     HIPCHK(c, hipSetDevice(c->device));
-    dbuf dm, dout; HIPCHK(c, dm.up(msgs, (size_t)msg_len * n)); HIPCHK(c, dout.alloc(96 * n));
-    hipLaunchKernelGGL(k_hash_to_g2, dim3(nblk(n)), dim3(WG), 0, 0, dm.as<uint8_t>(), msg_len, n, dout.as<uint8_t>());
-    HIPCHK(c, hipDeviceSynchronize()); HIPCHK(c, dout.down(out96, 96 * n)); return MBLS_OK;
+    sbuf dm(c, 0), dout(c, 1); HIPCHK(c, dm.up(msgs, (size_t)msg_len * n)); HIPCHK(c, dout.alloc(96 * n));
+    hipLaunchKernelGGL(k_hash_to_g2, dim3(nblk(n)), dim3(WG), 0, c->hs_a, dm.as<uint8_t>(), msg_len, n, dout.as<uint8_t>());
+    HIPCHK(c, hipStreamSynchronize(c->hs_a)); HIPCHK(c, dout.down(out96, 96 * n)); return MBLS_OK;
 }
 extern "C" int mbls_aggregate_public_keys_batch(mbls_ctx* c, const uint8_t* pks, int fmt, const uint32_t* off, uint64_t n, uint32_t k,
                                                 uint8_t* apks96, uint32_t* status) {
     if (!c || !apks96 || (fmt != 0 && fmt != 1)) return MBLS_ERR_ARGUMENT;
+    mbls_lock lk(c->mu);
     if (!n) return MBLS_OK;
+    if (off && !offsets_ok(off, n)) ARGFAIL(c, "offsets must be non-decreasing");
     HIPCHK(c, hipSetDevice(c->device));
     int rc = mbls_ctx_reserve(c, n); if (rc) return rc;
     uint64_t total = off ? off[n] : (uint64_t)k * n;
-    dbuf dp, doff, dout; HIPCHK(c, dp.up(pks, (fmt ? 96 : 48) * total)); if (off) HIPCHK(c, doff.up(off, 4 * (n + 1))); HIPCHK(c, dout.alloc(96 * n));
+    if (total && !pks) ARGFAIL(c, "null key buffer");
+    sbuf dp(c, 0), doff(c, 1), dout(c, 2); HIPCHK(c, dp.up(pks, (fmt ? 96 : 48) * total)); if (off) HIPCHK(c, doff.up(off, 4 * (n + 1))); HIPCHK(c, dout.alloc(96 * n));
     mbls_ws ws; ws.w = c->d_w; ws.stride = c->cap;
-    HIPCHK(c, hipMemsetAsync(c->d_status, 0, 4 * n, 0));      // k_aggregate ORs its bits in
-    hipLaunchKernelGGL(k_aggregate, dim3(nblk(n)), dim3(WG), 0, 0, ws, dp.as<uint8_t>(), off ? doff.as<uint32_t>() : (const uint32_t*)nullptr, k, fmt,
+    hipStream_t s = c->hs_a;
+    rc = ws_acquire(c, s); if (rc) return rc;
+    HIPCHK(c, hipMemsetAsync(c->d_status, 0, 4 * n, s));      // k_aggregate ORs its bits in
+    hipLaunchKernelGGL(k_aggregate, dim3(nblk(n)), dim3(WG), 0, s, ws, dp.as<uint8_t>(), off ? doff.as<uint32_t>() : (const uint32_t*)nullptr, k, fmt,
                        MBLS_MODE_FAST_AGGREGATE, c->d_status, n);
-    hipLaunchKernelGGL(k_apk_export, dim3(nblk(n)), dim3(WG), 0, 0, ws, n, dout.as<uint8_t>());
-    HIPCHK(c, hipDeviceSynchronize()); HIPCHK(c, dout.down(apks96, 96 * n));
+    hipLaunchKernelGGL(k_apk_export, dim3(nblk(n)), dim3(WG), 0, s, ws, n, dout.as<uint8_t>());
+    HIPCHK(c, hipStreamSynchronize(s)); c->ws_pending = false;
+    HIPCHK(c, dout.down(apks96, 96 * n));
     if (status) HIPCHK(c, hipMemcpy(status, c->d_status, 4 * n, hipMemcpyDeviceToHost));
+    return MBLS_OK;
+}
+extern "C" int mbls_aggregate_signatures_batch_device(mbls_ctx* c, const uint8_t* d_sigs, const uint32_t* d_off, uint64_t n, uint32_t k, uint64_t total,
+                                                      uint8_t* d_out96, uint8_t* d_errs, void* stream) {
+    if (!c) return MBLS_ERR_ARGUMENT;
+    mbls_lock lk(c->mu);
+    if (!n) return MBLS_OK;
+    if (!d_out96 || !d_errs || (total && !d_sigs)) ARGFAIL(c, "null buffer");
+    if (!d_off && total != (uint64_t)k * n) ARGFAIL(c, "total_sigs != n_sets * k");
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t s = (hipStream_t)stream;
+    sbuf dxy(c, 6), dfl(c, 7); HIPCHK(c, dxy.alloc(192 * total)); HIPCHK(c, dfl.alloc(total));
+    if (total) hipLaunchKernelGGL(k_g2_decode_affine, dim3(nblk(total)), dim3(WG), 0, s, d_sigs, total, dxy.as<uint32_t>(), dfl.as<uint8_t>());
+    hipLaunchKernelGGL(k_g2_sum, dim3(nblk(n)), dim3(WG), 0, s, (const uint32_t*)dxy.as<uint32_t>(), (const uint8_t*)dfl.as<uint8_t>(), d_off, k, n, d_out96, d_errs);
+    HIPCHK(c, hipGetLastError());
+    return MBLS_OK;
+}
+extern "C" int mbls_aggregate_signatures_batch(mbls_ctx* c, const uint8_t* sigs, const uint32_t* off, uint64_t n, uint32_t k, uint8_t* out96, uint8_t* errs) {
+    if (!c || !out96 || !errs) return MBLS_ERR_ARGUMENT;
+    mbls_lock lk(c->mu);
+    if (!n) return MBLS_OK;
+    if (off && !offsets_ok(off, n)) ARGFAIL(c, "offsets must be non-decreasing");
+    uint64_t total = off ? off[n] : (uint64_t)k * n;
+    if (total && !sigs) ARGFAIL(c, "null signature buffer");
+    HIPCHK(c, hipSetDevice(c->device));
+    sbuf di(c, 0), doff(c, 1), dout(c, 2), de(c, 3);
+    HIPCHK(c, di.up(sigs, 96 * total)); if (off) HIPCHK(c, doff.up(off, 4 * (n + 1))); HIPCHK(c, dout.alloc(96 * n)); HIPCHK(c, de.alloc(n));
+    int rc = mbls_aggregate_signatures_batch_device(c, di.as<uint8_t>(), off ? doff.as<uint32_t>() : nullptr, n, k, total, dout.as<uint8_t>(), de.as<uint8_t>(), c->hs_a);
+    if (rc) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->hs_a)); HIPCHK(c, dout.down(out96, 96 * n)); HIPCHK(c, de.down(errs, n));
+    for (uint64_t i = 0; i < n; i++) errs[i] = (uint8_t)map_dec_err_g2(errs[i]);
     return MBLS_OK;
 }
 extern "C" int mbls_fp_mul_batch(mbls_ctx* c, const uint8_t* a, const uint8_t* b, uint64_t n, uint8_t* out, int square) {
     if (!c || !a || !b || !out) return MBLS_ERR_ARGUMENT;
+    mbls_lock lk(c->mu);
     if (!n) return MBLS_OK;
     HIPCHK(c, hipSetDevice(c->device));
-    dbuf da, db, dout; HIPCHK(c, da.up(a, 48 * n)); HIPCHK(c, db.up(b, 48 * n)); HIPCHK(c, dout.alloc(48 * n));
-    hipLaunchKernelGGL(k_fp_mul, dim3(nblk(n)), dim3(WG), 0, 0, da.as<uint8_t>(), db.as<uint8_t>(), n, dout.as<uint8_t>(), square);
-    HIPCHK(c, hipDeviceSynchronize()); HIPCHK(c, dout.down(out, 48 * n)); return MBLS_OK;
+    sbuf da(c, 0), db(c, 1), dout(c, 2); HIPCHK(c, da.up(a, 48 * n)); HIPCHK(c, db.up(b, 48 * n)); HIPCHK(c, dout.alloc(48 * n));
+    hipLaunchKernelGGL(k_fp_mul, dim3(nblk(n)), dim3(WG), 0, c->hs_a, da.as<uint8_t>(), db.as<uint8_t>(), n, dout.as<uint8_t>(), square);
+    HIPCHK(c, hipStreamSynchronize(c->hs_a)); HIPCHK(c, dout.down(out, 48 * n)); return MBLS_OK;
 }
 extern "C" int mbls_fp_mul_bench(mbls_ctx* c, uint64_t n_lanes, uint32_t iters, float* ms_out) {
     if (!c || !ms_out || !n_lanes) return MBLS_ERR_ARGUMENT;
+    mbls_lock lk(c->mu);
     HIPCHK(c, hipSetDevice(c->device));
-    dbuf sink; HIPCHK(c, sink.alloc(4 * n_lanes));
-    hipLaunchKernelGGL(k_fp_mul_bench, dim3(nblk(n_lanes)), dim3(WG), 0, 0, sink.as<uint32_t>(), 16u, n_lanes);   // warm-up
-    HIPCHK(c, hipEventRecord(c->ev[0], 0));
-    hipLaunchKernelGGL(k_fp_mul_bench, dim3(nblk(n_lanes)), dim3(WG), 0, 0, sink.as<uint32_t>(), iters, n_lanes);
-    HIPCHK(c, hipEventRecord(c->ev[1], 0)); HIPCHK(c, hipEventSynchronize(c->ev[1]));
+    sbuf sink(c, 0); HIPCHK(c, sink.alloc(4 * n_lanes));
+    hipLaunchKernelGGL(k_fp_mul_bench, dim3(nblk(n_lanes)), dim3(WG), 0, c->hs_a, sink.as<uint32_t>(), 16u, n_lanes);   // warm-up
+    HIPCHK(c, hipEventRecord(c->ev[0], c->hs_a));
+    hipLaunchKernelGGL(k_fp_mul_bench, dim3(nblk(n_lanes)), dim3(WG), 0, c->hs_a, sink.as<uint32_t>(), iters, n_lanes);
+    HIPCHK(c, hipEventRecord(c->ev[1], c->hs_a)); HIPCHK(c, hipEventSynchronize(c->ev[1]));
+    HIPCHK(c, hipEventElapsedTime(ms_out, c->ev[0], c->ev[1]));
+    return MBLS_OK;
+}
+
+extern "C" int mbls_valu_bench(mbls_ctx* c, int mode, uint32_t waves_per_simd, uint32_t iters, float* ms_out) {
+    if (!c || !ms_out || !waves_per_simd || waves_per_simd > 8 || (mode != 0 && mode != 1)) return MBLS_ERR_ARGUMENT;
+    mbls_lock lk(c->mu);
+    HIPCHK(c, hipSetDevice(c->device));
+    hipDeviceProp_t prop; HIPCHK(c, hipGetDeviceProperties(&prop, c->device));
+    unsigned blocks = (unsigned)prop.multiProcessorCount * 4u * waves_per_simd;      // waves_per_simd waves on every SIMD
+    sbuf sink(c, 0); HIPCHK(c, sink.alloc((size_t)4 * WG * blocks));
+    hipLaunchKernelGGL(k_valu_bench, dim3(blocks), dim3(WG), 0, c->hs_a, sink.as<uint32_t>(), 64u, mode);     // warm-up
+    HIPCHK(c, hipEventRecord(c->ev[0], c->hs_a));
+    hipLaunchKernelGGL(k_valu_bench, dim3(blocks), dim3(WG), 0, c->hs_a, sink.as<uint32_t>(), iters, mode);
+    HIPCHK(c, hipEventRecord(c->ev[1], c->hs_a)); HIPCHK(c, hipEventSynchronize(c->ev[1]));
     HIPCHK(c, hipEventElapsedTime(ms_out, c->ev[0], c->ev[1]));
     return MBLS_OK;
 }
@@ -518,10 +811,11 @@ extern "C" int mbls_pk_as_bytes(mbls_ctx* c, const uint8_t pk[96], uint8_t out[4
 }
 extern "C" int mbls_pk_key_validate(mbls_ctx* c, const uint8_t pk[96]) {
     if (!c || !pk) return 0;
+    mbls_lock lk(c->mu);
     if (hipSetDevice(c->device) != hipSuccess) return 0;
-    dbuf di, dk; if (di.up(pk, 96) != hipSuccess || dk.alloc(1) != hipSuccess) return 0;
-    hipLaunchKernelGGL(k_g1_key_validate, dim3(1), dim3(WG), 0, 0, di.as<uint8_t>(), (uint64_t)1, dk.as<uint8_t>());
-    uint8_t ok = 0; if (hipDeviceSynchronize() != hipSuccess || dk.down(&ok, 1) != hipSuccess) return 0;
+    sbuf di(c, 0), dk(c, 1); if (di.up(pk, 96) != hipSuccess || dk.alloc(1) != hipSuccess) return 0;
+    hipLaunchKernelGGL(k_g1_key_validate, dim3(1), dim3(WG), 0, c->hs_a, di.as<uint8_t>(), (uint64_t)1, dk.as<uint8_t>());
+    uint8_t ok = 0; if (hipStreamSynchronize(c->hs_a) != hipSuccess || dk.down(&ok, 1) != hipSuccess) return 0;
     return ok;
 }
 extern "C" int mbls_pk_from_secret_key(mbls_ctx* c, const uint8_t* sk, size_t sk_len, uint8_t pk_out[96]) {
@@ -538,45 +832,49 @@ extern "C" int mbls_sig_from_bytes(mbls_ctx* c, const uint8_t* bytes, size_t len
 }
 extern "C" int mbls_sign(mbls_ctx* c, const uint8_t* msg, size_t msg_len, const uint8_t* sk, size_t sk_len, uint8_t sig_out[96]) {
     if (!c || !sig_out) return MBLS_ERR_ARGUMENT;
+    if (msg_len > 0xFFFFFFFFull) return MBLS_ERR_ARGUMENT;
     int e = sk_check(sk, sk_len); if (e) return e;
     return mbls_sign_batch(c, sk, msg, (uint32_t)msg_len, 1, sig_out);
 }
 extern "C" int mbls_verify(mbls_ctx* c, const uint8_t sig[96], const uint8_t* msg, size_t msg_len, const uint8_t pk[96]) {
-    uint8_t r = 0; if (!c || !sig || !pk) return 0;
+    uint8_t r = 0; if (!c || !sig || !pk || msg_len > 0xFFFFFFFFull) return 0;
     if (mbls_verify_batch(c, sig, msg, (uint32_t)msg_len, pk, MBLS_PK_UNCOMPRESSED, 1, &r, nullptr)) return 0;
     return r;
 }
 extern "C" int mbls_aggregate_public_keys(mbls_ctx* c, const uint8_t* pks96, size_t n, uint8_t apk_out[96]) {
     if (!c || !apk_out) return MBLS_ERR_ARGUMENT;
     if (n == 0) return MBLS_ERR_AGGREGATE_EMPTY_POINTS;               // reference src/aggregates.rs:30-32
+    if (n > 0xFFFFFFFFull) return MBLS_ERR_ARGUMENT;
     uint32_t st = 0; int rc = mbls_aggregate_public_keys_batch(c, pks96, MBLS_PK_UNCOMPRESSED, nullptr, 1, (uint32_t)n, apk_out, &st);
     if (rc) return rc;
     return (st & MBLS_ST_BAD_PK_ENCODING) ? MBLS_ERR_INVALID_POINT : MBLS_OK;
 }
 extern "C" int mbls_aggregate_public_key_add(mbls_ctx* c, const uint8_t a[96], const uint8_t b[96], uint8_t out[96]) {
     if (!c || !a || !b || !out) return MBLS_ERR_ARGUMENT;
+    mbls_lock lk(c->mu);
     HIPCHK(c, hipSetDevice(c->device));
-    dbuf da, db, dout, de; HIPCHK(c, da.up(a, 96)); HIPCHK(c, db.up(b, 96)); HIPCHK(c, dout.alloc(96)); HIPCHK(c, de.alloc(1));
-    hipLaunchKernelGGL(k_g1_add, dim3(1), dim3(WG), 0, 0, da.as<uint8_t>(), db.as<uint8_t>(), (uint64_t)1, dout.as<uint8_t>(), de.as<uint8_t>());
-    uint8_t e; HIPCHK(c, hipDeviceSynchronize()); HIPCHK(c, dout.down(out, 96)); HIPCHK(c, de.down(&e, 1));
+    sbuf da(c, 0), db(c, 1), dout(c, 2), de(c, 3); HIPCHK(c, da.up(a, 96)); HIPCHK(c, db.up(b, 96)); HIPCHK(c, dout.alloc(96)); HIPCHK(c, de.alloc(1));
+    hipLaunchKernelGGL(k_g1_add, dim3(1), dim3(WG), 0, c->hs_a, da.as<uint8_t>(), db.as<uint8_t>(), (uint64_t)1, dout.as<uint8_t>(), de.as<uint8_t>());
+    uint8_t e; HIPCHK(c, hipStreamSynchronize(c->hs_a)); HIPCHK(c, dout.down(out, 96)); HIPCHK(c, de.down(&e, 1));
     return map_dec_err_g1(e);
 }
 extern "C" int mbls_aggregate_signature_add(mbls_ctx* c, const uint8_t a[96], const uint8_t b[96], uint8_t out[96]) {
     if (!c || !a || !b || !out) return MBLS_ERR_ARGUMENT;
+    mbls_lock lk(c->mu);
     HIPCHK(c, hipSetDevice(c->device));
-    dbuf da, db, dout, de; HIPCHK(c, da.up(a, 96)); HIPCHK(c, db.up(b, 96)); HIPCHK(c, dout.alloc(96)); HIPCHK(c, de.alloc(1));
-    hipLaunchKernelGGL(k_g2_add, dim3(1), dim3(WG), 0, 0, da.as<uint8_t>(), db.as<uint8_t>(), (uint64_t)1, dout.as<uint8_t>(), de.as<uint8_t>());
-    uint8_t e; HIPCHK(c, hipDeviceSynchronize()); HIPCHK(c, dout.down(out, 96)); HIPCHK(c, de.down(&e, 1));
+    sbuf da(c, 0), db(c, 1), dout(c, 2), de(c, 3); HIPCHK(c, da.up(a, 96)); HIPCHK(c, db.up(b, 96)); HIPCHK(c, dout.alloc(96)); HIPCHK(c, de.alloc(1));
+    hipLaunchKernelGGL(k_g2_add, dim3(1), dim3(WG), 0, c->hs_a, da.as<uint8_t>(), db.as<uint8_t>(), (uint64_t)1, dout.as<uint8_t>(), de.as<uint8_t>());
+    uint8_t e; HIPCHK(c, hipStreamSynchronize(c->hs_a)); HIPCHK(c, dout.down(out, 96)); HIPCHK(c, de.down(&e, 1));
     return map_dec_err_g2(e);
 }
 extern "C" int mbls_fast_aggregate_verify(mbls_ctx* c, const uint8_t sig[96], const uint8_t* msg, size_t msg_len, const uint8_t* pks96, size_t n_pks) {
-    uint8_t r = 0; if (!c || !sig) return 0;
+    uint8_t r = 0; if (!c || !sig || msg_len > 0xFFFFFFFFull || n_pks > 0xFFFFFFFFull) return 0;
     if (n_pks == 0) return 0;                                         // reference src/aggregates.rs:179-181
     if (mbls_fast_aggregate_verify_batch(c, sig, msg, (uint32_t)msg_len, pks96, MBLS_PK_UNCOMPRESSED, nullptr, 1, (uint32_t)n_pks, &r, nullptr)) return 0;
     return r;
 }
 extern "C" int mbls_fast_aggregate_verify_pre_aggregated(mbls_ctx* c, const uint8_t sig[96], const uint8_t* msg, size_t msg_len, const uint8_t apk[96]) {
-    uint8_t r = 0; if (!c || !sig || !apk) return 0;
+    uint8_t r = 0; if (!c || !sig || !apk || msg_len > 0xFFFFFFFFull) return 0;
     // identical checks with a one-key set: sig in G2, key != infinity, pairing (reference src/aggregates.rs:223-253)
     if (mbls_fast_aggregate_verify_batch(c, sig, msg, (uint32_t)msg_len, apk, MBLS_PK_UNCOMPRESSED, nullptr, 1, 1, &r, nullptr)) return 0;
     return r;
@@ -589,76 +887,96 @@ static int npairing_finish(mbls_ctx* c, uint64_t n, hipStream_t s, int* result) 
     hipLaunchKernelGGL(k_miller_single, dim3(nblk(n + 1)), dim3(WG), 0, s, ws, n, 1, (uint64_t)0);
     uint64_t m = n + 1;
     while (m > 1) { uint64_t half = (m + 1) / 2; hipLaunchKernelGGL(k_f12_tree, dim3(nblk(half)), dim3(WG), 0, s, ws, m, half); m = half; }
-    hipLaunchKernelGGL(k_final, dim3(1), dim3(WG), 0, s, ws, c->d_scalar, c->d_results, (uint64_t)1);
-    uint8_t r = 0; uint32_t st = 0;
-    HIPCHK(c, hipStreamSynchronize(s));
+    HIPCHK(c, hipMemsetAsync(c->d_scalar + 8, 0, 4, s));               // status word of the single final exponentiation
+    hipLaunchKernelGGL(k_final, dim3(1), dim3(WG), 0, s, ws, c->d_scalar + 8, c->d_results, (uint64_t)1);
+    uint8_t r = 0;
+    HIPCHK(c, hipStreamSynchronize(s)); c->ws_pending = false;
     HIPCHK(c, hipMemcpy(&r, c->d_results, 1, hipMemcpyDeviceToHost));
-    HIPCHK(c, hipMemcpy(&st, c->d_scalar, 4, hipMemcpyDeviceToHost));
-    *result = r; (void)st; return MBLS_OK;
+    *result = r; return MBLS_OK;
 }
 extern "C" int mbls_aggregate_verify(mbls_ctx* c, const uint8_t sig[96], const uint8_t* msgs, const size_t* msg_lens, size_t n_msgs,
                                      const uint8_t* pks96, size_t n_pks) {
     if (!c || !sig) return 0;
     if (n_msgs != n_pks || n_pks == 0) return 0;                      // reference src/aggregates.rs:132-134
+    if (!msg_lens || !pks96) return 0;
+    mbls_lock lk(c->mu);
     if (hipSetDevice(c->device) != hipSuccess) return 0;
     uint64_t n = n_pks;
     if (mbls_ctx_reserve(c, n)) return 0;
-    size_t total = 0; uint64_t* off = (uint64_t*)malloc(8 * n); uint32_t* lens = (uint32_t*)malloc(4 * n);
-    for (size_t i = 0; i < n; i++) { off[i] = total; lens[i] = (uint32_t)msg_lens[i]; total += msg_lens[i]; }
-    dbuf dm, doff, dl, dp, dsig; int result = 0; bool ok = true;
-    ok = ok && dm.up(msgs, total) == hipSuccess && doff.up(off, 8 * n) == hipSuccess && dl.up(lens, 4 * n) == hipSuccess &&
-         dp.up(pks96, 96 * n) == hipSuccess && dsig.up(sig, 96) == hipSuccess;
-    free(off); free(lens);
-    if (!ok) return 0;
+    std::vector<uint64_t> off; std::vector<uint32_t> lens;
+    try { off.resize(n); lens.resize(n); } catch (...) { return 0; }
+    size_t total = 0;
+    for (size_t i = 0; i < n; i++) {
+        if (msg_lens[i] > 0xFFFFFFFFull) return 0;
+        off[i] = total; lens[i] = (uint32_t)msg_lens[i]; total += msg_lens[i];
+    }
+    if (total && !msgs) return 0;
+    sbuf dm(c, 0), doff(c, 1), dl(c, 2), dp(c, 3), dsig(c, 4); int result = 0;
+    if (dm.up(msgs, total) != hipSuccess || doff.up(off.data(), 8 * n) != hipSuccess || dl.up(lens.data(), 4 * n) != hipSuccess ||
+        dp.up(pks96, 96 * n) != hipSuccess || dsig.up(sig, 96) != hipSuccess) return 0;
     mbls_ws ws; ws.w = c->d_w; ws.stride = c->cap;
-    (void)hipMemsetAsync(c->d_scalar, 0, 64, 0);
-    hipLaunchKernelGGL(k_sig_to_slot, dim3(1), dim3(WG), 0, 0, ws, dsig.as<uint8_t>(), (uint64_t)0, c->d_scalar);
-    hipLaunchKernelGGL(k_blind_pair, dim3(nblk(n)), dim3(WG), 0, 0, ws, dp.as<uint8_t>(), (const uint8_t*)nullptr, (const uint64_t*)nullptr, c->d_status, n);
-    hipLaunchKernelGGL(k_status_or, dim3(nblk(n)), dim3(WG), 0, 0, c->d_status, n, c->d_scalar);
-    hipLaunchKernelGGL(k_hash, dim3(nblk(n)), dim3(WG), 0, 0, ws, dm.as<uint8_t>(), 0u, doff.as<uint64_t>(), dl.as<uint32_t>(), n);
+    hipStream_t s = c->hs_a;
+    if (ws_acquire(c, s)) return 0;
+    (void)hipMemsetAsync(c->d_scalar, 0, 64, s);
+    (void)hipMemsetAsync(c->d_status, 0, 4 * n, s);
+    hipLaunchKernelGGL(k_sig_to_slot, dim3(1), dim3(WG), 0, s, ws, dsig.as<uint8_t>(), (uint64_t)0, c->d_scalar);
+    hipLaunchKernelGGL(k_blind_g1, dim3(nblk(n)), dim3(WG), 0, s, ws, dp.as<uint8_t>(), (const uint64_t*)nullptr, c->d_status, n);   // r_i = 1: no blinding in AggregateVerify
+    hipLaunchKernelGGL(k_status_or, dim3(nblk(n)), dim3(WG), 0, s, c->d_status, n, c->d_scalar);
+    hipLaunchKernelGGL(k_hash, dim3(nblk(n)), dim3(WG), 0, s, ws, dm.as<uint8_t>(), 0u, doff.as<uint64_t>(), dl.as<uint32_t>(), n);
     uint32_t st = 0;
-    if (hipMemcpy(&st, c->d_scalar, 4, hipMemcpyDeviceToHost) != hipSuccess) return 0;
-    if (st & (MBLS_ST_BAD_SIG_ENCODING | MBLS_ST_SIG_NOT_IN_G2 | MBLS_ST_BAD_PK_ENCODING)) return 0;   // reference src/aggregates.rs:137-139
-    (void)hipMemsetAsync(c->d_scalar, 0, 64, 0);
-    if (npairing_finish(c, n, 0, &result)) return 0;
+    if (hipStreamSynchronize(s) != hipSuccess || hipMemcpy(&st, c->d_scalar, 4, hipMemcpyDeviceToHost) != hipSuccess) return 0;
+    if (st & (MBLS_ST_BAD_SIG_ENCODING | MBLS_ST_SIG_NOT_IN_G2 | MBLS_ST_BAD_PK_ENCODING)) { c->ws_pending = false; return 0; }   // reference src/aggregates.rs:137-139
+    if (npairing_finish(c, n, s, &result)) return 0;
     return result;
 }
 static int verify_multiple_impl(mbls_ctx* c, const uint8_t* d_sigs, const uint8_t* d_apks, const uint8_t* d_pks, int pk_format,
         const uint32_t* d_pk_offsets, uint32_t k, const uint8_t* d_msgs, uint32_t msg_len, const uint64_t* d_rands, uint64_t n, int* result, void* stream) {
     if (!c || !result) return MBLS_ERR_ARGUMENT;
+    mbls_lock lk(c->mu);
+    *result = 0;
+    if (n == 0) { *result = 1; return MBLS_OK; }     // empty iterator: S' = infinity, product of no pairings = 1 -> e(inf, -G1) = 1 -> true
+    if (!d_rands) ARGFAIL(c, "verify_multiple without blinding scalars is forgeable: rands must not be NULL");
+    if (!d_sigs || (!d_msgs && msg_len)) ARGFAIL(c, "null buffer");
     hipStream_t s = (hipStream_t)stream;
     HIPCHK(c, hipSetDevice(c->device));
-    int rc = mbls_ctx_reserve(c, n ? n : 1); if (rc) return rc;
+    int rc = mbls_ctx_reserve(c, n); if (rc) return rc;
     mbls_ws ws; ws.w = c->d_w; ws.stride = c->cap;
+    rc = ws_acquire(c, s); if (rc) return rc;
     HIPCHK(c, hipMemsetAsync(c->d_scalar, 0, 64, s));
-    if (n) {
-        if (!d_apks) {  // sets given by their wire-format keys: AggregatePublicKey::aggregate on the device first (src/aggregates.rs:29-39)
-            HIPCHK(c, hipMemsetAsync(c->d_status, 0, 4 * n, s));
-            hipLaunchKernelGGL(k_aggregate, dim3(nblk(n)), dim3(WG), 0, s, ws, d_pks, d_pk_offsets, k, pk_format, MBLS_MODE_VERIFY, c->d_status, n);
-        }
-        hipLaunchKernelGGL(k_blind_pair, dim3(nblk(n)), dim3(WG), 0, s, ws, d_apks, d_sigs, d_rands, c->d_status, n);
-        hipLaunchKernelGGL(k_status_or, dim3(nblk(n)), dim3(WG), 0, s, c->d_status, n, c->d_scalar);
-        hipLaunchKernelGGL(k_hash, dim3(nblk(n)), dim3(WG), 0, s, ws, d_msgs, msg_len, (const uint64_t*)nullptr, (const uint32_t*)nullptr, n);
-        uint64_t m = n;
-        while (m > 1) { uint64_t half = (m + 1) / 2; hipLaunchKernelGGL(k_g2_tree, dim3(nblk(half)), dim3(WG), 0, s, ws, m, half); m = half; }
-    } else {
-        // empty iterator: S' = infinity, product of no pairings = 1 -> e(inf, -G1) = 1 -> true (mathematical convention)
-        *result = 1; return MBLS_OK;
+    HIPCHK(c, hipMemsetAsync(c->d_status, 0, 4 * n, s));
+    // Three independent chains: keys (aggregate, [r]apk), signatures (decode, subgroup check, [r]sig, sum), messages (hash). Below
+    // 2^14 sets each of them leaves most SIMDs idle, so they run side by side on the context's streams and join before the
+    // Miller loops; larger batches fill the chip by themselves and stay on the caller's stream.
+    const bool fork = n <= 16384;
+    hipStream_t s_sig = fork ? c->hs_b : s, s_msg = fork ? c->hs_c : s;
+    if (fork) { HIPCHK(c, hipEventRecord(c->hs_ev, s)); HIPCHK(c, hipStreamWaitEvent(s_sig, c->hs_ev, 0)); HIPCHK(c, hipStreamWaitEvent(s_msg, c->hs_ev, 0)); }
+    if (!d_apks)    // sets given by their wire-format keys: AggregatePublicKey::aggregate on the device first (src/aggregates.rs:29-39)
+        hipLaunchKernelGGL(k_aggregate, dim3(nblk(n)), dim3(WG), 0, s, ws, d_pks, d_pk_offsets, k, pk_format, MBLS_MODE_VERIFY, c->d_status, n);
+    hipLaunchKernelGGL(k_blind_g1, dim3(nblk(n)), dim3(WG), 0, s, ws, d_apks, d_rands, c->d_status, n);
+    hipLaunchKernelGGL(k_blind_sig, dim3(nblk(n)), dim3(WG), 0, s_sig, ws, d_sigs, d_rands, c->d_status, n);
+    { uint64_t m = n; while (m > 1) { uint64_t half = (m + 1) / 2; hipLaunchKernelGGL(k_g2_tree, dim3(nblk(half)), dim3(WG), 0, s_sig, ws, m, half); m = half; } }
+    hipLaunchKernelGGL(k_hash, dim3(nblk(n)), dim3(WG), 0, s_msg, ws, d_msgs, msg_len, (const uint64_t*)nullptr, (const uint32_t*)nullptr, n);
+    if (fork) {
+        HIPCHK(c, hipEventRecord(c->hs_ev2, s_sig)); HIPCHK(c, hipEventRecord(c->hs_ev3, s_msg));
+        HIPCHK(c, hipStreamWaitEvent(s, c->hs_ev2, 0)); HIPCHK(c, hipStreamWaitEvent(s, c->hs_ev3, 0));
     }
+    hipLaunchKernelGGL(k_status_or, dim3(nblk(n)), dim3(WG), 0, s, c->d_status, n, c->d_scalar);
     uint32_t st = 0;
     HIPCHK(c, hipStreamSynchronize(s));
     HIPCHK(c, hipMemcpy(&st, c->d_scalar, 4, hipMemcpyDeviceToHost));
-    if (st & (MBLS_ST_BAD_SIG_ENCODING | MBLS_ST_SIG_NOT_IN_G2 | MBLS_ST_BAD_PK_ENCODING)) { *result = 0; return MBLS_OK; }   // reference src/aggregates.rs:274-276
-    HIPCHK(c, hipMemsetAsync(c->d_scalar, 0, 64, s));
+    if (st & MBLS_ST_BAD_SCALAR) { c->ws_pending = false; ARGFAIL(c, "a blinding scalar is zero"); }
+    if (st & (MBLS_ST_BAD_SIG_ENCODING | MBLS_ST_SIG_NOT_IN_G2 | MBLS_ST_BAD_PK_ENCODING)) { c->ws_pending = false; *result = 0; return MBLS_OK; }   // reference src/aggregates.rs:274-276
     return npairing_finish(c, n, s, result);
 }
 extern "C" int mbls_verify_multiple_aggregate_signatures_device(mbls_ctx* c, const uint8_t* d_sigs, const uint8_t* d_apks, const uint8_t* d_msgs,
         uint32_t msg_len, const uint64_t* d_rands, uint64_t n, int* result, void* stream) {
+    if (!c) return MBLS_ERR_ARGUMENT;
     if (n && !d_apks) return MBLS_ERR_ARGUMENT;
     return verify_multiple_impl(c, d_sigs, d_apks, nullptr, 0, nullptr, 0, d_msgs, msg_len, d_rands, n, result, stream);
 }
 extern "C" int mbls_verify_multiple_sets_device(mbls_ctx* c, const uint8_t* d_sigs, const uint8_t* d_pks, int pk_format, const uint32_t* d_pk_offsets,
         uint32_t k, const uint8_t* d_msgs, uint32_t msg_len, const uint64_t* d_rands, uint64_t n, int* result, void* stream) {
+    if (!c) return MBLS_ERR_ARGUMENT;
     if (pk_format != MBLS_PK_COMPRESSED && pk_format != MBLS_PK_UNCOMPRESSED) return MBLS_ERR_ARGUMENT;
     if (n && !d_pks) return MBLS_ERR_ARGUMENT;
     return verify_multiple_impl(c, d_sigs, nullptr, d_pks, pk_format, d_pk_offsets, k, d_msgs, msg_len, d_rands, n, result, stream);
@@ -668,11 +986,12 @@ extern "C" int mbls_verify_multiple_aggregate_signatures(mbls_ctx* c, const uint
     if (!c) return 0;
     if (n == 0) return 1;
     if (!sigs96 || !apks96 || !rands || (!msgs && msg_len)) return 0;
+    mbls_lock lk(c->mu);
     if (hipSetDevice(c->device) != hipSuccess) return 0;
-    dbuf ds, da, dm, dr;
+    sbuf ds(c, 0), da(c, 1), dm(c, 2), dr(c, 3);
     if (ds.up(sigs96, 96 * n) != hipSuccess || da.up(apks96, 96 * n) != hipSuccess || dm.up(msgs, (size_t)msg_len * n) != hipSuccess ||
         dr.up(rands, 8 * n) != hipSuccess) return 0;
     int result = 0;
-    if (mbls_verify_multiple_aggregate_signatures_device(c, ds.as<uint8_t>(), da.as<uint8_t>(), dm.as<uint8_t>(), msg_len, dr.as<uint64_t>(), n, &result, nullptr)) return 0;
+    if (mbls_verify_multiple_aggregate_signatures_device(c, ds.as<uint8_t>(), da.as<uint8_t>(), dm.as<uint8_t>(), msg_len, dr.as<uint64_t>(), n, &result, c->hs_a)) return 0;
     return result;
 }

@@ -115,6 +115,43 @@ MBLS_FN void lane_aggregate_decoded(const mbls_ws& ws, uint64_t i, const uint32_
     ws_st(ws, MBLS_SLOT_APK, i, acc.x); ws_st(ws, MBLS_SLOT_APK + 1, i, acc.y); ws_st(ws, MBLS_SLOT_APK + 2, i, acc.z);
     *status = st;
 }
+// Resident key table: one 128-byte record per key = affine Montgomery x (12 dwords), y (12 dwords), flags, 7 dwords of padding
+// (a record is one aligned cache line, fetched with six 16-byte loads + one dword). This is what a decoded PublicKey holds in
+// memory in the reference (src/keys.rs:116-120): no byte decoding, Montgomery conversion or on-curve check per use.
+#define MBLS_KEYREC_DWORDS 32
+MBLS_FN void keyrec_load(fp* x, fp* y, uint32_t* flags, const uint32_t* recs, uint64_t tsize, uint32_t id) {
+    bool oob = id >= tsize;                                   // an index outside the table counts as an undecodable key
+    const uint32_t* q = (const uint32_t*)__builtin_assume_aligned(recs + (uint64_t)MBLS_KEYREC_DWORDS * (oob ? 0 : id), 16);
+    fp a, b;
+#pragma unroll
+    for (int t = 0; t < 12; t++) { a[t] = q[t]; b[t] = q[12 + t]; }
+    uint32_t f = q[24];
+    *x = a; *y = b; *flags = oob ? (MBLS_KEYFLAG_BAD | MBLS_KEYFLAG_INF) : f;
+}
+MBLS_FN void lane_aggregate_indexed(const mbls_ws& ws, uint64_t i, const uint32_t* recs, uint64_t tsize, const uint32_t* idx, uint32_t k, int mode, uint32_t* status) {
+    uint32_t st = 0;
+    g1j acc; g1_set_inf(&acc);
+    // two-deep software pipeline (index two keys ahead, record one key ahead): one wave per SIMD has nothing else to hide the
+    // gather latency behind
+    fp nx = fp_zero(), ny = fp_zero(); uint32_t nf = 0;
+    uint32_t id1 = k > 1 ? idx[1] : 0;
+    if (k) keyrec_load(&nx, &ny, &nf, recs, tsize, idx[0]);
+    for (uint32_t j = 0; j < k; j++) {
+        fp x = nx, y = ny; uint32_t f = nf;
+        uint32_t id2 = (j + 2 < k) ? idx[j + 2] : 0;
+        if (j + 1 < k) keyrec_load(&nx, &ny, &nf, recs, tsize, id1);
+        id1 = id2;
+        if (f & MBLS_KEYFLAG_BAD) st |= MBLS_ST_BAD_PK_ENCODING;
+        if (f & MBLS_KEYFLAG_INF) st |= MBLS_ST_PK_INFINITY;
+        g1_madd_inl(&acc, &acc, x, y, (f & MBLS_KEYFLAG_INF) != 0);
+    }
+    if (mode == MBLS_MODE_FAST_AGGREGATE) {
+        if (k == 0) st |= MBLS_ST_NO_KEYS;
+        if (g1_is_inf(&acc)) st |= MBLS_ST_APK_INFINITY;
+    }
+    ws_st(ws, MBLS_SLOT_APK, i, acc.x); ws_st(ws, MBLS_SLOT_APK + 1, i, acc.y); ws_st(ws, MBLS_SLOT_APK + 2, i, acc.z);
+    *status = st;
+}
 MBLS_FN void lane_sig(const mbls_ws& ws, uint64_t i, const uint8_t* sig96, uint32_t* status) {
     fp2 x, y; bool inf; uint32_t st = 0;
     int e = g2_decode_compressed(&x, &y, &inf, sig96);

@@ -39,6 +39,57 @@ MBLS_FN void op_g2_check(uint64_t i, const uint8_t* in96, uint8_t* err, uint8_t*
         in_g2[i] = (!e && g2_in_subgroup(&p)) ? 1 : 0;
     }
 }
+// key table record from wire bytes: the decode of op_g1_decode, stored as affine Montgomery limbs (mbls_lanes.h, keyrec_load)
+MBLS_FN void op_keytable_append(uint64_t i, const uint8_t* in, int fmt, int validate, uint32_t* recs, uint8_t* errs) {
+    fp x, y; bool inf;
+    int e = (fmt == MBLS_PK_COMPRESSED) ? g1_decode_compressed(&x, &y, &inf, in + 48 * i) : g1_decode_uncompressed(&x, &y, &inf, in + 96 * i);
+    if (!e && validate) {
+        g1j p; p.x = x; p.y = y; p.z = fp_one();
+        if (inf) e = MBLS_DEC_POINT;
+        else if (!g1_in_subgroup(&p)) e = MBLS_DEC_POINT;
+    }
+    uint32_t* o = recs + MBLS_KEYREC_DWORDS * i;
+    if (e) { x = fp_zero(); y = fp_zero(); }
+#pragma unroll
+    for (int t = 0; t < 12; t++) { o[t] = x[t]; o[12 + t] = y[t]; }
+    o[24] = (e ? (MBLS_KEYFLAG_BAD | MBLS_KEYFLAG_INF) : 0u) | (inf ? MBLS_KEYFLAG_INF : 0u);
+    for (int t = 25; t < MBLS_KEYREC_DWORDS; t++) o[t] = 0;
+    errs[i] = (uint8_t)e;
+}
+// PublicKey::as_uncompressed_bytes of table entries (src/keys.rs:163-165); err = InvalidPoint for an entry that failed to decode
+MBLS_FN void op_keytable_export(uint64_t i, const uint32_t* recs, uint8_t* out96, uint8_t* errs) {
+    fp x, y; uint32_t f; keyrec_load(&x, &y, &f, recs, ~(uint64_t)0, (uint32_t)i);
+    if (f & MBLS_KEYFLAG_BAD) { for (int j = 0; j < 96; j++) out96[96 * i + j] = 0; errs[i] = MBLS_DEC_POINT; return; }
+    g1_encode_uncompressed(out96 + 96 * i, x, y, (f & MBLS_KEYFLAG_INF) != 0);
+    errs[i] = MBLS_DEC_OK;
+}
+// Signature::from_bytes into affine Montgomery limbs (48 dwords: x.c0, x.c1, y.c0, y.c1) + flag byte (decode error code | 0x80 = infinity)
+MBLS_FN void op_g2_decode_affine(uint64_t i, const uint8_t* sigs96, uint32_t* xy, uint8_t* flags) {
+    fp2 x, y; bool inf; int e = g2_decode_compressed(&x, &y, &inf, sigs96 + 96 * i);
+    uint32_t* o = xy + 48 * i;
+#pragma unroll
+    for (int t = 0; t < 12; t++) { o[t] = x.c0[t]; o[12 + t] = x.c1[t]; o[24 + t] = y.c0[t]; o[36 + t] = y.c1[t]; }
+    flags[i] = (uint8_t)(e | ((inf || e) ? 0x80 : 0));
+}
+MBLS_FN void g2_encode_jacobian(uint8_t* out96, const g2j* p);
+// AggregateSignature::aggregate (src/aggregates.rs:100-106): sum of k decoded signatures starting from infinity
+MBLS_FN void op_g2_sum(uint64_t i, const uint32_t* xy, const uint8_t* flags, uint32_t k, uint8_t* out96, uint8_t* errs) {
+    g2j acc; g2_set_inf(&acc); int e = 0;
+    for (uint32_t j = 0; j < k; j++) {
+        const uint32_t* o = xy + 48 * (uint64_t)j;
+        g2j q;
+#pragma unroll
+        for (int t = 0; t < 12; t++) { q.x.c0[t] = o[t]; q.x.c1[t] = o[12 + t]; q.y.c0[t] = o[24 + t]; q.y.c1[t] = o[36 + t]; }
+        q.z = fp2_one();
+        uint32_t f = flags[j];
+        if ((f & 0x7F) && !e) e = (int)(f & 0x7F);
+        if (f & 0x80) g2_set_inf(&q);
+        g2_add(&acc, &acc, &q);
+    }
+    if (e) { for (int j = 0; j < 96; j++) out96[96 * i + j] = 0; }
+    else g2_encode_jacobian(out96 + 96 * i, &acc);
+    errs[i] = (uint8_t)e;
+}
 MBLS_FN void g2_encode_jacobian(uint8_t* out96, const g2j* p) {
     fp2 x, y; bool inf; g2_to_affine(&x, &y, &inf, p); g2_encode_compressed(out96, x, y, inf);
 }

@@ -3,6 +3,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <random>
+#include <thread>
 #include "milagro_bls.hpp"
 using namespace milagro_bls;
 static int fails = 0;
@@ -68,6 +69,21 @@ int main() {
       CHECK(AggregateSignature::verify_multiple_aggregate_signatures(rng, sets));
       AggregateSignature wrong; wrong.add(Signature::new_(Bytes(32, 1), kps[3].sk)); std::get<0>(sets[1]) = &wrong;
       CHECK(!AggregateSignature::verify_multiple_aggregate_signatures(rng, sets)); }
+    // src/aggregates.rs:100-106 AggregateSignature::aggregate (one batched launch) == repeated add; src/keys.rs:36-77 key generation
+    { std::vector<Signature> ss; std::vector<const Signature*> ps; for (auto& kp : kps) ss.push_back(Signature::new_(msg, kp.sk)); for (auto& x : ss) ps.push_back(&x);
+      CHECK(AggregateSignature::aggregate(ps) == agg); CHECK(AggregateSignature::aggregate({}) == AggregateSignature()); }
+    { Bytes ikm(32); for (int i = 0; i < 32; i++) ikm[i] = uint8_t(i);
+      SecretKey g = SecretKey::key_generate(ikm);
+      CHECK(g.as_bytes() == hex("23360db7e337b0a32b264e06bc11c1b474d16f55665373de1ce93cf15ddb3456"));       // = hashlib/hmac restatement (tests/test_cpp_api.py)
+      CHECK(err_of([] { SecretKey::key_generate(Bytes(31, 1)); }) == AmclError::InvalidSecretKeySize);
+      Keypair kp = Keypair::random([&] { return uint8_t(gen()); });
+      Bytes m2 = str("keygen"); CHECK(Signature::new_(m2, kp.sk).verify(m2, kp.pk)); }
+    // one context shared by threads (every ABI entry takes its lock): concurrent verifications keep their own answers
+    { std::vector<std::thread> th; std::vector<int> bad(4, 0);
+      for (int t = 0; t < 4; t++) th.emplace_back([&, t] { for (int r = 0; r < 3; r++) { Bytes m(32, uint8_t(40 + t)); Signature s = Signature::new_(m, kps[t].sk);
+          if (!s.verify(m, kps[t].pk) || s.verify(m, kps[(t + 1) % 4].pk)) bad[t]++; } });
+      for (auto& x : th) x.join();
+      for (int b : bad) CHECK(b == 0); }
     std::printf(fails ? "%d checks failed\n" : "all C++ API checks passed\n", fails);
     return fails ? 1 : 0;
 }

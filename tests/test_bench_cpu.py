@@ -1,0 +1,82 @@
+"""CPU test of bench.py's multi-rank plumbing (world > 1) under gloo with a stub verifier: the timed region (warm-up, barrier +
+sync fences, K steps), the per-step all-gather of the bitmap, the MAX-reduce of the elapsed time and the MIN-reduce of the
+correctness flag -- so that the first real multi-GPU run cannot fail on anything but the GPU work itself."""
+import os
+import socket
+import time
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import helpers
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, q, fail_rank):
+    import sys
+    sys.path.insert(0, helpers.ROOT)
+    import bench
+    from milagro_bls_amd import shard
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    n = 1000                                                       # not a multiple of 64: the last bitmap word is partial
+    words = shard.bitmap_words(n)
+    expect = torch.ones(n, dtype=torch.uint8); expect[7::16] = 0
+    res = expect.clone()
+    if rank == fail_rank:
+        res[123] ^= 1                                              # this rank's verifier disagrees with the expectation
+    bm = shard.pack_bits(res)
+    d_all = torch.zeros(words * world, dtype=torch.int64)
+    calls = []
+
+    def step():                                                    # stub of the per-step work: "verify", then the gather
+        time.sleep(0.01 * (rank + 1))                              # ranks take different times: the MAX must come back
+        calls.append(1)
+        shard.all_gather_bitmap(bm, world, out=d_all)
+    elapsed = bench.timed_steps(step, steps=3, warmup=2, world=world, sync=lambda: None)
+    ok = bench.check_bitmap(res, bm, expect) and bench.check_gathered(d_all, world, words, bm, rank)
+    ok_all = bench.reduce_all_ok(ok, world)
+    q.put((rank, len(calls), elapsed, ok, ok_all, [int(x) for x in d_all[:2]], [int(x) for x in d_all[words:words + 2]]))
+    dist.barrier(); dist.destroy_process_group()
+
+
+def _run(fail_rank):
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, fail_rank)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = sorted(q.get(timeout=300) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    return out
+
+
+def test_timed_region_and_reductions_two_ranks():
+    r0, r1 = _run(fail_rank=-1)
+    assert r0[1] == r1[1] == 5                                     # 2 warm-up + 3 timed steps on every rank
+    assert r0[2] == r1[2] and r0[2] >= 3 * 0.02 * 0.9              # MAX over ranks: the slower rank's time, identical everywhere
+    assert r0[3] and r1[3] and r0[4] and r1[4]
+    assert r0[5] == r1[5] and r0[6] == r1[6]                       # every rank holds the whole gathered bitmap
+
+
+def test_one_bad_rank_fails_the_whole_job():
+    r0, r1 = _run(fail_rank=1)
+    assert r0[3] is True and r1[3] is False
+    assert r0[4] is False and r1[4] is False                       # MIN-reduce: rank 0 prints ok = false, every rank exits 3
+
+
+def test_single_rank_paths_need_no_process_group():
+    import sys
+    sys.path.insert(0, helpers.ROOT)
+    import bench
+    n = []
+    assert bench.timed_steps(lambda: n.append(1), 4, 1, 1, lambda: None) >= 0 and len(n) == 5
+    assert bench.reduce_max(1.5, 1) == 1.5 and bench.reduce_all_ok(True, 1) is True

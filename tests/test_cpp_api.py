@@ -16,7 +16,7 @@ def build_exe():
     lib = build.build()
     libdir = os.path.dirname(lib)
     cmd = ["g++", "-std=c++17", "-O1", "-I", os.path.join(helpers.ROOT, "include"), SRC, "-o", EXE, "-L", libdir, "-lmbls_hip",
-           "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"]
+           "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib", "-pthread"]
     subprocess.check_call(cmd)
     return EXE
 
@@ -24,6 +24,30 @@ def build_exe():
 def test_cpp_mirror_compiles_and_links():
     exe = build_exe()
     assert os.path.exists(exe)
+
+
+def test_cpp_key_generate_matches_hkdf_restatement():
+    """SecretKey::key_generate of include/milagro_bls.hpp (host-only C++: SHA-256, HMAC, HKDF, mod r) against the Python mirror,
+    which uses hashlib/hmac (reference src/keys.rs:45-77). No GPU involved."""
+    import random
+    from milagro_bls_amd.api import SecretKey, AmclError
+    libdir = os.path.join(helpers.ROOT, "milagro_bls_amd")
+    exe = os.path.join(helpers.ROOT, "tests", "cpp", "test_keygen")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-I", os.path.join(helpers.ROOT, "include"), os.path.join(helpers.ROOT, "tests", "cpp", "test_keygen.cpp"),
+                           "-o", exe, "-L", libdir, "-lmbls_hip", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
+    rnd = random.Random(5)
+    cases = [(bytes(range(32)), b""), (bytes(32), b""), (rnd.randbytes(32), b"info"), (rnd.randbytes(48), rnd.randbytes(7)), (rnd.randbytes(100), b"")]
+    args = []
+    for ikm, info in cases:
+        args += [ikm.hex(), info.hex() or "-"]
+    out = subprocess.run([exe] + args + ["00" * 31, "-"], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    lines = out.stdout.split("\n")
+    for (ikm, info), line in zip(cases, lines):
+        assert line == SecretKey.key_generate(ikm, info).as_bytes().hex()
+    assert lines[len(cases)] == "AmclError 5"                       # ikm shorter than 32 bytes: InvalidSecretKeySize
+    with pytest.raises(AmclError):
+        SecretKey.key_generate(bytes(31))
 
 
 @pytest.mark.gpu

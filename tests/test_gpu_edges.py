@@ -1,0 +1,412 @@
+"""GPU parity, second layer: the edge cases the reference's checks admit but its tests never feed (infinity keys in
+Signature::verify, infinity / undecodable members in verify_multiple and aggregate_verify), KeyValidate on garbage, the
+resident key table against the byte-format path, batched signature aggregation, context sharing between threads, argument
+validation of the C ABI, the config-5 shard size, and a seeded randomised sweep. Everything goes through the C ABI and is
+compared with the oracle bit for bit."""
+import ctypes as C
+import random
+import threading
+
+import numpy as np
+import pytest
+
+import helpers
+import orc
+
+pytestmark = pytest.mark.gpu
+
+G1_INF_C = bytes([0xC0]) + bytes(47)
+G1_INF_U = bytes([0x40]) + bytes(95)
+
+
+@pytest.fixture(scope="module")
+def mb():
+    from milagro_bls_amd import batch, _native
+    _native.default_context()
+    return batch
+
+
+@pytest.fixture(scope="module")
+def N():
+    from milagro_bls_amd import _native
+    return _native
+
+
+def _keys(rnd, n):
+    sks = [rnd.randrange(1, helpers.R) for _ in range(n)]
+    pk96 = orc.batch_sk_to_pk(b"".join(s.to_bytes(32, "big") for s in sks), n, 1, nthreads=8)
+    return sks, [pk96[96 * i:96 * i + 96] for i in range(n)]
+
+
+# ------------------------------------------------------------------------------------------------ Signature::verify, pk = infinity
+def test_verify_batch_with_infinite_public_keys(mb):
+    """reference src/signature.rs:27-40 has no infinity check on the key: (sig, msg, pk = infinity) reaches the pairing, where an
+    infinite argument contributes 1, so the item verifies iff e(sig, -G1) = 1 iff sig = infinity (and sig must be in G2)."""
+    rnd = random.Random(11)
+    sks, pks = _keys(rnd, 4)
+    msgs = [rnd.randbytes(32) for _ in range(8)]
+    sig = lambda i, m: orc.g2_compress(orc.sign(m, sks[i]))
+    items = [   # (sig, msg, pk96)
+        (sig(0, msgs[0]), msgs[0], pks[0]),              # valid
+        (sig(0, msgs[1]), msgs[1], G1_INF_U),            # real signature, infinite key -> false
+        (helpers.G2_INF, msgs[2], G1_INF_U),             # infinite signature, infinite key -> true (both pairings are 1)
+        (helpers.G2_INF, msgs[3], pks[1]),               # infinite signature, real key -> false
+        (sig(1, msgs[4]), msgs[4], pks[1]),              # valid
+        (sig(2, msgs[5]), msgs[5], pks[3]),              # wrong key
+    ]
+    want = [orc.verify(orc.g2_from_compressed(s)[1], m, p) for s, m, p in items]
+    assert want == [True, False, True, False, True, False]
+    n = len(items)
+    sigs = b"".join(i[0] for i in items); ms = b"".join(i[1] for i in items)
+    got_u, _ = mb.verify_batch(sigs, ms, b"".join(i[2] for i in items), n, pk_format=1)
+    got_c, _ = mb.verify_batch(sigs, ms, b"".join(orc.g1_compress(i[2]) for i in items), n, pk_format=0)
+    assert got_u == want and got_c == want
+    # the same items through fast_aggregate_verify (one-key sets): there the infinite key IS rejected (src/aggregates.rs:196-198)
+    got_f, st = mb.fast_aggregate_verify_batch(sigs, ms, b"".join(i[2] for i in items), n, 1, pk_format=1)
+    want_f = [orc.fast_aggregate_verify(orc.g2_from_compressed(s)[1], m, [p]) for s, m, p in items]
+    assert got_f == want_f == [True, False, False, False, True, False] and st[2] & 0x08
+
+
+# ------------------------------------------------------------------------------------------------ verify_multiple / aggregate_verify edges
+def _vm_sets(rnd, n):
+    sks, pks = _keys(rnd, n)
+    msgs = [rnd.randbytes(32) for _ in range(n)]
+    sigs = [orc.g2_compress(orc.sign(m, s)) for m, s in zip(msgs, sks)]
+    rands = [rnd.randrange(1, 1 << 63) for _ in range(n)]
+    return sks, pks, msgs, sigs, rands
+
+
+def _vm_gpu(N, sigs, apks, msgs, rands):
+    ctx = N.default_context()
+    n = len(sigs)
+    rr = (C.c_uint64 * max(1, n))(*rands)
+    return bool(N.lib().mbls_verify_multiple_aggregate_signatures(ctx.handle, N.cbuf(b"".join(sigs)), N.cbuf(b"".join(apks)), N.cbuf(b"".join(msgs)),
+                                                                 32, rr, n))
+
+
+def _vm_orc(sigs, apks, msgs, rands):
+    dec = [orc.g2_from_compressed(s) for s in sigs]
+    if any(e for e, _ in dec):
+        return None
+    return orc.verify_multiple([(d[1], a, m) for d, a, m in zip(dec, apks, msgs)], rands)
+
+
+def test_verify_multiple_edge_members_vs_oracle(N, vectors):
+    """reference src/aggregates.rs:261-316 with members its tests never contain: an infinite signature, an infinite
+    aggregate key, both at once in one set, a signature outside G2, a wrong key -- against the oracle with the same scalars."""
+    rnd = random.Random(12)
+    sks, pks, msgs, sigs, rands = _vm_sets(rnd, 7)
+    base = (list(sigs), list(pks), list(msgs))
+    assert _vm_gpu(N, *base, rands) is True and _vm_orc(*base, rands) is True
+
+    def variant(f):
+        s, a, m = list(sigs), list(pks), list(msgs)
+        f(s, a, m)
+        got, want = _vm_gpu(N, s, a, m, rands), _vm_orc(s, a, m, rands)
+        assert got == want, (got, want)
+        return got
+    assert variant(lambda s, a, m: s.__setitem__(2, helpers.G2_INF)) is False                    # a set loses its signature
+    assert variant(lambda s, a, m: a.__setitem__(3, G1_INF_U)) is False                          # a set loses its key
+    assert variant(lambda s, a, m: (s.__setitem__(4, helpers.G2_INF), a.__setitem__(4, G1_INF_U))) is True   # the set contributes 1 on both sides
+    assert variant(lambda s, a, m: a.__setitem__(1, pks[0])) is False
+    probe = bytes.fromhex(vectors["model"]["g2_subgroup_probes"][0]["compressed"])
+    assert variant(lambda s, a, m: s.__setitem__(6, probe)) is False                              # src/aggregates.rs:274-276
+    # all sets infinite on both sides: the product of no pairings is 1
+    assert _vm_gpu(N, [helpers.G2_INF] * 3, [G1_INF_U] * 3, msgs[:3], rands[:3]) is True
+    assert _vm_orc([helpers.G2_INF] * 3, [G1_INF_U] * 3, msgs[:3], rands[:3]) is True
+    # a member whose bytes do not decode: a reference caller could not have built the object; the ABI answers false
+    bad_sig = bytes([sigs[0][0] & 0x7F]) + sigs[0][1:]
+    assert _vm_gpu(N, [bad_sig] + sigs[1:], pks, msgs, rands) is False
+    bad_pk = bytes(48) + bytes([1]) + bytes(47)        # (0, 2^376): not on the curve
+    assert _vm_gpu(N, sigs, [bad_pk] + pks[1:], msgs, rands) is False
+
+
+def test_verify_multiple_scalar_requirements(N):
+    """The blinding scalars are the security of the batch check: NULL is refused and a zero scalar fails the call (the reference
+    draws until nonzero, src/aggregates.rs:280-287)."""
+    import torch
+    rnd = random.Random(13)
+    sks, pks, msgs, sigs, rands = _vm_sets(rnd, 3)
+    ctx = N.default_context()
+    dev = torch.device("cuda:0")
+    t = lambda b: torch.frombuffer(bytearray(b), dtype=torch.uint8).to(dev)
+    d_s, d_a, d_m = t(b"".join(sigs)), t(b"".join(pks)), t(b"".join(msgs))
+    res = C.c_int(7)
+    rc = N.lib().mbls_verify_multiple_aggregate_signatures_device(ctx.handle, d_s.data_ptr(), d_a.data_ptr(), d_m.data_ptr(), 32, None, 3, C.byref(res), None)
+    assert rc == N.ERR_ARGUMENT and res.value == 0
+    d_r = torch.tensor([rands[0], 0, rands[2]], dtype=torch.int64, device=dev)
+    rc = N.lib().mbls_verify_multiple_aggregate_signatures_device(ctx.handle, d_s.data_ptr(), d_a.data_ptr(), d_m.data_ptr(), 32, d_r.data_ptr(), 3, C.byref(res), None)
+    assert rc == N.ERR_ARGUMENT and res.value == 0
+    # forged pair (sig1 + D, sig2 - D): passes an unblinded check, must fail the blinded one
+    D = orc.sign(b"d" * 32, 12345)
+    f1 = orc.g2_compress(orc.g2_add(orc.g2_from_compressed(sigs[0])[1], D))
+    f2 = orc.g2_compress(orc.g2_add(orc.g2_from_compressed(sigs[1])[1], orc.g2_mul(D, helpers.R - 1)))
+    assert _vm_gpu(N, [f1, f2, sigs[2]], pks, msgs, rands) is False
+    assert _vm_gpu(N, sigs, pks, msgs, rands) is True
+    assert _vm_gpu(N, sigs, pks, msgs, [rands[0], 0, rands[2]]) is False
+    # 2^63 is what i64::MIN.abs() wraps to in a release build of the reference (src/aggregates.rs:285): any nonzero 64-bit scalar works
+    assert _vm_gpu(N, sigs, pks, msgs, [1 << 63, (1 << 64) - 1, 1]) is True
+
+
+def test_aggregate_verify_edge_members_vs_oracle(N, vectors):
+    """reference src/aggregates.rs:130-170 with infinite / invalid members, against the oracle."""
+    from milagro_bls_amd import AggregateSignature, PublicKey, Signature
+    rnd = random.Random(14)
+    n = 5
+    sks, pks = _keys(rnd, n)
+    msgs = [rnd.randbytes(20 + 3 * i) for i in range(n)]             # ragged message lengths
+    sig_pts = [orc.sign(m, s) for m, s in zip(msgs, sks)]
+    agg = sig_pts[0]
+    for p in sig_pts[1:]:
+        agg = orc.g2_add(agg, p)
+    agg_c = orc.g2_compress(agg)
+
+    def both(sigc, ms, ks):
+        got = AggregateSignature(sigc).aggregate_verify(ms, [PublicKey(k) for k in ks])
+        e, pt = orc.g2_from_compressed(sigc)
+        want = False if e else orc.aggregate_verify(pt, ms, ks)
+        assert got == want, (got, want)
+        return got
+    assert both(agg_c, msgs, pks) is True
+    assert both(agg_c, msgs, pks[:-1] + [G1_INF_U]) is False                      # a key replaced by infinity: its pairing drops out
+    # drop signer 4 from the aggregate and give it the infinite key: the remaining product is complete again
+    agg4 = sig_pts[0]
+    for p in sig_pts[1:4]:
+        agg4 = orc.g2_add(agg4, p)
+    assert both(orc.g2_compress(agg4), msgs, pks[:4] + [G1_INF_U]) is True
+    assert both(helpers.G2_INF, msgs, pks) is False                               # infinite signature against real keys
+    assert both(helpers.G2_INF, msgs, [G1_INF_U] * n) is True                      # nothing on either side
+    probe = bytes.fromhex(vectors["model"]["g2_subgroup_probes"][2]["compressed"])
+    assert both(probe, msgs, pks) is False                                        # src/aggregates.rs:137-139
+    assert both(agg_c, msgs[::-1], pks) is False
+    assert AggregateSignature(agg_c).aggregate_verify(msgs[:-1], [PublicKey(k) for k in pks]) is False      # length mismatch, :132-134
+    assert AggregateSignature(agg_c).aggregate_verify([], []) is False
+
+
+# ------------------------------------------------------------------------------------------------ KeyValidate on garbage
+def test_pk_decode_batch_validate_on_random_blobs(mb):
+    """PublicKey::from_bytes (decode + KeyValidate, reference src/keys.rs:140-147, :181-186) on 256 random / garbage encodings:
+    error class and decoded bytes equal the oracle's (which runs the full [r]P test)."""
+    rnd = random.Random(15)
+    sks, pks = _keys(rnd, 24)
+    blobs = [bytes([rnd.choice([0x80, 0xA0, 0xC0, 0x00, 0xE0, 0x9f]) | rnd.getrandbits(5)]) + rnd.randbytes(47) for _ in range(200)]
+    blobs += [orc.g1_compress(p) for p in pks]                           # valid keys in G1
+    blobs += [G1_INF_C, bytes([0x80]) + bytes(47), bytes([0xA0]) + bytes(47)]     # infinity; (0, +-2): on the curve, outside G1
+    while len(blobs) < 256:                                              # x-only randomness: on-curve points are ~half, almost none in G1
+        blobs.append(bytes([0x80 | rnd.getrandbits(5) & 0x19]) + rnd.randbytes(47))
+    out, errs = mb.pk_decode_batch(b"".join(blobs), len(blobs), validate=True)
+    n_ok = 0
+    for i, bl in enumerate(blobs):
+        e, pt = orc.pk_from_bytes(bl)
+        assert errs[i] == e, (i, bl.hex(), errs[i], e)
+        if e == 0:
+            assert out[96 * i:96 * i + 96] == pt
+            n_ok += 1
+    assert n_ok == 24
+    # the unchecked decode of the same blobs accepts strictly more
+    _, errs_u = mb.pk_decode_batch(b"".join(blobs), len(blobs), validate=False)
+    assert sum(e == 0 for e in errs_u) > n_ok + 20
+
+
+# ------------------------------------------------------------------------------------------------ resident key table
+def test_keytable_indexed_verification_matches_byte_path_and_oracle(mb, N):
+    rnd = random.Random(16)
+    pool_n, n, k = 40, 130, 6
+    sks, pks = _keys(rnd, pool_n)
+    tab = N.KeyTable(capacity_hint=8)                                   # small on purpose: appends must grow the table
+    comp = [orc.g1_compress(p) for p in pks]
+    first, errs = tab.append(b"".join(comp[:25]), 25, pk_format=0, validate=True)
+    assert first == 0 and errs == [0] * 25
+    first, errs = tab.append(b"".join(pks[25:]), pool_n - 25, pk_format=1, validate=False)
+    assert first == 25 and errs == [0] * (pool_n - 25) and len(tab) == pool_n
+    got, e = tab.get(0, pool_n)
+    assert e == [0] * pool_n and got == b"".join(pks)                   # as_uncompressed_bytes round trip of every entry
+    # special entries: infinity (unchecked), a rejected key (infinity under KeyValidate), a key outside G1, undecodable bytes
+    s_first, s_errs = tab.append(G1_INF_C, 1, pk_format=0, validate=False)
+    assert s_errs == [0]
+    IDX_INF = s_first
+    v_first, v_errs = tab.append(G1_INF_C + bytes([0x80]) + bytes(47) + bytes([0x80]) + b"\xff" * 47, 3, pk_format=0, validate=True)
+    assert v_errs == [N.ERR_INVALID_POINT] * 3                          # src/keys.rs:334-350
+    IDX_BAD = v_first
+    idxs, sigs, msgs = [], [], []
+    for i in range(n):
+        idx = rnd.sample(range(pool_n), k)
+        m = rnd.randbytes(32)
+        sigs.append(orc.g2_compress(orc.sign(m, sum(sks[j] for j in idx) % helpers.R)))
+        msgs.append(m); idxs.append(idx)
+    kinds = ["valid"] * n
+    for i in range(3, n, 5):
+        kind = ["wrong_key", "inf_member", "bad_member", "oob_index", "flip_msg", "dup_key"][(i // 5) % 6]
+        kinds[i] = kind
+        if kind == "wrong_key":
+            idxs[i][0] = next(j for j in range(pool_n) if j not in idxs[i])
+        elif kind == "inf_member":
+            pass                                                        # rebuilt below: k-1 signers + the infinity entry
+        elif kind == "bad_member":
+            idxs[i][2] = IDX_BAD + (i % 3)
+        elif kind == "oob_index":
+            idxs[i][1] = len(tab) + 5
+        elif kind == "flip_msg":
+            msgs[i] = bytes([msgs[i][0] ^ 2]) + msgs[i][1:]
+        elif kind == "dup_key":
+            idxs[i][1] = idxs[i][0]
+    # rebuild the inf_member items properly: k-1 signers + the infinity entry (sum unchanged) -> valid
+    for i in range(n):
+        if kinds[i] == "inf_member":
+            idx = rnd.sample(range(pool_n), k - 1)
+            m = msgs[i]
+            sigs[i] = orc.g2_compress(orc.sign(m, sum(sks[j] for j in idx) % helpers.R))
+            idxs[i] = idx[:2] + [IDX_INF] + idx[2:]
+    flat = [j for idx in idxs for j in idx]
+    got, st = mb.fast_aggregate_verify_batch_indexed(tab, b"".join(sigs), b"".join(msgs), flat, n, k)
+    # byte-format path over the same keys (an invalid / out-of-range entry has no byte form: substitute undecodable bytes)
+    all96, all_e = tab.get(0, len(tab))
+    undec = bytes(48) + bytes([1]) + bytes(47)
+    key_bytes = lambda j: undec if (j >= len(tab) or all_e[j]) else all96[96 * j:96 * j + 96]
+    pkb = b"".join(key_bytes(j) for j in flat)
+    got_b, st_b = mb.fast_aggregate_verify_batch(b"".join(sigs), b"".join(msgs), pkb, n, k, pk_format=1)
+    want = orc.batch_fast_aggregate_verify(b"".join(sigs), b"".join(msgs), pkb, n, k, 1, nthreads=8)
+    assert got == got_b == want
+    assert st == st_b
+    for i in range(n):
+        exp = kinds[i] in ("valid", "inf_member")
+        assert got[i] == exp, (i, kinds[i])
+        if kinds[i] in ("bad_member", "oob_index"):
+            assert st[i] & 0x04
+    # ragged index lists incl. an empty one
+    counts = [k, 0, k, 2, k]
+    off = [0]
+    rag = []
+    for i, c in enumerate(counts):
+        rag += idxs[i][:c]; off.append(off[-1] + c)
+    got_r, st_r = mb.fast_aggregate_verify_batch_indexed(tab, b"".join(sigs[:5]), b"".join(msgs[:5]), rag, 5, offsets=off)
+    assert got_r[0] == got[0] and got_r[2] == got[2] and got_r[4] == got[4] and got_r[1] is False and st_r[1] & 0x10 and got_r[3] is False
+    tab.close()
+
+
+def test_keytable_device_entry_at_batch_size(N):
+    """2^13 x 128 keys through the indexed device entry against the byte-format device entry: identical results, bitmap and status."""
+    import torch
+    import bench
+    ctx = N.default_context()
+    dev = torch.device("cuda:0")
+    n, k = 1 << 13, 128
+    inp = bench.build_inputs(ctx, dev, n, k, N.PK_UNCOMPRESSED, rank=5, return_indices=True)
+    d_sigs, d_msgs, d_pks, expect, d_idx, tab = inp
+    outs = []
+    for mode in ("bytes", "indexed"):
+        d_res = torch.zeros(n, dtype=torch.uint8, device=dev); d_bm = torch.zeros(n // 64, dtype=torch.int64, device=dev)
+        d_st = torch.zeros(n, dtype=torch.int32, device=dev)
+        if mode == "bytes":
+            ctx.check(N.lib().mbls_fast_aggregate_verify_batch_device(ctx.handle, d_sigs.data_ptr(), d_msgs.data_ptr(), 32, d_pks.data_ptr(), N.PK_UNCOMPRESSED,
+                                                                      None, n, k, d_res.data_ptr(), d_bm.data_ptr(), d_st.data_ptr(), None))
+        else:
+            ctx.check(N.lib().mbls_fast_aggregate_verify_batch_indexed_device(ctx.handle, tab.handle, d_sigs.data_ptr(), d_msgs.data_ptr(), 32, d_idx.data_ptr(),
+                                                                              None, n, k, d_res.data_ptr(), d_bm.data_ptr(), d_st.data_ptr(), None))
+        torch.cuda.synchronize()
+        outs.append((d_res.cpu(), d_bm.cpu(), d_st.cpu()))
+    assert torch.equal(outs[0][0], expect) and torch.equal(outs[1][0], expect)
+    assert torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][2], outs[1][2])
+
+
+# ------------------------------------------------------------------------------------------------ batched AggregateSignature::aggregate
+def test_aggregate_signatures_batch_vs_oracle(mb):
+    rnd = random.Random(17)
+    n, k = 70, 5
+    sks = [rnd.randrange(1, helpers.R) for _ in range(n * k)]
+    msgs = [rnd.randbytes(32) for _ in range(n)]
+    pts = [orc.sign(msgs[i // k], sks[i]) for i in range(n * k)]
+    sigs = [orc.g2_compress(p) for p in pts]
+    sigs[7] = helpers.G2_INF                                   # an infinite member
+    pts[7] = orc.g2_from_compressed(helpers.G2_INF)[1]
+    sigs[11] = sigs[10]; pts[11] = pts[10]                     # a doubled member (the complete addition doubles)
+    sigs[16] = orc.g2_compress(orc.g2_mul(pts[15], helpers.R - 1)); pts[16] = orc.g2_from_compressed(sigs[16])[1]   # inverse pair -> passes through infinity
+    out, errs = mb.aggregate_signatures_batch(b"".join(sigs), n, k)
+    assert errs == [0] * n
+    for i in range(n):
+        acc = pts[k * i]
+        for p in pts[k * i + 1:k * i + k]:
+            acc = orc.g2_add(acc, p)
+        assert out[96 * i:96 * i + 96] == orc.g2_compress(acc), i
+    # an undecodable member -> the Signature::from_bytes error of that member; ragged sets incl. an empty one -> infinity
+    bad = list(sigs[:6]); bad[4] = bytes([bad[4][0] & 0x7F]) + bad[4][1:]
+    out2, errs2 = mb.aggregate_signatures_batch(b"".join(bad), 3, offsets=[0, 3, 3, 6])
+    assert errs2 == [0, 0, 2] and out2[96:192] == helpers.G2_INF and out2[:96] != bytes(96) and out2[192:] == bytes(96)
+    # the aggregate verifies: sum of k signatures on one message under the k keys
+    pk96 = orc.batch_sk_to_pk(b"".join(s.to_bytes(32, "big") for s in sks[20:25]), 5, 1)
+    got, _ = mb.fast_aggregate_verify_batch(out[96 * 4:96 * 5], msgs[4], pk96, 1, 5, pk_format=1)
+    assert got == [True]
+
+
+# ------------------------------------------------------------------------------------------------ threads, argument validation
+def test_one_context_shared_by_threads(mb):
+    """Every entry point takes the context's lock (the reference's functions are re-entrant): four threads hammer
+    one context with different batches; each must get its own answers."""
+    batches = [helpers.make_batch(40 + 13 * t, 3, fmt=t % 2, seed=300 + t) for t in range(4)]
+    want = [orc.batch_fast_aggregate_verify(b.sigs, b.msgs, b.pks, b.n, b.k, b.fmt, nthreads=4) for b in batches]
+    errors = []
+
+    def work(t):
+        b = batches[t]
+        for _ in range(4):
+            got, _ = mb.fast_aggregate_verify_batch(b.sigs, b.msgs, b.pks, b.n, b.k, pk_format=b.fmt)
+            if got != want[t]:
+                errors.append(t)
+    th = [threading.Thread(target=work, args=(t,)) for t in range(4)]
+    [x.start() for x in th]; [x.join() for x in th]
+    assert not errors
+
+
+def test_argument_validation(mb, N):
+    ctx = N.default_context()
+    b = helpers.make_batch(4, 3, fmt=0, seed=31, negatives=False)
+    res = N.outbuf(4)
+    bad_off = (C.c_uint32 * 5)(0, 3, 2, 6, 9)                          # not non-decreasing
+    rc = N.lib().mbls_fast_aggregate_verify_batch(ctx.handle, N.cbuf(b.sigs), N.cbuf(b.msgs), 32, N.cbuf(b.pks), 0, bad_off, 4, 0, res, None)
+    assert rc == N.ERR_ARGUMENT and "offsets" in ctx.last_error()
+    rc = N.lib().mbls_fast_aggregate_verify_batch(ctx.handle, N.cbuf(b.sigs), N.cbuf(b.msgs), 32, N.cbuf(b.pks), 7, None, 4, 3, res, None)
+    assert rc == N.ERR_ARGUMENT
+    rc = N.lib().mbls_fast_aggregate_verify_batch(ctx.handle, None, N.cbuf(b.msgs), 32, N.cbuf(b.pks), 0, None, 4, 3, res, None)
+    assert rc == N.ERR_ARGUMENT
+    # the context still works afterwards
+    assert mb.fast_aggregate_verify_batch(b.sigs, b.msgs, b.pks, 4, 3)[0] == [True] * 4
+
+
+# ------------------------------------------------------------------------------------------------ config 5 shard size
+def test_config5_shard_2_17_items_128_keys(N):
+    """BASELINE configs[4]: 2^20 items over 8 GPUs = 2^17 items x 128 keys per GPU. One shard through the device entry point:
+    bitmap and results by construction (sign -> aggregate -> verify round trip, every 16th item corrupted in five ways), status
+    classes, and a 64-item subsample pinned to the oracle."""
+    import torch
+    import bench
+    ctx = N.default_context()
+    dev = torch.device("cuda:0")
+    n, k = 1 << 17, 128
+    d_sigs, d_msgs, d_pks, expect = bench.build_inputs(ctx, dev, n, k, N.PK_UNCOMPRESSED, rank=6)
+    d_res = torch.zeros(n, dtype=torch.uint8, device=dev); d_bm = torch.zeros(n // 64, dtype=torch.int64, device=dev)
+    d_st = torch.zeros(n, dtype=torch.int32, device=dev)
+    ctx.check(N.lib().mbls_fast_aggregate_verify_batch_device(ctx.handle, d_sigs.data_ptr(), d_msgs.data_ptr(), 32, d_pks.data_ptr(), N.PK_UNCOMPRESSED, None,
+                                                              n, k, d_res.data_ptr(), d_bm.data_ptr(), d_st.data_ptr(), None))
+    torch.cuda.synchronize()
+    assert torch.equal(d_res.cpu(), expect)
+    bits = d_bm.cpu().numpy().view(np.uint64)
+    unpacked = ((bits[:, None] >> np.arange(64, dtype=np.uint64)[None, :]) & np.uint64(1)).reshape(-1).astype(np.uint8)
+    assert (unpacked == expect.numpy()).all()
+    st = d_st.cpu().numpy()
+    assert (st[expect.numpy() == 1] & 0x5F == 0).all()                 # accepted items carry no rejection bit
+    sel = list(range(n - 64, n))                                        # the last wave of the last round of workgroups
+    sub = lambda t: t[sel].cpu().numpy().tobytes()
+    got = orc.batch_fast_aggregate_verify(sub(d_sigs), sub(d_msgs), sub(d_pks), 64, k, 1, nthreads=8)
+    assert got == [bool(x) for x in expect[sel].tolist()]
+
+
+# ------------------------------------------------------------------------------------------------ seeded randomised sweep
+@pytest.mark.parametrize("seed", [100, 101, 102])
+def test_randomised_sweep_vs_oracle(mb, seed):
+    """scripts/stress_parity.py as a test: many shapes (n around the wave size, odd key counts, both formats), seven rejection
+    classes, every accept bit against the oracle."""
+    for n, k, fmt in ((1, 3, 1), (63, 5, 0), (65, 2, 1), (129, 7, 1), (500, 4, 1), (200, 16, 0)):
+        b = helpers.make_batch(n, k, fmt=fmt, seed=seed * 7 + n, pool_n=64)
+        got, st = mb.fast_aggregate_verify_batch(b.sigs, b.msgs, b.pks, b.n, b.k, pk_format=fmt)
+        want = orc.batch_fast_aggregate_verify(b.sigs, b.msgs, b.pks, b.n, b.k, fmt, nthreads=8)
+        assert got == want == b.expect, (seed, n, k, fmt)
