@@ -250,6 +250,26 @@ MBLS_FN void fp12_cyc_sqr_n_lds(MBLS_LDS uint32_t* ls, uint32_t lane, uint32_t n
     uint32_t addr = (uint32_t)(uintptr_t)(ls + lane);
     asm volatile(MBLS_ASM_CALL("mbls_cyc_sqr_asm_fn") : "+{s38}"(n) : "{v252}"(addr) : MBLS_TOWER_ASM_CLOBBERS);
 }
+// Second generation (tools/gen_fpd_asm.py, tools/gen_tower_d.py): the same squaring on 14 signed 28-bit digits per value from the
+// first to the last of the n squarings -- bare product scans, carry-free additions, no conversions or conditional subtractions
+// between multiplications. The parked value is in the 2^392 Montgomery domain (x 2^392 mod p, canonical) for these routines; the
+// first-generation multiplication routine below works on it unchanged (it divides by 2^384 and takes its other operand in the
+// 2^384 domain, so its product stays in the 2^392 domain).
+#include "mbls_fpd_asm.inc"
+#include "mbls_towerd_asm.inc"
+extern "C" __device__ __attribute__((noinline, used, aligned(64))) void mbls_fp2_mul_d_asm_fn() { asm volatile(MBLS_FP2_MUL_D_ASM); }
+extern "C" __device__ __attribute__((noinline, used, aligned(64))) void mbls_fp2_sqr_d_asm_fn() { asm volatile(MBLS_FP2_SQR_D_ASM); }
+extern "C" __device__ __attribute__((noinline, used, aligned(64))) void mbls_fp2_mulfp_d_asm_fn() { asm volatile(MBLS_FP2_MULFP_D_ASM); }
+extern "C" __device__ __attribute__((noinline, used, aligned(64))) void mbls_cyc_sqr_d_asm_fn() { asm volatile(MBLS_CYC_SQR_D_ASM); }
+MBLS_FN void fp12_cyc_sqr_n_lds_d(MBLS_LDS uint32_t* ls, uint32_t lane, uint32_t n) {
+    uint32_t addr = (uint32_t)(uintptr_t)(ls + lane);
+    asm volatile(MBLS_ASM_CALL("mbls_cyc_sqr_d_asm_fn") : "+{s38}"(n) : "{v252}"(addr) : MBLS_TOWERD_ASM_CLOBBERS);
+}
+// x -> x 2^8 (2^384 domain -> 2^392 domain) and back, coefficient by coefficient, with the 32-bit-limb multiplier
+MBLS_FN void fp12_scale(fp12* a, const uint32_t* k) {
+    fp* c = &a->c0.c0.c0; fp kk = fp_load_const(k);
+    for (int e = 0; e < 12; e++) c[e] = fp_mul(c[e], kk);
+}
 // The Fp12 parked in LDS times g, in place (generated routine, prog_fp12_mul).
 extern "C" __device__ __attribute__((noinline, used, aligned(64))) void mbls_fp12_mul_asm_fn() {
     asm volatile(MBLS_FP12_MUL_ASM);
@@ -284,16 +304,26 @@ MBLS_FN void fp12_mul_via_lds(fp12* r, const fp12* a, const fp12* b, MBLS_LDS ui
 MBLS_NOINLINE void fp12_cyc_exp_x(fp12* r, const fp12* f, MBLS_LDS uint32_t* ls, uint32_t lane, bool use_lds) {
     fp12 acc = *f;
     if (use_lds) {
+#if MBLS_DEVICE_ASM && !defined(MBLS_NO_FP2_ASM) && !defined(MBLS_NO_DFORM)
+        fp12_scale(&acc, MBLS_TO_D392);                  // the running power lives in the 2^392 domain between here ...
+#define MBLS_CYC_SQR_N fp12_cyc_sqr_n_lds_d
+#else
+#define MBLS_CYC_SQR_N fp12_cyc_sqr_n_lds
+#endif
         fp12_lds_store(ls, lane, &acc);
         int i = 62;
         while (i >= 0) {
             int j = i;                                   // squarings for bits i..j, j = next set bit (or 0)
             while (j > 0 && !((MBLS_X_ABS >> j) & 1)) j--;
-            fp12_cyc_sqr_n_lds(ls, lane, (uint32_t)(i - j + 1));
+            MBLS_CYC_SQR_N(ls, lane, (uint32_t)(i - j + 1));
             if ((MBLS_X_ABS >> j) & 1) fp12_mul_lds(ls, lane, f);
             i = j - 1;
         }
         fp12_lds_load(&acc, ls, lane);
+#if MBLS_DEVICE_ASM && !defined(MBLS_NO_FP2_ASM) && !defined(MBLS_NO_DFORM)
+        fp12_scale(&acc, MBLS_FROM_D392);                // ... and here
+#endif
+#undef MBLS_CYC_SQR_N
     } else {
         // acc never escapes (the 5 multiplications go through a short-lived copy), so the 63 squarings keep it in registers
         for (int i = 62; i >= 0; i--) {

@@ -120,6 +120,26 @@ class Machine:
             elif op == "v_mad_u64_u32":
                 t = self.rd(args[2]) * self.rd(args[3]) + self.rd(args[4])
                 self.wr(args[0], t & 0xFFFFFFFFFFFFFFFF); self.wr_carry(args[1], t >> 64)
+            elif op == "v_mad_i64_i32":
+                t = s32(self.rd(args[2])) * s32(self.rd(args[3])) + s64(self.rd(args[4]))
+                assert -(1 << 63) <= t < (1 << 63), "signed 64-bit accumulator overflow: " + line
+                self.wr(args[0], t & 0xFFFFFFFFFFFFFFFF)
+            elif op == "v_ashrrev_i64":
+                self.wr(args[0], (s64(self.rd(args[2])) >> self.rd(args[1])) & 0xFFFFFFFFFFFFFFFF)
+            elif op == "v_ashrrev_i32_e64":
+                self.wr(args[0], s32(self.rd(args[2])) >> self.rd(args[1]))
+            elif op == "v_cvt_f32_i32_e64":
+                self.wr(args[0], f32_bits(float(s32(self.rd(args[1])))))
+            elif op == "v_mul_f32_e64":
+                self.wr(args[0], f32_bits(bits_f32(self.rd(args[1])) * bits_f32(self.rd(args[2]))))
+            elif op == "v_rndne_f32_e64":
+                self.wr(args[0], f32_bits(float(round(bits_f32(self.rd(args[1]))))))       # Python rounds half to even, like v_rndne
+            elif op == "v_cvt_i32_f32_e64":
+                self.wr(args[0], int(bits_f32(self.rd(args[1]))))
+            elif op in ("v_add_u32_e32", "v_add_u32_e64"):
+                self.wr(args[0], self.rd(args[1]) + self.rd(args[2]))
+            elif op == "v_sub_u32_e64":
+                self.wr(args[0], self.rd(args[1]) - self.rd(args[2]))
             elif op == "v_mul_lo_u32":
                 self.wr(args[0], self.rd(args[1]) * self.rd(args[2]))
             elif op in ("v_cndmask_b32_e32", "v_cndmask_b32_e64"):
@@ -189,6 +209,47 @@ class Machine:
         if cur.strip():
             out.append(cur)
         return out
+
+
+def f32_bits(x):
+    import struct
+    return struct.unpack("<I", struct.pack("<f", x))[0]
+
+
+def bits_f32(b):
+    import struct
+    return struct.unpack("<f", struct.pack("<I", b & M32))[0]
+
+
+def s32(x):
+    x &= M32
+    return x - (1 << 32) if x >> 31 else x
+
+
+def s64(x):
+    x &= 0xFFFFFFFFFFFFFFFF
+    return x - (1 << 64) if x >> 63 else x
+
+
+def digits_signed(x, dmax=None, rng=None):
+    """a 14-digit signed representation of the integer x (|x| < 2^395): canonical digits, optionally randomised redundantly so that
+    digits reach magnitudes up to dmax while the value stays x"""
+    neg = x < 0
+    ax = -x if neg else x
+    d = [(ax >> (28 * i)) & 0xFFFFFFF for i in range(13)] + [ax >> 364]
+    if neg:
+        d = [-v for v in d]
+    if dmax and rng:
+        for i in range(13):
+            c = rng.randrange(-(dmax >> 28), (dmax >> 28) + 1)      # move c * 2^28 from digit i+1 to digit i
+            if abs(d[i] + c * (1 << 28)) < dmax and abs(d[i + 1] - c) < (1 << 31):
+                d[i] += c * (1 << 28); d[i + 1] -= c
+    assert sum(v << (28 * i) for i, v in enumerate(d)) == x
+    return [v & M32 for v in d]
+
+
+def from_digits_signed(d):
+    return sum(s32(v) << (28 * i) for i, v in enumerate(d))
 
 
 def limbs(x):

@@ -1,0 +1,113 @@
+#!/usr/bin/env python3
+"""Generate milagro_bls_amd/csrc/mbls_fpd_asm.inc: the Fp2 multiplication routines of the digit-form ("D-form") tower routines.
+
+D-form: an Fp value is 14 SIGNED 32-bit digits d_0..d_13, value = sum d_j 2^(28 j), a representative of a * 2^392 mod p (Montgomery
+radix 2^392 = the radix of 14 digits). Digits are unsaturated: additions and subtractions are 14 independent v_add_u32 / v_sub_u32
+with no carries, no modular correction and no constant offsets (signed digits absorb the subtractions); a product column is a
+signed 64-bit sum accumulated by v_mad_i64_i32. The generator of the callers (tools/gen_tower_d.py) tracks exact bounds on the digits
+and on the value of everything it computes and renormalises (one carry pass) only where a routine's input limit would be exceeded.
+
+Compared with the 12 x 32-bit-limb routines of tools/gen_fp_asm.py (operands re-cut into digits on entry, results re-packed and
+conditionally reduced on exit) a routine here is only the two interleaved product scans: no conversions, no final subtraction, and
+its operand registers survive the call.
+
+Register contract (blocks of 14 VGPRs, block i = v[14 i .. 14 i + 13]):
+    mbls_fp2_mul_d_asm_fn    a0 blk0, a1 blk1, b0 blk2, b1 blk3 (preserved)  ->  c0 blk5, c1 blk6   (blk4 = -b1, v98..v101 accumulators)
+    mbls_fp2_sqr_d_asm_fn    a0 blk0, a1 blk1 (preserved)                    ->  c0 blk5, c1 blk6   (blk2..4 = a0+a1, a0-a1, 2 a1)
+    mbls_fp2_mulfp_d_asm_fn  a0 blk0, a1 blk1, s blk2 (preserved)            ->  a0 s blk5, a1 s blk6
+Resident constants (loaded once by the calling routine's shell, load_constants()): digits of p in s40-s47, s56-s61, -p^-1 mod 2^28
+in s64, the digit mask in s65. Carries: vcc and s[62:63]. Results: digits 0..12 in [0, 2^28), digit 13 signed (the value lies in
+(-X, p + X) with X = sum |a||b| / 2^392, a tiny multiple of p for every operand the callers produce).
+"""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from gen_fp_asm import P, P28, NP28, M28, SP28, SNP28, SMASK28, emit, zip2  # noqa: E402
+
+BLK = lambda i: (lambda j: "v%d" % (14 * i + j))
+ACC_A, ACC_B = 98, 100
+CARRY_A, CARRY_B = "vcc", "s[62:63]"
+R392 = 1 << 392
+
+
+def load_constants():
+    L = ["s_mov_b32 %s, 0x%08x" % (SP28(i), P28[i]) for i in range(14)]
+    L += ["s_mov_b32 %s, 0x%08x" % (SNP28, NP28), "s_mov_b32 %s, 0x%08x" % (SMASK28, M28)]
+    return L
+
+
+def signed_scan(pairs, out, acc, cy):
+    """sum of the listed digit-vector products, Montgomery-reduced by 2^392, on signed digits; quotient digits and then result
+    digits in `out` (14 registers, distinct from every operand: the operands are read until the last column)"""
+    A, lo = "v[%d:%d]" % (acc, acc + 1), "v%d" % acc
+    S, first = [], True
+    for k in range(28):
+        macs = []
+        for i in range(max(0, k - 13), min(k, 13) + 1):
+            for (X, Y) in pairs:
+                macs.append((X(i), Y(k - i)))
+        if k < 14:
+            macs += [(SP28(k - i), out(i)) for i in range(k)]
+        else:
+            macs += [(SP28(k - i), out(i)) for i in range(k - 13, 14)]
+        for (x, y) in macs:
+            S.append("v_mad_i64_i32 %s, %s, %s, %s, %s" % (A, cy, x, y, "0" if first else A)); first = False
+        if k < 14:
+            S += ["v_mul_lo_u32 %s, %s, %s" % (out(k), lo, SNP28), "v_and_b32_e64 %s, %s, %s" % (out(k), out(k), SMASK28),
+                  "v_mad_i64_i32 %s, %s, %s, %s, %s" % (A, cy, SP28(0), out(k), A), "v_ashrrev_i64 %s, 28, %s" % (A, A)]
+        elif k < 27:
+            S += ["v_and_b32_e64 %s, %s, %s" % (out(k - 14), lo, SMASK28), "v_ashrrev_i64 %s, 28, %s" % (A, A)]
+        else:
+            S.append("v_mov_b32_e64 %s, %s" % (out(13), lo))          # top digit: signed, whatever is left
+    return S
+
+
+def fp2_mul_d_body():
+    A0, A1, B0, B1, NB, C0, C1 = BLK(0), BLK(1), BLK(2), BLK(3), BLK(4), BLK(5), BLK(6)
+    L = ["v_sub_u32_e64 %s, 0, %s" % (NB(j), B1(j)) for j in range(14)]                      # -b1: c0 = a0 b0 - a1 b1
+    L += zip2(signed_scan([(A0, B0), (A1, NB)], C0, ACC_A, CARRY_A), signed_scan([(A0, B1), (A1, B0)], C1, ACC_B, CARRY_B))
+    return L
+
+
+def fp2_sqr_d_body():
+    A0, A1, S, D, A1D, C0, C1 = BLK(0), BLK(1), BLK(2), BLK(3), BLK(4), BLK(5), BLK(6)
+    L = []
+    for j in range(14):                                                                          # c0 = (a0 + a1)(a0 - a1), c1 = a0 (2 a1)
+        L += ["v_add_u32_e64 %s, %s, %s" % (S(j), A0(j), A1(j)), "v_sub_u32_e64 %s, %s, %s" % (D(j), A0(j), A1(j)),
+              "v_lshlrev_b32_e64 %s, 1, %s" % (A1D(j), A1(j))]
+    L += zip2(signed_scan([(S, D)], C0, ACC_A, CARRY_A), signed_scan([(A0, A1D)], C1, ACC_B, CARRY_B))
+    return L
+
+
+def fp2_mulfp_d_body():
+    A0, A1, SB, C0, C1 = BLK(0), BLK(1), BLK(2), BLK(5), BLK(6)
+    return zip2(signed_scan([(A0, SB)], C0, ACC_A, CARRY_A), signed_scan([(A1, SB)], C1, ACC_B, CARRY_B))
+
+
+ROUTINE_BODIES = {"mbls_fp2_mul_d_asm_fn": fp2_mul_d_body, "mbls_fp2_sqr_d_asm_fn": fp2_sqr_d_body, "mbls_fp2_mulfp_d_asm_fn": fp2_mulfp_d_body}
+
+
+# ---- input limits: the worst column of a scan must stay inside a signed 64-bit accumulator
+def column_ok(products):
+    """products: list of (Da, Db) digit-magnitude bounds of the vector products summed in one scan"""
+    worst = 14 * sum(a * b for a, b in products) + 14 * (1 << 56)
+    worst += (worst >> 28) + (1 << 32)           # carry from the previous column, slack
+    return worst < (1 << 63)
+
+
+def main():
+    here = os.path.dirname(os.path.abspath(__file__))
+    path = os.path.join(os.path.dirname(here), "milagro_bls_amd", "csrc", "mbls_fpd_asm.inc")
+    txt = "// GENERATED by tools/gen_fpd_asm.py -- do not edit.\n// gfx950 Fp2 multiplication routines on 14 signed 28-bit digits (D-form), private calling convention.\n"
+    for sym, fn in ROUTINE_BODIES.items():
+        body = fn()
+        txt += emit("MBLS_" + sym.upper()[5:-7] + "_ASM", [".p2align 6"] + body) + "\n"
+        print(sym, len(body), "instructions")
+    with open(path, "w") as f:
+        f.write(txt)
+    print("wrote", path)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,691 @@
+#!/usr/bin/env python3
+"""Generate milagro_bls_amd/csrc/mbls_towerd_asm.inc: the hot loop bodies as straight-line gfx950 routines in DIGIT FORM.
+
+Second generation of tools/gen_tower_asm.py (which stays for the one-shot Fp12 products). There, an Fp between multiplications is
+12 saturated 32-bit limbs: every multiplication routine re-cuts its operands into 28-bit digits and packs / conditionally reduces
+its results (15 % of its instructions), and every addition is a carry chain with a conditional correction (36 instructions).
+Here a value STAYS 14 signed 28-bit digits (tools/gen_fpd_asm.py, "D-form", Montgomery radix 2^392) from the moment it enters a
+routine until it leaves: multiplications are bare product scans, additions / subtractions / doublings are 14 independent
+instructions without carries or corrections. What replaces modular reduction is bookkeeping done HERE, at generation time: every value
+carries exact interval bounds on its digits, its top digit and its integer value (class Bound); an operation whose result could
+leave the 32-bit digit range, or an operand that could overflow a 64-bit product column of a multiplication routine, gets one
+carry pass ("norm", 39 instructions) inserted in front, and a value that re-enters the next round linearly (the cyclotomic squaring's
+3 t -+ 2 z) gets a fused quotient-estimate / subtract / carry pass ("reduce", 74 instructions). A Montgomery product brings any
+operands back to (-eps, p + eps), so products never accumulate growth.
+
+Storage: 14-register blocks -- 18 VGPR blocks (blocks 0..7 are the window of the multiplication routines: operands in 0..3, which
+the routines preserve, results in 5 and 6, block 4 / 7 scratch), 18 AGPR blocks, LDS digit slots; Belady eviction with exact next-use
+knowledge as in the first generation. State that crosses a routine boundary lives in LDS as 12 packed words per value (packing needs
+a non-negative normalised value below 2^384: add a multiple of p, carry pass, pack).
+
+Everything emitted is executed on the CPU by tools/asm_sim.py against big-integer arithmetic (tests/test_asm_sim_cpu.py).
+Run:  python3 tools/gen_tower_d.py    (output committed; tests check it is up to date)
+"""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from gen_fp_asm import P, P28, M28, SP28, SMASK28, emit  # noqa: E402
+from gen_fpd_asm import load_constants, column_ok  # noqa: E402
+from gen_tower_asm import Prog, expand_calls, INF  # noqa: E402
+
+R392 = 1 << 392
+PTOP = P >> 364                      # top digit of p
+NV, NA = 18, 18                      # VGPR / AGPR blocks of 14
+WIN_IN = [0, 1, 2, 3]
+FREE_V = list(range(8, 18))
+ALL_V = FREE_V + [3, 2, 1, 0, 4, 6, 5]          # block 7 holds the routines' accumulators: never a home
+LADDR, TMP = "v252", "v254"             # v253: -q of reduce, v[254:255]: its 64-bit running sum; v254 also the carry of norm
+
+
+def vb(b):
+    return 14 * b
+
+
+ROUTINES = {
+    "mul": dict(name="mbls_fp2_mul_d_asm_fn", ins=[0, 1, 2, 3], outs=[5, 6], clob=[4, 5, 6, 7]),
+    "sqr": dict(name="mbls_fp2_sqr_d_asm_fn", ins=[0, 1], outs=[5, 6], clob=[2, 3, 4, 5, 6, 7]),
+    "mulfp": dict(name="mbls_fp2_mulfp_d_asm_fn", ins=[0, 1, 2], outs=[5, 6], clob=[5, 6, 7]),
+}
+
+
+class Bound:
+    """exact interval bounds of a D-form value: digits 0..12 in [dlo, dhi], top digit in [tlo, thi], integer value in [vlo, vhi]"""
+    __slots__ = ("dlo", "dhi", "tlo", "thi", "vlo", "vhi")
+
+    def __init__(self, dlo, dhi, tlo, thi, vlo, vhi):
+        self.dlo, self.dhi, self.tlo, self.thi, self.vlo, self.vhi = dlo, dhi, tlo, thi, vlo, vhi
+
+    @staticmethod
+    def normalised(vlo, vhi):
+        return Bound(0, M28, (vlo >> 364) - 1, (vhi >> 364) + 1, vlo, vhi)
+
+    def mag(self):
+        return max(abs(self.dlo), abs(self.dhi), abs(self.tlo), abs(self.thi))
+
+    def fits(self):
+        return self.mag() < (1 << 31)
+
+    def __add__(self, o):
+        return Bound(self.dlo + o.dlo, self.dhi + o.dhi, self.tlo + o.tlo, self.thi + o.thi, self.vlo + o.vlo, self.vhi + o.vhi)
+
+    def __sub__(self, o):
+        return Bound(self.dlo - o.dhi, self.dhi - o.dlo, self.tlo - o.thi, self.thi - o.tlo, self.vlo - o.vhi, self.vhi - o.vlo)
+
+    def union(self, o):
+        return Bound(min(self.dlo, o.dlo), max(self.dhi, o.dhi), min(self.tlo, o.tlo), max(self.thi, o.thi), min(self.vlo, o.vlo), max(self.vhi, o.vhi))
+
+    def vabs(self):
+        return max(abs(self.vlo), abs(self.vhi))
+
+    def __repr__(self):
+        return "B(d[%.2f,%.2f] v[%.2fp,%.2fp])" % (self.dlo / (1 << 28), self.dhi / (1 << 28), self.vlo / P, self.vhi / P)
+
+
+def product_bound(pairs):
+    """result of a Montgomery scan over the listed (a, b) operand bounds: digits normalised, value in (-X, p + X)"""
+    X = sum(a.vabs() * b.vabs() for a, b in pairs) // R392 + 2
+    return Bound.normalised(-X, P + X)
+
+
+STATE_IN = None
+REDUCED = Bound.normalised(-(P // 2) - (P >> 10), (P // 2) + (P >> 10))      # after `reduce`: the representative nearest to zero
+
+
+STATE_IN = Bound.normalised(REDUCED.vlo, P)         # a loop-carried value: canonical on entry of a routine, reduced afterwards
+
+
+# ---------------------------------------------------------------------------------------------- instruction sequences
+def seq_conv(dst, src_regs, aform):
+    """14 digits from 12 x 32-bit words held in the registers src_regs (a list of 12 names); aform: digits of src * 2^8 (moves a
+    Montgomery-2^384 operand into the 2^392 domain). dst(j) may overlap src when the words sit in dst(2)..dst(13)."""
+    L = []
+    src = lambda q: src_regs[q]
+    for j in range(14):
+        o = 28 * j - (8 if aform else 0)
+        d = dst(j)
+        if o < 0:
+            L += ["v_lshlrev_b32_e64 %s, 8, %s" % (d, src(0)), "v_and_b32_e64 %s, %s, %s" % (d, d, SMASK28)]
+            continue
+        q, r = o >> 5, o & 31
+        if o + 28 > 384:
+            assert q == 11
+            L.append("v_lshrrev_b32_e64 %s, %d, %s" % (d, r, src(11)))
+        elif r == 0:
+            L.append("v_and_b32_e64 %s, %s, %s" % (d, src(q), SMASK28))
+        elif r + 28 == 32:
+            L.append("v_lshrrev_b32_e64 %s, %d, %s" % (d, r, src(q)))
+        elif r + 28 < 32:
+            L.append("v_bfe_u32 %s, %s, %d, 28" % (d, src(q), r))
+        else:
+            L += ["v_alignbit_b32 %s, %s, %s, %d" % (d, src(q + 1), src(q), r), "v_and_b32_e64 %s, %s, %s" % (d, d, SMASK28)]
+    return L
+
+
+def seq_to32(reg):
+    """12 x 32-bit words (in reg(0)..reg(11)) from 14 digits of exactly 28 bits in reg(0)..reg(13), in place"""
+    L = []
+    for q in range(12):
+        j, off = (32 * q) // 28, (32 * q) % 28
+        if off == 0:
+            L.append("v_lshl_or_b32 %s, %s, 28, %s" % (reg(q), reg(j + 1), reg(j)))
+        else:
+            L.append("v_lshrrev_b32_e64 %s, %d, %s" % (reg(q), off, reg(j)))
+            L.append("v_lshl_or_b32 %s, %s, %d, %s" % (reg(q), reg(j + 1), 28 - off, reg(q)))
+    return L
+
+
+def seq_norm(reg):
+    """one sequential carry pass: digits 0..12 into [0, 2^28), the top digit absorbs the rest (signed)"""
+    L = []
+    for j in range(13):
+        L += ["v_ashrrev_i32_e64 %s, 28, %s" % (TMP, reg(j)), "v_and_b32_e64 %s, %s, %s" % (reg(j), reg(j), SMASK28),
+              "v_add_u32_e64 %s, %s, %s" % (reg(j + 1), reg(j + 1), TMP)]
+    return L
+
+
+RECIP_PTOP = "0x%08x" % int.from_bytes(__import__("struct").pack(">f", 1.0 / PTOP), "big")
+
+
+def seq_qpass(reg, setup):
+    """ONE carry pass over a signed 64-bit running sum: acc = carry - q p_j + d_j (two v_mad_i64_i32, the second one by the inline
+    constant 1), digit = acc mod 2^28, carry = acc >> 28; `setup` leaves -q in NQ. Digits 0..12 come out in [0, 2^28); the 64-bit sum
+    makes the pass indifferent to the magnitudes of q and of the incoming digits."""
+    A, lo = "v[254:255]", "v254"
+    L = list(setup)
+    for j in range(14):
+        L += ["v_mad_i64_i32 %s, vcc, %s, %s, %s" % (A, NQ, SP28(j), "0" if j == 0 else A), "v_mad_i64_i32 %s, vcc, %s, 1, %s" % (A, reg(j), A)]
+        if j < 13:
+            L += ["v_and_b32_e64 %s, %s, %s" % (reg(j), lo, SMASK28), "v_ashrrev_i64 %s, 28, %s" % (A, A)]
+        else:
+            L.append("v_mov_b32_e64 %s, %s" % (reg(13), lo))
+    return L
+
+
+def seq_reduce(reg):
+    """value -> the representative nearest to zero, digits normalised: q = rndne(top digit / top digit of p) in floating point (the
+    unnormalised lower digits and the lower digits of p move the estimate by < 2e-4)"""
+    return seq_qpass(reg, ["v_cvt_f32_i32_e64 %s, %s" % (NQ, reg(13)), "v_mul_f32_e64 %s, %s, %s" % (NQ, RECIP_PTOP_S, NQ), "v_rndne_f32_e64 %s, %s" % (NQ, NQ),
+                           "v_cvt_i32_f32_e64 %s, %s" % (NQ, NQ), "v_sub_u32_e64 %s, 0, %s" % (NQ, NQ)])
+
+
+def seq_canonical(reg):
+    """a normalised value in (-p, p) -> [0, p): add p iff the top digit is negative (-q = top digit >> 31 = the sign mask ... as +1)"""
+    return seq_qpass(reg, ["v_lshrrev_b32_e64 %s, 31, %s" % (NQ, reg(13))])
+
+
+NQ = "v253"
+RECIP_PTOP_S = "s73"                 # 1 / (top digit of p) as f32, loaded by shell_constants()
+
+
+def shell_constants():
+    return load_constants() + ["s_mov_b32 %s, %s" % (RECIP_PTOP_S, RECIP_PTOP)]
+
+
+def digits_of(c):
+    assert 0 <= c < (1 << 392)
+    return [(c >> (28 * j)) & M28 for j in range(13)] + [c >> 364]
+
+
+def seq_add_const(reg, c):
+    """reg += the digits of the non-negative constant c"""
+    return ["v_add_u32_e32 %s, 0x%08x, %s" % (reg(j), d, reg(j)) for j, d in enumerate(digits_of(c)) if d]
+
+
+def lds_read_words(dst_regs, slot_dword):
+    """12 packed words of an LDS slot (dword offset slot_dword within the lane's column) into the listed registers"""
+    L = []
+    for j in range(0, 12, 2):
+        o = slot_dword + j
+        assert dst_regs[j + 1] == "v%d" % (int(dst_regs[j][1:]) + 1)
+        L.append("ds_read2st64_b32 v[%s:%s], %s offset0:%d offset1:%d" % (dst_regs[j][1:], dst_regs[j + 1][1:], LADDR, o, o + 1))
+    return L
+
+
+def lds_write_words(src_regs, slot_dword):
+    L = []
+    for j in range(0, 12, 2):
+        o = slot_dword + j
+        L.append("ds_write2st64_b32 %s, %s, %s offset0:%d offset1:%d" % (LADDR, src_regs[j], src_regs[j + 1], o, o + 1))
+    return L
+
+
+def lds_rw_digits(read, blk_or_regs, dword):
+    L = []
+    for j in range(0, 14, 2):
+        o = dword + j
+        if read:
+            L.append("ds_read2st64_b32 v[%d:%d], %s offset0:%d offset1:%d" % (blk_or_regs + j, blk_or_regs + j + 1, LADDR, o, o + 1))
+        else:
+            L.append("ds_write2st64_b32 %s, v%d, v%d offset0:%d offset1:%d" % (LADDR, blk_or_regs + j, blk_or_regs + j + 1, o, o + 1))
+    return L
+
+
+WAIT_LDS = ["s_waitcnt lgkmcnt(0)", "s_nop 0"]
+
+
+# ---------------------------------------------------------------------------------------------- the allocator
+class AllocD:
+    """Walks a Prog (tools/gen_tower_asm.py) and emits D-form code. Locations: ('v', blk), ('a', blk), ('l', k) = LDS digit slot k."""
+
+    def __init__(self, prog, in_bounds, n_lds=0, lds_base=0, a_pool=None):
+        self.p = prog
+        self.uses = {}
+        for k, (kind, outs, ins, aux) in enumerate(prog.ops):
+            for v in ins:
+                self.uses.setdefault(v, []).append(k)
+        self.loc = dict(prog.init_loc)
+        self.at = {l: v for v, l in self.loc.items()}
+        self.bound = dict(in_bounds)
+        self.out = []
+        self.pending_lds = False
+        self.n_lds, self.lds_base = n_lds, lds_base
+        self.a_pool = list(range(NA)) if a_pool is None else a_pool
+        self.stats = dict(vmov=0, acc=0, lds=0, arith=0, norm=0, reduce=0, calls=0, unpack=0)
+        # values whose live-in location is a packed LDS slot ('lp', s) keep it as a read-only home: evicting a register copy of
+        # such a value costs nothing, fetching it again is 6 LDS reads + the conversion into digits
+        self.home = {v: l for v, l in prog.init_loc.items() if l[0] == "lp"}
+        self.home_bound = {v: in_bounds[v] for v in self.home}
+
+    def next_use(self, v, k):
+        for u in self.uses.get(v, ()):
+            if u >= k:
+                return u
+        return INF
+
+    def place(self, v, l):
+        old = self.loc.get(v)
+        if old is not None and self.at.get(old) == v:
+            del self.at[old]
+        self.loc[v] = l
+        self.at[l] = v
+
+    def release(self, v):
+        l = self.loc.pop(v, None)
+        if l is not None and self.at.get(l) == v:
+            del self.at[l]
+
+    def e(self, s):
+        self.out.append(s)
+
+    def wait_lds(self):
+        if self.pending_lds:
+            for l in WAIT_LDS:
+                self.e(l)
+            self.pending_lds = False
+
+    def copy(self, src, dst):
+        (sk, sb), (dk, db) = src, dst
+        if sk == "v" and dk == "v":
+            for j in range(0, 14, 2):
+                self.e("v_mov_b64_e64 v[%d:%d], v[%d:%d]" % (vb(db) + j, vb(db) + j + 1, vb(sb) + j, vb(sb) + j + 1))
+            self.stats["vmov"] += 7
+        elif sk == "v" and dk == "a":
+            for j in range(14):
+                self.e("v_accvgpr_write_b32 a%d, v%d" % (vb(db) + j, vb(sb) + j))
+            self.stats["acc"] += 14
+        elif sk == "a" and dk == "v":
+            for j in range(14):
+                self.e("v_accvgpr_read_b32 v%d, a%d" % (vb(db) + j, vb(sb) + j))
+            self.stats["acc"] += 14
+        elif sk == "lp" and dk == "v":
+            reg = lambda j: "v%d" % (vb(db) + j)
+            self.wait_lds()
+            for l in lds_read_words([reg(j + 2) for j in range(12)], 12 * sb) + WAIT_LDS + seq_conv(reg, [reg(j + 2) for j in range(12)], False):
+                self.e(l)
+            self.stats["unpack"] += 30
+        elif sk == "l" and dk == "v":
+            for l in lds_rw_digits(True, vb(db), self.lds_base + 14 * sb):
+                self.e(l)
+            self.pending_lds = True
+            self.stats["lds"] += 7
+        elif sk == "v" and dk == "l":
+            for l in lds_rw_digits(False, vb(sb), self.lds_base + 14 * db):
+                self.e(l)
+            self.stats["lds"] += 7
+        else:
+            raise ValueError((src, dst))
+
+    def free_block(self, kind, pool, avoid=()):
+        for b in pool:
+            if (kind, b) not in self.at and b not in avoid:
+                return b
+        return None
+
+    def alloc_v(self, k, avoid=(), hint=None):
+        if hint is not None and ("v", hint) not in self.at and hint not in avoid:
+            return hint
+        b = self.free_block("v", ALL_V, avoid)
+        if b is not None:
+            return b
+        best, bu = None, -1
+        for blk in ALL_V:
+            if blk in avoid:
+                continue
+            w = self.at[("v", blk)]
+            u = self.next_use(w, k)
+            if u > bu:
+                best, bu = blk, u
+        assert best is not None, "no evictable block"
+        w = self.at[("v", best)]
+        if bu == INF:
+            self.release(w)
+            return best
+        self.spill(w)
+        return best
+
+    def spill(self, w):
+        src = self.loc[w]
+        if w in self.home:                                   # rematerialisable: drop the copy
+            self.place(w, self.home[w]); self.bound[w] = self.home_bound[w]; return
+        ab = self.free_block("a", self.a_pool)
+        if ab is not None:
+            self.copy(src, ("a", ab)); self.place(w, ("a", ab)); return
+        ls = self.free_block("l", range(self.n_lds))
+        if ls is None:
+            raise RuntimeError("out of storage")
+        self.copy(src, ("l", ls)); self.place(w, ("l", ls))
+
+    def to_vgpr(self, v, k, avoid=()):
+        l = self.loc[v]
+        if l[0] == "v":
+            return l[1]
+        b = self.alloc_v(k, avoid)
+        self.copy(l, ("v", b))
+        self.place(v, ("v", b))
+        return b
+
+    def hint_for(self, d, k):
+        u = self.next_use(d, k + 1)
+        if u == INF:
+            return None
+        for j in range(k + 1, u):
+            if self.p.ops[j][0] in ROUTINES:
+                return None
+        kind, outs, ins, aux = self.p.ops[u]
+        if kind in ROUTINES:
+            return ROUTINES[kind]["ins"][ins.index(d)]
+        return None
+
+    # ---- bound maintenance
+    def ensure(self, v, k, ok=None):
+        """carry pass on v (in place, in a VGPR block) if ok(bound) does not hold (always when ok is None); returns its block"""
+        b = self.to_vgpr(v, k)
+        if ok is None or not ok(self.bound[v]):
+            self.wait_lds()
+            for l in seq_norm(lambda j: "v%d" % (vb(b) + j)):
+                self.e(l)
+            self.stats["norm"] += 39
+            self.bound[v] = Bound.normalised(self.bound[v].vlo, self.bound[v].vhi)
+            assert ok is None or ok(self.bound[v]), ("operand cannot be brought inside the limit", self.bound[v])
+        return b
+
+    def run(self):
+        for k, (kind, outs, ins, aux) in enumerate(self.p.ops):
+            if kind in ("add", "sub", "sel"):
+                self.do_arith(k, kind, outs[0], ins[0], ins[1], aux)
+            elif kind == "pair":
+                a0, b0, a1, b1 = ins
+                self.do_arith(k, aux[0], outs[0], a0, b0, None, keep=(a1, b1))
+                self.do_arith(k, aux[1], outs[1], a1, b1, None)
+            elif kind == "const":
+                b = self.alloc_v(k, hint=self.hint_for(outs[0], k))
+                for j, d in enumerate(digits_of(aux)):
+                    self.e("v_mov_b32_e32 v%d, 0x%08x" % (vb(b) + j, d))
+                self.place(outs[0], ("v", b))
+                self.bound[outs[0]] = Bound(0, M28, aux >> 364, aux >> 364, aux, aux)
+            elif kind in ROUTINES:
+                self.do_call(k, kind, outs, ins)
+            elif kind == "store":
+                self.do_store(k, ins[0], aux)
+            elif kind == "reduce":
+                self.do_reduce(k, outs[0], ins[0])
+            elif kind == "keep":
+                for v in ins:
+                    assert self.loc[v] == self.p.init_loc[v], "pinned value moved"
+                continue
+            for v in set(ins):
+                if self.next_use(v, k + 1) == INF:
+                    self.release(v)
+        self.wait_lds()
+        return self.out
+
+    def do_arith(self, k, kind, d, a, b, aux, keep=()):
+        """keep: values that must survive this operation although their last use is the same program op (second half of a pair)"""
+        self.to_vgpr(a, k)
+        if b != a:
+            self.to_vgpr(b, k, avoid=(self.loc[a][1],))
+            if self.loc[a][0] != "v":                      # fetching b evicted a
+                self.to_vgpr(a, k, avoid=(self.loc[b][1],))
+        ba, bb = self.loc[a][1], self.loc[b][1]
+        Ba, Bb = self.bound[a], self.bound[b]
+        res = {"add": lambda: Ba + Bb, "sub": lambda: Ba - Bb, "sel": lambda: Ba.union(Bb)}[kind]
+        if not res().fits():                                # renormalise the larger operand(s) first
+            for v in sorted({a, b}, key=lambda x: -self.bound[x].mag()):
+                self.ensure(v, k)
+                Ba, Bb = self.bound[a], self.bound[b]
+                if res().fits():
+                    break
+            assert res().fits(), ("digit overflow", kind, Ba, Bb)
+        self.wait_lds()
+        avoid = tuple(self.loc[v][1] for v in keep if self.loc[v][0] == "v")
+        hint = self.hint_for(d, k)
+        bd = None
+        if hint is not None and hint not in (ba, bb) and hint not in avoid and ("v", hint) not in self.at:
+            bd = hint
+        if bd is None:
+            for v, blk in ((a, ba), (b, bb)):
+                if self.next_use(v, k + 1) == INF and v not in keep and blk not in avoid:
+                    bd = blk
+                    break
+        if bd is None:
+            bd = self.alloc_v(k, avoid=(ba, bb) + avoid)
+        D, A, B_ = vb(bd), vb(ba), vb(bb)
+        if kind == "add":
+            for j in range(14):
+                self.e("v_add_u32_e64 v%d, v%d, v%d" % (D + j, A + j, B_ + j))
+        elif kind == "sub":
+            for j in range(14):
+                self.e("v_sub_u32_e64 v%d, v%d, v%d" % (D + j, A + j, B_ + j))
+        else:                                               # sel: mask ? b : a
+            for j in range(14):
+                self.e("v_cndmask_b32_e64 v%d, v%d, v%d, %s" % (D + j, A + j, B_ + j, aux))
+        self.stats["arith"] += 14
+        for v in (a, b):
+            if self.loc.get(v) == ("v", bd):
+                self.release(v)
+        self.place(d, ("v", bd))
+        self.bound[d] = res()
+
+    def do_reduce(self, k, d, a):
+        b = self.to_vgpr(a, k)
+        self.wait_lds()
+        assert self.bound[a].vabs() < (P << 16), ("reduce: quotient estimate out of range", self.bound[a])
+        if self.next_use(a, k + 1) != INF:                  # the operand lives on: work on a copy
+            nb = self.alloc_v(k, avoid=(b,))
+            self.copy(("v", b), ("v", nb)); b = nb
+        else:
+            self.release(a)
+        for l in seq_reduce(lambda j: "v%d" % (vb(b) + j)):
+            self.e(l)
+        self.stats["reduce"] += 60
+        self.place(d, ("v", b))
+        self.bound[d] = REDUCED
+
+    def call_limits_ok(self, kind, B):
+        m = [x.mag() for x in B]
+        if kind == "mul":
+            return column_ok([(m[0], m[2]), (m[1], m[3])]) and column_ok([(m[0], m[3]), (m[1], m[2])])
+        if kind == "sqr":
+            s = B[0] + B[1]; dd = B[0] - B[1]
+            return s.fits() and dd.fits() and 2 * m[1] < (1 << 31) and column_ok([(s.mag(), dd.mag())]) and column_ok([(m[0], 2 * m[1])])
+        return column_ok([(m[0], m[2])]) and column_ok([(m[1], m[2])])
+
+    def do_call(self, k, kind, outs, ins):
+        R = ROUTINES[kind]
+        slots = R["ins"]
+        # 1. operand limits: renormalise the largest operand until the product columns fit
+        guard = 0
+        while not self.call_limits_ok(kind, [self.bound[v] for v in ins]):
+            v = max(ins, key=lambda x: (self.bound[x].mag(), -ins.index(x)))
+            before = self.bound[v].mag()
+            self.ensure(v, k)
+            guard += 1
+            assert self.bound[v].mag() < before or guard < 8, "cannot meet the routine's input limits"
+        want = {slots[i]: ins[i] for i in range(len(ins))}
+        clob = set(R["clob"])
+        # 2. vacate what the routine overwrites, and operand slots that hold something else
+        for s in sorted(clob | set(slots)):
+            w = self.at.get(("v", s))
+            if w is None or (s in want and want[s] == w):
+                continue
+            live = self.next_use(w, k) != INF
+            if not live:
+                self.release(w)
+                continue
+            u = self.next_use(w, k + 1 if w not in ins else k)
+            nk = self.p.ops[u][0] if u != INF else None
+            busy = clob | set(slots)
+            if w not in ins and nk in ROUTINES and self.free_block("a", self.a_pool) is not None:
+                self.spill(w)                                    # next consumed as a call operand: waits in an AGPR for free
+            else:
+                b = self.alloc_v(k, avoid=busy)
+                self.copy(("v", s), ("v", b)); self.place(w, ("v", b))
+        # 3. operands into their slots. The routines preserve blocks 0..3, so an operand that lives on simply stays tracked there.
+        for s, v in want.items():
+            if self.loc[v] == ("v", s):
+                continue
+            src = self.loc[v]
+            self.copy(src, ("v", s))
+            if src[0] != "v" or self.next_use(v, k + 1) == INF:
+                self.place(v, ("v", s))                          # moved (its old home is free again) ...
+            # ... or copied: the original stays where it was, the slot copy is untracked and dies with the next operand load
+        for s in slots[:len(ins)]:
+            w = self.at.get(("v", s))
+            assert w is None or w == want[s], "operand slot holds a foreign live value"
+        self.wait_lds()
+        self.e("CALL " + R["name"])
+        self.stats["calls"] += 1
+        for s in clob:
+            w = self.at.get(("v", s))
+            if w is not None:
+                assert self.next_use(w, k + 1) == INF, "live value in a clobbered block across a call"
+                self.release(w)
+        B = [self.bound[v] for v in ins]
+        if kind == "mul":
+            ob = [product_bound([(B[0], B[2]), (B[1], B[3])]), product_bound([(B[0], B[3]), (B[1], B[2])])]
+        elif kind == "sqr":
+            ob = [product_bound([(B[0] + B[1], B[0] - B[1])]), product_bound([(B[0], B[1] + B[1])])]
+        else:
+            ob = [product_bound([(B[0], B[2])]), product_bound([(B[1], B[2])])]
+        for i, o in enumerate(outs):
+            self.place(o, ("v", R["outs"][i]))
+            self.bound[o] = ob[i]
+
+    def do_store(self, k, a, dst):
+        """dst: ('a', blk) home; the stored value must satisfy the routine's live-in bound (checked by the caller of run())"""
+        w = self.at.get(dst)
+        if w is not None and w != a:
+            if not (isinstance(w, tuple)) and self.next_use(w, k + 1) != INF:
+                b = self.alloc_v(k, avoid=(self.loc[a][1],) if self.loc[a][0] == "v" else ())
+                self.copy(dst, ("v", b)); self.place(w, ("v", b))
+                self.wait_lds()
+            elif not isinstance(w, tuple):
+                self.release(w)
+        if self.loc[a] != dst:
+            b = self.to_vgpr(a, k)
+            self.wait_lds()
+            self.copy(("v", b), dst)
+        self.stored = getattr(self, "stored", {})
+        self.stored[dst] = self.bound[a]
+        if self.next_use(a, k + 1) == INF:
+            self.release(a)
+        self.at[dst] = ("stored", a)
+
+
+# ---------------------------------------------------------------------------------------------- programs
+def prog_reduce(p, a):
+    d = p.new(); p.ops.append(("reduce", [d], [a], None)); return d
+
+
+A_HOME = lambda i: ("a", i)
+
+
+def prog_cyc_sqr_d():
+    """Granger-Scott squaring in the cyclotomic subgroup (formulas of fp12_cyc_sqr in mbls_tower.h), state in AGPR blocks 0..11 in
+    tower order, in place. Every output re-enters the next squaring through the linear terms 3 t -+ 2 z, so each is reduced."""
+    p = Prog()
+    z = [(p.live_in(A_HOME(2 * e)), p.live_in(A_HOME(2 * e + 1))) for e in range(6)]
+    z0, z4, z3, z2, z1, z5 = z
+
+    def fp4_sqr(a, b):
+        t0 = p.sqr2(a); t1 = p.sqr2(b)
+        c0 = p.add2(p.mul_xi2(t1), t0)
+        s = p.sqr2(p.add2(a, b))
+        c1 = p.sub2(p.sub2(s, t0), t1)
+        return c0, c1
+
+    def out(v, e):
+        for i in range(2):
+            p.store(prog_reduce(p, v[i]), A_HOME(2 * e + i))
+    t0, t1 = fp4_sqr(z0, z1)
+    out(p.add2(p.dbl2(p.sub2(t0, z0)), t0), 0)
+    out(p.add2(p.dbl2(p.add2(t1, z1)), t1), 4)
+    t0, t1 = fp4_sqr(z2, z3)
+    t2, t3 = fp4_sqr(z4, z5)
+    out(p.add2(p.dbl2(p.sub2(t0, z4)), t0), 1)
+    out(p.add2(p.dbl2(p.add2(t1, z5)), t1), 5)
+    x = p.mul_xi2(t3)
+    out(p.add2(p.dbl2(p.add2(x, z2)), x), 3)
+    out(p.add2(p.dbl2(p.sub2(t2, z3)), t2), 2)
+    return p
+
+
+def build_cyc_sqr_d():
+    p = prog_cyc_sqr_d()
+    inb = {v: STATE_IN for v in p.init_loc}          # first round: canonical values from LDS; later rounds: reduced ones
+    al = AllocD(p, inb, n_lds=11, lds_base=0, a_pool=list(range(12, NA)))
+    body = al.run()
+    for dst, B in al.stored.items():
+        assert B.vlo >= REDUCED.vlo and B.vhi <= REDUCED.vhi and B.dlo >= 0 and B.dhi <= M28, (dst, B)
+    return body, al.stats
+
+
+def wrap_loop_d(lines, count_sgpr, prologue, epilogue):
+    back = ["s_sub_u32 %s, %s, 1" % (count_sgpr, count_sgpr), "s_cmp_lg_u32 %s, 0" % count_sgpr, "s_cbranch_scc0 2f",
+            "s_getpc_b64 s[66:67]", "3:", "s_sub_u32 s66, s66, 3b-1b", "s_subb_u32 s67, s67, 0", "s_setpc_b64 s[66:67]", "2:"]
+    return ["s_mov_b64 s[36:37], s[30:31]"] + shell_constants() + list(prologue) + [".p2align 6", "1:"] + lines + back + list(epilogue) + ["s_mov_b64 s[30:31], s[36:37]"]
+
+
+def expand_calls_d(lines):
+    out = []
+    for l in lines:
+        if l.startswith("CALL "):
+            sym = l.split()[1]
+            out += ["s_getpc_b64 s[66:67]", "s_add_u32 s66, s66, %s@rel32@lo+4" % sym, "s_addc_u32 s67, s67, %s@rel32@hi+12" % sym,
+                    "s_swappc_b64 s[30:31], s[66:67]"]
+        else:
+            out.append(l)
+    return out
+
+
+STATE_BLK = 8                       # VGPR block used by the shells for unpacking / packing
+
+
+def unpack_state(n, reduce_it):
+    """LDS packed slots 0..n-1 (12 words each, 2^392 domain, non-negative) -> AGPR homes 0..n-1 in D-form"""
+    L = []
+    reg = lambda j: "v%d" % (vb(STATE_BLK) + j)
+    for e in range(n):
+        L += lds_read_words([reg(j + 2) for j in range(12)], 12 * e) + WAIT_LDS
+        L += seq_conv(reg, [reg(j + 2) for j in range(12)], False)
+        if reduce_it:
+            L += seq_reduce(reg)
+        L += ["v_accvgpr_write_b32 a%d, %s" % (vb(e) + j, reg(j)) for j in range(14)]
+    return L
+
+
+def pack_state(n):
+    """AGPR homes 0..n-1 (reduced values: normalised digits, |value| < p) -> LDS packed slots, CANONICAL representatives in [0, p)"""
+    L = []
+    reg = lambda j: "v%d" % (vb(STATE_BLK) + j)
+    for e in range(n):
+        L += ["v_accvgpr_read_b32 %s, a%d" % (reg(j), vb(e) + j) for j in range(14)]
+        L += seq_canonical(reg) + seq_to32(reg)
+        L += lds_write_words([reg(j) for j in range(12)], 12 * e)
+    return L + WAIT_LDS
+
+
+def cyc_sqr_d_routine():
+    """s38 squarings of the Fp12 parked in LDS (12 packed values: canonical representatives of x 2^392, i.e. the 2^392 Montgomery
+    domain), in place. The first-generation Fp12 multiplication routine works on the same parked value unchanged: it divides by 2^384
+    and its other operand is in the 2^384 domain, so the product stays in the 2^392 domain."""
+    body, stats = build_cyc_sqr_d()
+    pro = ["s_mov_b32 s39, s38"] + unpack_state(12, False)
+    epi = pack_state(12)
+    return wrap_loop_d(expand_calls_d(body), "s39", pro, epi), body, stats, pro, epi
+
+
+def c_array(name, value):
+    return "MBLS_CONST uint32_t %s[12] = {%s};\n" % (name, ",".join("0x%08x" % ((value >> (32 * i)) & 0xFFFFFFFF) for i in range(12)))
+
+
+def main():
+    here = os.path.dirname(os.path.abspath(__file__))
+    path = os.path.join(os.path.dirname(here), "milagro_bls_amd", "csrc", "mbls_towerd_asm.inc")
+    txt = "// GENERATED by tools/gen_tower_d.py -- do not edit.\n"
+    txt += "// domain changes done by the callers with the 32-bit-limb fp_mul: x -> x 2^8 (into the 2^392 domain), x -> x / 2^8 (back)\n"
+    txt += c_array("MBLS_TO_D392", (1 << 392) % P) + c_array("MBLS_FROM_D392", (1 << 376) % P)
+    full, body, stats, _, _ = cyc_sqr_d_routine()
+    txt += emit("MBLS_CYC_SQR_D_ASM", full) + "\n"
+    print("cyc_sqr_d", len(body), "lines", stats)
+    sg = '"s30","s31","s36","s37","s39","s40","s41","s42","s43","s44","s45","s46","s47","s56","s57","s58","s59","s60","s61","s62","s63","s64","s65","s66","s67","s73","vcc","scc","memory"'
+    txt += "// everything a D-form tower routine may overwrite (v252 carries the LDS address and is preserved)\n"
+    txt += "#define MBLS_TOWERD_ASM_CLOBBERS %s,%s, \\\n    %s\n" % (",".join('"v%d"' % i for i in list(range(252)) + [253, 254, 255]), ",".join('"a%d"' % i for i in range(252)), sg)
+    with open(path, "w") as f:
+        f.write(txt)
+    print("wrote", path)
+
+
+if __name__ == "__main__":
+    main()
