@@ -19,7 +19,8 @@
 #include "../../include/mbls.h"
 
 #define MBLS_SLOT_S 25            // 6 Fp: Jacobian G2 accumulator for verify_multiple
-#define MBLS_SLOT_TOTAL 31
+#define MBLS_SLOT_T 31            // 12 Fp: the running points of the generated Miller loop (packed, 2^392 domain; tools/gen_tower_d.py T_SLOT)
+#define MBLS_SLOT_TOTAL 43
 #define WG 64
 // The pipeline kernels are built for one wave per SIMD (512 registers per lane): a batch of 2^16 items is exactly one wave
 // per SIMD on 256 CUs, and the hot loops are generated straight-line routines that already issue at the VALU rate with a
@@ -86,7 +87,7 @@ __global__ void MBLS_LB k_hash(mbls_ws ws, const uint8_t* msgs, uint32_t mlen, c
 __global__ void MBLS_LB k_miller(mbls_ws ws, uint64_t n) {
 #if !defined(MBLS_NO_LDS_STATE)
     // one wave per SIMD = 4 waves per CU: each wave can park 36 KB of loop state in LDS (144 of the 160 KB)
-    __shared__ uint32_t tstore[2 * 72 * 64];      // the two running points of each lane
+    __shared__ uint32_t tstore[154 * 64];         // 11 spill slots of 14 dwords per lane for the generated loop (the running points are in HBM)
     uint64_t i = gid(); if (i >= n) return;
     lane_miller(ws, i, (MBLS_LDS uint32_t*)tstore, threadIdx.x, true);
 #else

@@ -168,6 +168,46 @@ MBLS_FN void miller_loop_verify_lds(fp12* f_out, mbls_pair* pairs, MBLS_LDS uint
     }
     fp12_conj(f_out, &f);
 }
+#if !defined(MBLS_NO_DFORM)
+// Second generation (tools/gen_tower_d.py): the WHOLE loop -- 63 doubling iterations and the 5 addition steps of both pairs -- as one
+// generated routine on 14 signed 28-bit digits per value (bare product scans, carry-free additions, bounds tracked at generation
+// time). f lives in AGPRs; the running points, the fixed points Q_k and the second G1 argument live in the HBM workspace as packed
+// words and are fetched (prefetched, where a register block is free) when a step needs them, which leaves the whole LDS allocation
+// to the routine as spill space. No lane-private memory, no compiler-scheduled step inside the loop.
+extern "C" __device__ __attribute__((noinline, used, aligned(64))) void mbls_miller_loop_d_asm_fn() {
+    asm volatile(MBLS_MILLER_LOOP_D_ASM);
+}
+#define MBLS_MILLER_D_LDS_DWORDS (11 * 14)        // spill slots per lane
+#define MBLS_SLOT_QARG 0                          // workspace slots the routine reads: (-px, py, pz^3) of pair 1 over the aggregate key,
+#define MBLS_SLOT_Q1 7                            // Q1 in homogeneous form over the Jacobian H(m); slots 3..6 already hold Q0 = the signature
+MBLS_FN void miller_loop_verify_d(fp12* f_out, const mbls_pair* pairs, uint32_t* ws_w, uint64_t ws_stride, uint64_t item,
+                                  MBLS_LDS uint32_t* spill, uint32_t lane) {
+    uint32_t* w0 = ws_w + item;
+    const fp npx = fp_neg(pairs[1].p.px);
+    const fp* src[9] = {&npx, &pairs[1].p.py, &pairs[1].p.pz3, &pairs[1].q.x.c0, &pairs[1].q.x.c1, &pairs[1].q.y.c0, &pairs[1].q.y.c1, &pairs[1].q.z.c0, &pairs[1].q.z.c1};
+    const int slot[9] = {MBLS_SLOT_QARG, MBLS_SLOT_QARG + 1, MBLS_SLOT_QARG + 2, MBLS_SLOT_Q1, MBLS_SLOT_Q1 + 1, MBLS_SLOT_Q1 + 2, MBLS_SLOT_Q1 + 3, MBLS_SLOT_Q1 + 4, MBLS_SLOT_Q1 + 5};
+#pragma unroll
+    for (int t = 0; t < 9; t++) {
+        fp v = *src[t];
+#pragma unroll
+        for (int j = 0; j < 12; j++) w0[((uint64_t)slot[t] * 12 + j) * ws_stride] = v[j];
+    }
+    uint32_t flags = (pairs[0].skip ? 1u : 0u) | (pairs[1].skip ? 2u : 0u);
+    const uint32_t addr = (uint32_t)(uintptr_t)(spill + lane);
+    // the routine addresses word j of slot s as base + (12 s + j) * stride4 + v252: fold the item offset and the LDS address into the base
+    const uint64_t gb = (uint64_t)(uintptr_t)ws_w + 4ull * (item - lane) - (uint64_t)(uint32_t)(uintptr_t)spill;
+    const uint32_t gb_lo = __builtin_amdgcn_readfirstlane((uint32_t)gb), gb_hi = __builtin_amdgcn_readfirstlane((uint32_t)(gb >> 32));
+    const uint32_t st4 = __builtin_amdgcn_readfirstlane((uint32_t)(ws_stride * 4));
+    fp f0, f1, f2, f3, f4, f5, f6, f7, f8, f9, f10, f11;
+    asm volatile(MBLS_ASM_CALL("mbls_miller_loop_d_asm_fn")
+                 : MBLS_MILLER_D_OUT_REGS(f), "+{v253}"(flags)
+                 : "{v252}"(addr), "{s68}"(gb_lo), "{s69}"(gb_hi), "{s70}"(st4)
+                 : MBLS_MILLER_D_ASM_CLOBBERS);
+    fp12 f; fp* c = &f.c0.c0.c0;
+    c[0] = f0; c[1] = f1; c[2] = f2; c[3] = f3; c[4] = f4; c[5] = f5; c[6] = f6; c[7] = f7; c[8] = f8; c[9] = f9; c[10] = f10; c[11] = f11;
+    fp12_conj(f_out, &f);
+}
+#endif
 #else
 MBLS_FN void miller_loop_verify_lds(fp12* f, mbls_pair* pairs, MBLS_LDS uint32_t* tstore, uint32_t lane) {
     miller_loop_n<2, true>(f, pairs, tstore, lane, true);

@@ -21,6 +21,7 @@ class Machine:
         self.routines = routines or {}
         self.count = 0
         self.calls = 0
+        self.scc = 0
 
     # ---- operand helpers
     def rd(self, tok):
@@ -45,6 +46,8 @@ class Machine:
             return self.v[lo] | (self.v[lo + 1] << 32)
         if tok.startswith("0x"):
             return int(tok, 16)
+        if "." in tok:                               # inline floating-point constant
+            return f32_bits(float(tok))
         return int(tok) & M32
 
     def wr_carry(self, tok, val):
@@ -189,6 +192,26 @@ class Machine:
                 addr = self.rd(m.group(1))
                 o0, o1 = int(m.group(4) or 0), int(m.group(5) or 0)
                 self.lds[addr + o0 * 256] = self.rd(m.group(2)); self.lds[addr + o1 * 256] = self.rd(m.group(3))
+            elif op == "v_add_f32_e64":
+                self.wr(args[0], f32_bits(bits_f32(self.rd(args[1])) + bits_f32(self.rd(args[2]))))
+            elif op == "s_mul_i32":
+                self.wr(args[0], self.rd(args[1]) * self.rd(args[2]))
+            elif op == "s_mul_hi_u32":
+                self.wr(args[0], (self.rd(args[1]) * self.rd(args[2])) >> 32)
+            elif op == "s_add_u32":
+                t = self.rd(args[1]) + self.rd(args[2])
+                self.wr(args[0], t); self.scc = t >> 32
+            elif op == "s_addc_u32":
+                t = self.rd(args[1]) + self.rd(args[2]) + self.scc
+                self.wr(args[0], t); self.scc = t >> 32
+            elif op in ("global_load_dword", "global_store_dword"):
+                # global_load_dword vdst, voffset, s[lo:hi]  /  global_store_dword voffset, vdata, s[lo:hi]   (SADDR form)
+                m = re.fullmatch(r"s\[(\d+):(\d+)\]", args[2])
+                base = self.s[int(m.group(1))] | (self.s[int(m.group(2))] << 32)
+                if op == "global_load_dword":
+                    self.wr(args[0], self.mem[base + self.rd(args[1])])
+                else:
+                    self.mem[base + self.rd(args[0])] = self.rd(args[1])
             elif op in ("s_waitcnt", "s_nop"):
                 pass
             else:

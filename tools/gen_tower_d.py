@@ -93,6 +93,39 @@ REDUCED = Bound.normalised(-(P // 2) - (P >> 10), (P // 2) + (P >> 10))      # a
 
 
 STATE_IN = Bound.normalised(REDUCED.vlo, P)         # a loop-carried value: canonical on entry of a routine, reduced afterwards
+PACKED = Bound.normalised(P // 2 - (P >> 10), P + P // 2 + (P >> 10))      # a value parked in LDS by seq_pack_pass
+G_IN = Bound(0, M28, 0, M28, 0, (1 << 392) - 1)     # 12 words (2^384 domain) cut as digits of words * 2^8: the 2^392 domain, unreduced
+GBASE, GSTRIDE, GADDR, GT0, GT1 = "s[68:69]", "s70", "s[74:75]", "s76", "s77"   # HBM workspace: base (adjusted by the caller so that
+# LADDR is the lane offset), bytes between consecutive words of a value, running address, temporaries
+
+
+def seq_gaddr(slot):
+    return ["s_mul_i32 %s, %s, %d" % (GT0, GSTRIDE, 12 * slot), "s_mul_hi_u32 %s, %s, %d" % (GT1, GSTRIDE, 12 * slot),
+            "s_add_u32 s74, s68, %s" % GT0, "s_addc_u32 s75, s69, %s" % GT1]
+
+
+def seq_gstore(reg, slot):
+    """12 packed words in reg(0)..reg(11) -> workspace slot"""
+    L = seq_gaddr(slot)
+    for j in range(12):
+        L.append("global_store_dword %s, %s, %s" % (LADDR, reg(j), GADDR))
+        if j < 11:
+            L += ["s_add_u32 s74, s74, %s" % GSTRIDE, "s_addc_u32 s75, s75, 0"]
+    return L
+
+
+def seq_gload(reg, slot, aform=True):
+    """12 words of workspace slot `slot` (limb-major: word j of slot s at base + (12 s + j) * stride) into reg(2)..reg(13), then 14
+    digits into reg(0)..reg(13): of words * 2^8 (aform: a 2^384-domain value enters the 2^392 domain) or of the words themselves"""
+    L = seq_gaddr(slot)
+    for j in range(12):
+        L.append("global_load_dword %s, %s, %s" % (reg(j + 2), LADDR, GADDR))
+        if j < 11:
+            L += ["s_add_u32 s74, s74, %s" % GSTRIDE, "s_addc_u32 s75, s75, 0"]
+    if aform is None:                                # issue only: the caller waits and converts later (prefetch)
+        return L
+    L += ["s_waitcnt vmcnt(0)", "s_nop 0"]
+    return L + seq_conv(reg, [reg(j + 2) for j in range(12)], aform)
 
 
 # ---------------------------------------------------------------------------------------------- instruction sequences
@@ -167,6 +200,13 @@ def seq_reduce(reg):
     unnormalised lower digits and the lower digits of p move the estimate by < 2e-4)"""
     return seq_qpass(reg, ["v_cvt_f32_i32_e64 %s, %s" % (NQ, reg(13)), "v_mul_f32_e64 %s, %s, %s" % (NQ, RECIP_PTOP_S, NQ), "v_rndne_f32_e64 %s, %s" % (NQ, NQ),
                            "v_cvt_i32_f32_e64 %s, %s" % (NQ, NQ), "v_sub_u32_e64 %s, 0, %s" % (NQ, NQ)])
+
+
+def seq_pack_pass(reg):
+    """any value -> the representative in (0.5 p, 1.5 p), digits normalised (q = rndne(estimate - 1)): positive and below 2^384, which is
+    what packing into 12 words needs; one pass, no sign test"""
+    return seq_qpass(reg, ["v_cvt_f32_i32_e64 %s, %s" % (NQ, reg(13)), "v_mul_f32_e64 %s, %s, %s" % (NQ, RECIP_PTOP_S, NQ), "v_add_f32_e64 %s, -1.0, %s" % (NQ, NQ),
+                           "v_rndne_f32_e64 %s, %s" % (NQ, NQ), "v_cvt_i32_f32_e64 %s, %s" % (NQ, NQ), "v_sub_u32_e64 %s, 0, %s" % (NQ, NQ)])
 
 
 def seq_canonical(reg):
@@ -244,7 +284,7 @@ class AllocD:
         self.stats = dict(vmov=0, acc=0, lds=0, arith=0, norm=0, reduce=0, calls=0, unpack=0)
         # values whose live-in location is a packed LDS slot ('lp', s) keep it as a read-only home: evicting a register copy of
         # such a value costs nothing, fetching it again is 6 LDS reads + the conversion into digits
-        self.home = {v: l for v, l in prog.init_loc.items() if l[0] == "lp"}
+        self.home = {v: l for v, l in prog.init_loc.items() if l[0] in ("lp", "g", "gd")}
         self.home_bound = {v: in_bounds[v] for v in self.home}
 
     def next_use(self, v, k):
@@ -294,6 +334,12 @@ class AllocD:
             for l in lds_read_words([reg(j + 2) for j in range(12)], 12 * sb) + WAIT_LDS + seq_conv(reg, [reg(j + 2) for j in range(12)], False):
                 self.e(l)
             self.stats["unpack"] += 30
+        elif sk in ("g", "gd") and dk == "v":
+            reg = lambda j: "v%d" % (vb(db) + j)
+            self.wait_lds()
+            for l in seq_gload(reg, sb, aform=(sk == "g")):
+                self.e(l)
+            self.stats["unpack"] += 60
         elif sk == "l" and dk == "v":
             for l in lds_rw_digits(True, vb(db), self.lds_base + 14 * sb):
                 self.e(l)
@@ -308,16 +354,26 @@ class AllocD:
 
     def free_block(self, kind, pool, avoid=()):
         for b in pool:
-            if (kind, b) not in self.at and b not in avoid:
+            if (kind, b) not in self.at and b not in avoid and not (kind == "v" and ("vw", b) in self.at):
                 return b
         return None
 
+    def drop_prefetch(self, b):
+        """a block that only holds prefetched words of a value with a home can be taken at any time"""
+        w = self.at.pop(("vw", b), None)
+        if w is not None:
+            self.loc[w] = self.home[w]
+
     def alloc_v(self, k, avoid=(), hint=None):
-        if hint is not None and ("v", hint) not in self.at and hint not in avoid:
+        if hint is not None and ("v", hint) not in self.at and ("vw", hint) not in self.at and hint not in avoid:
             return hint
         b = self.free_block("v", ALL_V, avoid)
         if b is not None:
             return b
+        for blk in ALL_V:                                   # prefetched words are the cheapest thing to give up
+            if blk not in avoid and ("vw", blk) in self.at:
+                self.drop_prefetch(blk)
+                return blk
         best, bu = None, -1
         for blk in ALL_V:
             if blk in avoid:
@@ -350,6 +406,14 @@ class AllocD:
         l = self.loc[v]
         if l[0] == "v":
             return l[1]
+        if l[0] == "vw":                                    # words prefetched into this block: wait for them, cut them into digits
+            reg = lambda j: "v%d" % (vb(l[1]) + j)
+            for x in ["s_waitcnt vmcnt(0)", "s_nop 0"] + seq_conv(reg, [reg(j + 2) for j in range(12)], self.home[v][0] == "g"):
+                self.e(x)
+            del self.at[l]
+            self.loc[v] = ("v", l[1]); self.at[("v", l[1])] = v
+            self.bound[v] = self.home_bound[v]
+            return l[1]
         b = self.alloc_v(k, avoid)
         self.copy(l, ("v", b))
         self.place(v, ("v", b))
@@ -366,6 +430,26 @@ class AllocD:
         if kind in ROUTINES:
             return ROUTINES[kind]["ins"][ins.index(d)]
         return None
+
+    def prefetch(self, k, horizon=3):
+        """before a multiplication call: issue the HBM loads of values that the next few operations need and that only live in their
+        workspace home, into free blocks outside the routines' window (no eviction: a prefetch must not cost a spill)"""
+        calls, j = 0, k + 1
+        while j < len(self.p.ops) and calls < horizon:
+            kind, outs, ins, aux = self.p.ops[j]
+            for v in ins:
+                if self.loc.get(v, ("", 0))[0] in ("g", "gd") and v in self.home:
+                    b = self.free_block("v", FREE_V)
+                    if b is None:
+                        return
+                    reg = lambda q, b=b: "v%d" % (vb(b) + q)
+                    for x in seq_gload(reg, self.home[v][1], aform=None):
+                        self.e(x)
+                    self.loc[v] = ("vw", b); self.at[("vw", b)] = v
+                    self.stats["unpack"] += 40
+            if kind in ROUTINES:
+                calls += 1
+            j += 1
 
     # ---- bound maintenance
     def ensure(self, v, k, ok=None):
@@ -400,6 +484,10 @@ class AllocD:
                 self.do_store(k, ins[0], aux)
             elif kind == "reduce":
                 self.do_reduce(k, outs[0], ins[0])
+            elif kind == "norm":
+                self.do_norm(k, outs[0], ins[0])
+            elif kind == "storep":
+                self.do_storep(k, ins[0], aux)
             elif kind == "keep":
                 for v in ins:
                     assert self.loc[v] == self.p.init_loc[v], "pinned value moved"
@@ -472,6 +560,41 @@ class AllocD:
         self.place(d, ("v", b))
         self.bound[d] = REDUCED
 
+    def do_norm(self, k, d, a):
+        """explicit carry pass (a loop-carried value must meet its live-in bound)"""
+        b = self.to_vgpr(a, k)
+        self.wait_lds()
+        if self.next_use(a, k + 1) != INF:
+            nb = self.alloc_v(k, avoid=(b,))
+            self.copy(("v", b), ("v", nb)); b = nb
+        else:
+            self.release(a)
+        for l in seq_norm(lambda j: "v%d" % (vb(b) + j)):
+            self.e(l)
+        self.stats["norm"] += 39
+        self.place(d, ("v", b))
+        self.bound[d] = Bound.normalised(self.bound[a].vlo, self.bound[a].vhi)
+
+    def do_storep(self, k, a, slot):
+        """value -> workspace slot, packed (representative in (0.5 p, 1.5 p), 12 words, 2^392 domain); values that still call this
+        slot home are fetched first"""
+        for w in [w for w, h in self.home.items() if h == ("gd", slot)]:
+            if w != a and self.next_use(w, k + 1) != INF and self.loc.get(w) == ("gd", slot):
+                self.to_vgpr(w, k)
+            del self.home[w]
+        b = self.to_vgpr(a, k)
+        self.wait_lds()
+        if self.next_use(a, k + 1) != INF:
+            nb = self.alloc_v(k, avoid=(b,))
+            self.copy(("v", b), ("v", nb)); b = nb
+        else:
+            self.release(a)
+        assert self.bound[a].vabs() < (P << 16)
+        reg = lambda j: "v%d" % (vb(b) + j)
+        for l in seq_pack_pass(reg) + seq_to32(reg) + seq_gstore(reg, slot):
+            self.e(l)
+        self.stats["reduce"] += 62 + 21 + 38
+
     def call_limits_ok(self, kind, B):
         m = [x.mag() for x in B]
         if kind == "mul":
@@ -515,6 +638,8 @@ class AllocD:
         for s, v in want.items():
             if self.loc[v] == ("v", s):
                 continue
+            if self.loc[v][0] == "vw":
+                self.to_vgpr(v, k)
             src = self.loc[v]
             self.copy(src, ("v", s))
             if src[0] != "v" or self.next_use(v, k + 1) == INF:
@@ -524,6 +649,7 @@ class AllocD:
             w = self.at.get(("v", s))
             assert w is None or w == want[s], "operand slot holds a foreign live value"
         self.wait_lds()
+        self.prefetch(k)
         self.e("CALL " + R["name"])
         self.stats["calls"] += 1
         for s in clob:
@@ -666,6 +792,190 @@ def cyc_sqr_d_routine():
     return wrap_loop_d(expand_calls_d(body), "s39", pro, epi), body, stats, pro, epi
 
 
+# ---------------------------------------------------------------------------------------------- the Miller loop
+G1_X = 0x17f1d3a73197d7942695638c4fa9ac0fc3688c4f9774b905a14e3a3f171bac586c55e83ff97a1aeffb3af00adb22c6bb
+G1_Y = 0x08b3f481e3aaa0f1a09e30ed741d8ae4fcf5e095d5d00af600db18cb2c04b3edd03cc744a2888ae40caa232946c5e7e1
+ONE_D = R392 % P                                   # 1, x, -x, y ... as 2^392-domain constants
+NPX0_D = (P - G1_X) * R392 % P                     # pair 0 of a verification is (signature, -G1): the line needs -px and py of -G1
+PY0_D = (P - G1_Y) * R392 % P
+F_HOME = [("a", i) for i in range(12)]             # the Miller value between iterations, tower order
+P1_HOME = [("g", i) for i in range(3)]             # -px, py, pz^3 of the second pair's G1 argument: workspace slots 0..2 (the caller
+# writes them over the aggregate key), 2^384 domain
+SKIP_MASK = ["s[48:49]", "s[54:55]"]               # lanes whose pair contributes 1 (a member is infinity)
+T_SLOT = lambda k, e, i: 31 + 6 * k + 2 * e + i    # workspace slot of coordinate e (x, y, z) / component i of running point k (packed, 2^392 domain)
+# workspace slots (mbls_lanes.h) of the fixed points Q_k: the signature's affine x, y (slots 3..6) and H(m) in homogeneous form, which
+# the caller writes over the Jacobian H in slots 7..12 before the loop
+Q_SLOT = [[(3, 4), (5, 6), None], [(7, 8), (9, 10), (11, 12)]]
+F_IN = Bound.normalised(-16 * P, 16 * P)          # a coefficient of the Miller value between rounds: carry-normalised, a few p wide
+
+
+def prog_norm(p, a):
+    d = p.new(); p.ops.append(("norm", [d], [a], None)); return d
+
+
+def storep2(p, a, k, e):
+    for i in range(2):
+        p.ops.append(("storep", [], [a[i]], T_SLOT(k, e, i)))
+
+
+def line_into_f(p, f, c0, c2, c3, k):
+    m = SKIP_MASK[k]
+    c0 = (p.sel(m, c0[0], p.const(ONE_D)), p.sel(m, c0[1], p.const(0)))
+    c2 = (p.sel(m, c2[0], p.const(0)), p.sel(m, c2[1], p.const(0)))
+    c3 = (p.sel(m, c3[0], p.const(0)), p.sel(m, c3[1], p.const(0)))
+    return p.mul12_line(f, c0, c2, c3)
+
+
+def f_live_in(p):
+    fl = [p.live_in(h) for h in F_HOME]
+    return ([(fl[0], fl[1]), (fl[2], fl[3]), (fl[4], fl[5])], [(fl[6], fl[7]), (fl[8], fl[9]), (fl[10], fl[11])])
+
+
+def f_store(p, f):
+    for v, h in zip([x for half in f for c in half for x in c], F_HOME):
+        p.store(prog_norm(p, v), h)
+
+
+def prog_miller_dbl_d():
+    """One doubling iteration of the two-pair (verification-shape) Miller loop: f <- f^2, then for each pair T <- 2T and f <- f * line
+    (formulas of miller_dbl_step / fp12_sqr / fp12_mul_line in mbls_pairing.h / mbls_tower.h). f in AGPR homes; the running points and
+    the second G1 argument live in the HBM workspace as packed words (fetched when needed, the points written back at the end of their
+    step), which leaves the whole LDS allocation to the allocator as spill space."""
+    p = Prog()
+    f = f_live_in(p)
+    p1 = [p.live_in(h) for h in P1_HOME]
+    f = p.sqr12(f)
+    for k in range(2):
+        Tx, Ty, Tz = [(p.live_in(("gd", T_SLOT(k, e, 0))), p.live_in(("gd", T_SLOT(k, e, 1)))) for e in range(3)]
+        B = p.sqr2(Ty); C = p.sqr2(Tz)
+        E = p.mul12_2(p.mul_xi2(C))
+        F = p.mul3_2(E)
+        X2 = p.sqr2(Tx)
+        YZ = p.mul2(Ty, Tz)
+        c0 = p.sub2(B, E)
+        if k == 0:
+            c2 = p.mulfp2(p.mul3_2(X2), p.const(NPX0_D))
+            c3 = p.mulfp2(p.dbl2(YZ), p.const(PY0_D))
+        else:
+            c0 = p.mulfp2(c0, p1[2])
+            c2 = p.mulfp2(p.mul3_2(X2), p1[0])
+            c3 = p.mulfp2(p.dbl2(YZ), p1[1])
+        x3 = p.dbl2(p.mul2(p.mul2(Tx, Ty), p.sub2(B, F)))
+        y3 = p.sub2(p.sqr2(p.add2(B, F)), p.mul12_2(p.sqr2(E)))
+        z3 = p.mul8_2(p.mul2(B, YZ))
+        for e, v in enumerate((x3, y3, z3)):
+            storep2(p, v, k, e)
+        f = line_into_f(p, f, c0, c2, c3, k)
+    f_store(p, f)
+    return p
+
+
+def prog_miller_add_d(k):
+    """The addition step T_k <- T_k + Q_k, f <- f * line for ONE pair (formulas of miller_add_step in mbls_pairing.h). Q_k comes from the
+    HBM workspace (2^384 domain, converted on the way in); pair 0's Q is affine and its G1 argument the constant -G1."""
+    p = Prog()
+    f = f_live_in(p)
+    p1 = [p.live_in(h) for h in P1_HOME]
+    Tx, Ty, Tz = [(p.live_in(("gd", T_SLOT(k, e, 0))), p.live_in(("gd", T_SLOT(k, e, 1)))) for e in range(3)]
+    Q = [None if sl is None else (p.live_in(("g", sl[0])), p.live_in(("g", sl[1]))) for sl in Q_SLOT[k]]
+    Qx, Qy, Qz = Q
+    if Qz is None:                                   # affine Q: Z2 = 1
+        y1z2, x1z2, z1z2 = Ty, Tx, Tz
+    else:
+        y1z2, x1z2, z1z2 = p.mul2(Ty, Qz), p.mul2(Tx, Qz), p.mul2(Tz, Qz)
+    u = p.sub2(p.mul2(Qy, Tz), y1z2)
+    v = p.sub2(p.mul2(Qx, Tz), x1z2)
+    c0 = p.sub2(p.mul2(u, Qx), p.mul2(v, Qy))
+    if Qz is None:
+        c2 = p.mulfp2(u, p.const(NPX0_D))            # -u Z2 xP with Z2 = 1, -xP a constant
+        c3 = p.mulfp2(v, p.const(PY0_D))
+    else:
+        c0 = p.mulfp2(c0, p1[2])
+        c2 = p.mulfp2(p.mul2(u, Qz), p1[0])
+        c3 = p.mulfp2(p.mul2(v, Qz), p1[1])
+    uu = p.sqr2(u); vv = p.sqr2(v)
+    vvv = p.mul2(v, vv); R = p.mul2(vv, x1z2)
+    A = p.sub2(p.sub2(p.mul2(uu, z1z2), vvv), p.dbl2(R))
+    x3 = p.mul2(v, A)
+    y3 = p.sub2(p.mul2(u, p.sub2(R, A)), p.mul2(vvv, y1z2))
+    z3 = p.mul2(vvv, z1z2)
+    for e, w in enumerate((x3, y3, z3)):
+        storep2(p, w, k, e)
+    f = line_into_f(p, f, c0, c2, c3, k)
+    f_store(p, f)
+    return p
+
+
+def build_miller(which):
+    p = prog_miller_dbl_d() if which == "dbl" else prog_miller_add_d(which)
+    inb = {}
+    for v, l in p.init_loc.items():
+        inb[v] = PACKED if l[0] == "gd" else G_IN if l[0] == "g" else F_IN
+    al = AllocD(p, inb, n_lds=11, lds_base=0, a_pool=list(range(NA)))
+    body = al.run()
+    for dst, B in al.stored.items():
+        assert B.dlo >= F_IN.dlo and B.dhi <= F_IN.dhi and B.vlo >= F_IN.vlo and B.vhi <= F_IN.vhi and B.tlo >= F_IN.tlo and B.thi <= F_IN.thi, (dst, B)
+    return body, al.stats
+
+
+K384 = (1 << 384) % P                              # multiplying by it in the 2^392 domain leaves a 2^384-domain value
+F_OUT = [108 + 12 * i for i in range(12)]          # register groups (12 words each) in which the Miller routine returns f
+RUNS = [1, 2, 3, 9, 32, 16]                        # doubling iterations between the additions: |x| = 0xd201000000010000, bits 62..0
+
+
+def far_back(label):
+    """jump to an earlier numeric label from anywhere (the bodies exceed the reach of s_cbranch)"""
+    return ["s_getpc_b64 s[66:67]", "7:", "s_sub_u32 s66, s66, 7b-%db" % label, "s_subb_u32 s67, s67, 0", "s_setpc_b64 s[66:67]"]
+
+
+def miller_loop_d_routine():
+    """The whole two-pair Miller loop of a verification as ONE routine: f = prod_k f_{|x|,Q_k}(P_k) (the caller conjugates).
+    In:  v252 LDS byte address of the lane's column (11 spill slots), v253 skip flags (bit k: pair k contributes 1),
+         s[68:69] workspace base adjusted so that v252 is the lane offset, s70 bytes between consecutive words of a value;
+         workspace slots 0..2 = (-px, py, pz^3) of pair 1, 3..6 = Q0 (affine x, y), 7..12 = Q1 (homogeneous x, y, z), 2^384 domain.
+    Out: f in v108..v251 (twelve groups of 12 words, tower order, canonical, 2^384 domain). Workspace slots 31..42 are scratch."""
+    dbl, st_dbl = build_miller("dbl")
+    add0, st_a0 = build_miller(0)
+    add1, st_a1 = build_miller(1)
+    W = lambda j: "v%d" % (vb(8) + j)              # work block of the shell
+    pro = ["s_mov_b64 s[36:37], s[30:31]", "s_waitcnt vmcnt(0)"] + shell_constants()
+    pro += ["v_and_b32_e64 v254, 1, v253", "v_cmp_ne_u32_e64 %s, 0, v254" % SKIP_MASK[0], "v_and_b32_e64 v254, 2, v253", "v_cmp_ne_u32_e64 %s, 0, v254" % SKIP_MASK[1]]
+    for i in range(12):                             # f = 1
+        for j, dgt in enumerate(digits_of(ONE_D if i == 0 else 0)):
+            pro += ["v_mov_b32_e32 v254, 0x%08x" % dgt, "v_accvgpr_write_b32 a%d, v254" % (vb(i) + j)]
+    for k in range(2):                              # T_k = Q_k, into the packed 2^392-domain slots
+        for e in range(3):
+            for i in range(2):
+                sl = Q_SLOT[k][e]
+                if sl is None:
+                    pro += ["v_mov_b32_e32 %s, 0x%08x" % (W(j), dgt) for j, dgt in enumerate(digits_of(ONE_D if i == 0 else 0))]
+                else:
+                    pro += seq_gload(W, sl[i], True)
+                pro += seq_pack_pass(W) + seq_to32(W) + seq_gstore(W, T_SLOT(k, e, i))
+    pro += ["s_waitcnt vmcnt(0)", "s_mov_b32 s78, 0"]
+    top = ["4:", "s_mov_b32 s39, %d" % RUNS[5]]
+    for ph in range(5):
+        top += ["s_cmp_eq_u32 s78, %d" % ph, "s_cselect_b32 s39, %d, s39" % RUNS[ph]]
+    main = top + [".p2align 6", "1:"] + expand_calls_d(dbl)
+    main += ["s_sub_u32 s39, s39, 1", "s_cmp_lg_u32 s39, 0", "s_cbranch_scc0 2f"] + far_back(1) + ["2:"]
+    main += ["s_cmp_eq_u32 s78, 5", "s_cbranch_scc1 9f"]
+    main += expand_calls_d(add0) + expand_calls_d(add1)
+    main += ["s_add_u32 s78, s78, 1"] + far_back(4) + ["9:"]
+    epi = []
+    B0, B1, B2, B5, B6 = (lambda j: "v%d" % j), (lambda j: "v%d" % (14 + j)), (lambda j: "v%d" % (28 + j)), (lambda j: "v%d" % (70 + j)), (lambda j: "v%d" % (84 + j))
+    epi += ["v_mov_b32_e32 %s, 0x%08x" % (B2(j), dgt) for j, dgt in enumerate(digits_of(K384))]
+    for i in range(6):                              # pairs of coefficients: (x 2^392)(2^384) / 2^392 = x 2^384, then the canonical words
+        epi += ["v_accvgpr_read_b32 %s, a%d" % (B0(j), vb(2 * i) + j) for j in range(14)]
+        epi += ["v_accvgpr_read_b32 %s, a%d" % (B1(j), vb(2 * i + 1) + j) for j in range(14)]
+        epi += ["CALL mbls_fp2_mulfp_d_asm_fn"]
+        for h, B in ((0, B5), (1, B6)):
+            epi += seq_reduce(B) + seq_canonical(B) + seq_to32(B)
+            epi += ["v_mov_b32_e64 v%d, %s" % (F_OUT[2 * i + h] + j, B(j)) for j in range(12)]
+    epi += ["s_mov_b64 s[30:31], s[36:37]"]
+    pieces = dict(pro=pro, dbl=dbl, add0=add0, add1=add1, epi=epi)
+    return pro + main + expand_calls_d(epi), pieces, dict(dbl=st_dbl, add0=st_a0, add1=st_a1)
+
+
 def c_array(name, value):
     return "MBLS_CONST uint32_t %s[12] = {%s};\n" % (name, ",".join("0x%08x" % ((value >> (32 * i)) & 0xFFFFFFFF) for i in range(12)))
 
@@ -679,6 +989,16 @@ def main():
     full, body, stats, _, _ = cyc_sqr_d_routine()
     txt += emit("MBLS_CYC_SQR_D_ASM", full) + "\n"
     print("cyc_sqr_d", len(body), "lines", stats)
+    full, pieces, st = miller_loop_d_routine()
+    txt += emit("MBLS_MILLER_LOOP_D_ASM", full) + "\n"
+    for kname, v in st.items():
+        print("miller", kname, len(pieces[kname]), "lines", v)
+    sgm = '"s30","s31","s36","s37","s39","s40","s41","s42","s43","s44","s45","s46","s47","s48","s49","s54","s55","s56","s57","s58","s59","s60","s61","s62","s63","s64","s65","s66","s67","s73","s74","s75","s76","s77","s78","vcc","scc","memory"'
+    fout = set(r for b in F_OUT for r in range(b, b + 12))
+    txt += "// the Miller-loop routine returns f in twelve register groups\n"
+    txt += "#define MBLS_MILLER_D_OUT_REGS(x) " + ", ".join('"={v[%d:%d]}"(x##%d)' % (b, b + 11, i) for i, b in enumerate(F_OUT)) + "\n"
+    txt += "#define MBLS_MILLER_D_ASM_CLOBBERS %s,%s, \\\n    %s\n" % (
+        ",".join('"v%d"' % i for i in range(256) if i not in fout and i != 252 and i != 253), ",".join('"a%d"' % i for i in range(252)), sgm)
     sg = '"s30","s31","s36","s37","s39","s40","s41","s42","s43","s44","s45","s46","s47","s56","s57","s58","s59","s60","s61","s62","s63","s64","s65","s66","s67","s73","vcc","scc","memory"'
     txt += "// everything a D-form tower routine may overwrite (v252 carries the LDS address and is preserved)\n"
     txt += "#define MBLS_TOWERD_ASM_CLOBBERS %s,%s, \\\n    %s\n" % (",".join('"v%d"' % i for i in list(range(252)) + [253, 254, 255]), ",".join('"a%d"' % i for i in range(252)), sg)
