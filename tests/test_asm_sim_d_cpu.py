@@ -154,3 +154,212 @@ def test_generated_d_files_up_to_date():
         before = open(inc).read()
         subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", script)], stdout=subprocess.DEVNULL)
         assert open(inc).read() == before, name
+
+
+# ---------------------------------------------------------------------------------------------- the Miller loop and the G2 doubling runs
+# The programs of tools/gen_tower_d.py are executed twice: by the allocator (-> instructions, interpreted by asm_sim) and by ModelProg,
+# which implements the same Prog interface on true field values. Agreement checks the allocator, the bound tracking (no 32-bit /
+# 64-bit overflow is possible: the simulator asserts), the packing / HBM fetch sequences and the shells.
+from gen_tower_asm import Prog   # noqa: E402
+
+R392, R384 = 1 << 392, 1 << 384
+RI392 = pow(R392, -1, P)
+
+
+class _Ops(list):
+    def __init__(self, owner):
+        super().__init__(); self.o = owner
+
+    def append(self, op):
+        kind, outs, ins, aux = op
+        if kind in ("norm", "reduce"):
+            self.o.val[outs[0]] = self.o.val[ins[0]]
+        elif kind == "storep":
+            self.o.out_g[aux] = self.o.val[ins[0]]
+        else:
+            raise ValueError(kind)
+
+
+class ModelProg(Prog):
+    def __init__(self, init, masks):
+        self.val, self.nval, self.init, self.masks, self.out_g, self.out_home, self.init_loc = {}, 0, init, masks, {}, {}, {}
+        self.ops = _Ops(self)
+
+    def new(self):
+        self.nval += 1; return self.nval - 1
+
+    def live_in(self, loc):
+        v = self.new(); self.val[v] = self.init[loc] % P; self.init_loc[v] = loc; return v
+
+    def add(self, a, b):
+        d_ = self.new(); self.val[d_] = (self.val[a] + self.val[b]) % P; return d_
+
+    def sub(self, a, b):
+        d_ = self.new(); self.val[d_] = (self.val[a] - self.val[b]) % P; return d_
+
+    def const(self, c):
+        d_ = self.new(); self.val[d_] = c * RI392 % P; return d_
+
+    def sel(self, mask, a, b):
+        d_ = self.new(); self.val[d_] = self.val[b] if self.masks[mask] else self.val[a]; return d_
+
+    def pair(self, k0, a0, b0, k1, a1, b1):
+        f = {"add": self.add, "sub": self.sub}
+        return (f[k0](a0, b0), f[k1](a1, b1))
+
+    def call(self, kind, ins):
+        x = [self.val[i] for i in ins]; o = (self.new(), self.new())
+        if kind == "mul":
+            r = ((x[0] * x[2] - x[1] * x[3]) % P, (x[0] * x[3] + x[1] * x[2]) % P)
+        elif kind == "sqr":
+            r = ((x[0] * x[0] - x[1] * x[1]) % P, (2 * x[0] * x[1]) % P)
+        else:
+            r = (x[0] * x[2] % P, x[1] * x[2] % P)
+        self.val[o[0]], self.val[o[1]] = r
+        return o
+
+    def store(self, a, loc):
+        self.out_home[loc] = self.val[a]
+
+    def keep(self, vals):
+        pass
+
+
+def run_model(progf, init, masks):
+    mp = ModelProg(init, masks)
+    saved = t.Prog
+    t.Prog = lambda: mp
+    try:
+        progf()
+    finally:
+        t.Prog = saved
+    return mp
+
+
+STRIDE, GBASE, LADDR = 4096, 0x7F0000001000, 8192
+
+
+def ws_addr(slot, j):
+    return GBASE + ((slot * 12 + j) * STRIDE) * 4 + LADDR      # the caller folds (item offset - LADDR) into the base
+
+
+def ws_put(m, slot, x):
+    for j, w in enumerate(limbs(x)):
+        m.mem[ws_addr(slot, j)] = w
+
+
+def ws_get(m, slot):
+    return from_limbs([m.mem[ws_addr(slot, j)] for j in range(12)])
+
+
+def normalised_digits(x):
+    dd = [(x >> (28 * i)) & 0xFFFFFFF for i in range(13)]
+    return [v & 0xFFFFFFFF for v in dd + [(x - sum(v << (28 * i) for i, v in enumerate(dd))) >> 364]]
+
+
+def miller_machine(masks_bits):
+    m = Machine(ROUT); m.v[252] = LADDR; m.v[253] = masks_bits
+    m.s[68] = GBASE & 0xFFFFFFFF; m.s[69] = GBASE >> 32; m.s[70] = STRIDE * 4
+    return m
+
+
+@pytest.mark.parametrize("which", ["dbl", 0, 1])
+def test_miller_bodies(which):
+    """one doubling iteration / one addition step per pair from random state at the edges of the declared bounds, with and without skipped pairs"""
+    rng = random.Random(11)
+    body, _ = t.build_miller(which)
+    progf = t.prog_miller_dbl_d if which == "dbl" else (lambda: t.prog_miller_add_d(which))
+    for trial in range(3):
+        masks = {"s[48:49]": 1 if trial == 1 else 0, "s[54:55]": 1 if trial == 2 else 0}
+        m = miller_machine(0); m.run(t.shell_constants())
+        m.s[("pair", 48)] = masks["s[48:49]"]; m.s[("pair", 54)] = masks["s[54:55]"]
+        init = {}
+        for i in range(12):
+            x = rng.randrange(P); rep = (x * R392 % P) + rng.choice([-15, -1, 0, 14]) * P
+            init[("a", i)] = x; m.a[14 * i:14 * i + 14] = normalised_digits(rep)
+        for sl in range(13):
+            x = rng.randrange(P); init[("g", sl)] = x; ws_put(m, sl, x * R384 % P)
+        for sl in range(31, 43):
+            x = rng.randrange(P); rep = x * R392 % P
+            init[("gd", sl)] = x; ws_put(m, sl, rep + P if rep < P // 2 else rep)
+        m.run(body)
+        mp = run_model(progf, init, masks)
+        for loc, x in mp.out_home.items():
+            got = from_digits_signed(m.a[14 * loc[1]:14 * loc[1] + 14])
+            assert (got - x * R392) % P == 0 and t.F_IN.vlo <= got <= t.F_IN.vhi, (which, trial, loc)
+            assert all(0 <= s32(w) < (1 << 28) for w in m.a[14 * loc[1]:14 * loc[1] + 13])
+        for slot, x in mp.out_g.items():
+            got = ws_get(m, slot)
+            assert (got - x * R392) % P == 0 and t.PACKED.vlo <= got <= t.PACKED.vhi, (which, trial, slot)
+
+
+def miller_loop_sim(runs, seed, masks_bits=0):
+    rng = random.Random(seed)
+    full, pieces, st = t.miller_loop_d_routine()
+    m = miller_machine(masks_bits)
+    true = {}
+    for sl in range(13):
+        x = rng.randrange(P); true[sl] = x; ws_put(m, sl, x * R384 % P)
+    m.run(pieces["pro"])
+    masks = {"s[48:49]": masks_bits & 1, "s[54:55]": (masks_bits >> 1) & 1}
+    f = [1] + [0] * 11
+    T = {}
+    for k in range(2):
+        for e in range(3):
+            for i in range(2):
+                sl = t.Q_SLOT[k][e]
+                T[t.T_SLOT(k, e, i)] = (1 if i == 0 else 0) if sl is None else true[sl[i]]
+
+    def step(progf):
+        init = {("a", i): f[i] for i in range(12)}
+        init.update({("g", sl): true[sl] for sl in range(13)})
+        init.update({("gd", sl): T[sl] for sl in T})
+        mp = run_model(progf, init, masks)
+        for loc, x in mp.out_home.items():
+            f[loc[1]] = x
+        T.update(mp.out_g)
+    for ph, n in enumerate(runs):
+        for _ in range(n):
+            m.run(pieces["dbl"]); step(t.prog_miller_dbl_d)
+        if ph < len(runs) - 1:
+            m.run(pieces["add0"]); step(lambda: t.prog_miller_add_d(0))
+            m.run(pieces["add1"]); step(lambda: t.prog_miller_add_d(1))
+    m.run(pieces["epi"][:-1])
+    for i in range(12):
+        assert from_limbs(m.v[t.F_OUT[i]:t.F_OUT[i] + 12]) == f[i] * R384 % P, ("f", i)
+    assert not any("scratch" in l or "buffer_" in l for l in full)
+
+
+def test_miller_loop_routine_short_schedules():
+    """prologue (f = 1, T = Q into the packed slots), doubling runs, addition steps, epilogue (back to canonical 2^384-domain words);
+    the schedule of the real loop is the same sequence with runs of 1, 2, 3, 9, 32 and 16 iterations"""
+    assert t.RUNS == [1, 2, 3, 9, 32, 16] and sum(t.RUNS) == 63
+    miller_loop_sim([1, 2, 1], 5)
+    miller_loop_sim([2, 1], 6, masks_bits=1)          # pair 0 contributes 1 (infinite signature)
+    miller_loop_sim([1, 1], 7, masks_bits=2)
+
+
+def test_g2_doubling_runs():
+    rng = random.Random(21)
+    full, pieces, st = t.g2_dbl_d_routine()
+    for trial in range(4):
+        true = [rng.randrange(P) for _ in range(6)]
+        if trial == 0:
+            true = [0, 0, 1, 0, 0, 0]                   # the point at infinity (0 : 1 : 0)
+        m = Machine(ROUT); m.run(t.shell_constants())
+        for i in range(6):
+            m.v[t.G2D_ARG[i]:t.G2D_ARG[i] + 12] = limbs(true[i] * R384 % P)
+        m.run(pieces["pro"][1:])
+        cur = list(true)
+        for r in range([1, 2, 3, 4][trial]):
+            m.run(pieces["body"])
+            mp = run_model(t.prog_g2_dbl_d, {("a", i): cur[i] for i in range(6)}, {})
+            cur = [mp.out_home[("a", i)] for i in range(6)]
+        m.run(pieces["epi"])
+        for i in range(6):
+            assert from_limbs(m.v[t.G2D_ARG[i]:t.G2D_ARG[i] + 12]) == cur[i] * R384 % P, (trial, i)
+
+
+def test_miller_loop_routine_full_schedule():
+    """the complete loop as the kernel runs it: 63 doubling iterations and 5 addition steps per pair, ~6 million interpreted instructions"""
+    miller_loop_sim(t.RUNS, 7)
