@@ -230,13 +230,8 @@ MBLS_FN void g2_psi2(g2j* r, const g2j* p) {
     r->x = fp2_mul_fp(p->x, fp_load_const(MBLS_PSI2_CX)); r->y = fp2_neg(p->y); r->z = p->z;
 }
 #if MBLS_DEVICE_ASM && !defined(MBLS_NO_FP2_ASM)
-// n >= 1 doublings in place as one generated straight-line routine (tools/gen_tower_asm.py, prog_g2_dbl)
-extern "C" __device__ __attribute__((noinline, used, aligned(64))) void mbls_g2_dbl_asm_fn() {
-    asm volatile(MBLS_G2_DBL_ASM);
-}
-#if !defined(MBLS_NO_DFORM)
-// second generation (tools/gen_tower_d.py, prog_g2_dbl_d): the run of doublings on 14 signed 28-bit digits per coordinate; the
-// point is cut into digits on entry and brought back to canonical words on exit
+// n >= 1 doublings in place as one generated straight-line routine (tools/gen_tower_d.py, prog_g2_dbl_d): the run of doublings on
+// 14 signed 28-bit digits per coordinate; the point is cut into digits on entry and brought back to canonical words on exit
 extern "C" __device__ __attribute__((noinline, used, aligned(64))) void mbls_g2_dbl_d_asm_fn() {
     asm volatile(MBLS_G2_DBL_D_ASM);
 }
@@ -245,13 +240,6 @@ MBLS_FN void g2_dbl_n(g2j* p, uint32_t n) {
     asm volatile(MBLS_ASM_CALL("mbls_g2_dbl_d_asm_fn") : MBLS_G2D_ARG_REGS(p), "+{s38}"(n) : : MBLS_G2D_ASM_CLOBBERS);
     p->x.c0 = p0; p->x.c1 = p1; p->y.c0 = p2; p->y.c1 = p3; p->z.c0 = p4; p->z.c1 = p5;
 }
-#else
-MBLS_FN void g2_dbl_n(g2j* p, uint32_t n) {
-    fp p0 = p->x.c0, p1 = p->x.c1, p2 = p->y.c0, p3 = p->y.c1, p4 = p->z.c0, p5 = p->z.c1;
-    asm volatile(MBLS_ASM_CALL("mbls_g2_dbl_asm_fn") : MBLS_G2_ARG_REGS(p) : "{s38}"(n) : MBLS_G2_ARG_ASM_CLOBBERS);
-    p->x.c0 = p0; p->x.c1 = p1; p->y.c0 = p2; p->y.c1 = p3; p->z.c0 = p4; p->z.c1 = p5;
-}
-#endif
 #else
 MBLS_FN void g2_dbl_n(g2j* p, uint32_t n) { for (uint32_t i = 0; i < n; i++) g2_dbl(p, p); }
 #endif

@@ -184,10 +184,10 @@ MBLS_FN void lane_miller(const mbls_ws& ws, uint64_t i, MBLS_LDS uint32_t* tstor
     g2h_from_jacobian(&pr[1].q, &h); pr[1].t = pr[1].q;
     g1arg_from_jacobian(&pr[1].p, &a);
     fp12 f;
-#if MBLS_DEVICE_ASM && !defined(MBLS_NO_FP2_ASM) && !defined(MBLS_NO_DFORM)
+#if MBLS_DEVICE_ASM && !defined(MBLS_NO_FP2_ASM)
     if (use_lds) miller_loop_verify_d(&f, pr, ws.w, ws.stride, i, tstore, lane); else miller_loop(&f, pr, 2);
 #else
-    if (use_lds) miller_loop_verify_lds(&f, pr, tstore, lane); else miller_loop(&f, pr, 2);
+    if (use_lds) miller_loop_n<2, true>(&f, pr, tstore, lane, true); else miller_loop(&f, pr, 2);
 #endif
     const fp2* c = &f.c0.c0;
     for (int s = 0; s < 6; s++) ws_st2(ws, MBLS_SLOT_F + 2 * s, i, c[s]);

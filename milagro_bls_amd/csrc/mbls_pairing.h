@@ -126,50 +126,8 @@ MBLS_FN void miller_loop_n(fp12* f_out, mbls_pair* pairs, MBLS_LDS uint32_t* tst
 MBLS_NOINLINE void miller_loop(fp12* f, mbls_pair* pairs, int npairs) {
     if (npairs == 2) miller_loop_n<2, true>(f, pairs, nullptr, 0, false); else miller_loop_n<1, false>(f, pairs, nullptr, 0, false);
 }
-// the verification shape with the running points in LDS (inlined into k_miller so that the LDS accesses are ds_* instructions)
 #if MBLS_DEVICE_ASM && !defined(MBLS_NO_FP2_ASM)
-// Doubling iterations as one generated straight-line routine (tools/gen_tower_asm.py, prog_miller_dbl): f^2 and both
-// doubling steps with explicit VGPR/AGPR placement, interleaved carry chains and no scratch memory. It is specific to the
-// verification shape: pair 0's G1 argument is the constant -G1 (folded into the code), pair 1's arrives as (-px, py, pz^3).
-extern "C" __device__ __attribute__((noinline, used, aligned(64))) void mbls_fp2_mulfp_asm_fn() {
-    asm volatile(MBLS_FP2_MULFP_ASM);
-}
-extern "C" __device__ __attribute__((noinline, used, aligned(64))) void mbls_miller_dbl_asm_fn() {
-    asm volatile(MBLS_MILLER_DBL_ASM);
-}
-MBLS_FN void miller_dbl_n_asm(fp12* f, fp npx1, fp py1, fp pz3, uint32_t flags, MBLS_LDS uint32_t* ts, uint32_t lane, uint32_t n) {
-    uint32_t addr = (uint32_t)(uintptr_t)(ts + lane);
-    fp* c = &f->c0.c0.c0;
-    fp f0 = c[0], f1 = c[1], f2 = c[2], f3 = c[3], f4 = c[4], f5 = c[5], f6 = c[6], f7 = c[7], f8 = c[8], f9 = c[9], f10 = c[10], f11 = c[11];
-    fp d0 = npx1, d1 = py1, d2 = pz3;      // the operand registers are overwritten by the routine
-    asm volatile(MBLS_ASM_CALL("mbls_miller_dbl_asm_fn")
-                 : MBLS_F12_ARG_REGS(f),
-                   "+{v[0:11]}"(d0), "+{v[12:23]}"(d1), "+{v[24:35]}"(d2)
-                 : "{v252}"(addr), "{v253}"(flags), "{s38}"(n)
-                 : MBLS_MILLER_ASM_CLOBBERS);
-    c[0] = f0; c[1] = f1; c[2] = f2; c[3] = f3; c[4] = f4; c[5] = f5; c[6] = f6; c[7] = f7; c[8] = f8; c[9] = f9; c[10] = f10; c[11] = f11;
-}
-MBLS_FN void miller_loop_verify_lds(fp12* f_out, mbls_pair* pairs, MBLS_LDS uint32_t* tstore, uint32_t lane) {
-    fp12 f; fp12_set_one(&f);
-    g2h_lds_store(tstore, 0, lane, &pairs[0].t); g2h_lds_store(tstore, 1, lane, &pairs[1].t);
-    const fp npx1 = fp_neg(pairs[1].p.px), py1 = pairs[1].p.py, pz3 = pairs[1].p.pz3;
-    const uint32_t flags = (pairs[0].skip ? 1u : 0u) | (pairs[1].skip ? 2u : 0u);
-    int i = 62;
-    while (i >= 0) {
-        int j = i;                                       // doubling iterations for bits i..j, j = next set bit of |x| (or 0)
-        while (j > 0 && !((MBLS_X_ABS >> j) & 1)) j--;
-        miller_dbl_n_asm(&f, npx1, py1, pz3, flags, tstore, lane, (uint32_t)(i - j + 1));
-        if ((MBLS_X_ABS >> j) & 1) {
-            g2h tt;
-            g2h_lds_load(&tt, tstore, 0, lane); miller_add_step(&f, &tt, &pairs[0]); g2h_lds_store(tstore, 0, lane, &tt);
-            g2h_lds_load(&tt, tstore, 1, lane); miller_add_step(&f, &tt, &pairs[1]); g2h_lds_store(tstore, 1, lane, &tt);
-        }
-        i = j - 1;
-    }
-    fp12_conj(f_out, &f);
-}
-#if !defined(MBLS_NO_DFORM)
-// Second generation (tools/gen_tower_d.py): the WHOLE loop -- 63 doubling iterations and the 5 addition steps of both pairs -- as one
+// The verification shape (tools/gen_tower_d.py): the WHOLE loop -- 63 doubling iterations and the 5 addition steps of both pairs -- as one
 // generated routine on 14 signed 28-bit digits per value (bare product scans, carry-free additions, bounds tracked at generation
 // time). f lives in AGPRs; the running points, the fixed points Q_k and the second G1 argument live in the HBM workspace as packed
 // words and are fetched (prefetched, where a register block is free) when a step needs them, which leaves the whole LDS allocation
@@ -206,11 +164,6 @@ MBLS_FN void miller_loop_verify_d(fp12* f_out, const mbls_pair* pairs, uint32_t*
     fp12 f; fp* c = &f.c0.c0.c0;
     c[0] = f0; c[1] = f1; c[2] = f2; c[3] = f3; c[4] = f4; c[5] = f5; c[6] = f6; c[7] = f7; c[8] = f8; c[9] = f9; c[10] = f10; c[11] = f11;
     fp12_conj(f_out, &f);
-}
-#endif
-#else
-MBLS_FN void miller_loop_verify_lds(fp12* f, mbls_pair* pairs, MBLS_LDS uint32_t* tstore, uint32_t lane) {
-    miller_loop_n<2, true>(f, pairs, tstore, lane, true);
 }
 #endif
 // f^(3 (p^12-1)/r). Hard part: 3 (p^4-p^2+1)/r = (x-1)^2 (x+p) (x^2+p^2-1) + 3 (Hayashida-Hayasaka-Teruya);

@@ -239,19 +239,11 @@ MBLS_FN void fp12_lds_store(MBLS_LDS uint32_t* ls, uint32_t lane, const fp12* a)
     }
 }
 #if MBLS_DEVICE_ASM && !defined(MBLS_NO_FP2_ASM)
-// n >= 1 Granger-Scott squarings of the Fp12 parked in LDS, in place, as one generated straight-line routine
-// (tools/gen_tower_asm.py: explicit VGPR/AGPR placement, no scratch memory; the compiler-scheduled fp12_cyc_sqr spills and,
-// with one wave per SIMD, waits a full memory round trip for every reload).
 #include "mbls_tower_asm.inc"
-extern "C" __device__ __attribute__((noinline, used, aligned(64))) void mbls_cyc_sqr_asm_fn() {
-    asm volatile(MBLS_CYC_SQR_ASM);
-}
-MBLS_FN void fp12_cyc_sqr_n_lds(MBLS_LDS uint32_t* ls, uint32_t lane, uint32_t n) {
-    uint32_t addr = (uint32_t)(uintptr_t)(ls + lane);
-    asm volatile(MBLS_ASM_CALL("mbls_cyc_sqr_asm_fn") : "+{s38}"(n) : "{v252}"(addr) : MBLS_TOWER_ASM_CLOBBERS);
-}
-// Second generation (tools/gen_fpd_asm.py, tools/gen_tower_d.py): the same squaring on 14 signed 28-bit digits per value from the
-// first to the last of the n squarings -- bare product scans, carry-free additions, no conversions or conditional subtractions
+// n >= 1 Granger-Scott squarings of the Fp12 parked in LDS, in place, as one generated straight-line routine with explicit
+// VGPR/AGPR placement and no scratch memory (the compiler-scheduled fp12_cyc_sqr spills and, with one wave per SIMD, waits a full
+// memory round trip for every reload). The routine (tools/gen_fpd_asm.py, tools/gen_tower_d.py) keeps every value as 14 signed 28-bit digits
+// from the first to the last of the n squarings -- bare product scans, carry-free additions, no conversions or conditional subtractions
 // between multiplications. The parked value is in the 2^392 Montgomery domain (x 2^392 mod p, canonical) for these routines; the
 // first-generation multiplication routine below works on it unchanged (it divides by 2^384 and takes its other operand in the
 // 2^384 domain, so its product stays in the 2^392 domain).
@@ -304,7 +296,7 @@ MBLS_FN void fp12_mul_via_lds(fp12* r, const fp12* a, const fp12* b, MBLS_LDS ui
 MBLS_NOINLINE void fp12_cyc_exp_x(fp12* r, const fp12* f, MBLS_LDS uint32_t* ls, uint32_t lane, bool use_lds) {
     fp12 acc = *f;
     if (use_lds) {
-#if MBLS_DEVICE_ASM && !defined(MBLS_NO_FP2_ASM) && !defined(MBLS_NO_DFORM)
+#if MBLS_DEVICE_ASM && !defined(MBLS_NO_FP2_ASM)
         fp12_scale(&acc, MBLS_TO_D392);                  // the running power lives in the 2^392 domain between here ...
 #define MBLS_CYC_SQR_N fp12_cyc_sqr_n_lds_d
 #else
@@ -320,7 +312,7 @@ MBLS_NOINLINE void fp12_cyc_exp_x(fp12* r, const fp12* f, MBLS_LDS uint32_t* ls,
             i = j - 1;
         }
         fp12_lds_load(&acc, ls, lane);
-#if MBLS_DEVICE_ASM && !defined(MBLS_NO_FP2_ASM) && !defined(MBLS_NO_DFORM)
+#if MBLS_DEVICE_ASM && !defined(MBLS_NO_FP2_ASM)
         fp12_scale(&acc, MBLS_FROM_D392);                // ... and here
 #endif
 #undef MBLS_CYC_SQR_N

@@ -1,5 +1,6 @@
-"""The generated gfx950 routines (tools/gen_fp_asm.py, tools/gen_tower_asm.py) interpreted on the CPU by tools/asm_sim.py and
-compared with big-integer arithmetic: Montgomery products, the fused Fp2 routines, and the straight-line tower routines."""
+"""The generated gfx950 routines on 12 x 32-bit limbs (tools/gen_fp_asm.py, tools/gen_tower_asm.py) interpreted on the CPU by
+tools/asm_sim.py and compared with big-integer arithmetic: Montgomery products, the fused Fp2 routines, the fixed-exponent
+exponentiations and the Fp12 multiplication routine. The digit-form routines have their own file, test_asm_sim_d_cpu.py."""
 import os
 import random
 import sys
@@ -83,37 +84,6 @@ def lds_get(m, base, slot):
     return from_limbs([m.lds[base + (slot * 12 + j) * 256] for j in range(12)])
 
 
-def test_cyc_sqr_routine():
-    lines, stats = t.build("cyc_sqr")
-    assert not any("scratch" in l for l in lines)
-    rng = random.Random(5)
-
-    def fp4(a, b):
-        t0 = f2mul(a, a); t1 = f2mul(b, b)
-        s = f2add(a, b)
-        return f2add(xi(t1), t0), f2sub(f2sub(f2mul(s, s), t0), t1)
-
-    def dbl(a):
-        return f2add(a, a)
-    for trial in range(4):
-        z = [(rng.randrange(P), rng.randrange(P)) for _ in range(6)]
-        if trial == 0:
-            z = [(0, 0)] * 5 + [(P - 1, 1)]
-        m = Machine(ROUTINES); m.v[252] = 4096; m.s[("pair", 30)] = 7
-        for e in range(6):
-            lds_put(m, 4096, 2 * e, z[e][0]); lds_put(m, 4096, 2 * e + 1, z[e][1])
-        m.run(lines)
-        z0, z4, z3, z2, z1, z5 = z
-        t0, t1 = fp4(z0, z1)
-        n0 = f2add(dbl(f2sub(t0, z0)), t0); n1 = f2add(dbl(f2add(t1, z1)), t1)
-        t0, t1 = fp4(z2, z3); t2, t3 = fp4(z4, z5)
-        n4 = f2add(dbl(f2sub(t0, z4)), t0); n5 = f2add(dbl(f2add(t1, z5)), t1); x = xi(t3)
-        n2 = f2add(dbl(f2add(x, z2)), x); n3 = f2add(dbl(f2sub(t2, z3)), t2)
-        exp = [n0, n4, n3, n2, n1, n5]
-        for e in range(6):
-            assert (lds_get(m, 4096, 2 * e), lds_get(m, 4096, 2 * e + 1)) == exp[e], (trial, e)
-
-
 def test_generated_files_up_to_date():
     import io
     import contextlib
@@ -154,73 +124,6 @@ def f6mul(a, b):
     return [c0, c1, c2]
 
 
-def f12sqr(f):
-    a, b = f
-    ab = f6mul(a, b)
-    st = f6sub(f6mul(f6add(a, b), f6add(a, f6mulv(b))), ab)
-    return (f6sub(st, f6mulv(ab)), f6add(ab, ab))
-
-
-def f12mul_line(f, c0, c2, c3):
-    a, b = f
-    zero = (0, 0)
-    l0, l1 = [c0, c2, zero], [zero, c3, zero]
-    t0, t1 = f6mul(a, l0), f6mul(b, l1)
-    c1 = f6sub(f6sub(f6mul(f6add(a, b), f6add(l0, l1)), t0), t1)
-    return (f6add(t0, f6mulv(t1)), c1)
-
-
-def dbl_step_model(f, T, npx, py, pz3, skip):
-    Tx, Ty, Tz = T
-    B = f2mul(Ty, Ty); C = f2mul(Tz, Tz)
-    E = f2k(xi(C), 12); F = f2k(E, 3)
-    X2 = f2mul(Tx, Tx); YZ = f2mul(Ty, Tz)
-    c0 = f2sub(B, E)
-    if pz3 is not None:
-        c0 = f2mulfp(c0, pz3)
-    c2 = f2mulfp(f2k(X2, 3), npx)
-    c3 = f2mulfp(f2k(YZ, 2), py)
-    x3 = f2k(f2mul(f2mul(Tx, Ty), f2sub(B, F)), 2)
-    BF = f2add(B, F)
-    y3 = f2sub(f2mul(BF, BF), f2k(f2mul(E, E), 12))
-    z3 = f2k(f2mul(B, YZ), 8)
-    if skip:
-        c0, c2, c3 = (t.ONE_M, 0), (0, 0), (0, 0)
-    return f12mul_line(f, c0, c2, c3), (x3, y3, z3)
-
-
-@pytest.mark.parametrize("skips", [(0, 0), (1, 0), (0, 1)])
-def test_miller_dbl_routine(skips):
-    lines, stats = t.build("miller_dbl")
-    assert not any("scratch" in l for l in lines)
-    rng = random.Random(11 + skips[0] + 2 * skips[1])
-    r2 = lambda: (rng.randrange(P), rng.randrange(P))
-    f = ([r2(), r2(), r2()], [r2(), r2(), r2()])
-    T = [(r2(), r2(), r2()), (r2(), r2(), r2())]
-    p1 = [rng.randrange(P) for _ in range(3)]           # -px, py, pz^3
-    m = Machine(ROUTINES); m.v[252] = 8192
-    m.s[("pair", 48)], m.s[("pair", 54)] = skips
-    flat = [x for h in f for c in h for x in c]
-    for i, x in enumerate(flat):
-        m.a[12 * i:12 * i + 12] = limbs(x)
-    for i, x in enumerate(p1):
-        m.a[144 + 12 * i:144 + 12 * i + 12] = limbs(x)
-    for k in range(2):
-        for e in range(3):
-            lds_put(m, 8192, 6 * k + 2 * e, T[k][e][0]); lds_put(m, 8192, 6 * k + 2 * e + 1, T[k][e][1])
-    m.run(lines)
-    g1 = f12sqr(f)
-    g1, T0n = dbl_step_model(g1, T[0], t.NPX0_M, t.PY0_M, None, skips[0])
-    g1, T1n = dbl_step_model(g1, T[1], p1[0], p1[1], p1[2], skips[1])
-    exp = [x for h in g1 for c in h for x in c]
-    got = [from_limbs(m.a[12 * i:12 * i + 12]) for i in range(12)]
-    assert got == exp
-    for k, Tn in enumerate((T0n, T1n)):
-        for e in range(3):
-            assert (lds_get(m, 8192, 6 * k + 2 * e), lds_get(m, 8192, 6 * k + 2 * e + 1)) == Tn[e], (k, e)
-    assert [from_limbs(m.a[144 + 12 * i:144 + 12 * i + 12]) for i in range(3)] == p1      # the G1 argument stays in its home
-
-
 def test_fp12_mul_routine():
     lines, stats = t.build("fp12_mul")
     assert not any("scratch" in l for l in lines)
@@ -230,7 +133,7 @@ def test_fp12_mul_routine():
         a = ([r2(), r2(), r2()], [r2(), r2(), r2()])
         b = ([r2(), r2(), r2()], [r2(), r2(), r2()])
         if trial == 0:
-            b = ([(t.ONE_M, 0), (0, 0), (0, 0)], [(0, 0), (0, 0), (0, 0)])
+            b = ([((1 << 384) % P, 0), (0, 0), (0, 0)], [(0, 0), (0, 0), (0, 0)])
         m = Machine(ROUTINES); m.v[252] = 512
         for i, x in enumerate([x for h in a for c in h for x in c]):
             lds_put(m, 512, i, x)
@@ -244,30 +147,6 @@ def test_fp12_mul_routine():
         assert [lds_get(m, 512, i) for i in range(12)] == exp
         if trial == 0:
             assert exp == [x for h in a for c in h for x in c]
-
-
-def test_g2_dbl_routine():
-    lines, stats = t.build("g2_dbl")
-    rng = random.Random(31)
-    r2 = lambda: (rng.randrange(P), rng.randrange(P))
-    for trial in range(3):
-        X, Y, Z = r2(), r2(), r2()
-        if trial == 0:
-            Z = (0, 0)
-        m = Machine(ROUTINES)
-        for i, x in enumerate([X[0], X[1], Y[0], Y[1], Z[0], Z[1]]):
-            m.a[12 * i:12 * i + 12] = limbs(x)
-        m.run(lines)
-        sq = lambda a: f2mul(a, a)
-        A, B = sq(X), sq(Y)
-        C = sq(B)
-        D = f2k(f2sub(f2sub(sq(f2add(X, B)), A), C), 2)
-        E = f2k(A, 3); F = sq(E)
-        Z3 = f2k(f2mul(Y, Z), 2)
-        X3 = f2sub(F, f2k(D, 2))
-        Y3 = f2sub(f2mul(E, f2sub(D, X3)), f2k(C, 8))
-        got = [from_limbs(m.a[12 * i:12 * i + 12]) for i in range(6)]
-        assert got == [X3[0], X3[1], Y3[0], Y3[1], Z3[0], Z3[1]]
 
 
 @pytest.mark.parametrize("which", ["pm3d4", "pm2"])

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Generate milagro_bls_amd/csrc/mbls_tower_asm.inc: straight-line gfx950 routines for the two hot loop bodies
-(Granger-Scott cyclotomic squaring of the final exponentiation, doubling iteration of the Miller loop).
+"""Generate milagro_bls_amd/csrc/mbls_tower_asm.inc: the Fp12 multiplication as a straight-line gfx950 routine on 12 x 32-bit limbs
+(first generation of the tower generator; the loop bodies -- Miller loop, cyclotomic squaring, G2 doubling runs -- are generated in
+digit form by tools/gen_tower_d.py, which reuses the Prog recorder of this file).
 
 Why: inside these loops hipcc cannot keep the working set (an Fp12 = 144 registers, plus Fp6 temporaries, plus the fixed
 register window of the Fp2 multiplication routines) in registers; it spills to lane-private scratch memory, and with one wave
@@ -498,89 +499,8 @@ class Alloc:
         self.at[dst] = ("stored", a)  # the slot now holds a result: never reused as spill space
 
 
-# ------------------------------------------------------------------------------------------ the programs
+# ------------------------------------------------------------------------------------------ the program
 # Fp2 coefficient e2 of an Fp12 in tower order: 0 c0.c0, 1 c0.c1, 2 c0.c2, 3 c1.c0, 4 c1.c1, 5 c1.c2  (LDS slots 2*e2, 2*e2+1)
-def prog_cyc_sqr():
-    """Granger-Scott squaring in the cyclotomic subgroup, state in LDS slots 0..11, in place
-    (same formulas as fp12_cyc_sqr in mbls_tower.h)."""
-    p = Prog()
-    z = [(p.live_in(("l", 2 * e)), p.live_in(("l", 2 * e + 1))) for e in range(6)]
-    z0, z4, z3, z2, z1, z5 = z
-
-    def fp4_sqr(a, b):
-        t0 = p.sqr2(a); t1 = p.sqr2(b)
-        c0 = p.add2(p.mul_xi2(t1), t0)
-        s = p.sqr2(p.add2(a, b))
-        c1 = p.sub2(p.sub2(s, t0), t1)
-        return c0, c1
-    t0, t1 = fp4_sqr(z0, z1)
-    p.store2(p.add2(p.dbl2(p.sub2(t0, z0)), t0), 0)
-    p.store2(p.add2(p.dbl2(p.add2(t1, z1)), t1), 4)
-    t0, t1 = fp4_sqr(z2, z3)
-    t2, t3 = fp4_sqr(z4, z5)
-    p.store2(p.add2(p.dbl2(p.sub2(t0, z4)), t0), 1)
-    p.store2(p.add2(p.dbl2(p.add2(t1, z5)), t1), 5)
-    x = p.mul_xi2(t3)
-    p.store2(p.add2(p.dbl2(p.add2(x, z2)), x), 3)
-    p.store2(p.add2(p.dbl2(p.sub2(t2, z3)), t2), 2)
-    return p
-
-
-R384 = 1 << 384
-G1_X = 0x17f1d3a73197d7942695638c4fa9ac0fc3688c4f9774b905a14e3a3f171bac586c55e83ff97a1aeffb3af00adb22c6bb
-G1_Y = 0x08b3f481e3aaa0f1a09e30ed741d8ae4fcf5e095d5d00af600db18cb2c04b3edd03cc744a2888ae40caa232946c5e7e1
-ONE_M = R384 % P                                  # Montgomery form of 1
-# pair 0 of a verification is (signature, -G1): the G1 argument is the constant (G1_X, -G1_Y); the line needs -px and py
-NPX0_M = (P - G1_X) * R384 % P
-PY0_M = (P - G1_Y) * R384 % P
-F_HOME = [("a", 12 * i) for i in range(12)]        # the Miller value between iterations, tower order
-P1_HOME = [("a", 144 + 12 * i) for i in range(3)]  # -px, py, pz^3 of the second pair's G1 argument
-SKIP_MASK = ["s[48:49]", "s[54:55]"]               # lanes whose pair contributes 1 (a member is infinity)
-
-
-def prog_miller_dbl():
-    """One doubling iteration of the two-pair (verification-shape) Miller loop: f <- f^2, then for each pair T <- 2T and
-    f <- f * line (formulas of miller_dbl_step / fp12_sqr / fp12_mul_line in mbls_pairing.h / mbls_tower.h).
-    State: f in AGPR homes, running points T0/T1 in LDS slots 0..5 / 6..11 (x, y, z as Fp2), second G1 argument in AGPR homes."""
-    p = Prog()
-    fl = [p.live_in(h) for h in F_HOME]
-    f = ([(fl[0], fl[1]), (fl[2], fl[3]), (fl[4], fl[5])], [(fl[6], fl[7]), (fl[8], fl[9]), (fl[10], fl[11])])
-    p1 = [p.live_in(h) for h in P1_HOME]
-    f = p.sqr12(f)
-    for k in range(2):
-        T = [(p.live_in(("l", 6 * k + 2 * e)), p.live_in(("l", 6 * k + 2 * e + 1))) for e in range(3)]
-        Tx, Ty, Tz = T
-        B = p.sqr2(Ty); C = p.sqr2(Tz)
-        E = p.mul12_2(p.mul_xi2(C))
-        F = p.mul3_2(E)
-        X2 = p.sqr2(Tx)
-        YZ = p.mul2(Ty, Tz)
-        c0 = p.sub2(B, E)
-        if k == 0:
-            npx, py = p.const(NPX0_M), None
-            c2 = p.mulfp2(p.mul3_2(X2), npx)
-            c3 = p.mulfp2(p.dbl2(YZ), p.const(PY0_M))
-        else:
-            c0 = p.mulfp2(c0, p1[2])
-            c2 = p.mulfp2(p.mul3_2(X2), p1[0])
-            c3 = p.mulfp2(p.dbl2(YZ), p1[1])
-        x3 = p.dbl2(p.mul2(p.mul2(Tx, Ty), p.sub2(B, F)))
-        y3 = p.sub2(p.sqr2(p.add2(B, F)), p.mul12_2(p.sqr2(E)))
-        z3 = p.mul8_2(p.mul2(B, YZ))
-        for e, v in enumerate((x3, y3, z3)):
-            p.store2(v, 3 * k + e)
-        m = SKIP_MASK[k]
-        c0 = (p.sel(m, c0[0], p.const(ONE_M)), p.sel(m, c0[1], p.const(0)))
-        c2 = (p.sel(m, c2[0], p.const(0)), p.sel(m, c2[1], p.const(0)))
-        c3 = (p.sel(m, c3[0], p.const(0)), p.sel(m, c3[1], p.const(0)))
-        f = p.mul12_line(f, c0, c2, c3)
-    flat = [x for h in f for c in h for x in c]
-    for v, h in zip(flat, F_HOME):
-        p.store(v, h)
-    p.keep(p1)
-    return p
-
-
 def prog_fp12_mul():
     """acc <- acc * g: acc in LDS slots 0..11 (tower order), g arriving in the twelve blocks F12_ARG (asm operands)."""
     p = Prog()
@@ -598,56 +518,9 @@ def prog_fp12_mul():
     return p
 
 
-G2_HOME = [("a", 12 * i) for i in range(6)]
-G2_ARG = FREE_V[:6]
-
-
-def prog_g2_dbl():
-    """Jacobian doubling of a point of E'(Fp2) (formulas of g2_dbl in mbls_curve.h; valid for every curve point including
-    infinity, the curve has no 2-torsion). X, Y, Z in AGPR homes."""
-    p = Prog()
-    l = [p.live_in(h) for h in G2_HOME]
-    X, Y, Z = (l[0], l[1]), (l[2], l[3]), (l[4], l[5])
-    A = p.sqr2(X); B = p.sqr2(Y); C = p.sqr2(B)
-    D = p.dbl2(p.sub2(p.sub2(p.sqr2(p.add2(X, B)), A), C))
-    E = p.mul3_2(A); F = p.sqr2(E)
-    Z3 = p.dbl2(p.mul2(Y, Z))
-    X3 = p.sub2(F, p.dbl2(D))
-    Y3 = p.sub2(p.mul2(E, p.sub2(D, X3)), p.mul8_2(C))
-    for v, h in zip((X3[0], X3[1], Y3[0], Y3[1], Z3[0], Z3[1]), G2_HOME):
-        p.store(v, h)
-    return p
-
-
-def g2_dbl_shell(body):
-    """the point arrives in the six blocks G2_ARG (asm operands) and is doubled s38 times"""
-    pro = ["s_mov_b32 s39, s38"]
-    epi = []
-    for i in range(6):
-        pro += ["v_accvgpr_write_b32 a%d, v%d" % (12 * i + j, G2_ARG[i] + j) for j in range(12)]
-        epi += ["v_accvgpr_read_b32 v%d, a%d" % (G2_ARG[i] + j, 12 * i + j) for j in range(12)]
-    return wrap_loop(body, count_sgpr="s39", prologue=pro, epilogue=epi)
-
-
 def plain_shell(body):
     """a routine without a loop: only the return address needs saving around the nested calls"""
     return ["s_mov_b64 s[36:37], s[30:31]", ".p2align 6"] + body + ["s_mov_b64 s[30:31], s[36:37]"]
-
-
-def miller_dbl_shell(body):
-    """f arrives in the blocks F12_ARG and the second G1 argument in v0..v35 (asm operands of the call site); both move to their AGPR
-    homes around the loop. v253 carries the per-lane skip flags (bit 0: pair 0, bit 1: pair 1), s38 the number of iterations."""
-    pro = ["v_and_b32_e32 v254, 1, v253", "v_cmp_ne_u32_e64 %s, 0, v254" % SKIP_MASK[0],
-           "v_and_b32_e32 v254, 2, v253", "v_cmp_ne_u32_e64 %s, 0, v254" % SKIP_MASK[1], "s_mov_b32 s39, s38"]
-    epi = []
-    for i in range(12):
-        for j in range(12):
-            pro.append("v_accvgpr_write_b32 a%d, v%d" % (12 * i + j, F12_ARG[i] + j))
-            epi.append("v_accvgpr_read_b32 v%d, a%d" % (F12_ARG[i] + j, 12 * i + j))
-    for i in range(3):
-        for j in range(12):
-            pro.append("v_accvgpr_write_b32 a%d, v%d" % (144 + 12 * i + j, 12 * i + j))
-    return wrap_loop(body, count_sgpr="s39", prologue=pro, epilogue=epi)
 
 
 def expand_calls(lines):
@@ -662,16 +535,8 @@ def expand_calls(lines):
     return out
 
 
-def wrap_loop(lines, count_sgpr="s38", prologue=(), epilogue=()):
-    """routine shell: save the return address (nested calls overwrite s[30:31]) and repeat the body count_sgpr times (>= 1).
-    The body can exceed the +-128 KB reach of s_cbranch, so the back edge is a computed jump."""
-    back = ["s_sub_u32 %s, %s, 1" % (count_sgpr, count_sgpr), "s_cmp_lg_u32 %s, 0" % count_sgpr, "s_cbranch_scc0 2f",
-            "s_getpc_b64 s[40:41]", "3:", "s_sub_u32 s40, s40, 3b-1b", "s_subb_u32 s41, s41, 0", "s_setpc_b64 s[40:41]", "2:"]
-    return ["s_mov_b64 s[36:37], s[30:31]"] + list(prologue) + [".p2align 6", "1:"] + lines + back + list(epilogue) + ["s_mov_b64 s[30:31], s[36:37]"]
-
-
 def build(name):
-    prog = {"cyc_sqr": prog_cyc_sqr, "miller_dbl": prog_miller_dbl, "fp12_mul": prog_fp12_mul, "g2_dbl": prog_g2_dbl}[name]()
+    prog = {"fp12_mul": prog_fp12_mul}[name]()
     al = Alloc(prog)
     lines = al.run()
     return lines, al.stats
@@ -681,29 +546,16 @@ def main():
     here = os.path.dirname(os.path.abspath(__file__))
     path = os.path.join(os.path.dirname(here), "milagro_bls_amd", "csrc", "mbls_tower_asm.inc")
     txt = "// GENERATED by tools/gen_tower_asm.py -- do not edit.\n"
-    for name, macro, shell in (("cyc_sqr", "MBLS_CYC_SQR_ASM", wrap_loop), ("miller_dbl", "MBLS_MILLER_DBL_ASM", miller_dbl_shell),
-                               ("fp12_mul", "MBLS_FP12_MUL_ASM", plain_shell), ("g2_dbl", "MBLS_G2_DBL_ASM", g2_dbl_shell)):
-        lines, stats = build(name)
-        txt += emit(macro, shell(expand_calls(lines))) + "\n"
-        print(name, len(lines), "lines", stats)
+    lines, stats = build("fp12_mul")
+    txt += emit("MBLS_FP12_MUL_ASM", plain_shell(expand_calls(lines))) + "\n"
+    print("fp12_mul", len(lines), "lines", stats)
     sg = '"s30","s31","s36","s37","s39","s40","s41","s42","s43","s44","s45","s46","s47","s48","s49","s50","s51","s52","s53","s54","s55","s56","s57","s58","s59","s60","s61","s62","s63","s64","s65","vcc","scc","memory"'
-    vr = ",".join('"v%d"' % i for i in list(range(252)) + [254])
-    txt += "// everything a tower routine may overwrite (v252 carries the LDS address and is preserved)\n"
-    txt += "#define MBLS_TOWER_ASM_CLOBBERS %s,%s, \\\n    %s\n" % (vr, ",".join('"a%d"' % i for i in range(252)), sg)
     argregs = set(r for b in F12_ARG for r in range(b, b + 12))
     other = [i for i in list(range(0, 120)) + list(range(240, 252)) + [254] if i not in argregs]
-    txt += "// routines that take an Fp12 as twelve operands; its register blocks, in tower order:\n"
+    txt += "// the routine takes its second operand as twelve register blocks, in tower order (v252 carries the LDS address and is preserved):\n"
     txt += "#define MBLS_F12_ARG_REGS(x) " + ", ".join('"+{v[%d:%d]}"(x##%d)' % (b, b + 11, i) for i, b in enumerate(F12_ARG)) + "\n"
     txt += "#define MBLS_FP12_ARG_ASM_CLOBBERS %s,%s, \\\n    %s\n" % (
         ",".join('"v%d"' % i for i in other), ",".join('"a%d"' % i for i in range(252)), sg)
-    g2regs = set(r for b in G2_ARG for r in range(b, b + 12))
-    txt += "// the G2 doubling routine takes X, Y, Z as six operands\n"
-    txt += "#define MBLS_G2_ARG_REGS(x) " + ", ".join('"+{v[%d:%d]}"(x##%d)' % (b, b + 11, i) for i, b in enumerate(G2_ARG)) + "\n"
-    txt += "#define MBLS_G2_ARG_ASM_CLOBBERS %s,%s, \\\n    %s\n" % (
-        ",".join('"v%d"' % i for i in list(range(0, 252)) + [254] if i not in g2regs), ",".join('"a%d"' % i for i in range(252)), sg)
-    txt += "// the Miller routine additionally takes the G1 argument in v0..v35\n"
-    txt += "#define MBLS_MILLER_ASM_CLOBBERS %s,%s, \\\n    %s\n" % (
-        ",".join('"v%d"' % i for i in other if i >= 36), ",".join('"a%d"' % i for i in range(252)), sg)
     with open(path, "w") as f:
         f.write(txt)
     print("wrote", path)

@@ -286,6 +286,8 @@ class AllocD:
         # such a value costs nothing, fetching it again is 6 LDS reads + the conversion into digits
         self.home = {v: l for v, l in prog.init_loc.items() if l[0] in ("lp", "g", "gd")}
         self.home_bound = {v: in_bounds[v] for v in self.home}
+        self.vm = 0                                          # vector-memory operations issued so far (they retire in issue order)
+        self.vm_mark = {}                                    # value -> count after the last load of its prefetch
 
     def next_use(self, v, k):
         for u in self.uses.get(v, ()):
@@ -306,6 +308,8 @@ class AllocD:
             del self.at[l]
 
     def e(self, s):
+        if s.startswith("global_"):
+            self.vm += 1
         self.out.append(s)
 
     def wait_lds(self):
@@ -370,19 +374,21 @@ class AllocD:
         b = self.free_block("v", ALL_V, avoid)
         if b is not None:
             return b
-        for blk in ALL_V:                                   # prefetched words are the cheapest thing to give up
-            if blk not in avoid and ("vw", blk) in self.at:
-                self.drop_prefetch(blk)
-                return blk
-        best, bu = None, -1
+        best, bu, pre = None, -1, False                      # Belady: the block whose content is needed last (prefetched words included)
         for blk in ALL_V:
             if blk in avoid:
                 continue
-            w = self.at[("v", blk)]
+            w = self.at.get(("v", blk))
+            is_pre = w is None
+            if is_pre:
+                w = self.at[("vw", blk)]
             u = self.next_use(w, k)
             if u > bu:
-                best, bu = blk, u
+                best, bu, pre = blk, u, is_pre
         assert best is not None, "no evictable block"
+        if pre:
+            self.drop_prefetch(best)
+            return best
         w = self.at[("v", best)]
         if bu == INF:
             self.release(w)
@@ -392,11 +398,11 @@ class AllocD:
 
     def spill(self, w):
         src = self.loc[w]
+        ab = self.free_block("a", self.a_pool)
+        if ab is not None:                                   # an AGPR round trip (28 moves) beats a second fetch from the home
+            self.copy(src, ("a", ab)); self.place(w, ("a", ab)); return
         if w in self.home:                                   # rematerialisable: drop the copy
             self.place(w, self.home[w]); self.bound[w] = self.home_bound[w]; return
-        ab = self.free_block("a", self.a_pool)
-        if ab is not None:
-            self.copy(src, ("a", ab)); self.place(w, ("a", ab)); return
         ls = self.free_block("l", range(self.n_lds))
         if ls is None:
             raise RuntimeError("out of storage")
@@ -408,7 +414,8 @@ class AllocD:
             return l[1]
         if l[0] == "vw":                                    # words prefetched into this block: wait for them, cut them into digits
             reg = lambda j: "v%d" % (vb(l[1]) + j)
-            for x in ["s_waitcnt vmcnt(0)", "s_nop 0"] + seq_conv(reg, [reg(j + 2) for j in range(12)], self.home[v][0] == "g"):
+            younger = min(self.vm - self.vm_mark[v], 63)     # operations issued after its loads may still be in flight
+            for x in ["s_waitcnt vmcnt(%d)" % younger, "s_nop 0"] + seq_conv(reg, [reg(j + 2) for j in range(12)], self.home[v][0] == "g"):
                 self.e(x)
             del self.at[l]
             self.loc[v] = ("v", l[1]); self.at[("v", l[1])] = v
@@ -435,16 +442,33 @@ class AllocD:
         """before a multiplication call: issue the HBM loads of values that the next few operations need and that only live in their
         workspace home, into free blocks outside the routines' window (no eviction: a prefetch must not cost a spill)"""
         calls, j = 0, k + 1
+        ins_now = set(self.p.ops[k][2])
         while j < len(self.p.ops) and calls < horizon:
             kind, outs, ins, aux = self.p.ops[j]
             for v in ins:
                 if self.loc.get(v, ("", 0))[0] in ("g", "gd") and v in self.home:
                     b = self.free_block("v", FREE_V)
-                    if b is None:
-                        return
+                    if b is None:                            # take the block whose value is needed last, if that is later than this use
+                        best, bu = None, j
+                        for blk in FREE_V:
+                            w = self.at.get(("v", blk))
+                            if w is None or w in ins_now:
+                                continue
+                            u = self.next_use(w, k)
+                            if u > bu:
+                                best, bu = blk, u
+                        if best is None:
+                            return
+                        w = self.at[("v", best)]
+                        if bu == INF:
+                            self.release(w)
+                        else:
+                            self.spill(w)
+                        b = best
                     reg = lambda q, b=b: "v%d" % (vb(b) + q)
                     for x in seq_gload(reg, self.home[v][1], aform=None):
                         self.e(x)
+                    self.vm_mark[v] = self.vm
                     self.loc[v] = ("vw", b); self.at[("vw", b)] = v
                     self.stats["unpack"] += 40
             if kind in ROUTINES:
@@ -809,6 +833,10 @@ Q_SLOT = [[(3, 4), (5, 6), None], [(7, 8), (9, 10), (11, 12)]]
 F_IN = Bound.normalised(-16 * P, 16 * P)          # a coefficient of the Miller value between rounds: carry-normalised, a few p wide
 
 
+def t_live_in(p, k):
+    return [(p.live_in(("gd", T_SLOT(k, e, 0))), p.live_in(("gd", T_SLOT(k, e, 1)))) for e in range(3)]
+
+
 def prog_norm(p, a):
     d = p.new(); p.ops.append(("norm", [d], [a], None)); return d
 
@@ -885,7 +913,7 @@ def prog_miller_dbl_d():
         f = p.sqr12(f)
     lines = []
     for k in range(2):
-        Tx, Ty, Tz = [(p.live_in(("gd", T_SLOT(k, e, 0))), p.live_in(("gd", T_SLOT(k, e, 1)))) for e in range(3)]
+        Tx, Ty, Tz = t_live_in(p, k)
         B = p.sqr2(Ty); C = p.sqr2(Tz)
         E = p.mul12_2(p.mul_xi2(C))
         F = p.mul3_2(E)
@@ -924,7 +952,7 @@ def prog_miller_add_d(k):
     p = Prog()
     f = f_live_in(p)
     p1 = [p.live_in(h) for h in P1_HOME]
-    Tx, Ty, Tz = [(p.live_in(("gd", T_SLOT(k, e, 0))), p.live_in(("gd", T_SLOT(k, e, 1)))) for e in range(3)]
+    Tx, Ty, Tz = t_live_in(p, k)
     Q = [None if sl is None else (p.live_in(("g", sl[0])), p.live_in(("g", sl[1]))) for sl in Q_SLOT[k]]
     Qx, Qy, Qz = Q
     if Qz is None:                                   # affine Q: Z2 = 1
@@ -1009,7 +1037,7 @@ def miller_loop_d_routine():
     main += ["s_cmp_eq_u32 s78, 5", "s_cbranch_scc1 9f"]
     main += expand_calls_d(add0) + expand_calls_d(add1)
     main += ["s_add_u32 s78, s78, 1"] + far_back(4) + ["9:"]
-    epi = []
+    epi = ["s_waitcnt vmcnt(0)"]                    # nothing may still be in flight into registers when the routine returns
     B0, B1, B2, B5, B6 = (lambda j: "v%d" % j), (lambda j: "v%d" % (14 + j)), (lambda j: "v%d" % (28 + j)), (lambda j: "v%d" % (70 + j)), (lambda j: "v%d" % (84 + j))
     epi += ["v_mov_b32_e32 %s, 0x%08x" % (B2(j), dgt) for j, dgt in enumerate(digits_of(K384))]
     for i in range(6):                              # pairs of coefficients: (x 2^392)(2^384) / 2^392 = x 2^384, then the canonical words
