@@ -150,23 +150,28 @@ __global__ void MBLS_LB k_blind_sig(mbls_ws ws, const uint8_t* sigs96, const uin
     ws_st2(ws, MBLS_SLOT_S, i, s.x); ws_st2(ws, MBLS_SLOT_S + 2, i, s.y); ws_st2(ws, MBLS_SLOT_S + 4, i, s.z);
     if (st) atomicOr(status + i, st);
 }
-// f_i = Miller(H_i, P_i) for i < n; lane n (if sig_slot_valid) computes Miller(S, -G1) with S read from slot S of item `s_item`
+// f_i = Miller(H_i, P_i) for i < n; lane n (if with_sig) computes Miller(S, -G1) with S read from slot S of item `s_item`.
+// The loop itself is the generated single-pair routine (mbls_pairing.h, miller_loop_single_d).
 __global__ void MBLS_LB k_miller_single(mbls_ws ws, uint64_t n, int with_sig, uint64_t s_item) {
+    __shared__ uint32_t spill[154 * 64];
     uint64_t i = gid(); if (i > n || (i == n && !with_sig)) return;
+    // branch-free operand selection (lane n takes S and the constant -G1): the generated routine is called from uniform control flow
+    const bool last = (i == n);
+    const int qslot = last ? MBLS_SLOT_S : MBLS_SLOT_H;
+    const uint64_t qitem = last ? s_item : i;
+    g2j h; h.x = ws_ld2(ws, qslot, qitem); h.y = ws_ld2(ws, qslot + 2, qitem); h.z = ws_ld2(ws, qslot + 4, qitem);
+    g1j a; a.x = ws_ld(ws, MBLS_SLOT_APK, i); a.y = ws_ld(ws, MBLS_SLOT_APK + 1, i); a.z = ws_ld(ws, MBLS_SLOT_APK + 2, i);
+    a.x = fp_select(last, fp_load_const(MBLS_G1_X), a.x); a.y = fp_select(last, fp_load_const(MBLS_G1_NEG_Y), a.y); a.z = fp_select(last, fp_one(), a.z);
     mbls_pair pr;
-    if (i < n) {
-        g2j h; h.x = ws_ld2(ws, MBLS_SLOT_H, i); h.y = ws_ld2(ws, MBLS_SLOT_H + 2, i); h.z = ws_ld2(ws, MBLS_SLOT_H + 4, i);
-        g1j a; a.x = ws_ld(ws, MBLS_SLOT_APK, i); a.y = ws_ld(ws, MBLS_SLOT_APK + 1, i); a.z = ws_ld(ws, MBLS_SLOT_APK + 2, i);
-        pr.skip = g2_is_inf(&h) | g1_is_inf(&a);
-        g2h_from_jacobian(&pr.q, &h); g1arg_from_jacobian(&pr.p, &a);
-    } else {
-        g2j s; s.x = ws_ld2(ws, MBLS_SLOT_S, s_item); s.y = ws_ld2(ws, MBLS_SLOT_S + 2, s_item); s.z = ws_ld2(ws, MBLS_SLOT_S + 4, s_item);
-        pr.skip = g2_is_inf(&s);
-        g2h_from_jacobian(&pr.q, &s);
-        g1arg_from_affine(&pr.p, fp_load_const(MBLS_G1_X), fp_load_const(MBLS_G1_NEG_Y));
-    }
+    pr.skip = g2_is_inf(&h) | g1_is_inf(&a);
+    g2h_from_jacobian(&pr.q, &h); g1arg_from_jacobian(&pr.p, &a);
     pr.t = pr.q;
-    fp12 f; miller_loop(&f, &pr, 1);
+    fp12 f;
+#if MBLS_DEVICE_ASM && !defined(MBLS_NO_FP2_ASM) && !defined(MBLS_NO_LDS_STATE)
+    miller_loop_single_d(&f, &pr, ws.w, ws.stride, i, (MBLS_LDS uint32_t*)spill, threadIdx.x);
+#else
+    miller_loop(&f, &pr, 1);
+#endif
     const fp2* c = &f.c0.c0;
     for (int s = 0; s < 6; s++) ws_st2(ws, MBLS_SLOT_F + 2 * s, i, c[s]);
 }

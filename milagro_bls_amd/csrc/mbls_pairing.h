@@ -138,11 +138,16 @@ extern "C" __device__ __attribute__((noinline, used, aligned(64))) void mbls_mil
 #define MBLS_MILLER_D_LDS_DWORDS (11 * 14)        // spill slots per lane
 #define MBLS_SLOT_QARG 0                          // workspace slots the routine reads: (-px, py, pz^3) of pair 1 over the aggregate key,
 #define MBLS_SLOT_Q1 7                            // Q1 in homogeneous form over the Jacobian H(m); slots 3..6 already hold Q0 = the signature
-MBLS_FN void miller_loop_verify_d(fp12* f_out, const mbls_pair* pairs, uint32_t* ws_w, uint64_t ws_stride, uint64_t item,
-                                  MBLS_LDS uint32_t* spill, uint32_t lane) {
+extern "C" __device__ __attribute__((noinline, used, aligned(64))) void mbls_miller_loop_1p_d_asm_fn() {
+    asm volatile(MBLS_MILLER_LOOP_1P_D_ASM);
+}
+// pair 1's operands into the workspace slots the routines read, then the call. SINGLE: the one-pair routine (n-pairing paths).
+template <bool SINGLE>
+MBLS_FN void miller_loop_d_call(fp12* f_out, const mbls_pair* pr1, uint32_t flags, uint32_t* ws_w, uint64_t ws_stride, uint64_t item,
+                                MBLS_LDS uint32_t* spill, uint32_t lane) {
     uint32_t* w0 = ws_w + item;
-    const fp npx = fp_neg(pairs[1].p.px);
-    const fp* src[9] = {&npx, &pairs[1].p.py, &pairs[1].p.pz3, &pairs[1].q.x.c0, &pairs[1].q.x.c1, &pairs[1].q.y.c0, &pairs[1].q.y.c1, &pairs[1].q.z.c0, &pairs[1].q.z.c1};
+    const fp npx = fp_neg(pr1->p.px);
+    const fp* src[9] = {&npx, &pr1->p.py, &pr1->p.pz3, &pr1->q.x.c0, &pr1->q.x.c1, &pr1->q.y.c0, &pr1->q.y.c1, &pr1->q.z.c0, &pr1->q.z.c1};
     const int slot[9] = {MBLS_SLOT_QARG, MBLS_SLOT_QARG + 1, MBLS_SLOT_QARG + 2, MBLS_SLOT_Q1, MBLS_SLOT_Q1 + 1, MBLS_SLOT_Q1 + 2, MBLS_SLOT_Q1 + 3, MBLS_SLOT_Q1 + 4, MBLS_SLOT_Q1 + 5};
 #pragma unroll
     for (int t = 0; t < 9; t++) {
@@ -150,20 +155,35 @@ MBLS_FN void miller_loop_verify_d(fp12* f_out, const mbls_pair* pairs, uint32_t*
 #pragma unroll
         for (int j = 0; j < 12; j++) w0[((uint64_t)slot[t] * 12 + j) * ws_stride] = v[j];
     }
-    uint32_t flags = (pairs[0].skip ? 1u : 0u) | (pairs[1].skip ? 2u : 0u);
     const uint32_t addr = (uint32_t)(uintptr_t)(spill + lane);
     // the routine addresses word j of slot s as base + (12 s + j) * stride4 + v252: fold the item offset and the LDS address into the base
     const uint64_t gb = (uint64_t)(uintptr_t)ws_w + 4ull * (item - lane) - (uint64_t)(uint32_t)(uintptr_t)spill;
     const uint32_t gb_lo = __builtin_amdgcn_readfirstlane((uint32_t)gb), gb_hi = __builtin_amdgcn_readfirstlane((uint32_t)(gb >> 32));
     const uint32_t st4 = __builtin_amdgcn_readfirstlane((uint32_t)(ws_stride * 4));
     fp f0, f1, f2, f3, f4, f5, f6, f7, f8, f9, f10, f11;
-    asm volatile(MBLS_ASM_CALL("mbls_miller_loop_d_asm_fn")
-                 : MBLS_MILLER_D_OUT_REGS(f), "+{v253}"(flags)
-                 : "{v252}"(addr), "{s68}"(gb_lo), "{s69}"(gb_hi), "{s70}"(st4)
-                 : MBLS_MILLER_D_ASM_CLOBBERS);
+    if (SINGLE)
+        asm volatile(MBLS_ASM_CALL("mbls_miller_loop_1p_d_asm_fn")
+                     : MBLS_MILLER_D_OUT_REGS(f), "+{v253}"(flags)
+                     : "{v252}"(addr), "{s68}"(gb_lo), "{s69}"(gb_hi), "{s70}"(st4)
+                     : MBLS_MILLER_D_ASM_CLOBBERS);
+    else
+        asm volatile(MBLS_ASM_CALL("mbls_miller_loop_d_asm_fn")
+                     : MBLS_MILLER_D_OUT_REGS(f), "+{v253}"(flags)
+                     : "{v252}"(addr), "{s68}"(gb_lo), "{s69}"(gb_hi), "{s70}"(st4)
+                     : MBLS_MILLER_D_ASM_CLOBBERS);
     fp12 f; fp* c = &f.c0.c0.c0;
     c[0] = f0; c[1] = f1; c[2] = f2; c[3] = f3; c[4] = f4; c[5] = f5; c[6] = f6; c[7] = f7; c[8] = f8; c[9] = f9; c[10] = f10; c[11] = f11;
     fp12_conj(f_out, &f);
+}
+// the verification shape: pair 0 = (signature, -G1) -- the signature already sits in workspace slots 3..6 --, pair 1 = (H(m), apk)
+MBLS_FN void miller_loop_verify_d(fp12* f_out, const mbls_pair* pairs, uint32_t* ws_w, uint64_t ws_stride, uint64_t item,
+                                  MBLS_LDS uint32_t* spill, uint32_t lane) {
+    miller_loop_d_call<false>(f_out, &pairs[1], (pairs[0].skip ? 1u : 0u) | (pairs[1].skip ? 2u : 0u), ws_w, ws_stride, item, spill, lane);
+}
+// one general pair (Q, P): f_{|x|,Q}(P)
+MBLS_FN void miller_loop_single_d(fp12* f_out, const mbls_pair* pr, uint32_t* ws_w, uint64_t ws_stride, uint64_t item,
+                                  MBLS_LDS uint32_t* spill, uint32_t lane) {
+    miller_loop_d_call<true>(f_out, pr, pr->skip ? 2u : 0u, ws_w, ws_stride, item, spill, lane);
 }
 #endif
 // f^(3 (p^12-1)/r). Hard part: 3 (p^4-p^2+1)/r = (x-1)^2 (x+p) (x^2+p^2-1) + 3 (Hayashida-Hayasaka-Teruya);

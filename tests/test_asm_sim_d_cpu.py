@@ -293,9 +293,9 @@ def test_miller_bodies(which):
             assert (got - x * R392) % P == 0 and t.PACKED.vlo <= got <= t.PACKED.vhi, (which, trial, slot)
 
 
-def miller_loop_sim(runs, seed, masks_bits=0):
+def miller_loop_sim(runs, seed, masks_bits=0, pairs=(0, 1)):
     rng = random.Random(seed)
-    full, pieces, st = t.miller_loop_d_routine()
+    full, pieces, st = t.miller_loop_d_routine(pairs)
     m = miller_machine(masks_bits)
     true = {}
     for sl in range(13):
@@ -304,7 +304,7 @@ def miller_loop_sim(runs, seed, masks_bits=0):
     masks = {"s[48:49]": masks_bits & 1, "s[54:55]": (masks_bits >> 1) & 1}
     f = [1] + [0] * 11
     T = {}
-    for k in range(2):
+    for k in pairs:
         for e in range(3):
             for i in range(2):
                 sl = t.Q_SLOT[k][e]
@@ -320,10 +320,10 @@ def miller_loop_sim(runs, seed, masks_bits=0):
         T.update(mp.out_g)
     for ph, n in enumerate(runs):
         for _ in range(n):
-            m.run(pieces["dbl"]); step(t.prog_miller_dbl_d)
+            m.run(pieces["dbl"]); step(lambda: t.prog_miller_dbl_d(pairs))
         if ph < len(runs) - 1:
-            m.run(pieces["add0"]); step(lambda: t.prog_miller_add_d(0))
-            m.run(pieces["add1"]); step(lambda: t.prog_miller_add_d(1))
+            for k in pairs:
+                m.run(pieces["add%d" % k]); step(lambda k=k: t.prog_miller_add_d(k))
     m.run(pieces["epi"][:-1])
     for i in range(12):
         assert from_limbs(m.v[t.F_OUT[i]:t.F_OUT[i] + 12]) == f[i] * R384 % P, ("f", i)
@@ -337,6 +337,8 @@ def test_miller_loop_routine_short_schedules():
     miller_loop_sim([1, 2, 1], 5)
     miller_loop_sim([2, 1], 6, masks_bits=1)          # pair 0 contributes 1 (infinite signature)
     miller_loop_sim([1, 1], 7, masks_bits=2)
+    miller_loop_sim([2, 1, 1], 8, pairs=(1,))           # the single-pair routine of the n-pairing paths
+    miller_loop_sim([1, 1], 9, masks_bits=2, pairs=(1,))
 
 
 def test_g2_doubling_runs():

@@ -38,6 +38,10 @@ ALL_V = FREE_V + [3, 2, 1, 0, 4, 6, 5]          # block 7 holds the routines' ac
 LADDR, TMP = "v252", "v254"             # v253: -q of reduce, v[254:255]: its 64-bit running sum; v254 also the carry of norm
 
 
+UNTOUCHED_V = range(102, 108)        # block 7 only holds the product scans' accumulators (v98..v101); the shells' register groups start at
+# v108: these six registers are never written by any routine here and stay available to the calling code across a call
+
+
 def vb(b):
     return 14 * b
 
@@ -901,18 +905,19 @@ def f_store(p, f):
         p.store(prog_norm(p, v), h)
 
 
-def prog_miller_dbl_d():
-    """One doubling iteration of the two-pair (verification-shape) Miller loop: f <- f^2, then for each pair T <- 2T and f <- f * line
+def prog_miller_dbl_d(pairs=(0, 1)):
+    """One doubling iteration of the Miller loop for the two pairs of a verification (or, pairs = (1,), for a single general pair): f <- f^2, then for each pair T <- 2T and f <- f * line
     (formulas of miller_dbl_step / fp12_sqr / fp12_mul_line in mbls_pairing.h / mbls_tower.h). f in AGPR homes; the running points and
     the second G1 argument live in the HBM workspace as packed words (fetched when needed, the points written back at the end of their
     step), which leaves the whole LDS allocation to the allocator as spill space."""
     p = Prog()
     f = f_live_in(p)
     p1 = [p.live_in(h) for h in P1_HOME]
-    if not MERGE_LINES:
+    merge = MERGE_LINES and len(pairs) == 2
+    if not merge:
         f = p.sqr12(f)
     lines = []
-    for k in range(2):
+    for k in pairs:
         Tx, Ty, Tz = t_live_in(p, k)
         B = p.sqr2(Ty); C = p.sqr2(Tz)
         E = p.mul12_2(p.mul_xi2(C))
@@ -932,11 +937,11 @@ def prog_miller_dbl_d():
         z3 = p.mul4_2(p.mul2(B, YZ2))
         for e, v in enumerate((x3, y3, z3)):
             storep2(p, v, k, e)
-        if MERGE_LINES:
+        if merge:
             lines.append(masked_line(p, c0, c2, c3, k))
         else:
             f = line_into_f(p, f, c0, c2, c3, k)
-    if MERGE_LINES:                                  # the two lines are multiplied together first: 6 + 17 instead of 13 + 13 products
+    if merge:                                        # the two lines are multiplied together first: 6 + 17 instead of 13 + 13 products
         L0, L1 = mul_lines(p, lines[0], lines[1])
         f = mul12_by_lines(p, p.sqr12(f), L0, L1)
     f_store(p, f)
@@ -982,8 +987,8 @@ def prog_miller_add_d(k):
     return p
 
 
-def build_miller(which):
-    p = prog_miller_dbl_d() if which == "dbl" else prog_miller_add_d(which)
+def build_miller(which, pairs=(0, 1)):
+    p = prog_miller_dbl_d(pairs) if which == "dbl" else prog_miller_add_d(which)
     inb = {}
     for v, l in p.init_loc.items():
         inb[v] = PACKED if l[0] == "gd" else G_IN if l[0] == "g" else F_IN
@@ -1004,14 +1009,15 @@ def far_back(label):
     return ["s_getpc_b64 s[66:67]", "7:", "s_sub_u32 s66, s66, 7b-%db" % label, "s_subb_u32 s67, s67, 0", "s_setpc_b64 s[66:67]"]
 
 
-def miller_loop_d_routine():
-    """The whole two-pair Miller loop of a verification as ONE routine: f = prod_k f_{|x|,Q_k}(P_k) (the caller conjugates).
+def miller_loop_d_routine(pairs=(0, 1)):
+    """The whole two-pair Miller loop of a verification as ONE routine: f = prod_k f_{|x|,Q_k}(P_k) (the caller conjugates); with
+    pairs = (1,) the loop of a single general pair (Q_1, P_1) for the n-pairing paths (pair 0's slots are then unused).
     In:  v252 LDS byte address of the lane's column (11 spill slots), v253 skip flags (bit k: pair k contributes 1),
          s[68:69] workspace base adjusted so that v252 is the lane offset, s70 bytes between consecutive words of a value;
          workspace slots 0..2 = (-px, py, pz^3) of pair 1, 3..6 = Q0 (affine x, y), 7..12 = Q1 (homogeneous x, y, z), 2^384 domain.
     Out: f in v108..v251 (twelve groups of 12 words, tower order, canonical, 2^384 domain). Workspace slots 31..42 are scratch."""
-    dbl, st_dbl = build_miller("dbl")
-    add0, st_a0 = build_miller(0)
+    dbl, st_dbl = build_miller("dbl", pairs)
+    add0, st_a0 = build_miller(0) if 0 in pairs else ([], {})
     add1, st_a1 = build_miller(1)
     W = lambda j: "v%d" % (vb(8) + j)              # work block of the shell
     pro = ["s_mov_b64 s[36:37], s[30:31]", "s_waitcnt vmcnt(0)"] + shell_constants()
@@ -1019,7 +1025,7 @@ def miller_loop_d_routine():
     for i in range(12):                             # f = 1
         for j, dgt in enumerate(digits_of(ONE_D if i == 0 else 0)):
             pro += ["v_mov_b32_e32 v254, 0x%08x" % dgt, "v_accvgpr_write_b32 a%d, v254" % (vb(i) + j)]
-    for k in range(2):                              # T_k = Q_k, into the packed 2^392-domain slots
+    for k in pairs:                                 # T_k = Q_k, into the packed 2^392-domain slots
         for e in range(3):
             for i in range(2):
                 sl = Q_SLOT[k][e]
@@ -1116,12 +1122,15 @@ def main():
     txt += emit("MBLS_MILLER_LOOP_D_ASM", full) + "\n"
     for kname, v in st.items():
         print("miller", kname, len(pieces[kname]), "lines", v)
+    full, pieces, st = miller_loop_d_routine((1,))
+    txt += emit("MBLS_MILLER_LOOP_1P_D_ASM", full) + "\n"
+    print("miller single pair: dbl", len(pieces["dbl"]), "lines", st["dbl"])
     sgm = '"s30","s31","s36","s37","s39","s40","s41","s42","s43","s44","s45","s46","s47","s48","s49","s54","s55","s56","s57","s58","s59","s60","s61","s62","s63","s64","s65","s66","s67","s73","s74","s75","s76","s77","s78","vcc","scc","memory"'
     fout = set(r for b in F_OUT for r in range(b, b + 12))
     txt += "// the Miller-loop routine returns f in twelve register groups\n"
     txt += "#define MBLS_MILLER_D_OUT_REGS(x) " + ", ".join('"={v[%d:%d]}"(x##%d)' % (b, b + 11, i) for i, b in enumerate(F_OUT)) + "\n"
     txt += "#define MBLS_MILLER_D_ASM_CLOBBERS %s,%s, \\\n    %s\n" % (
-        ",".join('"v%d"' % i for i in range(256) if i not in fout and i != 252 and i != 253), ",".join('"a%d"' % i for i in range(252)), sgm)
+        ",".join('"v%d"' % i for i in range(256) if i not in fout and i not in (252, 253) and i not in UNTOUCHED_V), ",".join('"a%d"' % i for i in range(252)), sgm)
     full, pieces, st = g2_dbl_d_routine()
     txt += emit("MBLS_G2_DBL_D_ASM", full) + "\n"
     print("g2_dbl_d", len(pieces["body"]), "lines", st)
@@ -1129,9 +1138,9 @@ def main():
     txt += "#define MBLS_G2D_ARG_REGS(x) " + ", ".join('"+{v[%d:%d]}"(x##%d)' % (b, b + 11, i) for i, b in enumerate(G2D_ARG)) + "\n"
     sg = '"s30","s31","s36","s37","s39","s40","s41","s42","s43","s44","s45","s46","s47","s56","s57","s58","s59","s60","s61","s62","s63","s64","s65","s66","s67","s73","vcc","scc","memory"'
     txt += "// everything a D-form tower routine may overwrite (v252 carries the LDS address and is preserved)\n"
-    txt += "#define MBLS_TOWERD_ASM_CLOBBERS %s,%s, \\\n    %s\n" % (",".join('"v%d"' % i for i in list(range(252)) + [253, 254, 255]), ",".join('"a%d"' % i for i in range(252)), sg)
+    txt += "#define MBLS_TOWERD_ASM_CLOBBERS %s,%s, \\\n    %s\n" % (",".join('"v%d"' % i for i in list(range(252)) + [253, 254, 255] if i not in UNTOUCHED_V), ",".join('"a%d"' % i for i in range(252)), sg)
     txt += "#define MBLS_G2D_ASM_CLOBBERS %s,%s, \\\n    %s\n" % (
-        ",".join('"v%d"' % i for i in range(256) if i not in g2r), ",".join('"a%d"' % i for i in range(252)), sg)
+        ",".join('"v%d"' % i for i in range(256) if i not in g2r and i not in UNTOUCHED_V), ",".join('"a%d"' % i for i in range(252)), sg)
     with open(path, "w") as f:
         f.write(txt)
     print("wrote", path)
