@@ -89,3 +89,40 @@ def test_code_object_has_no_base_pointer_frames(lib_path):
     assert "v_mfma" not in dis                         # carry-chain integer work, no MFMA
     assert not re.search(r"s_andn2_b32 s33, s33", dis), "a function realigns its stack (base pointer hazard)"
     assert not re.search(r"s_mov_b32 s32, s34", dis), "a function restores SP from the base pointer s34"
+
+
+def kernel_metadata(lib_path):
+    """per-kernel resource metadata of the gfx950 code object (llvm-readelf --notes)"""
+    with tempfile.TemporaryDirectory() as d:
+        so = os.path.join(d, "lib.so")
+        shutil.copy(lib_path, so)
+        subprocess.check_call([LLVM + "/llvm-objdump", "--offloading", so], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        co = [f for f in os.listdir(d) if "gfx950" in f]
+        notes = subprocess.check_output([LLVM + "/llvm-readelf", "--notes", os.path.join(d, co[0])], text=True)
+    meta, cur = {}, {}
+    for line in notes.splitlines():
+        m = re.match(r"\s+-?\s*\.(name|private_segment_fixed_size|vgpr_count|agpr_count|vgpr_spill_count|group_segment_fixed_size):\s+(\S+)", line)
+        if not m:
+            continue
+        if m.group(1) == "agpr_count" and "name" in cur:          # the first key of the next kernel's record
+            meta[cur["name"]] = cur; cur = {}
+        cur[m.group(1)] = m.group(2)
+    if "name" in cur:
+        meta[cur["name"]] = cur
+    return meta
+
+
+def test_kernel_resources(lib_path):
+    """What the design rests on, read back from the built code object: the generated Miller kernel has no lane-private memory, the five
+    pipeline kernels are 512-register / one-wave-per-SIMD kernels whose LDS fits four waves per CU, and the key-decompression kernel is
+    (like them) a one-wave kernel -- its square-root routine keeps a 210-register window table."""
+    meta = kernel_metadata(lib_path)
+    by = lambda prefix: next(v for k, v in meta.items() if k.startswith(prefix))
+    km = by("_Z8k_miller")
+    assert int(km["private_segment_fixed_size"]) == 0 and int(km["vgpr_spill_count"]) == 0
+    assert int(by("_Z15k_miller_single")["private_segment_fixed_size"]) < int(by("_Z7k_final")["private_segment_fixed_size"])
+    for k in ("_Z8k_miller", "_Z7k_final", "_Z6k_hash", "_Z5k_sig"):
+        assert int(by(k)["vgpr_count"]) == 512, k
+    for k in ("_Z8k_miller", "_Z7k_final", "_Z15k_miller_single"):
+        assert int(by(k)["group_segment_fixed_size"]) * 4 <= 160 * 1024, k
+    assert int(by("_Z15k_pk_decompress")["agpr_count"]) >= 210
