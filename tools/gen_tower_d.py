@@ -1060,7 +1060,7 @@ def miller_loop_d_routine(pairs=(0, 1)):
 
 # ---------------------------------------------------------------------------------------------- G2 doubling (subgroup check, cofactor clearing)
 G2D_ARG = [108 + 12 * i for i in range(6)]         # X.c0, X.c1, Y.c0, Y.c1, Z.c0, Z.c1 as six groups of 12 words, in and out
-G2_IN = Bound.normalised(-16 * P, 16 * P)
+G2_IN = Bound.normalised(-16 * P, 16 * P)          # every round, the first included: the shell reduces the converted inputs
 
 
 def prog_g2_dbl_d():
@@ -1089,8 +1089,8 @@ def g2_dbl_d_routine():
         assert B.vlo >= G2_IN.vlo and B.vhi <= G2_IN.vhi and B.dlo >= 0 and B.dhi <= M28, (dst, B)
     W = lambda j: "v%d" % j
     pro = ["s_mov_b32 s39, s38"]
-    for i in range(6):
-        pro += seq_conv(W, ["v%d" % (G2D_ARG[i] + q) for q in range(12)], True)
+    for i in range(6):                              # words * 2^8 can be 256 p: reduce, so that the bounds the body was generated under hold
+        pro += seq_conv(W, ["v%d" % (G2D_ARG[i] + q) for q in range(12)], True) + seq_reduce(W)        # from the first round on
         pro += ["v_accvgpr_write_b32 a%d, v%d" % (vb(i) + j, j) for j in range(14)]
     B0, B1, B2, B5, B6 = (lambda j: "v%d" % j), (lambda j: "v%d" % (14 + j)), (lambda j: "v%d" % (28 + j)), (lambda j: "v%d" % (70 + j)), (lambda j: "v%d" % (84 + j))
     epi = ["v_mov_b32_e32 %s, 0x%08x" % (B2(j), dgt) for j, dgt in enumerate(digits_of(K384))]
