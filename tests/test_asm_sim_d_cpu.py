@@ -160,7 +160,7 @@ def test_generated_d_files_up_to_date():
 # The programs of tools/gen_tower_d.py are executed twice: by the allocator (-> instructions, interpreted by asm_sim) and by ModelProg,
 # which implements the same Prog interface on true field values. Agreement checks the allocator, the bound tracking (no 32-bit /
 # 64-bit overflow is possible: the simulator asserts), the packing / HBM fetch sequences and the shells.
-from gen_tower_asm import Prog   # noqa: E402
+from gen_tower_d import Prog     # noqa: E402  (the digit-form recorder: the limb recorder plus scale / shadd)
 
 R392, R384 = 1 << 392, 1 << 384
 RI392 = pow(R392, -1, P)
@@ -174,6 +174,10 @@ class _Ops(list):
         kind, outs, ins, aux = op
         if kind in ("norm", "reduce"):
             self.o.val[outs[0]] = self.o.val[ins[0]]
+        elif kind == "scale":
+            self.o.val[outs[0]] = self.o.val[ins[0]] * aux % P
+        elif kind == "shadd":
+            self.o.val[outs[0]] = ((self.o.val[ins[0]] << aux) + self.o.val[ins[1]]) % P
         elif kind == "storep":
             self.o.out_g[aux] = self.o.val[ins[0]]
         else:

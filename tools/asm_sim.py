@@ -159,6 +159,8 @@ class Machine:
                 self.wr(args[0], self.rd(args[2]) >> self.rd(args[1]))
             elif op == "v_lshl_add_u64":
                 self.wr(args[0], ((self.rd(args[1]) << self.rd(args[2])) + self.rd(args[3])) & 0xFFFFFFFFFFFFFFFF)
+            elif op == "v_lshl_add_u32":
+                self.wr(args[0], (self.rd(args[1]) << self.rd(args[2])) + self.rd(args[3]))
             elif op == "v_lshl_or_b32":
                 self.wr(args[0], (self.rd(args[1]) << self.rd(args[2])) | self.rd(args[3]))
             elif op == "v_sub_u32_e32":

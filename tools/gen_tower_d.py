@@ -27,7 +27,27 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from gen_fp_asm import P, P28, M28, SP28, SMASK28, emit  # noqa: E402
 from gen_fpd_asm import load_constants, column_ok  # noqa: E402
-from gen_tower_asm import Prog, expand_calls, INF  # noqa: E402
+from gen_tower_asm import Prog as LimbProg, expand_calls, INF  # noqa: E402
+
+
+class Prog(LimbProg):
+    """the recorder of tools/gen_tower_asm.py with the small-constant multiples as single operations: on carry-free digits k * a is one
+    instruction per digit (a shift or v_mul_lo_u32 by an inline constant) instead of a chain of additions, and 2^s a + b is one
+    v_lshl_add_u32"""
+
+    def scale(self, a, k):
+        d = self.new(); self.ops.append(("scale", [d], [a], k)); return d
+
+    def shadd(self, a, s, b):
+        d = self.new(); self.ops.append(("shadd", [d], [a, b], s)); return d
+
+    def scale2(self, a, k): return (self.scale(a[0], k), self.scale(a[1], k))
+    def shadd2(self, a, s, b): return (self.shadd(a[0], s, b[0]), self.shadd(a[1], s, b[1]))
+    def dbl2(self, a): return self.scale2(a, 2)
+    def mul3_2(self, a): return self.scale2(a, 3)
+    def mul4_2(self, a): return self.scale2(a, 4)
+    def mul8_2(self, a): return self.scale2(a, 8)
+    def mul12_2(self, a): return self.scale2(a, 12)
 
 R392 = 1 << 392
 PTOP = P >> 364                      # top digit of p
@@ -75,6 +95,10 @@ class Bound:
 
     def __sub__(self, o):
         return Bound(self.dlo - o.dhi, self.dhi - o.dlo, self.tlo - o.thi, self.thi - o.tlo, self.vlo - o.vhi, self.vhi - o.vlo)
+
+    def scaled(self, k):
+        assert k > 0
+        return Bound(self.dlo * k, self.dhi * k, self.tlo * k, self.thi * k, self.vlo * k, self.vhi * k)
 
     def union(self, o):
         return Bound(min(self.dlo, o.dlo), max(self.dhi, o.dhi), min(self.tlo, o.tlo), max(self.thi, o.thi), min(self.vlo, o.vlo), max(self.vhi, o.vhi))
@@ -514,6 +538,10 @@ class AllocD:
                 self.do_reduce(k, outs[0], ins[0])
             elif kind == "norm":
                 self.do_norm(k, outs[0], ins[0])
+            elif kind == "scale":
+                self.do_scale(k, outs[0], ins[0], aux)
+            elif kind == "shadd":
+                self.do_arith(k, "shadd", outs[0], ins[0], ins[1], aux)
             elif kind == "storep":
                 self.do_storep(k, ins[0], aux)
             elif kind == "keep":
@@ -535,7 +563,7 @@ class AllocD:
                 self.to_vgpr(a, k, avoid=(self.loc[b][1],))
         ba, bb = self.loc[a][1], self.loc[b][1]
         Ba, Bb = self.bound[a], self.bound[b]
-        res = {"add": lambda: Ba + Bb, "sub": lambda: Ba - Bb, "sel": lambda: Ba.union(Bb)}[kind]
+        res = {"add": lambda: Ba + Bb, "sub": lambda: Ba - Bb, "sel": lambda: Ba.union(Bb), "shadd": lambda: Ba.scaled(1 << aux) + Bb}[kind]
         if not res().fits():                                # renormalise the larger operand(s) first
             for v in sorted({a, b}, key=lambda x: -self.bound[x].mag()):
                 self.ensure(v, k)
@@ -563,6 +591,9 @@ class AllocD:
         elif kind == "sub":
             for j in range(14):
                 self.e("v_sub_u32_e64 v%d, v%d, v%d" % (D + j, A + j, B_ + j))
+        elif kind == "shadd":                               # 2^aux a + b
+            for j in range(14):
+                self.e("v_lshl_add_u32 v%d, v%d, %d, v%d" % (D + j, A + j, aux, B_ + j))
         else:                                               # sel: mask ? b : a
             for j in range(14):
                 self.e("v_cndmask_b32_e64 v%d, v%d, v%d, %s" % (D + j, A + j, B_ + j, aux))
@@ -587,6 +618,42 @@ class AllocD:
         self.stats["reduce"] += 60
         self.place(d, ("v", b))
         self.bound[d] = REDUCED
+
+    def do_scale(self, k, d, a, c):
+        """d = c a for a small positive constant: a shift or one multiplication by an inline constant per digit; where c a would
+        leave the 32-bit digit range the constant is split into factors with a carry pass in between (12 = 4 * 3)"""
+        b = self.to_vgpr(a, k)
+        self.wait_lds()
+        hint = self.hint_for(d, k)
+        if hint is not None and hint != b and ("v", hint) not in self.at and ("vw", hint) not in self.at:
+            bd = hint
+        elif self.next_use(a, k + 1) == INF:
+            bd = b
+        else:
+            bd = self.alloc_v(k, avoid=(b,))
+        B, src, rest = self.bound[a], b, c
+        while rest > 1:
+            f = max((g for g in range(2, rest + 1) if rest % g == 0 and B.scaled(g).fits()), default=None)
+            if f is None:                                   # no factor fits: carry pass first (in the destination block)
+                assert B.mag() > (1 << 28) + 64, ("scale: digit overflow", B, c)
+                if src != bd:
+                    self.copy(("v", src), ("v", bd)); src = bd
+                for l in seq_norm(lambda j: "v%d" % (vb(bd) + j)):
+                    self.e(l)
+                self.stats["norm"] += 39
+                B = Bound.normalised(B.vlo, B.vhi)
+                continue
+            for j in range(14):
+                if f & (f - 1) == 0:
+                    self.e("v_lshlrev_b32_e64 v%d, %d, v%d" % (vb(bd) + j, f.bit_length() - 1, vb(src) + j))
+                else:
+                    self.e("v_mul_lo_u32 v%d, v%d, %d" % (vb(bd) + j, vb(src) + j, f))
+            self.stats["arith"] += 14
+            B, src, rest = B.scaled(f), bd, rest // f
+        if self.loc.get(a) == ("v", bd):
+            self.release(a)
+        self.place(d, ("v", bd))
+        self.bound[d] = B
 
     def do_norm(self, k, d, a):
         """explicit carry pass (a loop-carried value must meet its live-in bound)"""
@@ -743,15 +810,15 @@ def prog_cyc_sqr_d():
         for i in range(2):
             p.store(prog_reduce(p, v[i]), A_HOME(2 * e + i))
     t0, t1 = fp4_sqr(z0, z1)
-    out(p.add2(p.dbl2(p.sub2(t0, z0)), t0), 0)
-    out(p.add2(p.dbl2(p.add2(t1, z1)), t1), 4)
+    out(p.shadd2(p.sub2(t0, z0), 1, t0), 0)          # 2 (t - z) + t
+    out(p.shadd2(p.add2(t1, z1), 1, t1), 4)
     t0, t1 = fp4_sqr(z2, z3)
     t2, t3 = fp4_sqr(z4, z5)
-    out(p.add2(p.dbl2(p.sub2(t0, z4)), t0), 1)
-    out(p.add2(p.dbl2(p.add2(t1, z5)), t1), 5)
+    out(p.shadd2(p.sub2(t0, z4), 1, t0), 1)
+    out(p.shadd2(p.add2(t1, z5), 1, t1), 5)
     x = p.mul_xi2(t3)
-    out(p.add2(p.dbl2(p.add2(x, z2)), x), 3)
-    out(p.add2(p.dbl2(p.sub2(t2, z3)), t2), 2)
+    out(p.shadd2(p.add2(x, z2), 1, x), 3)
+    out(p.shadd2(p.sub2(t2, z3), 1, t2), 2)
     return p
 
 
