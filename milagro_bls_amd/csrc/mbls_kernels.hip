@@ -97,7 +97,7 @@ __global__ void MBLS_LB k_miller(mbls_ws ws, uint64_t n) {
 }
 __global__ void MBLS_LB k_final(mbls_ws ws, uint32_t* status, uint8_t* results, uint64_t n) {
 #if !defined(MBLS_NO_LDS_STATE)
-    __shared__ uint32_t accstore[144 * 64];       // the running power of the cyclotomic exponentiations
+    __shared__ uint32_t accstore[154 * 64];       // spill slots of the generated exponentiation routine / the Fp12 parked by the one-shot products
     uint64_t i = gid(); if (i >= n) return;
     uint32_t st = status[i]; uint8_t r; lane_final(ws, i, &st, &r, (MBLS_LDS uint32_t*)accstore, threadIdx.x, true); status[i] = st; results[i] = r;
 #else

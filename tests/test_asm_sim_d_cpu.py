@@ -1,7 +1,7 @@
 """The digit-form ("D-form") routines of tools/gen_fpd_asm.py and tools/gen_tower_d.py interpreted on the CPU by tools/asm_sim.py and
 compared with big-integer arithmetic in the 2^392 Montgomery domain: the three Fp2 product scans on signed unsaturated digits (with
-redundant digit vectors at the routines' input limits), the carry / reduce / canonical passes, and the complete cyclotomic-squaring
-routine (unpack from LDS, n squarings on AGPR-resident digits, canonical repack) against the formulas of fp12_cyc_sqr."""
+redundant digit vectors at the routines' input limits), the carry / reduce / canonical passes, the cyclotomic squaring body against
+the formulas of fp12_cyc_sqr, and the Miller-loop, exponentiation and G2-doubling routines against the same programs run on field values."""
 import os
 import random
 import subprocess
@@ -123,29 +123,27 @@ def cyc_model(z):
 
 
 def test_cyclotomic_squaring_routine():
-    full, body, stats, pro, epi = t.cyc_sqr_d_routine()
-    assert not any("scratch" in l or "buffer_" in l for l in full)
+    """the squaring body of the exponentiation routine (state in AGPRs, reduced and normalised between iterations) against the formulas
+    of fp12_cyc_sqr written out above -- independent of the program recorder the other tests share with the generator"""
+    body, stats = t.build_cyc_sqr_d()
+    assert not any("scratch" in l or "buffer_" in l for l in body)
     rng = random.Random(9)
     for trial in range(4):
         z = [(rng.randrange(P), rng.randrange(P)) for _ in range(6)]
         if trial == 0:
             z = [(0, P - 1)] * 3 + [(P - 1, 0)] * 3
-        m = Machine(ROUT); m.v[252] = 8192
+        m = miller_machine(0); m.run(t.shell_constants())
         for e in range(6):
             for i in range(2):
-                for j, w in enumerate(limbs(z[e][i])):
-                    m.lds[8192 + ((2 * e + i) * 12 + j) * 256] = w
-        m.run(t.shell_constants()); m.run(pro[1:])
+                rep = z[e][i] + rng.choice([-15, -1, 0, 14]) * P
+                m.a[14 * (2 * e + i):14 * (2 * e + i) + 14] = normalised_digits(rep)
         exp = z
         for r in range([1, 2, 3, 5][trial]):
             m.run(body); exp = cyc_model(exp)
             for e in range(12):                                      # loop invariant: reduced, normalised
                 v = from_digits_signed(m.a[14 * e:14 * e + 14])
                 assert t.REDUCED.vlo <= v <= t.REDUCED.vhi and all(0 <= s32(w) < (1 << 28) for w in m.a[14 * e:14 * e + 13])
-        m.run(epi)
-        for e in range(6):
-            got = tuple(from_limbs([m.lds[8192 + ((2 * e + i) * 12 + j) * 256] for j in range(12)]) for i in range(2))
-            assert got == exp[e], (trial, e)
+                assert v % P == exp[e // 2][e % 2], (trial, r, e)
 
 
 def test_generated_d_files_up_to_date():
@@ -369,3 +367,32 @@ def test_g2_doubling_runs():
 def test_miller_loop_routine_full_schedule():
     """the complete loop as the kernel runs it: 63 doubling iterations and 5 addition steps per pair, ~6 million interpreted instructions"""
     miller_loop_sim(t.RUNS, 7)
+
+
+def test_cyclotomic_exponentiation_routine_short_schedule():
+    """prologue (acc = y from the workspace, reduced), squaring runs with the state in AGPRs, multiplications by y fetched from the
+    workspace, epilogue (canonical 2^384-domain words); the real schedule is runs of 1, 2, 3, 9, 32 and 16 squarings"""
+    full, pieces, st = t.cyc_exp_x_d_routine()
+    assert not any("scratch" in l or "buffer_" in l for l in full)
+    rng = random.Random(31)
+    for runs in ([1, 2, 1], [3, 1]):
+        m = miller_machine(0)
+        y = [rng.randrange(P) for _ in range(12)]
+        for i in range(12):
+            ws_put(m, t.G12_SLOT + i, y[i] * R384 % P)
+        m.run(pieces["pro"])
+        acc = list(y)
+
+        def step(progf, acc):
+            init = {("a", i): acc[i] for i in range(12)}
+            init.update({("g", t.G12_SLOT + i): y[i] for i in range(12)})
+            mp = run_model(progf, init, {})
+            return [mp.out_home[("a", i)] for i in range(12)]
+        for ph, n in enumerate(runs):
+            for _ in range(n):
+                m.run(pieces["sqr"]); acc = step(t.prog_cyc_sqr_d, acc)
+            if ph < len(runs) - 1:
+                m.run(pieces["mul"]); acc = step(t.prog_cyc_mul_d, acc)
+        m.run(pieces["epi"][:-1])
+        for i in range(12):
+            assert from_limbs(m.v[t.F_OUT[i]:t.F_OUT[i] + 12]) == acc[i] * R384 % P, (runs, i)

@@ -794,7 +794,8 @@ A_HOME = lambda i: ("a", i)
 
 def prog_cyc_sqr_d():
     """Granger-Scott squaring in the cyclotomic subgroup (formulas of fp12_cyc_sqr in mbls_tower.h), state in AGPR blocks 0..11 in
-    tower order, in place. Every output re-enters the next squaring through the linear terms 3 t -+ 2 z, so each is reduced."""
+    tower order, in place (the loop body of cyc_exp_x_d_routine). Every output re-enters the next squaring through the linear terms
+    3 t -+ 2 z, so each is reduced."""
     p = Prog()
     z = [(p.live_in(A_HOME(2 * e)), p.live_in(A_HOME(2 * e + 1))) for e in range(6)]
     z0, z4, z3, z2, z1, z5 = z
@@ -848,43 +849,6 @@ def expand_calls_d(lines):
         else:
             out.append(l)
     return out
-
-
-STATE_BLK = 8                       # VGPR block used by the shells for unpacking / packing
-
-
-def unpack_state(n, reduce_it):
-    """LDS packed slots 0..n-1 (12 words each, 2^392 domain, non-negative) -> AGPR homes 0..n-1 in D-form"""
-    L = []
-    reg = lambda j: "v%d" % (vb(STATE_BLK) + j)
-    for e in range(n):
-        L += lds_read_words([reg(j + 2) for j in range(12)], 12 * e) + WAIT_LDS
-        L += seq_conv(reg, [reg(j + 2) for j in range(12)], False)
-        if reduce_it:
-            L += seq_reduce(reg)
-        L += ["v_accvgpr_write_b32 a%d, %s" % (vb(e) + j, reg(j)) for j in range(14)]
-    return L
-
-
-def pack_state(n):
-    """AGPR homes 0..n-1 (reduced values: normalised digits, |value| < p) -> LDS packed slots, CANONICAL representatives in [0, p)"""
-    L = []
-    reg = lambda j: "v%d" % (vb(STATE_BLK) + j)
-    for e in range(n):
-        L += ["v_accvgpr_read_b32 %s, a%d" % (reg(j), vb(e) + j) for j in range(14)]
-        L += seq_canonical(reg) + seq_to32(reg)
-        L += lds_write_words([reg(j) for j in range(12)], 12 * e)
-    return L + WAIT_LDS
-
-
-def cyc_sqr_d_routine():
-    """s38 squarings of the Fp12 parked in LDS (12 packed values: canonical representatives of x 2^392, i.e. the 2^392 Montgomery
-    domain), in place. The first-generation Fp12 multiplication routine works on the same parked value unchanged: it divides by 2^384
-    and its other operand is in the 2^384 domain, so the product stays in the 2^392 domain."""
-    body, stats = build_cyc_sqr_d()
-    pro = ["s_mov_b32 s39, s38"] + unpack_state(12, False)
-    epi = pack_state(12)
-    return wrap_loop_d(expand_calls_d(body), "s39", pro, epi), body, stats, pro, epi
 
 
 # ---------------------------------------------------------------------------------------------- the Miller loop
@@ -1076,6 +1040,22 @@ def far_back(label):
     return ["s_getpc_b64 s[66:67]", "7:", "s_sub_u32 s66, s66, 7b-%db" % label, "s_subb_u32 s67, s67, 0", "s_setpc_b64 s[66:67]"]
 
 
+def f_out_epilogue():
+    """the Fp12 in AGPR blocks 0..11 (D-form, 2^392 domain) -> canonical words of the 2^384 domain in the register groups F_OUT"""
+    epi = ["s_waitcnt vmcnt(0)"]                    # nothing may still be in flight into registers when the routine returns
+    B0, B1, B2, B5, B6 = (lambda j: "v%d" % j), (lambda j: "v%d" % (14 + j)), (lambda j: "v%d" % (28 + j)), (lambda j: "v%d" % (70 + j)), (lambda j: "v%d" % (84 + j))
+    epi += ["v_mov_b32_e32 %s, 0x%08x" % (B2(j), dgt) for j, dgt in enumerate(digits_of(K384))]
+    for i in range(6):                              # pairs of coefficients: (x 2^392)(2^384) / 2^392 = x 2^384, then the canonical words
+        epi += ["v_accvgpr_read_b32 %s, a%d" % (B0(j), vb(2 * i) + j) for j in range(14)]
+        epi += ["v_accvgpr_read_b32 %s, a%d" % (B1(j), vb(2 * i + 1) + j) for j in range(14)]
+        epi += ["CALL mbls_fp2_mulfp_d_asm_fn"]
+        for h, B in ((0, B5), (1, B6)):
+            epi += seq_reduce(B) + seq_canonical(B) + seq_to32(B)
+            epi += ["v_mov_b32_e64 v%d, %s" % (F_OUT[2 * i + h] + j, B(j)) for j in range(12)]
+    epi += ["s_mov_b64 s[30:31], s[36:37]"]
+    return epi
+
+
 def miller_loop_d_routine(pairs=(0, 1)):
     """The whole two-pair Miller loop of a verification as ONE routine: f = prod_k f_{|x|,Q_k}(P_k) (the caller conjugates); with
     pairs = (1,) the loop of a single general pair (Q_1, P_1) for the n-pairing paths (pair 0's slots are then unused).
@@ -1110,19 +1090,68 @@ def miller_loop_d_routine(pairs=(0, 1)):
     main += ["s_cmp_eq_u32 s78, 5", "s_cbranch_scc1 9f"]
     main += expand_calls_d(add0) + expand_calls_d(add1)
     main += ["s_add_u32 s78, s78, 1"] + far_back(4) + ["9:"]
-    epi = ["s_waitcnt vmcnt(0)"]                    # nothing may still be in flight into registers when the routine returns
-    B0, B1, B2, B5, B6 = (lambda j: "v%d" % j), (lambda j: "v%d" % (14 + j)), (lambda j: "v%d" % (28 + j)), (lambda j: "v%d" % (70 + j)), (lambda j: "v%d" % (84 + j))
-    epi += ["v_mov_b32_e32 %s, 0x%08x" % (B2(j), dgt) for j, dgt in enumerate(digits_of(K384))]
-    for i in range(6):                              # pairs of coefficients: (x 2^392)(2^384) / 2^392 = x 2^384, then the canonical words
-        epi += ["v_accvgpr_read_b32 %s, a%d" % (B0(j), vb(2 * i) + j) for j in range(14)]
-        epi += ["v_accvgpr_read_b32 %s, a%d" % (B1(j), vb(2 * i + 1) + j) for j in range(14)]
-        epi += ["CALL mbls_fp2_mulfp_d_asm_fn"]
-        for h, B in ((0, B5), (1, B6)):
-            epi += seq_reduce(B) + seq_canonical(B) + seq_to32(B)
-            epi += ["v_mov_b32_e64 v%d, %s" % (F_OUT[2 * i + h] + j, B(j)) for j in range(12)]
-    epi += ["s_mov_b64 s[30:31], s[36:37]"]
+    epi = f_out_epilogue()
     pieces = dict(pro=pro, dbl=dbl, add0=add0, add1=add1, epi=epi)
     return pro + main + expand_calls_d(epi), pieces, dict(dbl=st_dbl, add0=st_a0, add1=st_a1)
+
+
+# ---------------------------------------------------------------------------------------------- y^|x| in the cyclotomic subgroup
+G12_SLOT = 13                                       # workspace slots 13..24: the base y of the exponentiation (2^384 domain, canonical)
+
+
+def prog_cyc_mul_d():
+    """acc <- acc * y inside the exponentiation: acc in AGPR blocks 0..11 (between squaring runs it never leaves them), y in the
+    workspace (fetched, and cut into digits, when a product needs it); the reduced product goes back to the AGPR blocks."""
+    p = Prog()
+    al = [p.live_in(("a", i)) for i in range(12)]
+    gl = [p.live_in(("g", G12_SLOT + i)) for i in range(12)]
+    six = lambda l: ([(l[0], l[1]), (l[2], l[3]), (l[4], l[5])], [(l[6], l[7]), (l[8], l[9]), (l[10], l[11])])
+    a, g = six(al), six(gl)
+    c1 = p.mul6(p.add6(a[0], a[1]), p.add6(g[0], g[1]))      # the sums first: the operands then die pair by pair
+    t0 = p.mul6(a[0], g[0])
+    t1 = p.mul6(a[1], g[1])
+    c1 = p.sub6(p.sub6(c1, t0), t1)
+    c0 = p.add6(t0, p.mul_v6(t1))
+    for i, v in enumerate([x for h in (c0, c1) for c in h for x in c]):
+        p.store(prog_reduce(p, v), ("a", i))
+    return p
+
+
+def build_cyc_mul_d():
+    p = prog_cyc_mul_d()
+    inb = {v: (STATE_IN if l[0] == "a" else G_IN) for v, l in p.init_loc.items()}
+    al = AllocD(p, inb, n_lds=11, lds_base=0, a_pool=list(range(NA)))
+    body = al.run()
+    for dst, B in al.stored.items():
+        assert B.vlo >= REDUCED.vlo and B.vhi <= REDUCED.vhi and B.dhi <= M28, (dst, B)
+    return body, al.stats
+
+
+def cyc_exp_x_d_routine():
+    """y^|x| for y in the cyclotomic subgroup as ONE routine: the running power stays in AGPRs (D-form) from the first squaring to the
+    last, through the six runs of Granger-Scott squarings and the five multiplications by y.
+    In:  workspace slots 13..24 = y (2^384 domain, canonical); v252 LDS byte address of the lane's column (11 spill slots);
+         s[68:69] workspace base adjusted so that v252 is the lane offset, s70 bytes between consecutive words of a value.
+    Out: y^|x| in v108..v251 (twelve groups of 12 words, tower order, canonical, 2^384 domain)."""
+    sqr, st_sqr = build_cyc_sqr_d()
+    mul, st_mul = build_cyc_mul_d()
+    W = lambda j: "v%d" % (vb(8) + j)
+    pro = ["s_mov_b64 s[36:37], s[30:31]", "s_waitcnt vmcnt(0)"] + shell_constants()
+    for i in range(12):                             # acc = y: fetched, cut into digits of y * 2^8, reduced (the bodies' live-in bound)
+        pro += seq_gload(W, G12_SLOT + i, True) + seq_reduce(W)
+        pro += ["v_accvgpr_write_b32 a%d, %s" % (vb(i) + j, W(j)) for j in range(14)]
+    pro += ["s_mov_b32 s78, 0"]
+    top = ["4:", "s_mov_b32 s39, %d" % RUNS[5]]
+    for ph in range(5):
+        top += ["s_cmp_eq_u32 s78, %d" % ph, "s_cselect_b32 s39, %d, s39" % RUNS[ph]]
+    main = top + [".p2align 6", "1:"] + expand_calls_d(sqr)
+    main += ["s_sub_u32 s39, s39, 1", "s_cmp_lg_u32 s39, 0", "s_cbranch_scc0 2f"] + far_back(1) + ["2:"]
+    main += ["s_cmp_eq_u32 s78, 5", "s_cbranch_scc1 9f"]
+    main += expand_calls_d(mul)
+    main += ["s_add_u32 s78, s78, 1"] + far_back(4) + ["9:"]
+    epi = f_out_epilogue()
+    pieces = dict(pro=pro, sqr=sqr, mul=mul, epi=epi)
+    return pro + main + expand_calls_d(epi), pieces, dict(sqr=st_sqr, mul=st_mul)
 
 
 # ---------------------------------------------------------------------------------------------- G2 doubling (subgroup check, cofactor clearing)
@@ -1172,18 +1201,11 @@ def g2_dbl_d_routine():
     return full, dict(pro=pro, body=body, epi=epi), al.stats
 
 
-def c_array(name, value):
-    return "MBLS_CONST uint32_t %s[12] = {%s};\n" % (name, ",".join("0x%08x" % ((value >> (32 * i)) & 0xFFFFFFFF) for i in range(12)))
-
-
 def main():
     here = os.path.dirname(os.path.abspath(__file__))
     path = os.path.join(os.path.dirname(here), "milagro_bls_amd", "csrc", "mbls_towerd_asm.inc")
     txt = "// GENERATED by tools/gen_tower_d.py -- do not edit.\n"
-    txt += "// domain changes done by the callers with the 32-bit-limb fp_mul: x -> x 2^8 (into the 2^392 domain), x -> x / 2^8 (back)\n"
-    txt += c_array("MBLS_TO_D392", (1 << 392) % P) + c_array("MBLS_FROM_D392", (1 << 376) % P)
-    full, body, stats, _, _ = cyc_sqr_d_routine()
-    txt += emit("MBLS_CYC_SQR_D_ASM", full) + "\n"
+    body, stats = build_cyc_sqr_d()
     print("cyc_sqr_d", len(body), "lines", stats)
     full, pieces, st = miller_loop_d_routine()
     txt += emit("MBLS_MILLER_LOOP_D_ASM", full) + "\n"
@@ -1198,14 +1220,15 @@ def main():
     txt += "#define MBLS_MILLER_D_OUT_REGS(x) " + ", ".join('"={v[%d:%d]}"(x##%d)' % (b, b + 11, i) for i, b in enumerate(F_OUT)) + "\n"
     txt += "#define MBLS_MILLER_D_ASM_CLOBBERS %s,%s, \\\n    %s\n" % (
         ",".join('"v%d"' % i for i in range(256) if i not in fout and i not in (252, 253) and i not in UNTOUCHED_V), ",".join('"a%d"' % i for i in range(252)), sgm)
+    full, pieces, st = cyc_exp_x_d_routine()
+    txt += emit("MBLS_CYC_EXP_X_D_ASM", full) + "\n"
+    print("cyc_exp_x_d: mul", len(pieces["mul"]), "lines", st["mul"])
     full, pieces, st = g2_dbl_d_routine()
     txt += emit("MBLS_G2_DBL_D_ASM", full) + "\n"
     print("g2_dbl_d", len(pieces["body"]), "lines", st)
     g2r = set(r for b in G2D_ARG for r in range(b, b + 12))
     txt += "#define MBLS_G2D_ARG_REGS(x) " + ", ".join('"+{v[%d:%d]}"(x##%d)' % (b, b + 11, i) for i, b in enumerate(G2D_ARG)) + "\n"
     sg = '"s30","s31","s36","s37","s39","s40","s41","s42","s43","s44","s45","s46","s47","s56","s57","s58","s59","s60","s61","s62","s63","s64","s65","s66","s67","s73","vcc","scc","memory"'
-    txt += "// everything a D-form tower routine may overwrite (v252 carries the LDS address and is preserved)\n"
-    txt += "#define MBLS_TOWERD_ASM_CLOBBERS %s,%s, \\\n    %s\n" % (",".join('"v%d"' % i for i in list(range(252)) + [253, 254, 255] if i not in UNTOUCHED_V), ",".join('"a%d"' % i for i in range(252)), sg)
     txt += "#define MBLS_G2D_ASM_CLOBBERS %s,%s, \\\n    %s\n" % (
         ",".join('"v%d"' % i for i in range(256) if i not in g2r and i not in UNTOUCHED_V), ",".join('"a%d"' % i for i in range(252)), sg)
     with open(path, "w") as f:
