@@ -194,8 +194,14 @@ MBLS_FN void lane_miller(const mbls_ws& ws, uint64_t i, MBLS_LDS uint32_t* tstor
 }
 MBLS_FN void lane_final(const mbls_ws& ws, uint64_t i, uint32_t* status, uint8_t* result, MBLS_LDS uint32_t* ls = nullptr, uint32_t lane = 0, bool use_lds = false) {
     fp12 f; fp2* c = &f.c0.c0;
-    for (int s = 0; s < 6; s++) c[s] = ws_ld2(ws, MBLS_SLOT_F + 2 * s, i);
-    final_exp(&f, &f, ls, lane, use_lds, ws.w, ws.stride, i);
+#if MBLS_DEVICE_ASM && !defined(MBLS_NO_FP2_ASM)
+    if (use_lds) final_exp_ws_d(&f, ws.w, ws.stride, i, ls, lane);       // the generated routine reads f from the workspace itself
+    else
+#endif
+    {
+        for (int s = 0; s < 6; s++) c[s] = ws_ld2(ws, MBLS_SLOT_F + 2 * s, i);
+        final_exp(&f, &f);
+    }
     uint32_t st = *status;
     if (!fp12_is_one(&f)) st |= MBLS_ST_PAIRING_FAILED;
     *status = st;

@@ -188,18 +188,17 @@ MBLS_FN void miller_loop_single_d(fp12* f_out, const mbls_pair* pr, uint32_t* ws
 #endif
 // f^(3 (p^12-1)/r). Hard part: 3 (p^4-p^2+1)/r = (x-1)^2 (x+p) (x^2+p^2-1) + 3 (Hayashida-Hayasaka-Teruya);
 // gcd(3, r) = 1, so comparing with 1 gives the same boolean as amcl's fexp (reference src/amcl_utils.rs:40-41).
-MBLS_NOINLINE void final_exp(fp12* r, const fp12* f, MBLS_LDS uint32_t* ls = nullptr, uint32_t lane = 0, bool use_lds = false,
-                             uint32_t* ws_w = nullptr, uint64_t ws_stride = 0, uint64_t item = 0) {
+// This compiled version serves host emulation and debug builds; the kernels run the same sequence as one generated routine
+// (final_exp_ws_d in mbls_tower.h, tools/gen_tower_d.py final_exp_d_routine).
+MBLS_NOINLINE void final_exp(fp12* r, const fp12* f) {
     fp12 t, u, a, b, c, m;
-#define MBLS_F12MUL(r, x, y) do { if (use_lds) fp12_mul_via_lds(r, x, y, ls, lane); else fp12_mul(r, x, y); } while (0)
-    fp12_conj(&t, f); fp12_inv(&u, f); MBLS_F12MUL(&t, &t, &u);              // f^(p^6-1)
-    fp12_frob(&u, &t); fp12_frob(&u, &u); MBLS_F12MUL(&m, &u, &t);            // ^(p^2+1): now cyclotomic
-    fp12_cyc_exp_x(&a, &m, ls, lane, use_lds, ws_w, ws_stride, item); fp12_conj(&u, &m); MBLS_F12MUL(&a, &a, &u);       // m^(x-1)
-    fp12_cyc_exp_x(&t, &a, ls, lane, use_lds, ws_w, ws_stride, item); fp12_conj(&u, &a); MBLS_F12MUL(&a, &t, &u);       // m^((x-1)^2)
-    fp12_cyc_exp_x(&b, &a, ls, lane, use_lds, ws_w, ws_stride, item); fp12_frob(&u, &a); MBLS_F12MUL(&b, &b, &u);       // a^(x+p)
-    fp12_cyc_exp_x(&c, &b, ls, lane, use_lds, ws_w, ws_stride, item); fp12_cyc_exp_x(&c, &c, ls, lane, use_lds, ws_w, ws_stride, item);                        // b^(x^2)
-    fp12_frob(&u, &b); fp12_frob(&u, &u); MBLS_F12MUL(&c, &c, &u);            // * b^(p^2)
-    fp12_conj(&u, &b); MBLS_F12MUL(&c, &c, &u);                               // * b^-1
-    fp12_cyc_sqr(&u, &m); MBLS_F12MUL(&u, &u, &m); MBLS_F12MUL(r, &c, &u);       // * m^3
-#undef MBLS_F12MUL
+    fp12_conj(&t, f); fp12_inv(&u, f); fp12_mul(&t, &t, &u);                 // f^(p^6-1)
+    fp12_frob(&u, &t); fp12_frob(&u, &u); fp12_mul(&m, &u, &t);               // ^(p^2+1): now cyclotomic
+    fp12_cyc_exp_x(&a, &m); fp12_conj(&u, &m); fp12_mul(&a, &a, &u);          // m^(x-1)
+    fp12_cyc_exp_x(&t, &a); fp12_conj(&u, &a); fp12_mul(&a, &t, &u);          // m^((x-1)^2)
+    fp12_cyc_exp_x(&b, &a); fp12_frob(&u, &a); fp12_mul(&b, &b, &u);          // a^(x+p)
+    fp12_cyc_exp_x(&c, &b); fp12_cyc_exp_x(&c, &c);                           // b^(x^2)
+    fp12_frob(&u, &b); fp12_frob(&u, &u); fp12_mul(&c, &c, &u);               // * b^(p^2)
+    fp12_conj(&u, &b); fp12_mul(&c, &c, &u);                                  // * b^-1
+    fp12_cyc_sqr(&u, &m); fp12_mul(&u, &u, &m); fp12_mul(r, &c, &u);          // * m^3
 }

@@ -220,26 +220,7 @@ MBLS_TOWER_FN void fp12_cyc_sqr(fp12* r, const fp12* f) {
     r->c0.c0 = z0; r->c0.c1 = z4; r->c0.c2 = z3; r->c1.c0 = z2; r->c1.c1 = z1; r->c1.c2 = z5;
 }
 // f^x, x = -0xd201000000010000, f in the cyclotomic subgroup
-// An Fp12 parked in LDS between uses: coefficient dword e of lane l at ls[e*64 + l] (conflict-free across the wave).
-MBLS_FN void fp12_lds_load(fp12* a, const MBLS_LDS uint32_t* ls, uint32_t lane) {
-    fp* c = &a->c0.c0.c0;
-    for (int e = 0; e < 12; e++) {
-        fp v;
-#pragma unroll
-        for (int j = 0; j < 12; j++) v[j] = ls[(e * 12 + j) * 64 + lane];
-        c[e] = v;
-    }
-}
-MBLS_FN void fp12_lds_store(MBLS_LDS uint32_t* ls, uint32_t lane, const fp12* a) {
-    const fp* c = &a->c0.c0.c0;
-    for (int e = 0; e < 12; e++) {
-        fp v = c[e];
-#pragma unroll
-        for (int j = 0; j < 12; j++) ls[(e * 12 + j) * 64 + lane] = v[j];
-    }
-}
 #if MBLS_DEVICE_ASM && !defined(MBLS_NO_FP2_ASM)
-#include "mbls_tower_asm.inc"
 // The digit-form routines (tools/gen_fpd_asm.py, tools/gen_tower_d.py): every value is 14 signed 28-bit digits from the moment it enters a
 // routine until it leaves -- bare product scans, carry-free additions, no conversions or conditional subtractions between
 // multiplications; explicit VGPR/AGPR/LDS placement and no lane-private memory (the compiler-scheduled fp12_cyc_sqr spills and,
@@ -249,89 +230,32 @@ MBLS_FN void fp12_lds_store(MBLS_LDS uint32_t* ls, uint32_t lane, const fp12* a)
 extern "C" __device__ __attribute__((noinline, used, aligned(64))) void mbls_fp2_mul_d_asm_fn() { asm volatile(MBLS_FP2_MUL_D_ASM); }
 extern "C" __device__ __attribute__((noinline, used, aligned(64))) void mbls_fp2_sqr_d_asm_fn() { asm volatile(MBLS_FP2_SQR_D_ASM); }
 extern "C" __device__ __attribute__((noinline, used, aligned(64))) void mbls_fp2_mulfp_d_asm_fn() { asm volatile(MBLS_FP2_MULFP_D_ASM); }
-// y^|x| for y in the cyclotomic subgroup as ONE routine (cyc_exp_x_d_routine): the running power stays in AGPRs through the six runs of
-// Granger-Scott squarings and the five multiplications by y, which the routine fetches from the workspace (slots 13..24) when a
-// product needs it. `spill`: 11 x 14 dwords per lane of LDS.
-extern "C" __device__ __attribute__((noinline, used, aligned(64))) void mbls_cyc_exp_x_d_asm_fn() { asm volatile(MBLS_CYC_EXP_X_D_ASM); }
-MBLS_FN void fp12_cyc_pow_x_d(fp12* r, const fp12* y, uint32_t* ws_w, uint64_t ws_stride, uint64_t item, MBLS_LDS uint32_t* spill, uint32_t lane) {
-    uint32_t* w0 = ws_w + item;
-    const fp* c = &y->c0.c0.c0;
-#pragma unroll
-    for (int t = 0; t < 12; t++) {
-        fp v = c[t];
-#pragma unroll
-        for (int j = 0; j < 12; j++) w0[((uint64_t)(13 + t) * 12 + j) * ws_stride] = v[j];
-    }
+// The whole final exponentiation as ONE routine (final_exp_d_routine): easy part (Fp12 inversion through the fixed-exponent Fp
+// inversion, Frobenius^2), five powers by |x| with the running power in AGPRs, the Fp12 products between them; three Fp12 temporaries in
+// the workspace. In: f in workspace slots 13..24 (the Miller kernel left it there). `spill`: 11 x 14 dwords per lane of LDS.
+extern "C" __device__ __attribute__((noinline, used, aligned(64))) void mbls_final_exp_d_asm_fn() { asm volatile(MBLS_FINAL_EXP_D_ASM); }
+MBLS_FN void final_exp_ws_d(fp12* r, uint32_t* ws_w, uint64_t ws_stride, uint64_t item, MBLS_LDS uint32_t* spill, uint32_t lane) {
     const uint32_t addr = (uint32_t)(uintptr_t)(spill + lane);
     const uint64_t gb = (uint64_t)(uintptr_t)ws_w + 4ull * (item - lane) - (uint64_t)(uint32_t)(uintptr_t)spill;
     const uint32_t gb_lo = __builtin_amdgcn_readfirstlane((uint32_t)gb), gb_hi = __builtin_amdgcn_readfirstlane((uint32_t)(gb >> 32));
     const uint32_t st4 = __builtin_amdgcn_readfirstlane((uint32_t)(ws_stride * 4));
     fp f0, f1, f2, f3, f4, f5, f6, f7, f8, f9, f10, f11;
-    asm volatile(MBLS_ASM_CALL("mbls_cyc_exp_x_d_asm_fn")
+    asm volatile(MBLS_ASM_CALL("mbls_final_exp_d_asm_fn")
                  : MBLS_MILLER_D_OUT_REGS(f)
                  : "{v252}"(addr), "{s68}"(gb_lo), "{s69}"(gb_hi), "{s70}"(st4)
-                 : MBLS_MILLER_D_ASM_CLOBBERS, "v253");
+                 : MBLS_FINAL_EXP_D_ASM_CLOBBERS);
     fp* o = &r->c0.c0.c0;
     o[0] = f0; o[1] = f1; o[2] = f2; o[3] = f3; o[4] = f4; o[5] = f5; o[6] = f6; o[7] = f7; o[8] = f8; o[9] = f9; o[10] = f10; o[11] = f11;
 }
-// The Fp12 parked in LDS times g, in place (generated routine, prog_fp12_mul).
-extern "C" __device__ __attribute__((noinline, used, aligned(64))) void mbls_fp12_mul_asm_fn() {
-    asm volatile(MBLS_FP12_MUL_ASM);
-}
-MBLS_FN void fp12_mul_lds(MBLS_LDS uint32_t* ls, uint32_t lane, const fp12* g) {
-    uint32_t addr = (uint32_t)(uintptr_t)(ls + lane);
-    const fp* c = &g->c0.c0.c0;
-    fp g0 = c[0], g1 = c[1], g2 = c[2], g3 = c[3], g4 = c[4], g5 = c[5], g6 = c[6], g7 = c[7], g8 = c[8], g9 = c[9], g10 = c[10], g11 = c[11];
-    asm volatile(MBLS_ASM_CALL("mbls_fp12_mul_asm_fn")          // the operand registers are overwritten: read-write operands
-                 : MBLS_F12_ARG_REGS(g)
-                 : "{v252}"(addr)
-                 : MBLS_FP12_ARG_ASM_CLOBBERS);
-}
-// r = a * b through the LDS home (a is parked, multiplied in place, read back)
-MBLS_FN void fp12_mul_via_lds(fp12* r, const fp12* a, const fp12* b, MBLS_LDS uint32_t* ls, uint32_t lane) {
-    fp12_lds_store(ls, lane, a); fp12_mul_lds(ls, lane, b); fp12_lds_load(r, ls, lane);
-}
-#else
-MBLS_FN void fp12_mul_lds(MBLS_LDS uint32_t* ls, uint32_t lane, const fp12* g) {
-    fp12 acc; fp12_lds_load(&acc, ls, lane); fp12_mul(&acc, &acc, g); fp12_lds_store(ls, lane, &acc);
-}
-MBLS_FN void fp12_mul_via_lds(fp12* r, const fp12* a, const fp12* b, MBLS_LDS uint32_t* ls, uint32_t lane) { fp12_mul(r, a, b); }
 #endif
-MBLS_FN void fp12_cyc_sqr_n_lds(MBLS_LDS uint32_t* ls, uint32_t lane, uint32_t n) {       // plain version (no workspace at hand)
-    fp12 acc; fp12_lds_load(&acc, ls, lane);
-    for (uint32_t i = 0; i < n; i++) fp12_cyc_sqr(&acc, &acc);
-    fp12_lds_store(ls, lane, &acc);
-}
-// f^x, x = -0xd201000000010000, f in the cyclotomic subgroup. With ls != nullptr the running power lives in LDS (it would
-// otherwise pin 144 registers for 63 iterations while each squaring needs the register file itself) and is squared in place,
-// run by run between the 5 multiplications.
-MBLS_NOINLINE void fp12_cyc_exp_x(fp12* r, const fp12* f, MBLS_LDS uint32_t* ls, uint32_t lane, bool use_lds,
-                                  uint32_t* ws_w = nullptr, uint64_t ws_stride = 0, uint64_t item = 0) {
+// f^x, x = -0xd201000000010000, f in the cyclotomic subgroup (the compiled version: host emulation and debug builds; the kernels run
+// final_exp_ws_d)
+MBLS_NOINLINE void fp12_cyc_exp_x(fp12* r, const fp12* f) {
     fp12 acc = *f;
-#if MBLS_DEVICE_ASM && !defined(MBLS_NO_FP2_ASM)
-    if (use_lds && ws_w) {                               // the generated routine: |x| is folded into its schedule
-        fp12_cyc_pow_x_d(&acc, f, ws_w, ws_stride, item, ls, lane);
-        fp12_conj(r, &acc);
-        return;
-    }
-#endif
-    if (use_lds) {
-        fp12_lds_store(ls, lane, &acc);
-        int i = 62;
-        while (i >= 0) {
-            int j = i;                                   // squarings for bits i..j, j = next set bit (or 0)
-            while (j > 0 && !((MBLS_X_ABS >> j) & 1)) j--;
-            fp12_cyc_sqr_n_lds(ls, lane, (uint32_t)(i - j + 1));
-            if ((MBLS_X_ABS >> j) & 1) fp12_mul_lds(ls, lane, f);
-            i = j - 1;
-        }
-        fp12_lds_load(&acc, ls, lane);
-    } else {
-        // acc never escapes (the 5 multiplications go through a short-lived copy), so the 63 squarings keep it in registers
-        for (int i = 62; i >= 0; i--) {
-            fp12_cyc_sqr(&acc, &acc);
-            if ((MBLS_X_ABS >> i) & 1) { fp12 t = acc; fp12_mul(&t, &t, f); acc = t; }
-        }
+    // acc never escapes (the 5 multiplications go through a short-lived copy), so the 63 squarings keep it in registers
+    for (int i = 62; i >= 0; i--) {
+        fp12_cyc_sqr(&acc, &acc);
+        if ((MBLS_X_ABS >> i) & 1) { fp12 t = acc; fp12_mul(&t, &t, f); acc = t; }
     }
     fp12_conj(r, &acc);
 }

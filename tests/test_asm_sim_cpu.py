@@ -1,6 +1,6 @@
-"""The generated gfx950 routines on 12 x 32-bit limbs (tools/gen_fp_asm.py, tools/gen_tower_asm.py) interpreted on the CPU by
-tools/asm_sim.py and compared with big-integer arithmetic: Montgomery products, the fused Fp2 routines, the fixed-exponent
-exponentiations and the Fp12 multiplication routine. The digit-form routines have their own file, test_asm_sim_d_cpu.py."""
+"""The generated gfx950 routines on 12 x 32-bit limbs (tools/gen_fp_asm.py) interpreted on the CPU by tools/asm_sim.py and compared
+with big-integer arithmetic: Montgomery products, the fused Fp2 routines and the fixed-exponent exponentiations. The digit-form
+routines have their own file, test_asm_sim_d_cpu.py."""
 import os
 import random
 import sys
@@ -10,7 +10,6 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 import gen_fp_asm as g          # noqa: E402
-import gen_tower_asm as t       # noqa: E402
 from asm_sim import Machine, limbs, from_limbs   # noqa: E402
 
 P = g.P
@@ -87,66 +86,12 @@ def lds_get(m, base, slot):
 def test_generated_files_up_to_date():
     import io
     import contextlib
-    for mod, name in ((g, "mbls_fp_asm.inc"), (t, "mbls_tower_asm.inc")):
+    for mod, name in ((g, "mbls_fp_asm.inc"),):
         path = os.path.join(ROOT, "milagro_bls_amd", "csrc", name)
         before = open(path).read()
         with contextlib.redirect_stdout(io.StringIO()):
             mod.main()
         assert open(path).read() == before, name + " is stale: run tools/" + mod.__name__ + ".py"
-
-
-# ---- big-integer mirror of one doubling iteration (Montgomery-domain values, formulas of mbls_pairing.h / mbls_tower.h)
-def f2mulfp(a, s):
-    return (mm(a[0], s), mm(a[1], s))
-
-
-def f2k(a, k):
-    return (a[0] * k % P, a[1] * k % P)
-
-
-def f6add(a, b):
-    return [f2add(a[i], b[i]) for i in range(3)]
-
-
-def f6sub(a, b):
-    return [f2sub(a[i], b[i]) for i in range(3)]
-
-
-def f6mulv(a):
-    return [xi(a[2]), a[0], a[1]]
-
-
-def f6mul(a, b):
-    t0, t1, t2 = f2mul(a[0], b[0]), f2mul(a[1], b[1]), f2mul(a[2], b[2])
-    c0 = f2add(xi(f2sub(f2sub(f2mul(f2add(a[1], a[2]), f2add(b[1], b[2])), t1), t2)), t0)
-    c1 = f2add(f2sub(f2sub(f2mul(f2add(a[0], a[1]), f2add(b[0], b[1])), t0), t1), xi(t2))
-    c2 = f2add(f2sub(f2sub(f2mul(f2add(a[0], a[2]), f2add(b[0], b[2])), t0), t2), t1)
-    return [c0, c1, c2]
-
-
-def test_fp12_mul_routine():
-    lines, stats = t.build("fp12_mul")
-    assert not any("scratch" in l for l in lines)
-    rng = random.Random(21)
-    r2 = lambda: (rng.randrange(P), rng.randrange(P))
-    for trial in range(3):
-        a = ([r2(), r2(), r2()], [r2(), r2(), r2()])
-        b = ([r2(), r2(), r2()], [r2(), r2(), r2()])
-        if trial == 0:
-            b = ([((1 << 384) % P, 0), (0, 0), (0, 0)], [(0, 0), (0, 0), (0, 0)])
-        m = Machine(ROUTINES); m.v[252] = 512
-        for i, x in enumerate([x for h in a for c in h for x in c]):
-            lds_put(m, 512, i, x)
-        for i, x in enumerate([x for h in b for c in h for x in c]):
-            m.v[t.F12_ARG[i]:t.F12_ARG[i] + 12] = limbs(x)
-        m.run(lines)
-        t0, t1 = f6mul(a[0], b[0]), f6mul(a[1], b[1])
-        c1 = f6sub(f6sub(f6mul(f6add(a[0], a[1]), f6add(b[0], b[1])), t0), t1)
-        c0 = f6add(t0, f6mulv(t1))
-        exp = [x for h in (c0, c1) for c in h for x in c]
-        assert [lds_get(m, 512, i) for i in range(12)] == exp
-        if trial == 0:
-            assert exp == [x for h in a for c in h for x in c]
 
 
 @pytest.mark.parametrize("which", ["pm3d4", "pm2"])

@@ -158,7 +158,7 @@ def test_generated_d_files_up_to_date():
 # The programs of tools/gen_tower_d.py are executed twice: by the allocator (-> instructions, interpreted by asm_sim) and by ModelProg,
 # which implements the same Prog interface on true field values. Agreement checks the allocator, the bound tracking (no 32-bit /
 # 64-bit overflow is possible: the simulator asserts), the packing / HBM fetch sequences and the shells.
-from gen_tower_d import Prog     # noqa: E402  (the digit-form recorder: the limb recorder plus scale / shadd)
+from gen_tower_d import Prog     # noqa: E402  (the program recorder)
 
 R392, R384 = 1 << 392, 1 << 384
 RI392 = pow(R392, -1, P)
@@ -178,6 +178,10 @@ class _Ops(list):
             self.o.val[outs[0]] = ((self.o.val[ins[0]] << aux) + self.o.val[ins[1]]) % P
         elif kind == "storep":
             self.o.out_g[aux] = self.o.val[ins[0]]
+        elif kind == "neg":
+            self.o.val[outs[0]] = -self.o.val[ins[0]] % P
+        elif kind == "inv":                                  # the operand is x 2^-8 (see Prog.inv); 0 -> 0 like a^(p-2)
+            self.o.val[outs[0]] = pow(self.o.val[ins[0]] * 256, P - 2, P)
         else:
             raise ValueError(kind)
 
@@ -369,30 +373,67 @@ def test_miller_loop_routine_full_schedule():
     miller_loop_sim(t.RUNS, 7)
 
 
-def test_cyclotomic_exponentiation_routine_short_schedule():
-    """prologue (acc = y from the workspace, reduced), squaring runs with the state in AGPRs, multiplications by y fetched from the
-    workspace, epilogue (canonical 2^384-domain words); the real schedule is runs of 1, 2, 3, 9, 32 and 16 squarings"""
-    full, pieces, st = t.cyc_exp_x_d_routine()
-    assert not any("scratch" in l or "buffer_" in l for l in full)
-    rng = random.Random(31)
-    for runs in ([1, 2, 1], [3, 1]):
-        m = miller_machine(0)
-        y = [rng.randrange(P) for _ in range(12)]
-        for i in range(12):
-            ws_put(m, t.G12_SLOT + i, y[i] * R384 % P)
-        m.run(pieces["pro"])
-        acc = list(y)
+# ---------------------------------------------------------------------------------------------- the final exponentiation routine
+import gen_fp_asm as g1          # noqa: E402  (the fixed-exponent inversion the easy part calls)
 
-        def step(progf, acc):
-            init = {("a", i): acc[i] for i in range(12)}
-            init.update({("g", t.G12_SLOT + i): y[i] for i in range(12)})
-            mp = run_model(progf, init, {})
-            return [mp.out_home[("a", i)] for i in range(12)]
+FEXP_ROUT = dict(ROUT)
+FEXP_ROUT.update(g1.pow_subroutines())
+FEXP_ROUT["mbls_fp_pow_pm2_asm_fn"] = g1.pow_body(g1.EXP_PM2)
+
+
+def fexp_sim(runs, seed, f=None):
+    """the routine's bodies in the order its control skeleton runs them, with `runs` as the squaring runs of every power; returns
+    (result of the instruction stream, result of the same programs on field values)"""
+    full, pieces, st = t.final_exp_d_routine()
+    assert not any("scratch" in l or "buffer_" in l for l in full)
+    rng = random.Random(seed)
+    f = f or [rng.randrange(P) for _ in range(12)]
+    m = Machine(FEXP_ROUT); m.v[252] = LADDR
+    m.s[68] = GBASE & 0xFFFFFFFF; m.s[69] = GBASE >> 32; m.s[70] = STRIDE * 4
+    for i in range(12):
+        ws_put(m, t.FEXP_IN_SLOT + i, f[i] * R384 % P)
+    m.run(pieces["pro"])
+    state = {("g", t.FEXP_IN_SLOT + i): f[i] for i in range(12)}
+
+    def step(name):
+        m.run(pieces[name])
+        prog = t.prog_cyc_sqr_d if name == "sqr" else t.FEXP_BODIES[name]
+        mp = run_model(prog, state, {})
+        for loc, v in mp.out_home.items():
+            state[loc] = v
+        for slot, v in mp.out_g.items():
+            state[("gd", slot)] = v
+    step("easy")
+    for k in range(5):
         for ph, n in enumerate(runs):
             for _ in range(n):
-                m.run(pieces["sqr"]); acc = step(t.prog_cyc_sqr_d, acc)
+                step("sqr")
             if ph < len(runs) - 1:
-                m.run(pieces["mul"]); acc = step(t.prog_cyc_mul_d, acc)
-        m.run(pieces["epi"][:-1])
-        for i in range(12):
-            assert from_limbs(m.v[t.F_OUT[i]:t.F_OUT[i] + 12]) == acc[i] * R384 % P, (runs, i)
+                step("mul_y")
+        if k < 4:
+            step(["step_conj", "step_conj", "step_frob", "step_base"][k])
+    step("tail")
+    m.run(pieces["epi"][:-1])
+    got = [from_limbs(m.v[t.F_OUT[i]:t.F_OUT[i] + 12]) for i in range(12)]
+    return got, [state[("a", i)] * R384 % P for i in range(12)], f
+
+
+def test_final_exponentiation_routine_short_schedule():
+    got, model, _ = fexp_sim([1, 2], 41)
+    assert got == model
+
+
+def test_final_exponentiation_routine_full_schedule():
+    """the complete routine (~5 million interpreted instructions) against the Python model's final exponentiation -- an independent
+    statement of the same function: f^((p^12-1)/r) by Frobenius maps, a generic inversion and one literal 1269-bit power. The routine
+    computes the cube of that value (its hard part is 3 (p^4-p^2+1)/r, see mbls_pairing.h)."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    from pymodel import bls12_381 as M
+    got, model, f = fexp_sim(t.RUNS, 43)
+    assert got == model
+    ri = pow(R384, -1, P)
+    tower = [(got[2 * e] * ri % P, got[2 * e + 1] * ri % P) for e in range(6)]          # c0.c0, c0.c1, c0.c2, c1.c0, c1.c1, c1.c2
+    fin = [(f[2 * e], f[2 * e + 1]) for e in range(6)]
+    wpow = lambda x: [x[0], x[3], x[1], x[4], x[2], x[5]]                                # coefficients of w^0 .. w^5
+    want = M.f12_pow(M.final_exp(wpow(fin)), 3)
+    assert M.f12_eq(wpow(tower), want)

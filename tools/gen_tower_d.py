@@ -1,24 +1,28 @@
 #!/usr/bin/env python3
-"""Generate milagro_bls_amd/csrc/mbls_towerd_asm.inc: the hot loop bodies as straight-line gfx950 routines in DIGIT FORM.
+"""Generate milagro_bls_amd/csrc/mbls_towerd_asm.inc: the hot paths of the pairing as straight-line gfx950 routines in DIGIT FORM --
+the whole Miller loop (two pairs / one pair), the whole final exponentiation, and runs of G2 doublings.
 
-Second generation of tools/gen_tower_asm.py (which stays for the one-shot Fp12 products). There, an Fp between multiplications is
-12 saturated 32-bit limbs: every multiplication routine re-cuts its operands into 28-bit digits and packs / conditionally reduces
-its results (15 % of its instructions), and every addition is a carry chain with a conditional correction (36 instructions).
+With 12 saturated 32-bit limbs between multiplications (tools/gen_fp_asm.py's routines, still used by the compiled code around the hot
+paths) every multiplication re-cuts its operands into 28-bit digits and packs / conditionally reduces its results (15 % of its
+instructions), and every addition is a carry chain with a conditional correction (36 instructions).
 Here a value STAYS 14 signed 28-bit digits (tools/gen_fpd_asm.py, "D-form", Montgomery radix 2^392) from the moment it enters a
 routine until it leaves: multiplications are bare product scans, additions / subtractions / doublings are 14 independent
 instructions without carries or corrections. What replaces modular reduction is bookkeeping done HERE, at generation time: every value
 carries exact interval bounds on its digits, its top digit and its integer value (class Bound); an operation whose result could
 leave the 32-bit digit range, or an operand that could overflow a 64-bit product column of a multiplication routine, gets one
-carry pass ("norm", 39 instructions) inserted in front, and a value that re-enters the next round linearly (the cyclotomic squaring's
-3 t -+ 2 z) gets a fused quotient-estimate / subtract / carry pass ("reduce", 74 instructions). A Montgomery product brings any
-operands back to (-eps, p + eps), so products never accumulate growth.
+carry pass ("norm", 39 instructions) or, when it is the value itself that has grown too wide, a fused quotient-estimate / subtract /
+carry pass ("reduce", 60 instructions) inserted in front. A Montgomery product brings any operands back to (-eps, p + eps), so
+products never accumulate growth.
 
-Storage: 14-register blocks -- 18 VGPR blocks (blocks 0..7 are the window of the multiplication routines: operands in 0..3, which
-the routines preserve, results in 5 and 6, block 4 / 7 scratch), 18 AGPR blocks, LDS digit slots; Belady eviction with exact next-use
-knowledge as in the first generation. State that crosses a routine boundary lives in LDS as 12 packed words per value (packing needs
-a non-negative normalised value below 2^384: add a multiple of p, carry pass, pack).
+A computation is written once as a program (class Prog: a list of operations on value handles, same formulas as mbls_tower.h /
+mbls_pairing.h) and walked by the allocator (class AllocD). Storage: 14-register blocks -- 18 VGPR blocks (blocks 0..7 are the window
+of the multiplication routines: operands in 0..3, which the routines preserve, results in 5 and 6, block 4 / 7 scratch), 18 AGPR
+blocks, 11 LDS digit slots per lane, and workspace (HBM) slots that serve as homes: a value with a home can be dropped from the
+registers and fetched again (prefetched a few calls ahead, with exact s_waitcnt vmcnt counts); Belady eviction with exact next-use
+knowledge. No lane-private memory anywhere.
 
-Everything emitted is executed on the CPU by tools/asm_sim.py against big-integer arithmetic (tests/test_asm_sim_cpu.py).
+Everything emitted is executed on the CPU by tools/asm_sim.py: the instruction stream of every program against the same program run
+on field values, and the complete routines against independent big-integer models (tests/test_asm_sim_d_cpu.py).
 Run:  python3 tools/gen_tower_d.py    (output committed; tests check it is up to date)
 """
 import os
@@ -27,20 +31,131 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from gen_fp_asm import P, P28, M28, SP28, SMASK28, emit  # noqa: E402
 from gen_fpd_asm import load_constants, column_ok  # noqa: E402
-from gen_tower_asm import Prog as LimbProg, expand_calls, INF  # noqa: E402
 
 
-class Prog(LimbProg):
-    """the recorder of tools/gen_tower_asm.py with the small-constant multiples as single operations: on carry-free digits k * a is one
-    instruction per digit (a shift or v_mul_lo_u32 by an inline constant) instead of a chain of additions, and 2^s a + b is one
-    v_lshl_add_u32"""
+class Prog:
+    """Records a tower computation as a list of operations on Fp value handles: (kind, outputs, inputs, aux). The allocator below walks
+    the list and emits digit-form code; tests/test_asm_sim_d_cpu.py runs the same programs on field values. On carry-free digits the
+    small-constant multiple k * a is one instruction per digit and 2^s a + b is one v_lshl_add_u32: both are single operations."""
 
+    def __init__(self):
+        self.ops = []
+        self.nval = 0
+        self.init_loc = {}
+
+    def new(self):
+        self.nval += 1
+        return self.nval - 1
+
+    def live_in(self, loc):
+        v = self.new()
+        self.init_loc[v] = loc
+        return v
+
+    def add(self, a, b):
+        d = self.new(); self.ops.append(("add", [d], [a, b], None)); return d
+
+    def sub(self, a, b):
+        d = self.new(); self.ops.append(("sub", [d], [a, b], None)); return d
+
+    def const(self, value):
+        d = self.new(); self.ops.append(("const", [d], [], value)); return d
+
+    def sel(self, mask, a, b):                 # mask (an SGPR pair, one bit per lane) ? b : a
+        d = self.new(); self.ops.append(("sel", [d], [a, b], mask)); return d
+
+    def call(self, kind, ins):
+        outs = [self.new(), self.new()]
+        assert len(set(ins)) == len(ins)
+        self.ops.append((kind, outs, list(ins), None))
+        return tuple(outs)
+
+    def store(self, a, loc):
+        self.ops.append(("store", [], [a], loc))
+
+    def keep(self, vals):
+        """values that stay in their live-in homes for the next round of the loop (never moved, only copied)"""
+        self.ops.append(("keep", [], list(vals), None))
+
+    # ---- Fp2 layer (an Fp2 is a pair of values)
+    def pair(self, k0, a0, b0, k1, a1, b1):
+        """two independent Fp additions / subtractions (the two halves of an Fp2 operation)"""
+        d0, d1 = self.new(), self.new()
+        self.ops.append(("pair", [d0, d1], [a0, b0, a1, b1], (k0, k1)))
+        return (d0, d1)
+
+    def add2(self, a, b): return self.pair("add", a[0], b[0], "add", a[1], b[1])
+    def sub2(self, a, b): return self.pair("sub", a[0], b[0], "sub", a[1], b[1])
+    def sqr2(self, a): return self.call("sqr", [a[0], a[1]])
+    def mulfp2(self, a, s): return self.call("mulfp", [a[0], a[1], s])
+    def mul_xi2(self, a): return self.pair("sub", a[0], a[1], "add", a[0], a[1])    # (1 + i) a
+    def sel2(self, mask, a, b): return (self.sel(mask, a[0], b[0]), self.sel(mask, a[1], b[1]))
+    def store2(self, a, slot2): self.store(a[0], ("l", 2 * slot2)); self.store(a[1], ("l", 2 * slot2 + 1))
+
+    # ---- Fp6 layer (lists of three Fp2), same formulas as mbls_tower.h
+    def add6(self, a, b): return [self.add2(a[i], b[i]) for i in range(3)]
+    def sub6(self, a, b): return [self.sub2(a[i], b[i]) for i in range(3)]
+    def mul_v6(self, a): return [self.mul_xi2(a[2]), a[0], a[1]]
+
+    def mul6(self, a, b):
+        t0, t1, t2 = self.mul2(a[0], b[0]), self.mul2(a[1], b[1]), self.mul2(a[2], b[2])
+        c0 = self.mul2(self.add2(a[1], a[2]), self.add2(b[1], b[2]))
+        c0 = self.add2(self.mul_xi2(self.sub2(self.sub2(c0, t1), t2)), t0)
+        c1 = self.mul2(self.add2(a[0], a[1]), self.add2(b[0], b[1]))
+        c1 = self.add2(self.sub2(self.sub2(c1, t0), t1), self.mul_xi2(t2))
+        c2 = self.mul2(self.add2(a[0], a[2]), self.add2(b[0], b[2]))
+        c2 = self.add2(self.sub2(self.sub2(c2, t0), t2), t1)
+        return [c0, c1, c2]
+
+    def mul6_01(self, a, x, y):            # a (x + y v)
+        t0, t1 = self.mul2(a[0], x), self.mul2(a[1], y)
+        c1 = self.sub2(self.sub2(self.mul2(self.add2(a[0], a[1]), self.add2(x, y)), t0), t1)
+        c0 = self.add2(self.mul_xi2(self.mul2(a[2], y)), t0)
+        c2 = self.add2(self.mul2(a[2], x), t1)
+        return [c0, c1, c2]
+
+    def mul6_1(self, a, y):                # a (y v)
+        return [self.mul_xi2(self.mul2(a[2], y)), self.mul2(a[0], y), self.mul2(a[1], y)]
+
+    # ---- Fp12 layer: (c0, c1) of Fp6
+    def sqr12(self, f):
+        a, b = f
+        ab = self.mul6(a, b)
+        s = self.add6(a, b)
+        t = self.add6(a, self.mul_v6(b))
+        st = self.sub6(self.mul6(s, t), ab)
+        return (self.sub6(st, self.mul_v6(ab)), self.add6(ab, ab))
+
+    def mul12_line(self, f, c0, c2, c3):   # f (c0 + c2 w^2 + c3 w^3)
+        a, b = f
+        t0 = self.mul6_01(a, c0, c2)
+        t1 = self.mul6_1(b, c3)
+        c1 = self.mul6_01(self.add6(a, b), c0, self.add2(c2, c3))
+        c1 = self.sub6(self.sub6(c1, t0), t1)
+        return (self.add6(t0, self.mul_v6(t1)), c1)
+
+    # ---- digit-form operations
     def scale(self, a, k):
         d = self.new(); self.ops.append(("scale", [d], [a], k)); return d
 
     def shadd(self, a, s, b):
         d = self.new(); self.ops.append(("shadd", [d], [a, b], s)); return d
 
+    def neg(self, a):
+        d = self.new(); self.ops.append(("neg", [d], [a], None)); return d
+
+    def inv(self, a):
+        """1 / a by the fixed-exponent routine of tools/gen_fp_asm.py (a^(p-2): 0 -> 0). That routine works on 12 canonical words of the
+        2^384 domain: a * (2^384 mod p) is such a value in digit form, and the words it returns, cut as digits of words * 2^8, are the
+        inverse in the 2^392 domain again."""
+        w = self.mulfp2((a, self.const(0)), self.const(K384))[0]
+        r = self.new(); self.ops.append(("reduce", [r], [w], None))
+        d = self.new(); self.ops.append(("inv", [d], [r], None)); return d
+
+    def mul2(self, a, b): return self.sqr2(a) if tuple(a) == tuple(b) else self.call("mul", [a[0], a[1], b[0], b[1]])
+    def neg2(self, a): return (self.neg(a[0]), self.neg(a[1]))
+    def conj2(self, a): return (a[0], self.neg(a[1]))
+    def neg6(self, a): return [self.neg2(c) for c in a]
     def scale2(self, a, k): return (self.scale(a[0], k), self.scale(a[1], k))
     def shadd2(self, a, s, b): return (self.shadd(a[0], s, b[0]), self.shadd(a[1], s, b[1]))
     def dbl2(self, a): return self.scale2(a, 2)
@@ -49,8 +164,11 @@ class Prog(LimbProg):
     def mul8_2(self, a): return self.scale2(a, 8)
     def mul12_2(self, a): return self.scale2(a, 12)
 
+
 R392 = 1 << 392
+K384 = (1 << 384) % P                # multiplying by it in the 2^392 domain leaves a 2^384-domain value
 PTOP = P >> 364                      # top digit of p
+INF = 1 << 60
 NV, NA = 18, 18                      # VGPR / AGPR blocks of 14
 WIN_IN = [0, 1, 2, 3]
 FREE_V = list(range(8, 18))
@@ -95,6 +213,9 @@ class Bound:
 
     def __sub__(self, o):
         return Bound(self.dlo - o.dhi, self.dhi - o.dlo, self.tlo - o.thi, self.thi - o.tlo, self.vlo - o.vhi, self.vhi - o.vlo)
+
+    def neg(self):
+        return Bound(-self.dhi, -self.dlo, -self.thi, -self.tlo, -self.vhi, -self.vlo)
 
     def scaled(self, k):
         assert k > 0
@@ -294,7 +415,7 @@ WAIT_LDS = ["s_waitcnt lgkmcnt(0)", "s_nop 0"]
 
 # ---------------------------------------------------------------------------------------------- the allocator
 class AllocD:
-    """Walks a Prog (tools/gen_tower_asm.py) and emits D-form code. Locations: ('v', blk), ('a', blk), ('l', k) = LDS digit slot k."""
+    """Walks a Prog and emits D-form code. Locations: ('v', blk), ('a', blk), ('l', k) = LDS digit slot k."""
 
     def __init__(self, prog, in_bounds, n_lds=0, lds_base=0, a_pool=None):
         self.p = prog
@@ -432,9 +553,22 @@ class AllocD:
         if w in self.home:                                   # rematerialisable: drop the copy
             self.place(w, self.home[w]); self.bound[w] = self.home_bound[w]; return
         ls = self.free_block("l", range(self.n_lds))
-        if ls is None:
+        if ls is not None:
+            self.copy(src, ("l", ls)); self.place(w, ("l", ls)); return
+        # everything is full: take the AGPR block of the rematerialisable value needed last (it falls back to its workspace home)
+        best, bu = None, -1
+        for blk in self.a_pool:
+            x = self.at.get(("a", blk))
+            if x is None or isinstance(x, tuple) or x not in self.home:
+                continue
+            u = min((q for q in self.uses.get(x, ()) if q >= self.k_now), default=INF)
+            if u > bu:
+                best, bu = blk, u
+        if best is None:
             raise RuntimeError("out of storage")
-        self.copy(src, ("l", ls)); self.place(w, ("l", ls))
+        x = self.at[("a", best)]
+        self.place(x, self.home[x]); self.bound[x] = self.home_bound[x]
+        self.copy(src, ("a", best)); self.place(w, ("a", best))
 
     def to_vgpr(self, v, k, avoid=()):
         l = self.loc[v]
@@ -516,8 +650,23 @@ class AllocD:
             assert ok is None or ok(self.bound[v]), ("operand cannot be brought inside the limit", self.bound[v])
         return b
 
+    def narrow(self, v, k):
+        """bring v's digits down, in place: a carry pass, or -- when the digits are normalised already and it is the value (the top
+        digit) that is too wide -- a reduction"""
+        if self.bound[v].dlo >= 0 and self.bound[v].dhi <= M28:
+            b = self.to_vgpr(v, k)
+            self.wait_lds()
+            assert self.bound[v].vabs() < (P << 16)
+            for l in seq_reduce(lambda j: "v%d" % (vb(b) + j)):
+                self.e(l)
+            self.stats["reduce"] += 60
+            self.bound[v] = REDUCED
+        else:
+            self.ensure(v, k)
+
     def run(self):
         for k, (kind, outs, ins, aux) in enumerate(self.p.ops):
+            self.k_now = k
             if kind in ("add", "sub", "sel"):
                 self.do_arith(k, kind, outs[0], ins[0], ins[1], aux)
             elif kind == "pair":
@@ -538,6 +687,10 @@ class AllocD:
                 self.do_reduce(k, outs[0], ins[0])
             elif kind == "norm":
                 self.do_norm(k, outs[0], ins[0])
+            elif kind == "neg":
+                self.do_neg(k, outs[0], ins[0])
+            elif kind == "inv":
+                self.do_inv(k, outs[0], ins[0])
             elif kind == "scale":
                 self.do_scale(k, outs[0], ins[0], aux)
             elif kind == "shadd":
@@ -564,13 +717,15 @@ class AllocD:
         ba, bb = self.loc[a][1], self.loc[b][1]
         Ba, Bb = self.bound[a], self.bound[b]
         res = {"add": lambda: Ba + Bb, "sub": lambda: Ba - Bb, "sel": lambda: Ba.union(Bb), "shadd": lambda: Ba.scaled(1 << aux) + Bb}[kind]
-        if not res().fits():                                # renormalise the larger operand(s) first
+        for attempt in range(2):                            # renormalise the larger operand(s) first: carry pass, then reduction
+            if res().fits():
+                break
             for v in sorted({a, b}, key=lambda x: -self.bound[x].mag()):
-                self.ensure(v, k)
+                self.narrow(v, k)
                 Ba, Bb = self.bound[a], self.bound[b]
                 if res().fits():
                     break
-            assert res().fits(), ("digit overflow", kind, Ba, Bb)
+        assert res().fits(), ("digit overflow", kind, Ba, Bb)
         self.wait_lds()
         avoid = tuple(self.loc[v][1] for v in keep if self.loc[v][0] == "v")
         hint = self.hint_for(d, k)
@@ -670,6 +825,88 @@ class AllocD:
         self.place(d, ("v", b))
         self.bound[d] = Bound.normalised(self.bound[a].vlo, self.bound[a].vhi)
 
+    def do_neg(self, k, d, a):
+        b = self.to_vgpr(a, k)
+        self.wait_lds()
+        hint = self.hint_for(d, k)
+        if hint is not None and hint != b and ("v", hint) not in self.at and ("vw", hint) not in self.at:
+            bd = hint
+        elif self.next_use(a, k + 1) == INF:
+            bd = b
+        else:
+            bd = self.alloc_v(k, avoid=(b,))
+        for j in range(14):
+            self.e("v_sub_u32_e64 v%d, 0, v%d" % (vb(bd) + j, vb(b) + j))
+        self.stats["arith"] += 14
+        if self.loc.get(a) == ("v", bd):
+            self.release(a)
+        self.place(d, ("v", bd))
+        self.bound[d] = self.bound[a].neg()
+
+    INV_CLOB_V, INV_CLOB_A = range(0, 7), range(0, 15)       # mbls_fp_pow_pm2_asm_fn: v0..v84, a0..a209 (the 15-entry window table)
+
+    def do_inv(self, k, d, a):
+        """a: reduced value x * 2^384 (digit form) -> canonical words in v0..v11 -> the exponentiation routine -> words of x^-1 * 2^384,
+        cut into digits of the 2^392 domain. Everything live leaves the registers that routine uses."""
+        b = self.to_vgpr(a, k)
+        self.wait_lds()
+        B = self.bound[a]
+        assert B.vlo >= REDUCED.vlo and B.vhi <= REDUCED.vhi and B.dlo >= 0 and B.dhi <= M28, ("inv: operand not reduced", B)
+        assert self.next_use(a, k + 1) == INF
+        reg = lambda j: "v%d" % (vb(b) + j)
+        for l in seq_canonical(reg) + seq_to32(reg):
+            self.e(l)
+        for blk in range(NV):                                 # prefetched words are rematerialisable: drop them
+            self.drop_prefetch(blk)
+        safe_v = [x for x in FREE_V if x not in self.INV_CLOB_V and x != b]
+        safe_a = [x for x in self.a_pool if x not in self.INV_CLOB_A]
+
+        def park(w, src):
+            """live value w, currently readable in VGPR block src: to a place the exponentiation leaves alone"""
+            for blk in safe_v:
+                if ("v", blk) not in self.at:
+                    self.copy(("v", src), ("v", blk)); self.place(w, ("v", blk)); return
+            for blk in safe_a:
+                if ("a", blk) not in self.at:
+                    self.copy(("v", src), ("a", blk)); self.place(w, ("a", blk)); return
+            if w in self.home:
+                self.place(w, self.home[w]); self.bound[w] = self.home_bound[w]; return
+            ls = self.free_block("l", range(self.n_lds))
+            if ls is None:
+                raise RuntimeError("out of storage around the inversion")
+            self.copy(("v", src), ("l", ls)); self.place(w, ("l", ls))
+        for blk in self.INV_CLOB_V:
+            w = self.at.get(("v", blk))
+            if w is None or w == a:
+                continue
+            if self.next_use(w, k + 1) == INF:
+                self.release(w)
+            else:
+                park(w, blk)
+        tmp = next(x for x in self.INV_CLOB_V if x != b and ("v", x) not in self.at)
+        for blk in self.INV_CLOB_A:
+            w = self.at.get(("a", blk))
+            if w is None:
+                continue
+            assert not isinstance(w, tuple), "a stored output sits in the exponentiation's table registers"
+            if self.next_use(w, k + 1) == INF:
+                self.release(w)
+            else:
+                self.copy(("a", blk), ("v", tmp)); park(w, tmp)
+        self.release(a)
+        self.wait_lds()
+        if b != 0:
+            for j in range(12):
+                self.e("v_mov_b32_e64 v%d, v%d" % (j, vb(b) + j))
+        self.e("s_waitcnt vmcnt(0)")
+        self.e("CALL mbls_fp_pow_pm2_asm_fn")
+        self.stats["calls"] += 1
+        dst = lambda j: "v%d" % (vb(1) + j)
+        for l in seq_conv(dst, ["v%d" % j for j in range(12)], True):
+            self.e(l)
+        self.place(d, ("v", 1))
+        self.bound[d] = G_IN
+
     def do_storep(self, k, a, slot):
         """value -> workspace slot, packed (representative in (0.5 p, 1.5 p), 12 words, 2^392 domain); values that still call this
         slot home are fetched first"""
@@ -689,6 +926,9 @@ class AllocD:
         for l in seq_pack_pass(reg) + seq_to32(reg) + seq_gstore(reg, slot):
             self.e(l)
         self.stats["reduce"] += 62 + 21 + 38
+        if self.next_use(a, k + 1) != INF:                  # from now on the slot is a home of the value: register copies of it can be
+            self.home[a] = ("gd", slot)                     # dropped and fetched again (same value, the packed representative)
+            self.home_bound[a] = PACKED
 
     def call_limits_ok(self, kind, B):
         m = [x.mag() for x in B]
@@ -707,7 +947,7 @@ class AllocD:
         while not self.call_limits_ok(kind, [self.bound[v] for v in ins]):
             v = max(ins, key=lambda x: (self.bound[x].mag(), -ins.index(x)))
             before = self.bound[v].mag()
-            self.ensure(v, k)
+            self.narrow(v, k)
             guard += 1
             assert self.bound[v].mag() < before or guard < 8, "cannot meet the routine's input limits"
         want = {slots[i]: ins[i] for i in range(len(ins))}
@@ -792,12 +1032,9 @@ def prog_reduce(p, a):
 A_HOME = lambda i: ("a", i)
 
 
-def prog_cyc_sqr_d():
-    """Granger-Scott squaring in the cyclotomic subgroup (formulas of fp12_cyc_sqr in mbls_tower.h), state in AGPR blocks 0..11 in
-    tower order, in place (the loop body of cyc_exp_x_d_routine). Every output re-enters the next squaring through the linear terms
-    3 t -+ 2 z, so each is reduced."""
-    p = Prog()
-    z = [(p.live_in(A_HOME(2 * e)), p.live_in(A_HOME(2 * e + 1))) for e in range(6)]
+def cyc_sqr_formula(p, z, out):
+    """Granger-Scott squaring in the cyclotomic subgroup (formulas of fp12_cyc_sqr in mbls_tower.h) on six Fp2 values in tower order
+    (c0.c0, c0.c1, c0.c2, c1.c0, c1.c1, c1.c2); out(e, value) receives result e (unreduced) as soon as it exists"""
     z0, z4, z3, z2, z1, z5 = z
 
     def fp4_sqr(a, b):
@@ -806,20 +1043,28 @@ def prog_cyc_sqr_d():
         s = p.sqr2(p.add2(a, b))
         c1 = p.sub2(p.sub2(s, t0), t1)
         return c0, c1
-
-    def out(v, e):
-        for i in range(2):
-            p.store(prog_reduce(p, v[i]), A_HOME(2 * e + i))
     t0, t1 = fp4_sqr(z0, z1)
-    out(p.shadd2(p.sub2(t0, z0), 1, t0), 0)          # 2 (t - z) + t
-    out(p.shadd2(p.add2(t1, z1), 1, t1), 4)
+    out(0, p.shadd2(p.sub2(t0, z0), 1, t0))          # 2 (t - z) + t
+    out(4, p.shadd2(p.add2(t1, z1), 1, t1))
     t0, t1 = fp4_sqr(z2, z3)
     t2, t3 = fp4_sqr(z4, z5)
-    out(p.shadd2(p.sub2(t0, z4), 1, t0), 1)
-    out(p.shadd2(p.add2(t1, z5), 1, t1), 5)
+    out(1, p.shadd2(p.sub2(t0, z4), 1, t0))
+    out(5, p.shadd2(p.add2(t1, z5), 1, t1))
     x = p.mul_xi2(t3)
-    out(p.shadd2(p.add2(x, z2), 1, x), 3)
-    out(p.shadd2(p.sub2(t2, z3), 1, t2), 2)
+    out(3, p.shadd2(p.add2(x, z2), 1, x))
+    out(2, p.shadd2(p.sub2(t2, z3), 1, t2))
+
+
+def prog_cyc_sqr_d():
+    """one cyclotomic squaring, state in AGPR blocks 0..11 in tower order, in place (the loop body of the powers by |x|). Every output
+    re-enters the next squaring through the linear terms 3 t -+ 2 z, so each is reduced."""
+    p = Prog()
+    z = [(p.live_in(A_HOME(2 * e)), p.live_in(A_HOME(2 * e + 1))) for e in range(6)]
+
+    def out(e, v):
+        for i in range(2):
+            p.store(prog_reduce(p, v[i]), A_HOME(2 * e + i))
+    cyc_sqr_formula(p, z, out)
     return p
 
 
@@ -1030,7 +1275,6 @@ def build_miller(which, pairs=(0, 1)):
     return body, al.stats
 
 
-K384 = (1 << 384) % P                              # multiplying by it in the 2^392 domain leaves a 2^384-domain value
 F_OUT = [108 + 12 * i for i in range(12)]          # register groups (12 words each) in which the Miller routine returns f
 RUNS = [1, 2, 3, 9, 32, 16]                        # doubling iterations between the additions: |x| = 0xd201000000010000, bits 62..0
 
@@ -1040,7 +1284,7 @@ def far_back(label):
     return ["s_getpc_b64 s[66:67]", "7:", "s_sub_u32 s66, s66, 7b-%db" % label, "s_subb_u32 s67, s67, 0", "s_setpc_b64 s[66:67]"]
 
 
-def f_out_epilogue():
+def f_out_epilogue(ret="s[36:37]"):
     """the Fp12 in AGPR blocks 0..11 (D-form, 2^392 domain) -> canonical words of the 2^384 domain in the register groups F_OUT"""
     epi = ["s_waitcnt vmcnt(0)"]                    # nothing may still be in flight into registers when the routine returns
     B0, B1, B2, B5, B6 = (lambda j: "v%d" % j), (lambda j: "v%d" % (14 + j)), (lambda j: "v%d" % (28 + j)), (lambda j: "v%d" % (70 + j)), (lambda j: "v%d" % (84 + j))
@@ -1052,7 +1296,7 @@ def f_out_epilogue():
         for h, B in ((0, B5), (1, B6)):
             epi += seq_reduce(B) + seq_canonical(B) + seq_to32(B)
             epi += ["v_mov_b32_e64 v%d, %s" % (F_OUT[2 * i + h] + j, B(j)) for j in range(12)]
-    epi += ["s_mov_b64 s[30:31], s[36:37]"]
+    epi += ["s_mov_b64 s[30:31], %s" % ret]
     return epi
 
 
@@ -1095,31 +1339,178 @@ def miller_loop_d_routine(pairs=(0, 1)):
     return pro + main + expand_calls_d(epi), pieces, dict(dbl=st_dbl, add0=st_a0, add1=st_a1)
 
 
-# ---------------------------------------------------------------------------------------------- y^|x| in the cyclotomic subgroup
-G12_SLOT = 13                                       # workspace slots 13..24: the base y of the exponentiation (2^384 domain, canonical)
+# ---------------------------------------------------------------------------------------------- the final exponentiation as ONE routine
+# f^(3 (p^12 - 1) / r) with the hard part (x-1)^2 (x+p) (x^2+p^2-1) + 3 (Hayashida-Hayasaka-Teruya), exactly the sequence of final_exp in
+# mbls_pairing.h: easy part (one Fp12 inversion, Frobenius^2), five powers by |x| (conjugated: x < 0) with Fp12 products in between.
+# Between the bodies below the running value lives in AGPR blocks 0..11; three Fp12 temporaries live in the workspace as packed
+# 2^392-domain words: Y (the base of the running power), M (f after the easy part) and B.
+FEXP_IN_SLOT, Y_SLOT, M_SLOT, B_SLOT = 13, 31, 0, 13     # the input f is dead when B is first written
 
 
-def prog_cyc_mul_d():
-    """acc <- acc * y inside the exponentiation: acc in AGPR blocks 0..11 (between squaring runs it never leaves them), y in the
-    workspace (fetched, and cut into digits, when a product needs it); the reduced product goes back to the AGPR blocks."""
+def f2mul_py(a, b): return ((a[0] * b[0] - a[1] * b[1]) % P, (a[0] * b[1] + a[1] * b[0]) % P)
+
+
+def f2pow_py(a, e):
+    r = (1, 0)
+    while e:
+        if e & 1:
+            r = f2mul_py(r, a)
+        a = f2mul_py(a, a); e >>= 1
+    return r
+
+
+FROB_W = [f2pow_py((1, 1), k * (P - 1) // 6) for k in range(6)]                 # (c w^k)^p = conj(c) FROB_W[k] w^k
+FROB2_W = [(g[0] * g[0] + g[1] * g[1]) % P for g in FROB_W]                      # (c w^k)^(p^2) = c FROB2_W[k] w^k, in Fp
+D392 = lambda x: x * R392 % P
+
+
+def six(l):
+    return ([(l[0], l[1]), (l[2], l[3]), (l[4], l[5])], [(l[6], l[7]), (l[8], l[9]), (l[10], l[11])])
+
+
+def flat12(f):
+    return [x for h in f for c in h for x in c]
+
+
+def mul12(p, a, b, conj_b=False):
+    """(a0 + a1 w)(b0 +- b1 w), Karatsuba over Fp6: 18 Fp2 multiplications; conj_b folds the conjugation of b into the signs"""
+    t0 = None
+    if not conj_b:
+        c1 = p.mul6(p.add6(a[0], a[1]), p.add6(b[0], b[1]))
+        t0 = p.mul6(a[0], b[0]); t1 = p.mul6(a[1], b[1])
+        return (p.add6(t0, p.mul_v6(t1)), p.sub6(p.sub6(c1, t0), t1))
+    c1 = p.mul6(p.add6(a[0], a[1]), p.sub6(b[0], b[1]))
+    t0 = p.mul6(a[0], b[0]); t1 = p.mul6(a[1], b[1])
+    return (p.sub6(t0, p.mul_v6(t1)), p.add6(p.sub6(c1, t0), t1))
+
+
+def sqr6(p, a):
+    """(a0 + a1 v + a2 v^2)^2, Chung-Hasan: 2 multiplications + 3 squarings"""
+    s0, s4 = p.sqr2(a[0]), p.sqr2(a[2])
+    s1 = p.dbl2(p.mul2(a[0], a[1])); s3 = p.dbl2(p.mul2(a[1], a[2]))
+    s2 = p.sqr2(p.add2(p.sub2(a[0], a[1]), a[2]))
+    return [p.add2(s0, p.mul_xi2(s3)), p.add2(s1, p.mul_xi2(s4)), p.sub2(p.sub2(p.add2(p.add2(s1, s2), s3), s0), s4)]
+
+
+def frob12(p, a):
+    out = ([None] * 3, [None] * 3)
+    for k in range(6):
+        c = p.conj2(a[k & 1][k >> 1])
+        out[k & 1][k >> 1] = c if k == 0 else p.mul2(c, (p.const(D392(FROB_W[k][0])), p.const(D392(FROB_W[k][1]))))
+    return out
+
+
+def frob12_2(p, a):
+    out = ([None] * 3, [None] * 3)
+    for k in range(6):
+        c = a[k & 1][k >> 1]
+        g = FROB2_W[k]
+        out[k & 1][k >> 1] = c if g == 1 else p.neg2(c) if g == P - 1 else p.mulfp2(c, p.const(D392(g)))
+    return out
+
+
+def acc_live_in(p):
+    return six([p.live_in(("a", i)) for i in range(12)])
+
+
+def gd_live_in(p, slot):
+    return six([p.live_in(("gd", slot + i)) for i in range(12)])
+
+
+def acc_store(p, f, also=()):
+    """the Fp12 f -> the AGPR state (reduced) and, packed, to the workspace temporaries listed in `also`"""
+    for i, v in enumerate(flat12(f)):
+        r = prog_reduce(p, v)
+        for slot in also:
+            p.ops.append(("storep", [], [r], slot + i))
+        p.store(r, ("a", i))
+
+
+def park12(p, f, slot):
+    """write the Fp12 to workspace slots slot..slot+11: its twelve values can be dropped from the registers and fetched again"""
+    for i, v in enumerate(flat12(f)):
+        p.ops.append(("storep", [], [v], slot + i))
+    return f
+
+
+def prog_fexp_easy():
+    """m = f^((p^6 - 1)(p^2 + 1)): f from the workspace (2^384 domain); m -> state, Y and M"""
     p = Prog()
-    al = [p.live_in(("a", i)) for i in range(12)]
-    gl = [p.live_in(("g", G12_SLOT + i)) for i in range(12)]
-    six = lambda l: ([(l[0], l[1]), (l[2], l[3]), (l[4], l[5])], [(l[6], l[7]), (l[8], l[9]), (l[10], l[11])])
-    a, g = six(al), six(gl)
-    c1 = p.mul6(p.add6(a[0], a[1]), p.add6(g[0], g[1]))      # the sums first: the operands then die pair by pair
-    t0 = p.mul6(a[0], g[0])
-    t1 = p.mul6(a[1], g[1])
-    c1 = p.sub6(p.sub6(c1, t0), t1)
-    c0 = p.add6(t0, p.mul_v6(t1))
-    for i, v in enumerate([x for h in (c0, c1) for c in h for x in c]):
-        p.store(prog_reduce(p, v), ("a", i))
+    # the words from the workspace are a 2^392-domain value up to 2^11 p wide: reduce each coefficient once and give it a packed home
+    f = park12(p, six([prog_reduce(p, p.live_in(("g", FEXP_IN_SLOT + i))) for i in range(12)]), M_SLOT)
+    a0, a1 = f
+    t = p.sub6(sqr6(p, a0), p.mul_v6(sqr6(p, a1)))                     # a0^2 - v a1^2 (the norm to Fp6)
+    c0, c1, c2 = t
+    A = p.sub2(p.sqr2(c0), p.mul_xi2(p.mul2(c1, c2)))
+    B = p.sub2(p.mul_xi2(p.sqr2(c2)), p.mul2(c0, c1))
+    C = p.sub2(p.sqr2(c1), p.mul2(c0, c2))
+    F = p.add2(p.mul_xi2(p.add2(p.mul2(c2, B), p.mul2(c1, C))), p.mul2(c0, A))      # the norm to Fp2
+    Fc = p.conj2(F)
+    n = p.mul2(F, (p.neg(p.neg(F[0])), Fc[1]))[0]                        # F0^2 + F1^2 (the routine wants four distinct operands)
+    Fi = p.mulfp2(Fc, p.inv(n))
+    T = [p.mul2(A, Fi), p.mul2(B, Fi), p.mul2(C, Fi)]                    # 1 / t
+    fi = (p.mul6(a0, T), p.neg6(p.mul6(a1, T)))                          # 1 / f
+    t = park12(p, mul12(p, fi, f, conj_b=True), Y_SLOT)                  # f^(p^6 - 1) = conj(f) / f
+    m = mul12(p, park12(p, frob12_2(p, t), M_SLOT), t)
+    acc_store(p, m, also=(Y_SLOT, M_SLOT))
     return p
 
 
-def build_cyc_mul_d():
-    p = prog_cyc_mul_d()
-    inb = {v: (STATE_IN if l[0] == "a" else G_IN) for v, l in p.init_loc.items()}
+def prog_fexp_mul_y():
+    """state <- state * Y (inside a power by |x|)"""
+    p = Prog()
+    acc_store(p, mul12(p, acc_live_in(p), gd_live_in(p, Y_SLOT)))
+    return p
+
+
+def prog_fexp_step_conj():
+    """after the first and the second power: state <- conj(state) * conj(Y), also the next base (x < 0: the power is conjugated)"""
+    p = Prog()
+    a = acc_live_in(p)
+    r = mul12(p, a, gd_live_in(p, Y_SLOT))                               # conj(a) conj(y) = conj(a y)
+    acc_store(p, (r[0], p.neg6(r[1])), also=(Y_SLOT,))
+    return p
+
+
+def prog_fexp_step_frob():
+    """after the third power: b = conj(state) * frob(Y) -> state, Y, B"""
+    p = Prog()
+    a = acc_live_in(p)
+    r = mul12(p, park12(p, frob12(p, gd_live_in(p, Y_SLOT)), B_SLOT), a, conj_b=True)
+    acc_store(p, r, also=(Y_SLOT, B_SLOT))
+    return p
+
+
+def prog_fexp_step_base():
+    """after the fourth power: conj(state) is the base of the fifth"""
+    p = Prog()
+    a = acc_live_in(p)
+    acc_store(p, (a[0], p.neg6(a[1])), also=(Y_SLOT,))
+    return p
+
+
+def prog_fexp_tail():
+    """after the fifth power: conj(state) * frob^2(B) * conj(B) * M^3"""
+    p = Prog()
+    a = acc_live_in(p)
+    b = gd_live_in(p, B_SLOT)
+    c = mul12(p, park12(p, frob12_2(p, b), Y_SLOT), a, conj_b=True)
+    c = park12(p, mul12(p, c, b, conj_b=True), B_SLOT)
+    m = gd_live_in(p, M_SLOT)
+    m2 = [None] * 6
+    cyc_sqr_formula(p, m[0] + m[1], lambda e, v: m2.__setitem__(e, v))
+    c = mul12(p, c, park12(p, mul12(p, (m2[:3], m2[3:]), m), Y_SLOT))
+    acc_store(p, c)
+    return p
+
+
+FEXP_BODIES = dict(easy=prog_fexp_easy, mul_y=prog_fexp_mul_y, step_conj=prog_fexp_step_conj, step_frob=prog_fexp_step_frob,
+                   step_base=prog_fexp_step_base, tail=prog_fexp_tail)
+
+
+def build_fexp(which):
+    p = FEXP_BODIES[which]()
+    inb = {v: (STATE_IN if l[0] == "a" else PACKED if l[0] == "gd" else G_IN) for v, l in p.init_loc.items()}
     al = AllocD(p, inb, n_lds=11, lds_base=0, a_pool=list(range(NA)))
     body = al.run()
     for dst, B in al.stored.items():
@@ -1127,31 +1518,37 @@ def build_cyc_mul_d():
     return body, al.stats
 
 
-def cyc_exp_x_d_routine():
-    """y^|x| for y in the cyclotomic subgroup as ONE routine: the running power stays in AGPRs (D-form) from the first squaring to the
-    last, through the six runs of Granger-Scott squarings and the five multiplications by y.
-    In:  workspace slots 13..24 = y (2^384 domain, canonical); v252 LDS byte address of the lane's column (11 spill slots);
+def far_fwd(label):
+    return ["s_getpc_b64 s[66:67]", "7:", "s_add_u32 s66, s66, %df-7b" % label, "s_addc_u32 s67, s67, 0", "s_setpc_b64 s[66:67]"]
+
+
+def final_exp_d_routine():
+    """In:  workspace slots 13..24 = f (2^384 domain, canonical); v252 LDS byte address of the lane's column (11 spill slots);
          s[68:69] workspace base adjusted so that v252 is the lane offset, s70 bytes between consecutive words of a value.
-    Out: y^|x| in v108..v251 (twelve groups of 12 words, tower order, canonical, 2^384 domain)."""
-    sqr, st_sqr = build_cyc_sqr_d()
-    mul, st_mul = build_cyc_mul_d()
-    W = lambda j: "v%d" % (vb(8) + j)
-    pro = ["s_mov_b64 s[36:37], s[30:31]", "s_waitcnt vmcnt(0)"] + shell_constants()
-    for i in range(12):                             # acc = y: fetched, cut into digits of y * 2^8, reduced (the bodies' live-in bound)
-        pro += seq_gload(W, G12_SLOT + i, True) + seq_reduce(W)
-        pro += ["v_accvgpr_write_b32 a%d, %s" % (vb(i) + j, W(j)) for j in range(14)]
-    pro += ["s_mov_b32 s78, 0"]
-    top = ["4:", "s_mov_b32 s39, %d" % RUNS[5]]
+    Out: f^(3 (p^12 - 1) / r) in v108..v251 (twelve groups of 12 words, tower order, canonical, 2^384 domain).
+    Workspace slots 0..24 and 31..42 are overwritten."""
+    bodies, stats = {}, {}
+    for name in FEXP_BODIES:
+        bodies[name], stats[name] = build_fexp(name)
+    bodies["sqr"], stats["sqr"] = build_cyc_sqr_d()
+    X = lambda name: expand_calls_d(bodies[name])
+    pro = ["s_mov_b64 s[80:81], s[30:31]", "s_waitcnt vmcnt(0)"] + shell_constants()
+    main = X("easy") + ["s_mov_b32 s79, 0"]
+    main += ["5:", "s_mov_b32 s78, 0", "4:", "s_mov_b32 s39, %d" % RUNS[5]]
     for ph in range(5):
-        top += ["s_cmp_eq_u32 s78, %d" % ph, "s_cselect_b32 s39, %d, s39" % RUNS[ph]]
-    main = top + [".p2align 6", "1:"] + expand_calls_d(sqr)
+        main += ["s_cmp_eq_u32 s78, %d" % ph, "s_cselect_b32 s39, %d, s39" % RUNS[ph]]
+    main += [".p2align 6", "1:"] + X("sqr")
     main += ["s_sub_u32 s39, s39, 1", "s_cmp_lg_u32 s39, 0", "s_cbranch_scc0 2f"] + far_back(1) + ["2:"]
-    main += ["s_cmp_eq_u32 s78, 5", "s_cbranch_scc1 9f"]
-    main += expand_calls_d(mul)
-    main += ["s_add_u32 s78, s78, 1"] + far_back(4) + ["9:"]
-    epi = f_out_epilogue()
-    pieces = dict(pro=pro, sqr=sqr, mul=mul, epi=epi)
-    return pro + main + expand_calls_d(epi), pieces, dict(sqr=st_sqr, mul=st_mul)
+    main += ["s_cmp_eq_u32 s78, 5", "s_cbranch_scc0 3f"] + far_fwd(9) + ["3:"]
+    main += X("mul_y") + ["s_add_u32 s78, s78, 1"] + far_back(4)
+    main += ["9:", "s_cmp_lt_u32 s79, 2", "s_cbranch_scc1 13f"] + far_fwd(11) + ["13:"] + X("step_conj") + far_fwd(20)
+    main += ["11:", "s_cmp_eq_u32 s79, 2", "s_cbranch_scc1 13f"] + far_fwd(12) + ["13:"] + X("step_frob") + far_fwd(20)
+    main += ["12:", "s_cmp_eq_u32 s79, 3", "s_cbranch_scc1 13f"] + far_fwd(14) + ["13:"] + X("step_base")
+    main += ["20:", "s_add_u32 s79, s79, 1"] + far_back(5)
+    main += ["14:"] + X("tail")
+    epi = f_out_epilogue("s[80:81]")
+    pieces = dict(bodies, pro=pro, epi=epi)
+    return pro + main + expand_calls_d(epi), pieces, stats
 
 
 # ---------------------------------------------------------------------------------------------- G2 doubling (subgroup check, cofactor clearing)
@@ -1220,9 +1617,11 @@ def main():
     txt += "#define MBLS_MILLER_D_OUT_REGS(x) " + ", ".join('"={v[%d:%d]}"(x##%d)' % (b, b + 11, i) for i, b in enumerate(F_OUT)) + "\n"
     txt += "#define MBLS_MILLER_D_ASM_CLOBBERS %s,%s, \\\n    %s\n" % (
         ",".join('"v%d"' % i for i in range(256) if i not in fout and i not in (252, 253) and i not in UNTOUCHED_V), ",".join('"a%d"' % i for i in range(252)), sgm)
-    full, pieces, st = cyc_exp_x_d_routine()
-    txt += emit("MBLS_CYC_EXP_X_D_ASM", full) + "\n"
-    print("cyc_exp_x_d: mul", len(pieces["mul"]), "lines", st["mul"])
+    full, pieces, st = final_exp_d_routine()
+    txt += emit("MBLS_FINAL_EXP_D_ASM", full) + "\n"
+    for kname, v in st.items():
+        print("final_exp_d", kname, len(pieces[kname]), "lines", v)
+    txt += "#define MBLS_FINAL_EXP_D_ASM_CLOBBERS MBLS_MILLER_D_ASM_CLOBBERS, \"v253\", \"s79\", \"s80\", \"s81\"\n"
     full, pieces, st = g2_dbl_d_routine()
     txt += emit("MBLS_G2_DBL_D_ASM", full) + "\n"
     print("g2_dbl_d", len(pieces["body"]), "lines", st)
