@@ -40,6 +40,32 @@ __global__ void MBLS_LB k_aggregate(mbls_ws ws, const uint8_t* pks, const uint32
     if (offsets && offsets[i + 1] < offsets[i]) { cnt = 0; bad = MBLS_ST_BAD_PK_ENCODING; }     // a non-monotonic offset table never becomes a read
     uint32_t st; lane_aggregate(ws, i, pks + pkb * first, cnt, fmt, mode, &st); st |= bad; if (st) atomicOr(status + i, st);
 }
+// the generated routines (96-byte keys at 4-byte aligned addresses; table indices)
+__global__ void MBLS_LB k_aggregate_raw_d(mbls_ws ws, const uint8_t* pks, const uint32_t* offsets, uint32_t k, int mode, uint32_t* status, uint64_t n) {
+    uint64_t i = gid(); if (i >= n) return;
+    uint64_t first = offsets ? offsets[i] : (uint64_t)k * i; uint32_t cnt = offsets ? offsets[i + 1] - offsets[i] : k;
+    uint32_t bad = 0;
+    if (offsets && offsets[i + 1] < offsets[i]) { cnt = 0; bad = MBLS_ST_BAD_PK_ENCODING; }
+#if MBLS_DEVICE_ASM && !defined(MBLS_NO_FP2_ASM)
+    uint32_t st = lane_aggregate_d<false>(ws, i, pks + 96 * first, cnt, mode, threadIdx.x) | bad;
+#else
+    uint32_t st; lane_aggregate(ws, i, pks + 96 * first, cnt, MBLS_PK_UNCOMPRESSED, mode, &st); st |= bad;
+#endif
+    if (st) atomicOr(status + i, st);
+}
+__global__ void MBLS_LB k_aggregate_indexed_d(mbls_ws ws, const uint32_t* recs, uint64_t tsize, const uint32_t* idx, const uint32_t* offsets, uint32_t k,
+                                              int mode, uint32_t* status, uint64_t n) {
+    uint64_t i = gid(); if (i >= n) return;
+    uint64_t first = offsets ? offsets[i] : (uint64_t)k * i; uint32_t cnt = offsets ? offsets[i + 1] - offsets[i] : k;
+    uint32_t bad = 0;
+    if (offsets && offsets[i + 1] < offsets[i]) { cnt = 0; bad = MBLS_ST_BAD_PK_ENCODING; }
+#if MBLS_DEVICE_ASM && !defined(MBLS_NO_FP2_ASM)
+    uint32_t st = lane_aggregate_d<true>(ws, i, idx + first, cnt, mode, threadIdx.x, recs, tsize) | bad;
+#else
+    uint32_t st; lane_aggregate_indexed(ws, i, recs, tsize, idx + first, cnt, mode, &st); st |= bad;
+#endif
+    if (st) atomicOr(status + i, st);
+}
 // one key per lane; the square-root routine keeps its window table in 210 AGPRs, so this kernel too runs one wave per SIMD
 __global__ void MBLS_LB k_pk_decompress(const uint8_t* pks48, uint64_t nkeys, uint32_t* keys_xy, uint8_t* flags) {
     uint64_t j = gid(); if (j >= nkeys) return;
@@ -290,6 +316,14 @@ typedef std::lock_guard<std::recursive_mutex> mbls_lock;
 #define ARGFAIL(ctx, what) do { snprintf((ctx)->err, sizeof((ctx)->err), "invalid argument: %s", what); return MBLS_ERR_ARGUMENT; } while (0)
 
 static inline unsigned nblk(uint64_t n) { return (unsigned)((n + WG - 1) / WG); }
+// the per-item key sum from wire-format keys: the generated routine for 96-byte keys (its 16-byte loads want 4-byte alignment),
+// the compiled lane body for 48-byte keys summed in place and for unaligned buffers
+static void launch_aggregate(mbls_ws ws, const uint8_t* d_pks, const uint32_t* d_off, uint32_t k, int fmt, int mode, uint32_t* st, uint64_t n, hipStream_t s) {
+    if (fmt == MBLS_PK_UNCOMPRESSED && (((uintptr_t)d_pks) & 3u) == 0)
+        hipLaunchKernelGGL(k_aggregate_raw_d, dim3(nblk(n)), dim3(WG), 0, s, ws, d_pks, d_off, k, mode, st, n);
+    else
+        hipLaunchKernelGGL(k_aggregate, dim3(nblk(n)), dim3(WG), 0, s, ws, d_pks, d_off, k, fmt, mode, st, n);
+}
 
 static void ctx_free(mbls_ctx* c) {
     (void)hipSetDevice(c->device);
@@ -444,12 +478,12 @@ static int verify_pipeline(mbls_ctx* c, const uint8_t* d_sigs, const uint8_t* d_
     }
     if (tm) HIPCHK(c, hipEventRecord(c->ev[0], s));
     if (ks.indexed)
-        hipLaunchKernelGGL(k_aggregate_indexed, dim3(g), dim3(WG), 0, s, ws, ks.d_recs, ks.tsize, ks.d_idx, d_off, k, mode, st, n);
+        hipLaunchKernelGGL(k_aggregate_indexed_d, dim3(g), dim3(WG), 0, s, ws, ks.d_recs, ks.tsize, ks.d_idx, d_off, k, mode, st, n);
     else if (staged) {
         hipLaunchKernelGGL(k_pk_decompress, dim3(nblk(n * (uint64_t)k)), dim3(WG), 0, s, ks.d_pks, n * (uint64_t)k, c->d_keys_xy, c->d_key_flags);
         hipLaunchKernelGGL(k_aggregate_decoded, dim3(g), dim3(WG), 0, s, ws, (const uint32_t*)c->d_keys_xy, (const uint8_t*)c->d_key_flags, k, mode, st, n);
     } else
-        hipLaunchKernelGGL(k_aggregate, dim3(g), dim3(WG), 0, s, ws, ks.d_pks, d_off, k, fmt, mode, st, n);
+        launch_aggregate(ws, ks.d_pks, d_off, k, fmt, mode, st, n, s);
     if (tm) HIPCHK(c, hipEventRecord(c->ev[1], s));
     if (!keys_later) hipLaunchKernelGGL(k_sig, dim3(g), dim3(WG), 0, s_sig, ws, d_sigs, st, n);
     if (tm) HIPCHK(c, hipEventRecord(c->ev[2], s));
@@ -728,8 +762,7 @@ extern "C" int mbls_aggregate_public_keys_batch(mbls_ctx* c, const uint8_t* pks,
     hipStream_t s = c->hs_a;
     rc = ws_acquire(c, s); if (rc) return rc;
     HIPCHK(c, hipMemsetAsync(c->d_status, 0, 4 * n, s));      // k_aggregate ORs its bits in
-    hipLaunchKernelGGL(k_aggregate, dim3(nblk(n)), dim3(WG), 0, s, ws, dp.as<uint8_t>(), off ? doff.as<uint32_t>() : (const uint32_t*)nullptr, k, fmt,
-                       MBLS_MODE_FAST_AGGREGATE, c->d_status, n);
+    launch_aggregate(ws, dp.as<uint8_t>(), off ? doff.as<uint32_t>() : (const uint32_t*)nullptr, k, fmt, MBLS_MODE_FAST_AGGREGATE, c->d_status, n, s);
     hipLaunchKernelGGL(k_apk_export, dim3(nblk(n)), dim3(WG), 0, s, ws, n, dout.as<uint8_t>());
     HIPCHK(c, hipStreamSynchronize(s)); c->ws_pending = false;
     HIPCHK(c, dout.down(apks96, 96 * n));
@@ -973,7 +1006,7 @@ static int verify_multiple_impl(mbls_ctx* c, const uint8_t* d_sigs, const uint8_
     hipStream_t s_sig = fork ? c->hs_b : s, s_msg = fork ? c->hs_c : s;
     if (fork) { HIPCHK(c, hipEventRecord(c->hs_ev, s)); HIPCHK(c, hipStreamWaitEvent(s_sig, c->hs_ev, 0)); HIPCHK(c, hipStreamWaitEvent(s_msg, c->hs_ev, 0)); }
     if (!d_apks)    // sets given by their wire-format keys: AggregatePublicKey::aggregate on the device first (src/aggregates.rs:29-39)
-        hipLaunchKernelGGL(k_aggregate, dim3(nblk(n)), dim3(WG), 0, s, ws, d_pks, d_pk_offsets, k, pk_format, MBLS_MODE_VERIFY, c->d_status, n);
+        launch_aggregate(ws, d_pks, d_pk_offsets, k, pk_format, MBLS_MODE_VERIFY, c->d_status, n, s);
     hipLaunchKernelGGL(k_blind_g1, dim3(nblk(n)), dim3(WG), 0, s, ws, d_apks, d_rands, c->d_status, n);
     hipLaunchKernelGGL(k_blind_sig, dim3(nblk(n)), dim3(WG), 0, s_sig, ws, d_sigs, d_rands, c->d_status, n);
     { uint64_t m = n; while (m > 1) { uint64_t half = (m + 1) / 2; hipLaunchKernelGGL(k_g2_tree, dim3(nblk(half)), dim3(WG), 0, s_sig, ws, m, half); m = half; } }

@@ -82,6 +82,43 @@ MBLS_FN void lane_aggregate(const mbls_ws& ws, uint64_t i, const uint8_t* pks, u
     ws_st(ws, MBLS_SLOT_APK, i, acc.x); ws_st(ws, MBLS_SLOT_APK + 1, i, acc.y); ws_st(ws, MBLS_SLOT_APK + 2, i, acc.z);
     *status = st;
 }
+// The same sum as one generated digit-form routine per key format (tools/gen_tower_d.py, g1_aggregate_d_routine): the loop over the lane's
+// keys -- fetch one key ahead, decode, mixed addition with the reference's case handling -- without lane-private memory. `keys`: the
+// lane's first 96-byte key (4-byte aligned) or, with a table, its first index. Returns the status bits.
+#if MBLS_DEVICE_ASM && !defined(MBLS_NO_FP2_ASM)
+extern "C" __device__ __attribute__((noinline, used, aligned(64))) void mbls_fp_mulpair_d_asm_fn() { asm volatile(MBLS_FP_MULPAIR_D_ASM); }
+extern "C" __device__ __attribute__((noinline, used, aligned(64))) void mbls_fp_mul1_d_asm_fn() { asm volatile(MBLS_FP_MUL1_D_ASM); }
+extern "C" __device__ __attribute__((noinline, used, aligned(64))) void mbls_g1_aggregate_raw_d_asm_fn() { asm volatile(MBLS_G1_AGGREGATE_RAW_D_ASM); }
+extern "C" __device__ __attribute__((noinline, used, aligned(64))) void mbls_g1_aggregate_indexed_d_asm_fn() { asm volatile(MBLS_G1_AGGREGATE_INDEXED_D_ASM); }
+template <bool INDEXED>
+MBLS_FN uint32_t lane_aggregate_d(const mbls_ws& ws, uint64_t i, const void* keys, uint32_t cnt, int mode, uint32_t lane,
+                                  const uint32_t* recs = nullptr, uint64_t tsize = 0) {
+    uint32_t addr = 4u * lane;
+    const uint64_t gb = (uint64_t)(uintptr_t)ws.w + 4ull * (i - lane);
+    const uint32_t gb_lo = __builtin_amdgcn_readfirstlane((uint32_t)gb), gb_hi = __builtin_amdgcn_readfirstlane((uint32_t)(gb >> 32));
+    const uint32_t st4 = __builtin_amdgcn_readfirstlane((uint32_t)(ws.stride * 4));
+    uint32_t plo = (uint32_t)(uintptr_t)keys, phi = (uint32_t)((uint64_t)(uintptr_t)keys >> 32), c = cnt, fl;
+    if (INDEXED) {
+        const uint32_t r_lo = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)recs), r_hi = __builtin_amdgcn_readfirstlane((uint32_t)((uint64_t)(uintptr_t)recs >> 32));
+        const uint32_t ts = __builtin_amdgcn_readfirstlane((uint32_t)(tsize > 0xFFFFFFFFull ? 0xFFFFFFFFull : tsize));
+        asm volatile(MBLS_ASM_CALL("mbls_g1_aggregate_indexed_d_asm_fn")
+                     : "={v251}"(fl), "+{v248}"(plo), "+{v249}"(phi), "+{v250}"(c)
+                     : "{v252}"(addr), "{s68}"(gb_lo), "{s69}"(gb_hi), "{s70}"(st4), "{s94}"(r_lo), "{s95}"(r_hi), "{s96}"(ts)
+                     : MBLS_G1_AGG_D_ASM_CLOBBERS);
+    } else {
+        asm volatile(MBLS_ASM_CALL("mbls_g1_aggregate_raw_d_asm_fn")
+                     : "={v251}"(fl), "+{v248}"(plo), "+{v249}"(phi), "+{v250}"(c)
+                     : "{v252}"(addr), "{s68}"(gb_lo), "{s69}"(gb_hi), "{s70}"(st4)
+                     : MBLS_G1_AGG_D_ASM_CLOBBERS, "s94", "s95", "s96");
+    }
+    uint32_t st = ((fl & 1u) ? MBLS_ST_PK_INFINITY : 0u) | ((fl & 2u) ? MBLS_ST_BAD_PK_ENCODING : 0u);
+    if (mode == MBLS_MODE_FAST_AGGREGATE) {
+        if (cnt == 0) st |= MBLS_ST_NO_KEYS;
+        if (fl & 4u) st |= MBLS_ST_APK_INFINITY;
+    }
+    return st;
+}
+#endif
 // Compressed keys are decompressed one key per lane first (one Fp square root each: the dominant cost of the 48-byte
 // format, and with n*k lanes the kernel runs at full occupancy), into an array of affine Montgomery coordinates
 // (24 dwords per key); the per-item sum then only does the mixed additions.

@@ -178,6 +178,10 @@ class _Ops(list):
             self.o.val[outs[0]] = ((self.o.val[ins[0]] << aux) + self.o.val[ins[1]]) % P
         elif kind == "storep":
             self.o.out_g[aux] = self.o.val[ins[0]]
+        elif kind == "iszero":
+            self.o.masks[aux] = 1 if self.o.val[ins[0]] % P == 0 else 0
+        elif kind == "mask_orn2":
+            self.o.masks[aux[0]] = self.o.masks[aux[1]] | (1 - self.o.masks[aux[2]])
         elif kind == "neg":
             self.o.val[outs[0]] = -self.o.val[ins[0]] % P
         elif kind == "inv":                                  # the operand is x 2^-8 (see Prog.inv); 0 -> 0 like a^(p-2)
@@ -215,7 +219,12 @@ class ModelProg(Prog):
 
     def call(self, kind, ins):
         x = [self.val[i] for i in ins]; o = (self.new(), self.new())
-        if kind == "mul":
+        if kind == "mul1":
+            self.val[o[0]] = x[0] * x[1] % P
+            return (o[0],)
+        if kind == "mulpair":
+            r = (x[0] * x[2] % P, x[1] * x[3] % P)
+        elif kind == "mul":
             r = ((x[0] * x[2] - x[1] * x[3]) % P, (x[0] * x[3] + x[1] * x[2]) % P)
         elif kind == "sqr":
             r = ((x[0] * x[0] - x[1] * x[1]) % P, (2 * x[0] * x[1]) % P)
@@ -437,3 +446,173 @@ def test_final_exponentiation_routine_full_schedule():
     wpow = lambda x: [x[0], x[3], x[1], x[4], x[2], x[5]]                                # coefficients of w^0 .. w^5
     want = M.f12_pow(M.final_exp(wpow(fin)), 3)
     assert M.f12_eq(wpow(tower), want)
+
+
+# ---------------------------------------------------------------------------------------------- the public-key sum
+def g1_model_masks(which, init, masks):
+    """the program on field values; returns the model (its masks dictionary is updated in place by iszero / mask_orn2)"""
+    prog = t.prog_g1_dbl if which == "dbl" else (lambda: t.prog_g1_step(which))
+    return run_model(prog, init, masks)
+
+
+def jac_affine(X, Y, Z):
+    if Z % P == 0:
+        return None
+    zi = pow(Z, -1, P)
+    return (X * zi * zi % P, Y * zi * zi * zi % P)
+
+
+def g1_add_affine(a, b):
+    if a is None: return b
+    if b is None: return a
+    if a[0] == b[0]:
+        if (a[1] + b[1]) % P == 0: return None
+        l = 3 * a[0] * a[0] * pow(2 * a[1], -1, P) % P
+    else:
+        l = (b[1] - a[1]) * pow(b[0] - a[0], -1, P) % P
+    x = (l * l - a[0] - b[0]) % P
+    return (x, (l * (a[0] - x) - a[1]) % P)
+
+
+G1_GEN = (t.G1_X, t.G1_Y)
+
+
+def g1_mul_affine(pt, k):
+    r = None
+    while k:
+        if k & 1: r = g1_add_affine(r, pt)
+        pt = g1_add_affine(pt, pt); k >>= 1
+    return r
+
+
+@pytest.mark.parametrize("mode", ["raw", "indexed"])
+def test_g1_sum_step_and_doubling(mode):
+    """one key into the running sum, against affine chord-and-tangent arithmetic: general position, sum at infinity, key flagged infinite,
+    key = -sum (result infinity), key = sum (the masks must select the doubling body, which is then run), off-curve key (raw)"""
+    step, _ = t.build_g1(mode)
+    dbl, _ = t.build_g1("dbl")
+    rng = random.Random(77)
+    for case in ("general", "acc_inf", "key_inf", "inverse", "double", "offcurve"):
+        if case == "offcurve" and mode != "raw":
+            continue
+        accp = g1_mul_affine(G1_GEN, rng.randrange(1, 1 << 64))
+        key = g1_mul_affine(G1_GEN, rng.randrange(1, 1 << 64))
+        if case == "inverse": key = (accp[0], P - accp[1])
+        if case == "double": key = accp
+        if case == "offcurve": key = (key[0], (key[1] + 1) % P)
+        z = rng.randrange(1, P)
+        acc = (accp[0] * z * z % P, accp[1] * z * z * z % P, z) if case != "acc_inf" else (rng.randrange(P), rng.randrange(P), 0)
+        m = Machine(ROUT); m.run(t.shell_constants())
+        init, masks = {}, {t.M_INF2: 1 if case == "key_inf" else 0}
+        m.s[("pair", 48)] = masks[t.M_INF2]
+        for i in range(3):
+            init[("a", i)] = acc[i]
+            m.a[14 * i:14 * i + 14] = normalised_digits(acc[i] * R392 % P + rng.choice([-1, 0]) * 0)
+        if mode == "raw":                                   # plain integers below p
+            init[("v", 8)], init[("v", 9)] = key[0] * RI392 % P, key[1] * RI392 % P      # the model's value is rep / 2^392
+            m.v[112:126] = normalised_digits(key[0]); m.v[126:140] = normalised_digits(key[1])
+        else:                                               # Montgomery words (2^384) cut as digits of words * 2^8
+            init[("v", 8)], init[("v", 9)] = key[0], key[1]
+            m.v[112:126] = normalised_digits((key[0] * R384 % P) << 8); m.v[126:140] = normalised_digits((key[1] * R384 % P) << 8)
+        m.run(step)
+        mp = g1_model_masks(mode, init, masks)
+        got = [from_digits_signed(m.a[14 * i:14 * i + 14]) * RI392 % P for i in range(3)]
+        assert got == [mp.out_home[("a", i)] for i in range(3)], case
+        for name, idx in ((t.M_H0, 52), (t.M_R0, 54), (t.M_INF1, 84)):
+            assert m.s[("pair", idx)] == masks[name], (case, name)
+        infk = masks[t.M_INF2F] if mode == "raw" else masks[t.M_INF2]
+        if mode == "raw":
+            assert m.s[("pair", 86)] == masks[t.M_INF2F] == (1 if case in ("key_inf", "offcurve") else 0)
+        need_dbl = masks[t.M_H0] and masks[t.M_R0] and not masks[t.M_INF1] and not infk
+        assert bool(need_dbl) == (case == "double")
+        if need_dbl:
+            m.run(dbl)
+            old = {("a", 5 + i): mp.out_home[("a", 5 + i)] for i in range(3)}
+            assert [old[("a", 5 + i)] for i in range(3)] == list(acc)
+            mp = g1_model_masks("dbl", old, {})
+            got = [from_digits_signed(m.a[14 * i:14 * i + 14]) * RI392 % P for i in range(3)]
+            assert got == [mp.out_home[("a", i)] for i in range(3)]
+        want = accp if case != "acc_inf" else None
+        if case not in ("key_inf", "offcurve"):
+            want = g1_add_affine(want, key)
+        assert jac_affine(*got) == want, case
+
+
+def test_g1_raw_key_decoding():
+    """byte order, flag bits and range checks of the 96-byte format (g1_decode_uncompressed_w in mbls_curve.h)"""
+    dec = t.g1_decode_raw()
+    rng = random.Random(5)
+    pt = g1_mul_affine(G1_GEN, 12345)
+    cases = []
+    enc = lambda x, y: x.to_bytes(48, "big") + y.to_bytes(48, "big")
+    cases.append((enc(*pt), 0, 0, pt))
+    cases.append((bytes([0x40]) + bytes(95), 1, 0, None))                                    # canonical infinity
+    cases.append((bytes([0x40]) + bytes(94) + b"\x01", 1, 1, None))                           # infinity with a stray bit
+    cases.append((bytes([0x41]) + bytes(95), 1, 1, None))
+    cases.append((bytes([enc(*pt)[0] | 0x80]) + enc(*pt)[1:], 1, 1, None))                    # compression flag on a 96-byte key
+    cases.append((bytes([enc(*pt)[0] | 0x20]) + enc(*pt)[1:], 1, 1, None))                    # sign flag
+    cases.append((enc(P, pt[1]), 1, 1, None))                                                 # x = p
+    cases.append((enc(pt[0], P + 5), 1, 1, None))
+    cases.append((enc(P - 1, P - 1), 0, 0, (P - 1, P - 1)))                                   # in range (off curve: the body's business)
+    for blob, inf, bad, xy in cases:
+        m = Machine(ROUT); m.run(t.shell_constants()); m.s[77] = 0x00010203
+        for j in range(24):
+            m.v[224 + j] = int.from_bytes(blob[4 * j:4 * j + 4], "little")
+        for j in range(12):
+            m.v[196 + j] = t.P_LIMBS[j]
+        m.run(dec)
+        assert (m.s[("pair", 48)], m.s[("pair", 88)]) == (inf, bad), blob[:2].hex()
+        if xy:
+            assert from_digits_signed(m.v[112:126]) == xy[0] and from_digits_signed(m.v[126:140]) == xy[1]
+
+
+@pytest.mark.parametrize("mode", ["raw", "indexed"])
+def test_g1_sum_routine_shell(mode):
+    """prologue, per-key fetch / decode / step / status, epilogue in the order the routine's loop runs them, for one lane with five keys
+    (a repeated key, an infinite key, an undecodable key) -> the sum in the workspace and the status bits"""
+    full, pieces, _ = t.g1_aggregate_d_routine(mode)
+    assert not any("scratch" in l or "buffer_" in l for l in full)
+    pts = [g1_mul_affine(G1_GEN, s) for s in (5, 7, 11)]
+    keys = [pts[0], pts[1], "inf", pts[1], "bad", pts[2]]
+    KEYS, IDX, TAB = 0x7E0000100000, 0x7E0000200000, 0x7E0000300000
+    m = miller_machine(0)
+    m.v[252] = LADDR
+    words = lambda b: [int.from_bytes(b[4 * j:4 * j + 4], "little") for j in range(len(b) // 4)]
+    if mode == "raw":
+        for n_, kx in enumerate(keys + [pts[0]]):                  # one more record: the fetch runs a key ahead
+            blob = bytes([0x40]) + bytes(95) if kx == "inf" else bytes([0x20]) + bytes(95) if kx == "bad" else kx[0].to_bytes(48, "big") + kx[1].to_bytes(48, "big")
+            for j, w in enumerate(words(blob)):
+                m.mem[KEYS + 96 * n_ + 4 * j] = w
+        m.v[248], m.v[249] = KEYS & 0xFFFFFFFF, KEYS >> 32
+    else:
+        table = [pts[0], pts[1], "inf", pts[2]]
+        for n_, kx in enumerate(table):
+            rec = [0] * 32
+            if kx == "inf":
+                rec[24] = 1
+            else:
+                rec[0:12] = limbs(kx[0] * R384 % P); rec[12:24] = limbs(kx[1] * R384 % P)
+            for j, w in enumerate(rec):
+                m.mem[TAB + 128 * n_ + 4 * j] = w
+        ids = [0, 1, 2, 1, 99, 3, 0, 0]                            # 99: outside the table = undecodable
+        for n_, w in enumerate(ids):
+            m.mem[IDX + 4 * n_] = w
+        m.v[248], m.v[249] = IDX & 0xFFFFFFFF, IDX >> 32
+        m.s[94], m.s[95], m.s[96] = TAB & 0xFFFFFFFF, TAB >> 32, len(table)
+    m.v[250] = len(keys)
+    m.run(pieces["pro"])
+    want = None
+    for n_, kx in enumerate(keys):
+        m.s[39] = n_
+        m.run(pieces["decode"]); m.run(pieces["nxt"]); m.run(pieces["step"]); m.run(pieces["post"])
+        h0, r0, i1 = m.s[("pair", 52)], m.s[("pair", 54)], m.s[("pair", 84)]
+        i2 = m.s[("pair", 86)] if mode == "raw" else m.s[("pair", 48)]
+        if h0 and r0 and not i1 and not i2:
+            m.run(pieces["dbl"])
+        if kx not in ("inf", "bad"):
+            want = g1_add_affine(want, kx)
+    m.run(pieces["epi"][1:-1])
+    ri = pow(R384, -1, P)
+    X, Y, Z = [ws_get(m, sl) * ri % P for sl in range(3)]
+    assert jac_affine(X, Y, Z) == want
+    assert m.v[251] == 3                                            # an infinite and an undecodable key were seen, the sum is finite

@@ -284,6 +284,51 @@ def test_keytable_indexed_verification_matches_byte_path_and_oracle(mb, N):
     tab.close()
 
 
+def test_key_sum_routines_with_divergent_lanes(mb, N):
+    """The generated key-sum routines (96-byte keys; table indices) when every lane of a wave meets something different: ragged set sizes
+    (0..9 keys), and sets drawn from {G, 2G, -G, Q, infinity, an undecodable key} so that doublings (the running sum equals the next key),
+    sums passing through infinity, infinite and undecodable keys fall on arbitrary lanes and positions. AggregatePublicKey::aggregate
+    (src/aggregates.rs:29-39) per set against the oracle, then fast_aggregate_verify over the same sets through both key forms."""
+    rnd = random.Random(33)
+    R = helpers.R
+    sk_of = {"g": 1, "g2": 2, "mg": R - 1, "q": 0xABCDEF, "inf": 0}
+    pk_of = {name: orc.sk_to_pk(sk) if sk else G1_INF_U for name, sk in sk_of.items()}
+    undec = bytes(48) + bytes([1]) + bytes(47)                          # (0, 2^376): not on the curve
+    n = 150
+    sets = []
+    for i in range(n):
+        cnt = rnd.randrange(10)
+        sets.append([rnd.choice(["g", "g", "g2", "mg", "q", "inf", "bad"] if i % 5 else ["g", "g2", "mg", "q"]) for _ in range(cnt)])
+    sets[3] = ["g", "g"]; sets[4] = ["g", "g", "g2", "g2", "g2"]; sets[5] = ["g", "mg"]; sets[6] = []; sets[7] = ["q"]
+    key_bytes = lambda name: undec if name == "bad" else pk_of[name]
+    flat = b"".join(key_bytes(x) for s_ in sets for x in s_)
+    offsets = [0]
+    for s_ in sets:
+        offsets.append(offsets[-1] + len(s_))
+    apks, st = mb.aggregate_public_keys_batch(flat, n, pk_format=1, pk_offsets=offsets)
+    for i, s_ in enumerate(sets):
+        good = [pk_of[x] for x in s_ if x != "bad"]                      # an undecodable key is skipped and reported
+        e, want = orc.aggregate_pks(good) if good else (0, G1_INF_U)
+        assert apks[96 * i:96 * i + 96] == want, (i, s_)
+        assert bool(st[i] & 0x04) == ("bad" in s_) and bool(st[i] & 0x10) == (len(s_) == 0), (i, s_, hex(st[i]))
+    # the same sets verified: signatures by the sum of the secret keys (an undecodable key makes the item fail)
+    msgs = [rnd.randbytes(32) for _ in range(n)]
+    sigs = [orc.g2_compress(orc.sign(msgs[i], sum(sk_of[x] for x in s_ if x != "bad") % R or 1)) for i, s_ in enumerate(sets)]
+    got_b, st_b = mb.fast_aggregate_verify_batch(b"".join(sigs), b"".join(msgs), flat, n, pk_format=1, pk_offsets=offsets)
+    tab = N.KeyTable()
+    names = ["g", "g2", "mg", "q", "inf"]
+    first, errs = tab.append(b"".join(pk_of[x] for x in names), len(names), pk_format=1, validate=False)
+    assert errs == [0] * len(names)
+    idx = [names.index(x) if x != "bad" else 1000 + i for i, s_ in enumerate(sets) for x in s_]      # outside the table = undecodable
+    got_i, st_i = mb.fast_aggregate_verify_batch_indexed(tab, b"".join(sigs), b"".join(msgs), idx, n, offsets=offsets)
+    for i, s_ in enumerate(sets):
+        total = sum(sk_of[x] for x in s_ if x != "bad") % R
+        expect = len(s_) > 0 and "bad" not in s_ and total != 0
+        assert got_b[i] == got_i[i] == expect, (i, s_, hex(st_b[i]), hex(st_i[i]))
+        assert (st_b[i] & 0x3C) == (st_i[i] & 0x3C), (i, s_, hex(st_b[i]), hex(st_i[i]))
+    assert sum(got_b) > n // 4
+
+
 def test_keytable_device_entry_at_batch_size(N):
     """2^13 x 128 keys through the indexed device entry against the byte-format device entry: identical results, bitmap and status."""
     import torch

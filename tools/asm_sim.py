@@ -28,6 +28,8 @@ class Machine:
         tok = tok.strip()
         if tok == "vcc":
             return self.vcc
+        if tok == "exec":                            # one lane, always active
+            return 1
         m = re.fullmatch(r"v(\d+)", tok)
         if m:
             return self.v[int(m.group(1))]
@@ -52,6 +54,8 @@ class Machine:
 
     def wr_carry(self, tok, val):
         tok = tok.strip()
+        if tok == "exec":                            # the one simulated lane stays active: masked regions are the caller's business
+            return
         if tok == "vcc":
             self.vcc = val
         else:
@@ -101,7 +105,7 @@ class Machine:
             elif op in ("s_mov_b32",):
                 self.wr(args[0], self.rd(args[1]))
             elif op == "s_mov_b64":
-                self.wr_carry(args[0], self.rd(args[1])) if args[0] == "vcc" else self.wr(args[0], self.rd(args[1]))
+                self.wr_carry(args[0], self.rd(args[1])) if args[0] in ("vcc", "exec") else self.wr(args[0], self.rd(args[1]))
             elif op in ("v_mov_b32_e32", "v_mov_b32_e64"):
                 self.wr(args[0], self.rd(args[1]))
             elif op in ("v_mov_b64_e32", "v_mov_b64_e64"):
@@ -170,8 +174,23 @@ class Machine:
             elif op == "v_alignbit_b32":
                 t = (self.rd(args[1]) << 32) | self.rd(args[2])
                 self.wr(args[0], t >> self.rd(args[3]))
-            elif op == "v_or_b32_e32":
+            elif op in ("v_or_b32_e32", "v_or_b32_e64"):
                 self.wr(args[0], self.rd(args[1]) | self.rd(args[2]))
+            elif op == "v_or3_b32":
+                self.wr(args[0], self.rd(args[1]) | self.rd(args[2]) | self.rd(args[3]))
+            elif op == "v_perm_b32":                 # byte i of the result = byte sel[i] of {src0 (4..7), src1 (0..3)}
+                pool = self.rd(args[2]) | (self.rd(args[1]) << 32)
+                sel = self.rd(args[3])
+                r = 0
+                for i in range(4):
+                    q = (sel >> (8 * i)) & 0xFF
+                    assert q < 8, "v_perm_b32 selector outside the plain byte range"
+                    r |= ((pool >> (8 * q)) & 0xFF) << (8 * i)
+                self.wr(args[0], r)
+            elif op == "s_orn2_b64":
+                self.wr_carry(args[0], self.rd(args[1]) | (1 - self.rd(args[2])))
+            elif op == "s_andn2_b64":
+                self.wr_carry(args[0], self.rd(args[1]) & (1 - self.rd(args[2])))
             elif op == "v_cmp_eq_u32_e64":
                 self.wr_carry(args[0], 1 if self.rd(args[1]) == self.rd(args[2]) else 0)
             elif op == "v_cmp_ne_u32_e64":
@@ -206,6 +225,19 @@ class Machine:
             elif op == "s_addc_u32":
                 t = self.rd(args[1]) + self.rd(args[2]) + self.scc
                 self.wr(args[0], t); self.scc = t >> 32
+            elif op in ("global_load_dword", "global_load_dwordx4") and args[2].startswith("off"):
+                # global_load_dword[x4] vdst, v[lo:hi], off [offset:n]   (64-bit address in a VGPR pair)
+                m = re.fullmatch(r"off(?: offset:(\d+))?", args[2])
+                addr = self.rd(args[1]) + int(m.group(1) or 0)
+                lo = int(re.match(r"v\[?(\d+)", args[0]).group(1))
+                for q in range(4 if op.endswith("x4") else 1):
+                    self.v[lo + q] = self.mem[addr + 4 * q]
+            elif op == "v_lshlrev_b64":
+                self.wr(args[0], (self.rd(args[2]) << self.rd(args[1])) & 0xFFFFFFFFFFFFFFFF)
+            elif op == "v_cmp_gt_u32_e64":
+                self.wr_carry(args[0], 1 if self.rd(args[1]) > self.rd(args[2]) else 0)
+            elif op == "v_cmp_le_u32_e64":
+                self.wr_carry(args[0], 1 if self.rd(args[1]) <= self.rd(args[2]) else 0)
             elif op in ("global_load_dword", "global_store_dword"):
                 # global_load_dword vdst, voffset, s[lo:hi]  /  global_store_dword voffset, vdata, s[lo:hi]   (SADDR form)
                 m = re.fullmatch(r"s\[(\d+):(\d+)\]", args[2])

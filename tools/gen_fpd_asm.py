@@ -15,6 +15,8 @@ Register contract (blocks of 14 VGPRs, block i = v[14 i .. 14 i + 13]):
     mbls_fp2_mul_d_asm_fn    a0 blk0, a1 blk1, b0 blk2, b1 blk3 (preserved)  ->  c0 blk5, c1 blk6   (blk4 = -b1, v98..v101 accumulators)
     mbls_fp2_sqr_d_asm_fn    a0 blk0, a1 blk1 (preserved)                    ->  c0 blk5, c1 blk6   (blk2..4 = a0+a1, a0-a1, 2 a1)
     mbls_fp2_mulfp_d_asm_fn  a0 blk0, a1 blk1, s blk2 (preserved)            ->  a0 s blk5, a1 s blk6
+    mbls_fp_mulpair_d_asm_fn a0 blk0, a1 blk1, b0 blk2, b1 blk3 (preserved)  ->  a0 b0 blk5, a1 b1 blk6   (two independent Fp products)
+    mbls_fp_mul1_d_asm_fn    a0 blk0, b0 blk2 (preserved)                    ->  a0 b0 blk5
 Resident constants (loaded once by the calling routine's shell, load_constants()): digits of p in s40-s47, s56-s61, -p^-1 mod 2^28
 in s64, the digit mask in s65. Carries: vcc and s[62:63]. Results: digits 0..12 in [0, 2^28), digit 13 signed (the value lies in
 (-X, p + X) with X = sum |a||b| / 2^392, a tiny multiple of p for every operand the callers produce).
@@ -85,7 +87,19 @@ def fp2_mulfp_d_body():
     return zip2(signed_scan([(A0, SB)], C0, ACC_A, CARRY_A), signed_scan([(A1, SB)], C1, ACC_B, CARRY_B))
 
 
-ROUTINE_BODIES = {"mbls_fp2_mul_d_asm_fn": fp2_mul_d_body, "mbls_fp2_sqr_d_asm_fn": fp2_sqr_d_body, "mbls_fp2_mulfp_d_asm_fn": fp2_mulfp_d_body}
+def fp_mulpair_d_body():
+    """two independent Fp products (the G1 formulas have their multiplications in pairs): a0 b0, a1 b1"""
+    A0, A1, B0, B1, C0, C1 = BLK(0), BLK(1), BLK(2), BLK(3), BLK(5), BLK(6)
+    return zip2(signed_scan([(A0, B0)], C0, ACC_A, CARRY_A), signed_scan([(A1, B1)], C1, ACC_B, CARRY_B))
+
+
+def fp_mul1_d_body():
+    """one Fp product: a0 b0"""
+    return signed_scan([(BLK(0), BLK(2))], BLK(5), ACC_A, CARRY_A)
+
+
+ROUTINE_BODIES = {"mbls_fp2_mul_d_asm_fn": fp2_mul_d_body, "mbls_fp2_sqr_d_asm_fn": fp2_sqr_d_body, "mbls_fp2_mulfp_d_asm_fn": fp2_mulfp_d_body,
+                  "mbls_fp_mulpair_d_asm_fn": fp_mulpair_d_body, "mbls_fp_mul1_d_asm_fn": fp_mul1_d_body}
 
 
 # ---- input limits: the worst column of a scan must stay inside a signed 64-bit accumulator

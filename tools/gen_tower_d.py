@@ -65,8 +65,7 @@ class Prog:
         d = self.new(); self.ops.append(("sel", [d], [a, b], mask)); return d
 
     def call(self, kind, ins):
-        outs = [self.new(), self.new()]
-        assert len(set(ins)) == len(ins)
+        outs = [self.new() for _ in ROUTINES[kind]["outs"]]
         self.ops.append((kind, outs, list(ins), None))
         return tuple(outs)
 
@@ -134,6 +133,18 @@ class Prog:
         c1 = self.sub6(self.sub6(c1, t0), t1)
         return (self.add6(t0, self.mul_v6(t1)), c1)
 
+    # ---- Fp products in pairs (the G1 formulas) and masks
+    def mulpair(self, a0, b0, a1, b1): return self.call("mulpair", [a0, a1, b0, b1])
+    def mul1(self, a, b): return self.call("mul1", [a, b])[0]
+
+    def iszero(self, a, mask):
+        """mask (an SGPR pair) <- lanes in which a = 0 mod p"""
+        self.ops.append(("iszero", [], [a], mask))
+
+    def mask_orn2(self, dst, a, b):
+        """dst <- a | ~b on lane masks"""
+        self.ops.append(("mask_orn2", [], [], (dst, a, b)))
+
     # ---- digit-form operations
     def scale(self, a, k):
         d = self.new(); self.ops.append(("scale", [d], [a], k)); return d
@@ -188,6 +199,8 @@ ROUTINES = {
     "mul": dict(name="mbls_fp2_mul_d_asm_fn", ins=[0, 1, 2, 3], outs=[5, 6], clob=[4, 5, 6, 7]),
     "sqr": dict(name="mbls_fp2_sqr_d_asm_fn", ins=[0, 1], outs=[5, 6], clob=[2, 3, 4, 5, 6, 7]),
     "mulfp": dict(name="mbls_fp2_mulfp_d_asm_fn", ins=[0, 1, 2], outs=[5, 6], clob=[5, 6, 7]),
+    "mulpair": dict(name="mbls_fp_mulpair_d_asm_fn", ins=[0, 1, 2, 3], outs=[5, 6], clob=[5, 6, 7]),     # (a0 b0, a1 b1)
+    "mul1": dict(name="mbls_fp_mul1_d_asm_fn", ins=[0, 2], outs=[5], clob=[5, 7]),
 }
 
 
@@ -417,8 +430,10 @@ WAIT_LDS = ["s_waitcnt lgkmcnt(0)", "s_nop 0"]
 class AllocD:
     """Walks a Prog and emits D-form code. Locations: ('v', blk), ('a', blk), ('l', k) = LDS digit slot k."""
 
-    def __init__(self, prog, in_bounds, n_lds=0, lds_base=0, a_pool=None):
+    def __init__(self, prog, in_bounds, n_lds=0, lds_base=0, a_pool=None, free_v=None):
         self.p = prog
+        self.free_v = list(FREE_V) if free_v is None else list(free_v)     # VGPR blocks outside the routines' window
+        self.all_v = self.free_v + [3, 2, 1, 0, 4, 6, 5]
         self.uses = {}
         for k, (kind, outs, ins, aux) in enumerate(prog.ops):
             for v in ins:
@@ -520,11 +535,11 @@ class AllocD:
     def alloc_v(self, k, avoid=(), hint=None):
         if hint is not None and ("v", hint) not in self.at and ("vw", hint) not in self.at and hint not in avoid:
             return hint
-        b = self.free_block("v", ALL_V, avoid)
+        b = self.free_block("v", self.all_v, avoid)
         if b is not None:
             return b
         best, bu, pre = None, -1, False                      # Belady: the block whose content is needed last (prefetched words included)
-        for blk in ALL_V:
+        for blk in self.all_v:
             if blk in avoid:
                 continue
             w = self.at.get(("v", blk))
@@ -609,10 +624,10 @@ class AllocD:
             kind, outs, ins, aux = self.p.ops[j]
             for v in ins:
                 if self.loc.get(v, ("", 0))[0] in ("g", "gd") and v in self.home:
-                    b = self.free_block("v", FREE_V)
+                    b = self.free_block("v", self.free_v)
                     if b is None:                            # take the block whose value is needed last, if that is later than this use
                         best, bu = None, j
-                        for blk in FREE_V:
+                        for blk in self.free_v:
                             w = self.at.get(("v", blk))
                             if w is None or w in ins_now:
                                 continue
@@ -689,6 +704,10 @@ class AllocD:
                 self.do_norm(k, outs[0], ins[0])
             elif kind == "neg":
                 self.do_neg(k, outs[0], ins[0])
+            elif kind == "iszero":
+                self.do_iszero(k, ins[0], aux)
+            elif kind == "mask_orn2":
+                self.e("s_orn2_b64 %s, %s, %s" % aux)
             elif kind == "inv":
                 self.do_inv(k, outs[0], ins[0])
             elif kind == "scale":
@@ -843,6 +862,28 @@ class AllocD:
         self.place(d, ("v", bd))
         self.bound[d] = self.bound[a].neg()
 
+    def do_iszero(self, k, a, mask):
+        """the reduced representative is the one nearest to zero, |v| < p: the value is 0 mod p iff every digit is 0"""
+        b = self.to_vgpr(a, k)
+        self.wait_lds()
+        B = self.bound[a]
+        red = B.vlo >= REDUCED.vlo and B.vhi <= REDUCED.vhi and B.dlo >= 0 and B.dhi <= M28
+        if self.next_use(a, k + 1) != INF and not red:          # the operand lives on unreduced: test a copy
+            nb = self.alloc_v(k, avoid=(b,))
+            self.copy(("v", b), ("v", nb)); b = nb
+        if not red:
+            assert B.vabs() < (P << 16)
+            for l in seq_reduce(lambda j: "v%d" % (vb(b) + j)):
+                self.e(l)
+            self.stats["reduce"] += 60
+            if self.loc.get(a) == ("v", b):
+                self.bound[a] = REDUCED
+        self.e("v_or_b32_e64 %s, v%d, v%d" % (TMP, vb(b), vb(b) + 1))
+        for j in range(2, 14, 2):
+            self.e("v_or3_b32 %s, %s, v%d, v%d" % (TMP, TMP, vb(b) + j, vb(b) + j + 1))
+        self.e("v_cmp_eq_u32_e64 %s, 0, %s" % (mask, TMP))
+        self.stats["arith"] += 8
+
     INV_CLOB_V, INV_CLOB_A = range(0, 7), range(0, 15)       # mbls_fp_pow_pm2_asm_fn: v0..v84, a0..a209 (the 15-entry window table)
 
     def do_inv(self, k, d, a):
@@ -858,7 +899,7 @@ class AllocD:
             self.e(l)
         for blk in range(NV):                                 # prefetched words are rematerialisable: drop them
             self.drop_prefetch(blk)
-        safe_v = [x for x in FREE_V if x not in self.INV_CLOB_V and x != b]
+        safe_v = [x for x in self.free_v if x not in self.INV_CLOB_V and x != b]
         safe_a = [x for x in self.a_pool if x not in self.INV_CLOB_A]
 
         def park(w, src):
@@ -937,6 +978,10 @@ class AllocD:
         if kind == "sqr":
             s = B[0] + B[1]; dd = B[0] - B[1]
             return s.fits() and dd.fits() and 2 * m[1] < (1 << 31) and column_ok([(s.mag(), dd.mag())]) and column_ok([(m[0], 2 * m[1])])
+        if kind == "mulpair":
+            return column_ok([(m[0], m[2])]) and column_ok([(m[1], m[3])])
+        if kind == "mul1":
+            return column_ok([(m[0], m[1])])
         return column_ok([(m[0], m[2])]) and column_ok([(m[1], m[2])])
 
     def do_call(self, k, kind, outs, ins):
@@ -997,6 +1042,10 @@ class AllocD:
             ob = [product_bound([(B[0], B[2]), (B[1], B[3])]), product_bound([(B[0], B[3]), (B[1], B[2])])]
         elif kind == "sqr":
             ob = [product_bound([(B[0] + B[1], B[0] - B[1])]), product_bound([(B[0], B[1] + B[1])])]
+        elif kind == "mulpair":
+            ob = [product_bound([(B[0], B[2])]), product_bound([(B[1], B[3])])]
+        elif kind == "mul1":
+            ob = [product_bound([(B[0], B[1])])]
         else:
             ob = [product_bound([(B[0], B[2])]), product_bound([(B[1], B[2])])]
         for i, o in enumerate(outs):
@@ -1551,6 +1600,211 @@ def final_exp_d_routine():
     return pro + main + expand_calls_d(epi), pieces, stats
 
 
+# ---------------------------------------------------------------------------------------------- the sum of an item's public keys
+# AggregatePublicKey::aggregate (reference src/aggregates.rs:29-39) as ONE routine per key format: a loop over the lane's keys, each
+# iteration = fetch (one key ahead) + decode + Jacobian mixed addition (formulas and case handling of g1_madd_inl in mbls_curve.h),
+# the running sum in AGPR blocks 0..2. The Fp products come in independent pairs (mbls_fp_mulpair_d_asm_fn).
+#   raw:     96-byte uncompressed keys (big-endian x || y, flag bits in byte 0) at a per-lane address: byte order, flag and range
+#            checks in the shell, conversion to the Montgomery domain and the on-curve check y^2 = x^3 + 4 in the body (16 products)
+#   indexed: 32-bit indices at a per-lane address into a resident table of 128-byte records (x, y in the 2^384 Montgomery domain,
+#            a flag word; see MBLS_KEYREC_DWORDS in mbls_lanes.h): 11 products
+# Shell registers (blocks 15..17 are withheld from the allocator): v224..v247 the 24 words of the key in flight, v[248:249] running
+# address, v250 the lane's key count, v251 status out (bit 0: a key was infinity, bit 1: a key was undecodable, bit 2: the sum is
+# infinity), v210..v216 temporaries. s39 counts keys; exec = lanes that still have a key; s[82:83] the full exec mask.
+G1_FREE_V = list(range(8, 14))             # block 14: v196..v207 hold the limbs of p (range check of the raw coordinates)
+PLIMB = lambda j: "v%d" % (196 + j)
+KW = lambda j: "v%d" % (224 + j)
+M_INF2, M_CURVE, M_H0, M_R0, M_INF1, M_INF2F, M_BAD = "s[48:49]", "s[50:51]", "s[52:53]", "s[54:55]", "s[84:85]", "s[86:87]", "s[88:89]"
+EXEC_ALL, EXEC_ACT = "s[82:83]", "s[90:91]"
+R392SQ = R392 * R392 % P             # x (plain) times this, Montgomery-multiplied, is x in the 2^392 domain
+FOUR_D = 4 * R392 % P
+G1_RAW_IN = Bound.normalised(0, P - 1)
+
+
+def prog_g1_step(mode):
+    """acc <- acc + key. Live in: acc = (X, Y, Z) in AGPR blocks 0..2; the key's coordinates in VGPR blocks 8, 9 -- plain integers
+    below p (raw) or Montgomery words cut as 2^392-domain digits (indexed); mask M_INF2 = the key counts as infinity. Out: the new sum
+    in AGPR blocks 0..2, the old one in 5..7 (for the doubling case), masks M_H0, M_R0, M_INF1, M_INF2F (raw: includes off-curve)."""
+    p = Prog()
+    X, Y, Z = [p.live_in(("a", i)) for i in range(3)]
+    kx, ky = p.live_in(("v", 8)), p.live_in(("v", 9))
+    if mode == "raw":
+        r2 = p.const(R392SQ)
+        x2, y2 = p.mulpair(kx, r2, ky, r2)
+        xx, yy = p.mulpair(x2, x2, y2, y2)
+        x3, Z1Z1 = p.mulpair(xx, x2, Z, Z)
+        p.iszero(p.sub(p.sub(yy, x3), p.const(FOUR_D)), M_CURVE)           # y^2 = x^3 + 4
+        p.mask_orn2(M_INF2F, M_INF2, M_CURVE)
+        T, U2 = p.mulpair(y2, Z, x2, Z1Z1)
+        H = p.sub(U2, X)
+        S2, ZH = p.mulpair(T, Z1Z1, Z, H)
+    else:
+        x2, y2 = kx, ky
+        Z1Z1, T = p.mulpair(Z, Z, y2, Z)
+        U2, S2 = p.mulpair(x2, Z1Z1, T, Z1Z1)
+        H = p.sub(U2, X)
+        ZH = None
+    RR = p.scale(p.sub(S2, Y), 2)
+    p.iszero(H, M_H0); p.iszero(RR, M_R0); p.iszero(Z, M_INF1)
+    HH, RR2 = p.mulpair(H, H, RR, RR)
+    if ZH is None:
+        ZH = p.mul1(Z, H)
+    I4 = p.scale(HH, 4)
+    J, V = p.mulpair(H, I4, X, I4)
+    X3 = p.sub(p.sub(RR2, J), p.scale(V, 2))
+    M0, M1 = p.mulpair(RR, p.sub(V, X3), Y, J)
+    Y3 = p.sub(M0, p.scale(M1, 2))
+    Z3 = p.scale(ZH, 2)                                                    # (Z + H)^2 - Z^2 - H^2
+    inf2 = M_INF2F if mode == "raw" else M_INF2
+    out = [p.sel(M_INF1, X3, x2), p.sel(M_INF1, Y3, y2), p.sel(M_INF1, Z3, p.const(ONE_D))]
+    out = [p.sel(inf2, out[0], X), p.sel(inf2, out[1], Y), p.sel(inf2, out[2], Z)]
+    for i, v in enumerate((X, Y, Z)):
+        p.store(v, ("a", 5 + i))
+    for i, v in enumerate(out):
+        p.store(prog_reduce(p, v), ("a", i))
+    return p
+
+
+def prog_g1_dbl():
+    """the sum as it was before this key (AGPR blocks 5..7), doubled, into blocks 0..2: the key equals the running sum (g1_dbl's formulas)"""
+    p = Prog()
+    X, Y, Z = [p.live_in(("a", 5 + i)) for i in range(3)]
+    A, B = p.mulpair(X, X, Y, Y)
+    XB = p.add(X, B)
+    C, S = p.mulpair(B, B, XB, XB)
+    D = p.scale(p.sub(p.sub(S, A), C), 2)
+    E = p.scale(A, 3)
+    F, YZ = p.mulpair(E, E, Y, Z)
+    X3 = p.sub(F, p.scale(D, 2))
+    Y3 = p.sub(p.mul1(E, p.sub(D, X3)), p.scale(C, 8))
+    for i, v in enumerate((X3, Y3, p.scale(YZ, 2))):
+        p.store(prog_reduce(p, v), ("a", i))
+    return p
+
+
+def build_g1(which):
+    p = prog_g1_dbl() if which == "dbl" else prog_g1_step(which)
+    key_in = G1_RAW_IN if which == "raw" else G_IN
+    inb = {v: (STATE_IN if l[0] == "a" else key_in) for v, l in p.init_loc.items()}
+    al = AllocD(p, inb, n_lds=0, a_pool=list(range(8, NA)), free_v=G1_FREE_V)
+    body = al.run()
+    for dst, B in al.stored.items():
+        assert B.vlo >= STATE_IN.vlo and B.vhi <= STATE_IN.vhi and B.dlo >= 0 and B.dhi <= M28, (dst, B)
+    return body, al.stats
+
+
+P_LIMBS = [(P >> (32 * j)) & 0xFFFFFFFF for j in range(12)]
+
+
+def g1_decode_raw():
+    """the key in flight (KW: 24 memory-order words of the 96 big-endian bytes) -> plain digits of x, y in blocks 8, 9; M_INF2 = it
+    counts as infinity, M_BAD = it is undecodable (g1_decode_uncompressed_w: the compression flag, a non-canonical infinity, the sign
+    flag, a coordinate >= p; the on-curve test follows in the body). s77 holds the byte-swap selector."""
+    T0, T1 = "v210", "v211"
+    L = ["v_and_b32_e32 %s, 0xff, %s" % (T0, KW(0)), "v_lshrrev_b32_e64 %s, 8, %s" % (T1, KW(0))]
+    for j in range(1, 23, 2):
+        L.append("v_or3_b32 %s, %s, %s, %s" % (T1, T1, KW(j), KW(j + 1)))
+    L += ["v_or_b32_e64 %s, %s, %s" % (T1, T1, KW(23)),                                         # everything after byte 0
+          "v_and_b32_e64 v212, 0x3f, %s" % T0, "v_or_b32_e64 %s, %s, v212" % (T1, T1),              # ... and the low six bits of byte 0
+          "v_cmp_ne_u32_e64 s[92:93], 0, %s" % T1,                                              # an infinity flag with anything else set
+          "v_and_b32_e64 v212, 0x40, %s" % T0, "v_cmp_ne_u32_e64 %s, 0, v212" % M_INF2,
+          "s_and_b64 %s, %s, s[92:93]" % (M_BAD, M_INF2),
+          "v_and_b32_e32 v212, 0x80, %s" % T0, "v_cmp_ne_u32_e64 s[92:93], 0, v212", "s_or_b64 %s, %s, s[92:93]" % (M_BAD, M_BAD),
+          "v_and_b32_e64 v212, 0x20, %s" % T0, "v_cmp_ne_u32_e64 s[92:93], 0, v212"]                # sign flag: only an error when finite
+    for j in range(24):
+        L.append("v_perm_b32 %s, %s, %s, s77" % (KW(j), KW(j), KW(j)))
+    for base in (0, 12):                                                                          # borrow of (coordinate - p): set iff it is < p
+        for j in range(12):
+            w = KW(base + 11 - j)
+            L.append(("v_sub_co_u32_e32 %s, vcc, %s, %s" if j == 0 else "v_subb_co_u32_e32 %s, vcc, %s, %s, vcc") % (T1, w, PLIMB(j)))
+        L += ["s_orn2_b64 s[92:93], s[92:93], vcc"]
+    L += ["s_andn2_b64 s[92:93], s[92:93], %s" % M_INF2, "s_or_b64 %s, %s, s[92:93]" % (M_BAD, M_BAD), "s_and_b64 %s, %s, exec" % (M_BAD, M_BAD),
+          "s_or_b64 %s, %s, %s" % (M_INF2, M_INF2, M_BAD)]
+    L += seq_conv(lambda j: "v%d" % (vb(8) + j), [KW(11 - j) for j in range(12)], False)
+    L += seq_conv(lambda j: "v%d" % (vb(9) + j), [KW(23 - j) for j in range(12)], False)
+    return L
+
+
+def g1_status(inf_mask, bad_mask):
+    return ["v_cndmask_b32_e64 v211, 0, 1, %s" % inf_mask, "v_cndmask_b32_e64 v212, 0, 2, %s" % bad_mask, "v_or3_b32 v251, v251, v211, v212"]
+
+
+def g1_aggregate_d_routine(mode):
+    """In:  v[248:249] address of the lane's first key (raw: 96-byte records) or first index (indexed: uint32), v250 its key count;
+         indexed: s[94:95] the table's records, s96 its size; v252, s[68:69], s70 the workspace addressing of the other routines.
+    Out: the sum in workspace slots 0..2 (Jacobian X, Y, Z; canonical, 2^384 domain); v251 status bits."""
+    step, st_step = build_g1(mode)
+    dbl, st_dbl = build_g1("dbl")
+    pro = ["s_mov_b64 s[80:81], s[30:31]", "s_waitcnt vmcnt(0)"] + shell_constants()
+    pro += ["s_mov_b64 %s, exec" % EXEC_ALL, "s_mov_b32 s77, 0x00010203", "v_mov_b32_e32 v251, 0", "s_mov_b32 s39, 0", "v_mov_b32_e32 v254, 0"]
+    for i in range(3):                                  # the sum starts at infinity: (0, 1, 0)
+        for j, dgt in enumerate(digits_of(ONE_D if i == 1 else 0)):
+            pro += (["v_mov_b32_e32 v255, 0x%08x" % dgt, "v_accvgpr_write_b32 a%d, v255" % (vb(i) + j)] if dgt else ["v_accvgpr_write_b32 a%d, v254" % (vb(i) + j)])
+
+    def lanes_with_key(offset):
+        """exec <- lanes whose key count exceeds s39 + offset"""
+        src = "s39" if offset == 0 else "s76"
+        pre = [] if offset == 0 else ["s_add_u32 s76, s39, %d" % offset]
+        # the comparison itself must see every lane: a v_cmp writes zeros for lanes that are switched off
+        return pre + ["s_mov_b64 exec, %s" % EXEC_ALL, "v_cmp_gt_u32_e64 vcc, v250, %s" % src, "s_mov_b64 exec, vcc"]
+
+    if mode == "raw":
+        fetch = ["global_load_dwordx4 v[%d:%d], v[248:249], off offset:%d" % (224 + 4 * q, 227 + 4 * q, 16 * q) for q in range(6)]
+        advance = ["v_add_co_u32_e32 v248, vcc, 0x60, v248", "v_addc_co_u32_e32 v249, vcc, 0, v249, vcc"]
+        pro += ["v_mov_b32_e32 %s, 0x%08x" % (PLIMB(j), P_LIMBS[j]) for j in range(12)]
+        pro += lanes_with_key(0) + fetch + advance
+        decode = g1_decode_raw()
+        nxt = lanes_with_key(1) + fetch + advance
+    else:
+        ID, IDHI, RA, FL, OOB = "v214", "v215", "v[212:213]", "v210", "v216"
+        addr = ["v_cmp_le_u32_e64 vcc, s96, %s" % ID, "v_cndmask_b32_e64 %s, 0, 3, vcc" % OOB, "v_cndmask_b32_e64 %s, %s, 0, vcc" % (ID, ID),
+                "v_mov_b32_e32 %s, 0" % IDHI, "v_lshlrev_b64 %s, 7, v[214:215]" % RA,
+                "v_add_co_u32_e64 v212, vcc, s94, v212", "v_mov_b32_e32 v211, s95", "v_addc_co_u32_e64 v213, vcc, v211, v213, vcc"]
+        fetch = ["global_load_dwordx4 v[%d:%d], %s, off offset:%d" % (224 + 4 * q, 227 + 4 * q, RA, 16 * q) for q in range(6)]
+        fetch += ["global_load_dword v217, %s, off offset:96" % RA]
+        load_id = ["global_load_dword %s, v[248:249], off" % ID, "v_add_co_u32_e64 v248, vcc, 4, v248", "v_addc_co_u32_e64 v249, vcc, 0, v249, vcc"]
+        # prologue: index 0 -> record 0 in flight, index 1 in flight
+        pro += lanes_with_key(0) + load_id + ["s_waitcnt vmcnt(0)"] + addr + fetch + ["v_mov_b32_e32 v218, %s" % OOB] + lanes_with_key(1) + load_id
+        # top of an iteration (everything arrived): flags of this key (an index outside the table counts as undecodable)
+        decode = ["v_or_b32_e64 %s, v217, v218" % FL,
+                  "v_and_b32_e64 v211, 1, %s" % FL, "v_cmp_ne_u32_e64 %s, 0, v211" % M_INF2,
+                  "v_and_b32_e64 v211, 2, %s" % FL, "v_cmp_ne_u32_e64 %s, 0, v211" % M_BAD]
+        decode += seq_conv(lambda j: "v%d" % (vb(8) + j), [KW(j) for j in range(12)], True)
+        decode += seq_conv(lambda j: "v%d" % (vb(9) + j), [KW(12 + j) for j in range(12)], True)
+        nxt = lanes_with_key(1) + addr + fetch + ["v_mov_b32_e32 v218, %s" % OOB] + lanes_with_key(2) + load_id
+    inf_final = M_INF2F if mode == "raw" else M_INF2
+    loop = ["1:"] + lanes_with_key(0) + ["s_mov_b64 %s, exec" % EXEC_ACT, "s_cbranch_execnz 3f"] + far_fwd(9) + ["3:", "s_waitcnt vmcnt(0)"]
+    loop += decode + nxt + ["s_mov_b64 exec, %s" % EXEC_ACT]
+    loop += expand_calls_d(step)
+    post = []
+    if mode == "raw":                                   # an off-curve key is undecodable too
+        post += ["s_andn2_b64 s[92:93], %s, %s" % (M_INF2F, M_INF2), "s_or_b64 %s, %s, s[92:93]" % (M_BAD, M_BAD)]
+    post += g1_status(inf_final, M_BAD)
+    loop += post
+    # same x and same y as the running sum, neither infinite: the doubling, on those lanes only
+    loop += ["s_and_b64 s[92:93], %s, %s" % (M_H0, M_R0), "s_andn2_b64 s[92:93], s[92:93], %s" % M_INF1, "s_andn2_b64 s[92:93], s[92:93], %s" % inf_final,
+             "s_and_b64 s[92:93], s[92:93], exec", "s_cbranch_scc1 3f"] + far_fwd(4) + ["3:", "s_mov_b64 exec, s[92:93]"]
+    loop += expand_calls_d(dbl) + ["4:", "s_add_u32 s39, s39, 1"] + far_back(1)
+    # epilogue: canonical 2^384-domain words of X, Y, Z to the workspace; is the sum infinity?
+    epi = ["9:", "s_mov_b64 exec, %s" % EXEC_ALL, "s_waitcnt vmcnt(0)"]
+    B0, B1, B2, B5, B6 = (lambda j: "v%d" % j), (lambda j: "v%d" % (14 + j)), (lambda j: "v%d" % (28 + j)), (lambda j: "v%d" % (70 + j)), (lambda j: "v%d" % (84 + j))
+    epi += ["v_mov_b32_e32 %s, 0x%08x" % (B2(j), dgt) for j, dgt in enumerate(digits_of(K384))]
+    for half in range(2):
+        srcs = (0, 1) if half == 0 else (2, 2)
+        epi += ["v_accvgpr_read_b32 %s, a%d" % (B0(j), vb(srcs[0]) + j) for j in range(14)]
+        epi += ["v_accvgpr_read_b32 %s, a%d" % (B1(j), vb(srcs[1]) + j) for j in range(14)]
+        epi += ["CALL mbls_fp2_mulfp_d_asm_fn"]
+        for h, B in ((0, B5), (1, B6))[:2 if half == 0 else 1]:
+            epi += seq_reduce(B) + seq_canonical(B) + seq_to32(B)
+            if half == 1:
+                epi += ["v_or_b32_e64 v211, %s, %s" % (B(0), B(1))] + ["v_or3_b32 v211, v211, %s, %s" % (B(j), B(j + 1)) for j in range(2, 12, 2)]
+                epi += ["v_cmp_eq_u32_e64 vcc, 0, v211", "v_cndmask_b32_e64 v211, 0, 4, vcc", "v_or_b32_e64 v251, v251, v211"]
+            epi += seq_gstore(B, 2 * half + h)
+    epi += ["s_waitcnt vmcnt(0)", "s_mov_b64 s[30:31], s[80:81]"]
+    pieces = dict(pro=pro, decode=decode, nxt=nxt, step=step, post=post, dbl=dbl, epi=epi)
+    return pro + loop + expand_calls_d(epi), pieces, dict(step=st_step, dbl=st_dbl)
+
+
 # ---------------------------------------------------------------------------------------------- G2 doubling (subgroup check, cofactor clearing)
 G2D_ARG = [108 + 12 * i for i in range(6)]         # X.c0, X.c1, Y.c0, Y.c1, Z.c0, Z.c1 as six groups of 12 words, in and out
 G2_IN = Bound.normalised(-16 * P, 16 * P)          # every round, the first included: the shell reduces the converted inputs
@@ -1622,6 +1876,13 @@ def main():
     for kname, v in st.items():
         print("final_exp_d", kname, len(pieces[kname]), "lines", v)
     txt += "#define MBLS_FINAL_EXP_D_ASM_CLOBBERS MBLS_MILLER_D_ASM_CLOBBERS, \"v253\", \"s79\", \"s80\", \"s81\"\n"
+    for mode in ("raw", "indexed"):
+        full, pieces, st = g1_aggregate_d_routine(mode)
+        txt += emit("MBLS_G1_AGGREGATE_%s_D_ASM" % mode.upper(), full) + "\n"
+        print("g1 aggregate", mode, "step", len(pieces["step"]), "lines", st["step"], "dbl", len(pieces["dbl"]))
+    sga = sgm.replace('"vcc"', '"s50","s51","s52","s53","s79","s80","s81","s82","s83","s84","s85","s86","s87","s88","s89","s90","s91","s92","s93","vcc"')
+    txt += "#define MBLS_G1_AGG_D_ASM_CLOBBERS %s,%s, \\\n    %s\n" % (
+        ",".join('"v%d"' % i for i in range(256) if i not in (248, 249, 250, 251, 252) and i not in UNTOUCHED_V), ",".join('"a%d"' % i for i in range(252)), sga)
     full, pieces, st = g2_dbl_d_routine()
     txt += emit("MBLS_G2_DBL_D_ASM", full) + "\n"
     print("g2_dbl_d", len(pieces["body"]), "lines", st)
