@@ -300,13 +300,14 @@ def cpu_baseline(d_sigs, d_msgs, d_pks, expect, k, fmt, seconds_target=10.0):
 
 
 # ---------------------------------------------------------------------------------------------- instruction-level figure
-def valu_issue_figure(lib, ctx, phase_ms, n_items):
-    """Hardware-side efficiency of the two dominant kernels from numbers this run measures plus the generators' exact instruction
+def valu_issue_figure(lib, ctx, phase_ms, n_items, agg_kernel="k_aggregate"):
+    """Hardware-side efficiency of the generated kernels from numbers this run measures plus the generators' exact instruction
     counts (profiles/instr_census.json, written by tools/instr_census.py from the same generators that emit the routines):
     achieved = wave-instructions per item x items / 64 lanes / kernel time / 1024 SIMDs;
     ceiling  = the rate one SIMD issues this instruction mix at, measured live by mbls_valu_bench (8 waves per SIMD): v_mad_u64_u32
-    and plain 32-bit VALU timed separately and blended by the routines' mix. Only the generated straight-line routines are counted
-    (the cold compiler-scheduled paths -- 10 addition steps, one Fp12 inversion, Frobenius maps -- are not), so `frac` is a lower bound."""
+    and plain 32-bit VALU timed separately and blended by the routines' mix. Only the generated routines are counted (not the few
+    hundred compiler-scheduled instructions around them), so `frac` is a lower bound. agg_kernel: "k_aggregate" (the census row for
+    128 96-byte keys per item) -- pass None when the timed keys had another format."""
     cf = os.path.join(ROOT, "profiles", "instr_census.json")
     if not os.path.exists(cf):
         return None
@@ -319,7 +320,7 @@ def valu_issue_figure(lib, ctx, phase_ms, n_items):
         rate[name] = 8 * 4000 * 128 / (ms.value * 1e-3)            # wave-instructions per second per SIMD
     out = {"unit": "wave-instructions/s/SIMD", "ceiling_measured": rate, "kernels": {},
            "note": "ceiling = live mbls_valu_bench at 8 waves/SIMD; instruction counts = generated routines only (exact), cold paths excluded: frac is a lower bound"}
-    for kern, phase in (("k_miller", "miller"), ("k_final", "final")):
+    for kern, phase in (("k_miller", "miller"), ("k_final", "final"), (agg_kernel, "aggregate")):
         c = census["per_item"].get(kern)
         if not c or phase_ms.get(phase, 0) <= 0:
             continue
@@ -486,7 +487,7 @@ def main():
                          "note": "VALU-issue-bound path (see valu_issue): the HBM fraction is reported as measured; traffic (PMC counters) cannot "
                                  "be collected inside a timed run, see traffic_from_profile"},
             "traffic_from_profile": from_profile("hbm_traffic.json", dom),
-            "valu_issue": valu_issue_figure(lib, ctx, phase_ms, n),
+            "valu_issue": valu_issue_figure(lib, ctx, phase_ms, n, {"uncompressed": "k_aggregate", "indexed": "k_aggregate_indexed"}.get(args.pk_format) if k == 128 else None),
             "phase_ms": phase_ms,
             "variants": variants,
             "input_build_s": t_in,

@@ -147,15 +147,19 @@ MBLS_NOINLINE void map_to_curve_g2(g2j* out, const fp2* up) {
     }
     out->x = xnum; out->y = fp2_mul(y, ynum); out->z = fp2_add(x, fp2_load_const(MBLS_ISO3_K));
 }
-// hash_to_curve_g2 (reference src/amcl_utils.rs:33-35); result in Jacobian coordinates, in G2
-MBLS_NOINLINE void hash_to_g2(g2j* out, const uint8_t* msg, uint32_t mlen, const uint8_t* dst, uint32_t dlen) {
+// hash_to_field + the two map_to_curve evaluations of hash_to_curve_g2: points of E'(Fp2) in Jacobian coordinates
+MBLS_NOINLINE void hash_to_g2_maps(g2j* q0, g2j* q1, const uint8_t* msg, uint32_t mlen, const uint8_t* dst, uint32_t dlen) {
     uint32_t ub[64];
     expand_message_xmd_256(ub, msg, mlen, dst, dlen);
     fp2 u0, u1;
     u0.c0 = fp_from_two_digests(ub, ub + 8); u0.c1 = fp_from_two_digests(ub + 16, ub + 24);
     u1.c0 = fp_from_two_digests(ub + 32, ub + 40); u1.c1 = fp_from_two_digests(ub + 48, ub + 56);
+    map_to_curve_g2(q0, &u0); map_to_curve_g2(q1, &u1);
+}
+// hash_to_curve_g2 (reference src/amcl_utils.rs:33-35); result in Jacobian coordinates, in G2
+MBLS_NOINLINE void hash_to_g2(g2j* out, const uint8_t* msg, uint32_t mlen, const uint8_t* dst, uint32_t dlen) {
     g2j q0, q1;
-    map_to_curve_g2(&q0, &u0); map_to_curve_g2(&q1, &u1);
+    hash_to_g2_maps(&q0, &q1, msg, mlen, dst, dlen);
     g2_add(&q0, &q0, &q1);
     g2_clear_cofactor(out, &q0);
 }

@@ -20,7 +20,8 @@
 
 #define MBLS_SLOT_S 25            // 6 Fp: Jacobian G2 accumulator for verify_multiple
 #define MBLS_SLOT_T 31            // 12 Fp: the running points of the generated Miller loop (packed, 2^392 domain; tools/gen_tower_d.py T_SLOT)
-#define MBLS_SLOT_TOTAL 43
+#define MBLS_SLOT_G2TMP 43        // 6 Fp: scratch of the generated subgroup-test routine (tools/gen_tower_d.py G2_SLOTS)
+#define MBLS_SLOT_TOTAL 49
 #define WG 64
 // The pipeline kernels are built for one wave per SIMD (512 registers per lane): a batch of 2^16 items is exactly one wave
 // per SIMD on 256 CUs, and the hot loops are generated straight-line routines that already issue at the VALU rate with a
@@ -103,12 +104,26 @@ __global__ void MBLS_LB k_g2_sum(const uint32_t* xy, const uint8_t* flags, const
     op_g2_sum(i, xy + 48 * first, flags + first, cnt, out96, errs);
 }
 __global__ void MBLS_LB k_sig(mbls_ws ws, const uint8_t* sigs, uint32_t* status, uint64_t n) {
+#if !defined(MBLS_NO_LDS_STATE)
+    __shared__ uint32_t spill[154 * 64];          // 11 spill slots of 14 dwords per lane for the generated subgroup test
     uint64_t i = gid(); if (i >= n) return;
-    uint32_t st = 0; lane_sig(ws, i, sigs + 96 * i, &st); if (st) atomicOr(status + i, st);     // may run beside k_aggregate on another stream
+    uint32_t st = 0; lane_sig(ws, i, sigs + 96 * i, &st, (MBLS_LDS uint32_t*)spill, threadIdx.x, true);
+#else
+    uint64_t i = gid(); if (i >= n) return;
+    uint32_t st = 0; lane_sig(ws, i, sigs + 96 * i, &st);
+#endif
+    if (st) atomicOr(status + i, st);             // may run beside k_aggregate on another stream
 }
 __global__ void MBLS_LB k_hash(mbls_ws ws, const uint8_t* msgs, uint32_t mlen, const uint64_t* moff, const uint32_t* mlens, uint64_t n) {
+#if !defined(MBLS_NO_LDS_STATE)
+    __shared__ uint32_t spill[154 * 64];          // the same for the addition / cofactor-clearing routine
+    uint64_t i = gid(); if (i >= n) return;
+    if (moff) lane_hash(ws, i, msgs + moff[i], mlens[i], (MBLS_LDS uint32_t*)spill, threadIdx.x, true);
+    else lane_hash(ws, i, msgs + (uint64_t)mlen * i, mlen, (MBLS_LDS uint32_t*)spill, threadIdx.x, true);
+#else
     uint64_t i = gid(); if (i >= n) return;
     if (moff) lane_hash(ws, i, msgs + moff[i], mlens[i]); else lane_hash(ws, i, msgs + (uint64_t)mlen * i, mlen);
+#endif
 }
 __global__ void MBLS_LB k_miller(mbls_ws ws, uint64_t n) {
 #if !defined(MBLS_NO_LDS_STATE)

@@ -189,19 +189,56 @@ MBLS_FN void lane_aggregate_indexed(const mbls_ws& ws, uint64_t i, const uint32_
     ws_st(ws, MBLS_SLOT_APK, i, acc.x); ws_st(ws, MBLS_SLOT_APK + 1, i, acc.y); ws_st(ws, MBLS_SLOT_APK + 2, i, acc.z);
     *status = st;
 }
-MBLS_FN void lane_sig(const mbls_ws& ws, uint64_t i, const uint8_t* sig96, uint32_t* status) {
+#if MBLS_DEVICE_ASM && !defined(MBLS_NO_FP2_ASM)
+// The group arithmetic of the two phases below as generated routines (tools/gen_tower_d.py, g2_group_routine): operands and results in
+// the workspace, the running point in AGPRs, `spill` = 11 x 14 dwords per lane of LDS, no lane-private memory.
+extern "C" __device__ __attribute__((noinline, used, aligned(64))) void mbls_g2_subgroup_d_asm_fn() { asm volatile(MBLS_G2_SUBGROUP_D_ASM); }
+extern "C" __device__ __attribute__((noinline, used, aligned(64))) void mbls_g2_hash_tail_d_asm_fn() { asm volatile(MBLS_G2_HASH_TAIL_D_ASM); }
+template <bool HASH>
+MBLS_FN uint32_t g2_group_d_call(const mbls_ws& ws, uint64_t i, MBLS_LDS uint32_t* spill, uint32_t lane) {
+    const uint32_t addr = (uint32_t)(uintptr_t)(spill + lane);
+    const uint64_t gb = (uint64_t)(uintptr_t)ws.w + 4ull * (i - lane) - (uint64_t)(uint32_t)(uintptr_t)spill;
+    const uint32_t gb_lo = __builtin_amdgcn_readfirstlane((uint32_t)gb), gb_hi = __builtin_amdgcn_readfirstlane((uint32_t)(gb >> 32));
+    const uint32_t st4 = __builtin_amdgcn_readfirstlane((uint32_t)(ws.stride * 4));
+    uint32_t fl = 0;
+    if (HASH)
+        asm volatile(MBLS_ASM_CALL("mbls_g2_hash_tail_d_asm_fn") : "+{v251}"(fl) : "{v252}"(addr), "{s68}"(gb_lo), "{s69}"(gb_hi), "{s70}"(st4) : MBLS_G2_GROUP_D_ASM_CLOBBERS);
+    else
+        asm volatile(MBLS_ASM_CALL("mbls_g2_subgroup_d_asm_fn") : "+{v251}"(fl) : "{v252}"(addr), "{s68}"(gb_lo), "{s69}"(gb_hi), "{s70}"(st4) : MBLS_G2_GROUP_D_ASM_CLOBBERS);
+    return fl;
+}
+#endif
+// spill != nullptr (with use_lds): the subgroup test runs as the generated routine on the coordinates just stored
+MBLS_FN void lane_sig(const mbls_ws& ws, uint64_t i, const uint8_t* sig96, uint32_t* status, MBLS_LDS uint32_t* spill = nullptr, uint32_t lane = 0, bool use_lds = false) {
     fp2 x, y; bool inf; uint32_t st = 0;
     int e = g2_decode_compressed(&x, &y, &inf, sig96);
     if (e) { st |= MBLS_ST_BAD_SIG_ENCODING; inf = true; }
-    g2j p; p.x = x; p.y = y; p.z = fp2_one();
-    if (inf) g2_set_inf(&p);
-    if (!g2_in_subgroup(&p)) st |= MBLS_ST_SIG_NOT_IN_G2;
     // infinity is stored as y = 0 (no curve point has y = 0: there is no 2-torsion)
     if (inf) { x = fp2_zero(); y = fp2_zero(); }
     ws_st2(ws, MBLS_SLOT_SIG, i, x); ws_st2(ws, MBLS_SLOT_SIG + 2, i, y);
+    bool in_g2;
+#if MBLS_DEVICE_ASM && !defined(MBLS_NO_FP2_ASM)
+    if (use_lds) in_g2 = (g2_group_d_call<false>(ws, i, spill, lane) & 1u) | inf;       // infinity passes (psi(O) = [x]O)
+    else
+#endif
+    {
+        g2j p; p.x = x; p.y = y; p.z = fp2_one();
+        if (inf) g2_set_inf(&p);
+        in_g2 = g2_in_subgroup(&p);
+    }
+    if (!in_g2) st |= MBLS_ST_SIG_NOT_IN_G2;
     *status |= st;
 }
-MBLS_FN void lane_hash(const mbls_ws& ws, uint64_t i, const uint8_t* msg, uint32_t mlen) {
+MBLS_FN void lane_hash(const mbls_ws& ws, uint64_t i, const uint8_t* msg, uint32_t mlen, MBLS_LDS uint32_t* spill = nullptr, uint32_t lane = 0, bool use_lds = false) {
+#if MBLS_DEVICE_ASM && !defined(MBLS_NO_FP2_ASM)
+    if (use_lds) {          // the two map_to_curve points to the workspace; q0 + q1 and the cofactor clearing as the generated routine
+        g2j q0, q1; hash_to_g2_maps(&q0, &q1, msg, mlen, MBLS_DST_POP, MBLS_DST_POP_LEN);
+        ws_st2(ws, MBLS_SLOT_H, i, q0.x); ws_st2(ws, MBLS_SLOT_H + 2, i, q0.y); ws_st2(ws, MBLS_SLOT_H + 4, i, q0.z);
+        ws_st2(ws, 19, i, q1.x); ws_st2(ws, 21, i, q1.y); ws_st2(ws, 23, i, q1.z);
+        g2_group_d_call<true>(ws, i, spill, lane);
+        return;
+    }
+#endif
     g2j h; hash_to_g2(&h, msg, mlen, MBLS_DST_POP, MBLS_DST_POP_LEN);
     ws_st2(ws, MBLS_SLOT_H, i, h.x); ws_st2(ws, MBLS_SLOT_H + 2, i, h.y); ws_st2(ws, MBLS_SLOT_H + 4, i, h.z);
 }

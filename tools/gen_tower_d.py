@@ -141,6 +141,13 @@ class Prog:
         """mask (an SGPR pair) <- lanes in which a = 0 mod p"""
         self.ops.append(("iszero", [], [a], mask))
 
+    def mask_and(self, dst, a, b):
+        self.ops.append(("mask_and", [], [], (dst, a, b)))
+
+    def iszero2(self, a, mask, tmp):
+        """mask <- lanes in which the Fp2 value a is zero (tmp: a second SGPR pair)"""
+        self.iszero(a[0], mask); self.iszero(a[1], tmp); self.mask_and(mask, mask, tmp)
+
     def mask_orn2(self, dst, a, b):
         """dst <- a | ~b on lane masks"""
         self.ops.append(("mask_orn2", [], [], (dst, a, b)))
@@ -708,6 +715,8 @@ class AllocD:
                 self.do_iszero(k, ins[0], aux)
             elif kind == "mask_orn2":
                 self.e("s_orn2_b64 %s, %s, %s" % aux)
+            elif kind == "mask_and":
+                self.e("s_and_b64 %s, %s, %s" % aux)
             elif kind == "inv":
                 self.do_inv(k, outs[0], ins[0])
             elif kind == "scale":
@@ -1810,11 +1819,12 @@ G2D_ARG = [108 + 12 * i for i in range(6)]         # X.c0, X.c1, Y.c0, Y.c1, Z.c
 G2_IN = Bound.normalised(-16 * P, 16 * P)          # every round, the first included: the shell reduces the converted inputs
 
 
-def prog_g2_dbl_d():
+def prog_g2_dbl_d(src=0, dst=0):
     """Jacobian doubling in E'(Fp2) (formulas of g2_dbl in mbls_curve.h; valid for every curve point including infinity). X, Y, Z in
-    AGPR blocks 0..5. Every output is a combination of products only, so a carry pass at the store keeps the state bounded."""
+    AGPR blocks src..src+5, result in dst..dst+5. Every output is a combination of products only, so a carry pass at the store keeps
+    the state bounded."""
     p = Prog()
-    l = [p.live_in(("a", i)) for i in range(6)]
+    l = [p.live_in(("a", src + i)) for i in range(6)]
     X, Y, Z = (l[0], l[1]), (l[2], l[3]), (l[4], l[5])
     A = p.sqr2(X); B = p.sqr2(Y); C = p.sqr2(B)
     D = p.dbl2(p.sub2(p.sub2(p.sqr2(p.add2(X, B)), A), C))
@@ -1823,7 +1833,7 @@ def prog_g2_dbl_d():
     X3 = p.sub2(F, p.dbl2(D))
     Y3 = p.sub2(p.mul2(E, p.sub2(D, X3)), p.mul8_2(C))
     for v, i in zip((X3[0], X3[1], Y3[0], Y3[1], Z3[0], Z3[1]), range(6)):
-        p.store(prog_norm(p, v), ("a", i))
+        p.store(prog_norm(p, v), ("a", dst + i))
     return p
 
 
@@ -1850,6 +1860,212 @@ def g2_dbl_d_routine():
             epi += ["v_mov_b32_e64 v%d, %s" % (G2D_ARG[2 * i + h] + j, B(j)) for j in range(12)]
     full = wrap_loop_d(expand_calls_d(body), "s39", pro, expand_calls_d(epi))
     return full, dict(pro=pro, body=body, epi=epi), al.stats
+
+
+# ---------------------------------------------------------------------------------------------- G2 group routines
+# The group arithmetic of the signature and message phases as generated routines: the subgroup test psi(P) = [x]P of a decoded signature
+# (g2_in_subgroup in mbls_curve.h; reference src/signature.rs:29, src/aggregates.rs:184) and everything after the two map_to_curve
+# evaluations of hash_to_curve_g2 (q0 + q1, Budroni-Pintore cofactor clearing: g2_clear_cofactor; reference src/amcl_utils.rs:33-35).
+# The running point lives in AGPR blocks 0..5 (Jacobian X, Y, Z), every other point in workspace slots (packed, 2^392 domain); an
+# addition takes its second operand from the staging slots AD. Additions follow g2_add's case handling: operands at infinity by
+# selection, equal operands by a doubling run on those lanes only (exec-masked), opposite operands give Z = 0 by the formulas.
+G2M_TMP0, G2M_TMP1 = "s[86:87]", "s[88:89]"
+PSI_CX = None
+
+
+def f2inv_py(a):
+    n = pow(a[0] * a[0] + a[1] * a[1], P - 2, P)
+    return (a[0] * n % P, -a[1] * n % P)
+
+
+PSI_CX = f2inv_py(f2pow_py((1, 1), (P - 1) // 3))
+PSI_CY = f2inv_py(f2pow_py((1, 1), (P - 1) // 2))
+PSI2_CX = (PSI_CX[0] * PSI_CX[0] + PSI_CX[1] * PSI_CX[1]) % P
+
+
+def c2(p, c):
+    return (p.const(D392(c[0])), p.const(D392(c[1])))
+
+
+def pt_live_in(p, kind, base):
+    l = [p.live_in((kind, base + i)) for i in range(6)]
+    return [(l[0], l[1]), (l[2], l[3]), (l[4], l[5])]
+
+
+def pt_store_acc(p, pt, base=0):
+    for i, v in enumerate([x for c in pt for x in c]):
+        p.store(prog_norm(p, v), ("a", base + i))
+
+
+def pt_park(p, pt, slot):
+    for i, v in enumerate([x for c in pt for x in c]):
+        p.ops.append(("storep", [], [v], slot + i))
+
+
+def pt_psi(p, pt):
+    return [p.mul2(p.conj2(pt[0]), c2(p, PSI_CX)), p.mul2(p.conj2(pt[1]), c2(p, PSI_CY)), p.conj2(pt[2])]
+
+
+def pt_neg(p, pt):
+    return [pt[0], p.neg2(pt[1]), pt[2]]
+
+
+def prog_g2_add(ad_slot, negate):
+    """acc <- acc +- (the point in slots ad_slot..ad_slot+5); the old acc goes to AGPR blocks 6..11 for the doubling case; masks M_H0,
+    M_R0 (same x / same y), M_INF1, M_INF2 (an operand at infinity)"""
+    p = Prog()
+    A = pt_live_in(p, "a", 0)
+    Q = pt_live_in(p, "gd", ad_slot)
+    if negate:
+        Q = pt_neg(p, Q)
+    z1z1, z2z2 = p.sqr2(A[2]), p.sqr2(Q[2])
+    u1, u2 = p.mul2(A[0], z2z2), p.mul2(Q[0], z1z1)
+    s1 = p.mul2(p.mul2(A[1], Q[2]), z2z2)
+    s2 = p.mul2(p.mul2(Q[1], A[2]), z1z1)
+    h = p.sub2(u2, u1)
+    rr = p.dbl2(p.sub2(s2, s1))
+    p.iszero2(h, M_H0, G2M_TMP0); p.iszero2(rr, M_R0, G2M_TMP0)
+    p.iszero2(A[2], M_INF1, G2M_TMP0); p.iszero2(Q[2], M_INF2, G2M_TMP0)
+    i4 = p.sqr2(p.dbl2(h))
+    j, v = p.mul2(h, i4), p.mul2(u1, i4)
+    X3 = p.sub2(p.sub2(p.sqr2(rr), j), p.dbl2(v))
+    Y3 = p.sub2(p.mul2(rr, p.sub2(v, X3)), p.dbl2(p.mul2(s1, j)))
+    Z3 = p.mul2(p.sub2(p.sub2(p.sqr2(p.add2(A[2], Q[2])), z1z1), z2z2), h)
+    out = [p.sel2(M_INF1, o, q) for o, q in zip((X3, Y3, Z3), Q)]
+    out = [p.sel2(M_INF2, o, a) for o, a in zip(out, A)]
+    for i, v_ in enumerate([x for c in A for x in c]):
+        p.store(v_, ("a", 6 + i))
+    pt_store_acc(p, out)
+    return p
+
+
+# slots 0..12 hold the phases' results (sum of keys, signature, H) and 25..30 the n-pairing paths' G2 accumulator, which other kernels may be
+# writing or keeping meanwhile: the hash routine's scratch is 13..24 and 31..42, the signature routine's 43..48
+G2_SLOTS = dict(AD=13, P=31, T1=37, T2=19, T3=7, Q0=7, Q1=19, SIGAD=43, SIG=3, H=7)
+
+
+def prog_g2_glue(which):
+    """the point moves between the additions / ladders of the two routines (see g2_hash_tail_d_routine, g2_subgroup_d_routine)"""
+    p = Prog()
+    S = G2_SLOTS
+    acc = lambda: pt_live_in(p, "a", 0)
+    gd = lambda name: pt_live_in(p, "gd", S[name])
+    one = lambda: (p.const(ONE_D), p.const(0))
+    if which == "h_start":                           # acc = q0, AD = q1 (the map_to_curve outputs, 2^384 domain words)
+        q0 = [tuple(prog_reduce(p, x) for x in c) for c in pt_live_in(p, "g", S["Q0"])]
+        q1 = [tuple(prog_reduce(p, x) for x in c) for c in pt_live_in(p, "g", S["Q1"])]
+        pt_park(p, q1, S["AD"]); pt_store_acc(p, q0)
+    elif which == "h_base1":                         # p = q0 + q1: remember it, and it is the ladder's base
+        a = acc(); pt_park(p, a, S["P"]); pt_park(p, a, S["AD"]); pt_store_acc(p, a)
+    elif which == "h_after1":                        # t1 = -[|x|]p; t2 = psi(p); acc = p (to be doubled)
+        a = acc(); pt_park(p, pt_neg(p, a), S["T1"])
+        pp = gd("P")
+        pt_park(p, pt_psi(p, pp), S["T2"]); pt_store_acc(p, pp)
+    elif which == "h_psi2":                          # acc = psi^2(2p), AD = t2
+        a = acc()
+        pt_park(p, gd("T2"), S["AD"])
+        pt_store_acc(p, [p.mulfp2(a[0], p.const(D392(PSI2_CX))), p.neg2(a[1]), a[2]])
+    elif which == "h_t3":                            # t3 = acc; acc = t1, AD = t2
+        pt_park(p, acc(), S["T3"]); pt_park(p, gd("T2"), S["AD"]); pt_store_acc(p, gd("T1"))
+    elif which == "h_base2":                         # t1 + t2 is the second ladder's base
+        a = acc(); pt_park(p, a, S["AD"]); pt_store_acc(p, a)
+    elif which == "h_after2":                        # acc = -[|x|](t1 + t2), AD = t3
+        pt_park(p, gd("T3"), S["AD"]); pt_store_acc(p, pt_neg(p, acc()))
+    elif which == "h_ad_t1":
+        pt_park(p, gd("T1"), S["AD"]); pt_store_acc(p, acc())
+    elif which == "h_ad_p":
+        pt_park(p, gd("P"), S["AD"]); pt_store_acc(p, acc())
+    elif which == "s_start":                         # the decoded signature (affine x, y; 2^384 domain words): acc = AD = (x, y, 1)
+        l = [prog_reduce(p, p.live_in(("g", S["SIG"] + i))) for i in range(4)]
+        pt = [(l[0], l[1]), (l[2], l[3]), one()]
+        pt_park(p, pt, S["SIGAD"]); pt_store_acc(p, pt)
+    elif which == "s_compare":                       # g2_eq(psi(P), -acc) with P = (x, y, 1) -> mask M_H0
+        b = pt_neg(p, acc())
+        a = pt_psi(p, gd("SIGAD"))
+        za2, zb2 = p.sqr2(a[2]), p.sqr2(b[2])
+        p.iszero2(p.sub2(p.mul2(a[0], zb2), p.mul2(b[0], za2)), M_H0, G2M_TMP0)
+        p.iszero2(p.sub2(p.mul2(p.mul2(a[1], zb2), b[2]), p.mul2(p.mul2(b[1], za2), a[2])), M_R0, G2M_TMP0)
+        p.iszero2(a[2], M_INF1, G2M_TMP0); p.iszero2(b[2], M_INF2, G2M_TMP0)
+    else:
+        raise ValueError(which)
+    return p
+
+
+def build_g2(which, ad_slot=None):
+    if which in ("add", "sub"):
+        p = prog_g2_add(ad_slot, which == "sub")
+    elif which == "dbl":
+        p = prog_g2_dbl_d()
+    elif which == "fix":
+        p = prog_g2_dbl_d(6, 0)
+    else:
+        p = prog_g2_glue(which)
+    inb = {v: (G2_IN if l[0] == "a" else PACKED if l[0] == "gd" else G_IN) for v, l in p.init_loc.items()}
+    al = AllocD(p, inb, n_lds=11, lds_base=0, a_pool=list(range(NA)))
+    body = al.run()
+    for dst, B in getattr(al, "stored", {}).items():
+        assert B.vlo >= G2_IN.vlo and B.vhi <= G2_IN.vhi and B.dlo >= 0 and B.dhi <= M28, (which, dst, B)
+    return body, al.stats
+
+
+def call_sub(label):
+    """internal subroutine call: the return address (the instruction after the jump) in s[98:99]"""
+    return ["s_getpc_b64 s[98:99]", "7:", "s_add_u32 s98, s98, 8f-7b", "s_addc_u32 s99, s99, 0"] + far_fwd(label) + ["8:"]
+
+
+def g2_group_routine(kind):
+    """kind 'hash': in  q0 in workspace slots 7..12, q1 in 19..24 (Jacobian, 2^384 domain, canonical); out: clear_cofactor(q0 + q1) in
+    slots 7..12 (same form). kind 'sig': in  the signature's affine x, y in slots 3..6; out: v251 = 1 iff psi(P) = [x]P.
+    v252 / s[68:69] / s70: LDS column (11 spill slots) and workspace addressing as in the other routines."""
+    S = G2_SLOTS
+    ad = S["AD"] if kind == "hash" else S["SIGAD"]
+    B = {}
+    st = {}
+    names = ["add", "dbl", "fix"] + (["sub", "h_start", "h_base1", "h_after1", "h_psi2", "h_t3", "h_base2", "h_after2", "h_ad_t1", "h_ad_p"] if kind == "hash" else ["s_start", "s_compare"])
+    for nm in names:
+        B[nm], st[nm] = build_g2(nm, ad)
+    X = lambda nm: expand_calls_d(B[nm])
+    ADD, SUB, LADDER = 50, 51, 52
+    pro = ["s_mov_b64 s[80:81], s[30:31]", "s_waitcnt vmcnt(0)"] + shell_constants() + ["s_mov_b64 %s, exec" % EXEC_ALL]
+
+    def fixup():                                    # equal operands (same x, same y, neither at infinity): double the old acc on those lanes
+        return ["s_and_b64 s[92:93], %s, %s" % (M_H0, M_R0), "s_andn2_b64 s[92:93], s[92:93], %s" % M_INF1, "s_andn2_b64 s[92:93], s[92:93], %s" % M_INF2,
+                "s_and_b64 s[92:93], s[92:93], exec", "s_cbranch_scc1 3f"] + far_fwd(6) + ["3:", "s_mov_b64 exec, s[92:93]"] + X("fix") + ["6:", "s_mov_b64 exec, %s" % EXEC_ALL]
+    subs = ["%d:" % ADD] + X("add") + fixup() + ["s_setpc_b64 s[98:99]"]
+    if kind == "hash":
+        subs += ["%d:" % SUB] + X("sub") + fixup() + ["s_setpc_b64 s[98:99]"]
+    # [|x|] acc with the base in AD: runs of doublings, an addition of the base after each run but the last
+    lad = ["%d:" % LADDER, "s_mov_b32 s78, 0", "4:", "s_mov_b32 s39, %d" % RUNS[5]]
+    for ph in range(5):
+        lad += ["s_cmp_eq_u32 s78, %d" % ph, "s_cselect_b32 s39, %d, s39" % RUNS[ph]]
+    lad += [".p2align 6", "1:"] + X("dbl") + ["s_sub_u32 s39, s39, 1", "s_cmp_lg_u32 s39, 0", "s_cbranch_scc0 2f"] + far_back(1) + ["2:"]
+    lad += ["s_cmp_eq_u32 s78, 5", "s_cbranch_scc0 3f", "s_setpc_b64 s[96:97]", "3:"]
+    lad += call_sub(ADD) + ["s_add_u32 s78, s78, 1"] + far_back(4)
+
+    def call_ladder():
+        return ["s_getpc_b64 s[96:97]", "7:", "s_add_u32 s96, s96, 8f-7b", "s_addc_u32 s97, s97, 0"] + far_fwd(LADDER) + ["8:"]
+    if kind == "hash":
+        main = X("h_start") + call_sub(ADD) + X("h_base1") + call_ladder() + X("h_after1") + X("dbl") + X("h_psi2") + call_sub(SUB)
+        main += X("h_t3") + call_sub(ADD) + X("h_base2") + call_ladder() + X("h_after2") + call_sub(ADD)
+        main += X("h_ad_t1") + call_sub(SUB) + X("h_ad_p") + call_sub(SUB)
+        epi = ["s_waitcnt vmcnt(0)"]
+        B0, B1, B2, B5, B6 = (lambda j: "v%d" % j), (lambda j: "v%d" % (14 + j)), (lambda j: "v%d" % (28 + j)), (lambda j: "v%d" % (70 + j)), (lambda j: "v%d" % (84 + j))
+        epi += ["v_mov_b32_e32 %s, 0x%08x" % (B2(j), dgt) for j, dgt in enumerate(digits_of(K384))]
+        for i in range(3):
+            epi += ["v_accvgpr_read_b32 %s, a%d" % (B0(j), vb(2 * i) + j) for j in range(14)]
+            epi += ["v_accvgpr_read_b32 %s, a%d" % (B1(j), vb(2 * i + 1) + j) for j in range(14)]
+            epi += ["CALL mbls_fp2_mulfp_d_asm_fn"]
+            for h, Bk in ((0, B5), (1, B6)):
+                epi += seq_reduce(Bk) + seq_canonical(Bk) + seq_to32(Bk) + seq_gstore(Bk, S["H"] + 2 * i + h)
+    else:
+        main = X("s_start") + call_ladder() + X("s_compare")
+        # (ia & ib) | (!ia & !ib & ex & ey)
+        epi = ["s_and_b64 s[92:93], %s, %s" % (M_H0, M_R0), "s_andn2_b64 s[92:93], s[92:93], %s" % M_INF1, "s_andn2_b64 s[92:93], s[92:93], %s" % M_INF2,
+               "s_and_b64 %s, %s, %s" % (G2M_TMP0, M_INF1, M_INF2), "s_or_b64 s[92:93], s[92:93], %s" % G2M_TMP0, "v_cndmask_b32_e64 v251, 0, 1, s[92:93]"]
+    epi += ["s_waitcnt vmcnt(0)", "s_mov_b64 s[30:31], s[80:81]"]
+    ret = ["s_setpc_b64 s[30:31]"]                  # the routine's own return: the subroutines follow it
+    pieces = dict(B, pro=pro, epi=epi)
+    return pro + main + expand_calls_d(epi) + ret + lad + subs, pieces, st          # every internal call is a forward jump
 
 
 def main():
@@ -1883,6 +2099,13 @@ def main():
     sga = sgm.replace('"vcc"', '"s50","s51","s52","s53","s79","s80","s81","s82","s83","s84","s85","s86","s87","s88","s89","s90","s91","s92","s93","vcc"')
     txt += "#define MBLS_G1_AGG_D_ASM_CLOBBERS %s,%s, \\\n    %s\n" % (
         ",".join('"v%d"' % i for i in range(256) if i not in (248, 249, 250, 251, 252) and i not in UNTOUCHED_V), ",".join('"a%d"' % i for i in range(252)), sga)
+    for kind, macro in (("sig", "MBLS_G2_SUBGROUP_D_ASM"), ("hash", "MBLS_G2_HASH_TAIL_D_ASM")):
+        full, pieces, st = g2_group_routine(kind)
+        txt += emit(macro, full) + "\n"
+        print("g2 group routine", kind, len(full), "lines; add", len(pieces["add"]), st["add"])
+    sgg = sgm.replace('"vcc"', ",".join('"s%d"' % i for i in list(range(50, 54)) + list(range(79, 100))) + ',"vcc"')
+    txt += "#define MBLS_G2_GROUP_D_ASM_CLOBBERS %s,%s, \\\n    %s\n" % (
+        ",".join('"v%d"' % i for i in range(256) if i not in (251, 252) and i not in UNTOUCHED_V), ",".join('"a%d"' % i for i in range(252)), sgg)
     full, pieces, st = g2_dbl_d_routine()
     txt += emit("MBLS_G2_DBL_D_ASM", full) + "\n"
     print("g2_dbl_d", len(pieces["body"]), "lines", st)
