@@ -24,33 +24,46 @@ class Machine:
         self.scc = 0
 
     # ---- operand helpers
-    def rd(self, tok):
+    _TOK = {}                                        # operand text -> (kind, index / value): every distinct operand is parsed once
+
+    @classmethod
+    def _classify(cls, tok):
         tok = tok.strip()
         if tok == "vcc":
+            r = ("vcc", 0)
+        elif tok == "exec":                          # one lane, always active
+            r = ("imm", 1)
+        else:
+            m = re.fullmatch(r"([vsa])(\d+)", tok)
+            m2 = re.fullmatch(r"([vs])\[(\d+):(\d+)\]", tok)
+            if m:
+                r = (m.group(1), int(m.group(2)))
+            elif m2:
+                r = (m2.group(1) + "2", int(m2.group(2)))
+            elif tok.startswith("0x"):
+                r = ("imm", int(tok, 16))
+            elif "." in tok:                         # inline floating-point constant
+                r = ("imm", f32_bits(float(tok)))
+            else:
+                r = ("imm", int(tok) & M32)
+        cls._TOK[tok] = r
+        return r
+
+    def rd(self, tok):
+        k, i = self._TOK.get(tok) or self._classify(tok)
+        if k == "v":
+            return self.v[i]
+        if k == "imm":
+            return i
+        if k == "s":
+            return self.s[i]
+        if k == "a":
+            return self.a[i]
+        if k == "vcc":
             return self.vcc
-        if tok == "exec":                            # one lane, always active
-            return 1
-        m = re.fullmatch(r"v(\d+)", tok)
-        if m:
-            return self.v[int(m.group(1))]
-        m = re.fullmatch(r"s(\d+)", tok)
-        if m:
-            return self.s[int(m.group(1))]
-        m = re.fullmatch(r"a(\d+)", tok)
-        if m:
-            return self.a[int(m.group(1))]
-        m = re.fullmatch(r"s\[(\d+):(\d+)\]", tok)
-        if m:
-            return self.s.get(("pair", int(m.group(1))), 0)
-        m = re.fullmatch(r"v\[(\d+):(\d+)\]", tok)
-        if m:
-            lo = int(m.group(1))
-            return self.v[lo] | (self.v[lo + 1] << 32)
-        if tok.startswith("0x"):
-            return int(tok, 16)
-        if "." in tok:                               # inline floating-point constant
-            return f32_bits(float(tok))
-        return int(tok) & M32
+        if k == "s2":
+            return self.s.get(("pair", i), 0)
+        return self.v[i] | (self.v[i + 1] << 32)     # v2
 
     def wr_carry(self, tok, val):
         tok = tok.strip()
@@ -63,42 +76,41 @@ class Machine:
             self.s[("pair", int(m.group(1)))] = val
 
     def wr(self, tok, val):
-        tok = tok.strip()
-        m = re.fullmatch(r"v(\d+)", tok)
-        if m:
-            self.v[int(m.group(1))] = val & M32
-            return
-        m = re.fullmatch(r"a(\d+)", tok)
-        if m:
-            self.a[int(m.group(1))] = val & M32
-            return
-        m = re.fullmatch(r"s(\d+)", tok)
-        if m:
-            self.s[int(m.group(1))] = val & M32
-            return
-        m = re.fullmatch(r"v\[(\d+):(\d+)\]", tok)
-        if m:
-            lo = int(m.group(1))
-            assert lo % 2 == 0, "64-bit VGPR operands must be even-aligned: " + tok
-            self.v[lo] = val & M32
-            self.v[lo + 1] = (val >> 32) & M32
-            return
-        m = re.fullmatch(r"s\[(\d+):(\d+)\]", tok)
-        if m:
-            self.s[("pair", int(m.group(1)))] = val
-            return
-        raise ValueError("bad destination " + tok)
+        k, i = self._TOK.get(tok) or self._classify(tok)
+        if k == "v":
+            self.v[i] = val & M32
+        elif k == "a":
+            self.a[i] = val & M32
+        elif k == "s":
+            self.s[i] = val & M32
+        elif k == "v2":
+            assert i % 2 == 0, "64-bit VGPR operands must be even-aligned: " + tok
+            self.v[i] = val & M32
+            self.v[i + 1] = (val >> 32) & M32
+        elif k == "s2":
+            self.s[("pair", i)] = val
+        else:
+            raise ValueError("bad destination " + tok)
 
     # ---- execution
+    _LINES = {}                                      # instruction text -> (op, args, rest): parsed once
+
     def run(self, lines):
         pending_call = None
         for line in lines:
-            line = line.split("//")[0].strip()
-            if not line or line.startswith("."):      # assembler directives (.p2align)
+            parsed = self._LINES.get(line)
+            if parsed is None:
+                text = line.split("//")[0].strip()
+                if not text or text.startswith("."):  # assembler directives (.p2align)
+                    parsed = ()
+                else:
+                    op, _, rest = text.partition(" ")
+                    parsed = (op, [x.strip() for x in self._split(rest)], rest, text)
+                self._LINES[line] = parsed
+            if not parsed:
                 continue
+            op, args, rest, line = parsed
             self.count += 1
-            op, _, rest = line.partition(" ")
-            args = [x.strip() for x in self._split(rest)]
             if op == "CALL":                      # pseudo-instruction of the generator: s_getpc/s_add/s_addc/s_swappc to a routine
                 self.calls += 1
                 self.run(self.routines[args[0]])
