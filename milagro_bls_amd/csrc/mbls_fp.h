@@ -34,7 +34,7 @@
 // In the compiler-scheduled code (generic n-pair Miller loop, cold paths) Fp6/Fp12-level operations are inlined into the
 // functions that own the loops: their Fp6 temporaries then live in VGPRs/AGPRs instead of lane-private memory.
 // -DMBLS_OUTLINE_TOWER restores real functions on memory operands (smaller code, slower). The hot loops of the verification
-// path do not go through this code at all: they are generated routines (mbls_tower_asm.inc).
+// path do not go through this code at all: they are generated routines (mbls_towerd_asm.inc).
 #if !defined(MBLS_OUTLINE_TOWER)
 #define MBLS_INLINE_TOWER 1
 #endif

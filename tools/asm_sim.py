@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Single-lane interpreter for the small gfx950 instruction subset that tools/gen_fp_asm.py and tools/gen_tower_asm.py emit.
+"""Single-lane interpreter for the small gfx950 instruction subset that tools/gen_fp_asm.py, tools/gen_fpd_asm.py and tools/gen_tower_d.py emit.
 
 Development/test infrastructure only (tests/test_asm_sim_cpu.py): it lets the generated routines be checked against the
 big-integer model on the CPU before they ever run on a GPU. One lane is simulated, so VCC and the SGPR-pair carry registers
