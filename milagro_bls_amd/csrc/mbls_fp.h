@@ -347,11 +347,13 @@ MBLS_NOINLINE fp fp_pow_const(fp a, const uint32_t* e) {
 }
 #if MBLS_DEVICE_ASM
 // The two exponentiations of the hot path (square roots: (p-3)/4, inversion: p-2) as generated routines that work on 14
-// unsaturated 28-bit digits from start to end (tools/gen_fp_asm.py, pow_body): no conversions or carries between the ~480
-// dependent multiplications, squarings with half the cross products; the 4-bit-window table lives in AGPRs.
+// unsaturated 28-bit digits from start to end (tools/gen_fp_asm.py, pow_body): no conversions or carries between the ~460
+// dependent multiplications (sliding 5-bit windows: ~378 squarings + ~82 products), squarings with half the cross products; the
+// table of the 16 odd powers lives in AGPRs and the running value ping-pongs between two register groups.
 extern "C" __device__ __attribute__((noinline, used, aligned(64))) void mbls_pow_sqr_xy_asm_fn() { asm volatile(MBLS_POW_SQR_XY_ASM); }
 extern "C" __device__ __attribute__((noinline, used, aligned(64))) void mbls_pow_sqr_yx_asm_fn() { asm volatile(MBLS_POW_SQR_YX_ASM); }
-extern "C" __device__ __attribute__((noinline, used, aligned(64))) void mbls_pow_mul_xb_asm_fn() { asm volatile(MBLS_POW_MUL_XB_ASM); }
+extern "C" __device__ __attribute__((noinline, used, aligned(64))) void mbls_pow_mul_xb_y_asm_fn() { asm volatile(MBLS_POW_MUL_XB_Y_ASM); }
+extern "C" __device__ __attribute__((noinline, used, aligned(64))) void mbls_pow_mul_yb_x_asm_fn() { asm volatile(MBLS_POW_MUL_YB_X_ASM); }
 extern "C" __device__ __attribute__((noinline, used, aligned(64))) void mbls_fp_pow_pm3d4_asm_fn() { asm volatile(MBLS_FP_POW_PM3D4_ASM); }
 extern "C" __device__ __attribute__((noinline, used, aligned(64))) void mbls_fp_pow_pm2_asm_fn() { asm volatile(MBLS_FP_POW_PM2_ASM); }
 MBLS_FN fp fp_inv(fp a) {                                                          // 0 -> 0

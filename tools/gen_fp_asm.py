@@ -333,43 +333,80 @@ R384_DIGITS = [(((1 << 384) % P) >> (28 * i)) & M28 for i in range(14)]
 
 
 def pow_subroutines():
-    """the four leaf routines of an exponentiation: X -> Y squaring, Y -> X squaring, X <- X * B (through Y)"""
+    """the four leaf routines of an exponentiation: the value ping-pongs between X and Y (a squaring or a product by the table
+    entry B reads one and writes the other, so nothing is ever moved)"""
     return {
         "mbls_pow_sqr_xy_asm_fn": [".p2align 6"] + sqr_digits(POW_X, POW_D, POW_Y, POW_ACC, POW_ACC2),
         "mbls_pow_sqr_yx_asm_fn": [".p2align 6"] + sqr_digits(POW_Y, POW_D, POW_X, POW_ACC, POW_ACC2),
-        "mbls_pow_mul_xb_asm_fn": [".p2align 6"] + mul_digits(POW_X, POW_B, POW_Y, POW_ACC, POW_ACC2) +
-                                  ["v_mov_b32_e64 %s, %s" % (POW_X(j), POW_Y(j)) for j in range(14)],
+        "mbls_pow_mul_xb_y_asm_fn": [".p2align 6"] + mul_digits(POW_X, POW_B, POW_Y, POW_ACC, POW_ACC2),
+        "mbls_pow_mul_yb_x_asm_fn": [".p2align 6"] + mul_digits(POW_Y, POW_B, POW_X, POW_ACC, POW_ACC2),
     }
 
 
+POW_WINDOW = 5                     # sliding window: the odd powers a^1 .. a^31 in a0..a223
+
+
+def pow_schedule(e, w=POW_WINDOW):
+    """left-to-right sliding-window schedule of a^e: a list of ('sqr', n) and ('mul', odd value); the first entry is ('load', v)"""
+    bits = bin(e)[2:]
+    ops, i = [], 0
+    while i < len(bits):
+        if bits[i] == "0":
+            ops.append(("sqr", 1)); i += 1
+            continue
+        j = min(i + w, len(bits))
+        while bits[j - 1] == "0":
+            j -= 1
+        v = int(bits[i:j], 2)
+        ops.append(("load", v) if not ops else ("win", j - i, v))
+        i = j
+    out = []
+    for op in ops:                                     # merge runs of squarings
+        if op[0] == "win":
+            out += [("sqr", op[1]), ("mul", op[2])]
+        else:
+            out.append(op)
+    merged = []
+    for op in out:
+        if op[0] == "sqr" and merged and merged[-1][0] == "sqr":
+            merged[-1] = ("sqr", merged[-1][1] + op[1])
+        else:
+            merged.append(op)
+    return merged
+
+
 def pow_body(e):
-    """a^e for a in v[0:11] (Montgomery form, R = 2^384), result in v[0:11]; fixed 4-bit windows, the table a^1..a^15 in
-    a0..a209 as digit vectors. Pseudo-instruction CALL name = s_getpc/s_add/s_addc/s_swappc."""
-    nibs = [(e >> (4 * w)) & 15 for w in range(96)]
+    """a^e for a in v[0:11] (Montgomery form, R = 2^384), result in v[0:11]; sliding 5-bit windows over the odd powers a, a^3, ..
+    a^31 kept in a0..a223 as digit vectors. Pseudo-instruction CALL name = s_getpc/s_add/s_addc/s_swappc."""
     L = ["s_mov_b64 s[36:37], s[30:31]"] + load_modulus28()
     L += conv28(VR(60), VR(0), True)                              # digits of a * 2^8: the value in the 2^392 domain
     L += ["v_mov_b32_e64 %s, %s" % (POW_X(j), "v%d" % (60 + j)) for j in range(14)]
-    tab = lambda n, j: "a%d" % (14 * (n - 1) + j)
+    tab = lambda n, j: "a%d" % (14 * ((n - 1) // 2) + j)
+    REG = {"X": POW_X, "Y": POW_Y}
+    other = {"X": "Y", "Y": "X"}
+    sqr = {"X": "CALL mbls_pow_sqr_xy_asm_fn", "Y": "CALL mbls_pow_sqr_yx_asm_fn"}
+    mul = {"X": "CALL mbls_pow_mul_xb_y_asm_fn", "Y": "CALL mbls_pow_mul_yb_x_asm_fn"}
     L += ["v_accvgpr_write_b32 %s, %s" % (tab(1, j), POW_X(j)) for j in range(14)]
-    L += ["v_mov_b32_e64 %s, %s" % (POW_B(j), POW_X(j)) for j in range(14)]
-    for n in range(2, 16):                                        # a^n = a^(n-1) * a
-        L.append("CALL mbls_pow_mul_xb_asm_fn")
-        L += ["v_accvgpr_write_b32 %s, %s" % (tab(n, j), POW_X(j)) for j in range(14)]
-    started = False
-    for w in range(95, -1, -1):
-        if started:
-            L += ["CALL mbls_pow_sqr_xy_asm_fn", "CALL mbls_pow_sqr_yx_asm_fn"] * 2
-        if nibs[w]:
-            if started:
-                L += ["v_accvgpr_read_b32 %s, %s" % (POW_B(j), tab(nibs[w], j)) for j in range(14)]
-                L.append("CALL mbls_pow_mul_xb_asm_fn")
-            else:
-                L += ["v_accvgpr_read_b32 %s, %s" % (POW_X(j), tab(nibs[w], j)) for j in range(14)]
-                started = True
-    # leave the 2^392 domain: X * (2^384 mod p) / 2^392, then 12 x 32-bit words and the final conditional subtraction
+    L.append(sqr["X"])                                            # a^2 -> Y -> B; the odd powers by repeated products with it
+    L += ["v_mov_b32_e64 %s, %s" % (POW_B(j), POW_Y(j)) for j in range(14)]
+    loc = "X"
+    for n in range(3, 1 << POW_WINDOW, 2):
+        L.append(mul[loc]); loc = other[loc]
+        L += ["v_accvgpr_write_b32 %s, %s" % (tab(n, j), REG[loc](j)) for j in range(14)]
+    for op in pow_schedule(e):
+        if op[0] == "load":
+            loc = "X"
+            L += ["v_accvgpr_read_b32 %s, %s" % (POW_X(j), tab(op[1], j)) for j in range(14)]
+        elif op[0] == "sqr":
+            for _ in range(op[1]):
+                L.append(sqr[loc]); loc = other[loc]
+        else:
+            L += ["v_accvgpr_read_b32 %s, %s" % (POW_B(j), tab(op[1], j)) for j in range(14)]
+            L.append(mul[loc]); loc = other[loc]
+    # leave the 2^392 domain: value * (2^384 mod p) / 2^392, then 12 x 32-bit words and the final conditional subtraction
     L += ["v_mov_b32_e32 %s, 0x%08x" % (POW_B(j), R384_DIGITS[j]) for j in range(14)]
-    L.append("CALL mbls_pow_mul_xb_asm_fn")
-    L += to32(VR(60), POW_X)
+    L.append(mul[loc]); loc = other[loc]
+    L += to32(VR(60), REG[loc])
     L += cond_sub32(VR(60), VR(72), "v84")
     L += ["v_mov_b32_e64 v%d, v%d" % (j, 60 + j) for j in range(12)]
     L.append("s_mov_b64 s[30:31], s[36:37]")
@@ -439,7 +476,7 @@ def main():
         txt += emit("MBLS_" + sym.upper()[5:-7] + "_ASM", body) + "\n"
     txt += emit("MBLS_FP_POW_PM3D4_ASM", expand_pow_calls(pow_body(EXP_PM3D4))) + "\n"
     txt += emit("MBLS_FP_POW_PM2_ASM", expand_pow_calls(pow_body(EXP_PM2))) + "\n"
-    txt += "#define MBLS_FP_POW_CLOBBERS %s,%s, \\\n" % (vl(12, 84), ",".join('"a%d"' % i for i in range(210)))
+    txt += "#define MBLS_FP_POW_CLOBBERS %s,%s, \\\n" % (vl(12, 84), ",".join('"a%d"' % i for i in range(224)))
     txt += '    "s30","s31","s36","s37","s66","s67", %s\n' % sg
     with open(path, "w") as f:
         f.write(txt)

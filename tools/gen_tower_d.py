@@ -893,7 +893,7 @@ class AllocD:
         self.e("v_cmp_eq_u32_e64 %s, 0, %s" % (mask, TMP))
         self.stats["arith"] += 8
 
-    INV_CLOB_V, INV_CLOB_A = range(0, 7), range(0, 15)       # mbls_fp_pow_pm2_asm_fn: v0..v84, a0..a209 (the 15-entry window table)
+    INV_CLOB_V, INV_CLOB_A = range(0, 7), range(0, 16)       # mbls_fp_pow_pm2_asm_fn: v0..v84, a0..a223 (the 16-entry window table)
 
     def do_inv(self, k, d, a):
         """a: reduced value x * 2^384 (digit form) -> canonical words in v0..v11 -> the exponentiation routine -> words of x^-1 * 2^384,
