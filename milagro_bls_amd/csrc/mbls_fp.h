@@ -355,9 +355,11 @@ extern "C" __device__ __attribute__((noinline, used, aligned(64))) void mbls_pow
 extern "C" __device__ __attribute__((noinline, used, aligned(64))) void mbls_pow_mul_xb_y_asm_fn() { asm volatile(MBLS_POW_MUL_XB_Y_ASM); }
 extern "C" __device__ __attribute__((noinline, used, aligned(64))) void mbls_pow_mul_yb_x_asm_fn() { asm volatile(MBLS_POW_MUL_YB_X_ASM); }
 extern "C" __device__ __attribute__((noinline, used, aligned(64))) void mbls_fp_pow_pm3d4_asm_fn() { asm volatile(MBLS_FP_POW_PM3D4_ASM); }
-extern "C" __device__ __attribute__((noinline, used, aligned(64))) void mbls_fp_pow_pm2_asm_fn() { asm volatile(MBLS_FP_POW_PM2_ASM); }
+// The inversion is not an exponentiation: Bernstein-Yang safegcd divsteps on 13 signed 30-bit limbs (tools/gen_fp_asm.py,
+// fp_inv_gcd_body), the same 900 divsteps for every operand, ~30 k instructions instead of ~190 k for a^(p-2).
+extern "C" __device__ __attribute__((noinline, used, aligned(64))) void mbls_fp_inv_gcd_asm_fn() { asm volatile(MBLS_FP_INV_GCD_ASM); }
 MBLS_FN fp fp_inv(fp a) {                                                          // 0 -> 0
-    asm volatile(MBLS_ASM_CALL("mbls_fp_pow_pm2_asm_fn") : "+{v[0:11]}"(a) : : MBLS_FP_POW_CLOBBERS);
+    asm volatile(MBLS_ASM_CALL("mbls_fp_inv_gcd_asm_fn") : "+{v[0:11]}"(a) : : MBLS_FP_INV_GCD_CLOBBERS, "s30", "s31");
     return a;
 }
 // w = a^((p-3)/4): sqrt candidate = w*a, 1/a = chi * w^2 with chi = (w*a)^2 / a = +-1

@@ -96,6 +96,7 @@ def test_generated_files_up_to_date():
 
 @pytest.mark.parametrize("which", ["pm3d4", "pm2"])
 def test_fp_pow_routines(which):
+    """sliding-window exponentiations: (p-3)/4 is the one the kernels use (square roots); p-2 exercises another bit pattern"""
     e = g.EXP_PM3D4 if which == "pm3d4" else g.EXP_PM2
     body = g.pow_body(e)
     subs = g.pow_subroutines()
@@ -107,3 +108,34 @@ def test_fp_pow_routines(which):
         m.v[0:12] = limbs(am)
         m.run(body)
         assert from_limbs(m.v[0:12]) == pow(a, e, P) * R % P, (which, a)
+
+
+def test_fp_inversion_by_divsteps():
+    """the safegcd inversion routine (flat form of its two loops) against a^(p-2), operands at the edges included; and its pieces
+    against the limb-level model of the same algorithm in plain Python (transition matrix of one round, state after the round)"""
+    body = g.fp_inv_gcd_body(unrolled=True)
+    rng = random.Random(43)
+    R = 1 << 384
+    for a in [0, 1, 2, P - 1, P - 2, (P + 1) // 2] + [rng.randrange(P) for _ in range(6)]:
+        m = Machine()
+        m.v[0:12] = limbs(a * R % P)
+        m.run(body)
+        assert from_limbs(m.v[0:12]) == pow(a, P - 2, P) * R % P, a
+    # one round in isolation: f, g must stay exact multiples (u f + v g) / 2^30 and d, e congruent modulo p
+    pc = g.fp_inv_gcd_pieces()
+    val = lambda regs: sum((x - (1 << 32) if x >> 31 else x) << (30 * i) for i, x in enumerate(regs))
+    for trial in range(4):
+        x = rng.randrange(P)
+        m = Machine(); m.v[0:12] = limbs(x); m.run(pc["pro"])
+        for rounds in range(3):
+            f0, g0, d0, e0 = val(m.v[12:25]), val(m.v[25:38]), val(m.v[38:51]), val(m.v[51:64])
+            m.run(pc["head"])
+            for _ in range(30):
+                m.run(pc["step"])
+            s32 = lambda v: v - (1 << 32) if v >> 31 else v
+            u, v_, q, r = (s32(m.v[i]) for i in range(4))
+            m.run(pc["tail"])
+            f1, g1, d1, e1 = val(m.v[12:25]), val(m.v[25:38]), val(m.v[38:51]), val(m.v[51:64])
+            assert (f1 << 30) == u * f0 + v_ * g0 and (g1 << 30) == q * f0 + r * g0
+            assert (d1 * (1 << 30) - (u * d0 + v_ * e0)) % P == 0 and (e1 * (1 << 30) - (q * d0 + r * e0)) % P == 0
+            assert -2 * P < d1 < P and -2 * P < e1 < P

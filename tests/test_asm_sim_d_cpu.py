@@ -385,11 +385,10 @@ def test_miller_loop_routine_full_schedule():
 
 
 # ---------------------------------------------------------------------------------------------- the final exponentiation routine
-import gen_fp_asm as g1          # noqa: E402  (the fixed-exponent inversion the easy part calls)
+import gen_fp_asm as g1          # noqa: E402  (the inversion routine the easy part calls)
 
 FEXP_ROUT = dict(ROUT)
-FEXP_ROUT.update(g1.pow_subroutines())
-FEXP_ROUT["mbls_fp_pow_pm2_asm_fn"] = g1.pow_body(g1.EXP_PM2)
+FEXP_ROUT["mbls_fp_inv_gcd_asm_fn"] = g1.fp_inv_gcd_body(unrolled=True)
 
 
 def fexp_sim(runs, seed, f=None):

@@ -163,6 +163,11 @@ class Machine:
                 self.wr(args[0], self.rd(args[1]) * self.rd(args[2]))
             elif op in ("v_cndmask_b32_e32", "v_cndmask_b32_e64"):
                 self.wr(args[0], self.rd(args[2]) if self.rd(args[3]) else self.rd(args[1]))
+            elif op == "v_bfe_i32":
+                w = self.rd(args[3]); t = (self.rd(args[1]) >> self.rd(args[2])) & ((1 << w) - 1)
+                self.wr(args[0], t - (1 << w) if t >> (w - 1) else t)
+            elif op in ("v_xor_b32_e32", "v_xor_b32_e64"):
+                self.wr(args[0], self.rd(args[1]) ^ self.rd(args[2]))
             elif op == "v_bfe_u32":
                 self.wr(args[0], (self.rd(args[1]) >> self.rd(args[2])) & ((1 << self.rd(args[3])) - 1))
             elif op in ("v_and_b32_e32", "v_and_b32_e64"):

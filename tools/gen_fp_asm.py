@@ -446,6 +446,142 @@ def fp_mulpair_body():
     return L
 
 
+# ----------------------------------------------------------------------------------------------------------------------
+# Fp inversion by the Bernstein-Yang "safegcd" divsteps (the constant-time variant with delta starting at 1/2, as published for
+# secp256k1's modinv32): 30 rounds of 30 divsteps on the low words of f and g give a 2x2 transition matrix each, which is then
+# applied to the full f, g (13 signed 30-bit limbs) and, modulo p, to d, e. 900 >= floor((45907 * 381 + 26313) / 19929) = 878
+# divsteps end with g = 0, f = +-gcd and d = +-(e0 / x). Starting e at 2^768 mod p turns x R into x^-1 R without a final product.
+# About 30 k instructions against 190 k for a^(p-2); every lane does the same work whatever its operand (0 -> 0).
+GCD_N, GCD_ROUNDS = 13, 30
+M30 = (1 << 30) - 1
+GF, GG, GD, GE, GM = VR(12), VR(25), VR(38), VR(51), VR(64)          # f, g, d, e, modulus: 13 limbs each
+G_U, G_V, G_Q, G_R, G_ZETA, G_FW, G_GW, G_C1, G_C2, G_X, G_Y, G_Z = ["v%d" % i for i in range(12)]
+G_MD, G_ME, G_T, G_T2 = "v77", "v78", "v79", "v84"
+G_CD, G_CE = "v[80:81]", "v[82:83]"
+G_INV30 = "s66"
+
+
+def limbs30(x):
+    return [(x >> (30 * i)) & M30 for i in range(GCD_N - 1)] + [x >> (30 * (GCD_N - 1))]
+
+
+def gcd_prologue():
+    """x (12 words, v0..v11) -> g; f = p; d = 0; e = 2^768 mod p; zeta = -1"""
+    L = ["s_mov_b32 %s, 0x%08x" % (G_INV30, pow(P, -1, 1 << 30))]
+    for i in range(GCD_N):                                          # limb i = bits [30 i, 30 i + 30)
+        o = 30 * i
+        q, r = o >> 5, o & 31
+        if q >= 12:
+            L.append("v_mov_b32_e32 %s, 0" % GG(i))
+        elif q == 11 or r + 30 <= 32:
+            L.append("v_bfe_u32 %s, v%d, %d, 30" % (GG(i), q, r) if r + 30 <= 32 else "v_lshrrev_b32_e64 %s, %d, v%d" % (GG(i), r, q))
+        else:
+            L += ["v_alignbit_b32 %s, v%d, v%d, %d" % (GG(i), q + 1, q, r), "v_and_b32_e32 %s, 0x%08x, %s" % (GG(i), M30, GG(i))]
+    for i, (m, e) in enumerate(zip(limbs30(P), limbs30(pow(2, 768, P)))):
+        L += ["v_mov_b32_e32 %s, 0x%08x" % (GM(i), m), "v_mov_b32_e32 %s, 0x%08x" % (GF(i), m),
+              "v_mov_b32_e32 %s, 0" % GD(i), "v_mov_b32_e32 %s, 0x%08x" % (GE(i), e)]
+    L.append("v_mov_b32_e32 %s, -1" % G_ZETA)
+    return L
+
+
+def gcd_round_head():
+    return ["v_lshl_or_b32 %s, %s, 30, %s" % (G_FW, GF(1), GF(0)), "v_lshl_or_b32 %s, %s, 30, %s" % (G_GW, GG(1), GG(0)),
+            "v_mov_b32_e32 %s, 1" % G_U, "v_mov_b32_e32 %s, 0" % G_V, "v_mov_b32_e32 %s, 0" % G_Q, "v_mov_b32_e32 %s, 1" % G_R]
+
+
+def gcd_divstep():
+    L = ["v_ashrrev_i32_e64 %s, 31, %s" % (G_C1, G_ZETA), "v_bfe_i32 %s, %s, 0, 1" % (G_C2, G_GW)]       # zeta < 0; g odd (all-ones masks)
+    for dst, src in ((G_X, G_FW), (G_Y, G_U), (G_Z, G_V)):                                               # conditionally negated f, u, v
+        L += ["v_xor_b32_e64 %s, %s, %s" % (dst, src, G_C1), "v_sub_u32_e64 %s, %s, %s" % (dst, dst, G_C1)]
+    for acc, src in ((G_GW, G_X), (G_Q, G_Y), (G_R, G_Z)):                                               # g, q, r += those, if g is odd
+        L += ["v_and_b32_e64 %s, %s, %s" % (G_T, src, G_C2), "v_add_u32_e64 %s, %s, %s" % (acc, acc, G_T)]
+    L += ["v_and_b32_e64 %s, %s, %s" % (G_C1, G_C1, G_C2),
+          "v_xor_b32_e64 %s, %s, %s" % (G_ZETA, G_ZETA, G_C1), "v_add_u32_e64 %s, -1, %s" % (G_ZETA, G_ZETA)]
+    for acc, src in ((G_FW, G_GW), (G_U, G_Q), (G_V, G_R)):                                              # f, u, v += g, q, r on a swap
+        L += ["v_and_b32_e64 %s, %s, %s" % (G_T, src, G_C1), "v_add_u32_e64 %s, %s, %s" % (acc, acc, G_T)]
+    L += ["v_lshrrev_b32_e64 %s, 1, %s" % (G_GW, G_GW), "v_lshlrev_b32_e64 %s, 1, %s" % (G_U, G_U), "v_lshlrev_b32_e64 %s, 1, %s" % (G_V, G_V)]
+    return L
+
+
+def gcd_round_tail():
+    """apply the matrix (u v; q r) / 2^30 to (d, e) modulo p and to (f, g) exactly"""
+    mad = lambda acc, a, b, first=False: "v_mad_i64_i32 %s, vcc, %s, %s, %s" % (acc, a, b, "0" if first else acc)
+    lo = lambda pair: "v%s" % pair[2:pair.index(":")]
+    L = ["v_ashrrev_i32_e64 %s, 31, %s" % (G_T, GD(12)), "v_ashrrev_i32_e64 %s, 31, %s" % (G_T2, GE(12))]
+    L += ["v_and_b32_e64 %s, %s, %s" % (G_MD, G_U, G_T), "v_and_b32_e64 %s, %s, %s" % (G_C1, G_V, G_T2), "v_add_u32_e64 %s, %s, %s" % (G_MD, G_MD, G_C1),
+          "v_and_b32_e64 %s, %s, %s" % (G_ME, G_Q, G_T), "v_and_b32_e64 %s, %s, %s" % (G_C1, G_R, G_T2), "v_add_u32_e64 %s, %s, %s" % (G_ME, G_ME, G_C1)]
+    L += [mad(G_CD, G_U, GD(0), True), mad(G_CD, G_V, GE(0)), mad(G_CE, G_Q, GD(0), True), mad(G_CE, G_R, GE(0))]
+    for m, c in ((G_MD, G_CD), (G_ME, G_CE)):                       # the multiple of p that makes the low 30 bits vanish
+        L += ["v_mul_lo_u32 %s, %s, %s" % (G_T, lo(c), G_INV30), "v_add_u32_e64 %s, %s, %s" % (G_T, G_T, m),
+              "v_and_b32_e32 %s, 0x%08x, %s" % (G_T, M30, G_T), "v_sub_u32_e64 %s, %s, %s" % (m, m, G_T)]
+    L += [mad(G_CD, GM(0), G_MD), mad(G_CE, GM(0), G_ME), "v_ashrrev_i64 %s, 30, %s" % (G_CD, G_CD), "v_ashrrev_i64 %s, 30, %s" % (G_CE, G_CE)]
+    for i in range(1, GCD_N):
+        L += [mad(G_CD, G_U, GD(i)), mad(G_CE, G_Q, GD(i)), mad(G_CD, G_V, GE(i)), mad(G_CE, G_R, GE(i)), mad(G_CD, GM(i), G_MD), mad(G_CE, GM(i), G_ME)]
+        L += ["v_and_b32_e32 %s, 0x%08x, %s" % (GD(i - 1), M30, lo(G_CD)), "v_and_b32_e32 %s, 0x%08x, %s" % (GE(i - 1), M30, lo(G_CE)),
+              "v_ashrrev_i64 %s, 30, %s" % (G_CD, G_CD), "v_ashrrev_i64 %s, 30, %s" % (G_CE, G_CE)]
+    L += ["v_mov_b32_e32 %s, %s" % (GD(12), lo(G_CD)), "v_mov_b32_e32 %s, %s" % (GE(12), lo(G_CE))]
+    L += [mad(G_CD, G_U, GF(0), True), mad(G_CE, G_Q, GF(0), True), mad(G_CD, G_V, GG(0)), mad(G_CE, G_R, GG(0)),
+          "v_ashrrev_i64 %s, 30, %s" % (G_CD, G_CD), "v_ashrrev_i64 %s, 30, %s" % (G_CE, G_CE)]
+    for i in range(1, GCD_N):
+        L += [mad(G_CD, G_U, GF(i)), mad(G_CE, G_Q, GF(i)), mad(G_CD, G_V, GG(i)), mad(G_CE, G_R, GG(i))]
+        L += ["v_and_b32_e32 %s, 0x%08x, %s" % (GF(i - 1), M30, lo(G_CD)), "v_and_b32_e32 %s, 0x%08x, %s" % (GG(i - 1), M30, lo(G_CE)),
+              "v_ashrrev_i64 %s, 30, %s" % (G_CD, G_CD), "v_ashrrev_i64 %s, 30, %s" % (G_CE, G_CE)]
+    L += ["v_mov_b32_e32 %s, %s" % (GF(12), lo(G_CD)), "v_mov_b32_e32 %s, %s" % (GG(12), lo(G_CE))]
+    return L
+
+
+def gcd_epilogue():
+    """d, with the sign of f, into [0, p) -> 12 words in v0..v11"""
+    L = []
+
+    def cond_add_p():
+        S = ["v_ashrrev_i32_e64 %s, 31, %s" % (G_T, GD(12))]
+        for i in range(GCD_N):
+            S += ["v_and_b32_e64 %s, %s, %s" % (G_T2, GM(i), G_T), "v_add_u32_e64 %s, %s, %s" % (GD(i), GD(i), G_T2)]
+        return S
+
+    def carries():
+        S = []
+        for i in range(GCD_N - 1):
+            S += ["v_ashrrev_i32_e64 %s, 30, %s" % (G_T2, GD(i)), "v_add_u32_e64 %s, %s, %s" % (GD(i + 1), GD(i + 1), G_T2),
+                  "v_and_b32_e32 %s, 0x%08x, %s" % (GD(i), M30, GD(i))]
+        return S
+    L += cond_add_p()
+    L.append("v_ashrrev_i32_e64 %s, 31, %s" % (G_T, GF(12)))
+    for i in range(GCD_N):
+        L += ["v_xor_b32_e64 %s, %s, %s" % (GD(i), GD(i), G_T), "v_sub_u32_e64 %s, %s, %s" % (GD(i), GD(i), G_T)]
+    L += carries() + cond_add_p() + carries()
+    for q in range(12):                                             # word q = bits [32 q, 32 q + 32)
+        j, off = (32 * q) // 30, (32 * q) % 30
+        if off == 0:
+            L.append("v_lshl_or_b32 v%d, %s, 30, %s" % (q, GD(j + 1), GD(j)))
+        else:
+            L.append("v_lshrrev_b32_e64 v%d, %d, %s" % (q, off, GD(j)))
+            L.append("v_lshl_or_b32 v%d, %s, %d, v%d" % (q, GD(j + 1), 30 - off, q))
+            if 60 - off < 32:
+                L.append("v_lshl_or_b32 v%d, %s, %d, v%d" % (q, GD(j + 2), 60 - off, q))
+    return L
+
+
+def fp_inv_gcd_pieces():
+    return dict(pro=gcd_prologue(), head=gcd_round_head(), step=gcd_divstep(), tail=gcd_round_tail(), epi=gcd_epilogue())
+
+
+def fp_inv_gcd_body(unrolled=False):
+    """1 / a for a in v[0:11] (Montgomery form, R = 2^384, canonical; 0 -> 0), result in v[0:11]. Overwrites v12..v84, vcc, s66, s76,
+    s77. unrolled: the flat instruction list (for the simulator); otherwise two counted loops."""
+    pc = fp_inv_gcd_pieces()
+    if unrolled:
+        L = list(pc["pro"])
+        for _ in range(GCD_ROUNDS):
+            L += pc["head"] + pc["step"] * 30 + pc["tail"]
+        return L + pc["epi"]
+    L = pc["pro"] + ["s_mov_b32 s76, %d" % GCD_ROUNDS, ".p2align 6", "1:"] + pc["head"] + ["s_mov_b32 s77, 30", "2:"] + pc["step"]
+    L += ["s_sub_u32 s77, s77, 1", "s_cmp_lg_u32 s77, 0", "s_cbranch_scc1 2b"] + pc["tail"]
+    L += ["s_sub_u32 s76, s76, 1", "s_cmp_lg_u32 s76, 0", "s_cbranch_scc1 1b"] + pc["epi"]
+    return L
+
+
 def emit(name, lines):
     out = ["#define %s \\" % name]
     for l in lines:
@@ -475,7 +611,8 @@ def main():
     for sym, body in pow_subroutines().items():
         txt += emit("MBLS_" + sym.upper()[5:-7] + "_ASM", body) + "\n"
     txt += emit("MBLS_FP_POW_PM3D4_ASM", expand_pow_calls(pow_body(EXP_PM3D4))) + "\n"
-    txt += emit("MBLS_FP_POW_PM2_ASM", expand_pow_calls(pow_body(EXP_PM2))) + "\n"
+    txt += emit("MBLS_FP_INV_GCD_ASM", fp_inv_gcd_body()) + "\n"
+    txt += "#define MBLS_FP_INV_GCD_CLOBBERS %s, \"s66\",\"s76\",\"s77\",\"vcc\",\"scc\"\n" % vl(12, 84)
     txt += "#define MBLS_FP_POW_CLOBBERS %s,%s, \\\n" % (vl(12, 84), ",".join('"a%d"' % i for i in range(224)))
     txt += '    "s30","s31","s36","s37","s66","s67", %s\n' % sg
     with open(path, "w") as f:

@@ -163,9 +163,9 @@ class Prog:
         d = self.new(); self.ops.append(("neg", [d], [a], None)); return d
 
     def inv(self, a):
-        """1 / a by the fixed-exponent routine of tools/gen_fp_asm.py (a^(p-2): 0 -> 0). That routine works on 12 canonical words of the
-        2^384 domain: a * (2^384 mod p) is such a value in digit form, and the words it returns, cut as digits of words * 2^8, are the
-        inverse in the 2^392 domain again."""
+        """1 / a by the inversion routine of tools/gen_fp_asm.py (safegcd divsteps; 0 -> 0). That routine works on 12 canonical words of
+        the 2^384 domain: a * (2^384 mod p) is such a value in digit form, and the words it returns, cut as digits of words * 2^8, are
+        the inverse in the 2^392 domain again."""
         w = self.mulfp2((a, self.const(0)), self.const(K384))[0]
         r = self.new(); self.ops.append(("reduce", [r], [w], None))
         d = self.new(); self.ops.append(("inv", [d], [r], None)); return d
@@ -893,10 +893,10 @@ class AllocD:
         self.e("v_cmp_eq_u32_e64 %s, 0, %s" % (mask, TMP))
         self.stats["arith"] += 8
 
-    INV_CLOB_V, INV_CLOB_A = range(0, 7), range(0, 16)       # mbls_fp_pow_pm2_asm_fn: v0..v84, a0..a223 (the 16-entry window table)
+    INV_CLOB_V, INV_CLOB_A = range(0, 7), range(0, 0)        # mbls_fp_inv_gcd_asm_fn: v0..v84, no AGPRs
 
     def do_inv(self, k, d, a):
-        """a: reduced value x * 2^384 (digit form) -> canonical words in v0..v11 -> the exponentiation routine -> words of x^-1 * 2^384,
+        """a: reduced value x * 2^384 (digit form) -> canonical words in v0..v11 -> the inversion routine -> words of x^-1 * 2^384,
         cut into digits of the 2^392 domain. Everything live leaves the registers that routine uses."""
         b = self.to_vgpr(a, k)
         self.wait_lds()
@@ -949,7 +949,7 @@ class AllocD:
             for j in range(12):
                 self.e("v_mov_b32_e64 v%d, v%d" % (j, vb(b) + j))
         self.e("s_waitcnt vmcnt(0)")
-        self.e("CALL mbls_fp_pow_pm2_asm_fn")
+        self.e("CALL mbls_fp_inv_gcd_asm_fn")
         self.stats["calls"] += 1
         dst = lambda j: "v%d" % (vb(1) + j)
         for l in seq_conv(dst, ["v%d" % j for j in range(12)], True):
