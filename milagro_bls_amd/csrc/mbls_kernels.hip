@@ -21,7 +21,8 @@
 #define MBLS_SLOT_S 25            // 6 Fp: Jacobian G2 accumulator for verify_multiple
 #define MBLS_SLOT_T 31            // 12 Fp: the running points of the generated Miller loop (packed, 2^392 domain; tools/gen_tower_d.py T_SLOT)
 #define MBLS_SLOT_G2TMP 43        // 6 Fp: scratch of the generated subgroup-test routine (tools/gen_tower_d.py G2_SLOTS)
-#define MBLS_SLOT_TOTAL 49
+#define MBLS_SLOT_KREC 49         // 60 Fp: the six compressed powers of the final exponentiation (tools/gen_tower_d.py K_SLOT, K_REC)
+#define MBLS_SLOT_TOTAL 109
 #define WG 64
 // The pipeline kernels are built for one wave per SIMD (512 registers per lane): a batch of 2^16 items is exactly one wave
 // per SIMD on 256 CUs, and the hot loops are generated straight-line routines that already issue at the VALU rate with a

@@ -268,14 +268,20 @@ GBASE, GSTRIDE, GADDR, GT0, GT1 = "s[68:69]", "s70", "s[74:75]", "s76", "s77"   
 # LADDR is the lane offset), bytes between consecutive words of a value, running address, temporaries
 
 
-def seq_gaddr(slot):
-    return ["s_mul_i32 %s, %s, %d" % (GT0, GSTRIDE, 12 * slot), "s_mul_hi_u32 %s, %s, %d" % (GT1, GSTRIDE, 12 * slot),
-            "s_add_u32 s74, s68, %s" % GT0, "s_addc_u32 s75, s69, %s" % GT1]
+GKOFF = "s71"                       # run-time byte offset added to the address of the slots of kind 'gk' (one record of several)
 
 
-def seq_gstore(reg, slot):
+def seq_gaddr(slot, koff=False):
+    L = ["s_mul_i32 %s, %s, %d" % (GT0, GSTRIDE, 12 * slot), "s_mul_hi_u32 %s, %s, %d" % (GT1, GSTRIDE, 12 * slot),
+         "s_add_u32 s74, s68, %s" % GT0, "s_addc_u32 s75, s69, %s" % GT1]
+    if koff:
+        L += ["s_add_u32 s74, s74, %s" % GKOFF, "s_addc_u32 s75, s75, 0"]
+    return L
+
+
+def seq_gstore(reg, slot, koff=False):
     """12 packed words in reg(0)..reg(11) -> workspace slot"""
-    L = seq_gaddr(slot)
+    L = seq_gaddr(slot, koff)
     for j in range(12):
         L.append("global_store_dword %s, %s, %s" % (LADDR, reg(j), GADDR))
         if j < 11:
@@ -283,10 +289,10 @@ def seq_gstore(reg, slot):
     return L
 
 
-def seq_gload(reg, slot, aform=True):
+def seq_gload(reg, slot, aform=True, koff=False):
     """12 words of workspace slot `slot` (limb-major: word j of slot s at base + (12 s + j) * stride) into reg(2)..reg(13), then 14
     digits into reg(0)..reg(13): of words * 2^8 (aform: a 2^384-domain value enters the 2^392 domain) or of the words themselves"""
-    L = seq_gaddr(slot)
+    L = seq_gaddr(slot, koff)
     for j in range(12):
         L.append("global_load_dword %s, %s, %s" % (reg(j + 2), LADDR, GADDR))
         if j < 11:
@@ -455,7 +461,7 @@ class AllocD:
         self.stats = dict(vmov=0, acc=0, lds=0, arith=0, norm=0, reduce=0, calls=0, unpack=0)
         # values whose live-in location is a packed LDS slot ('lp', s) keep it as a read-only home: evicting a register copy of
         # such a value costs nothing, fetching it again is 6 LDS reads + the conversion into digits
-        self.home = {v: l for v, l in prog.init_loc.items() if l[0] in ("lp", "g", "gd")}
+        self.home = {v: l for v, l in prog.init_loc.items() if l[0] in ("lp", "g", "gd", "gk")}
         self.home_bound = {v: in_bounds[v] for v in self.home}
         self.vm = 0                                          # vector-memory operations issued so far (they retire in issue order)
         self.vm_mark = {}                                    # value -> count after the last load of its prefetch
@@ -509,10 +515,10 @@ class AllocD:
             for l in lds_read_words([reg(j + 2) for j in range(12)], 12 * sb) + WAIT_LDS + seq_conv(reg, [reg(j + 2) for j in range(12)], False):
                 self.e(l)
             self.stats["unpack"] += 30
-        elif sk in ("g", "gd") and dk == "v":
+        elif sk in ("g", "gd", "gk") and dk == "v":
             reg = lambda j: "v%d" % (vb(db) + j)
             self.wait_lds()
-            for l in seq_gload(reg, sb, aform=(sk == "g")):
+            for l in seq_gload(reg, sb, aform=(sk == "g"), koff=(sk == "gk")):
                 self.e(l)
             self.stats["unpack"] += 60
         elif sk == "l" and dk == "v":
@@ -630,7 +636,7 @@ class AllocD:
         while j < len(self.p.ops) and calls < horizon:
             kind, outs, ins, aux = self.p.ops[j]
             for v in ins:
-                if self.loc.get(v, ("", 0))[0] in ("g", "gd") and v in self.home:
+                if self.loc.get(v, ("", 0))[0] in ("g", "gd", "gk") and v in self.home:
                     b = self.free_block("v", self.free_v)
                     if b is None:                            # take the block whose value is needed last, if that is later than this use
                         best, bu = None, j
@@ -650,7 +656,7 @@ class AllocD:
                             self.spill(w)
                         b = best
                     reg = lambda q, b=b: "v%d" % (vb(b) + q)
-                    for x in seq_gload(reg, self.home[v][1], aform=None):
+                    for x in seq_gload(reg, self.home[v][1], aform=None, koff=(self.home[v][0] == "gk")):
                         self.e(x)
                     self.vm_mark[v] = self.vm
                     self.loc[v] = ("vw", b); self.at[("vw", b)] = v
@@ -960,8 +966,11 @@ class AllocD:
     def do_storep(self, k, a, slot):
         """value -> workspace slot, packed (representative in (0.5 p, 1.5 p), 12 words, 2^392 domain); values that still call this
         slot home are fetched first"""
-        for w in [w for w, h in self.home.items() if h == ("gd", slot)]:
-            if w != a and self.next_use(w, k + 1) != INF and self.loc.get(w) == ("gd", slot):
+        kind = "gd"
+        if isinstance(slot, tuple):                          # ('k', j): slot j of the record selected by the run-time offset
+            kind, slot = "gk", slot[1]
+        for w in [w for w, h in self.home.items() if h == (kind, slot)]:
+            if w != a and self.next_use(w, k + 1) != INF and self.loc.get(w) == (kind, slot):
                 self.to_vgpr(w, k)
             del self.home[w]
         b = self.to_vgpr(a, k)
@@ -973,11 +982,11 @@ class AllocD:
             self.release(a)
         assert self.bound[a].vabs() < (P << 16)
         reg = lambda j: "v%d" % (vb(b) + j)
-        for l in seq_pack_pass(reg) + seq_to32(reg) + seq_gstore(reg, slot):
+        for l in seq_pack_pass(reg) + seq_to32(reg) + seq_gstore(reg, slot, koff=(kind == "gk")):
             self.e(l)
         self.stats["reduce"] += 62 + 21 + 38
         if self.next_use(a, k + 1) != INF:                  # from now on the slot is a home of the value: register copies of it can be
-            self.home[a] = ("gd", slot)                     # dropped and fetched again (same value, the packed representative)
+            self.home[a] = (kind, slot)                     # dropped and fetched again (same value, the packed representative)
             self.home_bound[a] = PACKED
 
     def call_limits_ok(self, kind, B):
@@ -1514,10 +1523,117 @@ def prog_fexp_easy():
     return p
 
 
-def prog_fexp_mul_y():
-    """state <- state * Y (inside a power by |x|)"""
+# A power by |x| = 2^63 + 2^62 + 2^60 + 2^57 + 2^48 + 2^16 in the cyclotomic subgroup with Karabina's compressed squarings: the
+# Granger-Scott formulas for the coefficients (z2, z3, z4, z5) do not involve (z0, z1), so a chain of squarings carries only those
+# four (6 Fp2 squarings instead of 9); the six powers y^(2^i) the exponent needs are saved compressed, decompressed together
+#     z1 = (xi z5^2 + 3 z4^2 - 2 z3) / (4 z2)     [z2 = 0:  z1 = 2 z4 z5 / z3],     z0 = xi (2 z1^2 + z2 z5 - 3 z3 z4) + 1
+# with ONE Fp inversion for the six denominators (Montgomery's trick on their norms), and multiplied. A zero denominator (the element
+# 1: all four coefficients zero) is replaced by 1 inside the trick and its inverse by 0 afterwards, which decompresses to 1.
+K_SLOT, K_REC = 49, 10                              # six records: z2, z3, z4, z5 (8 Fp) + the inverse of the denominator (2 Fp)
+POW_RUNS = [16, 32, 9, 3, 2, 1]                     # squarings before each save: y^(2^16), ^(2^48), ^(2^57), ^(2^60), ^(2^62), ^(2^63)
+C_IDX = [6, 7, 4, 5, 2, 3, 10, 11]                  # z2, z3, z4, z5 in the flat tower order (c0.c0, c0.c1, c0.c2, c1.c0, c1.c1, c1.c2)
+ZMASK = ["s[48:49]", "s[50:51]", "s[52:53]", "s[54:55]", "s[84:85]", "s[86:87]"]
+TMASK, TMASK2 = "s[88:89]", "s[90:91]"
+
+
+def prog_fexp_pstart():
+    """compressed state <- the base Y"""
     p = Prog()
-    acc_store(p, mul12(p, acc_live_in(p), gd_live_in(p, Y_SLOT)))
+    y = [p.live_in(("gd", Y_SLOT + i)) for i in range(12)]
+    for i, idx in enumerate(C_IDX):
+        p.store(prog_reduce(p, y[idx]), ("a", i))
+    return p
+
+
+def prog_fexp_csqr():
+    """one compressed squaring: (z2, z3, z4, z5) in AGPR blocks 0..7, in place"""
+    p = Prog()
+    l = [p.live_in(("a", i)) for i in range(8)]
+    z2, z3, z4, z5 = (l[0], l[1]), (l[2], l[3]), (l[4], l[5]), (l[6], l[7])
+
+    def fp4_sqr(a, b):
+        t0 = p.sqr2(a); t1 = p.sqr2(b)
+        return p.add2(p.mul_xi2(t1), t0), p.sub2(p.sub2(p.sqr2(p.add2(a, b)), t0), t1)
+
+    def out(base, v):
+        for i in range(2):
+            p.store(prog_reduce(p, v[i]), ("a", base + i))
+    t0, t1 = fp4_sqr(z2, z3)
+    out(4, p.shadd2(p.sub2(t0, z4), 1, t0))
+    out(6, p.shadd2(p.add2(t1, z5), 1, t1))
+    t2, t3 = fp4_sqr(z4, z5)
+    x = p.mul_xi2(t3)
+    out(0, p.shadd2(p.add2(x, z2), 1, x))
+    out(2, p.shadd2(p.sub2(t2, z3), 1, t2))
+    return p
+
+
+def prog_fexp_psave():
+    """the compressed state -> the record selected by the run-time offset (the state stays)"""
+    p = Prog()
+    l = [p.live_in(("a", i)) for i in range(8)]
+    for i, v in enumerate(l):
+        p.ops.append(("storep", [], [v], ("k", K_SLOT + i)))         # record 0's slot: the run-time offset selects the record
+    for i, v in enumerate(l):
+        p.store(v, ("a", i))
+    return p
+
+
+def prog_fexp_pinv():
+    """the inverses of the six decompression denominators (4 z2, or z3 where z2 = 0) into slots 8, 9 of their records"""
+    p = Prog()
+    dens, norms = [], []
+    for i in range(6):
+        l = [p.live_in(("gd", K_SLOT + K_REC * i + j)) for j in range(4)]
+        z2, z3 = (l[0], l[1]), (l[2], l[3])
+        p.iszero2(z2, TMASK, TMASK2)
+        den = p.sel2(TMASK, p.scale2(z2, 4), z3)
+        sq = p.mulpair(den[0], den[0], den[1], den[1])
+        n = p.add(sq[0], sq[1])
+        p.iszero(n, ZMASK[i])
+        dens.append(den); norms.append(p.sel(ZMASK[i], n, p.const(ONE_D)))
+    pre = [norms[0]]
+    for i in range(1, 6):
+        pre.append(p.mul1(pre[-1], norms[i]))
+    inv = p.inv(pre[5])
+    for i in range(5, -1, -1):
+        if i:
+            invn, inv = p.mulpair(inv, pre[i - 1], inv, norms[i])
+        else:
+            invn = inv
+        invn = p.sel(ZMASK[i], invn, p.const(0))
+        r = p.mulfp2(p.conj2(dens[i]), invn)
+        for j in range(2):
+            p.ops.append(("storep", [], [r[j]], K_SLOT + K_REC * i + 8 + j))
+    return p
+
+
+def decompress12(p):
+    """the Fp12 of the record selected by the run-time offset, in six-form"""
+    l = [p.live_in(("gk", K_SLOT + j)) for j in range(K_REC)]
+    z2, z3, z4, z5, iden = (l[0], l[1]), (l[2], l[3]), (l[4], l[5]), (l[6], l[7]), (l[8], l[9])
+    p.iszero2(z2, TMASK, TMASK2)
+    n_gen = p.sub2(p.add2(p.mul_xi2(p.sqr2(z5)), p.scale2(p.sqr2(z4), 3)), p.scale2(z3, 2))
+    n_alt = p.scale2(p.mul2(z4, z5), 2)
+    z1 = p.mul2(p.sel2(TMASK, n_gen, n_alt), iden)
+    t = p.sub2(p.add2(p.scale2(p.sqr2(z1), 2), p.mul2(z2, z5)), p.scale2(p.mul2(z3, z4), 3))
+    t = p.mul_xi2(t)
+    z0 = (p.add(t[0], p.const(ONE_D)), t[1])
+    return ([z0, z4, z3], [z2, z1, z5])
+
+
+def prog_fexp_pfirst():
+    """state <- the decompressed first record"""
+    p = Prog()
+    acc_store(p, decompress12(p))
+    return p
+
+
+def prog_fexp_pmul():
+    """state <- state * (the decompressed record)"""
+    p = Prog()
+    a = acc_live_in(p)
+    acc_store(p, mul12(p, a, decompress12(p)))
     return p
 
 
@@ -1562,17 +1678,18 @@ def prog_fexp_tail():
     return p
 
 
-FEXP_BODIES = dict(easy=prog_fexp_easy, mul_y=prog_fexp_mul_y, step_conj=prog_fexp_step_conj, step_frob=prog_fexp_step_frob,
+FEXP_BODIES = dict(easy=prog_fexp_easy, pstart=prog_fexp_pstart, csqr=prog_fexp_csqr, psave=prog_fexp_psave, pinv=prog_fexp_pinv,
+                   pfirst=prog_fexp_pfirst, pmul=prog_fexp_pmul, step_conj=prog_fexp_step_conj, step_frob=prog_fexp_step_frob,
                    step_base=prog_fexp_step_base, tail=prog_fexp_tail)
 
 
 def build_fexp(which):
     p = FEXP_BODIES[which]()
-    inb = {v: (STATE_IN if l[0] == "a" else PACKED if l[0] == "gd" else G_IN) for v, l in p.init_loc.items()}
+    inb = {v: (STATE_IN if l[0] == "a" else PACKED if l[0] in ("gd", "gk") else G_IN) for v, l in p.init_loc.items()}
     al = AllocD(p, inb, n_lds=11, lds_base=0, a_pool=list(range(NA)))
     body = al.run()
-    for dst, B in al.stored.items():
-        assert B.vlo >= REDUCED.vlo and B.vhi <= REDUCED.vhi and B.dhi <= M28, (dst, B)
+    for dst, B in getattr(al, "stored", {}).items():
+        assert B.vlo >= STATE_IN.vlo and B.vhi <= STATE_IN.vhi and B.dhi <= M28, (dst, B)
     return body, al.stats
 
 
@@ -1584,29 +1701,31 @@ def final_exp_d_routine():
     """In:  workspace slots 13..24 = f (2^384 domain, canonical); v252 LDS byte address of the lane's column (11 spill slots);
          s[68:69] workspace base adjusted so that v252 is the lane offset, s70 bytes between consecutive words of a value.
     Out: f^(3 (p^12 - 1) / r) in v108..v251 (twelve groups of 12 words, tower order, canonical, 2^384 domain).
-    Workspace slots 0..24 and 31..42 are overwritten."""
+    Workspace slots 0..24, 31..42 and 49..108 are overwritten."""
     bodies, stats = {}, {}
     for name in FEXP_BODIES:
         bodies[name], stats[name] = build_fexp(name)
-    bodies["sqr"], stats["sqr"] = build_cyc_sqr_d()
     X = lambda name: expand_calls_d(bodies[name])
-    pro = ["s_mov_b64 s[80:81], s[30:31]", "s_waitcnt vmcnt(0)"] + shell_constants()
-    main = X("easy") + ["s_mov_b32 s79, 0"]
-    main += ["5:", "s_mov_b32 s78, 0", "4:", "s_mov_b32 s39, %d" % RUNS[5]]
-    for ph in range(5):
-        main += ["s_cmp_eq_u32 s78, %d" % ph, "s_cselect_b32 s39, %d, s39" % RUNS[ph]]
-    main += [".p2align 6", "1:"] + X("sqr")
-    main += ["s_sub_u32 s39, s39, 1", "s_cmp_lg_u32 s39, 0", "s_cbranch_scc0 2f"] + far_back(1) + ["2:"]
-    main += ["s_cmp_eq_u32 s78, 5", "s_cbranch_scc0 3f"] + far_fwd(9) + ["3:"]
-    main += X("mul_y") + ["s_add_u32 s78, s78, 1"] + far_back(4)
-    main += ["9:", "s_cmp_lt_u32 s79, 2", "s_cbranch_scc1 13f"] + far_fwd(11) + ["13:"] + X("step_conj") + far_fwd(20)
+    POWER, CSQR = 60, 61
+    next_rec = ["s_add_u32 %s, %s, s72" % (GKOFF, GKOFF)]
+    pro = ["s_mov_b64 s[80:81], s[30:31]", "s_waitcnt vmcnt(0)"] + shell_constants() + ["s_mul_i32 s72, %s, %d" % (GSTRIDE, 12 * K_REC)]
+    main = X("easy") + ["s_mov_b32 s79, 0", "5:"] + call_sub(POWER)
+    main += ["s_cmp_lt_u32 s79, 2", "s_cbranch_scc1 13f"] + far_fwd(11) + ["13:"] + X("step_conj") + far_fwd(20)
     main += ["11:", "s_cmp_eq_u32 s79, 2", "s_cbranch_scc1 13f"] + far_fwd(12) + ["13:"] + X("step_frob") + far_fwd(20)
     main += ["12:", "s_cmp_eq_u32 s79, 3", "s_cbranch_scc1 13f"] + far_fwd(14) + ["13:"] + X("step_base")
     main += ["20:", "s_add_u32 s79, s79, 1"] + far_back(5)
     main += ["14:"] + X("tail")
     epi = f_out_epilogue("s[80:81]")
+    # state <- Y^|x| (Y in its workspace home): compressed chain with six saves, joint decompression, five products
+    power = ["%d:" % POWER] + X("pstart") + ["s_mov_b32 %s, 0" % GKOFF]
+    for ph, n in enumerate(POW_RUNS):
+        power += ["s_mov_b32 s39, %d" % n, "s_getpc_b64 s[96:97]", "7:", "s_add_u32 s96, s96, 8f-7b", "s_addc_u32 s97, s97, 0"] + far_fwd(CSQR) + ["8:"]
+        power += X("psave") + (next_rec if ph < 5 else [])
+    power += ["s_waitcnt vmcnt(0)"] + X("pinv") + ["s_mov_b32 %s, 0" % GKOFF] + X("pfirst") + ["s_mov_b32 s39, 5", "1:"] + next_rec + X("pmul")
+    power += ["s_sub_u32 s39, s39, 1", "s_cmp_lg_u32 s39, 0", "s_cbranch_scc0 2f"] + far_back(1) + ["2:", "s_setpc_b64 s[98:99]"]
+    csqr = ["%d:" % CSQR, ".p2align 6", "1:"] + X("csqr") + ["s_sub_u32 s39, s39, 1", "s_cmp_lg_u32 s39, 0", "s_cbranch_scc0 2f"] + far_back(1) + ["2:", "s_setpc_b64 s[96:97]"]
     pieces = dict(bodies, pro=pro, epi=epi)
-    return pro + main + expand_calls_d(epi), pieces, stats
+    return pro + main + expand_calls_d(epi) + ["s_setpc_b64 s[30:31]"] + power + csqr, pieces, stats
 
 
 # ---------------------------------------------------------------------------------------------- the sum of an item's public keys
@@ -2091,7 +2210,7 @@ def main():
     txt += emit("MBLS_FINAL_EXP_D_ASM", full) + "\n"
     for kname, v in st.items():
         print("final_exp_d", kname, len(pieces[kname]), "lines", v)
-    txt += "#define MBLS_FINAL_EXP_D_ASM_CLOBBERS MBLS_MILLER_D_ASM_CLOBBERS, \"v253\", \"s79\", \"s80\", \"s81\"\n"
+    txt += "#define MBLS_FINAL_EXP_D_ASM_CLOBBERS MBLS_MILLER_D_ASM_CLOBBERS, \"v253\", \"s50\", \"s51\", \"s52\", \"s53\", \"s79\", \"s71\", \"s72\", \"s80\", \"s81\", " + ", ".join('\"s%d\"' % i for i in range(84, 100)) + "\n"
     for mode in ("raw", "indexed"):
         full, pieces, st = g1_aggregate_d_routine(mode)
         txt += emit("MBLS_G1_AGGREGATE_%s_D_ASM" % mode.upper(), full) + "\n"
