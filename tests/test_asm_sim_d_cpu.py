@@ -772,3 +772,37 @@ def test_g2_hash_tail_routine():
     ri = pow(R384, -1, P)
     got = [(ws_get(m, t.G2_SLOTS["H"] + 2 * e) * ri % P, ws_get(m, t.G2_SLOTS["H"] + 2 * e + 1) * ri % P) for e in range(3)]
     assert jac2_affine(M, *got) == want
+
+
+def test_compressed_squaring_decompression_formulas():
+    """The identities the decompression rests on, on a random element of the cyclotomic subgroup (tower coefficients z0, z4, z3, z2,
+    z1, z5 as in fp12_cyc_sqr):  4 z2 z1 = xi z5^2 + 3 z4^2 - 2 z3,  z3 z1 - 2 z4 z5 = z2 (1 - z0) / xi  (so z1 = 2 z4 z5 / z3 where
+    z2 = 0),  z0 = xi (2 z1^2 + z2 z5 - 3 z3 z4) + 1; and the decompression body on a record with z2 = 0 (the branch no random input
+    reaches) against the same program on field values."""
+    M = _g2m()
+    rng = random.Random(12)
+    f = [(rng.randrange(P), rng.randrange(P)) for _ in range(6)]
+    tt = M.f12_mul(M.f12_conj(f), M.f12_inv(f))
+    m = M.f12_mul(M.f12_frob(M.f12_frob(tt)), tt)
+    z0, z4, z3, z2, z1, z5 = m[0], m[2], m[4], m[1], m[3], m[5]          # w^0, w^2, w^4, w^1, w^3, w^5
+    xi = (1, 1)
+    mxi = lambda a: M.f2_mul(a, xi)
+    assert M.f2_eq(M.f2_muls(M.f2_mul(z2, z1), 4), M.f2_sub(M.f2_add(mxi(M.f2_sqr(z5)), M.f2_muls(M.f2_sqr(z4), 3)), M.f2_muls(z3, 2)))
+    assert M.f2_eq(mxi(M.f2_sub(M.f2_mul(z3, z1), M.f2_muls(M.f2_mul(z4, z5), 2))), M.f2_mul(z2, M.f2_sub((1, 0), z0)))
+    assert M.f2_eq(z0, M.f2_add(mxi(M.f2_sub(M.f2_add(M.f2_muls(M.f2_sqr(z1), 2), M.f2_mul(z2, z5)), M.f2_muls(M.f2_mul(z3, z4), 3))), (1, 0)))
+    # the body with z2 = 0: masks select the second numerator
+    body, _ = t.build_fexp("pfirst")
+    for zero_z2 in (True, False):
+        mch = miller_machine(0); mch.run(t.shell_constants()); mch.s[71] = 0
+        init = {}
+        for j in range(t.K_REC):
+            x = 0 if (zero_z2 and j < 2) else rng.randrange(P)
+            init[("gk", t.K_SLOT + j)] = x
+            rep = x * R392 % P
+            ws_put(mch, t.K_SLOT + j, rep + P if rep < P // 2 else rep)
+        masks = {}
+        mp = run_model(t.prog_fexp_pfirst, init, masks)
+        mch.run(body)
+        assert masks[t.TMASK] == (1 if zero_z2 else 0)
+        for i in range(12):
+            assert from_digits_signed(mch.a[14 * i:14 * i + 14]) * RI392 % P == mp.out_home[("a", i)], (zero_z2, i)
