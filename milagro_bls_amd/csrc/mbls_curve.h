@@ -112,6 +112,7 @@ MBLS_NOINLINE bool g1_in_subgroup(const g1j* p) {
 MBLS_FN bool mbls_all_zero(const uint8_t* b, int n) { uint32_t t = 0; for (int i = 0; i < n; i++) t |= b[i]; return t == 0; }
 
 // PublicKey::from_bytes_unchecked (reference src/keys.rs:150-155): 48 compressed bytes
+template <bool W4 = false>
 MBLS_NOINLINE int g1_decode_compressed(fp* x, fp* y, bool* inf, const uint8_t* b) {
     uint8_t b0 = b[0];
     *inf = false; *x = fp_zero(); *y = fp_zero();
@@ -122,7 +123,7 @@ MBLS_NOINLINE int g1_decode_compressed(fp* x, fp* y, bool* inf, const uint8_t* b
     fp xm = fp_to_mont(raw);
     fp four = fp_dbl(fp_dbl(fp_one()));
     fp ym;
-    if (!fp_sqrt(&ym, fp_add(fp_mul(fp_sqr(xm), xm), four))) return MBLS_DEC_POINT;
+    if (!fp_sqrt<W4>(&ym, fp_add(fp_mul(fp_sqr(xm), xm), four))) return MBLS_DEC_POINT;
     bool want = (b0 & 0x20) != 0;
     ym = fp_select(fp_lex_largest(ym) != want, fp_neg(ym), ym);
     *x = xm; *y = ym; return MBLS_DEC_OK;

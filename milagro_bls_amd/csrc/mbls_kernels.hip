@@ -68,8 +68,9 @@ __global__ void MBLS_LB k_aggregate_indexed_d(mbls_ws ws, const uint32_t* recs, 
 #endif
     if (st) atomicOr(status + i, st);
 }
-// one key per lane; the square-root routine keeps its window table in 224 AGPRs, so this kernel too runs one wave per SIMD
-__global__ void MBLS_LB k_pk_decompress(const uint8_t* pks48, uint64_t nkeys, uint32_t* keys_xy, uint8_t* flags) {
+// one key per lane, nothing but a square root: with the 8-entry window table (112 AGPRs) the kernel fits 256 registers and two
+// waves share a SIMD -- the plain 32-bit third of the instruction stream then issues at twice the rate (profiles/r02_ubench.txt)
+__global__ void __launch_bounds__(WG, 2) k_pk_decompress(const uint8_t* pks48, uint64_t nkeys, uint32_t* keys_xy, uint8_t* flags) {
     uint64_t j = gid(); if (j >= nkeys) return;
     lane_pk_decompress(j, pks48, keys_xy, flags);
 }

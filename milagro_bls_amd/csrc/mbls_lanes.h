@@ -126,7 +126,7 @@ MBLS_FN uint32_t lane_aggregate_d(const mbls_ws& ws, uint64_t i, const void* key
 #define MBLS_KEYFLAG_BAD 2u
 MBLS_FN void lane_pk_decompress(uint64_t j, const uint8_t* pks48, uint32_t* keys_xy, uint8_t* flags) {
     fp x, y; bool inf;
-    int e = g1_decode_compressed(&x, &y, &inf, pks48 + 48 * j);
+    int e = g1_decode_compressed<true>(&x, &y, &inf, pks48 + 48 * j);         // the two-waves-per-SIMD variant of the square root
     uint32_t* o = keys_xy + 24 * j;
 #pragma unroll
     for (int t = 0; t < 12; t++) { o[t] = x[t]; o[12 + t] = y[t]; }

@@ -115,7 +115,7 @@ def kernel_metadata(lib_path):
 def test_kernel_resources(lib_path):
     """What the design rests on, read back from the built code object: the generated Miller and final-exponentiation kernels have no
     lane-private memory, the pipeline kernels are one-wave-per-SIMD kernels (more than 256 registers) whose LDS fits four waves per CU, and
-    the key-decompression kernel is (like them) a one-wave kernel -- its square-root routine keeps a 224-register window table."""
+    the key-decompression kernel -- nothing but a square root with the 8-entry window table -- fits 256 registers (two waves per SIMD)."""
     meta = kernel_metadata(lib_path)
     by = lambda prefix: next(v for k, v in meta.items() if k.startswith(prefix))
     for k in ("_Z8k_miller", "_Z7k_final", "_Z15k_miller_single"):
@@ -124,4 +124,4 @@ def test_kernel_resources(lib_path):
         assert int(by(k)["vgpr_count"]) > 256, k
     for k in ("_Z8k_miller", "_Z7k_final", "_Z15k_miller_single"):
         assert int(by(k)["group_segment_fixed_size"]) * 4 <= 160 * 1024, k
-    assert int(by("_Z15k_pk_decompress")["agpr_count"]) >= 224
+    assert int(by("_Z15k_pk_decompress")["vgpr_count"]) <= 256 and int(by("_Z15k_pk_decompress")["agpr_count"]) >= 112

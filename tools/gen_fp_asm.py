@@ -375,9 +375,10 @@ def pow_schedule(e, w=POW_WINDOW):
     return merged
 
 
-def pow_body(e):
-    """a^e for a in v[0:11] (Montgomery form, R = 2^384), result in v[0:11]; sliding 5-bit windows over the odd powers a, a^3, ..
-    a^31 kept in a0..a223 as digit vectors. Pseudo-instruction CALL name = s_getpc/s_add/s_addc/s_swappc."""
+def pow_body(e, window=POW_WINDOW):
+    """a^e for a in v[0:11] (Montgomery form, R = 2^384), result in v[0:11]; sliding `window`-bit windows over the odd powers a, a^3,
+    .. kept in AGPRs as digit vectors (window 5: a0..a223; window 4: a0..a111, for kernels that run two waves per SIMD).
+    Pseudo-instruction CALL name = s_getpc/s_add/s_addc/s_swappc."""
     L = ["s_mov_b64 s[36:37], s[30:31]"] + load_modulus28()
     L += conv28(VR(60), VR(0), True)                              # digits of a * 2^8: the value in the 2^392 domain
     L += ["v_mov_b32_e64 %s, %s" % (POW_X(j), "v%d" % (60 + j)) for j in range(14)]
@@ -390,10 +391,10 @@ def pow_body(e):
     L.append(sqr["X"])                                            # a^2 -> Y -> B; the odd powers by repeated products with it
     L += ["v_mov_b32_e64 %s, %s" % (POW_B(j), POW_Y(j)) for j in range(14)]
     loc = "X"
-    for n in range(3, 1 << POW_WINDOW, 2):
+    for n in range(3, 1 << window, 2):
         L.append(mul[loc]); loc = other[loc]
         L += ["v_accvgpr_write_b32 %s, %s" % (tab(n, j), REG[loc](j)) for j in range(14)]
-    for op in pow_schedule(e):
+    for op in pow_schedule(e, window):
         if op[0] == "load":
             loc = "X"
             L += ["v_accvgpr_read_b32 %s, %s" % (POW_X(j), tab(op[1], j)) for j in range(14)]
@@ -611,9 +612,12 @@ def main():
     for sym, body in pow_subroutines().items():
         txt += emit("MBLS_" + sym.upper()[5:-7] + "_ASM", body) + "\n"
     txt += emit("MBLS_FP_POW_PM3D4_ASM", expand_pow_calls(pow_body(EXP_PM3D4))) + "\n"
+    txt += emit("MBLS_FP_POW_PM3D4_W4_ASM", expand_pow_calls(pow_body(EXP_PM3D4, 4))) + "\n"
     txt += emit("MBLS_FP_INV_GCD_ASM", fp_inv_gcd_body()) + "\n"
     txt += "#define MBLS_FP_INV_GCD_CLOBBERS %s, \"s66\",\"s76\",\"s77\",\"vcc\",\"scc\"\n" % vl(12, 84)
     txt += "#define MBLS_FP_POW_CLOBBERS %s,%s, \\\n" % (vl(12, 84), ",".join('"a%d"' % i for i in range(224)))
+    txt += '    "s30","s31","s36","s37","s66","s67", %s\n' % sg
+    txt += "#define MBLS_FP_POW_W4_CLOBBERS %s,%s, \\\n" % (vl(12, 84), ",".join('"a%d"' % i for i in range(112)))
     txt += '    "s30","s31","s36","s37","s66","s67", %s\n' % sg
     with open(path, "w") as f:
         f.write(txt)
