@@ -302,7 +302,8 @@ MBLS_NOINLINE void g2_to_affine(fp2* x, fp2* y, bool* inf, const g2j* p) {
     *x = fp2_mul(p->x, zi2); *y = fp2_mul(fp2_mul(p->y, zi2), zi);
 }
 // Signature::from_bytes (reference src/signature.rs:43-46): 96 compressed bytes x.c1 || x.c0. No subgroup check.
-MBLS_NOINLINE int g2_decode_compressed(fp2* x, fp2* y, bool* inf, const uint8_t* b) {
+template <bool INL>
+MBLS_FN int g2_decode_compressed_t(fp2* x, fp2* y, bool* inf, const uint8_t* b) {
     uint8_t b0 = b[0];
     *inf = false; *x = fp2_zero(); *y = fp2_zero();
     if (!(b0 & 0x80)) return MBLS_DEC_SIZE;
@@ -313,11 +314,12 @@ MBLS_NOINLINE int g2_decode_compressed(fp2* x, fp2* y, bool* inf, const uint8_t*
     fp2 xm; xm.c0 = fp_to_mont(r0); xm.c1 = fp_to_mont(r1);
     fp four = fp_dbl(fp_dbl(fp_one())); fp2 bb; bb.c0 = four; bb.c1 = four;
     fp2 y2 = fp2_add(fp2_mul(fp2_sqr(xm), xm), bb), ym;
-    if (!fp2_sqrt(&ym, &y2)) return MBLS_DEC_POINT;
+    if (!(INL ? fp2_sqrt_inl(&ym, &y2) : fp2_sqrt(&ym, &y2))) return MBLS_DEC_POINT;
     bool want = (b0 & 0x20) != 0;
     ym = fp2_select(fp2_lex_largest(ym) != want, fp2_neg(ym), ym);
     *x = xm; *y = ym; return MBLS_DEC_OK;
 }
+MBLS_NOINLINE int g2_decode_compressed(fp2* x, fp2* y, bool* inf, const uint8_t* b) { return g2_decode_compressed_t<false>(x, y, inf, b); }
 MBLS_FN void g2_encode_compressed(uint8_t* b, const fp2& x, const fp2& y, bool inf) {   // reference src/amcl_utils.rs:62-64
     if (inf) { for (int i = 0; i < 96; i++) b[i] = 0; b[0] = 0xC0; return; }
     fp_raw_to_be(b, fp_from_mont(x.c1)); fp_raw_to_be(b + 48, fp_from_mont(x.c0));

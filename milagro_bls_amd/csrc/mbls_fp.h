@@ -362,13 +362,13 @@ MBLS_FN fp fp_inv(fp a) {                                                       
     asm volatile(MBLS_ASM_CALL("mbls_fp_inv_gcd_asm_fn") : "+{v[0:11]}"(a) : : MBLS_FP_INV_GCD_CLOBBERS, "s30", "s31");
     return a;
 }
+// the same with 4-bit windows (8 table entries, a0..a111): for kernels that fit 256 registers and run two waves per SIMD
+extern "C" __device__ __attribute__((noinline, used, aligned(64))) void mbls_fp_pow_pm3d4_w4_asm_fn() { asm volatile(MBLS_FP_POW_PM3D4_W4_ASM); }
 // w = a^((p-3)/4): sqrt candidate = w*a, 1/a = chi * w^2 with chi = (w*a)^2 / a = +-1
 MBLS_FN fp fp_pow_pm3d4(fp a) {
     asm volatile(MBLS_ASM_CALL("mbls_fp_pow_pm3d4_asm_fn") : "+{v[0:11]}"(a) : : MBLS_FP_POW_CLOBBERS);
     return a;
 }
-// the same with 4-bit windows (8 table entries, a0..a111): for kernels that fit 256 registers and run two waves per SIMD
-extern "C" __device__ __attribute__((noinline, used, aligned(64))) void mbls_fp_pow_pm3d4_w4_asm_fn() { asm volatile(MBLS_FP_POW_PM3D4_W4_ASM); }
 MBLS_FN fp fp_pow_pm3d4_w4(fp a) {
     asm volatile(MBLS_ASM_CALL("mbls_fp_pow_pm3d4_w4_asm_fn") : "+{v[0:11]}"(a) : : MBLS_FP_POW_W4_CLOBBERS);
     return a;

@@ -18,7 +18,10 @@ MBLS_CONST uint8_t MBLS_DST_POP[43] = {'B','L','S','_','S','I','G','_','B','L','
 #define MBLS_DST_POP_LEN 43
 
 MBLS_FN uint32_t mbls_ror(uint32_t x, int n) { return (x >> n) | (x << (32 - n)); }
-MBLS_NOINLINE void sha256_compress(uint32_t* h, const uint32_t* blk) {
+// state and message block travel by value (vector types: registers), so that no caller needs an addressable array for them
+typedef uint32_t mbls_u32x8 __attribute__((ext_vector_type(8)));
+typedef uint32_t mbls_u32x16 __attribute__((ext_vector_type(16)));
+MBLS_NOINLINE mbls_u32x8 sha256_compress(mbls_u32x8 h, mbls_u32x16 blk) {
     uint32_t w[16];
 #pragma unroll
     for (int i = 0; i < 16; i++) w[i] = blk[i];
@@ -36,21 +39,22 @@ MBLS_NOINLINE void sha256_compress(uint32_t* h, const uint32_t* blk) {
         uint32_t S0 = mbls_ror(a, 2) ^ mbls_ror(a, 13) ^ mbls_ror(a, 22), mj = (a & b) ^ (a & c) ^ (b & c), t2 = S0 + mj;
         hh = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + t2;
     }
-    h[0] += a; h[1] += b; h[2] += c; h[3] += d; h[4] += e; h[5] += f; h[6] += g; h[7] += hh;
-}
-MBLS_FN void sha256_iv(uint32_t* h) {
-    h[0] = 0x6a09e667; h[1] = 0xbb67ae85; h[2] = 0x3c6ef372; h[3] = 0xa54ff53a; h[4] = 0x510e527f; h[5] = 0x9b05688c; h[6] = 0x1f83d9ab; h[7] = 0x5be0cd19;
+    mbls_u32x8 r = h;
+    r[0] += a; r[1] += b; r[2] += c; r[3] += d; r[4] += e; r[5] += f; r[6] += g; r[7] += hh;
+    return r;
 }
 // SHA-256 of a "virtual" byte string described by byte_at(pos), pos in [0, len)
 template <typename F>
-MBLS_FN void sha256_virtual(uint32_t* digest, uint32_t len, F byte_at) {
-    uint32_t h[8]; sha256_iv(h);
+MBLS_FN mbls_u32x8 sha256_virtual_v(uint32_t len, F byte_at) {
+    mbls_u32x8 h = {0x6a09e667u, 0xbb67ae85u, 0x3c6ef372u, 0xa54ff53au, 0x510e527fu, 0x9b05688cu, 0x1f83d9abu, 0x5be0cd19u};
     uint32_t padded = ((len + 9 + 63) / 64) * 64;
     uint64_t bits = (uint64_t)len * 8;
     for (uint32_t off = 0; off < padded; off += 64) {
-        uint32_t blk[16];
+        mbls_u32x16 blk;
+#pragma unroll
         for (uint32_t j = 0; j < 16; j++) {
             uint32_t wv = 0;
+#pragma unroll
             for (uint32_t k = 0; k < 4; k++) {
                 uint32_t pos = off + 4 * j + k; uint32_t by;
                 if (pos < len) by = byte_at(pos);
@@ -61,9 +65,21 @@ MBLS_FN void sha256_virtual(uint32_t* digest, uint32_t len, F byte_at) {
             }
             blk[j] = wv;
         }
-        sha256_compress(h, blk);
+        h = sha256_compress(h, blk);
     }
+    return h;
+}
+template <typename F>
+MBLS_FN void sha256_virtual(uint32_t* digest, uint32_t len, F byte_at) {
+    mbls_u32x8 h = sha256_virtual_v(len, byte_at);
+#pragma unroll
     for (int i = 0; i < 8; i++) digest[i] = h[i];
+}
+MBLS_FN uint32_t mbls_digest_byte_v(mbls_u32x8 d, uint32_t i) {          // byte i of a digest held as eight big-endian words, without indexing memory
+    uint32_t w = d[0];
+#pragma unroll
+    for (uint32_t q = 1; q < 8; q++) w = (i >> 2) == q ? d[q] : w;
+    return (w >> (8 * (3 - (i & 3)))) & 0xFF;
 }
 MBLS_FN uint32_t mbls_digest_byte(const uint32_t* d, uint32_t i) { return (d[i >> 2] >> (8 * (3 - (i & 3)))) & 0xFF; }
 
@@ -91,6 +107,32 @@ MBLS_NOINLINE void expand_message_xmd_256(uint32_t* out, const uint8_t* msg, uin
         for (int j = 0; j < 8; j++) out[8 * (i - 1) + j] = bi[j];
     }
 }
+// the same from digests held in registers
+MBLS_FN fp fp_from_two_digests_v(mbls_u32x8 hi, mbls_u32x8 lo) {
+    fp rh = 0, rl = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) { rh[i] = hi[7 - i]; rl[i] = lo[7 - i]; }
+    return fp_add(fp_mul(fp_to_mont(rh), fp_load_const(MBLS_TWO_256)), fp_to_mont(rl));
+}
+// one block b_i = H((b_0 xor b_(i-1)) || I2OSP(i,1) || DST || I2OSP(len(DST),1)) of expand_message_xmd
+MBLS_FN mbls_u32x8 expand_xmd_block(mbls_u32x8 b0, mbls_u32x8 prev, uint32_t i, const uint8_t* dst, uint32_t dlen) {
+    mbls_u32x8 x = b0 ^ prev;
+    return sha256_virtual_v(32 + 1 + dlen + 1, [&](uint32_t pos) -> uint32_t {
+        if (pos < 32) return mbls_digest_byte_v(x, pos);
+        pos -= 32; if (pos == 0) return i;
+        pos -= 1; if (pos < dlen) return dst[pos];
+        return dlen;
+    });
+}
+MBLS_FN mbls_u32x8 expand_xmd_b0(const uint8_t* msg, uint32_t mlen, const uint8_t* dst, uint32_t dlen) {
+    return sha256_virtual_v(64 + mlen + 3 + dlen + 1, [&](uint32_t pos) -> uint32_t {
+        if (pos < 64) return 0;
+        pos -= 64; if (pos < mlen) return msg[pos];
+        pos -= mlen; if (pos < 3) return pos == 0 ? 1u : 0u;
+        pos -= 3; if (pos < dlen) return dst[pos];
+        return dlen;
+    });
+}
 // OS2IP(64 bytes) mod p in Montgomery form; the 64 bytes are the two digests hi, lo (big-endian words)
 MBLS_FN fp fp_from_two_digests(const uint32_t* hi, const uint32_t* lo) {
     fp rh = 0, rl = 0;
@@ -101,7 +143,7 @@ MBLS_FN fp fp_from_two_digests(const uint32_t* hi, const uint32_t* lo) {
 
 // ------------------------------------------------------------------------------------------------ SSWU + isogeny
 // Simplified SWU for E': y^2 = x^3 + A'x + B' followed by the 3-isogeny to E, result in Jacobian coordinates.
-MBLS_NOINLINE void map_to_curve_g2(g2j* out, const fp2* up) {
+MBLS_FN void map_to_curve_g2_inl(g2j* out, const fp2* up) {
     const fp2 u = *up;
     const fp2 A = fp2_load_const(MBLS_SSWU_A), B = fp2_load_const(MBLS_SSWU_B), Z = fp2_load_const(MBLS_SSWU_Z);
     fp2 tv1 = fp2_mul(Z, fp2_sqr(u));                        // Z u^2
@@ -147,14 +189,20 @@ MBLS_NOINLINE void map_to_curve_g2(g2j* out, const fp2* up) {
     }
     out->x = xnum; out->y = fp2_mul(y, ynum); out->z = fp2_add(x, fp2_load_const(MBLS_ISO3_K));
 }
+MBLS_NOINLINE void map_to_curve_g2(g2j* out, const fp2* up) { map_to_curve_g2_inl(out, up); }
 // hash_to_field + the two map_to_curve evaluations of hash_to_curve_g2: points of E'(Fp2) in Jacobian coordinates
-MBLS_NOINLINE void hash_to_g2_maps(g2j* q0, g2j* q1, const uint8_t* msg, uint32_t mlen, const uint8_t* dst, uint32_t dlen) {
+template <bool INL>
+MBLS_FN void hash_to_g2_maps_t(g2j* q0, g2j* q1, const uint8_t* msg, uint32_t mlen, const uint8_t* dst, uint32_t dlen) {
     uint32_t ub[64];
     expand_message_xmd_256(ub, msg, mlen, dst, dlen);
     fp2 u0, u1;
     u0.c0 = fp_from_two_digests(ub, ub + 8); u0.c1 = fp_from_two_digests(ub + 16, ub + 24);
     u1.c0 = fp_from_two_digests(ub + 32, ub + 40); u1.c1 = fp_from_two_digests(ub + 48, ub + 56);
-    map_to_curve_g2(q0, &u0); map_to_curve_g2(q1, &u1);
+    if (INL) { map_to_curve_g2_inl(q0, &u0); map_to_curve_g2_inl(q1, &u1); }
+    else { map_to_curve_g2(q0, &u0); map_to_curve_g2(q1, &u1); }
+}
+MBLS_NOINLINE void hash_to_g2_maps(g2j* q0, g2j* q1, const uint8_t* msg, uint32_t mlen, const uint8_t* dst, uint32_t dlen) {
+    hash_to_g2_maps_t<false>(q0, q1, msg, mlen, dst, dlen);
 }
 // hash_to_curve_g2 (reference src/amcl_utils.rs:33-35); result in Jacobian coordinates, in G2
 MBLS_NOINLINE void hash_to_g2(g2j* out, const uint8_t* msg, uint32_t mlen, const uint8_t* dst, uint32_t dlen) {

@@ -208,10 +208,24 @@ MBLS_FN uint32_t g2_group_d_call(const mbls_ws& ws, uint64_t i, MBLS_LDS uint32_
     return fl;
 }
 #endif
+// hash_to_field: u0 -> workspace slots 31, 32, u1 -> 37, 38 (2^384 domain); the generated routine takes them from there. A function of
+// its own: its message schedule and digest arrays then stay out of the kernel's frame.
+MBLS_NOINLINE void hash_fields_to_ws(uint32_t* w, uint64_t stride, uint64_t i, const uint8_t* msg, uint32_t mlen) {
+    mbls_ws ws; ws.w = w; ws.stride = stride;
+    const mbls_u32x8 b0 = expand_xmd_b0(msg, mlen, MBLS_DST_POP, MBLS_DST_POP_LEN);
+    mbls_u32x8 prev = 0;
+    for (uint32_t k = 0; k < 4; k++) {               // four field elements of 64 bytes each = two blocks each; digests stay in registers
+        mbls_u32x8 hi = expand_xmd_block(b0, prev, 2 * k + 1, MBLS_DST_POP, MBLS_DST_POP_LEN);
+        mbls_u32x8 lo = expand_xmd_block(b0, hi, 2 * k + 2, MBLS_DST_POP, MBLS_DST_POP_LEN);
+        prev = lo;
+        ws_st(ws, (int)(31 + (k & 1) + 6 * (k >> 1)), i, fp_from_two_digests_v(hi, lo));
+    }
+}
 // spill != nullptr (with use_lds): the subgroup test runs as the generated routine on the coordinates just stored
 MBLS_FN void lane_sig(const mbls_ws& ws, uint64_t i, const uint8_t* sig96, uint32_t* status, MBLS_LDS uint32_t* spill = nullptr, uint32_t lane = 0, bool use_lds = false) {
     fp2 x, y; bool inf; uint32_t st = 0;
-    int e = g2_decode_compressed(&x, &y, &inf, sig96);
+    // in the kernel (use_lds) the decoder is inlined: its operands then never have an address and stay out of lane-private memory
+    int e = use_lds ? g2_decode_compressed_t<true>(&x, &y, &inf, sig96) : g2_decode_compressed(&x, &y, &inf, sig96);
     if (e) { st |= MBLS_ST_BAD_SIG_ENCODING; inf = true; }
     // infinity is stored as y = 0 (no curve point has y = 0: there is no 2-torsion)
     if (inf) { x = fp2_zero(); y = fp2_zero(); }
@@ -231,10 +245,8 @@ MBLS_FN void lane_sig(const mbls_ws& ws, uint64_t i, const uint8_t* sig96, uint3
 }
 MBLS_FN void lane_hash(const mbls_ws& ws, uint64_t i, const uint8_t* msg, uint32_t mlen, MBLS_LDS uint32_t* spill = nullptr, uint32_t lane = 0, bool use_lds = false) {
 #if MBLS_DEVICE_ASM && !defined(MBLS_NO_FP2_ASM)
-    if (use_lds) {          // the two map_to_curve points to the workspace; q0 + q1 and the cofactor clearing as the generated routine
-        g2j q0, q1; hash_to_g2_maps(&q0, &q1, msg, mlen, MBLS_DST_POP, MBLS_DST_POP_LEN);
-        ws_st2(ws, MBLS_SLOT_H, i, q0.x); ws_st2(ws, MBLS_SLOT_H + 2, i, q0.y); ws_st2(ws, MBLS_SLOT_H + 4, i, q0.z);
-        ws_st2(ws, 19, i, q1.x); ws_st2(ws, 21, i, q1.y); ws_st2(ws, 23, i, q1.z);
+    if (use_lds) {          // hash_to_field here; both map_to_curve evaluations, q0 + q1 and the cofactor clearing as the generated routine
+        hash_fields_to_ws(ws.w, ws.stride, i, msg, mlen);
         g2_group_d_call<true>(ws, i, spill, lane);
         return;
     }

@@ -93,7 +93,7 @@ MBLS_FN uint32_t fp2_sgn0(const fp2& a) {             // RFC 9380 section 4.1, m
 }
 // Square root in Fp2 by the complex method with two Fp exponentiations.
 // Returns false if a is not a square. Any of the two roots may be returned.
-MBLS_NOINLINE bool fp2_sqrt(fp2* out, const fp2* ap) {
+MBLS_FN bool fp2_sqrt_inl(fp2* out, const fp2* ap) {
     fp2 a = *ap;
     fp n = fp2_norm(a);
     fp s;
@@ -115,6 +115,7 @@ MBLS_NOINLINE bool fp2_sqrt(fp2* out, const fp2* ap) {
     // verify (also rejects non-squares whose norm happens to pass nothing: norm test is exact)
     return zero | (sq & fp2_eq(fp2_sqr(r), a));
 }
+MBLS_NOINLINE bool fp2_sqrt(fp2* out, const fp2* ap) { return fp2_sqrt_inl(out, ap); }
 
 // ------------------------------------------------------------------------------------------------ Fp6
 MBLS_FN void fp6_add(fp6* r, const fp6* a, const fp6* b) { r->c0 = fp2_add(a->c0, b->c0); r->c1 = fp2_add(a->c1, b->c1); r->c2 = fp2_add(a->c2, b->c2); }

@@ -46,6 +46,20 @@ void emul_g1_add(const uint8_t* a, const uint8_t* b, uint64_t n, uint8_t* out, u
 void emul_sign(const uint8_t* sks, const uint8_t* msgs, uint32_t mlen, uint64_t n, uint8_t* out96) { for (uint64_t i = 0; i < n; i++) op_sign(i, sks, msgs, mlen, out96); }
 void emul_sk_to_pk(const uint8_t* sks, int fmt, uint64_t n, uint8_t* out) { for (uint64_t i = 0; i < n; i++) op_sk_to_pk(i, sks, fmt, out); }
 void emul_hash_to_g2(const uint8_t* msgs, uint32_t mlen, uint64_t n, uint8_t* out96) { for (uint64_t i = 0; i < n; i++) op_hash_to_g2(i, msgs, mlen, out96); }
+// hash_to_field through the register-only function the hashing kernel uses (out: 4 x 12 words per item: u0.c0, u0.c1, u1.c0, u1.c1)
+// and through expand_message_xmd_256 + fp_from_two_digests (out_ref)
+void emul_hash_fields(const uint8_t* msgs, uint32_t mlen, uint64_t n, uint32_t* out, uint32_t* out_ref) {
+    mbls_ws ws; ws.stride = n ? n : 1; ws.w = (uint32_t*)calloc((size_t)49 * 12 * ws.stride, 4);
+    for (uint64_t i = 0; i < n; i++) {
+        hash_fields_to_ws(ws.w, ws.stride, i, msgs + (uint64_t)mlen * i, mlen);
+        const int slot[4] = {31, 32, 37, 38};
+        for (int q = 0; q < 4; q++) { fp v = ws_ld(ws, slot[q], i); for (int j = 0; j < 12; j++) out[(4 * i + q) * 12 + j] = v[j]; }
+        uint32_t ub[64];
+        expand_message_xmd_256(ub, msgs + (uint64_t)mlen * i, mlen, MBLS_DST_POP, MBLS_DST_POP_LEN);
+        for (int q = 0; q < 4; q++) { fp v = fp_from_two_digests(ub + 16 * q, ub + 16 * q + 8); for (int j = 0; j < 12; j++) out_ref[(4 * i + q) * 12 + j] = v[j]; }
+    }
+    free(ws.w);
+}
 void emul_fp_mul(const uint8_t* a, const uint8_t* b, uint64_t n, uint8_t* out, int op) { for (uint64_t i = 0; i < n; i++) op_fp_mul(i, n, a, b, out, op); }
 void emul_aggregate(const uint8_t* pks, int fmt, const uint32_t* offsets, uint64_t n, uint32_t k, uint8_t* out96, uint32_t* status) {
     mbls_ws ws; ws.stride = n ? n : 1; ws.w = (uint32_t*)calloc((size_t)MBLS_SLOT_COUNT * 12 * ws.stride, 4);

@@ -180,6 +180,13 @@ class _Ops(list):
             self.o.out_g[aux] = self.o.val[ins[0]]
         elif kind == "iszero":
             self.o.masks[aux] = 1 if self.o.val[ins[0]] % P == 0 else 0
+        elif kind == "mask_xor":
+            self.o.masks[aux[0]] = self.o.masks[aux[1]] ^ self.o.masks[aux[2]]
+        elif kind == "sgn0":                                 # the operands are plain integers: representation = value * 2^392
+            x0, x1 = (self.o.val[v] * R392 % P for v in ins)
+            self.o.masks[aux[0]] = (x0 & 1) | ((1 if x0 == 0 else 0) & (x1 & 1))
+        elif kind == "pow34":                                # like inv: the operand is x 2^-8
+            self.o.val[outs[0]] = pow(self.o.val[ins[0]] * 256, (P - 3) // 4, P)
         elif kind == "mask_and":
             self.o.masks[aux[0]] = self.o.masks[aux[1]] & self.o.masks[aux[2]]
         elif kind == "mask_orn2":
@@ -742,36 +749,37 @@ def test_g2_addition_cases():
         assert jac2_affine(M, *acc) == M.g2_add(a, b), case
 
 
-def test_g2_hash_tail_routine():
-    """q0 + q1 and the cofactor clearing through the routine's bodies in its control order (two full ladders) against the model's
-    clear_cofactor_g2 of the sum"""
+def test_g2_hash_routine():
+    """The message phase's generated routine through its bodies in its control order, from the two field elements u0, u1 to H: two
+    map_to_curve evaluations (run-time records 0 and 1), q0 + q1, the cofactor clearing with two full ladders -- against the Python
+    model (sswu_g2, iso3_g2, g2_add, clear_cofactor_g2)"""
     M = _g2m()
+    import gen_fp_asm as gf
     rng = random.Random(10)
-    def curve_point():
-        while True:
-            x = (rng.randrange(P), rng.randrange(P))
-            y = M.f2_sqrt(M.f2_add(M.f2_mul(M.f2_sqr(x), x), M.B2))
-            if y is not None:
-                return (x, y)
-    q0, q1 = curve_point(), curve_point()
+    S = t.G2_SLOTS
+    u = [(rng.randrange(P), rng.randrange(P)) for _ in range(2)]
     m, state, masks, step, add, ladder = g2_piece_runner("hash")
-    for base, pt in ((t.G2_SLOTS["Q0"], q0), (t.G2_SLOTS["Q1"], q1)):
-        z = (rng.randrange(1, P), rng.randrange(P)); z2 = M.f2_sqr(z)
-        j = [M.f2_mul(pt[0], z2), M.f2_mul(pt[1], M.f2_mul(z2, z)), z]
-        for e in range(3):
-            for i in range(2):
-                state[("g", base + 2 * e + i)] = j[e][i]
-                ws_put(m, base + 2 * e + i, j[e][i] * R384 % P)
+    m.routines.update(gf.pow_subroutines()); m.routines["mbls_fp_pow_pm3d4_asm_fn"] = gf.pow_body(gf.EXP_PM3D4)
+    full, pieces, _ = t.g2_group_routine("hash")
+    for rec in range(2):
+        for i in range(2):
+            ws_put(m, S["U"] + 6 * rec + i, u[rec][i] * R384 % P)
+        m.s[71] = rec * (STRIDE * 4 * 12 * 6)
+        m.run(pieces["sswu"])
+        mp = run_model(t.prog_sswu, {("gka", S["U"] + i): u[rec][i] for i in range(2)}, masks)
+        for slot, v in mp.out_g.items():
+            state[("gd", slot[1] + 6 * rec)] = v
     step("h_start"); add(); step("h_base1"); ladder(t.RUNS); step("h_after1"); step("dbl"); step("h_psi2"); add("sub")
     step("h_t3"); add(); step("h_base2"); ladder(t.RUNS); step("h_after2"); add()
     step("h_ad_t1"); add("sub"); step("h_ad_p"); add("sub")
     acc = [(state[("a", 2 * e)], state[("a", 2 * e + 1)]) for e in range(3)]
-    want = M.clear_cofactor_g2(M.g2_add(q0, q1))
+    want = M.clear_cofactor_g2(M.g2_add(M.iso3_g2(M.sswu_g2(u[0])), M.iso3_g2(M.sswu_g2(u[1]))))
     assert jac2_affine(M, *acc) == want and M.subgroup_check_g2(want)
-    m.run(t.g2_group_routine("hash")[1]["epi"][:-1])
+    m.run(pieces["epi"][:-1])
     ri = pow(R384, -1, P)
-    got = [(ws_get(m, t.G2_SLOTS["H"] + 2 * e) * ri % P, ws_get(m, t.G2_SLOTS["H"] + 2 * e + 1) * ri % P) for e in range(3)]
+    got = [(ws_get(m, S["H"] + 2 * e) * ri % P, ws_get(m, S["H"] + 2 * e + 1) * ri % P) for e in range(3)]
     assert jac2_affine(M, *got) == want
+
 
 
 def test_compressed_squaring_decompression_formulas():
@@ -806,3 +814,36 @@ def test_compressed_squaring_decompression_formulas():
         assert masks[t.TMASK] == (1 if zero_z2 else 0)
         for i in range(12):
             assert from_digits_signed(mch.a[14 * i:14 * i + 14]) * RI392 % P == mp.out_home[("a", i)], (zero_z2, i)
+
+
+def test_map_to_curve_body():
+    """simplified SWU + 3-isogeny on u (run-time record 0 and 1) against the Python model's sswu_g2 / iso3_g2: both square classes of
+    gx1 occur among the samples, and the degenerate u = 0 (tv2 = 0: the exceptional denominator)"""
+    M = _g2m()
+    import gen_fp_asm as gf
+    rout = dict(ROUT); rout.update(gf.pow_subroutines()); rout["mbls_fp_pow_pm3d4_asm_fn"] = gf.pow_body(gf.EXP_PM3D4)
+    body, _ = t.build_g2("sswu")
+    rng = random.Random(21)
+    S = t.G2_SLOTS
+    seen = set()
+    for trial, rec in ((0, 0), (1, 1), (2, 0), (3, 1), (4, 0)):
+        u = (rng.randrange(P), rng.randrange(P)) if trial < 4 else (0, 0)
+        m = Machine(rout); m.v[252] = LADDR
+        m.s[68] = GBASE & 0xFFFFFFFF; m.s[69] = GBASE >> 32; m.s[70] = STRIDE * 4
+        m.run(t.shell_constants())
+        m.s[71] = rec * (STRIDE * 4 * 12 * 6)
+        for i in range(2):
+            ws_put(m, S["U"] + 6 * rec + i, u[i] * R384 % P)
+        init, masks = {("gka", S["U"] + i): u[i] for i in range(2)}, {}
+        m.run(body)
+        mp = run_model(t.prog_sswu, init, masks)
+        seen.add(masks[t.M_SQ1])
+        got = []
+        for i in range(6):
+            rep = ws_get(m, S["Q0"] + 6 * rec + i)
+            assert (rep * RI392 - mp.out_g[("k", S["Q0"] + i)]) % P == 0, (trial, i)
+            got.append(rep * RI392 % P)
+        X, Y, Z = (got[0], got[1]), (got[2], got[3]), (got[4], got[5])
+        want = M.iso3_g2(M.sswu_g2(u))
+        assert jac2_affine(M, X, Y, Z) == want, trial
+    assert seen == {0, 1}

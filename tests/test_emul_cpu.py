@@ -127,3 +127,18 @@ def test_verify_mode_single_key(emul):
     b = helpers.make_batch(8, 1, fmt=0, seed=30)
     got, _ = _emul_verify(emul, b, mode=1)
     assert got == orc.batch_verify(b.sigs, b.msgs, b.pks, b.n, nthreads=4)
+
+
+def test_hash_to_field_register_only_path():
+    """hash_fields_to_ws (digests and message blocks by value, what the hashing kernel runs before its generated routine) against the
+    array-based expand_message_xmd_256 + fp_from_two_digests, for several message lengths incl. 0 and the multi-block 200"""
+    import ctypes as C, random
+    emu = helpers.load_emulator()
+    rnd = random.Random(17)
+    for mlen in (0, 1, 32, 55, 56, 64, 200):
+        n = 3
+        msgs = bytes(rnd.randrange(256) for _ in range(max(1, mlen * n)))
+        out = (C.c_uint32 * (48 * n))(); ref = (C.c_uint32 * (48 * n))()
+        emu.emul_hash_fields(msgs, C.c_uint32(mlen), C.c_uint64(n), out, ref)
+        assert list(out) == list(ref), mlen
+        assert any(out)

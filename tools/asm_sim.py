@@ -206,6 +206,8 @@ class Machine:
                 self.wr(args[0], r)
             elif op == "s_orn2_b64":
                 self.wr_carry(args[0], self.rd(args[1]) | (1 - self.rd(args[2])))
+            elif op == "s_xor_b64":
+                self.wr_carry(args[0], self.rd(args[1]) ^ self.rd(args[2]))
             elif op == "s_andn2_b64":
                 self.wr_carry(args[0], self.rd(args[1]) & (1 - self.rd(args[2])))
             elif op == "v_cmp_eq_u32_e64":

@@ -171,6 +171,22 @@ class Prog:
         d = self.new(); self.ops.append(("inv", [d], [r], None)); return d
 
     def mul2(self, a, b): return self.sqr2(a) if tuple(a) == tuple(b) else self.call("mul", [a[0], a[1], b[0], b[1]])
+    def pow34(self, a):
+        """a^((p-3)/4) by the fixed-exponent routine of tools/gen_fp_asm.py (same word interface as inv)"""
+        w = self.mulfp2((a, self.const(0)), self.const(K384))[0]
+        r = self.new(); self.ops.append(("reduce", [r], [w], None))
+        d = self.new(); self.ops.append(("pow34", [d], [r], None)); return d
+
+    def sgn0_2(self, a, mask, tmp):
+        """mask <- lanes in which sgn0(a) = 1 for the Fp2 value a (RFC 9380 section 4.1: parity of the plain representative of c0,
+        or of c1 when c0 = 0). The plain integers come out of a Montgomery product with the constant whose representation is 1."""
+        one = self.const(1)
+        x = self.mulpair(a[0], one, a[1], one)
+        self.ops.append(("sgn0", [], [x[0], x[1]], (mask, tmp)))
+
+    def mask_xor(self, dst, a, b):
+        self.ops.append(("mask_xor", [], [], (dst, a, b)))
+
     def neg2(self, a): return (self.neg(a[0]), self.neg(a[1]))
     def conj2(self, a): return (a[0], self.neg(a[1]))
     def neg6(self, a): return [self.neg2(c) for c in a]
@@ -461,7 +477,7 @@ class AllocD:
         self.stats = dict(vmov=0, acc=0, lds=0, arith=0, norm=0, reduce=0, calls=0, unpack=0)
         # values whose live-in location is a packed LDS slot ('lp', s) keep it as a read-only home: evicting a register copy of
         # such a value costs nothing, fetching it again is 6 LDS reads + the conversion into digits
-        self.home = {v: l for v, l in prog.init_loc.items() if l[0] in ("lp", "g", "gd", "gk")}
+        self.home = {v: l for v, l in prog.init_loc.items() if l[0] in ("lp", "g", "gd", "gk", "gka")}
         self.home_bound = {v: in_bounds[v] for v in self.home}
         self.vm = 0                                          # vector-memory operations issued so far (they retire in issue order)
         self.vm_mark = {}                                    # value -> count after the last load of its prefetch
@@ -515,10 +531,10 @@ class AllocD:
             for l in lds_read_words([reg(j + 2) for j in range(12)], 12 * sb) + WAIT_LDS + seq_conv(reg, [reg(j + 2) for j in range(12)], False):
                 self.e(l)
             self.stats["unpack"] += 30
-        elif sk in ("g", "gd", "gk") and dk == "v":
+        elif sk in ("g", "gd", "gk", "gka") and dk == "v":                 # gk / gka: gd / g in the record the run-time offset selects
             reg = lambda j: "v%d" % (vb(db) + j)
             self.wait_lds()
-            for l in seq_gload(reg, sb, aform=(sk == "g"), koff=(sk == "gk")):
+            for l in seq_gload(reg, sb, aform=(sk in ("g", "gka")), koff=(sk in ("gk", "gka"))):
                 self.e(l)
             self.stats["unpack"] += 60
         elif sk == "l" and dk == "v":
@@ -605,7 +621,7 @@ class AllocD:
         if l[0] == "vw":                                    # words prefetched into this block: wait for them, cut them into digits
             reg = lambda j: "v%d" % (vb(l[1]) + j)
             younger = min(self.vm - self.vm_mark[v], 63)     # operations issued after its loads may still be in flight
-            for x in ["s_waitcnt vmcnt(%d)" % younger, "s_nop 0"] + seq_conv(reg, [reg(j + 2) for j in range(12)], self.home[v][0] == "g"):
+            for x in ["s_waitcnt vmcnt(%d)" % younger, "s_nop 0"] + seq_conv(reg, [reg(j + 2) for j in range(12)], self.home[v][0] in ("g", "gka")):
                 self.e(x)
             del self.at[l]
             self.loc[v] = ("v", l[1]); self.at[("v", l[1])] = v
@@ -636,7 +652,7 @@ class AllocD:
         while j < len(self.p.ops) and calls < horizon:
             kind, outs, ins, aux = self.p.ops[j]
             for v in ins:
-                if self.loc.get(v, ("", 0))[0] in ("g", "gd", "gk") and v in self.home:
+                if self.loc.get(v, ("", 0))[0] in ("g", "gd", "gk", "gka") and v in self.home:
                     b = self.free_block("v", self.free_v)
                     if b is None:                            # take the block whose value is needed last, if that is later than this use
                         best, bu = None, j
@@ -656,7 +672,7 @@ class AllocD:
                             self.spill(w)
                         b = best
                     reg = lambda q, b=b: "v%d" % (vb(b) + q)
-                    for x in seq_gload(reg, self.home[v][1], aform=None, koff=(self.home[v][0] == "gk")):
+                    for x in seq_gload(reg, self.home[v][1], aform=None, koff=(self.home[v][0] in ("gk", "gka"))):
                         self.e(x)
                     self.vm_mark[v] = self.vm
                     self.loc[v] = ("vw", b); self.at[("vw", b)] = v
@@ -723,8 +739,12 @@ class AllocD:
                 self.e("s_orn2_b64 %s, %s, %s" % aux)
             elif kind == "mask_and":
                 self.e("s_and_b64 %s, %s, %s" % aux)
-            elif kind == "inv":
-                self.do_inv(k, outs[0], ins[0])
+            elif kind in ("inv", "pow34"):
+                self.do_inv(k, outs[0], ins[0], kind)
+            elif kind == "sgn0":
+                self.do_sgn0(k, ins[0], ins[1], aux)
+            elif kind == "mask_xor":
+                self.e("s_xor_b64 %s, %s, %s" % aux)
             elif kind == "scale":
                 self.do_scale(k, outs[0], ins[0], aux)
             elif kind == "shadd":
@@ -899,9 +919,39 @@ class AllocD:
         self.e("v_cmp_eq_u32_e64 %s, 0, %s" % (mask, TMP))
         self.stats["arith"] += 8
 
-    INV_CLOB_V, INV_CLOB_A = range(0, 7), range(0, 0)        # mbls_fp_inv_gcd_asm_fn: v0..v84, no AGPRs
+    # routines with the 12-word interface of tools/gen_fp_asm.py: (symbol, VGPR blocks, AGPR blocks they overwrite)
+    EXT = {"inv": ("mbls_fp_inv_gcd_asm_fn", range(0, 7), range(0, 0)),              # v0..v84, no AGPRs
+           "pow34": ("mbls_fp_pow_pm3d4_asm_fn", range(0, 7), range(0, 16))}         # v0..v84, a0..a223 (the window table)
 
-    def do_inv(self, k, d, a):
+    def do_sgn0(self, k, x0, x1, masks):
+        """x0, x1: plain integers mod p in digit form -> canonical digits -> s0 | (z0 & s1) as a lane mask"""
+        mask, tmp = masks
+        regs = []
+        for x in (x0, x1):
+            b = self.to_vgpr(x, k, avoid=tuple(regs))
+            self.wait_lds()
+            assert self.next_use(x, k + 1) == INF
+            reg = lambda j, b=b: "v%d" % (vb(b) + j)
+            B = self.bound[x]
+            red = B.vlo >= REDUCED.vlo and B.vhi <= REDUCED.vhi and B.dlo >= 0 and B.dhi <= M28
+            for l in ([] if red else seq_reduce(reg)) + seq_canonical(reg):
+                self.e(l)
+            regs.append(b)
+        b0, b1 = regs
+        self.e("v_or_b32_e64 %s, v%d, v%d" % (TMP, vb(b0), vb(b0) + 1))
+        for j in range(2, 14, 2):
+            self.e("v_or3_b32 %s, %s, v%d, v%d" % (TMP, TMP, vb(b0) + j, vb(b0) + j + 1))
+        self.e("v_cmp_eq_u32_e64 %s, 0, %s" % (tmp, TMP))                               # c0 = 0
+        self.e("v_and_b32_e64 %s, 1, v%d" % (TMP, vb(b1)))
+        self.e("v_cmp_ne_u32_e64 %s, 0, %s" % (mask, TMP))                              # parity of c1
+        self.e("s_and_b64 %s, %s, %s" % (mask, mask, tmp))
+        self.e("v_and_b32_e64 %s, 1, v%d" % (TMP, vb(b0)))
+        self.e("v_cmp_ne_u32_e64 %s, 0, %s" % (tmp, TMP))                               # parity of c0
+        self.e("s_or_b64 %s, %s, %s" % (mask, mask, tmp))
+        self.stats["arith"] += 14
+        self.release(x0); self.release(x1)
+
+    def do_inv(self, k, d, a, kind="inv"):
         """a: reduced value x * 2^384 (digit form) -> canonical words in v0..v11 -> the inversion routine -> words of x^-1 * 2^384,
         cut into digits of the 2^392 domain. Everything live leaves the registers that routine uses."""
         b = self.to_vgpr(a, k)
@@ -914,8 +964,9 @@ class AllocD:
             self.e(l)
         for blk in range(NV):                                 # prefetched words are rematerialisable: drop them
             self.drop_prefetch(blk)
-        safe_v = [x for x in self.free_v if x not in self.INV_CLOB_V and x != b]
-        safe_a = [x for x in self.a_pool if x not in self.INV_CLOB_A]
+        sym, CLOB_V, CLOB_A = self.EXT[kind]
+        safe_v = [x for x in self.free_v if x not in CLOB_V and x != b]
+        safe_a = [x for x in self.a_pool if x not in CLOB_A]
 
         def park(w, src):
             """live value w, currently readable in VGPR block src: to a place the exponentiation leaves alone"""
@@ -931,7 +982,7 @@ class AllocD:
             if ls is None:
                 raise RuntimeError("out of storage around the inversion")
             self.copy(("v", src), ("l", ls)); self.place(w, ("l", ls))
-        for blk in self.INV_CLOB_V:
+        for blk in CLOB_V:
             w = self.at.get(("v", blk))
             if w is None or w == a:
                 continue
@@ -939,8 +990,8 @@ class AllocD:
                 self.release(w)
             else:
                 park(w, blk)
-        tmp = next(x for x in self.INV_CLOB_V if x != b and ("v", x) not in self.at)
-        for blk in self.INV_CLOB_A:
+        tmp = next(x for x in CLOB_V if x != b and ("v", x) not in self.at)
+        for blk in CLOB_A:
             w = self.at.get(("a", blk))
             if w is None:
                 continue
@@ -955,7 +1006,7 @@ class AllocD:
             for j in range(12):
                 self.e("v_mov_b32_e64 v%d, v%d" % (j, vb(b) + j))
         self.e("s_waitcnt vmcnt(0)")
-        self.e("CALL mbls_fp_inv_gcd_asm_fn")
+        self.e("CALL " + sym)
         self.stats["calls"] += 1
         dst = lambda j: "v%d" % (vb(1) + j)
         for l in seq_conv(dst, ["v%d" % j for j in range(12)], True):
@@ -2029,6 +2080,88 @@ def pt_neg(p, pt):
     return [pt[0], p.neg2(pt[1]), pt[2]]
 
 
+# ---- map_to_curve (simplified SWU + 3-isogeny), formulas and case handling of map_to_curve_g2 in mbls_hash.h
+def read_product_constants(names):
+    """constants of milagro_bls_amd/csrc/mbls_constants.inc (32-bit limbs, 2^384 Montgomery form) as integers"""
+    import re
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "milagro_bls_amd", "csrc", "mbls_constants.inc")
+    txt = open(path).read()
+    ri = pow(1 << 384, -1, P)
+    out = {}
+    for nm in names:
+        m = re.search(r"MBLS_CONST uint32_t %s((?:\[\d+\])+) = (\{.*?\});" % nm, txt, re.S)
+        words = [int(w, 16) for w in re.findall(r"0x([0-9a-fA-F]{8})u", m.group(2))]
+        vals = [sum(words[12 * i + j] << (32 * j) for j in range(12)) * ri % P for i in range(len(words) // 12)]
+        out[nm] = vals
+    return out
+
+
+SSWU_A, SSWU_B, SSWU_Z = (0, 240), (1012, 1012), (P - 2, P - 1)
+SQRT_C5 = pow(5, (P + 1) // 4, P)                   # C5^2 = -5 = -norm(Z)
+INV2 = pow(2, -1, P)
+_ISO = read_product_constants(["MBLS_ISO3_XNUM", "MBLS_ISO3_YNUM", "MBLS_ISO3_K"])
+ISO3_XNUM = [(_ISO["MBLS_ISO3_XNUM"][2 * i], _ISO["MBLS_ISO3_XNUM"][2 * i + 1]) for i in range(4)]
+ISO3_YNUM = [(_ISO["MBLS_ISO3_YNUM"][2 * i], _ISO["MBLS_ISO3_YNUM"][2 * i + 1]) for i in range(4)]
+ISO3_K = tuple(_ISO["MBLS_ISO3_K"])
+M_SQ1, M_CHI, M_T0, M_S0, M_S1 = "s[48:49]", "s[50:51]", "s[52:53]", "s[54:55]", "s[84:85]"
+
+
+def prog_sswu():
+    """u (slots U, U + 1 of the record selected by the run-time offset; 2^384 domain) -> the point of E'(Fp2) in Jacobian coordinates
+    (slots Q0 .. Q0 + 5 of the same record, packed)"""
+    p = Prog()
+    S = G2_SLOTS
+    u = tuple(prog_reduce(p, p.live_in(("gka", S["U"] + i))) for i in range(2))
+    A, B, Z = c2(p, SSWU_A), c2(p, SSWU_B), c2(p, SSWU_Z)
+    fpc = lambda x: p.const(D392(x))
+    norm = lambda a: (lambda sq: p.add(sq[0], sq[1]))(p.mulpair(a[0], a[0], a[1], a[1]))
+    tv1 = p.mul2(Z, p.sqr2(u))
+    tv2 = p.add2(p.sqr2(tv1), tv1)
+    xn = p.mul2(B, (p.add(tv2[0], fpc(1)), tv2[1]))
+    p.iszero2(tv2, M_T0, G2M_TMP0)
+    xd = p.mul2(A, p.sel2(M_T0, p.neg2(tv2), Z))
+    xd2 = p.sqr2(xd); D = p.mul2(xd2, xd)
+    N = p.add2(p.mul2(p.add2(p.sqr2(xn), p.mul2(A, xd2)), xn), p.mul2(B, D))
+    g = p.mul2(N, D)
+    nd, nN = norm(xd), norm(N)
+    nd2 = p.mul1(nd, nd)
+    t_a, t_b = p.mulpair(nN, nd2, nd2, nd)                       # nN nd^2, nd^3
+    ng = p.mul1(nN, t_b)
+    w1 = p.pow34(ng)
+    s_, w1sq = p.mulpair(w1, ng, w1, w1)
+    p.iszero(p.sub(p.mul1(s_, s_), ng), M_SQ1)                   # gx1 is a square in Fp2
+    inv_ng = p.sel(M_SQ1, p.neg(w1sq), w1sq)                     # 1 / norm(g) = chi w1^2
+    inv_nd = p.mul1(t_a, inv_ng)
+    inv_xd = p.mulfp2(p.conj2(xd), inv_nd)
+    G = p.sel2(M_SQ1, p.mul2(tv1, g), g)
+    s_alt = p.mul1(p.mul1(norm(u), fpc(SQRT_C5)), s_)
+    Sr = p.sel(M_SQ1, s_alt, s_)
+    half = fpc(INV2)
+    t, t_alt = p.mulpair(p.add(G[0], Sr), half, p.sub(G[0], Sr), half)
+    p.iszero(t, M_CHI)
+    t = p.sel(M_CHI, t, t_alt)
+    w2 = p.pow34(t)
+    x0, w2sq = p.mulpair(w2, t, w2, w2)
+    p.iszero(p.sub(p.mul1(x0, x0), t), M_CHI)
+    g1h, x0w = p.mulpair(G[1], half, x0, w2sq)
+    other = p.mul1(g1h, x0w)
+    r = (p.sel(M_CHI, other, x0), p.sel(M_CHI, x0, other))
+    inv_D = p.mul2(p.sqr2(inv_xd), inv_xd)
+    x = p.mul2(xn, inv_xd); y = p.mul2(r, inv_D)
+    x = p.sel2(M_SQ1, p.mul2(tv1, x), x)
+    y = p.sel2(M_SQ1, p.mul2(tv1, y), y)
+    p.sgn0_2(u, M_S0, G2M_TMP0); p.sgn0_2(y, M_S1, G2M_TMP0); p.mask_xor(M_S0, M_S0, M_S1)
+    y = p.sel2(M_S0, y, p.neg2(y))
+    xnum, ynum = c2(p, ISO3_XNUM[3]), c2(p, ISO3_YNUM[3])
+    for i in (2, 1, 0):
+        xnum = p.add2(p.mul2(xnum, x), c2(p, ISO3_XNUM[i]))
+        ynum = p.add2(p.mul2(ynum, x), c2(p, ISO3_YNUM[i]))
+    out = [xnum, p.mul2(y, ynum), p.add2(x, c2(p, ISO3_K))]
+    for i, v in enumerate([c for pt in out for c in pt]):
+        p.ops.append(("storep", [], [v], ("k", S["Q0"] + i)))
+    return p
+
+
 def prog_g2_add(ad_slot, negate):
     """acc <- acc +- (the point in slots ad_slot..ad_slot+5); the old acc goes to AGPR blocks 6..11 for the doubling case; masks M_H0,
     M_R0 (same x / same y), M_INF1, M_INF2 (an operand at infinity)"""
@@ -2060,7 +2193,7 @@ def prog_g2_add(ad_slot, negate):
 
 # slots 0..12 hold the phases' results (sum of keys, signature, H) and 25..30 the n-pairing paths' G2 accumulator, which other kernels may be
 # writing or keeping meanwhile: the hash routine's scratch is 13..24 and 31..42, the signature routine's 43..48
-G2_SLOTS = dict(AD=13, P=31, T1=37, T2=19, T3=7, Q0=7, Q1=19, SIGAD=43, SIG=3, H=7)
+G2_SLOTS = dict(AD=19, P=31, T1=37, T2=13, T3=7, Q0=7, Q1=13, SIGAD=43, SIG=3, H=7, U=31)      # U: u0 in 31, 32; u1 in 37, 38
 
 
 def prog_g2_glue(which):
@@ -2070,10 +2203,8 @@ def prog_g2_glue(which):
     acc = lambda: pt_live_in(p, "a", 0)
     gd = lambda name: pt_live_in(p, "gd", S[name])
     one = lambda: (p.const(ONE_D), p.const(0))
-    if which == "h_start":                           # acc = q0, AD = q1 (the map_to_curve outputs, 2^384 domain words)
-        q0 = [tuple(prog_reduce(p, x) for x in c) for c in pt_live_in(p, "g", S["Q0"])]
-        q1 = [tuple(prog_reduce(p, x) for x in c) for c in pt_live_in(p, "g", S["Q1"])]
-        pt_park(p, q1, S["AD"]); pt_store_acc(p, q0)
+    if which == "h_start":                           # acc = q0, AD = q1 (the map_to_curve outputs, packed by the sswu body)
+        pt_park(p, gd("Q1"), S["AD"]); pt_store_acc(p, gd("Q0"))
     elif which == "h_base1":                         # p = q0 + q1: remember it, and it is the ladder's base
         a = acc(); pt_park(p, a, S["P"]); pt_park(p, a, S["AD"]); pt_store_acc(p, a)
     elif which == "h_after1":                        # t1 = -[|x|]p; t2 = psi(p); acc = p (to be doubled)
@@ -2117,9 +2248,11 @@ def build_g2(which, ad_slot=None):
         p = prog_g2_dbl_d()
     elif which == "fix":
         p = prog_g2_dbl_d(6, 0)
+    elif which == "sswu":
+        p = prog_sswu()
     else:
         p = prog_g2_glue(which)
-    inb = {v: (G2_IN if l[0] == "a" else PACKED if l[0] == "gd" else G_IN) for v, l in p.init_loc.items()}
+    inb = {v: (G2_IN if l[0] == "a" else PACKED if l[0] in ("gd", "gk") else G_IN) for v, l in p.init_loc.items()}      # g, gka: 2^384-domain words
     al = AllocD(p, inb, n_lds=11, lds_base=0, a_pool=list(range(NA)))
     body = al.run()
     for dst, B in getattr(al, "stored", {}).items():
@@ -2140,7 +2273,7 @@ def g2_group_routine(kind):
     ad = S["AD"] if kind == "hash" else S["SIGAD"]
     B = {}
     st = {}
-    names = ["add", "dbl", "fix"] + (["sub", "h_start", "h_base1", "h_after1", "h_psi2", "h_t3", "h_base2", "h_after2", "h_ad_t1", "h_ad_p"] if kind == "hash" else ["s_start", "s_compare"])
+    names = ["add", "dbl", "fix"] + (["sswu", "sub", "h_start", "h_base1", "h_after1", "h_psi2", "h_t3", "h_base2", "h_after2", "h_ad_t1", "h_ad_p"] if kind == "hash" else ["s_start", "s_compare"])
     for nm in names:
         B[nm], st[nm] = build_g2(nm, ad)
     X = lambda nm: expand_calls_d(B[nm])
@@ -2164,7 +2297,9 @@ def g2_group_routine(kind):
     def call_ladder():
         return ["s_getpc_b64 s[96:97]", "7:", "s_add_u32 s96, s96, 8f-7b", "s_addc_u32 s97, s97, 0"] + far_fwd(LADDER) + ["8:"]
     if kind == "hash":
-        main = X("h_start") + call_sub(ADD) + X("h_base1") + call_ladder() + X("h_after1") + X("dbl") + X("h_psi2") + call_sub(SUB)
+        # the two map_to_curve evaluations: u0 -> q0, u1 -> q1 (records six slots apart)
+        main = ["s_mul_i32 s72, %s, %d" % (GSTRIDE, 12 * 6), "s_mov_b32 %s, 0" % GKOFF] + X("sswu") + ["s_mov_b32 %s, s72" % GKOFF] + X("sswu")
+        main += X("h_start") + call_sub(ADD) + X("h_base1") + call_ladder() + X("h_after1") + X("dbl") + X("h_psi2") + call_sub(SUB)
         main += X("h_t3") + call_sub(ADD) + X("h_base2") + call_ladder() + X("h_after2") + call_sub(ADD)
         main += X("h_ad_t1") + call_sub(SUB) + X("h_ad_p") + call_sub(SUB)
         epi = ["s_waitcnt vmcnt(0)"]
@@ -2222,7 +2357,7 @@ def main():
         full, pieces, st = g2_group_routine(kind)
         txt += emit(macro, full) + "\n"
         print("g2 group routine", kind, len(full), "lines; add", len(pieces["add"]), st["add"])
-    sgg = sgm.replace('"vcc"', ",".join('"s%d"' % i for i in list(range(50, 54)) + list(range(79, 100))) + ',"vcc"')
+    sgg = sgm.replace('"vcc"', ",".join('"s%d"' % i for i in list(range(50, 54)) + [71, 72] + list(range(79, 100))) + ',"vcc"')
     txt += "#define MBLS_G2_GROUP_D_ASM_CLOBBERS %s,%s, \\\n    %s\n" % (
         ",".join('"v%d"' % i for i in range(256) if i not in (251, 252) and i not in UNTOUCHED_V), ",".join('"a%d"' % i for i in range(252)), sgg)
     full, pieces, st = g2_dbl_d_routine()
