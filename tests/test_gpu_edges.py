@@ -354,6 +354,29 @@ def test_keytable_device_entry_at_batch_size(N):
     assert torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][2], outs[1][2])
 
 
+def test_key_buffer_alignment_paths_agree(N):
+    """The generated key-sum routine fetches keys with 16-byte loads and is used for 4-byte aligned key buffers; any other address goes
+    through the compiled lane body. The same 96-byte keys at offsets 0, 1, 2 and 4 inside a device buffer must give identical results."""
+    import torch
+    import bench
+    ctx = N.default_context()
+    dev = torch.device("cuda:0")
+    n, k = 256, 16
+    d_sigs, d_msgs, d_pks, expect = bench.build_inputs(ctx, dev, n, k, N.PK_UNCOMPRESSED, rank=9)[:4]
+    flat = d_pks.reshape(-1)
+    outs = []
+    for off in (0, 1, 2, 4):
+        buf = torch.zeros(flat.numel() + 8, dtype=torch.uint8, device=dev)
+        buf[off:off + flat.numel()] = flat
+        d_res = torch.zeros(n, dtype=torch.uint8, device=dev); d_st = torch.zeros(n, dtype=torch.int32, device=dev)
+        ctx.check(N.lib().mbls_fast_aggregate_verify_batch_device(ctx.handle, d_sigs.data_ptr(), d_msgs.data_ptr(), 32, buf.data_ptr() + off, N.PK_UNCOMPRESSED,
+                                                                  None, n, k, d_res.data_ptr(), None, d_st.data_ptr(), None))
+        torch.cuda.synchronize()
+        outs.append((d_res.cpu(), d_st.cpu()))
+    for r, st in outs:
+        assert torch.equal(r, expect) and torch.equal(st, outs[0][1])
+
+
 # ------------------------------------------------------------------------------------------------ batched AggregateSignature::aggregate
 def test_aggregate_signatures_batch_vs_oracle(mb):
     rnd = random.Random(17)
