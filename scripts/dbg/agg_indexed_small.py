@@ -1,6 +1,6 @@
 """dev: indexed public-key sum on a tiny batch (run under `timeout`)"""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 for q in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "oracle", "pymodel"), os.path.join(ROOT, "tests")):
     sys.path.insert(0, q)
 import helpers, orc
