@@ -12,7 +12,7 @@ conditionally reduced on exit) a routine here is only the two interleaved produc
 its operand registers survive the call.
 
 Register contract (blocks of 14 VGPRs, block i = v[14 i .. 14 i + 13]):
-    mbls_fp2_mul_d_asm_fn    a0 blk0, a1 blk1, b0 blk2, b1 blk3 (preserved)  ->  c0 blk5, c1 blk6   (blk4 = -b1, v98..v101 accumulators)
+    mbls_fp2_mul_d_asm_fn    a0 blk0, a1 blk1, b0 blk2, b1 blk3 (preserved)  ->  c0 blk5, c1 blk6   (blk4 = a0-a1, blk8 = b1-b0, v98..v101 + v108..v111 accumulators)
     mbls_fp2_sqr_d_asm_fn    a0 blk0, a1 blk1 (preserved)                    ->  c0 blk5, c1 blk6   (blk2..4 = a0+a1, a0-a1, 2 a1)
     mbls_fp2_mulfp_d_asm_fn  a0 blk0, a1 blk1, s blk2 (preserved)            ->  a0 s blk5, a1 s blk6
     mbls_fp_mulpair_d_asm_fn a0 blk0, a1 blk1, b0 blk2, b1 blk3 (preserved)  ->  a0 b0 blk5, a1 b1 blk6   (two independent Fp products)
@@ -66,9 +66,39 @@ def signed_scan(pairs, out, acc, cy):
 
 
 def fp2_mul_d_body():
-    A0, A1, B0, B1, NB, C0, C1 = BLK(0), BLK(1), BLK(2), BLK(3), BLK(4), BLK(5), BLK(6)
-    L = ["v_sub_u32_e64 %s, 0, %s" % (NB(j), B1(j)) for j in range(14)]                      # -b1: c0 = a0 b0 - a1 b1
-    L += zip2(signed_scan([(A0, B0), (A1, NB)], C0, ACC_A, CARRY_A), signed_scan([(A0, B1), (A1, B0)], C1, ACC_B, CARRY_B))
+    """c0 = a0 b0 - a1 b1, c1 = a0 b1 + a1 b0 with THREE products: Karatsuba on the 64-bit column sums, in the subtractive form
+    c1 = (a0 - a1)(b1 - b0) + a0 b0 + a1 b1 (differences of non-negative digits are no larger than the digits, so the input limits stay
+    those of four plain scans). Both scans walk the columns in lockstep; X_k = sum a0_i b0_(k-i) and Y_k = sum a1_i b1_(k-i) are formed
+    once per column (fresh accumulators), the third product accumulates straight into c1's scan, and c0's scan receives X_k - Y_k, c1's
+    X_k + Y_k: 3 n + 5 instructions per column instead of 4 n. Measured in isolation (scripts/dbg/fp2dbench.hip): 5 % faster."""
+    A0, A1, B0, B1, DA, C0, C1, DB = BLK(0), BLK(1), BLK(2), BLK(3), BLK(4), BLK(5), BLK(6), BLK(8)
+    ACC0, ACC1, X, Y = "v[98:99]", "v[100:101]", "v[108:109]", "v[110:111]"          # v102..v107 stay untouched (see gen_tower_d.py)
+    L = []
+    for j in range(14):
+        L += ["v_sub_u32_e64 %s, %s, %s" % (DA(j), A0(j), A1(j)), "v_sub_u32_e64 %s, %s, %s" % (DB(j), B1(j), B0(j))]
+    first0 = first1 = True
+    for k in range(28):
+        idx = list(range(max(0, k - 13), min(k, 13) + 1))
+        fx = True
+        for i in idx:                                   # three independent chains, interleaved
+            L.append("v_mad_i64_i32 %s, vcc, %s, %s, %s" % (X, A0(i), B0(k - i), "0" if fx else X))
+            L.append("v_mad_i64_i32 %s, s[62:63], %s, %s, %s" % (Y, A1(i), B1(k - i), "0" if fx else Y)); fx = False
+            L.append("v_mad_i64_i32 %s, vcc, %s, %s, %s" % (ACC1, DA(i), DB(k - i), "0" if first1 else ACC1)); first1 = False
+        for i in (range(k) if k < 14 else range(k - 13, 14)):                       # the Montgomery quotient digits times p, both scans
+            L.append("v_mad_i64_i32 %s, vcc, %s, %s, %s" % (ACC0, SP28(k - i), C0(i), "0" if first0 else ACC0)); first0 = False
+            L.append("v_mad_i64_i32 %s, s[62:63], %s, %s, %s" % (ACC1, SP28(k - i), C1(i), ACC1))
+        if idx:
+            L += ["v_lshl_add_u64 %s, %s, 0, %s" % (ACC1, X, ACC1), "v_lshl_add_u64 %s, %s, 0, %s" % (ACC1, Y, ACC1)]                   # + X + Y
+            L += ["v_sub_co_u32_e64 v108, vcc, v108, v110", "v_subb_co_u32_e64 v109, vcc, v109, v111, vcc"]                            # X - Y
+            L.append("v_mov_b64_e64 %s, %s" % (ACC0, X) if first0 else "v_lshl_add_u64 %s, %s, 0, %s" % (ACC0, X, ACC0)); first0 = False
+        for (out, A, lo, cy) in ((C0, ACC0, "v98", "vcc"), (C1, ACC1, "v100", "s[62:63]")):
+            if k < 14:
+                L += ["v_mul_lo_u32 %s, %s, %s" % (out(k), lo, SNP28), "v_and_b32_e64 %s, %s, %s" % (out(k), out(k), SMASK28),
+                      "v_mad_i64_i32 %s, %s, %s, %s, %s" % (A, cy, SP28(0), out(k), A), "v_ashrrev_i64 %s, 28, %s" % (A, A)]
+            elif k < 27:
+                L += ["v_and_b32_e64 %s, %s, %s" % (out(k - 14), lo, SMASK28), "v_ashrrev_i64 %s, 28, %s" % (A, A)]
+            else:
+                L.append("v_mov_b32_e64 %s, %s" % (out(13), lo))
     return L
 
 

@@ -205,8 +205,8 @@ PTOP = P >> 364                      # top digit of p
 INF = 1 << 60
 NV, NA = 18, 18                      # VGPR / AGPR blocks of 14
 WIN_IN = [0, 1, 2, 3]
-FREE_V = list(range(8, 18))
-ALL_V = FREE_V + [3, 2, 1, 0, 4, 6, 5]          # block 7 holds the routines' accumulators: never a home
+FREE_V = list(range(9, 18))                     # blocks no routine overwrites (block 8 is scratch of the Fp2 product)
+ALL_V = FREE_V + [8, 3, 2, 1, 0, 4, 6, 5]       # block 7 holds the routines' accumulators: never a home
 LADDR, TMP = "v252", "v254"             # v253: -q of reduce, v[254:255]: its 64-bit running sum; v254 also the carry of norm
 
 
@@ -219,7 +219,7 @@ def vb(b):
 
 
 ROUTINES = {
-    "mul": dict(name="mbls_fp2_mul_d_asm_fn", ins=[0, 1, 2, 3], outs=[5, 6], clob=[4, 5, 6, 7]),
+    "mul": dict(name="mbls_fp2_mul_d_asm_fn", ins=[0, 1, 2, 3], outs=[5, 6], clob=[4, 5, 6, 7, 8]),
     "sqr": dict(name="mbls_fp2_sqr_d_asm_fn", ins=[0, 1], outs=[5, 6], clob=[2, 3, 4, 5, 6, 7]),
     "mulfp": dict(name="mbls_fp2_mulfp_d_asm_fn", ins=[0, 1, 2], outs=[5, 6], clob=[5, 6, 7]),
     "mulpair": dict(name="mbls_fp_mulpair_d_asm_fn", ins=[0, 1, 2, 3], outs=[5, 6], clob=[5, 6, 7]),     # (a0 b0, a1 b1)
@@ -462,7 +462,7 @@ class AllocD:
     def __init__(self, prog, in_bounds, n_lds=0, lds_base=0, a_pool=None, free_v=None):
         self.p = prog
         self.free_v = list(FREE_V) if free_v is None else list(free_v)     # VGPR blocks outside the routines' window
-        self.all_v = self.free_v + [3, 2, 1, 0, 4, 6, 5]
+        self.all_v = self.free_v + ([8] if 8 not in self.free_v else []) + [3, 2, 1, 0, 4, 6, 5]
         self.uses = {}
         for k, (kind, outs, ins, aux) in enumerate(prog.ops):
             for v in ins:
@@ -1042,8 +1042,10 @@ class AllocD:
 
     def call_limits_ok(self, kind, B):
         m = [x.mag() for x in B]
-        if kind == "mul":
-            return column_ok([(m[0], m[2]), (m[1], m[3])]) and column_ok([(m[0], m[3]), (m[1], m[2])])
+        if kind == "mul":                                   # Karatsuba on column sums: the third product is (a0 - a1)(b1 - b0)
+            da, db = (B[0] - B[1]), (B[3] - B[2])
+            return (da.fits() and db.fits() and column_ok([(m[0], m[2]), (m[1], m[3])]) and column_ok([(m[0], m[3]), (m[1], m[2])])
+                    and column_ok([(da.mag(), db.mag())]))
         if kind == "sqr":
             s = B[0] + B[1]; dd = B[0] - B[1]
             return s.fits() and dd.fits() and 2 * m[1] < (1 << 31) and column_ok([(s.mag(), dd.mag())]) and column_ok([(m[0], 2 * m[1])])
@@ -1091,8 +1093,8 @@ class AllocD:
                 self.to_vgpr(v, k)
             src = self.loc[v]
             self.copy(src, ("v", s))
-            if src[0] != "v" or self.next_use(v, k + 1) == INF:
-                self.place(v, ("v", s))                          # moved (its old home is free again) ...
+            if src[0] != "v" or self.next_use(v, k + 1) == INF or src[1] in clob:
+                self.place(v, ("v", s))                          # moved (its old home is free again, or about to be overwritten) ...
             # ... or copied: the original stays where it was, the slot copy is untracked and dies with the next operand load
         for s in slots[:len(ins)]:
             w = self.at.get(("v", s))
