@@ -1,11 +1,11 @@
 // time two bodies of the digit-form Fp2 product in isolation, one wave per SIMD (dev tool): four plain column scans against
-// Karatsuba on shared column sums (3 products, 64-bit combinations per column). scripts/dbg/fp2d_variants.inc is written by the
-// experiment script in the git history of this file's commit.
+// Karatsuba on shared column sums (3 products, 64-bit combinations per column). python3 scripts/dbg/gen_fp2d_variants.py writes the
+// include file. The Karatsuba body uses block 8 and v108..v111 as scratch.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdint.h>
 #include "fp2d_variants.inc"
-#define ALLV "v0","v1","v2","v3","v4","v5","v6","v7","v8","v9","v10","v11","v12","v13","v14","v15","v16","v17","v18","v19","v20","v21","v22","v23","v24","v25","v26","v27","v28","v29","v30","v31","v32","v33","v34","v35","v36","v37","v38","v39","v40","v41","v42","v43","v44","v45","v46","v47","v48","v49","v50","v51","v52","v53","v54","v55","v56","v57","v58","v59","v60","v61","v62","v63","v64","v65","v66","v67","v68","v69","v70","v71","v72","v73","v74","v75","v76","v77","v78","v79","v80","v81","v82","v83","v84","v85","v86","v87","v88","v89","v90","v91","v92","v93","v94","v95","v96","v97","v98","v99","v100","v101","v102","v103","v104","v105","v106","v107","v112","v113","v114","v115","v116","v117","v118","v119","v120","v121","v122","v123","v124","v125","v126","v127","v128","v129","v130","v131","v132","v133","v134","v135","v136","v137","v138","v139"
+#define ALLV "v0","v1","v2","v3","v4","v5","v6","v7","v8","v9","v10","v11","v12","v13","v14","v15","v16","v17","v18","v19","v20","v21","v22","v23","v24","v25","v26","v27","v28","v29","v30","v31","v32","v33","v34","v35","v36","v37","v38","v39","v40","v41","v42","v43","v44","v45","v46","v47","v48","v49","v50","v51","v52","v53","v54","v55","v56","v57","v58","v59","v60","v61","v62","v63","v64","v65","v66","v67","v68","v69","v70","v71","v72","v73","v74","v75","v76","v77","v78","v79","v80","v81","v82","v83","v84","v85","v86","v87","v88","v89","v90","v91","v92","v93","v94","v95","v96","v97","v98","v99","v100","v101","v102","v103","v104","v105","v106","v107","v108","v109","v110","v111","v112","v113","v114","v115","v116","v117","v118","v119","v120","v121","v122","v123","v124","v125","v126","v127","v128","v129","v130","v131","v132","v133","v134","v135","v136","v137","v138","v139"
 #define ALLS "s40","s41","s42","s43","s44","s45","s46","s47","s56","s57","s58","s59","s60","s61","s62","s63","s64","s65","vcc","scc"
 template <int V> __global__ void __launch_bounds__(64) kern(uint32_t* out, int iters) {
     uint32_t seed = threadIdx.x * 2654435761u + blockIdx.x;

@@ -847,3 +847,19 @@ def test_map_to_curve_body():
         want = M.iso3_g2(M.sswu_g2(u))
         assert jac2_affine(M, X, Y, Z) == want, trial
     assert seen == {0, 1}
+
+
+def test_three_product_and_four_scan_fp2_multiplication_agree():
+    """Karatsuba on the column sums must leave exactly the digits the four plain scans leave (same quotient digits, same results)"""
+    rng = random.Random(77)
+    for trial in range(6):
+        vals = [rng.randrange(-3 * P, 4 * P) for _ in range(4)]
+        out = []
+        for body in (d.fp2_mul_d_body(), d.fp2_mul_d4_body()):
+            m = Machine(); m.run(d.load_constants())
+            r2 = random.Random(trial)
+            for i, x in enumerate(vals):
+                m.v[14 * i:14 * i + 14] = digits_signed(x, 1 << 28, r2)
+            m.run(body)
+            out.append(list(m.v[70:98]))
+        assert out[0] == out[1], trial

@@ -102,6 +102,15 @@ def fp2_mul_d_body():
     return L
 
 
+def fp2_mul_d4_body():
+    """the same product as four plain scans (two merged pairs): the form fp2_mul_d_body replaced; kept as the reference of
+    scripts/dbg/fp2dbench.hip and of the tests (both bodies must give identical digits)"""
+    A0, A1, B0, B1, NB, C0, C1 = BLK(0), BLK(1), BLK(2), BLK(3), BLK(4), BLK(5), BLK(6)
+    L = ["v_sub_u32_e64 %s, 0, %s" % (NB(j), B1(j)) for j in range(14)]                      # -b1: c0 = a0 b0 - a1 b1
+    L += zip2(signed_scan([(A0, B0), (A1, NB)], C0, ACC_A, CARRY_A), signed_scan([(A0, B1), (A1, B0)], C1, ACC_B, CARRY_B))
+    return L
+
+
 def fp2_sqr_d_body():
     A0, A1, S, D, A1D, C0, C1 = BLK(0), BLK(1), BLK(2), BLK(3), BLK(4), BLK(5), BLK(6)
     L = []
