@@ -88,6 +88,7 @@ MBLS_FN void lane_aggregate(const mbls_ws& ws, uint64_t i, const uint8_t* pks, u
 #if MBLS_DEVICE_ASM && !defined(MBLS_NO_FP2_ASM)
 extern "C" __device__ __attribute__((noinline, used, aligned(64))) void mbls_fp_mulpair_d_asm_fn() { asm volatile(MBLS_FP_MULPAIR_D_ASM); }
 extern "C" __device__ __attribute__((noinline, used, aligned(64))) void mbls_fp_mul1_d_asm_fn() { asm volatile(MBLS_FP_MUL1_D_ASM); }
+extern "C" __device__ __attribute__((noinline, used, aligned(64))) void mbls_fp_sqrpair_d_asm_fn() { asm volatile(MBLS_FP_SQRPAIR_D_ASM); }
 extern "C" __device__ __attribute__((noinline, used, aligned(64))) void mbls_g1_aggregate_raw_d_asm_fn() { asm volatile(MBLS_G1_AGGREGATE_RAW_D_ASM); }
 extern "C" __device__ __attribute__((noinline, used, aligned(64))) void mbls_g1_aggregate_indexed_d_asm_fn() { asm volatile(MBLS_G1_AGGREGATE_INDEXED_D_ASM); }
 template <bool INDEXED>

@@ -231,7 +231,9 @@ class ModelProg(Prog):
         if kind == "mul1":
             self.val[o[0]] = x[0] * x[1] % P
             return (o[0],)
-        if kind == "mulpair":
+        if kind == "sqrpair":
+            r = (x[0] * x[0] % P, x[1] * x[1] % P)
+        elif kind == "mulpair":
             r = (x[0] * x[2] % P, x[1] * x[3] % P)
         elif kind == "mul":
             r = ((x[0] * x[2] - x[1] * x[3]) % P, (x[0] * x[3] + x[1] * x[2]) % P)
@@ -863,3 +865,30 @@ def test_three_product_and_four_scan_fp2_multiplication_agree():
             m.run(body)
             out.append(list(m.v[70:98]))
         assert out[0] == out[1], trial
+
+
+def test_paired_fp_products_and_squarings():
+    """fp_mulpair_d, fp_mul1_d, fp_sqrpair_d on redundant signed digits at the generator's limits; the squaring scan (cross products once,
+    against doubled digits) must leave exactly the digits of the product scan"""
+    rng = random.Random(78)
+    for trial in range(8):
+        dm = [1 << 28, 1 << 29][trial % 2]
+        vals = [rng.randrange(-3 * P, 4 * P) for _ in range(4)]
+        m = Machine(); m.run(d.load_constants())
+        for i, x in enumerate(vals):
+            m.v[14 * i:14 * i + 14] = digits_signed(x, dm, rng)
+        a_digits = [list(m.v[0:14]), list(m.v[14:28])]
+        m.run(d.fp_mulpair_d_body())
+        c0, c1 = from_digits_signed(m.v[70:84]), from_digits_signed(m.v[84:98])
+        assert (c0 - vals[0] * vals[2] * RI) % P == 0 and (c1 - vals[1] * vals[3] * RI) % P == 0
+        m.run(d.fp_mul1_d_body())
+        assert (from_digits_signed(m.v[70:84]) - vals[0] * vals[2] * RI) % P == 0
+        m2 = Machine(); m2.run(d.load_constants())
+        m2.v[0:14], m2.v[14:28] = a_digits
+        m2.run(d.fp_sqrpair_d_body())
+        s0, s1 = from_digits_signed(m2.v[70:84]), from_digits_signed(m2.v[84:98])
+        assert (s0 - vals[0] * vals[0] * RI) % P == 0 and (s1 - vals[1] * vals[1] * RI) % P == 0
+        m3 = Machine(); m3.run(d.load_constants())
+        m3.v[0:14], m3.v[14:28], m3.v[28:42], m3.v[42:56] = a_digits[0], a_digits[1], a_digits[0], a_digits[1]
+        m3.run(d.fp_mulpair_d_body())
+        assert list(m3.v[70:98]) == list(m2.v[70:98])

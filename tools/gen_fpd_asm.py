@@ -17,6 +17,7 @@ Register contract (blocks of 14 VGPRs, block i = v[14 i .. 14 i + 13]):
     mbls_fp2_mulfp_d_asm_fn  a0 blk0, a1 blk1, s blk2 (preserved)            ->  a0 s blk5, a1 s blk6
     mbls_fp_mulpair_d_asm_fn a0 blk0, a1 blk1, b0 blk2, b1 blk3 (preserved)  ->  a0 b0 blk5, a1 b1 blk6   (two independent Fp products)
     mbls_fp_mul1_d_asm_fn    a0 blk0, b0 blk2 (preserved)                    ->  a0 b0 blk5
+    mbls_fp_sqrpair_d_asm_fn a0 blk0, a1 blk1 (preserved)                    ->  a0^2 blk5, a1^2 blk6   (blk2, blk3 = doubled digits)
 Resident constants (loaded once by the calling routine's shell, load_constants()): digits of p in s40-s47, s56-s61, -p^-1 mod 2^28
 in s64, the digit mask in s65. Carries: vcc and s[62:63]. Results: digits 0..12 in [0, 2^28), digit 13 signed (the value lies in
 (-X, p + X) with X = sum |a||b| / 2^392, a tiny multiple of p for every operand the callers produce).
@@ -132,13 +133,51 @@ def fp_mulpair_d_body():
     return zip2(signed_scan([(A0, B0)], C0, ACC_A, CARRY_A), signed_scan([(A1, B1)], C1, ACC_B, CARRY_B))
 
 
+def signed_sqr_scan(X, D, out, acc, cy):
+    """X^2, Montgomery-reduced: the cross products once, against the doubled digit vector D (exact: digits carry no carries)"""
+    A, lo = "v[%d:%d]" % (acc, acc + 1), "v%d" % acc
+    S, first = [], True
+    for k in range(28):
+        macs = []
+        for i in range(max(0, k - 13), min(k, 13) + 1):
+            j = k - i
+            if i < j:
+                macs.append((X(i), D(j)))
+            elif i == j:
+                macs.append((X(i), X(i)))
+        if k < 14:
+            macs += [(SP28(k - i), out(i)) for i in range(k)]
+        else:
+            macs += [(SP28(k - i), out(i)) for i in range(k - 13, 14)]
+        for (x, y) in macs:
+            S.append("v_mad_i64_i32 %s, %s, %s, %s, %s" % (A, cy, x, y, "0" if first else A)); first = False
+        if k < 14:
+            S += ["v_mul_lo_u32 %s, %s, %s" % (out(k), lo, SNP28), "v_and_b32_e64 %s, %s, %s" % (out(k), out(k), SMASK28),
+                  "v_mad_i64_i32 %s, %s, %s, %s, %s" % (A, cy, SP28(0), out(k), A), "v_ashrrev_i64 %s, 28, %s" % (A, A)]
+        elif k < 27:
+            S += ["v_and_b32_e64 %s, %s, %s" % (out(k - 14), lo, SMASK28), "v_ashrrev_i64 %s, 28, %s" % (A, A)]
+        else:
+            S.append("v_mov_b32_e64 %s, %s" % (out(13), lo))
+    return S
+
+
+def fp_sqrpair_d_body():
+    """two independent Fp squarings a0^2, a1^2 (blocks 2, 3 = the doubled digits)"""
+    A0, A1, D0, D1, C0, C1 = BLK(0), BLK(1), BLK(2), BLK(3), BLK(5), BLK(6)
+    L = []
+    for j in range(14):
+        L += ["v_lshlrev_b32_e64 %s, 1, %s" % (D0(j), A0(j)), "v_lshlrev_b32_e64 %s, 1, %s" % (D1(j), A1(j))]
+    return L + zip2(signed_sqr_scan(A0, D0, C0, ACC_A, CARRY_A), signed_sqr_scan(A1, D1, C1, ACC_B, CARRY_B))
+
+
 def fp_mul1_d_body():
     """one Fp product: a0 b0"""
     return signed_scan([(BLK(0), BLK(2))], BLK(5), ACC_A, CARRY_A)
 
 
 ROUTINE_BODIES = {"mbls_fp2_mul_d_asm_fn": fp2_mul_d_body, "mbls_fp2_sqr_d_asm_fn": fp2_sqr_d_body, "mbls_fp2_mulfp_d_asm_fn": fp2_mulfp_d_body,
-                  "mbls_fp_mulpair_d_asm_fn": fp_mulpair_d_body, "mbls_fp_mul1_d_asm_fn": fp_mul1_d_body}
+                  "mbls_fp_mulpair_d_asm_fn": fp_mulpair_d_body, "mbls_fp_mul1_d_asm_fn": fp_mul1_d_body,
+                  "mbls_fp_sqrpair_d_asm_fn": fp_sqrpair_d_body}
 
 
 # ---- input limits: the worst column of a scan must stay inside a signed 64-bit accumulator

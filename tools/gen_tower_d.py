@@ -134,7 +134,8 @@ class Prog:
         return (self.add6(t0, self.mul_v6(t1)), c1)
 
     # ---- Fp products in pairs (the G1 formulas) and masks
-    def mulpair(self, a0, b0, a1, b1): return self.call("mulpair", [a0, a1, b0, b1])
+    def mulpair(self, a0, b0, a1, b1):
+        return self.call("sqrpair", [a0, a1]) if (a0 == b0 and a1 == b1 and a0 != a1) else self.call("mulpair", [a0, a1, b0, b1])
     def mul1(self, a, b): return self.call("mul1", [a, b])[0]
 
     def iszero(self, a, mask):
@@ -224,6 +225,7 @@ ROUTINES = {
     "mulfp": dict(name="mbls_fp2_mulfp_d_asm_fn", ins=[0, 1, 2], outs=[5, 6], clob=[5, 6, 7]),
     "mulpair": dict(name="mbls_fp_mulpair_d_asm_fn", ins=[0, 1, 2, 3], outs=[5, 6], clob=[5, 6, 7]),     # (a0 b0, a1 b1)
     "mul1": dict(name="mbls_fp_mul1_d_asm_fn", ins=[0, 2], outs=[5], clob=[5, 7]),
+    "sqrpair": dict(name="mbls_fp_sqrpair_d_asm_fn", ins=[0, 1], outs=[5, 6], clob=[2, 3, 5, 6, 7]),     # (a0^2, a1^2)
 }
 
 
@@ -1051,6 +1053,8 @@ class AllocD:
             return s.fits() and dd.fits() and 2 * m[1] < (1 << 31) and column_ok([(s.mag(), dd.mag())]) and column_ok([(m[0], 2 * m[1])])
         if kind == "mulpair":
             return column_ok([(m[0], m[2])]) and column_ok([(m[1], m[3])])
+        if kind == "sqrpair":                               # cross products against the doubled digits: the same column sums as a product
+            return 2 * m[0] < (1 << 31) and 2 * m[1] < (1 << 31) and column_ok([(m[0], m[0])]) and column_ok([(m[1], m[1])])
         if kind == "mul1":
             return column_ok([(m[0], m[1])])
         return column_ok([(m[0], m[2])]) and column_ok([(m[1], m[2])])
@@ -1115,6 +1119,8 @@ class AllocD:
             ob = [product_bound([(B[0] + B[1], B[0] - B[1])]), product_bound([(B[0], B[1] + B[1])])]
         elif kind == "mulpair":
             ob = [product_bound([(B[0], B[2])]), product_bound([(B[1], B[3])])]
+        elif kind == "sqrpair":
+            ob = [product_bound([(B[0], B[0])]), product_bound([(B[1], B[1])])]
         elif kind == "mul1":
             ob = [product_bound([(B[0], B[1])])]
         else:
