@@ -393,14 +393,14 @@ def main():
     def make_step(kind, d_res, d_bm, d_all, d_pk_c=None):
         if kind == "indexed":
             def verify():
-                ctx.check(lib.mbls_fast_aggregate_verify_batch_indexed_device(ctx.handle, table.handle, d_sigs.data_ptr(), d_msgs.data_ptr(), 32, d_idx.data_ptr(),
+                ctx.check(lib.mbls_fast_aggregate_verify_batch_indexed_device(ctx.handle, table.handle, d_sigs.data_ptr(), d_msgs.data_ptr(), 32, None, d_idx.data_ptr(),
                                                                               None, n, k, d_res.data_ptr(), d_bm.data_ptr(), None, sptr))
         else:
             fmt = N.PK_UNCOMPRESSED if kind == "uncompressed" else N.PK_COMPRESSED
             pk = d_pks if kind == "uncompressed" else d_pk_c
 
             def verify():
-                ctx.check(lib.mbls_fast_aggregate_verify_batch_device(ctx.handle, d_sigs.data_ptr(), d_msgs.data_ptr(), 32, pk.data_ptr(), fmt, None,
+                ctx.check(lib.mbls_fast_aggregate_verify_batch_device(ctx.handle, d_sigs.data_ptr(), d_msgs.data_ptr(), 32, None, pk.data_ptr(), fmt, None,
                                                                       n, k, d_res.data_ptr(), d_bm.data_ptr(), None, sptr))
 
         def step():

@@ -53,6 +53,7 @@ extern "C" {
 #define MBLS_ST_PK_INFINITY 0x20u
 #define MBLS_ST_PAIRING_FAILED 0x40u
 #define MBLS_ST_BAD_SCALAR 0x80u            /* verify_multiple: a zero blinding scalar */
+#define MBLS_ST_BAD_MSG_RANGE 0x100u        /* msg_offsets[i+1] < msg_offsets[i] (device entries; host entries refuse the call) */
 
 typedef struct mbls_ctx mbls_ctx;
 
@@ -71,23 +72,27 @@ const char* mbls_last_error(mbls_ctx* ctx);
 
 /* ---- the hot path -------------------------------------------------------------------------------------
  * Batch of n independent AggregateSignature::fast_aggregate_verify calls (reference src/aggregates.rs:177-215):
- * item i = (sigs[96 i..], msgs[msg_len i..], its public keys). Keys are either k per item, contiguous
+ * item i = (sigs[96 i..], its message, its public keys). The reference takes any `msg: &[u8]` per call: messages are
+ * either msg_len bytes each, contiguous (msg_offsets == NULL: item i's message is msgs[msg_len i ..]), or of any length
+ * each: item i's message is msgs[msg_offsets[i] .. msg_offsets[i+1]) with msg_offsets of n + 1 non-decreasing entries
+ * (msg_len is then ignored; host entries refuse a table that runs backwards or holds a message of 2^32 bytes or more,
+ * device entries reject such an item with MBLS_ST_BAD_MSG_RANGE). Keys are either k per item, contiguous
  * (pk_offsets == NULL), or ragged: item i owns keys [pk_offsets[i], pk_offsets[i+1]) of `pks`.
  * results[i] = 1/0 exactly as the reference function returns true/false, including its check order:
  * empty key list -> 0, signature outside G2 -> 0, aggregate key = infinity -> 0, pairing check.
  * bitmap (optional, ceil(n/64) words): bit (i%64) of word i/64 = results[i]. status (optional): MBLS_ST_* bits. */
 int mbls_fast_aggregate_verify_batch_device(mbls_ctx* ctx, const uint8_t* d_sigs, const uint8_t* d_msgs, uint32_t msg_len,
-                                            const uint8_t* d_pks, int pk_format, const uint32_t* d_pk_offsets,
-                                            uint64_t n, uint32_t k, uint8_t* d_results, uint64_t* d_bitmap,
-                                            uint32_t* d_status, void* stream);
+                                            const uint64_t* d_msg_offsets, const uint8_t* d_pks, int pk_format,
+                                            const uint32_t* d_pk_offsets, uint64_t n, uint32_t k, uint8_t* d_results,
+                                            uint64_t* d_bitmap, uint32_t* d_status, void* stream);
 int mbls_fast_aggregate_verify_batch(mbls_ctx* ctx, const uint8_t* sigs, const uint8_t* msgs, uint32_t msg_len,
-                                     const uint8_t* pks, int pk_format, const uint32_t* pk_offsets,
-                                     uint64_t n, uint32_t k, uint8_t* results, uint32_t* status);
+                                     const uint64_t* msg_offsets, const uint8_t* pks, int pk_format,
+                                     const uint32_t* pk_offsets, uint64_t n, uint32_t k, uint8_t* results, uint32_t* status);
 /* Batch of n Signature::verify calls (reference src/signature.rs:27-40): one key per item, no infinity check. */
 int mbls_verify_batch_device(mbls_ctx* ctx, const uint8_t* d_sigs, const uint8_t* d_msgs, uint32_t msg_len,
-                             const uint8_t* d_pks, int pk_format, uint64_t n, uint8_t* d_results, uint64_t* d_bitmap,
-                             uint32_t* d_status, void* stream);
-int mbls_verify_batch(mbls_ctx* ctx, const uint8_t* sigs, const uint8_t* msgs, uint32_t msg_len,
+                             const uint64_t* d_msg_offsets, const uint8_t* d_pks, int pk_format, uint64_t n,
+                             uint8_t* d_results, uint64_t* d_bitmap, uint32_t* d_status, void* stream);
+int mbls_verify_batch(mbls_ctx* ctx, const uint8_t* sigs, const uint8_t* msgs, uint32_t msg_len, const uint64_t* msg_offsets,
                       const uint8_t* pks, int pk_format, uint64_t n, uint8_t* results, uint32_t* status);
 
 /* ---- resident key table ---------------------------------------------------------------------------------
@@ -97,7 +102,10 @@ int mbls_verify_batch(mbls_ctx* ctx, const uint8_t* sigs, const uint8_t* msgs, u
  * what `&[&PublicKey]` is in the reference's fast_aggregate_verify (src/aggregates.rs:177). Per use this removes the byte
  * decoding, the Montgomery conversion and the on-curve check (5 of 16 multiplications per key), makes the compressed
  * 48-byte wire format a one-time cost, and cuts the per-item input to 96 + msg_len + 4 k bytes.
- * A table belongs to the context it was created with (same GPU, same lock). Entries are never removed; indices are stable. */
+ * A table belongs to the context it was created with (same GPU, same lock). Entries are never removed; indices are stable.
+ * Ordering: an append made through mbls_keytable_append_device on one stream is seen by verifications and mbls_keytable_get on any
+ * other stream (they wait for it on the device). Destroying the context first releases its tables' records; the handles stay
+ * valid for mbls_keytable_destroy only. */
 typedef struct mbls_keytable mbls_keytable;
 int mbls_keytable_create(mbls_ctx* ctx, uint64_t capacity_hint, mbls_keytable** out);
 void mbls_keytable_destroy(mbls_keytable* t);
@@ -115,11 +123,41 @@ int mbls_keytable_get(mbls_keytable* t, uint64_t first_index, uint64_t n, uint8_
  * key_idx[offsets[i] .. offsets[i+1]). An index >= mbls_keytable_size counts as an undecodable key. Same results, bitmap and
  * status words as mbls_fast_aggregate_verify_batch over the same keys in wire format. */
 int mbls_fast_aggregate_verify_batch_indexed_device(mbls_ctx* ctx, const mbls_keytable* t, const uint8_t* d_sigs, const uint8_t* d_msgs,
-                                                    uint32_t msg_len, const uint32_t* d_key_idx, const uint32_t* d_offsets, uint64_t n, uint32_t k,
+                                                    uint32_t msg_len, const uint64_t* d_msg_offsets, const uint32_t* d_key_idx,
+                                                    const uint32_t* d_offsets, uint64_t n, uint32_t k,
                                                     uint8_t* d_results, uint64_t* d_bitmap, uint32_t* d_status, void* stream);
 int mbls_fast_aggregate_verify_batch_indexed(mbls_ctx* ctx, const mbls_keytable* t, const uint8_t* sigs, const uint8_t* msgs, uint32_t msg_len,
-                                             const uint32_t* key_idx, const uint32_t* offsets, uint64_t n, uint32_t k, uint8_t* results,
-                                             uint32_t* status);
+                                             const uint64_t* msg_offsets, const uint32_t* key_idx, const uint32_t* offsets, uint64_t n,
+                                             uint32_t k, uint8_t* results, uint32_t* status);
+
+/* ---- several GPUs behind one handle ------------------------------------------------------------------------
+ * Items are independent (reference src/aggregates.rs:177-215 keeps no state between calls), so a batch shards embarrassingly:
+ * device g of G verifies items [n g / G, n (g + 1) / G). One context and one host thread per listed device; every thread stages its
+ * own shard from the caller's buffers and writes its results into them in place; no device talks to another (in a one-process-
+ * per-GPU deployment -- bench.py -- the same partition is milagro_bls_amd/shard.py and the accept bitmap is gathered with RCCL).
+ * A device id may be listed more than once (two contexts then share that GPU). Calls on one handle are serialised. */
+typedef struct mbls_multi mbls_multi;
+int mbls_multi_create(mbls_multi** out, const int* device_ids, int n_devices);
+void mbls_multi_destroy(mbls_multi* m);
+int mbls_multi_device_count(const mbls_multi* m);
+const char* mbls_multi_last_error(mbls_multi* m);
+mbls_ctx* mbls_multi_context(mbls_multi* m, int i);            /* the i-th device's context (for the scalar API, reserve, ...) */
+int mbls_multi_reserve(mbls_multi* m, uint64_t max_items);     /* workspace for batches of up to max_items items in total */
+/* same arguments, results and status words as mbls_fast_aggregate_verify_batch / mbls_verify_batch (host buffers) */
+int mbls_multi_fast_aggregate_verify_batch(mbls_multi* m, const uint8_t* sigs, const uint8_t* msgs, uint32_t msg_len,
+                                           const uint64_t* msg_offsets, const uint8_t* pks, int pk_format, const uint32_t* pk_offsets,
+                                           uint64_t n, uint32_t k, uint8_t* results, uint32_t* status);
+int mbls_multi_verify_batch(mbls_multi* m, const uint8_t* sigs, const uint8_t* msgs, uint32_t msg_len, const uint64_t* msg_offsets,
+                            const uint8_t* pks, int pk_format, uint64_t n, uint8_t* results, uint32_t* status);
+/* a key table replicated on every device of the handle: same indices everywhere */
+typedef struct mbls_multi_keytable mbls_multi_keytable;
+int mbls_multi_keytable_create(mbls_multi* m, uint64_t capacity_hint, mbls_multi_keytable** out);
+void mbls_multi_keytable_destroy(mbls_multi_keytable* t);
+uint64_t mbls_multi_keytable_size(const mbls_multi_keytable* t);
+int mbls_multi_keytable_append(mbls_multi_keytable* t, const uint8_t* pks, int pk_format, int validate, uint64_t n, uint64_t* first_index, uint8_t* errs);
+int mbls_multi_fast_aggregate_verify_batch_indexed(mbls_multi* m, const mbls_multi_keytable* t, const uint8_t* sigs, const uint8_t* msgs,
+                                                   uint32_t msg_len, const uint64_t* msg_offsets, const uint32_t* key_idx, const uint32_t* offsets,
+                                                   uint64_t n, uint32_t k, uint8_t* results, uint32_t* status);
 
 /* ---- scalar API, 1:1 with the reference's methods (each runs the batch kernels with n = 1) ---- */
 /* PublicKey::from_bytes (src/keys.rs:140-147): compressed decode + KeyValidate -> 96-byte decoded key */
@@ -162,16 +200,17 @@ int mbls_aggregate_verify(mbls_ctx* ctx, const uint8_t sig[96], const uint8_t* m
  * scalar (which would drop its set from the check) makes the call fail: result 0 and MBLS_ERR_ARGUMENT from the
  * *_device forms, 0 from the bool form. One bool for the whole batch. */
 int mbls_verify_multiple_aggregate_signatures(mbls_ctx* ctx, const uint8_t* sigs96, const uint8_t* apks96,
-                                              const uint8_t* msgs, uint32_t msg_len, const uint64_t* rands, size_t n);
+                                              const uint8_t* msgs, uint32_t msg_len, const uint64_t* msg_offsets,
+                                              const uint64_t* rands, size_t n);
 int mbls_verify_multiple_aggregate_signatures_device(mbls_ctx* ctx, const uint8_t* d_sigs96, const uint8_t* d_apks96,
-                                              const uint8_t* d_msgs, uint32_t msg_len, const uint64_t* d_rands, uint64_t n,
-                                              int* result, void* stream);
+                                              const uint8_t* d_msgs, uint32_t msg_len, const uint64_t* d_msg_offsets,
+                                              const uint64_t* d_rands, uint64_t n, int* result, void* stream);
 
 /* The same for sets given by their keys in wire format (BASELINE configs[3]: 2^14 sets x 128 keys): set i owns k keys
  * (or [pk_offsets[i], pk_offsets[i+1])), AggregatePublicKey::aggregate (src/aggregates.rs:29-39) runs on the device first. */
 int mbls_verify_multiple_sets_device(mbls_ctx* ctx, const uint8_t* d_sigs96, const uint8_t* d_pks, int pk_format,
                                      const uint32_t* d_pk_offsets, uint32_t k, const uint8_t* d_msgs, uint32_t msg_len,
-                                     const uint64_t* d_rands, uint64_t n, int* result, void* stream);
+                                     const uint64_t* d_msg_offsets, const uint64_t* d_rands, uint64_t n, int* result, void* stream);
 
 /* ---- batch helpers used to build inputs and caches on the device ---- */
 /* n x PublicKey::from_bytes[_unchecked] / from_uncompressed_bytes: errs[i] = MBLS_OK / MBLS_ERR_* per key */

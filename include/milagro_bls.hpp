@@ -99,6 +99,17 @@ inline std::array<uint8_t, 32> hmac_sha256(const Bytes& key, const Bytes& msg) {
     i.insert(i.end(), msg.begin(), msg.end()); auto inner = sha256(i);
     o.insert(o.end(), inner.begin(), inner.end()); return sha256(o);
 }
+// HKDF-SHA-256 (RFC 5869; amcl's HASH256::hkdf_extract / hkdf_extend, reference src/keys.rs:62-69). An empty salt is HashLen zero bytes.
+inline std::array<uint8_t, 32> hkdf_extract(const Bytes& salt, const Bytes& ikm) { return hmac_sha256(salt.empty() ? Bytes(32, 0) : salt, ikm); }
+inline Bytes hkdf_expand(const std::array<uint8_t, 32>& prk, const Bytes& info, size_t len) {
+    Bytes okm, t; uint8_t ctr = 1;
+    while (okm.size() < len) {
+        Bytes m = t; m.insert(m.end(), info.begin(), info.end()); m.push_back(ctr++);
+        auto d = hmac_sha256(Bytes(prk.begin(), prk.end()), m); t.assign(d.begin(), d.end());
+        okm.insert(okm.end(), t.begin(), t.end());
+    }
+    okm.resize(len); return okm;
+}
 // OS2IP(48 bytes) mod r -> 32 bytes big-endian (bitwise long division on 32-bit limbs; host-only, once per key)
 inline std::array<uint8_t, 32> mod_r(const uint8_t okm[48]) {
     static const uint32_t R[9] = {0x00000001, 0xffffffff, 0xfffe5bfe, 0x53bda402, 0x09a1d805, 0x3339d808, 0x299d7d48, 0x73eda753, 0};
@@ -128,14 +139,9 @@ public:
         while (zero) {
             auto hs = detail::sha256(salt); salt.assign(hs.begin(), hs.end());                          // salt = H(salt)
             Bytes ikm0 = ikm; ikm0.push_back(0);
-            auto prk = detail::hmac_sha256(salt, ikm0);                                                 // PRK = HKDF-Extract(salt, IKM || 0)
+            auto prk = detail::hkdf_extract(salt, ikm0);                                                // PRK = HKDF-Extract(salt, IKM || 0)
             Bytes info = key_info; info.push_back(0); info.push_back(48);                               // key_info || I2OSP(L, 2)
-            Bytes okm, t; uint8_t ctr = 1;                                                              // OKM = HKDF-Expand(PRK, info, L)
-            while (okm.size() < 48) {
-                Bytes m = t; m.insert(m.end(), info.begin(), info.end()); m.push_back(ctr++);
-                auto d = detail::hmac_sha256(Bytes(prk.begin(), prk.end()), m); t.assign(d.begin(), d.end());
-                okm.insert(okm.end(), t.begin(), t.end());
-            }
+            Bytes okm = detail::hkdf_expand(prk, info, 48);                                             // OKM = HKDF-Expand(PRK, info, L)
             s.x_ = detail::mod_r(okm.data());                                                           // SK = OS2IP(OKM) mod r
             for (uint8_t v : s.x_) if (v) zero = false;
         }
@@ -233,19 +239,18 @@ struct AggregateSignature {
     // rng(): one random byte per call. Blinding scalars drawn as at reference src/aggregates.rs:280-287.
     template <typename Rng>
     static bool verify_multiple_aggregate_signatures(Rng&& rng, const std::vector<std::tuple<const AggregateSignature*, const AggregatePublicKey*, Bytes>>& sets) {
-        if (sets.empty()) return mbls_verify_multiple_aggregate_signatures(detail::ctx(), nullptr, nullptr, nullptr, 0, nullptr, 0) == 1;
-        Bytes sigs, apks, msgs; std::vector<uint64_t> rands;
-        const size_t mlen = std::get<2>(sets[0]).size();
+        if (sets.empty()) return mbls_verify_multiple_aggregate_signatures(detail::ctx(), nullptr, nullptr, nullptr, 0, nullptr, nullptr, 0) == 1;
+        Bytes sigs, apks, msgs; std::vector<uint64_t> rands, moff{0};      // messages of any length each: one buffer + an offset table
         for (auto& s : sets) {
             uint64_t r = 0;
             while (r == 0) { uint64_t v = 0; for (int i = 0; i < 8; i++) v = (v << 8) | uint8_t(rng()); r = (v >> 63) ? (uint64_t(0) - v) : v; }      // i64::from_be_bytes(..).abs() as the release build wraps it
             rands.push_back(r);
             sigs.insert(sigs.end(), std::get<0>(s)->point.begin(), std::get<0>(s)->point.end());
             apks.insert(apks.end(), std::get<1>(s)->point.begin(), std::get<1>(s)->point.end());
-            if (std::get<2>(s).size() != mlen) throw std::invalid_argument("messages must have equal length");
             msgs.insert(msgs.end(), std::get<2>(s).begin(), std::get<2>(s).end());
+            moff.push_back(msgs.size());
         }
-        return mbls_verify_multiple_aggregate_signatures(detail::ctx(), sigs.data(), apks.data(), msgs.data(), uint32_t(mlen), rands.data(), sets.size()) == 1;
+        return mbls_verify_multiple_aggregate_signatures(detail::ctx(), sigs.data(), apks.data(), msgs.data(), 0, moff.data(), rands.data(), sets.size()) == 1;
     }
     static AggregateSignature from_bytes(const Bytes& b) { AggregateSignature a; detail::check(mbls_sig_from_bytes(detail::ctx(), b.data(), b.size(), a.point.data())); return a; }
     std::array<uint8_t, 96> as_bytes() const { return point; }

@@ -32,18 +32,18 @@ SIGNATURES = {
     "mbls_ctx_reserve": (C.c_int, [vp, C.c_uint64]),
     "mbls_ctx_reserve_keys": (C.c_int, [vp, C.c_uint64]),
     "mbls_last_error": (C.c_char_p, [vp]),
-    "mbls_fast_aggregate_verify_batch_device": (C.c_int, [vp, vp, vp, C.c_uint32, vp, C.c_int, vp, C.c_uint64, C.c_uint32, vp, vp, vp, vp]),
-    "mbls_fast_aggregate_verify_batch": (C.c_int, [vp, vp, vp, C.c_uint32, vp, C.c_int, vp, C.c_uint64, C.c_uint32, vp, vp]),
-    "mbls_verify_batch_device": (C.c_int, [vp, vp, vp, C.c_uint32, vp, C.c_int, C.c_uint64, vp, vp, vp, vp]),
-    "mbls_verify_batch": (C.c_int, [vp, vp, vp, C.c_uint32, vp, C.c_int, C.c_uint64, vp, vp]),
+    "mbls_fast_aggregate_verify_batch_device": (C.c_int, [vp, vp, vp, C.c_uint32, vp, vp, C.c_int, vp, C.c_uint64, C.c_uint32, vp, vp, vp, vp]),
+    "mbls_fast_aggregate_verify_batch": (C.c_int, [vp, vp, vp, C.c_uint32, vp, vp, C.c_int, vp, C.c_uint64, C.c_uint32, vp, vp]),
+    "mbls_verify_batch_device": (C.c_int, [vp, vp, vp, C.c_uint32, vp, vp, C.c_int, C.c_uint64, vp, vp, vp, vp]),
+    "mbls_verify_batch": (C.c_int, [vp, vp, vp, C.c_uint32, vp, vp, C.c_int, C.c_uint64, vp, vp]),
     "mbls_keytable_create": (C.c_int, [vp, C.c_uint64, C.POINTER(vp)]),
     "mbls_keytable_destroy": (None, [vp]),
     "mbls_keytable_size": (C.c_uint64, [vp]),
     "mbls_keytable_append": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_uint64, C.POINTER(C.c_uint64), vp]),
     "mbls_keytable_append_device": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_uint64, C.POINTER(C.c_uint64), vp, vp]),
     "mbls_keytable_get": (C.c_int, [vp, C.c_uint64, C.c_uint64, vp, vp]),
-    "mbls_fast_aggregate_verify_batch_indexed_device": (C.c_int, [vp, vp, vp, vp, C.c_uint32, vp, vp, C.c_uint64, C.c_uint32, vp, vp, vp, vp]),
-    "mbls_fast_aggregate_verify_batch_indexed": (C.c_int, [vp, vp, vp, vp, C.c_uint32, vp, vp, C.c_uint64, C.c_uint32, vp, vp]),
+    "mbls_fast_aggregate_verify_batch_indexed_device": (C.c_int, [vp, vp, vp, vp, C.c_uint32, vp, vp, vp, C.c_uint64, C.c_uint32, vp, vp, vp, vp]),
+    "mbls_fast_aggregate_verify_batch_indexed": (C.c_int, [vp, vp, vp, vp, C.c_uint32, vp, vp, vp, C.c_uint64, C.c_uint32, vp, vp]),
     "mbls_aggregate_signatures_batch": (C.c_int, [vp, vp, vp, C.c_uint64, C.c_uint32, vp, vp]),
     "mbls_aggregate_signatures_batch_device": (C.c_int, [vp, vp, vp, C.c_uint64, C.c_uint32, C.c_uint64, vp, vp, vp]),
     "mbls_pk_from_bytes": (C.c_int, [vp, vp, C.c_size_t, vp]),
@@ -61,9 +61,9 @@ SIGNATURES = {
     "mbls_fast_aggregate_verify": (C.c_int, [vp, vp, vp, C.c_size_t, vp, C.c_size_t]),
     "mbls_fast_aggregate_verify_pre_aggregated": (C.c_int, [vp, vp, vp, C.c_size_t, vp]),
     "mbls_aggregate_verify": (C.c_int, [vp, vp, vp, vp, C.c_size_t, vp, C.c_size_t]),
-    "mbls_verify_multiple_aggregate_signatures": (C.c_int, [vp, vp, vp, vp, C.c_uint32, vp, C.c_size_t]),
-    "mbls_verify_multiple_aggregate_signatures_device": (C.c_int, [vp, vp, vp, vp, C.c_uint32, vp, C.c_uint64, C.POINTER(C.c_int), vp]),
-    "mbls_verify_multiple_sets_device": (C.c_int, [vp, vp, vp, C.c_int, vp, C.c_uint32, vp, C.c_uint32, vp, C.c_uint64, C.POINTER(C.c_int), vp]),
+    "mbls_verify_multiple_aggregate_signatures": (C.c_int, [vp, vp, vp, vp, C.c_uint32, vp, vp, C.c_size_t]),
+    "mbls_verify_multiple_aggregate_signatures_device": (C.c_int, [vp, vp, vp, vp, C.c_uint32, vp, vp, C.c_uint64, C.POINTER(C.c_int), vp]),
+    "mbls_verify_multiple_sets_device": (C.c_int, [vp, vp, vp, C.c_int, vp, C.c_uint32, vp, C.c_uint32, vp, vp, C.c_uint64, C.POINTER(C.c_int), vp]),
     "mbls_pk_decode_batch": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_uint64, vp, vp]),
     "mbls_pk_compress_batch": (C.c_int, [vp, vp, C.c_uint64, vp, vp]),
     "mbls_sig_check_batch": (C.c_int, [vp, vp, C.c_uint64, vp, vp]),
@@ -76,6 +76,19 @@ SIGNATURES = {
     "mbls_fp_mul_batch": (C.c_int, [vp, vp, vp, C.c_uint64, vp, C.c_int]),
     "mbls_fp_mul_bench": (C.c_int, [vp, C.c_uint64, C.c_uint32, C.POINTER(C.c_float)]),
     "mbls_valu_bench": (C.c_int, [vp, C.c_int, C.c_uint32, C.c_uint32, C.POINTER(C.c_float)]),
+    "mbls_multi_create": (C.c_int, [C.POINTER(vp), C.POINTER(C.c_int), C.c_int]),
+    "mbls_multi_destroy": (None, [vp]),
+    "mbls_multi_device_count": (C.c_int, [vp]),
+    "mbls_multi_last_error": (C.c_char_p, [vp]),
+    "mbls_multi_context": (vp, [vp, C.c_int]),
+    "mbls_multi_reserve": (C.c_int, [vp, C.c_uint64]),
+    "mbls_multi_fast_aggregate_verify_batch": (C.c_int, [vp, vp, vp, C.c_uint32, vp, vp, C.c_int, vp, C.c_uint64, C.c_uint32, vp, vp]),
+    "mbls_multi_verify_batch": (C.c_int, [vp, vp, vp, C.c_uint32, vp, vp, C.c_int, C.c_uint64, vp, vp]),
+    "mbls_multi_keytable_create": (C.c_int, [vp, C.c_uint64, C.POINTER(vp)]),
+    "mbls_multi_keytable_destroy": (None, [vp]),
+    "mbls_multi_keytable_size": (C.c_uint64, [vp]),
+    "mbls_multi_keytable_append": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_uint64, C.POINTER(C.c_uint64), vp]),
+    "mbls_multi_fast_aggregate_verify_batch_indexed": (C.c_int, [vp, vp, vp, vp, C.c_uint32, vp, vp, vp, C.c_uint64, C.c_uint32, vp, vp]),
     "mbls_enable_phase_timing": (C.c_int, [vp, C.c_int]),
     "mbls_last_phase_ms": (C.c_int, [vp, C.POINTER(C.c_float)]),
 }
@@ -188,6 +201,75 @@ class KeyTable:
         out, errs = outbuf(96 * n), outbuf(n)
         self.ctx.check(lib().mbls_keytable_get(self._h, first, n, out, errs))
         return bytes(out)[:96 * n], list(bytes(errs)[:n])
+
+
+class MultiContext:
+    """Several GPUs behind one handle (include/mbls.h, mbls_multi_*): contiguous shards, one context and one host thread per device."""
+
+    def __init__(self, device_ids):
+        ids = (C.c_int * len(device_ids))(*device_ids)
+        self._h = vp()
+        rc = lib().mbls_multi_create(C.byref(self._h), ids, len(device_ids))
+        if rc != OK:
+            raise MblsError(rc, "mbls_multi_create failed")
+
+    def close(self):
+        if self._h:
+            lib().mbls_multi_destroy(self._h)
+            self._h = vp()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def handle(self):
+        return self._h
+
+    def __len__(self):
+        return int(lib().mbls_multi_device_count(self._h))
+
+    def check(self, rc):
+        if rc != OK:
+            raise MblsError(rc, lib().mbls_multi_last_error(self._h).decode())
+
+    def reserve(self, n):
+        self.check(lib().mbls_multi_reserve(self._h, n))
+
+
+class MultiKeyTable:
+    """A key table replicated on every device of a MultiContext (same indices everywhere)."""
+
+    def __init__(self, mctx, capacity_hint=0):
+        self.m = mctx
+        self._h = vp()
+        mctx.check(lib().mbls_multi_keytable_create(mctx.handle, capacity_hint, C.byref(self._h)))
+
+    def close(self):
+        if self._h:
+            lib().mbls_multi_keytable_destroy(self._h)
+            self._h = vp()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def handle(self):
+        return self._h
+
+    def __len__(self):
+        return int(lib().mbls_multi_keytable_size(self._h))
+
+    def append(self, pks, n, pk_format=PK_COMPRESSED, validate=True):
+        first = C.c_uint64(0)
+        errs = outbuf(n)
+        self.m.check(lib().mbls_multi_keytable_append(self._h, cbuf(pks), pk_format, int(validate), n, C.byref(first), errs))
+        return int(first.value), list(bytes(errs)[:n])
 
 
 _default_ctx = None

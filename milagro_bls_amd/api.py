@@ -48,6 +48,21 @@ class AmclError(Exception):
         return hash(self.code)
 
 
+def hkdf_extract(salt, ikm):
+    """HKDF-Extract with SHA-256 (RFC 5869 section 2.2; amcl HASH256::hkdf_extract, reference src/keys.rs:62)"""
+    return hmac.new(bytes(salt) if salt else bytes(32), bytes(ikm), hashlib.sha256).digest()
+
+
+def hkdf_expand(prk, info, length):
+    """HKDF-Expand with SHA-256 (RFC 5869 section 2.3; amcl HASH256::hkdf_extend, reference src/keys.rs:67)"""
+    okm, t, i = b"", b"", 1
+    while len(okm) < length:
+        t = hmac.new(prk, t + bytes(info) + bytes([i]), hashlib.sha256).digest()
+        okm += t
+        i += 1
+    return okm[:length]
+
+
 def _ctx():
     return N.default_context()
 
@@ -78,14 +93,9 @@ class SecretKey:
         sk, salt = 0, KEY_SALT
         while sk == 0:
             salt = hashlib.sha256(salt).digest()
-            prk = hmac.new(salt, bytes(ikm) + b"\x00", hashlib.sha256).digest()
-            info = bytes(key_info) + bytes([0, L])
-            okm, t, i = b"", b"", 1
-            while len(okm) < L:
-                t = hmac.new(prk, t + info + bytes([i]), hashlib.sha256).digest()
-                okm += t
-                i += 1
-            sk = int.from_bytes(okm[:L], "big") % CURVE_ORDER
+            prk = hkdf_extract(salt, bytes(ikm) + b"\x00")
+            okm = hkdf_expand(prk, bytes(key_info) + bytes([0, L]), L)
+            sk = int.from_bytes(okm, "big") % CURVE_ORDER
         return cls(sk)
 
     @classmethod
@@ -285,7 +295,7 @@ class AggregateSignature:
     def verify_multiple_aggregate_signatures(rng, signature_sets):
         """reference src/aggregates.rs:261-316. `rng` must offer getrandbits (random.Random); the blinding scalars
         are drawn exactly as at :280-287: 8 random bytes, big-endian i64, absolute value, retry on zero.
-        All messages must have the same length (the batch kernel's layout); 32 bytes in the Eth2 use."""
+        Messages may have any lengths (`&[u8]` per set in the reference): they travel as one buffer + an offset table."""
         sets = list(signature_sets)
         rands = []
         for _ in sets:
@@ -295,14 +305,15 @@ class AggregateSignature:
                 r = abs(v) & 0xFFFFFFFFFFFFFFFF
             rands.append(r)
         if not sets:
-            return bool(N.lib().mbls_verify_multiple_aggregate_signatures(_ctx().handle, None, None, None, 0, None, 0))
-        mlen = len(sets[0][2])
-        if any(len(s[2]) != mlen for s in sets):
-            raise ValueError("verify_multiple_aggregate_signatures: messages must have equal length")
+            return bool(N.lib().mbls_verify_multiple_aggregate_signatures(_ctx().handle, None, None, None, 0, None, None, 0))
+        offs = [0]
+        for s in sets:
+            offs.append(offs[-1] + len(s[2]))
+        moff = (C.c_uint64 * len(offs))(*offs)
         rr = (C.c_uint64 * len(sets))(*rands)
         return bool(N.lib().mbls_verify_multiple_aggregate_signatures(
             _ctx().handle, N.cbuf(b"".join(s[0].point for s in sets)), N.cbuf(b"".join(s[1].point for s in sets)),
-            N.cbuf(b"".join(bytes(s[2]) for s in sets)), mlen, rr, len(sets)))
+            N.cbuf(b"".join(bytes(s[2]) for s in sets)), 0, moff, rr, len(sets)))
 
     @classmethod
     def from_bytes(cls, data):

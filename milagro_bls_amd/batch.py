@@ -9,7 +9,12 @@ def _c():
     return N.default_context()
 
 
-def fast_aggregate_verify_batch(sigs, msgs, pks, n, k=None, pk_format=N.PK_COMPRESSED, msg_len=32, pk_offsets=None, ctx=None):
+def _moff(msg_offsets):
+    """n + 1 byte offsets into the message buffer (messages of any length each), or None for msg_len bytes per item"""
+    return None if msg_offsets is None else (C.c_uint64 * len(msg_offsets))(*msg_offsets)
+
+
+def fast_aggregate_verify_batch(sigs, msgs, pks, n, k=None, pk_format=N.PK_COMPRESSED, msg_len=32, pk_offsets=None, ctx=None, msg_offsets=None):
     """n x AggregateSignature::fast_aggregate_verify (reference src/aggregates.rs:177-215).
     Returns (results: list[bool], status: list[int])."""
     ctx = ctx or _c()
@@ -19,12 +24,12 @@ def fast_aggregate_verify_batch(sigs, msgs, pks, n, k=None, pk_format=N.PK_COMPR
     if pk_offsets is not None:
         off = (C.c_uint32 * len(pk_offsets))(*pk_offsets)
         k = 0
-    ctx.check(N.lib().mbls_fast_aggregate_verify_batch(ctx.handle, N.cbuf(sigs), N.cbuf(msgs), msg_len, N.cbuf(pks), pk_format,
+    ctx.check(N.lib().mbls_fast_aggregate_verify_batch(ctx.handle, N.cbuf(sigs), N.cbuf(msgs), msg_len, _moff(msg_offsets), N.cbuf(pks), pk_format,
                                                        off, n, k, res, st))
     return [bool(x) for x in bytes(res)[:n]], list(st)[:n]
 
 
-def fast_aggregate_verify_batch_indexed(table, sigs, msgs, key_idx, n, k=None, msg_len=32, offsets=None, ctx=None):
+def fast_aggregate_verify_batch_indexed(table, sigs, msgs, key_idx, n, k=None, msg_len=32, offsets=None, ctx=None, msg_offsets=None):
     """The same over a resident key table: item i uses table entries key_idx[k*i : k*i+k] (or key_idx[offsets[i]:offsets[i+1]])."""
     ctx = ctx or table.ctx
     res = N.outbuf(n)
@@ -34,7 +39,7 @@ def fast_aggregate_verify_batch_indexed(table, sigs, msgs, key_idx, n, k=None, m
     if offsets is not None:
         off = (C.c_uint32 * len(offsets))(*offsets)
         k = 0
-    ctx.check(N.lib().mbls_fast_aggregate_verify_batch_indexed(ctx.handle, table.handle, N.cbuf(sigs), N.cbuf(msgs), msg_len, idx, off, n, k, res, st))
+    ctx.check(N.lib().mbls_fast_aggregate_verify_batch_indexed(ctx.handle, table.handle, N.cbuf(sigs), N.cbuf(msgs), msg_len, _moff(msg_offsets), idx, off, n, k, res, st))
     return [bool(x) for x in bytes(res)[:n]], list(st)[:n]
 
 
@@ -50,12 +55,12 @@ def aggregate_signatures_batch(sigs96, n, k=None, offsets=None, ctx=None):
     return bytes(out)[:96 * n], list(bytes(errs)[:n])
 
 
-def verify_batch(sigs, msgs, pks, n, pk_format=N.PK_COMPRESSED, msg_len=32, ctx=None):
+def verify_batch(sigs, msgs, pks, n, pk_format=N.PK_COMPRESSED, msg_len=32, ctx=None, msg_offsets=None):
     """n x Signature::verify (reference src/signature.rs:27-40)."""
     ctx = ctx or _c()
     res = N.outbuf(n)
     st = (C.c_uint32 * max(1, n))()
-    ctx.check(N.lib().mbls_verify_batch(ctx.handle, N.cbuf(sigs), N.cbuf(msgs), msg_len, N.cbuf(pks), pk_format, n, res, st))
+    ctx.check(N.lib().mbls_verify_batch(ctx.handle, N.cbuf(sigs), N.cbuf(msgs), msg_len, _moff(msg_offsets), N.cbuf(pks), pk_format, n, res, st))
     return [bool(x) for x in bytes(res)[:n]], list(st)[:n]
 
 
@@ -135,6 +140,39 @@ def verify_multiple_sets_device(d_sigs, d_pks, d_msgs, d_rands, n, k, pk_format=
     their k wire-format keys each, everything resident on the device (raw device pointers / ints). One bool."""
     ctx = ctx or _c()
     res = C.c_int(0)
-    ctx.check(N.lib().mbls_verify_multiple_sets_device(ctx.handle, d_sigs, d_pks, pk_format, None, k, d_msgs, msg_len, d_rands, n,
+    ctx.check(N.lib().mbls_verify_multiple_sets_device(ctx.handle, d_sigs, d_pks, pk_format, None, k, d_msgs, msg_len, None, d_rands, n,
                                                        C.byref(res), stream))
     return bool(res.value)
+
+
+def multi_fast_aggregate_verify_batch(mctx, sigs, msgs, pks, n, k=None, pk_format=N.PK_COMPRESSED, msg_len=32, pk_offsets=None, msg_offsets=None):
+    """fast_aggregate_verify_batch sharded over the devices of a MultiContext (include/mbls.h, mbls_multi_*)"""
+    res = N.outbuf(n)
+    st = (C.c_uint32 * max(1, n))()
+    off = None
+    if pk_offsets is not None:
+        off = (C.c_uint32 * len(pk_offsets))(*pk_offsets)
+        k = 0
+    mctx.check(N.lib().mbls_multi_fast_aggregate_verify_batch(mctx.handle, N.cbuf(sigs), N.cbuf(msgs), msg_len, _moff(msg_offsets), N.cbuf(pks), pk_format,
+                                                              off, n, k, res, st))
+    return [bool(x) for x in bytes(res)[:n]], list(st)[:n]
+
+
+def multi_verify_batch(mctx, sigs, msgs, pks, n, pk_format=N.PK_COMPRESSED, msg_len=32, msg_offsets=None):
+    res = N.outbuf(n)
+    st = (C.c_uint32 * max(1, n))()
+    mctx.check(N.lib().mbls_multi_verify_batch(mctx.handle, N.cbuf(sigs), N.cbuf(msgs), msg_len, _moff(msg_offsets), N.cbuf(pks), pk_format, n, res, st))
+    return [bool(x) for x in bytes(res)[:n]], list(st)[:n]
+
+
+def multi_fast_aggregate_verify_batch_indexed(mctx, mtable, sigs, msgs, key_idx, n, k=None, msg_len=32, offsets=None, msg_offsets=None):
+    res = N.outbuf(n)
+    st = (C.c_uint32 * max(1, n))()
+    idx = (C.c_uint32 * max(1, len(key_idx)))(*key_idx)
+    off = None
+    if offsets is not None:
+        off = (C.c_uint32 * len(offsets))(*offsets)
+        k = 0
+    mctx.check(N.lib().mbls_multi_fast_aggregate_verify_batch_indexed(mctx.handle, mtable.handle, N.cbuf(sigs), N.cbuf(msgs), msg_len, _moff(msg_offsets),
+                                                                      idx, off, n, k, res, st))
+    return [bool(x) for x in bytes(res)[:n]], list(st)[:n]

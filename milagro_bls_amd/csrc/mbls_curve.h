@@ -16,6 +16,7 @@
 #define MBLS_ST_PK_INFINITY      0x20u   // informational: a decoded key is the point at infinity
 #define MBLS_ST_PAIRING_FAILED   0x40u   // pairing product != 1
 #define MBLS_ST_BAD_SCALAR       0x80u   // verify_multiple: a blinding scalar is zero (reference src/aggregates.rs:280-287 never draws one)
+#define MBLS_ST_BAD_MSG_RANGE    0x100u  // the item's entry of a message offset table runs backwards (no &[u8] a reference caller could pass)
 
 struct g1j { fp x, y, z; };
 struct g2j { fp2 x, y, z; };

@@ -116,15 +116,24 @@ __global__ void MBLS_LB k_sig(mbls_ws ws, const uint8_t* sigs, uint32_t* status,
 #endif
     if (st) atomicOr(status + i, st);             // may run beside k_aggregate on another stream
 }
-__global__ void MBLS_LB k_hash(mbls_ws ws, const uint8_t* msgs, uint32_t mlen, const uint64_t* moff, const uint32_t* mlens, uint64_t n) {
+// item i's message: msgs[mlen i ..] or, with an offset table of n + 1 entries, msgs[moff[i] .. moff[i+1]) (any length below 2^32; a range
+// that runs backwards is never read: the item is rejected with MBLS_ST_BAD_MSG_RANGE)
+__global__ void MBLS_LB k_hash(mbls_ws ws, const uint8_t* msgs, uint32_t mlen, const uint64_t* moff, uint32_t* status, uint64_t n) {
 #if !defined(MBLS_NO_LDS_STATE)
     __shared__ uint32_t spill[154 * 64];          // the same for the addition / cofactor-clearing routine
+#endif
     uint64_t i = gid(); if (i >= n) return;
-    if (moff) lane_hash(ws, i, msgs + moff[i], mlens[i], (MBLS_LDS uint32_t*)spill, threadIdx.x, true);
-    else lane_hash(ws, i, msgs + (uint64_t)mlen * i, mlen, (MBLS_LDS uint32_t*)spill, threadIdx.x, true);
+    const uint8_t* m = msgs + (uint64_t)mlen * i; uint32_t len = mlen;
+    if (moff) {
+        const uint64_t a = moff[i], b = moff[i + 1];
+        const bool bad = b < a || b - a > 0xFFFFFFFFull;
+        m = msgs + (bad ? 0 : a); len = bad ? 0u : (uint32_t)(b - a);
+        if (bad) atomicOr(status + i, MBLS_ST_BAD_MSG_RANGE);
+    }
+#if !defined(MBLS_NO_LDS_STATE)
+    lane_hash(ws, i, m, len, (MBLS_LDS uint32_t*)spill, threadIdx.x, true);
 #else
-    uint64_t i = gid(); if (i >= n) return;
-    if (moff) lane_hash(ws, i, msgs + moff[i], mlens[i]); else lane_hash(ws, i, msgs + (uint64_t)mlen * i, mlen);
+    lane_hash(ws, i, m, len);
 #endif
 }
 __global__ void MBLS_LB k_miller(mbls_ws ws, uint64_t n) {
@@ -300,7 +309,7 @@ __global__ void __launch_bounds__(WG) k_valu_bench(uint32_t* sink, uint32_t iter
 // Host-buffer entries stage through grow-only device buffers and two streams that the context owns (no allocation or stream
 // creation per call once the sizes have been seen); device-pointer entries only enqueue, and order their use of the
 // workspace against earlier calls on other streams with an event.
-#define MBLS_N_STAGE 8
+#define MBLS_N_STAGE 10
 struct mbls_ctx {
     std::recursive_mutex mu;
     int device = 0;
@@ -319,12 +328,14 @@ struct mbls_ctx {
     bool timing = false;
     hipEvent_t ev[MBLS_N_PHASES + 1] = {};
     float phase_ms[MBLS_N_PHASES] = {};
+    std::vector<struct mbls_keytable*> tables;     // the key tables created on this context (orphaned when it is destroyed)
     char err[256] = {};
 };
 struct mbls_keytable {
-    mbls_ctx* c = nullptr;
+    mbls_ctx* c = nullptr;             // nullptr: the context was destroyed first (the records went with it)
     uint32_t* d_recs = nullptr;        // [cap][MBLS_KEYREC_DWORDS]
     uint64_t size = 0, cap = 0;
+    hipEvent_t ev = nullptr; hipStream_t ev_stream = nullptr; bool pending = false;   // the last asynchronous append
 };
 typedef std::lock_guard<std::recursive_mutex> mbls_lock;
 
@@ -381,7 +392,15 @@ extern "C" int mbls_ctx_create(mbls_ctx** out, int device_id) {
 }
 extern "C" void mbls_ctx_destroy(mbls_ctx* c) {
     if (!c) return;
-    { mbls_lock lk(c->mu); (void)hipSetDevice(c->device); (void)hipDeviceSynchronize(); }
+    {
+        mbls_lock lk(c->mu); (void)hipSetDevice(c->device); (void)hipDeviceSynchronize();
+        for (mbls_keytable* t : c->tables) {      // tables that outlive their context become empty shells: mbls_keytable_destroy only frees the handle
+            if (t->d_recs) (void)hipFree(t->d_recs);
+            if (t->ev) (void)hipEventDestroy(t->ev);
+            t->d_recs = nullptr; t->ev = nullptr; t->size = t->cap = 0; t->c = nullptr;
+        }
+        c->tables.clear();
+    }
     ctx_free(c);
 }
 extern "C" const char* mbls_last_error(mbls_ctx* c) { return c ? c->err : "null context"; }
@@ -452,16 +471,22 @@ static int ws_release(mbls_ctx* c, hipStream_t s) {
 struct keysrc {
     const uint8_t* d_pks = nullptr; int fmt = MBLS_PK_UNCOMPRESSED; const uint32_t* d_off = nullptr;      // wire bytes
     const uint32_t* d_recs = nullptr; uint64_t tsize = 0; const uint32_t* d_idx = nullptr; bool indexed = false;   // key table
+    const mbls_keytable* tab = nullptr;
 };
+// readers of a key table on stream s wait (on the device) for the last asynchronous append made on another stream
+static int table_acquire(mbls_ctx* c, const mbls_keytable* t, hipStream_t s) {
+    if (t && t->pending && t->ev_stream != s) HIPCHK(c, hipStreamWaitEvent(s, t->ev, 0));
+    return MBLS_OK;
+}
 
-static int verify_pipeline(mbls_ctx* c, const uint8_t* d_sigs, const uint8_t* d_msgs, uint32_t msg_len, const keysrc& ks,
+static int verify_pipeline(mbls_ctx* c, const uint8_t* d_sigs, const uint8_t* d_msgs, uint32_t msg_len, const uint64_t* d_moff, const keysrc& ks,
                            uint64_t n, uint32_t k, int mode, uint8_t* d_results, uint64_t* d_bitmap,
                            uint32_t* d_status, hipStream_t s, int part = 0) {
     const int fmt = ks.fmt; const uint32_t* d_off = ks.d_off;
     if (!c || (fmt != MBLS_PK_COMPRESSED && fmt != MBLS_PK_UNCOMPRESSED)) return MBLS_ERR_ARGUMENT;
     if (n == 0) return MBLS_OK;
     const bool have_keys = ks.indexed ? (ks.d_idx != nullptr) : (ks.d_pks != nullptr);
-    if (!d_sigs || !d_msgs || !d_results || (!have_keys && (k || d_off) && part != 1)) ARGFAIL(c, "null buffer");
+    if (!d_sigs || (!d_msgs && msg_len && !d_moff) || !d_results || (!have_keys && (k || d_off) && part != 1)) ARGFAIL(c, "null buffer");
     HIPCHK(c, hipSetDevice(c->device));
     int rc = mbls_ctx_reserve(c, n); if (rc) return rc;
     mbls_ws ws; ws.w = c->d_w; ws.stride = c->cap;
@@ -489,11 +514,12 @@ static int verify_pipeline(mbls_ctx* c, const uint8_t* d_sigs, const uint8_t* d_
     }
     if (part == 1) {
         hipLaunchKernelGGL(k_sig, dim3(g), dim3(WG), 0, s_sig, ws, d_sigs, st, n);
-        hipLaunchKernelGGL(k_hash, dim3(g), dim3(WG), 0, s_msg, ws, d_msgs, msg_len, (const uint64_t*)nullptr, (const uint32_t*)nullptr, n);
+        hipLaunchKernelGGL(k_hash, dim3(g), dim3(WG), 0, s_msg, ws, d_msgs, msg_len, d_moff, st, n);
         HIPCHK(c, hipGetLastError());
         return MBLS_OK;
     }
     if (tm) HIPCHK(c, hipEventRecord(c->ev[0], s));
+    if (ks.indexed) { rc = table_acquire(c, ks.tab, s); if (rc) return rc; }
     if (ks.indexed)
         hipLaunchKernelGGL(k_aggregate_indexed_d, dim3(g), dim3(WG), 0, s, ws, ks.d_recs, ks.tsize, ks.d_idx, d_off, k, mode, st, n);
     else if (staged) {
@@ -504,7 +530,7 @@ static int verify_pipeline(mbls_ctx* c, const uint8_t* d_sigs, const uint8_t* d_
     if (tm) HIPCHK(c, hipEventRecord(c->ev[1], s));
     if (!keys_later) hipLaunchKernelGGL(k_sig, dim3(g), dim3(WG), 0, s_sig, ws, d_sigs, st, n);
     if (tm) HIPCHK(c, hipEventRecord(c->ev[2], s));
-    if (!keys_later) hipLaunchKernelGGL(k_hash, dim3(g), dim3(WG), 0, s_msg, ws, d_msgs, msg_len, (const uint64_t*)nullptr, (const uint32_t*)nullptr, n);
+    if (!keys_later) hipLaunchKernelGGL(k_hash, dim3(g), dim3(WG), 0, s_msg, ws, d_msgs, msg_len, d_moff, st, n);
     if (tm) HIPCHK(c, hipEventRecord(c->ev[3], s));
     if (fork) {      // join
         if (s_sig != s) { HIPCHK(c, hipEventRecord(c->hs_ev2, s_sig)); HIPCHK(c, hipStreamWaitEvent(s, c->hs_ev2, 0)); }
@@ -524,19 +550,19 @@ static int verify_pipeline(mbls_ctx* c, const uint8_t* d_sigs, const uint8_t* d_
     return ws_release(c, s);
 }
 extern "C" int mbls_fast_aggregate_verify_batch_device(mbls_ctx* c, const uint8_t* d_sigs, const uint8_t* d_msgs, uint32_t msg_len,
-        const uint8_t* d_pks, int fmt, const uint32_t* d_off, uint64_t n, uint32_t k, uint8_t* d_results, uint64_t* d_bitmap,
+        const uint64_t* d_moff, const uint8_t* d_pks, int fmt, const uint32_t* d_off, uint64_t n, uint32_t k, uint8_t* d_results, uint64_t* d_bitmap,
         uint32_t* d_status, void* stream) {
     if (!c) return MBLS_ERR_ARGUMENT;
     mbls_lock lk(c->mu);
     keysrc ks; ks.d_pks = d_pks; ks.fmt = fmt; ks.d_off = d_off;
-    return verify_pipeline(c, d_sigs, d_msgs, msg_len, ks, n, k, MBLS_MODE_FAST_AGGREGATE, d_results, d_bitmap, d_status, (hipStream_t)stream);
+    return verify_pipeline(c, d_sigs, d_msgs, msg_len, d_moff, ks, n, k, MBLS_MODE_FAST_AGGREGATE, d_results, d_bitmap, d_status, (hipStream_t)stream);
 }
-extern "C" int mbls_verify_batch_device(mbls_ctx* c, const uint8_t* d_sigs, const uint8_t* d_msgs, uint32_t msg_len,
+extern "C" int mbls_verify_batch_device(mbls_ctx* c, const uint8_t* d_sigs, const uint8_t* d_msgs, uint32_t msg_len, const uint64_t* d_moff,
         const uint8_t* d_pks, int fmt, uint64_t n, uint8_t* d_results, uint64_t* d_bitmap, uint32_t* d_status, void* stream) {
     if (!c) return MBLS_ERR_ARGUMENT;
     mbls_lock lk(c->mu);
     keysrc ks; ks.d_pks = d_pks; ks.fmt = fmt;
-    return verify_pipeline(c, d_sigs, d_msgs, msg_len, ks, n, 1, MBLS_MODE_VERIFY, d_results, d_bitmap, d_status, (hipStream_t)stream);
+    return verify_pipeline(c, d_sigs, d_msgs, msg_len, d_moff, ks, n, 1, MBLS_MODE_VERIFY, d_results, d_bitmap, d_status, (hipStream_t)stream);
 }
 
 // offsets of a ragged key / signature table handed over in host memory: non-decreasing, and the total fits the index type
@@ -544,56 +570,75 @@ static bool offsets_ok(const uint32_t* off, uint64_t n) {
     for (uint64_t i = 0; i < n; i++) if (off[i + 1] < off[i]) return false;
     return true;
 }
+// message ranges: non-decreasing, every message shorter than 2^32 bytes
+static bool msg_offsets_ok(const uint64_t* off, uint64_t n) {
+    for (uint64_t i = 0; i < n; i++) if (off[i + 1] < off[i] || off[i + 1] - off[i] > 0xFFFFFFFFull) return false;
+    return true;
+}
 
 // Host buffers in, results out. The keys (or key indices) are 99 % of the bytes: they are uploaded on a second stream while the
 // signature and message phases run.
-static int verify_host(mbls_ctx* c, const uint8_t* sigs, const uint8_t* msgs, uint32_t msg_len, const uint8_t* pks, int fmt,
+static int verify_host(mbls_ctx* c, const uint8_t* sigs, const uint8_t* msgs, uint32_t msg_len, const uint64_t* moff, const uint8_t* pks, int fmt,
                        const mbls_keytable* tab, const uint32_t* idx, const uint32_t* off, uint64_t n, uint32_t k, int mode,
                        uint8_t* results, uint32_t* status) {
     if (!c) return MBLS_ERR_ARGUMENT;
     mbls_lock lk(c->mu);
     if (n == 0) return MBLS_OK;
-    if (!sigs || (!msgs && msg_len) || !results) ARGFAIL(c, "null buffer");
+    if (moff && !msg_offsets_ok(moff, n)) ARGFAIL(c, "msg_offsets must be non-decreasing, messages below 2^32 bytes");
+    const uint64_t msg_first = moff ? moff[0] : 0;                       // the bytes this call uploads: msgs[msg_first .. msg_first + msg_total)
+    const size_t msg_total = moff ? (size_t)(moff[n] - moff[0]) : (size_t)msg_len * n;
+    if (!sigs || (!msgs && msg_total) || !results) ARGFAIL(c, "null buffer");
     if (fmt != MBLS_PK_COMPRESSED && fmt != MBLS_PK_UNCOMPRESSED) ARGFAIL(c, "pk_format");
     if (tab && tab->c != c) ARGFAIL(c, "key table belongs to another context");
     if (off && !offsets_ok(off, n)) ARGFAIL(c, "offsets must be non-decreasing");
     HIPCHK(c, hipSetDevice(c->device));
-    uint64_t total_keys = off ? off[n] : (uint64_t)k * n;
+    // like the messages, a key offset table may start anywhere (a shard of a larger batch): only keys [off[0], off[n]) are uploaded
+    const uint64_t key_first = off ? off[0] : 0;
+    uint64_t total_keys = off ? (uint64_t)(off[n] - off[0]) : (uint64_t)k * n;
     const bool indexed = tab != nullptr;
     if (total_keys && !(indexed ? (const void*)idx : (const void*)pks)) ARGFAIL(c, "null key buffer");
     size_t unit = indexed ? 4 : (fmt == MBLS_PK_COMPRESSED ? 48 : 96);
-    sbuf ds(c, 0), dm(c, 1), dp(c, 2), doff(c, 3), dr(c, 4), dst(c, 5);
-    HIPCHK(c, ds.up(sigs, 96 * n)); HIPCHK(c, dm.up(msgs, (size_t)msg_len * n));
+    sbuf ds(c, 0), dm(c, 1), dp(c, 2), doff(c, 3), dr(c, 4), dst(c, 5), dmo(c, 6);
+    HIPCHK(c, ds.up(sigs, 96 * n)); HIPCHK(c, dm.up(msgs ? msgs + msg_first : nullptr, msg_total));
     if (off) HIPCHK(c, doff.up(off, 4 * (n + 1)));
+    const uint64_t* d_moff = nullptr; const uint8_t* d_msgs = dm.as<uint8_t>();
+    if (moff) {                                                          // the table as given; the uploaded bytes start at msgs[moff[0]]
+        HIPCHK(c, dmo.up(moff, 8 * (n + 1))); d_moff = dmo.as<uint64_t>(); d_msgs -= msg_first;
+    }
     HIPCHK(c, dr.alloc(n)); HIPCHK(c, dst.alloc(4 * n)); HIPCHK(c, dp.alloc(unit * total_keys));
     bool tm = c->timing; c->timing = false;              // the phase timers assume the plain order
     keysrc ks; ks.fmt = fmt; ks.d_off = off ? doff.as<uint32_t>() : nullptr; ks.indexed = indexed;
-    if (indexed) { ks.d_recs = tab->d_recs; ks.tsize = tab->size; }
-    int rc = verify_pipeline(c, ds.as<uint8_t>(), dm.as<uint8_t>(), msg_len, ks, n, k, mode, dr.as<uint8_t>(), nullptr, dst.as<uint32_t>(), c->hs_a, 1);
+    if (indexed) { ks.d_recs = tab->d_recs; ks.tsize = tab->size; ks.tab = tab; }
+    int rc = verify_pipeline(c, ds.as<uint8_t>(), d_msgs, msg_len, d_moff, ks, n, k, mode, dr.as<uint8_t>(), nullptr, dst.as<uint32_t>(), c->hs_a, 1);
     if (!rc) {
         hipError_t e1 = hipSuccess;      // issued after the first two phases were queued: a copy from pageable memory may block the host
-        if (total_keys) e1 = hipMemcpyAsync(dp.p, indexed ? (const void*)idx : (const void*)pks, unit * total_keys, hipMemcpyHostToDevice, c->hs_b);
+        if (total_keys) e1 = hipMemcpyAsync(dp.p, indexed ? (const void*)(idx + key_first) : (const void*)(pks + unit * key_first), unit * total_keys, hipMemcpyHostToDevice, c->hs_b);
         if (e1 == hipSuccess) e1 = hipEventRecord(c->hs_ev, c->hs_b);
         if (e1 == hipSuccess) e1 = hipStreamWaitEvent(c->hs_a, c->hs_ev, 0);
-        if (e1 != hipSuccess) { c->timing = tm; HIPCHK(c, e1); }
-        if (indexed) ks.d_idx = dp.as<uint32_t>(); else ks.d_pks = dp.as<uint8_t>();
-        rc = verify_pipeline(c, ds.as<uint8_t>(), dm.as<uint8_t>(), msg_len, ks, n, k, mode, dr.as<uint8_t>(), nullptr, dst.as<uint32_t>(), c->hs_a, 2);
+        if (e1 != hipSuccess) { snprintf(c->err, sizeof(c->err), "key upload failed: %s", hipGetErrorString(e1)); rc = MBLS_ERR_DEVICE; }
+        if (!rc) {
+            if (indexed) ks.d_idx = dp.as<uint32_t>() - key_first; else ks.d_pks = dp.as<uint8_t>() - unit * key_first;     // the table's offsets are absolute
+            rc = verify_pipeline(c, ds.as<uint8_t>(), d_msgs, msg_len, d_moff, ks, n, k, mode, dr.as<uint8_t>(), nullptr, dst.as<uint32_t>(), c->hs_a, 2);
+        }
     }
     c->timing = tm;
-    if (rc) return rc;
+    if (rc) {         // part 1 may be running on the context's streams: nothing of this call is left in flight when it returns an error
+        (void)hipStreamSynchronize(c->hs_a); (void)hipStreamSynchronize(c->hs_b); (void)hipStreamSynchronize(c->hs_c); c->ws_pending = false;
+        return rc;
+    }
     HIPCHK(c, hipStreamSynchronize(c->hs_a));
     c->ws_pending = false;
     HIPCHK(c, dr.down(results, n));
     if (status) HIPCHK(c, dst.down(status, 4 * n));
     return MBLS_OK;
 }
-extern "C" int mbls_fast_aggregate_verify_batch(mbls_ctx* c, const uint8_t* sigs, const uint8_t* msgs, uint32_t msg_len, const uint8_t* pks,
-        int fmt, const uint32_t* off, uint64_t n, uint32_t k, uint8_t* results, uint32_t* status) {
-    return verify_host(c, sigs, msgs, msg_len, pks, fmt, nullptr, nullptr, off, n, k, MBLS_MODE_FAST_AGGREGATE, results, status);
+extern "C" int mbls_fast_aggregate_verify_batch(mbls_ctx* c, const uint8_t* sigs, const uint8_t* msgs, uint32_t msg_len, const uint64_t* moff,
+        const uint8_t* pks, int fmt, const uint32_t* off, uint64_t n, uint32_t k, uint8_t* results, uint32_t* status) {
+    return verify_host(c, sigs, msgs, msg_len, moff, pks, fmt, nullptr, nullptr, off, n, k, MBLS_MODE_FAST_AGGREGATE, results, status);
 }
-extern "C" int mbls_verify_batch(mbls_ctx* c, const uint8_t* sigs, const uint8_t* msgs, uint32_t msg_len, const uint8_t* pks, int fmt,
+extern "C" int mbls_verify_batch(mbls_ctx* c, const uint8_t* sigs, const uint8_t* msgs, uint32_t msg_len, const uint64_t* moff, const uint8_t* pks, int fmt,
         uint64_t n, uint8_t* results, uint32_t* status) {
-    return verify_host(c, sigs, msgs, msg_len, pks, fmt, nullptr, nullptr, nullptr, n, 1, MBLS_MODE_VERIFY, results, status);
+    return verify_host(c, sigs, msgs, msg_len, moff, pks, fmt, nullptr, nullptr, nullptr, n, 1, MBLS_MODE_VERIFY, results, status);
 }
 
 // ---- resident key table
@@ -605,31 +650,43 @@ extern "C" int mbls_keytable_create(mbls_ctx* c, uint64_t capacity_hint, mbls_ke
     if (!t) return MBLS_ERR_DEVICE;
     t->c = c; t->cap = capacity_hint ? capacity_hint : 1024;
     hipError_t e = hipMalloc(&t->d_recs, t->cap * MBLS_KEYREC_DWORDS * 4);
-    if (e != hipSuccess) { delete t; HIPCHK(c, e); }
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&t->ev, hipEventDisableTiming);
+    if (e != hipSuccess) { if (t->d_recs) (void)hipFree(t->d_recs); delete t; HIPCHK(c, e); }
+    try { c->tables.push_back(t); } catch (...) { (void)hipFree(t->d_recs); (void)hipEventDestroy(t->ev); delete t; return MBLS_ERR_DEVICE; }
     *out = t; return MBLS_OK;
 }
+// Either order of destruction is fine: a table whose context went first is an empty shell (mbls_ctx_destroy released its records).
 extern "C" void mbls_keytable_destroy(mbls_keytable* t) {
     if (!t) return;
-    { mbls_lock lk(t->c->mu); (void)hipSetDevice(t->c->device); (void)hipDeviceSynchronize(); if (t->d_recs) (void)hipFree(t->d_recs); }
+    if (t->c) {
+        mbls_ctx* c = t->c;
+        mbls_lock lk(c->mu); (void)hipSetDevice(c->device); (void)hipDeviceSynchronize();
+        if (t->d_recs) (void)hipFree(t->d_recs);
+        if (t->ev) (void)hipEventDestroy(t->ev);
+        for (size_t i = 0; i < c->tables.size(); i++) if (c->tables[i] == t) { c->tables.erase(c->tables.begin() + i); break; }
+    }
     delete t;
 }
-extern "C" uint64_t mbls_keytable_size(const mbls_keytable* t) { if (!t) return 0; mbls_lock lk(t->c->mu); return t->size; }
+extern "C" uint64_t mbls_keytable_size(const mbls_keytable* t) { if (!t || !t->c) return 0; mbls_lock lk(t->c->mu); return t->size; }
 static int keytable_grow(mbls_keytable* t, uint64_t need, hipStream_t s) {
     mbls_ctx* c = t->c;
     if (need <= t->cap) return MBLS_OK;
     uint64_t ncap = t->cap * 2 > need ? t->cap * 2 : need;
     uint32_t* nr = nullptr;
     HIPCHK(c, hipMalloc(&nr, ncap * MBLS_KEYREC_DWORDS * 4));
-    hipError_t e = hipSuccess;
-    if (t->size) e = hipMemcpyAsync(nr, t->d_recs, t->size * MBLS_KEYREC_DWORDS * 4, hipMemcpyDeviceToDevice, s);
-    if (e == hipSuccess) e = hipDeviceSynchronize();      // verifications in flight on other streams may still read the old records
+    // appends in flight on other streams must have written the old records before they are copied, and verifications in flight may
+    // still read them when they are freed: the device is drained on both sides of the copy (growth is rare; reserve with capacity_hint)
+    hipError_t e = hipDeviceSynchronize();
+    if (e == hipSuccess && t->size) e = hipMemcpyAsync(nr, t->d_recs, t->size * MBLS_KEYREC_DWORDS * 4, hipMemcpyDeviceToDevice, s);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e == hipSuccess) t->pending = false;
     if (e != hipSuccess) { (void)hipFree(nr); HIPCHK(c, e); }
     (void)hipFree(t->d_recs); t->d_recs = nr; t->cap = ncap;
     return MBLS_OK;
 }
 extern "C" int mbls_keytable_append_device(mbls_keytable* t, const uint8_t* d_pks, int fmt, int validate, uint64_t n, uint64_t* first_index,
                                            uint8_t* d_errs, void* stream) {
-    if (!t) return MBLS_ERR_ARGUMENT;
+    if (!t || !t->c) return MBLS_ERR_ARGUMENT;
     mbls_ctx* c = t->c;
     mbls_lock lk(c->mu);
     if ((fmt != MBLS_PK_COMPRESSED && fmt != MBLS_PK_UNCOMPRESSED) || (n && (!d_pks || !d_errs))) ARGFAIL(c, "keytable_append");
@@ -639,15 +696,19 @@ extern "C" int mbls_keytable_append_device(mbls_keytable* t, const uint8_t* d_pk
     int rc = keytable_grow(t, t->size + n, s); if (rc) return rc;
     if (first_index) *first_index = t->size;
     if (n) {
+        // an earlier append on another stream may still be writing its own records: nothing to order (disjoint), but the event below
+        // replaces the earlier one, so this stream inherits the earlier append's completion first
+        if (t->pending && t->ev_stream != s) HIPCHK(c, hipStreamWaitEvent(s, t->ev, 0));
         hipLaunchKernelGGL(k_keytable_append, dim3(nblk(n)), dim3(WG), 0, s, d_pks, fmt, validate, n, t->d_recs + t->size * MBLS_KEYREC_DWORDS, d_errs);
         HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipEventRecord(t->ev, s)); t->ev_stream = s; t->pending = true;     // readers on other streams wait for this (table_acquire)
     }
     t->size += n; return MBLS_OK;
 }
 static int map_dec_err_g1(int e) { return e == MBLS_DEC_OK ? MBLS_OK : (e == MBLS_DEC_SIZE ? MBLS_ERR_INVALID_G1_SIZE : MBLS_ERR_INVALID_POINT); }
 static int map_dec_err_g2(int e) { return e == MBLS_DEC_OK ? MBLS_OK : (e == MBLS_DEC_SIZE ? MBLS_ERR_INVALID_G2_SIZE : MBLS_ERR_INVALID_POINT); }
 extern "C" int mbls_keytable_append(mbls_keytable* t, const uint8_t* pks, int fmt, int validate, uint64_t n, uint64_t* first_index, uint8_t* errs) {
-    if (!t) return MBLS_ERR_ARGUMENT;
+    if (!t || !t->c) return MBLS_ERR_ARGUMENT;
     mbls_ctx* c = t->c;
     mbls_lock lk(c->mu);
     if ((fmt != MBLS_PK_COMPRESSED && fmt != MBLS_PK_UNCOMPRESSED) || (n && (!pks || !errs))) ARGFAIL(c, "keytable_append");
@@ -656,35 +717,37 @@ extern "C" int mbls_keytable_append(mbls_keytable* t, const uint8_t* pks, int fm
     HIPCHK(c, di.up(pks, (fmt ? 96 : 48) * n)); HIPCHK(c, de.alloc(n));
     int rc = mbls_keytable_append_device(t, di.as<uint8_t>(), fmt, validate, n, first_index, de.as<uint8_t>(), c->hs_a); if (rc) return rc;
     HIPCHK(c, hipStreamSynchronize(c->hs_a)); HIPCHK(c, de.down(errs, n));
+    if (t->ev_stream == c->hs_a) t->pending = false;
     for (uint64_t i = 0; i < n; i++) errs[i] = (uint8_t)map_dec_err_g1(errs[i]);
     return MBLS_OK;
 }
 extern "C" int mbls_keytable_get(mbls_keytable* t, uint64_t first, uint64_t n, uint8_t* pks96, uint8_t* errs) {
-    if (!t) return MBLS_ERR_ARGUMENT;
+    if (!t || !t->c) return MBLS_ERR_ARGUMENT;
     mbls_ctx* c = t->c;
     mbls_lock lk(c->mu);
     if (first + n > t->size || (n && (!pks96 || !errs))) ARGFAIL(c, "keytable_get range");
     if (!n) return MBLS_OK;
     HIPCHK(c, hipSetDevice(c->device));
     sbuf dout(c, 0), de(c, 1); HIPCHK(c, dout.alloc(96 * n)); HIPCHK(c, de.alloc(n));
+    { int rc = table_acquire(c, t, c->hs_a); if (rc) return rc; }
     hipLaunchKernelGGL(k_keytable_export, dim3(nblk(n)), dim3(WG), 0, c->hs_a, (const uint32_t*)t->d_recs, first, n, dout.as<uint8_t>(), de.as<uint8_t>());
     HIPCHK(c, hipStreamSynchronize(c->hs_a)); HIPCHK(c, dout.down(pks96, 96 * n)); HIPCHK(c, de.down(errs, n));
     for (uint64_t i = 0; i < n; i++) errs[i] = (uint8_t)map_dec_err_g1(errs[i]);
     return MBLS_OK;
 }
 extern "C" int mbls_fast_aggregate_verify_batch_indexed_device(mbls_ctx* c, const mbls_keytable* t, const uint8_t* d_sigs, const uint8_t* d_msgs,
-        uint32_t msg_len, const uint32_t* d_idx, const uint32_t* d_off, uint64_t n, uint32_t k, uint8_t* d_results, uint64_t* d_bitmap,
+        uint32_t msg_len, const uint64_t* d_moff, const uint32_t* d_idx, const uint32_t* d_off, uint64_t n, uint32_t k, uint8_t* d_results, uint64_t* d_bitmap,
         uint32_t* d_status, void* stream) {
     if (!c || !t) return MBLS_ERR_ARGUMENT;
     mbls_lock lk(c->mu);
     if (t->c != c) ARGFAIL(c, "key table belongs to another context");
-    keysrc ks; ks.indexed = true; ks.d_recs = t->d_recs; ks.tsize = t->size; ks.d_idx = d_idx; ks.d_off = d_off;
-    return verify_pipeline(c, d_sigs, d_msgs, msg_len, ks, n, k, MBLS_MODE_FAST_AGGREGATE, d_results, d_bitmap, d_status, (hipStream_t)stream);
+    keysrc ks; ks.indexed = true; ks.d_recs = t->d_recs; ks.tsize = t->size; ks.d_idx = d_idx; ks.d_off = d_off; ks.tab = t;
+    return verify_pipeline(c, d_sigs, d_msgs, msg_len, d_moff, ks, n, k, MBLS_MODE_FAST_AGGREGATE, d_results, d_bitmap, d_status, (hipStream_t)stream);
 }
 extern "C" int mbls_fast_aggregate_verify_batch_indexed(mbls_ctx* c, const mbls_keytable* t, const uint8_t* sigs, const uint8_t* msgs, uint32_t msg_len,
-        const uint32_t* idx, const uint32_t* off, uint64_t n, uint32_t k, uint8_t* results, uint32_t* status) {
+        const uint64_t* moff, const uint32_t* idx, const uint32_t* off, uint64_t n, uint32_t k, uint8_t* results, uint32_t* status) {
     if (!c || !t) return MBLS_ERR_ARGUMENT;
-    return verify_host(c, sigs, msgs, msg_len, nullptr, MBLS_PK_UNCOMPRESSED, t, idx, off, n, k, MBLS_MODE_FAST_AGGREGATE, results, status);
+    return verify_host(c, sigs, msgs, msg_len, moff, nullptr, MBLS_PK_UNCOMPRESSED, t, idx, off, n, k, MBLS_MODE_FAST_AGGREGATE, results, status);
 }
 
 // ---- batch helpers
@@ -795,11 +858,14 @@ extern "C" int mbls_aggregate_signatures_batch_device(mbls_ctx* c, const uint8_t
     if (!d_off && total != (uint64_t)k * n) ARGFAIL(c, "total_sigs != n_sets * k");
     HIPCHK(c, hipSetDevice(c->device));
     hipStream_t s = (hipStream_t)stream;
-    sbuf dxy(c, 6), dfl(c, 7); HIPCHK(c, dxy.alloc(192 * total)); HIPCHK(c, dfl.alloc(total));
+    // the decoded points pass through two of the context's staging buffers: ordered against calls on other streams like the workspace
+    // (a buffer that has to grow is freed, which drains the device first)
+    int rc = ws_acquire(c, s); if (rc) return rc;
+    sbuf dxy(c, 7), dfl(c, 8); HIPCHK(c, dxy.alloc(192 * total)); HIPCHK(c, dfl.alloc(total));
     if (total) hipLaunchKernelGGL(k_g2_decode_affine, dim3(nblk(total)), dim3(WG), 0, s, d_sigs, total, dxy.as<uint32_t>(), dfl.as<uint8_t>());
     hipLaunchKernelGGL(k_g2_sum, dim3(nblk(n)), dim3(WG), 0, s, (const uint32_t*)dxy.as<uint32_t>(), (const uint8_t*)dfl.as<uint8_t>(), d_off, k, n, d_out96, d_errs);
     HIPCHK(c, hipGetLastError());
-    return MBLS_OK;
+    return ws_release(c, s);
 }
 extern "C" int mbls_aggregate_signatures_batch(mbls_ctx* c, const uint8_t* sigs, const uint32_t* off, uint64_t n, uint32_t k, uint8_t* out96, uint8_t* errs) {
     if (!c || !out96 || !errs) return MBLS_ERR_ARGUMENT;
@@ -910,7 +976,7 @@ extern "C" int mbls_sign(mbls_ctx* c, const uint8_t* msg, size_t msg_len, const 
 }
 extern "C" int mbls_verify(mbls_ctx* c, const uint8_t sig[96], const uint8_t* msg, size_t msg_len, const uint8_t pk[96]) {
     uint8_t r = 0; if (!c || !sig || !pk || msg_len > 0xFFFFFFFFull) return 0;
-    if (mbls_verify_batch(c, sig, msg, (uint32_t)msg_len, pk, MBLS_PK_UNCOMPRESSED, 1, &r, nullptr)) return 0;
+    if (mbls_verify_batch(c, sig, msg, (uint32_t)msg_len, nullptr, pk, MBLS_PK_UNCOMPRESSED, 1, &r, nullptr)) return 0;
     return r;
 }
 extern "C" int mbls_aggregate_public_keys(mbls_ctx* c, const uint8_t* pks96, size_t n, uint8_t apk_out[96]) {
@@ -942,13 +1008,13 @@ extern "C" int mbls_aggregate_signature_add(mbls_ctx* c, const uint8_t a[96], co
 extern "C" int mbls_fast_aggregate_verify(mbls_ctx* c, const uint8_t sig[96], const uint8_t* msg, size_t msg_len, const uint8_t* pks96, size_t n_pks) {
     uint8_t r = 0; if (!c || !sig || msg_len > 0xFFFFFFFFull || n_pks > 0xFFFFFFFFull) return 0;
     if (n_pks == 0) return 0;                                         // reference src/aggregates.rs:179-181
-    if (mbls_fast_aggregate_verify_batch(c, sig, msg, (uint32_t)msg_len, pks96, MBLS_PK_UNCOMPRESSED, nullptr, 1, (uint32_t)n_pks, &r, nullptr)) return 0;
+    if (mbls_fast_aggregate_verify_batch(c, sig, msg, (uint32_t)msg_len, nullptr, pks96, MBLS_PK_UNCOMPRESSED, nullptr, 1, (uint32_t)n_pks, &r, nullptr)) return 0;
     return r;
 }
 extern "C" int mbls_fast_aggregate_verify_pre_aggregated(mbls_ctx* c, const uint8_t sig[96], const uint8_t* msg, size_t msg_len, const uint8_t apk[96]) {
     uint8_t r = 0; if (!c || !sig || !apk || msg_len > 0xFFFFFFFFull) return 0;
     // identical checks with a one-key set: sig in G2, key != infinity, pairing (reference src/aggregates.rs:223-253)
-    if (mbls_fast_aggregate_verify_batch(c, sig, msg, (uint32_t)msg_len, apk, MBLS_PK_UNCOMPRESSED, nullptr, 1, 1, &r, nullptr)) return 0;
+    if (mbls_fast_aggregate_verify_batch(c, sig, msg, (uint32_t)msg_len, nullptr, apk, MBLS_PK_UNCOMPRESSED, nullptr, 1, 1, &r, nullptr)) return 0;
     return r;
 }
 
@@ -975,16 +1041,17 @@ extern "C" int mbls_aggregate_verify(mbls_ctx* c, const uint8_t sig[96], const u
     if (hipSetDevice(c->device) != hipSuccess) return 0;
     uint64_t n = n_pks;
     if (mbls_ctx_reserve(c, n)) return 0;
-    std::vector<uint64_t> off; std::vector<uint32_t> lens;
-    try { off.resize(n); lens.resize(n); } catch (...) { return 0; }
+    std::vector<uint64_t> off;
+    try { off.resize(n + 1); } catch (...) { return 0; }
     size_t total = 0;
     for (size_t i = 0; i < n; i++) {
         if (msg_lens[i] > 0xFFFFFFFFull) return 0;
-        off[i] = total; lens[i] = (uint32_t)msg_lens[i]; total += msg_lens[i];
+        off[i] = total; total += msg_lens[i];
     }
+    off[n] = total;
     if (total && !msgs) return 0;
-    sbuf dm(c, 0), doff(c, 1), dl(c, 2), dp(c, 3), dsig(c, 4); int result = 0;
-    if (dm.up(msgs, total) != hipSuccess || doff.up(off.data(), 8 * n) != hipSuccess || dl.up(lens.data(), 4 * n) != hipSuccess ||
+    sbuf dm(c, 0), doff(c, 1), dp(c, 3), dsig(c, 4); int result = 0;
+    if (dm.up(msgs, total) != hipSuccess || doff.up(off.data(), 8 * (n + 1)) != hipSuccess ||
         dp.up(pks96, 96 * n) != hipSuccess || dsig.up(sig, 96) != hipSuccess) return 0;
     mbls_ws ws; ws.w = c->d_w; ws.stride = c->cap;
     hipStream_t s = c->hs_a;
@@ -994,7 +1061,7 @@ extern "C" int mbls_aggregate_verify(mbls_ctx* c, const uint8_t sig[96], const u
     hipLaunchKernelGGL(k_sig_to_slot, dim3(1), dim3(WG), 0, s, ws, dsig.as<uint8_t>(), (uint64_t)0, c->d_scalar);
     hipLaunchKernelGGL(k_blind_g1, dim3(nblk(n)), dim3(WG), 0, s, ws, dp.as<uint8_t>(), (const uint64_t*)nullptr, c->d_status, n);   // r_i = 1: no blinding in AggregateVerify
     hipLaunchKernelGGL(k_status_or, dim3(nblk(n)), dim3(WG), 0, s, c->d_status, n, c->d_scalar);
-    hipLaunchKernelGGL(k_hash, dim3(nblk(n)), dim3(WG), 0, s, ws, dm.as<uint8_t>(), 0u, doff.as<uint64_t>(), dl.as<uint32_t>(), n);
+    hipLaunchKernelGGL(k_hash, dim3(nblk(n)), dim3(WG), 0, s, ws, dm.as<uint8_t>(), 0u, (const uint64_t*)doff.as<uint64_t>(), c->d_status, n);
     uint32_t st = 0;
     if (hipStreamSynchronize(s) != hipSuccess || hipMemcpy(&st, c->d_scalar, 4, hipMemcpyDeviceToHost) != hipSuccess) return 0;
     if (st & (MBLS_ST_BAD_SIG_ENCODING | MBLS_ST_SIG_NOT_IN_G2 | MBLS_ST_BAD_PK_ENCODING)) { c->ws_pending = false; return 0; }   // reference src/aggregates.rs:137-139
@@ -1002,13 +1069,13 @@ extern "C" int mbls_aggregate_verify(mbls_ctx* c, const uint8_t sig[96], const u
     return result;
 }
 static int verify_multiple_impl(mbls_ctx* c, const uint8_t* d_sigs, const uint8_t* d_apks, const uint8_t* d_pks, int pk_format,
-        const uint32_t* d_pk_offsets, uint32_t k, const uint8_t* d_msgs, uint32_t msg_len, const uint64_t* d_rands, uint64_t n, int* result, void* stream) {
+        const uint32_t* d_pk_offsets, uint32_t k, const uint8_t* d_msgs, uint32_t msg_len, const uint64_t* d_moff, const uint64_t* d_rands, uint64_t n, int* result, void* stream) {
     if (!c || !result) return MBLS_ERR_ARGUMENT;
     mbls_lock lk(c->mu);
     *result = 0;
     if (n == 0) { *result = 1; return MBLS_OK; }     // empty iterator: S' = infinity, product of no pairings = 1 -> e(inf, -G1) = 1 -> true
     if (!d_rands) ARGFAIL(c, "verify_multiple without blinding scalars is forgeable: rands must not be NULL");
-    if (!d_sigs || (!d_msgs && msg_len)) ARGFAIL(c, "null buffer");
+    if (!d_sigs || (!d_msgs && msg_len && !d_moff)) ARGFAIL(c, "null buffer");
     hipStream_t s = (hipStream_t)stream;
     HIPCHK(c, hipSetDevice(c->device));
     int rc = mbls_ctx_reserve(c, n); if (rc) return rc;
@@ -1027,7 +1094,7 @@ static int verify_multiple_impl(mbls_ctx* c, const uint8_t* d_sigs, const uint8_
     hipLaunchKernelGGL(k_blind_g1, dim3(nblk(n)), dim3(WG), 0, s, ws, d_apks, d_rands, c->d_status, n);
     hipLaunchKernelGGL(k_blind_sig, dim3(nblk(n)), dim3(WG), 0, s_sig, ws, d_sigs, d_rands, c->d_status, n);
     { uint64_t m = n; while (m > 1) { uint64_t half = (m + 1) / 2; hipLaunchKernelGGL(k_g2_tree, dim3(nblk(half)), dim3(WG), 0, s_sig, ws, m, half); m = half; } }
-    hipLaunchKernelGGL(k_hash, dim3(nblk(n)), dim3(WG), 0, s_msg, ws, d_msgs, msg_len, (const uint64_t*)nullptr, (const uint32_t*)nullptr, n);
+    hipLaunchKernelGGL(k_hash, dim3(nblk(n)), dim3(WG), 0, s_msg, ws, d_msgs, msg_len, d_moff, c->d_status, n);
     if (fork) {
         HIPCHK(c, hipEventRecord(c->hs_ev2, s_sig)); HIPCHK(c, hipEventRecord(c->hs_ev3, s_msg));
         HIPCHK(c, hipStreamWaitEvent(s, c->hs_ev2, 0)); HIPCHK(c, hipStreamWaitEvent(s, c->hs_ev3, 0));
@@ -1037,33 +1104,157 @@ static int verify_multiple_impl(mbls_ctx* c, const uint8_t* d_sigs, const uint8_
     HIPCHK(c, hipStreamSynchronize(s));
     HIPCHK(c, hipMemcpy(&st, c->d_scalar, 4, hipMemcpyDeviceToHost));
     if (st & MBLS_ST_BAD_SCALAR) { c->ws_pending = false; ARGFAIL(c, "a blinding scalar is zero"); }
-    if (st & (MBLS_ST_BAD_SIG_ENCODING | MBLS_ST_SIG_NOT_IN_G2 | MBLS_ST_BAD_PK_ENCODING)) { c->ws_pending = false; *result = 0; return MBLS_OK; }   // reference src/aggregates.rs:274-276
+    if (st & (MBLS_ST_BAD_SIG_ENCODING | MBLS_ST_SIG_NOT_IN_G2 | MBLS_ST_BAD_PK_ENCODING | MBLS_ST_BAD_MSG_RANGE)) { c->ws_pending = false; *result = 0; return MBLS_OK; }   // reference src/aggregates.rs:274-276
     return npairing_finish(c, n, s, result);
 }
 extern "C" int mbls_verify_multiple_aggregate_signatures_device(mbls_ctx* c, const uint8_t* d_sigs, const uint8_t* d_apks, const uint8_t* d_msgs,
-        uint32_t msg_len, const uint64_t* d_rands, uint64_t n, int* result, void* stream) {
+        uint32_t msg_len, const uint64_t* d_moff, const uint64_t* d_rands, uint64_t n, int* result, void* stream) {
     if (!c) return MBLS_ERR_ARGUMENT;
     if (n && !d_apks) return MBLS_ERR_ARGUMENT;
-    return verify_multiple_impl(c, d_sigs, d_apks, nullptr, 0, nullptr, 0, d_msgs, msg_len, d_rands, n, result, stream);
+    return verify_multiple_impl(c, d_sigs, d_apks, nullptr, 0, nullptr, 0, d_msgs, msg_len, d_moff, d_rands, n, result, stream);
 }
 extern "C" int mbls_verify_multiple_sets_device(mbls_ctx* c, const uint8_t* d_sigs, const uint8_t* d_pks, int pk_format, const uint32_t* d_pk_offsets,
-        uint32_t k, const uint8_t* d_msgs, uint32_t msg_len, const uint64_t* d_rands, uint64_t n, int* result, void* stream) {
+        uint32_t k, const uint8_t* d_msgs, uint32_t msg_len, const uint64_t* d_moff, const uint64_t* d_rands, uint64_t n, int* result, void* stream) {
     if (!c) return MBLS_ERR_ARGUMENT;
     if (pk_format != MBLS_PK_COMPRESSED && pk_format != MBLS_PK_UNCOMPRESSED) return MBLS_ERR_ARGUMENT;
     if (n && !d_pks) return MBLS_ERR_ARGUMENT;
-    return verify_multiple_impl(c, d_sigs, nullptr, d_pks, pk_format, d_pk_offsets, k, d_msgs, msg_len, d_rands, n, result, stream);
+    return verify_multiple_impl(c, d_sigs, nullptr, d_pks, pk_format, d_pk_offsets, k, d_msgs, msg_len, d_moff, d_rands, n, result, stream);
 }
 extern "C" int mbls_verify_multiple_aggregate_signatures(mbls_ctx* c, const uint8_t* sigs96, const uint8_t* apks96, const uint8_t* msgs,
-        uint32_t msg_len, const uint64_t* rands, size_t n) {
+        uint32_t msg_len, const uint64_t* moff, const uint64_t* rands, size_t n) {
     if (!c) return 0;
     if (n == 0) return 1;
-    if (!sigs96 || !apks96 || !rands || (!msgs && msg_len)) return 0;
+    if (moff && !msg_offsets_ok(moff, n)) return 0;
+    const uint64_t msg_first = moff ? moff[0] : 0;
+    const size_t msg_total = moff ? (size_t)(moff[n] - moff[0]) : (size_t)msg_len * n;
+    if (!sigs96 || !apks96 || !rands || (!msgs && msg_total)) return 0;
     mbls_lock lk(c->mu);
     if (hipSetDevice(c->device) != hipSuccess) return 0;
-    sbuf ds(c, 0), da(c, 1), dm(c, 2), dr(c, 3);
-    if (ds.up(sigs96, 96 * n) != hipSuccess || da.up(apks96, 96 * n) != hipSuccess || dm.up(msgs, (size_t)msg_len * n) != hipSuccess ||
-        dr.up(rands, 8 * n) != hipSuccess) return 0;
+    sbuf ds(c, 0), da(c, 1), dm(c, 2), dr(c, 3), dmo(c, 6);
+    if (ds.up(sigs96, 96 * n) != hipSuccess || da.up(apks96, 96 * n) != hipSuccess || dm.up(msgs ? msgs + msg_first : nullptr, msg_total) != hipSuccess ||
+        dr.up(rands, 8 * n) != hipSuccess || (moff && dmo.up(moff, 8 * (n + 1)) != hipSuccess)) return 0;
     int result = 0;
-    if (mbls_verify_multiple_aggregate_signatures_device(c, ds.as<uint8_t>(), da.as<uint8_t>(), dm.as<uint8_t>(), msg_len, dr.as<uint64_t>(), n, &result, c->hs_a)) return 0;
+    if (mbls_verify_multiple_aggregate_signatures_device(c, ds.as<uint8_t>(), da.as<uint8_t>(), dm.as<uint8_t>() - msg_first, msg_len,
+                                                         moff ? dmo.as<uint64_t>() : nullptr, dr.as<uint64_t>(), n, &result, c->hs_a)) return 0;
     return result;
+}
+
+// ------------------------------------------------------------------------------------------------ several GPUs behind one handle
+// items are independent (reference src/aggregates.rs:177-215 holds no state between calls), so a batch is cut
+// into contiguous shards, one per device; each device has its own context, and one host thread per device stages and verifies its
+// shard, writing results straight into the caller's buffers. No device talks to another. Key tables are replicated on every device.
+#include <thread>
+struct mbls_multi { std::vector<mbls_ctx*> ctx; char err[256] = {}; std::mutex mu; };
+struct mbls_multi_keytable { mbls_multi* m = nullptr; std::vector<mbls_keytable*> tab; };
+
+extern "C" int mbls_multi_create(mbls_multi** out, const int* device_ids, int n_devices) {
+    if (!out || !device_ids || n_devices <= 0) return MBLS_ERR_ARGUMENT;
+    mbls_multi* m = new (std::nothrow) mbls_multi();
+    if (!m) return MBLS_ERR_DEVICE;
+    for (int g = 0; g < n_devices; g++) {          // the same device may be listed more than once (two contexts share it)
+        mbls_ctx* c = nullptr;
+        int rc = mbls_ctx_create(&c, device_ids[g]);
+        if (rc) { for (mbls_ctx* x : m->ctx) mbls_ctx_destroy(x); delete m; return rc; }
+        m->ctx.push_back(c);
+    }
+    *out = m; return MBLS_OK;
+}
+extern "C" void mbls_multi_destroy(mbls_multi* m) {
+    if (!m) return;
+    for (mbls_ctx* c : m->ctx) mbls_ctx_destroy(c);
+    delete m;
+}
+extern "C" int mbls_multi_device_count(const mbls_multi* m) { return m ? (int)m->ctx.size() : 0; }
+extern "C" const char* mbls_multi_last_error(mbls_multi* m) { return m ? m->err : "null handle"; }
+extern "C" mbls_ctx* mbls_multi_context(mbls_multi* m, int i) { return (m && i >= 0 && i < (int)m->ctx.size()) ? m->ctx[i] : nullptr; }
+extern "C" int mbls_multi_reserve(mbls_multi* m, uint64_t max_items) {
+    if (!m) return MBLS_ERR_ARGUMENT;
+    const uint64_t G = m->ctx.size();
+    for (mbls_ctx* c : m->ctx) { int rc = mbls_ctx_reserve(c, (max_items + G - 1) / G); if (rc) return rc; }
+    return MBLS_OK;
+}
+// shard g of n items over G devices: [n g / G, n (g + 1) / G)  (the same partition as milagro_bls_amd/shard.py)
+static inline uint64_t shard_lo(uint64_t n, uint64_t g, uint64_t G) { return (uint64_t)(((unsigned __int128)n * g) / G); }
+
+static int multi_run(mbls_multi* m, const mbls_multi_keytable* mt, const uint8_t* sigs, const uint8_t* msgs, uint32_t msg_len, const uint64_t* moff,
+                     const uint8_t* pks, int fmt, const uint32_t* idx, const uint32_t* off, uint64_t n, uint32_t k, int mode, uint8_t* results, uint32_t* status) {
+    if (!m || (mt && mt->m != m)) return MBLS_ERR_ARGUMENT;
+    std::lock_guard<std::mutex> lk(m->mu);
+    const uint64_t G = m->ctx.size();
+    const size_t unit = mt ? 4 : (fmt == MBLS_PK_COMPRESSED ? 48 : 96);
+    std::vector<int> rcs(G, MBLS_OK);
+    std::vector<std::thread> th;
+    auto work = [&](uint64_t g) {
+        const uint64_t lo = shard_lo(n, g, G), hi = shard_lo(n, g + 1, G), cnt = hi - lo;
+        if (!cnt) return;
+        // uniform layouts advance the base pointers; offset tables are absolute, so their slice [lo, hi] goes with the unmoved base
+        const uint8_t* s_msgs = (moff || !msgs) ? msgs : msgs + (uint64_t)msg_len * lo;
+        const uint8_t* s_pks = (off || !pks) ? pks : pks + unit * (uint64_t)k * lo;
+        const uint32_t* s_idx = (off || !idx) ? idx : idx + (uint64_t)k * lo;
+        rcs[g] = verify_host(m->ctx[g], sigs ? sigs + 96 * lo : nullptr, s_msgs, msg_len, moff ? moff + lo : nullptr, s_pks, fmt,
+                             mt ? mt->tab[g] : nullptr, s_idx, off ? off + lo : nullptr, cnt, k, mode, results ? results + lo : nullptr,
+                             status ? status + lo : nullptr);
+    };
+    try { for (uint64_t g = 1; g < G; g++) th.emplace_back(work, g); } catch (...) { for (auto& t : th) t.join(); snprintf(m->err, sizeof(m->err), "cannot start a host thread"); return MBLS_ERR_DEVICE; }
+    work(0);
+    for (auto& t : th) t.join();
+    for (uint64_t g = 0; g < G; g++)
+        if (rcs[g]) { snprintf(m->err, sizeof(m->err), "device %d (shard %llu): %s", m->ctx[g]->device, (unsigned long long)g, m->ctx[g]->err); return rcs[g]; }
+    return MBLS_OK;
+}
+extern "C" int mbls_multi_fast_aggregate_verify_batch(mbls_multi* m, const uint8_t* sigs, const uint8_t* msgs, uint32_t msg_len, const uint64_t* moff,
+        const uint8_t* pks, int fmt, const uint32_t* off, uint64_t n, uint32_t k, uint8_t* results, uint32_t* status) {
+    return multi_run(m, nullptr, sigs, msgs, msg_len, moff, pks, fmt, nullptr, off, n, k, MBLS_MODE_FAST_AGGREGATE, results, status);
+}
+extern "C" int mbls_multi_verify_batch(mbls_multi* m, const uint8_t* sigs, const uint8_t* msgs, uint32_t msg_len, const uint64_t* moff, const uint8_t* pks, int fmt,
+        uint64_t n, uint8_t* results, uint32_t* status) {
+    return multi_run(m, nullptr, sigs, msgs, msg_len, moff, pks, fmt, nullptr, nullptr, n, 1, MBLS_MODE_VERIFY, results, status);
+}
+extern "C" int mbls_multi_keytable_create(mbls_multi* m, uint64_t capacity_hint, mbls_multi_keytable** out) {
+    if (!m || !out) return MBLS_ERR_ARGUMENT;
+    mbls_multi_keytable* t = new (std::nothrow) mbls_multi_keytable();
+    if (!t) return MBLS_ERR_DEVICE;
+    t->m = m;
+    for (mbls_ctx* c : m->ctx) {
+        mbls_keytable* x = nullptr;
+        int rc = mbls_keytable_create(c, capacity_hint, &x);
+        if (rc) { for (mbls_keytable* y : t->tab) mbls_keytable_destroy(y); delete t; return rc; }
+        t->tab.push_back(x);
+    }
+    *out = t; return MBLS_OK;
+}
+extern "C" void mbls_multi_keytable_destroy(mbls_multi_keytable* t) {
+    if (!t) return;
+    for (mbls_keytable* x : t->tab) mbls_keytable_destroy(x);
+    delete t;
+}
+extern "C" uint64_t mbls_multi_keytable_size(const mbls_multi_keytable* t) { return (t && !t->tab.empty()) ? mbls_keytable_size(t->tab[0]) : 0; }
+// the same keys, decoded on every device side by side (the indices are the same everywhere); errs as mbls_keytable_append
+extern "C" int mbls_multi_keytable_append(mbls_multi_keytable* t, const uint8_t* pks, int fmt, int validate, uint64_t n, uint64_t* first_index, uint8_t* errs) {
+    if (!t || !t->m) return MBLS_ERR_ARGUMENT;
+    mbls_multi* m = t->m;
+    std::lock_guard<std::mutex> lk(m->mu);
+    const size_t G = t->tab.size();
+    std::vector<int> rcs(G, MBLS_OK); std::vector<uint64_t> first(G, 0);
+    std::vector<std::vector<uint8_t>> e(G);
+    std::vector<std::thread> th;
+    auto work = [&](size_t g) {
+        uint8_t* eg = errs;
+        if (g) { try { e[g].resize(n ? n : 1); } catch (...) { rcs[g] = MBLS_ERR_DEVICE; return; } eg = e[g].data(); }
+        rcs[g] = mbls_keytable_append(t->tab[g], pks, fmt, validate, n, &first[g], eg);
+    };
+    try { for (size_t g = 1; g < G; g++) th.emplace_back(work, g); } catch (...) { for (auto& x : th) x.join(); return MBLS_ERR_DEVICE; }
+    work(0);
+    for (auto& x : th) x.join();
+    for (size_t g = 0; g < G; g++) {
+        if (rcs[g]) { snprintf(m->err, sizeof(m->err), "device %d: %s", m->ctx[g]->device, m->ctx[g]->err); return rcs[g]; }
+        if (first[g] != first[0] || (g && n && memcmp(e[g].data(), errs, n) != 0)) { snprintf(m->err, sizeof(m->err), "replicas of the key table disagree"); return MBLS_ERR_DEVICE; }
+    }
+    if (first_index) *first_index = first[0];
+    return MBLS_OK;
+}
+extern "C" int mbls_multi_fast_aggregate_verify_batch_indexed(mbls_multi* m, const mbls_multi_keytable* t, const uint8_t* sigs, const uint8_t* msgs, uint32_t msg_len,
+        const uint64_t* moff, const uint32_t* idx, const uint32_t* off, uint64_t n, uint32_t k, uint8_t* results, uint32_t* status) {
+    if (!t) return MBLS_ERR_ARGUMENT;
+    return multi_run(m, t, sigs, msgs, msg_len, moff, nullptr, MBLS_PK_UNCOMPRESSED, idx, off, n, k, MBLS_MODE_FAST_AGGREGATE, results, status);
 }

@@ -293,6 +293,6 @@ MBLS_FN void lane_final(const mbls_ws& ws, uint64_t i, uint32_t* status, uint8_t
     if (!fp12_is_one(&f)) st |= MBLS_ST_PAIRING_FAILED;
     *status = st;
     const uint32_t reject = MBLS_ST_BAD_SIG_ENCODING | MBLS_ST_SIG_NOT_IN_G2 | MBLS_ST_BAD_PK_ENCODING |
-                            MBLS_ST_APK_INFINITY | MBLS_ST_NO_KEYS | MBLS_ST_PAIRING_FAILED;
+                            MBLS_ST_APK_INFINITY | MBLS_ST_NO_KEYS | MBLS_ST_PAIRING_FAILED | MBLS_ST_BAD_MSG_RANGE;
     *result = (st & reject) ? 0 : 1;
 }

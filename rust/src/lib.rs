@@ -63,17 +63,18 @@ extern "C" {
     fn mbls_fast_aggregate_verify(ctx: *mut MblsCtx, sig: *const u8, msg: *const u8, msg_len: usize, pks96: *const u8, n_pks: usize) -> c_int;
     fn mbls_fast_aggregate_verify_pre_aggregated(ctx: *mut MblsCtx, sig: *const u8, msg: *const u8, msg_len: usize, apk: *const u8) -> c_int;
     fn mbls_aggregate_verify(ctx: *mut MblsCtx, sig: *const u8, msgs: *const u8, msg_lens: *const usize, n_msgs: usize, pks96: *const u8, n_pks: usize) -> c_int;
-    fn mbls_verify_multiple_aggregate_signatures(ctx: *mut MblsCtx, sigs96: *const u8, apks96: *const u8, msgs: *const u8, msg_len: u32, rands: *const u64, n: usize) -> c_int;
-    fn mbls_fast_aggregate_verify_batch(ctx: *mut MblsCtx, sigs: *const u8, msgs: *const u8, msg_len: u32, pks: *const u8, pk_format: c_int,
+    fn mbls_verify_multiple_aggregate_signatures(ctx: *mut MblsCtx, sigs96: *const u8, apks96: *const u8, msgs: *const u8, msg_len: u32, msg_offsets: *const u64,
+                                                 rands: *const u64, n: usize) -> c_int;
+    fn mbls_fast_aggregate_verify_batch(ctx: *mut MblsCtx, sigs: *const u8, msgs: *const u8, msg_len: u32, msg_offsets: *const u64, pks: *const u8, pk_format: c_int,
                                         pk_offsets: *const u32, n: u64, k: u32, results: *mut u8, status: *mut u32) -> c_int;
-    fn mbls_verify_batch(ctx: *mut MblsCtx, sigs: *const u8, msgs: *const u8, msg_len: u32, pks: *const u8, pk_format: c_int, n: u64,
+    fn mbls_verify_batch(ctx: *mut MblsCtx, sigs: *const u8, msgs: *const u8, msg_len: u32, msg_offsets: *const u64, pks: *const u8, pk_format: c_int, n: u64,
                          results: *mut u8, status: *mut u32) -> c_int;
     fn mbls_keytable_create(ctx: *mut MblsCtx, capacity_hint: u64, out: *mut *mut MblsKeyTable) -> c_int;
     fn mbls_keytable_destroy(t: *mut MblsKeyTable);
     fn mbls_keytable_size(t: *const MblsKeyTable) -> u64;
     fn mbls_keytable_append(t: *mut MblsKeyTable, pks: *const u8, pk_format: c_int, validate: c_int, n: u64, first_index: *mut u64, errs: *mut u8) -> c_int;
     fn mbls_keytable_get(t: *mut MblsKeyTable, first_index: u64, n: u64, pks96: *mut u8, errs: *mut u8) -> c_int;
-    fn mbls_fast_aggregate_verify_batch_indexed(ctx: *mut MblsCtx, t: *const MblsKeyTable, sigs: *const u8, msgs: *const u8, msg_len: u32,
+    fn mbls_fast_aggregate_verify_batch_indexed(ctx: *mut MblsCtx, t: *const MblsKeyTable, sigs: *const u8, msgs: *const u8, msg_len: u32, msg_offsets: *const u64,
                                                 key_idx: *const u32, offsets: *const u32, n: u64, k: u32, results: *mut u8, status: *mut u32) -> c_int;
 }
 const PK_COMPRESSED: c_int = 0;
@@ -492,7 +493,7 @@ impl AggregateSignature {
         I: Iterator<Item = (&'a AggregateSignature, &'a AggregatePublicKey, &'a [u8])>,
     {
         let (mut sigs, mut apks, mut msgs, mut rands) = (Vec::new(), Vec::new(), Vec::new(), Vec::<u64>::new());
-        let mut mlen: Option<usize> = None;
+        let mut moff: Vec<u64> = vec![0]; // messages of any length each (`&[u8]` per set): one buffer + an offset table
         for (s, a, m) in signature_sets {
             let mut rand = 0u64;
             while rand == 0 {
@@ -503,16 +504,14 @@ impl AggregateSignature {
             rands.push(rand);
             sigs.extend_from_slice(&s.point);
             apks.extend_from_slice(&a.point);
-            if *mlen.get_or_insert(m.len()) != m.len() {
-                panic!("verify_multiple_aggregate_signatures: messages must have equal length");
-            }
             msgs.extend_from_slice(m);
+            moff.push(msgs.len() as u64);
         }
         let n = rands.len();
         if n == 0 {
             return true; // e(infinity, -G1) = 1
         }
-        unsafe { mbls_verify_multiple_aggregate_signatures(ctx(), sigs.as_ptr(), apks.as_ptr(), msgs.as_ptr(), mlen.unwrap() as u32, rands.as_ptr(), n) == 1 }
+        unsafe { mbls_verify_multiple_aggregate_signatures(ctx(), sigs.as_ptr(), apks.as_ptr(), msgs.as_ptr(), 0, moff.as_ptr(), rands.as_ptr(), n) == 1 }
     }
     /// `src/aggregates.rs:319-322`
     pub fn from_bytes(bytes: &[u8]) -> Result<AggregateSignature, AmclError> {
@@ -547,7 +546,7 @@ pub mod batch {
         }
         let mut res = vec![0u8; n];
         let rc = unsafe {
-            mbls_fast_aggregate_verify_batch(ctx(), sigs.as_ptr(), msgs.as_ptr(), 32, pks.as_ptr(), PK_UNCOMPRESSED, offsets.as_ptr(), n as u64, 0, res.as_mut_ptr(), std::ptr::null_mut())
+            mbls_fast_aggregate_verify_batch(ctx(), sigs.as_ptr(), msgs.as_ptr(), 32, std::ptr::null(), pks.as_ptr(), PK_UNCOMPRESSED, offsets.as_ptr(), n as u64, 0, res.as_mut_ptr(), std::ptr::null_mut())
         };
         if rc != 0 {
             err(rc);
@@ -562,7 +561,7 @@ pub mod batch {
         let msgs: Vec<u8> = messages.iter().flat_map(|m| m.iter().copied()).collect();
         let pks: Vec<u8> = public_keys.iter().flat_map(|k| k.point.iter().copied()).collect();
         let mut res = vec![0u8; n];
-        let rc = unsafe { mbls_verify_batch(ctx(), sigs.as_ptr(), msgs.as_ptr(), 32, pks.as_ptr(), PK_UNCOMPRESSED, n as u64, res.as_mut_ptr(), std::ptr::null_mut()) };
+        let rc = unsafe { mbls_verify_batch(ctx(), sigs.as_ptr(), msgs.as_ptr(), 32, std::ptr::null(), pks.as_ptr(), PK_UNCOMPRESSED, n as u64, res.as_mut_ptr(), std::ptr::null_mut()) };
         if rc != 0 {
             err(rc);
         }
@@ -633,7 +632,7 @@ impl KeyTable {
         let msgs: Vec<u8> = messages.iter().flat_map(|m| m.iter().copied()).collect();
         let mut res = vec![0u8; n];
         let rc = unsafe {
-            mbls_fast_aggregate_verify_batch_indexed(ctx(), self.h, sigs.as_ptr(), msgs.as_ptr(), 32, key_indices.as_ptr(), std::ptr::null(), n as u64, k, res.as_mut_ptr(), std::ptr::null_mut())
+            mbls_fast_aggregate_verify_batch_indexed(ctx(), self.h, sigs.as_ptr(), msgs.as_ptr(), 32, std::ptr::null(), key_indices.as_ptr(), std::ptr::null(), n as u64, k, res.as_mut_ptr(), std::ptr::null_mut())
         };
         if rc != 0 {
             err(rc);

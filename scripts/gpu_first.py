@@ -72,7 +72,7 @@ ctx.reserve(Nn)
 N.lib().mbls_enable_phase_timing(ctx.handle, 1)
 for it in range(2):
     torch.cuda.synchronize(); t = time.time()
-    rc = N.lib().mbls_fast_aggregate_verify_batch_device(ctx.handle, d_s.data_ptr(), d_m.data_ptr(), 32, d_p.data_ptr(), 1, None, Nn, K,
+    rc = N.lib().mbls_fast_aggregate_verify_batch_device(ctx.handle, d_s.data_ptr(), d_m.data_ptr(), 32, None, d_p.data_ptr(), 1, None, Nn, K,
                                                          d_r.data_ptr(), d_b.data_ptr(), None, None)
     torch.cuda.synchronize(); dt = time.time() - t
     ms = (C.c_float * 6)(); N.lib().mbls_last_phase_ms(ctx.handle, ms)

@@ -29,16 +29,16 @@ for n in (1, 64, 1024, 16384, 65536):
     res = (C.c_uint8 * n)()
     s_, m_, p_, i_ = sigs[:n].tobytes(), msgs[:n].tobytes(), pks[:n].tobytes(), np.ascontiguousarray(idx[:n]).ctypes.data_as(C.c_void_p)
     def f_bytes():
-        ctx.check(lib.mbls_fast_aggregate_verify_batch(ctx.handle, s_, m_, 32, p_, N.PK_UNCOMPRESSED, None, n, k, res, None))
+        ctx.check(lib.mbls_fast_aggregate_verify_batch(ctx.handle, s_, m_, 32, None, p_, N.PK_UNCOMPRESSED, None, n, k, res, None))
     def f_idx():
-        ctx.check(lib.mbls_fast_aggregate_verify_batch_indexed(ctx.handle, table.handle, s_, m_, 32, i_, None, n, k, res, None))
+        ctx.check(lib.mbls_fast_aggregate_verify_batch_indexed(ctx.handle, table.handle, s_, m_, 32, None, i_, None, n, k, res, None))
     d_res = torch.zeros(n, dtype=torch.uint8, device=dev)
     def f_dev():
-        ctx.check(lib.mbls_fast_aggregate_verify_batch_device(ctx.handle, d_sigs.data_ptr(), d_msgs.data_ptr(), 32, d_pks.data_ptr(), N.PK_UNCOMPRESSED, None, n, k,
+        ctx.check(lib.mbls_fast_aggregate_verify_batch_device(ctx.handle, d_sigs.data_ptr(), d_msgs.data_ptr(), 32, None, d_pks.data_ptr(), N.PK_UNCOMPRESSED, None, n, k,
                                                               d_res.data_ptr(), None, None, None))
         torch.cuda.synchronize()
     def f_dev_idx():
-        ctx.check(lib.mbls_fast_aggregate_verify_batch_indexed_device(ctx.handle, table.handle, d_sigs.data_ptr(), d_msgs.data_ptr(), 32, d_idx.data_ptr(), None, n, k,
+        ctx.check(lib.mbls_fast_aggregate_verify_batch_indexed_device(ctx.handle, table.handle, d_sigs.data_ptr(), d_msgs.data_ptr(), 32, None, d_idx.data_ptr(), None, n, k,
                                                                       d_res.data_ptr(), None, None, None))
         torch.cuda.synchronize()
     rows[str(n)] = {"host_bytes_ms": med(f_bytes), "host_indexed_ms": med(f_idx), "device_bytes_ms": med(f_dev), "device_indexed_ms": med(f_dev_idx)}
@@ -61,7 +61,7 @@ n = 1 << 16
 c_sigs, c_msgs, c_pks, c_exp = bench.build_inputs(ctx, dev, n, 1, N.PK_COMPRESSED, rank=11)
 c_res = torch.zeros(n, dtype=torch.uint8, device=dev)
 def f_c2():
-    ctx.check(lib.mbls_verify_batch_device(ctx.handle, c_sigs.data_ptr(), c_msgs.data_ptr(), 32, c_pks.data_ptr(), N.PK_COMPRESSED, n, c_res.data_ptr(), None, None, None))
+    ctx.check(lib.mbls_verify_batch_device(ctx.handle, c_sigs.data_ptr(), c_msgs.data_ptr(), 32, None, c_pks.data_ptr(), N.PK_COMPRESSED, n, c_res.data_ptr(), None, None, None))
     torch.cuda.synchronize()
 t = med(f_c2); assert torch.equal(c_res.cpu(), c_exp)
 out["config2_verify_2_16"] = {"ms": t, "verify_per_s": n / t * 1e3}
@@ -76,7 +76,7 @@ def f_c4():
 t4 = med(f_c4); assert all(okv)
 v_res = torch.zeros(n, dtype=torch.uint8, device=dev)
 def f_c4b():
-    ctx.check(lib.mbls_fast_aggregate_verify_batch_device(ctx.handle, v_sigs.data_ptr(), v_msgs.data_ptr(), 32, v_pks.data_ptr(), N.PK_UNCOMPRESSED, None, n, k, v_res.data_ptr(), None, None, None))
+    ctx.check(lib.mbls_fast_aggregate_verify_batch_device(ctx.handle, v_sigs.data_ptr(), v_msgs.data_ptr(), 32, None, v_pks.data_ptr(), N.PK_UNCOMPRESSED, None, n, k, v_res.data_ptr(), None, None, None))
     torch.cuda.synchronize()
 t4b = med(f_c4b)
 out["config4_verify_multiple_2_14x128"] = {"ms": t4, "sets_per_s": n / t4 * 1e3, "same_sets_one_by_one_ms": t4b}

@@ -11,7 +11,7 @@ d_sigs, d_msgs, d_pks, expect = bench.build_inputs(ctx, dev, n, 1, N.PK_COMPRESS
 d_res = torch.zeros(n, dtype=torch.uint8, device=dev); d_bm = torch.zeros(n // 64, dtype=torch.int64, device=dev)
 for it in range(3):
     torch.cuda.synchronize(); t = time.perf_counter()
-    ctx.check(lib.mbls_verify_batch_device(ctx.handle, d_sigs.data_ptr(), d_msgs.data_ptr(), 32, d_pks.data_ptr(), N.PK_COMPRESSED, n, d_res.data_ptr(), d_bm.data_ptr(), None, None))
+    ctx.check(lib.mbls_verify_batch_device(ctx.handle, d_sigs.data_ptr(), d_msgs.data_ptr(), 32, None, d_pks.data_ptr(), N.PK_COMPRESSED, n, d_res.data_ptr(), d_bm.data_ptr(), None, None))
     torch.cuda.synchronize(); dt = time.perf_counter() - t
 print("config 2: 2^16 x verify: %.1f ms -> %.0f verify/s, correct=%s" % (dt * 1e3, n / dt, bool(torch.equal(d_res.cpu(), expect))))
 # config 4: verify_multiple, 2^14 sets x 128 keys
@@ -27,6 +27,6 @@ print("config 4: verify_multiple 2^14 sets x 128 keys: %.1f ms -> %.0f sets/s, r
 res = torch.zeros(n, dtype=torch.uint8, device=dev)
 for it in range(2):
     torch.cuda.synchronize(); t = time.perf_counter()
-    ctx.check(lib.mbls_fast_aggregate_verify_batch_device(ctx.handle, d_sigs.data_ptr(), d_msgs.data_ptr(), 32, d_pks.data_ptr(), N.PK_UNCOMPRESSED, None, n, k, res.data_ptr(), None, None, None))
+    ctx.check(lib.mbls_fast_aggregate_verify_batch_device(ctx.handle, d_sigs.data_ptr(), d_msgs.data_ptr(), 32, None, d_pks.data_ptr(), N.PK_UNCOMPRESSED, None, n, k, res.data_ptr(), None, None, None))
     torch.cuda.synchronize(); dt2 = time.perf_counter() - t
 print("  (same 2^14 sets through fast_aggregate_verify: %.1f ms)" % (dt2 * 1e3))

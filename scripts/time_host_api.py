@@ -11,6 +11,6 @@ sigs = d_sigs.cpu().numpy().tobytes(); msgs = d_msgs.cpu().numpy().tobytes(); pk
 res = (C.c_uint8 * n)()
 for it in range(4):
     t0 = time.time()
-    rc = N.lib().mbls_fast_aggregate_verify_batch(ctx.handle, sigs, msgs, 32, pks, 1, None, n, k, res, None)
+    rc = N.lib().mbls_fast_aggregate_verify_batch(ctx.handle, sigs, msgs, 32, None, pks, 1, None, n, k, res, None)
     t1 = time.time()
     print("host-buffer call rc %d  %.1f ms  -> %.0f verify/s, accepted %d of %d" % (rc, (t1 - t0) * 1e3, n / (t1 - t0), sum(res), n))

@@ -50,6 +50,33 @@ def test_cpp_key_generate_matches_hkdf_restatement():
         SecretKey.key_generate(bytes(31))
 
 
+def test_key_generate_external_vectors():
+    """External pins for KeyGenerate (reference src/keys.rs:45-77 holds none): RFC 5869 A.1-A.3 for the HKDF primitives and the four
+    EIP-2333 master-key cases (HKDF_mod_r with key_info = "" is exactly SecretKey::key_generate(seed, b"")), on BOTH host mirrors --
+    include/milagro_bls.hpp (its own SHA-256 / HMAC / HKDF / mod r) and milagro_bls_amd/api.py. No GPU involved."""
+    import json
+    from milagro_bls_amd import api
+    with open(os.path.join(helpers.ROOT, "tests", "golden", "keygen_vectors.json")) as f:
+        vec = json.load(f)
+    libdir = os.path.join(helpers.ROOT, "milagro_bls_amd")
+    exe = os.path.join(helpers.ROOT, "tests", "cpp", "test_keygen")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-I", os.path.join(helpers.ROOT, "include"), os.path.join(helpers.ROOT, "tests", "cpp", "test_keygen.cpp"),
+                           "-o", exe, "-L", libdir, "-lmbls_hip", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
+    for v in vec["rfc5869"]:
+        ikm, salt, info = bytes.fromhex(v["ikm"]), bytes.fromhex(v["salt"]), bytes.fromhex(v["info"])
+        prk = api.hkdf_extract(salt, ikm)
+        assert prk.hex() == v["prk"] and api.hkdf_expand(prk, info, v["L"]).hex() == v["okm"], v["name"]
+        out = subprocess.run([exe, "hkdf", v["ikm"] or "-", v["salt"] or "-", v["info"] or "-", str(v["L"])], capture_output=True, text=True, timeout=60)
+        assert out.returncode == 0 and out.stdout.split() == [v["prk"], v["okm"]], (v["name"], out.stdout, out.stderr)
+    args = []
+    for v in vec["eip2333_master_sk"]:
+        assert api.SecretKey.key_generate(bytes.fromhex(v["seed"]), b"").as_raw() == int(v["sk"])
+        args += [v["seed"], "-"]
+    out = subprocess.run([exe] + args, capture_output=True, text=True, timeout=60)
+    assert out.returncode == 0, out.stderr
+    assert [int(x, 16) for x in out.stdout.split()] == [int(v["sk"]) for v in vec["eip2333_master_sk"]]
+
+
 @pytest.mark.gpu
 def test_cpp_mirror_reference_tests_on_gpu():
     exe = build_exe()

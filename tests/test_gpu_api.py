@@ -221,7 +221,7 @@ def test_verify_multiple_signatures(api, vectors):
         rr = (C.c_uint64 * len(s))(*vm["rands"])
         got = N.lib().mbls_verify_multiple_aggregate_signatures(N.default_context().handle, N.cbuf(b"".join(bytes.fromhex(x["sig"]) for x in s)),
                                                                 N.cbuf(b"".join(bytes.fromhex(x["apk"]) for x in s)),
-                                                                N.cbuf(b"".join(bytes.fromhex(x["msg"]) for x in s)), 32, rr, len(s))
+                                                                N.cbuf(b"".join(bytes.fromhex(x["msg"]) for x in s)), 32, None, rr, len(s))
         assert bool(got) is vm[name]["result"]
     # a set whose signature is outside G2 fails the whole batch (src/aggregates.rs:274-276)
     sets = _sets(api, rnd, 3, 2)

@@ -30,7 +30,7 @@ def test_config3_fast_aggregate_verify_128_keys_both_formats(env):
         d_sigs, d_msgs, d_pks, expect = bench.build_inputs(ctx, dev, n, k, fmt, rank=3)
         d_res = torch.zeros(n, dtype=torch.uint8, device=dev); d_bm = torch.zeros(n // 64, dtype=torch.int64, device=dev)
         d_st = torch.zeros(n, dtype=torch.int32, device=dev)
-        ctx.check(N.lib().mbls_fast_aggregate_verify_batch_device(ctx.handle, d_sigs.data_ptr(), d_msgs.data_ptr(), 32, d_pks.data_ptr(), fmt, None,
+        ctx.check(N.lib().mbls_fast_aggregate_verify_batch_device(ctx.handle, d_sigs.data_ptr(), d_msgs.data_ptr(), 32, None, d_pks.data_ptr(), fmt, None,
                                                                   n, k, d_res.data_ptr(), d_bm.data_ptr(), d_st.data_ptr(), None))
         torch.cuda.synchronize()
         assert torch.equal(d_res.cpu(), expect)

@@ -81,7 +81,7 @@ def _vm_gpu(N, sigs, apks, msgs, rands):
     n = len(sigs)
     rr = (C.c_uint64 * max(1, n))(*rands)
     return bool(N.lib().mbls_verify_multiple_aggregate_signatures(ctx.handle, N.cbuf(b"".join(sigs)), N.cbuf(b"".join(apks)), N.cbuf(b"".join(msgs)),
-                                                                 32, rr, n))
+                                                                 32, None, rr, n))
 
 
 def _vm_orc(sigs, apks, msgs, rands):
@@ -132,10 +132,10 @@ def test_verify_multiple_scalar_requirements(N):
     t = lambda b: torch.frombuffer(bytearray(b), dtype=torch.uint8).to(dev)
     d_s, d_a, d_m = t(b"".join(sigs)), t(b"".join(pks)), t(b"".join(msgs))
     res = C.c_int(7)
-    rc = N.lib().mbls_verify_multiple_aggregate_signatures_device(ctx.handle, d_s.data_ptr(), d_a.data_ptr(), d_m.data_ptr(), 32, None, 3, C.byref(res), None)
+    rc = N.lib().mbls_verify_multiple_aggregate_signatures_device(ctx.handle, d_s.data_ptr(), d_a.data_ptr(), d_m.data_ptr(), 32, None, None, 3, C.byref(res), None)
     assert rc == N.ERR_ARGUMENT and res.value == 0
     d_r = torch.tensor([rands[0], 0, rands[2]], dtype=torch.int64, device=dev)
-    rc = N.lib().mbls_verify_multiple_aggregate_signatures_device(ctx.handle, d_s.data_ptr(), d_a.data_ptr(), d_m.data_ptr(), 32, d_r.data_ptr(), 3, C.byref(res), None)
+    rc = N.lib().mbls_verify_multiple_aggregate_signatures_device(ctx.handle, d_s.data_ptr(), d_a.data_ptr(), d_m.data_ptr(), 32, None, d_r.data_ptr(), 3, C.byref(res), None)
     assert rc == N.ERR_ARGUMENT and res.value == 0
     # forged pair (sig1 + D, sig2 - D): passes an unblinded check, must fail the blinded one
     D = orc.sign(b"d" * 32, 12345)
@@ -343,10 +343,10 @@ def test_keytable_device_entry_at_batch_size(N):
         d_res = torch.zeros(n, dtype=torch.uint8, device=dev); d_bm = torch.zeros(n // 64, dtype=torch.int64, device=dev)
         d_st = torch.zeros(n, dtype=torch.int32, device=dev)
         if mode == "bytes":
-            ctx.check(N.lib().mbls_fast_aggregate_verify_batch_device(ctx.handle, d_sigs.data_ptr(), d_msgs.data_ptr(), 32, d_pks.data_ptr(), N.PK_UNCOMPRESSED,
+            ctx.check(N.lib().mbls_fast_aggregate_verify_batch_device(ctx.handle, d_sigs.data_ptr(), d_msgs.data_ptr(), 32, None, d_pks.data_ptr(), N.PK_UNCOMPRESSED,
                                                                       None, n, k, d_res.data_ptr(), d_bm.data_ptr(), d_st.data_ptr(), None))
         else:
-            ctx.check(N.lib().mbls_fast_aggregate_verify_batch_indexed_device(ctx.handle, tab.handle, d_sigs.data_ptr(), d_msgs.data_ptr(), 32, d_idx.data_ptr(),
+            ctx.check(N.lib().mbls_fast_aggregate_verify_batch_indexed_device(ctx.handle, tab.handle, d_sigs.data_ptr(), d_msgs.data_ptr(), 32, None, d_idx.data_ptr(),
                                                                               None, n, k, d_res.data_ptr(), d_bm.data_ptr(), d_st.data_ptr(), None))
         torch.cuda.synchronize()
         outs.append((d_res.cpu(), d_bm.cpu(), d_st.cpu()))
@@ -369,7 +369,7 @@ def test_key_buffer_alignment_paths_agree(N):
         buf = torch.zeros(flat.numel() + 8, dtype=torch.uint8, device=dev)
         buf[off:off + flat.numel()] = flat
         d_res = torch.zeros(n, dtype=torch.uint8, device=dev); d_st = torch.zeros(n, dtype=torch.int32, device=dev)
-        ctx.check(N.lib().mbls_fast_aggregate_verify_batch_device(ctx.handle, d_sigs.data_ptr(), d_msgs.data_ptr(), 32, buf.data_ptr() + off, N.PK_UNCOMPRESSED,
+        ctx.check(N.lib().mbls_fast_aggregate_verify_batch_device(ctx.handle, d_sigs.data_ptr(), d_msgs.data_ptr(), 32, None, buf.data_ptr() + off, N.PK_UNCOMPRESSED,
                                                                   None, n, k, d_res.data_ptr(), None, d_st.data_ptr(), None))
         torch.cuda.synchronize()
         outs.append((d_res.cpu(), d_st.cpu()))
@@ -430,11 +430,11 @@ def test_argument_validation(mb, N):
     b = helpers.make_batch(4, 3, fmt=0, seed=31, negatives=False)
     res = N.outbuf(4)
     bad_off = (C.c_uint32 * 5)(0, 3, 2, 6, 9)                          # not non-decreasing
-    rc = N.lib().mbls_fast_aggregate_verify_batch(ctx.handle, N.cbuf(b.sigs), N.cbuf(b.msgs), 32, N.cbuf(b.pks), 0, bad_off, 4, 0, res, None)
+    rc = N.lib().mbls_fast_aggregate_verify_batch(ctx.handle, N.cbuf(b.sigs), N.cbuf(b.msgs), 32, None, N.cbuf(b.pks), 0, bad_off, 4, 0, res, None)
     assert rc == N.ERR_ARGUMENT and "offsets" in ctx.last_error()
-    rc = N.lib().mbls_fast_aggregate_verify_batch(ctx.handle, N.cbuf(b.sigs), N.cbuf(b.msgs), 32, N.cbuf(b.pks), 7, None, 4, 3, res, None)
+    rc = N.lib().mbls_fast_aggregate_verify_batch(ctx.handle, N.cbuf(b.sigs), N.cbuf(b.msgs), 32, None, N.cbuf(b.pks), 7, None, 4, 3, res, None)
     assert rc == N.ERR_ARGUMENT
-    rc = N.lib().mbls_fast_aggregate_verify_batch(ctx.handle, None, N.cbuf(b.msgs), 32, N.cbuf(b.pks), 0, None, 4, 3, res, None)
+    rc = N.lib().mbls_fast_aggregate_verify_batch(ctx.handle, None, N.cbuf(b.msgs), 32, None, N.cbuf(b.pks), 0, None, 4, 3, res, None)
     assert rc == N.ERR_ARGUMENT
     # the context still works afterwards
     assert mb.fast_aggregate_verify_batch(b.sigs, b.msgs, b.pks, 4, 3)[0] == [True] * 4
@@ -453,7 +453,7 @@ def test_config5_shard_2_17_items_128_keys(N):
     d_sigs, d_msgs, d_pks, expect = bench.build_inputs(ctx, dev, n, k, N.PK_UNCOMPRESSED, rank=6)
     d_res = torch.zeros(n, dtype=torch.uint8, device=dev); d_bm = torch.zeros(n // 64, dtype=torch.int64, device=dev)
     d_st = torch.zeros(n, dtype=torch.int32, device=dev)
-    ctx.check(N.lib().mbls_fast_aggregate_verify_batch_device(ctx.handle, d_sigs.data_ptr(), d_msgs.data_ptr(), 32, d_pks.data_ptr(), N.PK_UNCOMPRESSED, None,
+    ctx.check(N.lib().mbls_fast_aggregate_verify_batch_device(ctx.handle, d_sigs.data_ptr(), d_msgs.data_ptr(), 32, None, d_pks.data_ptr(), N.PK_UNCOMPRESSED, None,
                                                               n, k, d_res.data_ptr(), d_bm.data_ptr(), d_st.data_ptr(), None))
     torch.cuda.synchronize()
     assert torch.equal(d_res.cpu(), expect)
@@ -478,3 +478,195 @@ def test_randomised_sweep_vs_oracle(mb, seed):
         got, st = mb.fast_aggregate_verify_batch(b.sigs, b.msgs, b.pks, b.n, b.k, pk_format=fmt)
         want = orc.batch_fast_aggregate_verify(b.sigs, b.msgs, b.pks, b.n, b.k, fmt, nthreads=8)
         assert got == want == b.expect, (seed, n, k, fmt)
+
+
+# ------------------------------------------------------------------------------------------------ per-item message lengths
+def test_ragged_message_lengths_vs_oracle(mb, N):
+    """The reference takes any `msg: &[u8]` per call (src/aggregates.rs:177; its tests sign 0 .. 133 700 bytes, :436): the batch entries
+    take one message buffer + an offset table. Lengths 0 .. 300 and one 133 700-byte item, fast_aggregate_verify and Signature::verify,
+    byte keys and table indices, against the oracle item by item; a corrupted length must fail exactly its item."""
+    rnd = random.Random(77)
+    k = 3
+    sks, pks = _keys(rnd, 8)
+    lens = [0, 1, 31, 32, 33, 55, 56, 63, 64, 65, 119, 120, 127, 128, 129, 255, 256, 300, 133700, 7]
+    n = len(lens)
+    msgs = [rnd.randbytes(l) if l != 133700 else bytes([42]) * l for l in lens]
+    idx = [rnd.sample(range(8), k) for _ in range(n)]
+    sig192 = [orc.sign(msgs[i], sum(sks[j] for j in idx[i]) % helpers.R) for i in range(n)]
+    sigs = [orc.g2_compress(s) for s in sig192]
+    # negatives: a signature over the message minus its last byte / plus one byte
+    msgs_v = list(msgs)
+    msgs_v[5] = msgs[5][:-1]; msgs_v[9] = msgs[9] + b"\x00"; msgs_v[18] = msgs[18][:-1]
+    want = [orc.fast_aggregate_verify(sig192[i], msgs_v[i], [pks[j] for j in idx[i]]) for i in range(n)]
+    assert want == [i not in (5, 9, 18) for i in range(n)]
+    offs = [0]
+    for m in msgs_v:
+        offs.append(offs[-1] + len(m))
+    flat_pk = b"".join(b"".join(pks[j] for j in idx[i]) for i in range(n))
+    got, st = mb.fast_aggregate_verify_batch(b"".join(sigs), b"".join(msgs_v), flat_pk, n, k, pk_format=1, msg_offsets=offs)
+    assert got == want
+    assert all((s & 0x40) != 0 for i, s in enumerate(st) if not want[i])
+    # the same through a key table
+    tab = N.KeyTable(capacity_hint=8)
+    first, errs = tab.append(b"".join(pks), 8, pk_format=1, validate=True)
+    assert not any(errs)
+    got2, _ = mb.fast_aggregate_verify_batch_indexed(tab, b"".join(sigs), b"".join(msgs_v), [first + j for ix in idx for j in ix], n, k, msg_offsets=offs)
+    assert got2 == want
+    # a table that does not start at 0 (a shard of a larger buffer): only msgs[offs[0] .. offs[n]) is read
+    pad = 13
+    offs2 = [o + pad for o in offs]
+    got3, _ = mb.fast_aggregate_verify_batch(b"".join(sigs), bytes(pad) + b"".join(msgs_v), flat_pk, n, k, pk_format=1, msg_offsets=offs2)
+    assert got3 == want
+    # Signature::verify over the same ragged messages (one key each)
+    sig1 = [orc.g2_compress(orc.sign(msgs[i], sks[i % 8])) for i in range(n)]
+    want1 = [orc.verify(orc.g2_from_compressed(sig1[i])[1], msgs_v[i], pks[i % 8]) for i in range(n)]
+    got4, _ = mb.verify_batch(b"".join(sig1), b"".join(msgs_v), b"".join(pks[i % 8] for i in range(n)), n, pk_format=1, msg_offsets=offs)
+    assert got4 == want1 == want
+    # host entries refuse a table that runs backwards; the device entry rejects exactly that item
+    bad = list(offs); bad[3], bad[4] = bad[4], bad[3]
+    with pytest.raises(N.MblsError):
+        mb.fast_aggregate_verify_batch(b"".join(sigs), b"".join(msgs_v), flat_pk, n, k, pk_format=1, msg_offsets=bad)
+    import torch
+    dev = torch.device("cuda:0")
+    t = lambda b: torch.frombuffer(bytearray(b), dtype=torch.uint8).to(dev)
+    d_s, d_m, d_p = t(b"".join(sigs)), t(b"".join(msgs_v)), t(flat_pk)
+    d_off = torch.tensor(bad, dtype=torch.int64, device=dev)
+    d_res = torch.zeros(n, dtype=torch.uint8, device=dev); d_st = torch.zeros(n, dtype=torch.int32, device=dev)
+    ctx = N.default_context()
+    ctx.check(N.lib().mbls_fast_aggregate_verify_batch_device(ctx.handle, d_s.data_ptr(), d_m.data_ptr(), 0, d_off.data_ptr(), d_p.data_ptr(), 1, None, n, k,
+                                                              d_res.data_ptr(), None, d_st.data_ptr(), None))
+    torch.cuda.synchronize()
+    res, stt = d_res.cpu().tolist(), d_st.cpu().tolist()
+    assert (stt[3] & 0x100) and res[3] == 0
+    # bad[3] > bad[4] only breaks item 3's own range; items 2 and 4 now cover different bytes and fail their pairing; the rest stand
+    assert [bool(r) for i, r in enumerate(res) if i not in (2, 3, 4)] == [w for i, w in enumerate(want) if i not in (2, 3, 4)]
+
+
+def test_verify_multiple_ragged_messages(N):
+    """verify_multiple_aggregate_signatures with messages of different lengths (reference src/aggregates.rs:261-316 takes `&[u8]` per set)"""
+    from milagro_bls_amd import api
+    rnd = random.Random(5)
+    sks, pks = _keys(rnd, 4)
+    msgs = [b"", b"a", rnd.randbytes(100), bytes([42]) * 133700]
+    sets, osets = [], []
+    for i in range(4):
+        s192 = orc.sign(msgs[i], sks[i])
+        sets.append((api.AggregateSignature.from_bytes(orc.g2_compress(s192)), api.AggregatePublicKey.from_public_key(api.PublicKey.from_uncompressed_bytes(pks[i])), msgs[i]))
+        osets.append((s192, pks[i], msgs[i]))
+    assert orc.verify_multiple(osets, [3, 5, 7, 11]) is True
+    assert api.AggregateSignature.verify_multiple_aggregate_signatures(random.Random(1), sets) is True
+    bad = list(sets); bad[2] = (sets[2][0], sets[2][1], msgs[2][:-1])
+    assert api.AggregateSignature.verify_multiple_aggregate_signatures(random.Random(1), bad) is False
+
+
+# ------------------------------------------------------------------------------------------------ key table: ordering across streams
+def test_keytable_append_and_verify_on_different_streams(N):
+    """An append made on stream A must be visible to a verification enqueued on stream B right behind it (no host synchronisation in
+    between), also when the append makes the table grow (the records move): the library orders them with an event / drains the device
+    around the move (include/mbls.h, key table section)."""
+    import torch
+    dev = torch.device("cuda:0")
+    ctx = N.default_context()
+    rnd = random.Random(21)
+    n, k, pool = 256, 4, 192
+    sks, pks = _keys(rnd, pool)
+    idx = [rnd.sample(range(pool), k) for _ in range(n)]
+    msgs = [rnd.randbytes(32) for _ in range(n)]
+    sigs = orc.batch_sign(b"".join((sum(sks[j] for j in ix) % helpers.R).to_bytes(32, "big") for ix in idx), b"".join(msgs), n, nthreads=8)
+    want = [True] * n
+    t = lambda b: torch.frombuffer(bytearray(b), dtype=torch.uint8).to(dev)
+    d_s, d_m = t(sigs), t(b"".join(msgs))
+    d_idx = torch.tensor([j for ix in idx for j in ix], dtype=torch.int32, device=dev)
+    sa, sb = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+    for rep in range(3):
+        tab = N.KeyTable(ctx, capacity_hint=64)                 # three appends of 64: the second and third make it grow
+        d_errs = torch.full((pool,), 9, dtype=torch.uint8, device=dev)
+        d_res = torch.zeros(n, dtype=torch.uint8, device=dev); d_st = torch.zeros(n, dtype=torch.int32, device=dev)
+        torch.cuda.synchronize()
+        # something long on stream A first, so that the appends behind it are still pending when stream B's work is enqueued
+        d_p = t(b"".join(pks))
+        ms = C.c_float()
+        for c0 in range(0, pool, 64):
+            st = sa if (c0 // 64) % 2 == 0 else None            # alternate between stream A and the null stream
+            tab.append_device(d_p.data_ptr() + 96 * c0, 64, d_errs.data_ptr() + c0, pk_format=1, validate=True,
+                              stream=C.c_void_p(st.cuda_stream) if st is not None else None)
+        ctx.check(N.lib().mbls_fast_aggregate_verify_batch_indexed_device(ctx.handle, tab.handle, d_s.data_ptr(), d_m.data_ptr(), 32, None, d_idx.data_ptr(), None,
+                                                                          n, k, d_res.data_ptr(), None, d_st.data_ptr(), C.c_void_p(sb.cuda_stream)))
+        torch.cuda.synchronize()
+        assert d_errs.cpu().tolist() == [0] * pool
+        assert [bool(x) for x in d_res.cpu().tolist()] == want, "rep %d" % rep
+        got, errs = tab.get(0, pool)
+        assert got == b"".join(pks) and not any(errs)
+        tab.close()
+
+
+def test_keytable_outlives_its_context(N):
+    """mbls_keytable_destroy after mbls_ctx_destroy must not touch freed memory (either order of destruction is allowed)"""
+    ctx = N.Context(0)
+    tab = N.KeyTable(ctx, capacity_hint=4)
+    rnd = random.Random(3)
+    _, pks = _keys(rnd, 2)
+    first, errs = tab.append(b"".join(pks), 2, pk_format=1, validate=True)
+    assert first == 0 and not any(errs) and len(tab) == 2
+    ctx.close()
+    assert len(tab) == 0
+    tab.close()
+
+
+# ------------------------------------------------------------------------------------------------ several devices behind one handle
+def test_multi_device_handle_matches_single_context_and_oracle(mb, N):
+    """mbls_multi_* (device list + contiguous shards, one host thread per device) on the one GPU of this box with
+    device_ids = {0, 0} and {0, 0, 0}: odd item counts, ragged key sets and ragged messages, byte keys and a replicated key table --
+    results and status words identical to the single-context entry and to the oracle."""
+    rnd = random.Random(8)
+    pool = 24
+    sks, pks = _keys(rnd, pool)
+    n = 203                                                      # odd: shards of 101 + 102, 67 + 68 + 68
+    cnts = [rnd.randrange(0, 6) for _ in range(n)]
+    cnts[0] = 0; cnts[n - 1] = 5
+    lens = [rnd.randrange(0, 90) for _ in range(n)]
+    idx = [rnd.sample(range(pool), c) for c in cnts]
+    msgs = [rnd.randbytes(l) for l in lens]
+    sig192 = [orc.sign(msgs[i], (sum(sks[j] for j in idx[i]) % helpers.R) or 1) for i in range(n)]
+    sigs = [orc.g2_compress(s) for s in sig192]
+    for i in range(5, n, 9):                                     # negatives: flipped message byte / infinity signature / signature outside G2
+        kind = (i // 9) % 3
+        if kind == 0 and lens[i]:
+            msgs[i] = bytes([msgs[i][0] ^ 1]) + msgs[i][1:]
+        elif kind == 1:
+            sigs[i] = helpers.G2_INF; sig192[i] = None
+        else:
+            sigs[i] = bytes.fromhex(helpers.load_vectors()["model"]["g2_subgroup_probes"][i % 3]["compressed"]); sig192[i] = None
+    want = []
+    for i in range(n):
+        s = sig192[i] if sig192[i] is not None else orc.g2_from_compressed(sigs[i])[1]
+        want.append(orc.fast_aggregate_verify(s, msgs[i], [pks[j] for j in idx[i]]))
+    assert any(want) and not all(want) and want[0] is False
+    koff, moff = [0], [0]
+    for i in range(n):
+        koff.append(koff[-1] + cnts[i]); moff.append(moff[-1] + len(msgs[i]))
+    flat_pk = b"".join(b"".join(pks[j] for j in ix) for ix in idx)
+    flat_idx = [j for ix in idx for j in ix]
+    one, st_one = mb.fast_aggregate_verify_batch(b"".join(sigs), b"".join(msgs), flat_pk, n, pk_format=1, pk_offsets=koff, msg_offsets=moff)
+    assert one == want
+    for devs in ([0, 0], [0, 0, 0]):
+        m = N.MultiContext(devs)
+        assert len(m) == len(devs)
+        m.reserve(n)
+        got, st = mb.multi_fast_aggregate_verify_batch(m, b"".join(sigs), b"".join(msgs), flat_pk, n, pk_format=1, pk_offsets=koff, msg_offsets=moff)
+        assert got == want and st == st_one
+        tab = N.MultiKeyTable(m, capacity_hint=4)              # grows on every replica
+        first, errs = tab.append(b"".join(pks), pool, pk_format=1, validate=True)
+        assert first == 0 and not any(errs) and len(tab) == pool
+        got2, st2 = mb.multi_fast_aggregate_verify_batch_indexed(m, tab, b"".join(sigs), b"".join(msgs), flat_idx, n, offsets=koff, msg_offsets=moff)
+        assert got2 == want and st2 == st_one
+        # uniform layout: k keys and 32 bytes per item
+        b = helpers.make_batch(37, 3, fmt=1, seed=14)
+        got3, _ = mb.multi_fast_aggregate_verify_batch(m, b.sigs, b.msgs, b.pks, b.n, b.k, pk_format=1)
+        assert got3 == b.expect
+        # Signature::verify shape, more devices than items
+        s1 = orc.g2_compress(orc.sign(b"x", sks[0]))
+        got4, _ = mb.multi_verify_batch(m, s1, b"x", pks[0], 1, pk_format=1, msg_len=1)
+        assert got4 == [True]
+        assert mb.multi_fast_aggregate_verify_batch(m, b"", b"", b"", 0, 1, pk_format=1)[0] == []
+        tab.close(); m.close()

@@ -259,7 +259,7 @@ def test_device_entry_point_bitmap_and_large_batch_properties(mb):
     bad = torch.arange(7, n, 16, device=dev)
     d_msg[bad, 0] ^= 1
     d_res = torch.empty(n, dtype=torch.uint8, device=dev); d_bm = torch.zeros(n // 64, dtype=torch.int64, device=dev)
-    ctx.check(N.lib().mbls_verify_batch_device(ctx.handle, d_sig.data_ptr(), d_msg.data_ptr(), 32, d_pk.data_ptr(), 0, n,
+    ctx.check(N.lib().mbls_verify_batch_device(ctx.handle, d_sig.data_ptr(), d_msg.data_ptr(), 32, None, d_pk.data_ptr(), 0, n,
                                                d_res.data_ptr(), d_bm.data_ptr(), None, None))
     torch.cuda.synchronize()
     res = d_res.cpu()
