@@ -257,4 +257,33 @@ struct AggregateSignature {
     bool operator==(const AggregateSignature& o) const { return point == o.point; }
 };
 
+// Several GPUs behind one handle (mbls_multi_*; not part of the reference's API): contiguous shards, one context and one host thread per
+// device inside the library, results written in place. Items are independent (reference src/aggregates.rs:177-215 keeps no state).
+class MultiGpu {
+    mbls_multi* h_ = nullptr;
+public:
+    explicit MultiGpu(const std::vector<int>& device_ids) {
+        if (mbls_multi_create(&h_, device_ids.data(), int(device_ids.size())) != MBLS_OK) throw DeviceError("mbls_multi_create failed");
+    }
+    MultiGpu(const MultiGpu&) = delete; MultiGpu& operator=(const MultiGpu&) = delete;
+    ~MultiGpu() { mbls_multi_destroy(h_); }
+    int devices() const { return mbls_multi_device_count(h_); }
+    // n x AggregateSignature::fast_aggregate_verify; messages of any length each
+    std::vector<bool> fast_aggregate_verify(const std::vector<AggregateSignature>& sigs, const std::vector<Bytes>& msgs, const std::vector<std::vector<const PublicKey*>>& keys) const {
+        const size_t n = sigs.size();
+        if (msgs.size() != n || keys.size() != n) throw std::invalid_argument("one message and one key set per signature");
+        Bytes s, m, p; std::vector<uint64_t> moff{0}; std::vector<uint32_t> koff{0};
+        for (size_t i = 0; i < n; i++) {
+            s.insert(s.end(), sigs[i].point.begin(), sigs[i].point.end());
+            m.insert(m.end(), msgs[i].begin(), msgs[i].end()); moff.push_back(m.size());
+            for (auto* k : keys[i]) p.insert(p.end(), k->point.begin(), k->point.end());
+            koff.push_back(uint32_t(p.size() / 96));
+        }
+        std::vector<uint8_t> res(n ? n : 1);
+        int rc = mbls_multi_fast_aggregate_verify_batch(h_, s.data(), m.data(), 0, moff.data(), p.data(), MBLS_PK_UNCOMPRESSED, koff.data(), n, 0, res.data(), nullptr);
+        if (rc != MBLS_OK) throw DeviceError(std::string("mbls_multi: ") + mbls_multi_last_error(h_));
+        return std::vector<bool>(res.begin(), res.begin() + n);
+    }
+};
+
 }  // namespace milagro_bls

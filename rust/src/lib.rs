@@ -77,6 +77,17 @@ extern "C" {
     fn mbls_fast_aggregate_verify_batch_indexed(ctx: *mut MblsCtx, t: *const MblsKeyTable, sigs: *const u8, msgs: *const u8, msg_len: u32, msg_offsets: *const u64,
                                                 key_idx: *const u32, offsets: *const u32, n: u64, k: u32, results: *mut u8, status: *mut u32) -> c_int;
 }
+#[repr(C)]
+pub struct MblsMulti {
+    _private: [u8; 0],
+}
+extern "C" {
+    fn mbls_multi_create(out: *mut *mut MblsMulti, device_ids: *const c_int, n_devices: c_int) -> c_int;
+    fn mbls_multi_destroy(m: *mut MblsMulti);
+    fn mbls_multi_device_count(m: *const MblsMulti) -> c_int;
+    fn mbls_multi_fast_aggregate_verify_batch(m: *mut MblsMulti, sigs: *const u8, msgs: *const u8, msg_len: u32, msg_offsets: *const u64, pks: *const u8,
+                                              pk_format: c_int, pk_offsets: *const u32, n: u64, k: u32, results: *mut u8, status: *mut u32) -> c_int;
+}
 const PK_COMPRESSED: c_int = 0;
 const PK_UNCOMPRESSED: c_int = 1;
 
@@ -566,6 +577,61 @@ pub mod batch {
             err(rc);
         }
         res.into_iter().map(|b| b == 1).collect()
+    }
+}
+
+/// Several GPUs behind one handle (`mbls_multi_*`): items are independent (`src/aggregates.rs:177-215` keeps no state between calls), so a
+/// batch is cut into contiguous shards, one per device, each staged and verified by its own host thread inside the library.
+pub struct MultiGpu {
+    h: *mut MblsMulti,
+}
+unsafe impl Send for MultiGpu {}
+unsafe impl Sync for MultiGpu {}
+impl MultiGpu {
+    pub fn new(device_ids: &[i32]) -> Self {
+        let mut h: *mut MblsMulti = std::ptr::null_mut();
+        let rc = unsafe { mbls_multi_create(&mut h, device_ids.as_ptr(), device_ids.len() as c_int) };
+        if rc != 0 {
+            err(rc);
+        }
+        MultiGpu { h }
+    }
+    pub fn devices(&self) -> usize {
+        unsafe { mbls_multi_device_count(self.h) as usize }
+    }
+    /// n x `AggregateSignature::fast_aggregate_verify` over all devices; messages of any length each.
+    pub fn fast_aggregate_verify(&self, signatures: &[AggregateSignature], messages: &[&[u8]], public_keys: &[Vec<&PublicKey>]) -> Vec<bool> {
+        let n = signatures.len();
+        assert!(messages.len() == n && public_keys.len() == n);
+        let sigs: Vec<u8> = signatures.iter().flat_map(|s| s.point.iter().copied()).collect();
+        let mut msgs: Vec<u8> = Vec::new();
+        let mut moff: Vec<u64> = vec![0];
+        for m in messages {
+            msgs.extend_from_slice(m);
+            moff.push(msgs.len() as u64);
+        }
+        let mut offsets: Vec<u32> = vec![0];
+        let mut pks: Vec<u8> = Vec::new();
+        for set in public_keys {
+            for k in set {
+                pks.extend_from_slice(&k.point);
+            }
+            offsets.push((pks.len() / 96) as u32);
+        }
+        let mut res = vec![0u8; n];
+        let rc = unsafe {
+            mbls_multi_fast_aggregate_verify_batch(self.h, sigs.as_ptr(), msgs.as_ptr(), 0, moff.as_ptr(), pks.as_ptr(), PK_UNCOMPRESSED, offsets.as_ptr(), n as u64, 0,
+                                                   res.as_mut_ptr(), std::ptr::null_mut())
+        };
+        if rc != 0 {
+            err(rc);
+        }
+        res.into_iter().map(|b| b == 1).collect()
+    }
+}
+impl Drop for MultiGpu {
+    fn drop(&mut self) {
+        unsafe { mbls_multi_destroy(self.h) }
     }
 }
 
