@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmbls_hip.so")
 SOURCES = ["mbls_kernels.hip"]
-DEPS = ["mbls_fp.h", "mbls_fp_asm.inc", "mbls_fpd_asm.inc", "mbls_towerd_asm.inc", "mbls_tower.h", "mbls_curve.h", "mbls_hash.h", "mbls_pairing.h", "mbls_lanes.h", "mbls_ops.h",
+DEPS = ["mbls_fp.h", "mbls_fp_asm.inc", "mbls_fpd_asm.inc", "mbls_towerd_asm.inc", "mbls_tower.h", "mbls_curve.h", "mbls_hash.h", "mbls_pairing.h", "mbls_lanes.h", "mbls_ops.h", "mbls_coop.h", "mbls_coop_prog.inc",
         "mbls_constants.inc", os.path.join("..", "..", "include", "mbls.h")]
 
 

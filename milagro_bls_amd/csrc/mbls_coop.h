@@ -1,0 +1,245 @@
+// mbls_coop.h -- the WAVE-COOPERATIVE engine: one item per wave, its Fp values in LDS slots shared by the 64 lanes, the computation a
+// sequence of steps in which every lane performs one Fp operation of its own (tools/gen_coop.py is the compiler of the microprograms,
+// tools/coop_sim.py the digit-exact CPU model of this kernel).
+//
+// Why: the pipeline kernels give every item ONE LANE -- the right shape for throughput (2^16 items fill the chip), the wrong one
+// when a single value is on the critical path: one lane walks 4 M dependent instructions through a final exponentiation (8 ms), 14 M
+// through a whole verification (20 ms), however small the batch. Here the 18 Fp products of a cyclotomic squaring, or the 54 of an
+// Fp12 product, sit side by side in ONE step of ~600 instructions. Used for
+//   * the tail of verify_multiple_aggregate_signatures / aggregate_verify (reference src/aggregates.rs:307-315, :158-169): the Miller loop of
+//     (sum r_i sig_i, -G1), its product with the sets' Miller values, ONE final exponentiation -- program `vmtail`;
+//   * the pairing check of small batches (Signature::verify / fast_aggregate_verify with n <= MBLS_COOP_MAX_ITEMS items: reference
+//     src/signature.rs:27-40, src/aggregates.rs:177-215), one wave per item -- program `pairing2`;
+//   * the last levels of the n-pairing paths' product trees -- program `f12mul`.
+// Values are in the digit form of tools/gen_fpd_asm.py (14 signed 28-bit digits, Montgomery radix 2^392); products are the same
+// generated scan the pipeline's routines use (mbls_fp_mul1_d_asm_fn's body, inlined). No MFMA (carry-chain integer work), no
+// lane-private memory; LDS is the shared register file of the wave.
+#pragma once
+#include "mbls_lanes.h"
+#include "mbls_coop_prog.inc"
+
+#define COOP_SW 15                       // dwords per slot: 14 digits + 1 (an odd stride spreads the slots over the LDS banks)
+#define COOP_K_END 0
+#define COOP_K_MUL 1
+#define COOP_K_LIN 2
+#define COOP_K_INV 3
+#define COOP_K_ISZ 4
+#define COOP_K_FLG 5
+#define COOP_K_LOADW 6
+#define COOP_K_STOREW 7
+#define COOP_K_RES 8
+#define COOP_RES_ITEM 0                  // RES: fold the pairing bit into status[item], results[item] like lane_final
+#define COOP_RES_BATCH 1                 // RES: one bool for the whole batch: the pairing bit and no rejecting bit in the OR of all status words
+
+struct coop_prog { const uint32_t* steps; const uint32_t* rows; const uint32_t* consts; uint32_t nconsts; };
+typedef int32_t coop_v16 __attribute__((ext_vector_type(16)));
+
+#define COOP_M28 0x0fffffff
+#define COOP_REJECT (MBLS_ST_BAD_SIG_ENCODING | MBLS_ST_SIG_NOT_IN_G2 | MBLS_ST_BAD_PK_ENCODING | MBLS_ST_APK_INFINITY | MBLS_ST_NO_KEYS | MBLS_ST_PAIRING_FAILED | MBLS_ST_BAD_MSG_RANGE)
+#define COOP_REJECT_BATCH (MBLS_ST_BAD_SIG_ENCODING | MBLS_ST_SIG_NOT_IN_G2 | MBLS_ST_BAD_PK_ENCODING | MBLS_ST_BAD_MSG_RANGE | MBLS_ST_BAD_SCALAR)
+
+#if MBLS_DEVICE_ASM && !defined(MBLS_NO_FP2_ASM)
+MBLS_CONST int32_t COOP_P28[14] = MBLS_COOP_P28;
+
+// a * b / 2^392 on signed digits: the generated product scan (tools/gen_fpd_asm.py fp_mul1_d_body), inlined. Operands in v0..v13 and
+// v28..v41 (preserved), result in v70..v83, accumulator v98..v99; the digits of p and -1/p live in the SGPRs the scan expects.
+MBLS_FN void coop_mul(int32_t* r, const int32_t* a, const int32_t* b) {
+    coop_v16 va, vb, vr;
+#pragma unroll
+    for (int j = 0; j < 14; j++) { va[j] = a[j]; vb[j] = b[j]; }
+    va[14] = 0; va[15] = 0; vb[14] = 0; vb[15] = 0;
+    asm volatile(MBLS_FP_MUL1_D_ASM
+                 : "={v[70:85]}"(vr)
+                 : "{v[0:15]}"(va), "{v[28:43]}"(vb),
+                   "{s40}"(0xfffaaab), "{s41}"(0xfefffff), "{s42}"(0x3ffffb9), "{s43}"(0xfffeb15), "{s44}"(0x6241eab), "{s45}"(0xa0f6b0f), "{s46}"(0xf6730d2),
+                   "{s47}"(0xf38512b), "{s56}"(0x4774b84), "{s57}"(0x4bacd76), "{s58}"(0xba7b643), "{s59}"(0xe69a4b1), "{s60}"(0x1ea397f), "{s61}"(0x1a011),
+                   "{s64}"(MBLS_COOP_NP28), "{s65}"(COOP_M28)
+                 : "v98", "v99", "vcc", "scc");
+#pragma unroll
+    for (int j = 0; j < 14; j++) r[j] = vr[j];
+}
+// 64-bit digit sums -> the representative nearest to zero, digits 0..12 in [0, 2^28): carry pass, quotient estimate from the true top
+// digit, subtraction pass (tools/coop_sim.py reduce_digits is the same sequence)
+MBLS_FN void coop_reduce(int32_t* out, const int64_t* s) {
+    int64_t acc = 0; int32_t n[13];
+#pragma unroll
+    for (int j = 0; j < 13; j++) { acc += s[j]; n[j] = (int32_t)(acc & COOP_M28); acc >>= 28; }
+    acc += s[13];
+    const int64_t q = (int64_t)__builtin_rint((double)acc * MBLS_COOP_RECIP_PTOP);
+    int64_t c = 0;
+#pragma unroll
+    for (int j = 0; j < 13; j++) { c += (int64_t)n[j] - q * COOP_P28[j]; out[j] = (int32_t)(c & COOP_M28); c >>= 28; }
+    c += acc - q * COOP_P28[13];
+    out[13] = (int32_t)c;
+}
+// a reduced value -> [0, p): add p when it is negative
+MBLS_FN void coop_canonical(int32_t* d) {
+    const int64_t nq = d[13] < 0 ? 1 : 0;
+    int64_t c = 0;
+#pragma unroll
+    for (int j = 0; j < 13; j++) { c += (int64_t)d[j] + nq * COOP_P28[j]; d[j] = (int32_t)(c & COOP_M28); c >>= 28; }
+    c += (int64_t)d[13] + nq * COOP_P28[13];
+    d[13] = (int32_t)c;
+}
+// canonical digits (a value below 2^384) -> 12 words
+MBLS_FN fp coop_to_words(const int32_t* d) {
+    fp w;
+#pragma unroll
+    for (int q = 0; q < 12; q++) {
+        const int j = (32 * q) / 28, off = (32 * q) % 28;
+        uint32_t v = (uint32_t)d[j] >> off;
+        v |= (uint32_t)d[j + 1] << (28 - off);
+        if (28 - off + 28 < 32 && j + 2 < 14) v |= (uint32_t)d[j + 2] << (56 - off);
+        w[q] = v;
+    }
+    return w;
+}
+// 12 words w -> the 14 digits of w * 2^8 (a 2^384-domain value enters the 2^392 domain), then reduced
+MBLS_FN void coop_from_words(int32_t* out, fp w) {
+    int64_t s[14];
+#pragma unroll
+    for (int j = 0; j < 14; j++) {
+        const int o = 28 * j - 8;
+        uint32_t v;
+        if (o < 0) v = w[0] << 8;
+        else {
+            const int q = o >> 5, r = o & 31;
+            v = w[q] >> r;
+            if (r > 4 && q + 1 < 12) v |= w[q + 1] << (32 - r);
+        }
+        s[j] = (int64_t)(v & COOP_M28);
+    }
+    coop_reduce(out, s);
+}
+
+#endif
+
+// One wave per workgroup; workgroup b runs the program on item first_item + b * item_step (workspace addressing of mbls_lanes.h).
+// partner_step: LOADW with bit 16 of its workspace slot set reads from item + partner_step instead (the other operand of a tree product).
+__global__ void __launch_bounds__(64) k_coop(coop_prog pg, mbls_ws ws, uint64_t first_item, uint64_t item_step, uint64_t partner_step, uint64_t n_items,
+                                             uint32_t* status, uint8_t* results, int res_mode) {
+#if MBLS_DEVICE_ASM && !defined(MBLS_NO_FP2_ASM)
+    __shared__ int32_t S[MBLS_COOP_MAX_SLOTS * COOP_SW];
+    __shared__ uint32_t flags[64];
+    const uint32_t lane = threadIdx.x;
+    const uint64_t item = first_item + (uint64_t)blockIdx.x * item_step;
+    for (uint32_t t = lane; t < MBLS_COOP_MAX_SLOTS * COOP_SW; t += 64) S[t] = 0;
+    flags[lane] = lane == 1 ? 1u : 0u;
+    __syncthreads();
+    for (uint32_t t = lane; t < pg.nconsts * 14; t += 64) S[pg.consts[15 * (t / 14)] * COOP_SW + (t % 14)] = (int32_t)pg.consts[15 * (t / 14) + 1 + (t % 14)];
+    __syncthreads();
+    const uint4* rows = (const uint4*)pg.rows;
+    uint32_t info = pg.steps[0], row = pg.steps[1];
+    uint4 m0 = rows[(uint64_t)row * 128 + 2 * lane], m1 = rows[(uint64_t)row * 128 + 2 * lane + 1];
+    for (uint32_t step = 0;; step++) {
+        const uint32_t kind = info & 0xFF, na = (info >> 8) & 0xF, nb = (info >> 12) & 0xF;
+        if (kind == COOP_K_END) break;
+        const uint4 c0 = m0, c1 = m1;
+        // the next step's microcode is requested before this step runs (the rows are shared by every wave: L2 hits)
+        info = pg.steps[2 * (step + 1)]; row = pg.steps[2 * (step + 1) + 1];
+        m0 = rows[(uint64_t)row * 128 + 2 * lane]; m1 = rows[(uint64_t)row * 128 + 2 * lane + 1];
+        int32_t cf[8]; uint32_t ix[8];
+#pragma unroll
+        for (int t = 0; t < 4; t++) { cf[t] = (int32_t)(int8_t)(c0.x >> (8 * t)); cf[4 + t] = (int32_t)(int8_t)(c0.y >> (8 * t)); }
+        ix[0] = c0.z & 1023; ix[1] = (c0.z >> 10) & 1023; ix[2] = (c0.z >> 20) & 1023;
+        ix[3] = c0.w & 1023; ix[4] = (c0.w >> 10) & 1023; ix[5] = (c0.w >> 20) & 1023;
+        ix[6] = c1.x & 1023; ix[7] = (c1.x >> 10) & 1023;
+        const uint32_t dst = (c1.x >> 20) & 1023;
+        const uint32_t fl = c1.y & 0xFF, fl2 = (c1.y >> 8) & 0xFF, fop = (c1.y >> 16) & 0xFF;
+        const bool active = (c1.y >> 31) != 0;
+        const uint32_t wslot = c1.z;
+        if (kind == COOP_K_MUL) {
+            int32_t a[14], b[14], r[14];
+#pragma unroll
+            for (int j = 0; j < 14; j++) { a[j] = cf[0] * S[ix[0] * COOP_SW + j]; b[j] = cf[4] * S[ix[4] * COOP_SW + j]; }
+            for (uint32_t t = 1; t < na; t++) {
+#pragma unroll
+                for (int j = 0; j < 14; j++) a[j] += cf[t] * S[ix[t] * COOP_SW + j];
+            }
+            for (uint32_t t = 1; t < nb; t++) {
+#pragma unroll
+                for (int j = 0; j < 14; j++) b[j] += cf[4 + t] * S[ix[4 + t] * COOP_SW + j];
+            }
+            coop_mul(r, a, b);
+            __syncthreads();                       // every lane has read its operands
+#pragma unroll
+            for (int j = 0; j < 14; j++) S[dst * COOP_SW + j] = r[j];
+        } else if (kind == COOP_K_LIN) {
+            int64_t s[14]; int32_t r[14];
+            const bool second = fop == 1 && flags[fl] != 0;          // a selection: flag ? terms 4..7 : terms 0..3
+#pragma unroll
+            for (int j = 0; j < 14; j++) s[j] = 0;
+            for (uint32_t t = 0; t < na; t++) {
+                const int64_t c = (fop == 1 && second) ? 0 : cf[t];
+#pragma unroll
+                for (int j = 0; j < 14; j++) s[j] += c * S[ix[t] * COOP_SW + j];
+            }
+            for (uint32_t t = 0; t < nb; t++) {
+                const int64_t c = (fop == 1 && !second) ? 0 : cf[4 + t];
+#pragma unroll
+                for (int j = 0; j < 14; j++) s[j] += c * S[ix[4 + t] * COOP_SW + j];
+            }
+            coop_reduce(r, s);
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < 14; j++) S[dst * COOP_SW + j] = r[j];
+        } else if (kind == COOP_K_INV) {
+            int32_t d[14], r[14];
+#pragma unroll
+            for (int j = 0; j < 14; j++) d[j] = S[ix[0] * COOP_SW + j];
+            coop_canonical(d);
+            fp w = fp_inv(coop_to_words(d));           // the safegcd routine on 12 canonical words of the 2^384 domain (0 -> 0)
+            coop_from_words(r, w);
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < 14; j++) S[dst * COOP_SW + j] = r[j];
+        } else if (kind == COOP_K_ISZ) {
+            uint32_t o = 0;
+#pragma unroll
+            for (int j = 0; j < 14; j++) o |= (uint32_t)S[ix[0] * COOP_SW + j];
+            __syncthreads();
+            if (active) flags[fl] = o == 0 ? 1u : 0u;
+        } else if (kind == COOP_K_FLG) {
+            if (active) {
+                const uint32_t x = flags[fl2];
+                uint32_t v;
+                if (fop == 5) { v = 1; for (uint32_t t = 0; t < wslot; t++) v &= flags[fl2 + t]; }
+                else {
+                    const uint32_t y = flags[wslot & 63];
+                    v = fop == 0 ? (x & y) : fop == 1 ? (x | y) : fop == 2 ? (x & (1u - y)) : fop == 3 ? (x ^ y) : (x | (1u - y));
+                }
+                flags[fl] = v;
+            }
+        } else if (kind == COOP_K_LOADW) {
+            int32_t r[14];
+            const uint64_t it = (wslot & 0x10000u) ? item + partner_step : item;
+            fp w = fp_zero();
+            if (active) w = ws_ld(ws, (int)(wslot & 0xFFFF), it < ws.stride ? it : item);
+            coop_from_words(r, w);
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < 14; j++) S[dst * COOP_SW + j] = r[j];
+        } else if (kind == COOP_K_STOREW) {
+            int32_t d[14];
+#pragma unroll
+            for (int j = 0; j < 14; j++) d[j] = S[ix[0] * COOP_SW + j];
+            coop_canonical(d);
+            if (active) ws_st(ws, (int)wslot, item, coop_to_words(d));
+        } else if (kind == COOP_K_RES) {
+            if (active) {
+                const bool ok = flags[fl] != 0 && flags[fl2] == 0;
+                if (res_mode == COOP_RES_ITEM) {
+                    uint32_t st = status[item];
+                    if (!ok) st |= MBLS_ST_PAIRING_FAILED;
+                    status[item] = st;
+                    results[item] = (st & COOP_REJECT) ? 0 : 1;
+                } else {
+                    const uint32_t st = status[0];         // the OR of every set's status bits (k_status_or)
+                    results[0] = (ok && !(st & COOP_REJECT_BATCH)) ? 1 : 0;
+                }
+            }
+        }
+        __syncthreads();
+    }
+#endif
+}

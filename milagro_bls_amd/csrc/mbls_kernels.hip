@@ -16,6 +16,7 @@
 #include <mutex>
 #include <vector>
 #include "mbls_ops.h"
+#include "mbls_coop.h"
 #include "../../include/mbls.h"
 
 #define MBLS_SLOT_S 25            // 6 Fp: Jacobian G2 accumulator for verify_multiple
@@ -329,6 +330,9 @@ struct mbls_ctx {
     hipEvent_t ev[MBLS_N_PHASES + 1] = {};
     float phase_ms[MBLS_N_PHASES] = {};
     std::vector<struct mbls_keytable*> tables;     // the key tables created on this context (orphaned when it is destroyed)
+    coop_prog coop[3] = {};            // the cooperative engine's microprograms in HBM (mbls_coop.h): pairing2, vmtail, f12mul
+    uint32_t* d_coop = nullptr;
+    uint64_t coop_max_items = 2048;    // batches up to this size take the one-wave-per-item pairing check (latency path)
     char err[256] = {};
 };
 struct mbls_keytable {
@@ -361,6 +365,7 @@ static void ctx_free(mbls_ctx* c) {
     if (c->d_scalar) (void)hipFree(c->d_scalar);
     if (c->d_keys_xy) (void)hipFree(c->d_keys_xy);
     if (c->d_key_flags) (void)hipFree(c->d_key_flags);
+    if (c->d_coop) (void)hipFree(c->d_coop);
     for (int i = 0; i < MBLS_N_STAGE; i++) if (c->stage[i].p) (void)hipFree(c->stage[i].p);
     for (int i = 0; i <= MBLS_N_PHASES; i++) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
     if (c->hs_ev) (void)hipEventDestroy(c->hs_ev);
@@ -387,8 +392,35 @@ extern "C" int mbls_ctx_create(mbls_ctx** out, int device_id) {
          hipStreamCreateWithFlags(&c->hs_c, hipStreamNonBlocking) == hipSuccess;
     ok = ok && hipEventCreateWithFlags(&c->hs_ev, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&c->hs_ev2, hipEventDisableTiming) == hipSuccess &&
          hipEventCreateWithFlags(&c->hs_ev3, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&c->ws_ev, hipEventDisableTiming) == hipSuccess;
+    if (ok) {       // the cooperative engine's programs: one upload per context
+        const uint32_t* src[3][3] = {{MBLS_COOP_PAIRING2_STEPS, MBLS_COOP_PAIRING2_ROWS, MBLS_COOP_PAIRING2_CONSTS}, {MBLS_COOP_VMTAIL_STEPS, MBLS_COOP_VMTAIL_ROWS, MBLS_COOP_VMTAIL_CONSTS},
+                                     {MBLS_COOP_F12MUL_STEPS, MBLS_COOP_F12MUL_ROWS, MBLS_COOP_F12MUL_CONSTS}};
+        const size_t cnt[3][3] = {{2 * MBLS_COOP_PAIRING2_NSTEPS, 512 * MBLS_COOP_PAIRING2_NROWS, 15 * MBLS_COOP_PAIRING2_NCONSTS}, {2 * MBLS_COOP_VMTAIL_NSTEPS, 512 * MBLS_COOP_VMTAIL_NROWS, 15 * MBLS_COOP_VMTAIL_NCONSTS},
+                                  {2 * MBLS_COOP_F12MUL_NSTEPS, 512 * MBLS_COOP_F12MUL_NROWS, 15 * MBLS_COOP_F12MUL_NCONSTS}};
+        const uint32_t nconst[3] = {MBLS_COOP_PAIRING2_NCONSTS, MBLS_COOP_VMTAIL_NCONSTS, MBLS_COOP_F12MUL_NCONSTS};
+        size_t total = 0;
+        for (int p = 0; p < 3; p++) for (int a = 0; a < 3; a++) total += (cnt[p][a] + 3) & ~(size_t)3;       // 16-byte aligned pieces (the rows are read as uint4)
+        ok = hipMalloc(&c->d_coop, total * 4) == hipSuccess;
+        size_t at = 0;
+        for (int p = 0; p < 3 && ok; p++) {
+            const uint32_t* dp[3];
+            for (int a = 0; a < 3 && ok; a++) {
+                dp[a] = c->d_coop + at;
+                ok = hipMemcpy(c->d_coop + at, src[p][a], cnt[p][a] * 4, hipMemcpyHostToDevice) == hipSuccess;
+                at += (cnt[p][a] + 3) & ~(size_t)3;
+            }
+            c->coop[p].steps = dp[0]; c->coop[p].rows = dp[1]; c->coop[p].consts = dp[2]; c->coop[p].nconsts = nconst[p];
+        }
+        const char* e = getenv("MBLS_COOP_MAX_ITEMS");
+        if (e) c->coop_max_items = strtoull(e, nullptr, 10);
+    }
     if (!ok) { ctx_free(c); return MBLS_ERR_DEVICE; }
     *out = c; return MBLS_OK;
+}
+// batches of up to max_items items run their pairing check one wave per item (mbls_coop.h); 0 = always one lane per item
+extern "C" int mbls_ctx_set_coop_max_items(mbls_ctx* c, uint64_t max_items) {
+    if (!c) return MBLS_ERR_ARGUMENT;
+    mbls_lock lk(c->mu); c->coop_max_items = max_items; return MBLS_OK;
 }
 extern "C" void mbls_ctx_destroy(mbls_ctx* c) {
     if (!c) return;
@@ -536,10 +568,16 @@ static int verify_pipeline(mbls_ctx* c, const uint8_t* d_sigs, const uint8_t* d_
         if (s_sig != s) { HIPCHK(c, hipEventRecord(c->hs_ev2, s_sig)); HIPCHK(c, hipStreamWaitEvent(s, c->hs_ev2, 0)); }
         HIPCHK(c, hipEventRecord(c->hs_ev3, s_msg)); HIPCHK(c, hipStreamWaitEvent(s, c->hs_ev3, 0));
     }
-    hipLaunchKernelGGL(k_miller, dim3(g), dim3(WG), 0, s, ws, n);
-    if (tm) HIPCHK(c, hipEventRecord(c->ev[4], s));
-    hipLaunchKernelGGL(k_final, dim3(g), dim3(WG), 0, s, ws, st, d_results, n);
-    if (tm) HIPCHK(c, hipEventRecord(c->ev[5], s));
+    if (n <= c->coop_max_items) {
+        // small batch: one WAVE per item walks the Miller loop and the final exponentiation with its lanes side by side (mbls_coop.h)
+        hipLaunchKernelGGL(k_coop, dim3((unsigned)n), dim3(64), 0, s, c->coop[0], ws, (uint64_t)0, (uint64_t)1, (uint64_t)0, n, st, d_results, COOP_RES_ITEM);
+        if (tm) { HIPCHK(c, hipEventRecord(c->ev[4], s)); HIPCHK(c, hipEventRecord(c->ev[5], s)); }
+    } else {
+        hipLaunchKernelGGL(k_miller, dim3(g), dim3(WG), 0, s, ws, n);
+        if (tm) HIPCHK(c, hipEventRecord(c->ev[4], s));
+        hipLaunchKernelGGL(k_final, dim3(g), dim3(WG), 0, s, ws, st, d_results, n);
+        if (tm) HIPCHK(c, hipEventRecord(c->ev[5], s));
+    }
     if (d_bitmap) hipLaunchKernelGGL(k_pack, dim3(g), dim3(WG), 0, s, d_results, d_bitmap, n);
     if (tm) {
         HIPCHK(c, hipEventRecord(c->ev[6], s));

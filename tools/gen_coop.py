@@ -1,0 +1,928 @@
+#!/usr/bin/env python3
+"""Generate milagro_bls_amd/csrc/mbls_coop_prog.inc: microprograms for the WAVE-COOPERATIVE engine (mbls_coop.h).
+
+The pipeline kernels give every item one lane, which is what throughput wants -- and what makes ONE item cost 20 ms however small the
+batch is (a lane walks 14 M dependent instructions), and what makes the single final exponentiation of verify_multiple (reference
+src/aggregates.rs:313-315) an 8 ms tail. The cooperative engine turns that around for the latency-bound cases: ONE item per WAVE, its
+Fp values in LDS slots shared by the 64 lanes, and the computation cut into steps in which every lane performs one Fp operation of its
+own on operands it picks from the slots:
+    MUL   S[dst] <- (sum of up to 4 slots with small coefficients) * (sum of up to 4 slots) / 2^392      (mbls_fp_mul1_d_asm_fn: 461 instr.)
+    LIN   S[dst] <- reduce(sum of up to 8 slots with small coefficients), or a flag-selected one of two 4-term sums
+    INV / ISZ / FLG / LOADW / STOREW / RES   inversion, zero test -> flag, flag logic, workspace words in / out, result out
+An Fp12 product is then three steps deep instead of 54 multiplications long: the final exponentiation takes ~0.9 M instruction
+slots of ONE wave ... in ~1700 steps of ~500 instructions, i.e. under a millisecond instead of 8.
+
+This file is the "compiler": the formulas are the ones of tools/gen_tower_d.py (same Prog layer: Fp2 / Fp6 / Fp12 methods, line
+products, Frobenius constants), evaluated over LAZY LINEAR COMBINATIONS -- additions, subtractions, small multiples and
+multiplications by xi cost nothing until a product or a store needs the value; an operand that has more than 4 terms, or whose digit
+bound would overflow a product column, is materialised by a LIN step first. Bounds are tracked exactly as in gen_tower_d.py
+(class Bound). A list scheduler packs the Fp operations of a block into steps (64 lanes each), slots are assigned by liveness, loop
+bodies are blocks whose microcode is emitted once and referenced by every iteration.
+
+Digit-exact simulation of the microcode: tools/coop_sim.py (tests/test_coop_cpu.py checks the programs against the big-integer model).
+Run:  python3 tools/gen_coop.py     (output committed; tests check it is up to date)
+"""
+import os
+import struct
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from gen_fp_asm import P, M28  # noqa: E402
+from gen_fpd_asm import column_ok  # noqa: E402
+import gen_tower_d as T  # noqa: E402
+from gen_tower_d import Bound, product_bound, REDUCED, G_IN, R392, ONE_D, K384, D392  # noqa: E402
+
+K_END, K_MUL, K_LIN, K_INV, K_ISZ, K_FLG, K_LOADW, K_STOREW, K_RES = range(9)
+KIND_NAMES = ["END", "MUL", "LIN", "INV", "ISZ", "FLG", "LOADW", "STOREW", "RES"]
+NLANE = 64
+MAXT = 4                     # terms per product operand
+SLOT_ZERO = 0                # slot 0 holds zero: unused terms point there (coefficient 0), idle lanes write there
+FLAG_FALSE, FLAG_TRUE = 0, 1  # flag words 0 / 1 are constants
+F_AND, F_OR, F_ANDN, F_XOR, F_ORN, F_ALL = range(6)        # d = a & b, a | b, a & ~b, a ^ b, a | ~b, AND of flags a .. a + b - 1
+
+
+class LC:
+    """lazy linear combination: {node: coefficient}"""
+    __slots__ = ("t",)
+
+    def __init__(self, t=None):
+        self.t = {k: v for k, v in (t or {}).items() if v}
+
+    def key(self):
+        return tuple(sorted((n.id, c) for n, c in self.t.items()))
+
+    def __add__(self, o):
+        d = dict(self.t)
+        for n, c in o.t.items():
+            d[n] = d.get(n, 0) + c
+        return LC(d)
+
+    def __sub__(self, o):
+        d = dict(self.t)
+        for n, c in o.t.items():
+            d[n] = d.get(n, 0) - c
+        return LC(d)
+
+    def scaled(self, k):
+        return LC({n: c * k for n, c in self.t.items()})
+
+    def bound(self):
+        b = None
+        for n, c in self.t.items():
+            x = n.bound.scaled(c) if c > 0 else n.bound.scaled(-c).neg()
+            b = x if b is None else b + x
+        return b if b is not None else Bound(0, 0, 0, 0, 0, 0)
+
+    def nterms(self):
+        return len(self.t)
+
+    def single(self):
+        """the node if this is exactly 1 * node"""
+        if len(self.t) == 1:
+            (n, c), = self.t.items()
+            if c == 1:
+                return n
+        return None
+
+
+class Node:
+    __slots__ = ("id", "kind", "a", "b", "bound", "slot", "step", "lane", "pin", "aux", "last_use", "flag")
+
+    def __init__(self, nid, kind, bound, a=None, b=None, aux=None):
+        self.id, self.kind, self.bound, self.a, self.b, self.aux = nid, kind, bound, a, b, aux
+        self.slot = self.step = self.lane = self.pin = self.flag = None
+        self.last_use = -1
+
+
+class Block(T.Prog):
+    """One block of a cooperative program: a DAG of Fp operations over lazy linear combinations, with the Fp2 / Fp6 / Fp12 layers of
+    gen_tower_d.Prog on top (its primitives are overridden below). Live-in values are pinned slots of the program's state."""
+
+    def __init__(self, machine, name):
+        self.m, self.name = machine, name
+        self.nodes = []
+        self.mat_cache, self.mul_cache, self.const_cache = {}, {}, {}
+        self.items = []                  # schedulable operations in creation order
+        self.outs = []                   # (state name, node) written at the end of the block
+        self.in_nodes = {}
+
+    # ---- leaves
+    def _node(self, kind, bound, a=None, b=None, aux=None):
+        n = Node(len(self.nodes), kind, bound, a, b, aux)
+        self.nodes.append(n)
+        return n
+
+    def inp(self, name, bound=REDUCED):
+        """a state value (pinned slot), as it is when the block starts"""
+        if name not in self.in_nodes:
+            n = self._node("in", bound)
+            n.pin = self.m.state_slot(name)
+            self.in_nodes[name] = n
+        return LC({self.in_nodes[name]: 1})
+
+    def const(self, value):
+        if value == 0:
+            return LC()
+        if value not in self.const_cache:
+            n = self._node("in", Bound(0, M28, value >> 364, value >> 364, value, value))
+            n.pin = self.m.const_slot(value)
+            self.const_cache[value] = n
+        return LC({self.const_cache[value]: 1})
+
+    # ---- Prog primitives on lazy values
+    def add(self, a, b): return a + b
+    def sub(self, a, b): return a - b
+    def neg(self, a): return a.scaled(-1)
+    def scale(self, a, k): return a.scaled(k)
+    def shadd(self, a, s, b): return a.scaled(1 << s) + b
+
+    def pair(self, k0, a0, b0, k1, a1, b1):
+        return ((a0 + b0) if k0 == "add" else (a0 - b0), (a1 + b1) if k1 == "add" else (a1 - b1))
+
+    def materialise(self, a, force=False):
+        """the value as ONE slot holding its reduced representative"""
+        if not force and a.single() is not None and _is_reduced(a.single().bound):
+            return a
+        k = a.key()
+        if k in self.mat_cache:
+            return LC({self.mat_cache[k]: 1})
+        terms = list(a.t.items())
+        for i, (nd, c) in enumerate(terms):                  # a coefficient outside int8: 127 * (node) is materialised on its own
+            if not -127 <= c <= 127:
+                big = self.materialise(LC({nd: 127}), True).single()
+                k_, r_ = divmod(abs(c), 127)
+                sg = 1 if c > 0 else -1
+                assert k_ <= 127
+                terms[i] = (big, sg * k_)
+                if r_:
+                    terms.append((nd, sg * r_))
+        while len(terms) > 2 * MAXT:                         # more than a LIN step takes: partial sums first
+            part = LC(dict(terms[:2 * MAXT]))
+            terms = list(self.materialise(part, True).t.items()) + terms[2 * MAXT:]
+        lc = LC(dict(terms))
+        B = lc.bound()
+        # a LIN step sums in 64 bits, carries, estimates the quotient from the true top digit and subtracts: any digit bound below 2^50 works
+        assert B.mag() < (1 << 50) and B.vabs() < (P << 30), ("cannot reduce", B)
+        for n, c in lc.t.items():
+            assert -128 <= c <= 127
+        n = self._node("lin", REDUCED, a=lc)
+        self.items.append(n)
+        self.mat_cache[k] = n
+        return LC({n: 1})
+
+    def _operand(self, a):
+        if a.nterms() > MAXT or any(not -128 <= c <= 127 for c in a.t.values()) or not a.bound().fits():
+            a = self.materialise(a)
+        return a
+
+    def _sel_operand(self, a):
+        if a.nterms() > MAXT or any(not -128 <= c <= 127 for c in a.t.values()):
+            a = self.materialise(a)
+        return a
+
+    def mul(self, a, b):
+        """one Fp product (Montgomery, radix 2^392) of two lazy values"""
+        if not a.t or not b.t:
+            return LC()
+        a, b = self._operand(a), self._operand(b)
+        guard = 0
+        while not column_ok([(a.bound().mag(), b.bound().mag())]):
+            if a.bound().mag() >= b.bound().mag() and not (a.single() is not None and _is_reduced(a.single().bound)):
+                a = self.materialise(a)
+            else:
+                b = self.materialise(b)
+            guard += 1
+            assert guard < 4, "operands cannot be brought inside the column limit"
+        k = (a.key(), b.key())
+        if k not in self.mul_cache and (k[1], k[0]) in self.mul_cache:
+            k = (k[1], k[0])
+        if k not in self.mul_cache:
+            n = self._node("mul", product_bound([(a.bound(), b.bound())]), a=a, b=b)
+            self.items.append(n)
+            self.mul_cache[k] = n
+        return LC({self.mul_cache[k]: 1})
+
+    def call(self, kind, ins):
+        if kind == "mul":                                    # Karatsuba: 3 products
+            a0, a1, b0, b1 = ins
+            t0, t1, t2 = self.mul(a0, b0), self.mul(a1, b1), self.mul(a0 + a1, b0 + b1)
+            return (t0 - t1, t2 - t0 - t1)
+        if kind == "sqr":
+            a0, a1 = ins
+            return (self.mul(a0 + a1, a0 - a1), self.mul(a0, a1).scaled(2))
+        if kind == "mulfp":
+            a0, a1, s = ins
+            return (self.mul(a0, s), self.mul(a1, s))
+        if kind == "mulpair":
+            a0, a1, b0, b1 = ins
+            return (self.mul(a0, b0), self.mul(a1, b1))
+        if kind == "sqrpair":
+            return (self.mul(ins[0], ins[0]), self.mul(ins[1], ins[1]))
+        if kind == "mul1":
+            return (self.mul(ins[0], ins[1]),)
+        raise ValueError(kind)
+
+    def mulpair(self, a0, b0, a1, b1):
+        return (self.mul(a0, b0), self.mul(a1, b1))
+
+    def mul1(self, a, b):
+        return self.mul(a, b)
+
+    def mul2(self, a, b):
+        return self.sqr2(a) if (a[0] is b[0] and a[1] is b[1]) else self.call("mul", [a[0], a[1], b[0], b[1]])
+
+    def sel(self, flag, a, b):
+        """flag ? b : a   (flag: a flag word index)"""
+        if flag == FLAG_FALSE:
+            return a
+        if flag == FLAG_TRUE:
+            return b
+        a, b = self._sel_operand(a), self._sel_operand(b)
+        n = self._node("sel", REDUCED, a=a, b=b, aux=flag)
+        self.items.append(n)
+        return LC({n: 1})
+
+    def reduce(self, a):
+        return self.materialise(a)
+
+    def inv(self, a):
+        """1 / a (0 -> 0): a * 2^384-domain words through the safegcd routine of tools/gen_fp_asm.py, like gen_tower_d.Prog.inv"""
+        w = self.materialise(self.mul(a, self.const(K384)), True)
+        n = self._node("inv", REDUCED, a=w)                  # the kernel reduces the converted words
+        self.items.append(n)
+        return LC({n: 1})
+
+    def iszero(self, a, flag):
+        """flag word <- (a = 0 mod p)"""
+        w = self.materialise(a)
+        n = self._node("isz", None, a=w, aux=flag)
+        self.items.append(n)
+
+    def iszero2(self, a, flag, tmp):
+        self.iszero(a[0], flag); self.iszero(a[1], tmp); self.flagop(F_AND, flag, flag, tmp)
+
+    def flagop(self, op, dst, a, b):
+        n = self._node("flg", None, aux=(op, dst, a, b))
+        self.items.append(n)
+
+    def out(self, name, a):
+        """state[name] <- a (reduced) when the block ends"""
+        w = self.materialise(a, True)
+        node = w.single()
+        if node.pin is not None or any(node is o for _, o in self.outs):       # one node cannot live in two pinned slots: a fresh copy
+            node = self._node("lin", REDUCED, a=LC({node: 1}))
+            self.items.append(node)
+        node.pin = self.m.state_slot(name)
+        self.outs.append((name, node))
+
+    def loadw(self, name, ws_slot):
+        """state[name] <- the 12 words of workspace slot ws_slot of this wave's item (2^384 domain) as 2^392-domain digits, reduced"""
+        n = self._node("loadw", REDUCED, aux=ws_slot)
+        n.pin = self.m.state_slot(name)
+        self.items.append(n)
+        self.in_nodes[name] = n
+        return LC({n: 1})
+
+    def storew(self, a, ws_slot):
+        """workspace slot <- canonical 2^384-domain words of a"""
+        w = self.materialise(self.mul(a, self.const(K384)), True)
+        n = self._node("storew", None, a=w, aux=ws_slot)
+        self.items.append(n)
+
+    def result(self, flag_ok, flag_skip=FLAG_FALSE):
+        n = self._node("res", None, aux=(flag_ok, flag_skip))
+        self.items.append(n)
+
+
+def _is_reduced(B):
+    return B is not None and B.dlo >= 0 and B.dhi <= M28 and B.vlo >= REDUCED.vlo and B.vhi <= REDUCED.vhi
+
+
+class Machine:
+    """slot and flag numbering of one program; blocks are scheduled against it"""
+
+    def __init__(self, name, n_slots=600):
+        self.name = name
+        self.state = {}                  # name -> slot
+        self.consts = {}                 # value -> slot
+        self.next_slot = 1               # slot 0 = zero
+        self.flags = {"false": FLAG_FALSE, "true": FLAG_TRUE}
+        self.blocks = {}
+        self.order = []                  # [(block name, repeat)]
+        self.n_slots = n_slots
+
+    def state_slot(self, name):
+        if name not in self.state:
+            self.state[name] = self.next_slot; self.next_slot += 1
+        return self.state[name]
+
+    def const_slot(self, value):
+        if value not in self.consts:
+            self.consts[value] = self.next_slot; self.next_slot += 1
+        return self.consts[value]
+
+    def flag(self, name):
+        if name not in self.flags:
+            self.flags[name] = len(self.flags)
+        return self.flags[name]
+
+    def block(self, name):
+        b = Block(self, name)
+        self.blocks[name] = b
+        return b
+
+    def run(self, name, repeat=1):
+        self.order.append((name, repeat))
+
+
+# ---------------------------------------------------------------------------------------------- scheduling
+class Step:
+    def __init__(self, kind):
+        self.kind = kind
+        self.lanes = []                  # nodes
+
+
+def node_inputs(n):
+    out = []
+    for lc in (n.a, n.b):
+        if isinstance(lc, LC):
+            out += list(lc.t.keys())
+    return out
+
+
+STEP_KIND = {"mul": K_MUL, "lin": K_LIN, "sel": K_LIN, "inv": K_INV, "isz": K_ISZ, "flg": K_FLG, "loadw": K_LOADW, "storew": K_STOREW, "res": K_RES}
+
+
+def schedule(block):
+    """list scheduling in creation order (a topological order): every operation goes into the earliest step of its kind after its
+    operands. Flag producers / consumers and stores to the state keep their program order through explicit ready times."""
+    steps = []
+    flag_ready = {}                      # flag -> first step index at which it can be read
+    flag_last_read = {}
+    last_read = {}                       # node -> last step that reads it
+    pin_out = {node: name for name, node in block.outs}
+    for n in block.items:
+        kind = STEP_KIND[n.kind]
+        ready = 0
+        for x in node_inputs(n):
+            if x.kind != "in":
+                ready = max(ready, x.step + 1)
+        if n.kind == "sel":
+            ready = max(ready, flag_ready.get(n.aux, 0))
+        if n.kind == "isz":
+            ready = max(ready, flag_last_read.get(n.aux, -1) + 0, flag_ready.get(n.aux, 0))
+        if n.kind == "flg":
+            op, d, a, b = n.aux
+            srcs = list(range(a, a + b)) if op == F_ALL else [a, b]
+            for f in srcs:
+                ready = max(ready, flag_ready.get(f, 0))
+            ready = max(ready, flag_last_read.get(d, -1), flag_ready.get(d, 0))
+        if n.kind == "res":
+            ready = max([ready, len(steps)] + [flag_ready.get(f, 0) for f in n.aux])
+        if n in pin_out or n.kind == "loadw":
+            # the write of a state slot comes after every read of the value the slot held when the block started (same step is fine: a
+            # step reads all its operands before it writes)
+            old = block.in_nodes.get(pin_out.get(n))
+            if old is not None and old is not n:
+                ready = max(ready, last_read.get(old, -1))
+            for other in block.nodes:                        # ... and of any other live-in that shares the slot (it does not happen: names are unique)
+                pass
+        if n.kind in ("storew", "res"):
+            ready = max(ready, 0)
+        # earliest step of this kind with a free lane; MUL / LIN steps take 64 operations, the serial kinds as well
+        k = None
+        for i in range(ready, len(steps)):
+            if steps[i].kind == kind and len(steps[i].lanes) < NLANE and not (kind == K_FLG and steps[i].lanes):
+                k = i
+                break
+        if k is None:
+            steps.append(Step(kind)); k = len(steps) - 1
+        n.step, n.lane = k, len(steps[k].lanes)
+        steps[k].lanes.append(n)
+        for x in node_inputs(n):
+            last_read[x] = max(last_read.get(x, -1), k)
+        if n.kind == "sel":
+            flag_last_read[n.aux] = max(flag_last_read.get(n.aux, -1), k)
+        if n.kind == "isz":
+            flag_ready[n.aux] = k + 1
+        if n.kind == "flg":
+            op, d, a, b = n.aux
+            for f in (list(range(a, a + b)) if op == F_ALL else [a, b]):
+                flag_last_read[f] = max(flag_last_read.get(f, -1), k)
+            flag_ready[d] = k + 1
+        if n.kind == "res":
+            for f in n.aux:
+                flag_last_read[f] = max(flag_last_read.get(f, -1), k)
+    # a state write must not land before a LATER-scheduled read of the old value: verify (creation order makes this hold; assert it)
+    for name, node in block.outs:
+        old = block.in_nodes.get(name)
+        if old is not None and old is not node:
+            assert last_read.get(old, -1) <= node.step, ("state slot rewritten before its last read", block.name, name)
+    for n in block.nodes:
+        n.last_use = last_read.get(n, -1)
+    return steps
+
+
+def assign_slots(machine, block, steps, temp_base):
+    """temporaries by liveness from temp_base upwards (a slot read for the last time in step t may be written in step t)"""
+    free, nxt, peak = [], temp_base, temp_base
+    release_at = {}
+    for si, st in enumerate(steps):
+        for n in release_at.pop(si, []):
+            free.append(n.slot)
+        for n in st.lanes:
+            if n.kind in ("isz", "flg", "storew", "res"):
+                continue
+            if n.pin is not None:
+                n.slot = n.pin
+                continue
+            if free:
+                n.slot = free.pop()
+            else:
+                n.slot = nxt; nxt += 1
+            peak = max(peak, nxt)
+            lu = n.last_use if n.last_use >= 0 else si
+            release_at.setdefault(max(lu, si + 1), []).append(n)
+    for n in block.nodes:
+        if n.kind == "in":
+            n.slot = n.pin
+    assert peak <= machine.n_slots, ("out of LDS slots", peak)
+    return peak
+
+
+# ---------------------------------------------------------------------------------------------- microcode
+# per lane and step: 8 dwords
+#   w0, w1: eight signed 8-bit coefficients (terms 0..3 = operand A / first sum, 4..7 = operand B / second sum)
+#   w2, w3, w4: nine 10-bit slot indices (3 per dword): the eight terms, then dst
+#   w5: bits 0..7 flag index (sel: flag ? second sum : first sum; isz: flag to write; res: ok flag), bits 8..15 second flag, bits 16..23
+#       flag op, bit 31 lane is active
+#   w6: workspace slot (loadw / storew), w7: reserved
+def pack_lane(coefs, idxs, dst, flag=0, flag2=0, fop=0, active=True, wslot=0):
+    assert len(coefs) == 8 and len(idxs) == 8
+    w0 = sum((c & 0xFF) << (8 * i) for i, c in enumerate(coefs[:4]))
+    w1 = sum((c & 0xFF) << (8 * i) for i, c in enumerate(coefs[4:]))
+    ii = list(idxs) + [dst]
+    assert all(0 <= x < 1024 for x in ii)
+    w2 = ii[0] | (ii[1] << 10) | (ii[2] << 20)
+    w3 = ii[3] | (ii[4] << 10) | (ii[5] << 20)
+    w4 = ii[6] | (ii[7] << 10) | (ii[8] << 20)
+    w5 = (flag & 0xFF) | ((flag2 & 0xFF) << 8) | ((fop & 0xFF) << 16) | ((1 << 31) if active else 0)
+    return [w0, w1, w2, w3, w4, w5, wslot, 0]
+
+
+IDLE_LANE = pack_lane([0] * 8, [0] * 8, SLOT_ZERO, active=False)
+
+
+def lane_words(n):
+    def terms(lc, cnt):
+        t = [(x.slot, c) for x, c in lc.t.items()] if lc is not None else []
+        assert len(t) <= cnt
+        t += [(SLOT_ZERO, 0)] * (cnt - len(t))
+        return t
+    if n.kind == "mul":
+        t = terms(n.a, 4) + terms(n.b, 4)
+        return pack_lane([c for _, c in t], [s for s, _ in t], n.slot)
+    if n.kind == "lin":
+        t = terms(n.a, 8)
+        return pack_lane([c for _, c in t], [s for s, _ in t], n.slot)
+    if n.kind == "sel":
+        t = terms(n.a, 4) + terms(n.b, 4)
+        return pack_lane([c for _, c in t], [s for s, _ in t], n.slot, flag=n.aux, fop=1)
+    if n.kind == "inv":
+        return pack_lane([1] + [0] * 7, [n.a.single().slot] + [0] * 7, n.slot)
+    if n.kind == "isz":
+        return pack_lane([1] + [0] * 7, [n.a.single().slot] + [0] * 7, SLOT_ZERO, flag=n.aux)
+    if n.kind == "flg":
+        op, d, a, b = n.aux
+        return pack_lane([0] * 8, [0] * 8, SLOT_ZERO, flag=d, flag2=a, fop=op, wslot=b)
+    if n.kind == "loadw":
+        return pack_lane([0] * 8, [0] * 8, n.slot, wslot=n.aux)
+    if n.kind == "storew":
+        return pack_lane([1] + [0] * 7, [n.a.single().slot] + [0] * 7, SLOT_ZERO, wslot=n.aux)
+    if n.kind == "res":
+        return pack_lane([0] * 8, [0] * 8, SLOT_ZERO, flag=n.aux[0], flag2=n.aux[1])
+    raise ValueError(n.kind)
+
+
+def step_info(st):
+    """descriptor word: kind | nA << 8 | nB << 12 (the largest term counts over the lanes: the kernel skips the rest)"""
+    na = nb = 0
+    for n in st.lanes:
+        if n.kind == "mul":
+            na, nb = max(na, n.a.nterms()), max(nb, n.b.nterms())
+        elif n.kind == "lin":
+            t = n.a.nterms()
+            na, nb = max(na, min(t, 4)), max(nb, max(0, t - 4))
+        elif n.kind == "sel":
+            na, nb = max(na, n.a.nterms()), max(nb, n.b.nterms())
+        elif n.kind in ("inv", "isz", "storew"):
+            na = max(na, 1)
+    return st.kind | (na << 8) | (nb << 12)
+
+
+def compile_program(machine):
+    """-> dict(steps=[(info, microcode row)], rows=[[64 x 8 words]], consts={slot: value}, n_slots, n_flags, stats)"""
+    temp_base = None
+    sched = {}
+    # pinned slots (state + constants) are numbered while the blocks are built; temporaries live above all of them
+    for name, blk in machine.blocks.items():
+        sched[name] = schedule(blk)
+    temp_base = machine.next_slot
+    peak = temp_base
+    for name, blk in machine.blocks.items():
+        peak = max(peak, assign_slots(machine, blk, sched[name], temp_base))
+    rows, row_of = [], {}
+    block_rows = {}
+    for name, blk in machine.blocks.items():
+        br = []
+        for st in sched[name]:
+            words = []
+            for n in st.lanes:
+                words += lane_words(n)
+            for _ in range(NLANE - len(st.lanes)):
+                words += IDLE_LANE
+            key = (step_info(st), tuple(words))
+            if key not in row_of:
+                row_of[key] = len(rows); rows.append(words)
+            br.append((step_info(st), row_of[key]))
+        block_rows[name] = br
+    steps = []
+    for name, rep in machine.order:
+        for _ in range(rep):
+            steps += block_rows[name]
+    steps.append((K_END, 0))
+    stats = {name: dict(steps=len(sched[name]), mul=sum(1 for s in sched[name] if s.kind == K_MUL), lin=sum(1 for s in sched[name] if s.kind == K_LIN),
+                        ops=len(machine.blocks[name].items)) for name in machine.blocks}
+    return dict(steps=steps, rows=rows, consts=dict((s, v) for v, s in machine.consts.items()), n_slots=peak, n_flags=len(machine.flags),
+                stats=stats, total_steps=len(steps), sched=sched, block_rows=block_rows)
+
+
+# ---------------------------------------------------------------------------------------------- the programs
+RUNS = T.RUNS                                   # doublings between the additions of the Miller loop / squarings between the products of a power by |x|
+F_NAMES = ["f%d" % i for i in range(12)]
+WS_APK, WS_SIG, WS_H, WS_F, WS_S = 0, 3, 7, 13, 25      # workspace slots of the pipeline (mbls_lanes.h, mbls_kernels.hip)
+NPX0_D, PY0_D = T.NPX0_D, T.PY0_D
+
+
+def six(l):
+    return T.six(l)
+
+
+def flat12(f):
+    return T.flat12(f)
+
+
+def st12(b, f, prefix="f"):
+    for i, v in enumerate(flat12(f)):
+        b.out("%s%d" % (prefix, i), v)
+
+
+def ld12(b, prefix="f"):
+    return six([b.inp("%s%d" % (prefix, i)) for i in range(12)])
+
+
+def pt_in(b, prefix):
+    l = [b.inp("%s%d" % (prefix, i)) for i in range(6)]
+    return [(l[0], l[1]), (l[2], l[3]), (l[4], l[5])]
+
+
+def pt_out(b, prefix, pt):
+    for i, v in enumerate([x for c in pt for x in c]):
+        b.out("%s%d" % (prefix, i), v)
+
+
+def masked_line(b, c0, c2, c3, skip):
+    """a pair with a member at infinity contributes 1: its line is replaced by (1, 0, 0)"""
+    one, zero = b.const(ONE_D), LC()
+    return ((b.sel(skip, c0[0], one), b.sel(skip, c0[1], zero)), (b.sel(skip, c2[0], zero), b.sel(skip, c2[1], zero)),
+            (b.sel(skip, c3[0], zero), b.sel(skip, c3[1], zero)))
+
+
+def dbl_step(b, Tn, pxyz):
+    """T <- 2T and the line through it (formulas of prog_miller_dbl_d in tools/gen_tower_d.py / miller_dbl_step in mbls_pairing.h);
+    pxyz = (-px, py, pz3 or None): the G1 argument as an Fp value each"""
+    Tx, Ty, Tz = Tn
+    B = b.sqr2(Ty); C = b.sqr2(Tz)
+    E = b.mul12_2(b.mul_xi2(C))
+    F = b.mul3_2(E)
+    X2 = b.sqr2(Tx)
+    YZ2 = b.sub2(b.sub2(b.sqr2(b.add2(Ty, Tz)), B), C)
+    c0 = b.sub2(B, E)
+    if pxyz[2] is not None:
+        c0 = b.mulfp2(c0, pxyz[2])
+    c2 = b.mulfp2(b.mul3_2(X2), pxyz[0])
+    c3 = b.mulfp2(YZ2, pxyz[1])
+    x3 = b.dbl2(b.mul2(b.mul2(Tx, Ty), b.sub2(B, F)))
+    y3 = b.sub2(b.sqr2(b.add2(B, F)), b.mul12_2(b.sqr2(E)))
+    z3 = b.mul4_2(b.mul2(B, YZ2))
+    return [x3, y3, z3], (c0, c2, c3)
+
+
+def add_step(b, Tn, Q, pxyz):
+    """T <- T + Q and the line through them (prog_miller_add_d / miller_add_step); Q = (x, y, z or None for an affine point)"""
+    Tx, Ty, Tz = Tn
+    Qx, Qy, Qz = Q
+    if Qz is None:
+        y1z2, x1z2, z1z2 = Ty, Tx, Tz
+    else:
+        y1z2, x1z2, z1z2 = b.mul2(Ty, Qz), b.mul2(Tx, Qz), b.mul2(Tz, Qz)
+    u = b.sub2(b.mul2(Qy, Tz), y1z2)
+    v = b.sub2(b.mul2(Qx, Tz), x1z2)
+    c0 = b.sub2(b.mul2(u, Qx), b.mul2(v, Qy))
+    if pxyz[2] is not None:
+        c0 = b.mulfp2(c0, pxyz[2])
+    uq, vq = (u, v) if Qz is None else (b.mul2(u, Qz), b.mul2(v, Qz))
+    c2 = b.mulfp2(uq, pxyz[0])
+    c3 = b.mulfp2(vq, pxyz[1])
+    uu = b.sqr2(u); vv = b.sqr2(v)
+    vvv = b.mul2(v, vv); R = b.mul2(vv, x1z2)
+    A = b.sub2(b.sub2(b.mul2(uu, z1z2), vvv), b.dbl2(R))
+    x3 = b.mul2(v, A)
+    y3 = b.sub2(b.mul2(u, b.sub2(R, A)), b.mul2(vvv, y1z2))
+    z3 = b.mul2(vvv, z1z2)
+    return [x3, y3, z3], (c0, c2, c3)
+
+
+def build_miller(m, pairs, prefix=""):
+    """blocks `dbl` and `add` of the Miller loop over the listed pairs. Pair descriptor: dict(T=state prefix of the running point,
+    Q=state prefix of the fixed point, affine=bool, P=(name -px, name py, name pz3 | None) or constants, skip=flag)"""
+    def parg(b, pr):
+        out = []
+        for x in pr["P"]:
+            out.append(None if x is None else (b.const(x) if isinstance(x, int) else b.inp(x)))
+        return out
+    b = m.block(prefix + "dbl")
+    f = b.sqr12(ld12(b))
+    lines = []
+    for pr in pairs:
+        Tn, line = dbl_step(b, pt_in(b, pr["T"]), parg(b, pr))
+        pt_out(b, pr["T"], Tn)
+        lines.append(masked_line(b, *line, pr["skip"]))
+    if len(lines) == 2:
+        L0, L1 = T.mul_lines(b, lines[0], lines[1])
+        f = T.mul12_by_lines(b, f, L0, L1)
+    else:
+        f = b.mul12_line(f, *lines[0])
+    st12(b, f)
+    b = m.block(prefix + "add")
+    f = ld12(b)
+    for pr in pairs:
+        q = [b.inp("%s%d" % (pr["Q"], i)) for i in range(4 if pr["affine"] else 6)]
+        Q = [(q[0], q[1]), (q[2], q[3]), None if pr["affine"] else (q[4], q[5])]
+        Tn, line = add_step(b, pt_in(b, pr["T"]), Q, parg(b, pr))
+        pt_out(b, pr["T"], Tn)
+        f = b.mul12_line(f, *masked_line(b, *line, pr["skip"]))
+    st12(b, f)
+
+
+def run_miller(m, prefix=""):
+    for ph in range(6):
+        m.run(prefix + "dbl", RUNS[ph])
+        if ph < 5:
+            m.run(prefix + "add")
+
+
+def cyc_sqr_block(m, name="csq"):
+    b = m.block(name)
+    z = ld12(b)
+    zz = z[0] + z[1]
+    outv = [None] * 6
+    T.cyc_sqr_formula(b, zz, lambda e, v: outv.__setitem__(e, v))
+    st12(b, (outv[:3], outv[3:]))
+
+
+def build_final_exp(m):
+    """f (state f0..f11) <- f^(3 (p^12 - 1) / r), the sequence of final_exp in mbls_pairing.h / final_exp_d_routine in gen_tower_d.py, with
+    plain Granger-Scott squarings (all 18 products of a squaring sit in ONE step here: compression would only add the decompressions).
+    State: f (running value), y (base of the running power), mm (f after the easy part), bb."""
+    b = m.block("easy")
+    f = ld12(b)
+    a0, a1 = f
+    t = b.sub6(T.sqr6(b, a0), b.mul_v6(T.sqr6(b, a1)))
+    c0, c1, c2 = t
+    A = b.sub2(b.sqr2(c0), b.mul_xi2(b.mul2(c1, c2)))
+    Bv = b.sub2(b.mul_xi2(b.sqr2(c2)), b.mul2(c0, c1))
+    C = b.sub2(b.sqr2(c1), b.mul2(c0, c2))
+    F = b.add2(b.mul_xi2(b.add2(b.mul2(c2, Bv), b.mul2(c1, C))), b.mul2(c0, A))
+    n = b.add(b.mul(F[0], F[0]), b.mul(F[1], F[1]))
+    ni = b.inv(n)
+    Fi = b.mulfp2(b.conj2(F), ni)
+    Tt = [b.mul2(A, Fi), b.mul2(Bv, Fi), b.mul2(C, Fi)]
+    fi = (b.mul6(a0, Tt), b.neg6(b.mul6(a1, Tt)))
+    t = T.mul12(b, fi, f, conj_b=True)                          # f^(p^6 - 1)
+    mm = T.mul12(b, T.frob12_2(b, t), t)                        # ^(p^2 + 1)
+    st12(b, mm); st12(b, mm, "y"); st12(b, mm, "m")
+    cyc_sqr_block(m)
+    b = m.block("mulbase")                                       # f <- f * y
+    st12(b, T.mul12(b, ld12(b), ld12(b, "y")))
+    b = m.block("pstart")                                        # f <- y
+    st12(b, ld12(b, "y"))
+    b = m.block("step_conj")                                     # after powers 1, 2: f <- conj(f) conj(y) = conj(f y); also the next base
+    r = T.mul12(b, ld12(b), ld12(b, "y"))
+    r = (r[0], b.neg6(r[1]))
+    st12(b, r); st12(b, r, "y")
+    b = m.block("step_frob")                                     # after power 3: b = conj(f) frob(y) -> f, y, bb
+    r = T.mul12(b, T.frob12(b, ld12(b, "y")), ld12(b), conj_b=True)
+    st12(b, r); st12(b, r, "y"); st12(b, r, "b")
+    b = m.block("step_base")                                     # after power 4: conj(f) is the base of the fifth
+    a = ld12(b)
+    r = (a[0], b.neg6(a[1]))
+    st12(b, r); st12(b, r, "y")
+    b = m.block("tail")                                          # conj(f) * frob^2(b) * conj(b) * m^3
+    a = ld12(b); bb = ld12(b, "b"); mmv = ld12(b, "m")
+    c = T.mul12(b, T.frob12_2(b, bb), a, conj_b=True)
+    c = T.mul12(b, c, bb, conj_b=True)
+    m2 = [None] * 6
+    T.cyc_sqr_formula(b, mmv[0] + mmv[1], lambda e, v: m2.__setitem__(e, v))
+    c = T.mul12(b, c, T.mul12(b, (m2[:3], m2[3:]), mmv))
+    st12(b, c)
+
+
+def run_power(m):
+    """f <- y^|x| (|x| = 2^63 + 2^62 + 2^60 + 2^57 + 2^48 + 2^16): start from y, squarings with a product by y after runs of 1, 2, 3, 9, 32"""
+    m.run("pstart")
+    for ph in range(6):
+        m.run("csq", RUNS[ph])
+        if ph < 5:
+            m.run("mulbase")
+
+
+def run_final_exp(m):
+    m.run("easy")
+    for k in range(5):
+        run_power(m)
+        if k < 2:
+            m.run("step_conj")
+        elif k == 2:
+            m.run("step_frob")
+        elif k == 3:
+            m.run("step_base")
+    m.run("tail")
+
+
+def is_one_block(m, name, ok_flag, extra_ok=None):
+    """ok_flag <- (f == 1) [& extra flag]"""
+    b = m.block(name)
+    f = flat12(ld12(b))
+    fl = [m.flag("z%d" % i) for i in range(12)]
+    assert fl == list(range(fl[0], fl[0] + 12))
+    b.iszero(b.sub(f[0], b.const(ONE_D)), fl[0])
+    for i in range(1, 12):
+        b.iszero(f[i], fl[i])
+    b.flagop(F_ALL, ok_flag, fl[0], 12)
+    return b
+
+
+def prog_pairing2():
+    """The pairing check of ONE verification (Signature::verify / fast_aggregate_verify, reference src/amcl_utils.rs:38-42) on a wave:
+    pair 0 = (signature, -G1), pair 1 = (H(m), apk), from the workspace slots the phase kernels filled (APK 0..2 Jacobian, SIG 3..6 affine,
+    H 7..12 Jacobian): Miller loop over both pairs with a shared squaring, final exponentiation, == 1. Result flag; the status word
+    receives MBLS_ST_PAIRING_FAILED through the kernel."""
+    m = Machine("pairing2")
+    skip0, skip1, tmp, tmp2 = m.flag("skip0"), m.flag("skip1"), m.flag("tmp"), m.flag("tmp2")
+    b = m.block("load")
+    apk = [b.loadw("apk%d" % i, WS_APK + i) for i in range(3)]
+    sig = [b.loadw("q0_%d" % i, WS_SIG + i) for i in range(4)]
+    h = [b.loadw("hj%d" % i, WS_H + i) for i in range(6)]
+    b.iszero2((sig[2], sig[3]), skip0, tmp)                       # infinity is stored as y = 0 (lane_sig)
+    b.iszero2((h[4], h[5]), skip1, tmp); b.iszero(apk[2], tmp2); b.flagop(F_OR, skip1, skip1, tmp2)
+    # pair 1: Q1 = (X Z : Y : Z^3) homogeneous, P1 = (-(X Z), Y, Z^3) (g2h_from_jacobian / g1arg_from_jacobian, mbls_pairing.h)
+    H = [(h[0], h[1]), (h[2], h[3]), (h[4], h[5])]
+    qx = b.mul2(H[0], H[2]); qz = b.mul2(b.sqr2(H[2]), H[2])
+    for i, v in enumerate([qx[0], qx[1], H[1][0], H[1][1], qz[0], qz[1]]):
+        b.out("q1_%d" % i, v); b.out("t1_%d" % i, v)
+    one = b.const(ONE_D)
+    for i, v in enumerate([sig[0], sig[1], sig[2], sig[3], one, LC()]):      # T0 = (x, y, 1)
+        b.out("t0_%d" % i, v)
+    zz = b.mul(apk[2], apk[2])
+    b.out("npx", b.neg(b.mul(apk[0], apk[2]))); b.out("py", apk[1]); b.out("pz3", b.mul(zz, apk[2]))
+    for i in range(12):
+        b.out("f%d" % i, one if i == 0 else LC())
+    pairs = [dict(T="t0_", Q="q0_", affine=True, P=(NPX0_D, PY0_D, None), skip=skip0),
+             dict(T="t1_", Q="q1_", affine=False, P=("npx", "py", "pz3"), skip=skip1)]
+    build_miller(m, pairs)
+    build_final_exp(m)
+    ok = m.flag("ok")
+    b = is_one_block(m, "isone", ok)
+    b.result(ok)
+    m.run("load"); run_miller(m); run_final_exp(m); m.run("isone")
+    return m
+
+
+def prog_vmtail():
+    """The tail of verify_multiple_aggregate_signatures / aggregate_verify (reference src/aggregates.rs:307-315, :158-169) on ONE wave:
+    F = the product of the per-set Miller values (workspace slots 13..24 of item 0, conjugated values as k_miller_single leaves them),
+    S = sum r_i sig_i (slots 25..30, Jacobian). result = (final_exp(F * conj(f_{|x|,S}(-G1))) == 1); S = infinity contributes 1."""
+    m = Machine("vmtail")
+    skip, tmp = m.flag("skip"), m.flag("tmp")
+    b = m.block("load")
+    F = [b.loadw("g%d" % i, WS_F + i) for i in range(12)]        # kept aside in g0..g11 until the loop is done
+    s = [b.loadw("sj%d" % i, WS_S + i) for i in range(6)]
+    b.iszero2((s[4], s[5]), skip, tmp)
+    Sx, Sy, Sz = (s[0], s[1]), (s[2], s[3]), (s[4], s[5])
+    qx = b.mul2(Sx, Sz); qz = b.mul2(b.sqr2(Sz), Sz)
+    for i, v in enumerate([qx[0], qx[1], Sy[0], Sy[1], qz[0], qz[1]]):
+        b.out("q%d" % i, v); b.out("t%d" % i, v)
+    one = b.const(ONE_D)
+    for i in range(12):
+        b.out("f%d" % i, one if i == 0 else LC())
+    build_miller(m, [dict(T="t", Q="q", affine=False, P=(NPX0_D, PY0_D, None), skip=skip)])
+    b = m.block("join")                                           # f <- F * conj(f)
+    st12(b, T.mul12(b, ld12(b, "g"), ld12(b), conj_b=True))
+    build_final_exp(m)
+    ok = m.flag("ok")
+    b = is_one_block(m, "isone", ok)
+    b.result(ok)
+    m.run("load"); run_miller(m); m.run("join"); run_final_exp(m); m.run("isone")
+    return m
+
+
+def prog_f12tree():
+    """item 0's Miller value <- the product of the Miller values of up to 64 consecutive items (workspace slots 13..24), for the product
+    trees of the n-pairing paths: the kernel maps lane groups to items; here: state f <- f * g, a block the kernel runs log-many times with
+    g loaded from the partner item. (See k_coop_f12tree in mbls_coop.h.)"""
+    m = Machine("f12mul")
+    b = m.block("load")
+    for i in range(12):
+        b.loadw("f%d" % i, WS_F + i)
+    b = m.block("loadg")
+    for i in range(12):
+        b.loadw("g%d" % i, WS_F + i)
+    b = m.block("mul")
+    st12(b, T.mul12(b, ld12(b), ld12(b, "g")))
+    b = m.block("store")
+    f = flat12(ld12(b))
+    for i in range(12):
+        b.storew(f[i], WS_F + i)
+    m.run("load"); m.run("loadg"); m.run("mul"); m.run("store")
+    return m
+
+
+PROGRAMS = {"pairing2": prog_pairing2, "vmtail": prog_vmtail, "f12mul": prog_f12tree}
+
+
+def emit_c(name, comp):
+    U = name.upper()
+    L = ["// program %s: %d steps, %d microcode rows, %d slots, %d flags" % (name, len(comp["steps"]), len(comp["rows"]), comp["n_slots"], comp["n_flags"])]
+    L.append("static const uint32_t MBLS_COOP_%s_STEPS[%d] = {" % (U, 2 * len(comp["steps"])))
+    row = []
+    for info, r in comp["steps"]:
+        row.append("0x%x,%d" % (info, r))
+    for i in range(0, len(row), 16):
+        L.append("  " + ",".join(row[i:i + 16]) + ",")
+    L.append("};")
+    L.append("static const uint32_t MBLS_COOP_%s_ROWS[%d] = {" % (U, 512 * len(comp["rows"])))
+    for words in comp["rows"]:
+        for i in range(0, 512, 32):
+            L.append("  " + ",".join("0x%x" % w for w in words[i:i + 32]) + ",")
+    L.append("};")
+    cs = sorted(comp["consts"].items())
+    L.append("static const uint32_t MBLS_COOP_%s_CONSTS[%d] = {      // slot, 14 digits" % (U, 15 * max(1, len(cs))))
+    for slot, v in cs:
+        L.append("  %d," % slot + ",".join("0x%x" % d for d in T.digits_of(v)) + ",")
+    if not cs:
+        L.append("  0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,")
+    L.append("};")
+    L.append("#define MBLS_COOP_%s_NSTEPS %d" % (U, len(comp["steps"])))
+    L.append("#define MBLS_COOP_%s_NROWS %d" % (U, len(comp["rows"])))
+    L.append("#define MBLS_COOP_%s_NCONSTS %d" % (U, len(cs)))
+    L.append("#define MBLS_COOP_%s_NSLOTS %d" % (U, comp["n_slots"]))
+    return "\n".join(L) + "\n"
+
+
+def digit_constants():
+    from gen_fp_asm import P28, NP28
+    L = ["// the resident constants of mbls_fp_mul1_d_asm_fn (tools/gen_fpd_asm.py load_constants): digits of p, -1/p mod 2^28"]
+    L.append("#define MBLS_COOP_P28 {" + ",".join("0x%x" % d for d in P28) + "}")
+    L.append("#define MBLS_COOP_NP28 0x%xu" % NP28)
+    L.append("#define MBLS_COOP_RECIP_PTOP %r" % (1.0 / (P >> 364)))
+    return "\n".join(L) + "\n"
+
+
+def build_all():
+    out = {}
+    for name, fn in PROGRAMS.items():
+        out[name] = compile_program(fn())
+    return out
+
+
+def main():
+    here = os.path.dirname(os.path.abspath(__file__))
+    path = os.path.join(os.path.dirname(here), "milagro_bls_amd", "csrc", "mbls_coop_prog.inc")
+    txt = "// GENERATED by tools/gen_coop.py -- do not edit. Microprograms of the wave-cooperative engine (mbls_coop.h).\n"
+    mx = 0
+    for name, comp in build_all().items():
+        txt += emit_c(name, comp)
+        mx = max(mx, comp["n_slots"])
+        print(name, "steps", comp["total_steps"], "rows", len(comp["rows"]), "slots", comp["n_slots"], "flags", comp["n_flags"])
+        for bn, s in comp["stats"].items():
+            print("   ", bn, s)
+    txt += "#define MBLS_COOP_MAX_SLOTS %d\n" % mx
+    txt += digit_constants()
+    with open(path, "w") as f:
+        f.write(txt)
+    print("wrote", path)
+
+
+if __name__ == "__main__":
+    main()
