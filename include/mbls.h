@@ -60,8 +60,8 @@ typedef struct mbls_ctx mbls_ctx;
 /* ---- context: one per GPU (one process per GPU in multi-GPU runs) ----
  * Thread safety: every entry point takes the context's lock, so a context may be shared by any number of threads (the
  * reference's functions are pure and re-entrant); calls on one context run one after the other.
- * Device-pointer entries only enqueue work: a later call on another stream waits (on the device) for the workspace of
- * the earlier one. For concurrent streams of work create one context per stream. */
+ * Device-pointer entries only enqueue work (none of them synchronises with the host): a later call on another stream waits
+ * (on the device) for the workspace of the earlier one. For concurrent streams of work create one context per stream. */
 int mbls_ctx_create(mbls_ctx** out, int device_id);
 void mbls_ctx_destroy(mbls_ctx* ctx);
 /* pre-allocate the HBM workspace for batches of up to max_items items (5 232 bytes per item; avoids allocation in timed regions) */
@@ -201,20 +201,25 @@ int mbls_aggregate_verify(mbls_ctx* ctx, const uint8_t sig[96], const uint8_t* m
  * (aggregate signature, aggregate public key, message); rands[i] = the NONZERO blinding scalars (63 bits in the
  * reference) drawn from the caller's RNG exactly as at src/aggregates.rs:280-287 -- the reference owns that loop, here
  * the caller does. The scalars are the security of the batch check: rands == NULL is MBLS_ERR_ARGUMENT, and a zero
- * scalar (which would drop its set from the check) makes the call fail: result 0 and MBLS_ERR_ARGUMENT from the
- * *_device forms, 0 from the bool form. One bool for the whole batch. */
+ * scalar (which would drop its set from the check) makes the check fail: 0 from the bool form; from the *_device forms
+ * *d_result = 0 and MBLS_ST_BAD_SCALAR in the status word. One bool for the whole batch.
+ * The *_device forms ONLY ENQUEUE (no host synchronisation anywhere): *d_result (one byte of device memory) receives 1 / 0,
+ * *d_status (optional, one device word) the OR of the MBLS_ST_* bits of all sets -- a signature outside G2 (the reference's early
+ * `return false`, src/aggregates.rs:274-276), an undecodable member or a zero scalar give 0 through it. */
 int mbls_verify_multiple_aggregate_signatures(mbls_ctx* ctx, const uint8_t* sigs96, const uint8_t* apks96,
                                               const uint8_t* msgs, uint32_t msg_len, const uint64_t* msg_offsets,
                                               const uint64_t* rands, size_t n);
 int mbls_verify_multiple_aggregate_signatures_device(mbls_ctx* ctx, const uint8_t* d_sigs96, const uint8_t* d_apks96,
                                               const uint8_t* d_msgs, uint32_t msg_len, const uint64_t* d_msg_offsets,
-                                              const uint64_t* d_rands, uint64_t n, int* result, void* stream);
+                                              const uint64_t* d_rands, uint64_t n, uint8_t* d_result, uint32_t* d_status,
+                                              void* stream);
 
 /* The same for sets given by their keys in wire format (BASELINE configs[3]: 2^14 sets x 128 keys): set i owns k keys
  * (or [pk_offsets[i], pk_offsets[i+1])), AggregatePublicKey::aggregate (src/aggregates.rs:29-39) runs on the device first. */
 int mbls_verify_multiple_sets_device(mbls_ctx* ctx, const uint8_t* d_sigs96, const uint8_t* d_pks, int pk_format,
                                      const uint32_t* d_pk_offsets, uint32_t k, const uint8_t* d_msgs, uint32_t msg_len,
-                                     const uint64_t* d_msg_offsets, const uint64_t* d_rands, uint64_t n, int* result, void* stream);
+                                     const uint64_t* d_msg_offsets, const uint64_t* d_rands, uint64_t n, uint8_t* d_result,
+                                     uint32_t* d_status, void* stream);
 
 /* ---- batch helpers used to build inputs and caches on the device ---- */
 /* n x PublicKey::from_bytes[_unchecked] / from_uncompressed_bytes: errs[i] = MBLS_OK / MBLS_ERR_* per key */

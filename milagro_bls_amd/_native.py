@@ -63,8 +63,8 @@ SIGNATURES = {
     "mbls_fast_aggregate_verify_pre_aggregated": (C.c_int, [vp, vp, vp, C.c_size_t, vp]),
     "mbls_aggregate_verify": (C.c_int, [vp, vp, vp, vp, C.c_size_t, vp, C.c_size_t]),
     "mbls_verify_multiple_aggregate_signatures": (C.c_int, [vp, vp, vp, vp, C.c_uint32, vp, vp, C.c_size_t]),
-    "mbls_verify_multiple_aggregate_signatures_device": (C.c_int, [vp, vp, vp, vp, C.c_uint32, vp, vp, C.c_uint64, C.POINTER(C.c_int), vp]),
-    "mbls_verify_multiple_sets_device": (C.c_int, [vp, vp, vp, C.c_int, vp, C.c_uint32, vp, C.c_uint32, vp, vp, C.c_uint64, C.POINTER(C.c_int), vp]),
+    "mbls_verify_multiple_aggregate_signatures_device": (C.c_int, [vp, vp, vp, vp, C.c_uint32, vp, vp, C.c_uint64, vp, vp, vp]),
+    "mbls_verify_multiple_sets_device": (C.c_int, [vp, vp, vp, C.c_int, vp, C.c_uint32, vp, C.c_uint32, vp, vp, C.c_uint64, vp, vp, vp]),
     "mbls_pk_decode_batch": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_uint64, vp, vp]),
     "mbls_pk_compress_batch": (C.c_int, [vp, vp, C.c_uint64, vp, vp]),
     "mbls_sig_check_batch": (C.c_int, [vp, vp, C.c_uint64, vp, vp]),

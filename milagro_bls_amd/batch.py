@@ -135,14 +135,24 @@ def fp_mul_bench(n_lanes, iters, ctx=None):
     return ms.value
 
 
-def verify_multiple_sets_device(d_sigs, d_pks, d_msgs, d_rands, n, k, pk_format=N.PK_COMPRESSED, msg_len=32, stream=None, ctx=None):
+def verify_multiple_sets_device(d_sigs, d_pks, d_msgs, d_rands, n, k, pk_format=N.PK_COMPRESSED, msg_len=32, stream=None, ctx=None, d_result=None, d_status=None):
     """AggregateSignature::verify_multiple_aggregate_signatures (reference src/aggregates.rs:261-316) over n sets given by
-    their k wire-format keys each, everything resident on the device (raw device pointers / ints). One bool."""
+    their k wire-format keys each, everything resident on the device (raw device pointers / ints). The C entry only enqueues: the bool
+    arrives in the device byte d_result (and the OR of the sets' status bits in the device word d_status). Without d_result this wrapper
+    provides both (torch tensors), synchronises and returns the bool."""
     ctx = ctx or _c()
-    res = C.c_int(0)
+    if d_result is not None:
+        ctx.check(N.lib().mbls_verify_multiple_sets_device(ctx.handle, d_sigs, d_pks, pk_format, None, k, d_msgs, msg_len, None, d_rands, n,
+                                                           d_result, d_status, stream))
+        return None
+    import torch
+    res = torch.full((8,), 7, dtype=torch.uint8, device="cuda")
     ctx.check(N.lib().mbls_verify_multiple_sets_device(ctx.handle, d_sigs, d_pks, pk_format, None, k, d_msgs, msg_len, None, d_rands, n,
-                                                       C.byref(res), stream))
-    return bool(res.value)
+                                                       res.data_ptr(), None, stream))
+    torch.cuda.synchronize()
+    v = int(res[0].item())
+    assert v in (0, 1)
+    return bool(v)
 
 
 def multi_fast_aggregate_verify_batch(mctx, sigs, msgs, pks, n, k=None, pk_format=N.PK_COMPRESSED, msg_len=32, pk_offsets=None, msg_offsets=None):

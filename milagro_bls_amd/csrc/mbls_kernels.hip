@@ -203,6 +203,25 @@ __global__ void MBLS_LB k_blind_sig(mbls_ws ws, const uint8_t* sigs96, const uin
     ws_st2(ws, MBLS_SLOT_S, i, s.x); ws_st2(ws, MBLS_SLOT_S + 2, i, s.y); ws_st2(ws, MBLS_SLOT_S + 4, i, s.z);
     if (st) atomicOr(status + i, st);
 }
+// the same with the generated routines (decode inlined like k_sig; subgroup test + windowed [r] sig: g2_blind_routine): no lane-private memory
+__global__ void MBLS_LB k_blind_sig_d(mbls_ws ws, const uint8_t* sigs96, const uint64_t* rands, uint32_t* status, uint64_t n) {
+#if MBLS_DEVICE_ASM && !defined(MBLS_NO_FP2_ASM) && !defined(MBLS_NO_LDS_STATE)
+    __shared__ uint32_t spill[154 * 64];
+    uint64_t i = gid(); if (i >= n) return;
+    uint32_t st = 0;
+    fp2 x, y; bool inf;
+    int e = g2_decode_compressed_t<true>(&x, &y, &inf, sigs96 + 96 * i);
+    if (e) { st |= MBLS_ST_BAD_SIG_ENCODING; inf = true; }
+    if (inf) { x = fp2_zero(); y = fp2_zero(); }
+    ws_st2(ws, MBLS_SLOT_SIG, i, x); ws_st2(ws, MBLS_SLOT_SIG + 2, i, y);
+    const uint64_t r = rands[i];
+    if (r == 0) st |= MBLS_ST_BAD_SCALAR;
+    // an infinite (or undecodable) signature is (0, 0) in the slots: with the scalar 0 every window digit is 0 and the sum stays at infinity
+    const uint32_t fl = g2_blind_d_call(ws, i, (MBLS_LDS uint32_t*)spill, threadIdx.x, inf ? 0 : r);
+    if (!((fl & 1u) | inf)) st |= MBLS_ST_SIG_NOT_IN_G2;
+    if (st) atomicOr(status + i, st);
+#endif
+}
 // f_i = Miller(H_i, P_i) for i < n; lane n (if with_sig) computes Miller(S, -G1) with S read from slot S of item `s_item`.
 // The loop itself is the generated single-pair routine (mbls_pairing.h, miller_loop_single_d).
 __global__ void MBLS_LB k_miller_single(mbls_ws ws, uint64_t n, int with_sig, uint64_t s_item) {
@@ -330,7 +349,7 @@ struct mbls_ctx {
     hipEvent_t ev[MBLS_N_PHASES + 1] = {};
     float phase_ms[MBLS_N_PHASES] = {};
     std::vector<struct mbls_keytable*> tables;     // the key tables created on this context (orphaned when it is destroyed)
-    coop_prog coop[3] = {};            // the cooperative engine's microprograms in HBM (mbls_coop.h): pairing2, vmtail, f12mul
+    coop_prog coop[4] = {};            // the cooperative engine's microprograms in HBM (mbls_coop.h): pairing2, vmtail, f12mul, g2add
     uint32_t* d_coop = nullptr;
     uint64_t coop_max_items = 2048;    // batches up to this size take the one-wave-per-item pairing check (latency path)
     char err[256] = {};
@@ -393,16 +412,17 @@ extern "C" int mbls_ctx_create(mbls_ctx** out, int device_id) {
     ok = ok && hipEventCreateWithFlags(&c->hs_ev, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&c->hs_ev2, hipEventDisableTiming) == hipSuccess &&
          hipEventCreateWithFlags(&c->hs_ev3, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&c->ws_ev, hipEventDisableTiming) == hipSuccess;
     if (ok) {       // the cooperative engine's programs: one upload per context
-        const uint32_t* src[3][3] = {{MBLS_COOP_PAIRING2_STEPS, MBLS_COOP_PAIRING2_ROWS, MBLS_COOP_PAIRING2_CONSTS}, {MBLS_COOP_VMTAIL_STEPS, MBLS_COOP_VMTAIL_ROWS, MBLS_COOP_VMTAIL_CONSTS},
-                                     {MBLS_COOP_F12MUL_STEPS, MBLS_COOP_F12MUL_ROWS, MBLS_COOP_F12MUL_CONSTS}};
-        const size_t cnt[3][3] = {{2 * MBLS_COOP_PAIRING2_NSTEPS, 512 * MBLS_COOP_PAIRING2_NROWS, 15 * MBLS_COOP_PAIRING2_NCONSTS}, {2 * MBLS_COOP_VMTAIL_NSTEPS, 512 * MBLS_COOP_VMTAIL_NROWS, 15 * MBLS_COOP_VMTAIL_NCONSTS},
-                                  {2 * MBLS_COOP_F12MUL_NSTEPS, 512 * MBLS_COOP_F12MUL_NROWS, 15 * MBLS_COOP_F12MUL_NCONSTS}};
-        const uint32_t nconst[3] = {MBLS_COOP_PAIRING2_NCONSTS, MBLS_COOP_VMTAIL_NCONSTS, MBLS_COOP_F12MUL_NCONSTS};
+#define COOP_SRC(P) {MBLS_COOP_##P##_STEPS, MBLS_COOP_##P##_ROWS, MBLS_COOP_##P##_CONSTS}
+#define COOP_CNT(P) {2 * MBLS_COOP_##P##_NSTEPS, 512 * MBLS_COOP_##P##_NROWS, 15 * (MBLS_COOP_##P##_NCONSTS ? MBLS_COOP_##P##_NCONSTS : 1)}
+        const int NP = 4;
+        const uint32_t* src[NP][3] = {COOP_SRC(PAIRING2), COOP_SRC(VMTAIL), COOP_SRC(F12MUL), COOP_SRC(G2ADD)};
+        const size_t cnt[NP][3] = {COOP_CNT(PAIRING2), COOP_CNT(VMTAIL), COOP_CNT(F12MUL), COOP_CNT(G2ADD)};
+        const uint32_t nconst[NP] = {MBLS_COOP_PAIRING2_NCONSTS, MBLS_COOP_VMTAIL_NCONSTS, MBLS_COOP_F12MUL_NCONSTS, MBLS_COOP_G2ADD_NCONSTS};
         size_t total = 0;
-        for (int p = 0; p < 3; p++) for (int a = 0; a < 3; a++) total += (cnt[p][a] + 3) & ~(size_t)3;       // 16-byte aligned pieces (the rows are read as uint4)
+        for (int p = 0; p < NP; p++) for (int a = 0; a < 3; a++) total += (cnt[p][a] + 3) & ~(size_t)3;       // 16-byte aligned pieces (the rows are read as uint4)
         ok = hipMalloc(&c->d_coop, total * 4) == hipSuccess;
         size_t at = 0;
-        for (int p = 0; p < 3 && ok; p++) {
+        for (int p = 0; p < NP && ok; p++) {
             const uint32_t* dp[3];
             for (int a = 0; a < 3 && ok; a++) {
                 dp[a] = c->d_coop + at;
@@ -1056,19 +1076,37 @@ extern "C" int mbls_fast_aggregate_verify_pre_aggregated(mbls_ctx* c, const uint
     return r;
 }
 
-// n-pairing product check shared by aggregate_verify and verify_multiple. On entry the workspace holds, for
-// items 0..n-1, H_i (slot H) and P_i (slot APK); the (S, -G1) pair takes S from slot S of item 0.
-static int npairing_finish(mbls_ctx* c, uint64_t n, hipStream_t s, int* result) {
+// Product / sum trees of the n-pairing paths: m values in slot F (slot S) of items 0..m-1 -> item 0. A level with many pairs is one lane
+// per product (k_f12_tree / k_g2_tree: the chip is full of them); below MBLS_COOP_TREE_PAIRS pairs a level is one WAVE per product
+// (mbls_coop.h, programs f12mul / g2add: 14 / 28 steps instead of a 25 k-instruction dependent chain).
+#define MBLS_COOP_TREE_PAIRS 2048
+static void f12_tree(mbls_ctx* c, mbls_ws ws, uint64_t m, hipStream_t s) {
+    while (m > 1) {
+        const uint64_t half = (m + 1) / 2, pairs = m - half;
+        if (pairs > MBLS_COOP_TREE_PAIRS) hipLaunchKernelGGL(k_f12_tree, dim3(nblk(half)), dim3(WG), 0, s, ws, m, half);
+        else hipLaunchKernelGGL(k_coop, dim3((unsigned)pairs), dim3(64), 0, s, c->coop[2], ws, (uint64_t)0, (uint64_t)1, half, pairs, (uint32_t*)nullptr, (uint8_t*)nullptr, COOP_RES_ITEM);
+        m = half;
+    }
+}
+static void g2_tree(mbls_ctx* c, mbls_ws ws, uint64_t m, hipStream_t s) {
+    while (m > 1) {
+        const uint64_t half = (m + 1) / 2, pairs = m - half;
+        if (pairs > MBLS_COOP_TREE_PAIRS) hipLaunchKernelGGL(k_g2_tree, dim3(nblk(half)), dim3(WG), 0, s, ws, m, half);
+        else hipLaunchKernelGGL(k_coop, dim3((unsigned)pairs), dim3(64), 0, s, c->coop[3], ws, (uint64_t)0, (uint64_t)1, half, pairs, (uint32_t*)nullptr, (uint8_t*)nullptr, COOP_RES_ITEM);
+        m = half;
+    }
+}
+// n-pairing product check shared by aggregate_verify and verify_multiple (reference src/aggregates.rs:158-169, :307-315). On entry the
+// workspace holds, for items 0..n-1, H_i (slot H) and P_i (slot APK); S (the (S, -G1) pair's G2 point) in slot S of item 0; the OR of
+// every status word in d_scalar[0]. Everything is enqueued on s: one Miller loop per lane, the product tree, and ONE wave for the tail --
+// the Miller loop of (S, -G1), the product, the single final exponentiation, the comparison and the status bits (program vmtail).
+static int npairing_finish(mbls_ctx* c, uint64_t n, hipStream_t s, uint8_t* d_result) {
     mbls_ws ws; ws.w = c->d_w; ws.stride = c->cap;
-    hipLaunchKernelGGL(k_miller_single, dim3(nblk(n + 1)), dim3(WG), 0, s, ws, n, 1, (uint64_t)0);
-    uint64_t m = n + 1;
-    while (m > 1) { uint64_t half = (m + 1) / 2; hipLaunchKernelGGL(k_f12_tree, dim3(nblk(half)), dim3(WG), 0, s, ws, m, half); m = half; }
-    HIPCHK(c, hipMemsetAsync(c->d_scalar + 8, 0, 4, s));               // status word of the single final exponentiation
-    hipLaunchKernelGGL(k_final, dim3(1), dim3(WG), 0, s, ws, c->d_scalar + 8, c->d_results, (uint64_t)1);
-    uint8_t r = 0;
-    HIPCHK(c, hipStreamSynchronize(s)); c->ws_pending = false;
-    HIPCHK(c, hipMemcpy(&r, c->d_results, 1, hipMemcpyDeviceToHost));
-    *result = r; return MBLS_OK;
+    hipLaunchKernelGGL(k_miller_single, dim3(nblk(n)), dim3(WG), 0, s, ws, n, 0, (uint64_t)0);
+    f12_tree(c, ws, n, s);
+    hipLaunchKernelGGL(k_coop, dim3(1), dim3(64), 0, s, c->coop[1], ws, (uint64_t)0, (uint64_t)1, (uint64_t)0, (uint64_t)1, c->d_scalar, d_result, COOP_RES_BATCH);
+    HIPCHK(c, hipGetLastError());
+    return MBLS_OK;
 }
 extern "C" int mbls_aggregate_verify(mbls_ctx* c, const uint8_t sig[96], const uint8_t* msgs, const size_t* msg_lens, size_t n_msgs,
                                      const uint8_t* pks96, size_t n_pks) {
@@ -1100,28 +1138,35 @@ extern "C" int mbls_aggregate_verify(mbls_ctx* c, const uint8_t sig[96], const u
     hipLaunchKernelGGL(k_blind_g1, dim3(nblk(n)), dim3(WG), 0, s, ws, dp.as<uint8_t>(), (const uint64_t*)nullptr, c->d_status, n);   // r_i = 1: no blinding in AggregateVerify
     hipLaunchKernelGGL(k_status_or, dim3(nblk(n)), dim3(WG), 0, s, c->d_status, n, c->d_scalar);
     hipLaunchKernelGGL(k_hash, dim3(nblk(n)), dim3(WG), 0, s, ws, dm.as<uint8_t>(), 0u, (const uint64_t*)doff.as<uint64_t>(), c->d_status, n);
-    uint32_t st = 0;
-    if (hipStreamSynchronize(s) != hipSuccess || hipMemcpy(&st, c->d_scalar, 4, hipMemcpyDeviceToHost) != hipSuccess) return 0;
-    if (st & (MBLS_ST_BAD_SIG_ENCODING | MBLS_ST_SIG_NOT_IN_G2 | MBLS_ST_BAD_PK_ENCODING)) { c->ws_pending = false; return 0; }   // reference src/aggregates.rs:137-139
-    if (npairing_finish(c, n, s, &result)) return 0;
+    // a signature outside G2 or an undecodable member makes the tail answer false (reference src/aggregates.rs:137-139): no host round trip
+    if (npairing_finish(c, n, s, c->d_results)) return 0;
+    uint8_t r = 0;
+    if (hipStreamSynchronize(s) != hipSuccess) return 0;
+    c->ws_pending = false;
+    if (hipMemcpy(&r, c->d_results, 1, hipMemcpyDeviceToHost) != hipSuccess) return 0;
+    result = r;
     return result;
 }
 static int verify_multiple_impl(mbls_ctx* c, const uint8_t* d_sigs, const uint8_t* d_apks, const uint8_t* d_pks, int pk_format,
-        const uint32_t* d_pk_offsets, uint32_t k, const uint8_t* d_msgs, uint32_t msg_len, const uint64_t* d_moff, const uint64_t* d_rands, uint64_t n, int* result, void* stream) {
-    if (!c || !result) return MBLS_ERR_ARGUMENT;
+        const uint32_t* d_pk_offsets, uint32_t k, const uint8_t* d_msgs, uint32_t msg_len, const uint64_t* d_moff, const uint64_t* d_rands, uint64_t n,
+        uint8_t* d_result, uint32_t* d_status_or, void* stream) {
+    if (!c || !d_result) return MBLS_ERR_ARGUMENT;
     mbls_lock lk(c->mu);
-    *result = 0;
-    if (n == 0) { *result = 1; return MBLS_OK; }     // empty iterator: S' = infinity, product of no pairings = 1 -> e(inf, -G1) = 1 -> true
-    if (!d_rands) ARGFAIL(c, "verify_multiple without blinding scalars is forgeable: rands must not be NULL");
-    if (!d_sigs || (!d_msgs && msg_len && !d_moff)) ARGFAIL(c, "null buffer");
     hipStream_t s = (hipStream_t)stream;
     HIPCHK(c, hipSetDevice(c->device));
+    if (n == 0) {     // empty iterator: S' = infinity, product of no pairings = 1 -> e(inf, -G1) = 1 -> true
+        HIPCHK(c, hipMemsetAsync(d_result, 1, 1, s));
+        if (d_status_or) HIPCHK(c, hipMemsetAsync(d_status_or, 0, 4, s));
+        return MBLS_OK;
+    }
+    if (!d_rands) ARGFAIL(c, "verify_multiple without blinding scalars is forgeable: rands must not be NULL");
+    if (!d_sigs || (!d_msgs && msg_len && !d_moff)) ARGFAIL(c, "null buffer");
     int rc = mbls_ctx_reserve(c, n); if (rc) return rc;
     mbls_ws ws; ws.w = c->d_w; ws.stride = c->cap;
     rc = ws_acquire(c, s); if (rc) return rc;
     HIPCHK(c, hipMemsetAsync(c->d_scalar, 0, 64, s));
     HIPCHK(c, hipMemsetAsync(c->d_status, 0, 4 * n, s));
-    // Three independent chains: keys (aggregate, [r]apk), signatures (decode, subgroup check, [r]sig, sum), messages (hash). Below
+    // Three independent chains: keys (aggregate, [r]apk), signatures (decode, subgroup check, [r]sig, sum tree), messages (hash). Below
     // 2^14 sets each of them leaves most SIMDs idle, so they run side by side on the context's streams and join before the
     // Miller loops; larger batches fill the chip by themselves and stay on the caller's stream.
     const bool fork = n <= 16384;
@@ -1130,33 +1175,33 @@ static int verify_multiple_impl(mbls_ctx* c, const uint8_t* d_sigs, const uint8_
     if (!d_apks)    // sets given by their wire-format keys: AggregatePublicKey::aggregate on the device first (src/aggregates.rs:29-39)
         launch_aggregate(ws, d_pks, d_pk_offsets, k, pk_format, MBLS_MODE_VERIFY, c->d_status, n, s);
     hipLaunchKernelGGL(k_blind_g1, dim3(nblk(n)), dim3(WG), 0, s, ws, d_apks, d_rands, c->d_status, n);
-    hipLaunchKernelGGL(k_blind_sig, dim3(nblk(n)), dim3(WG), 0, s_sig, ws, d_sigs, d_rands, c->d_status, n);
-    { uint64_t m = n; while (m > 1) { uint64_t half = (m + 1) / 2; hipLaunchKernelGGL(k_g2_tree, dim3(nblk(half)), dim3(WG), 0, s_sig, ws, m, half); m = half; } }
+    hipLaunchKernelGGL(k_blind_sig_d, dim3(nblk(n)), dim3(WG), 0, s_sig, ws, d_sigs, d_rands, c->d_status, n);
+    g2_tree(c, ws, n, s_sig);
     hipLaunchKernelGGL(k_hash, dim3(nblk(n)), dim3(WG), 0, s_msg, ws, d_msgs, msg_len, d_moff, c->d_status, n);
     if (fork) {
         HIPCHK(c, hipEventRecord(c->hs_ev2, s_sig)); HIPCHK(c, hipEventRecord(c->hs_ev3, s_msg));
         HIPCHK(c, hipStreamWaitEvent(s, c->hs_ev2, 0)); HIPCHK(c, hipStreamWaitEvent(s, c->hs_ev3, 0));
     }
     hipLaunchKernelGGL(k_status_or, dim3(nblk(n)), dim3(WG), 0, s, c->d_status, n, c->d_scalar);
-    uint32_t st = 0;
-    HIPCHK(c, hipStreamSynchronize(s));
-    HIPCHK(c, hipMemcpy(&st, c->d_scalar, 4, hipMemcpyDeviceToHost));
-    if (st & MBLS_ST_BAD_SCALAR) { c->ws_pending = false; ARGFAIL(c, "a blinding scalar is zero"); }
-    if (st & (MBLS_ST_BAD_SIG_ENCODING | MBLS_ST_SIG_NOT_IN_G2 | MBLS_ST_BAD_PK_ENCODING | MBLS_ST_BAD_MSG_RANGE)) { c->ws_pending = false; *result = 0; return MBLS_OK; }   // reference src/aggregates.rs:274-276
-    return npairing_finish(c, n, s, result);
+    // a set whose signature is outside G2 (reference src/aggregates.rs:274-276), an undecodable member or a zero scalar makes the tail
+    // answer false: the status bits are folded in on the device, the call only enqueues
+    rc = npairing_finish(c, n, s, d_result); if (rc) return rc;
+    if (d_status_or) HIPCHK(c, hipMemcpyAsync(d_status_or, c->d_scalar, 4, hipMemcpyDeviceToDevice, s));
+    return ws_release(c, s);
 }
 extern "C" int mbls_verify_multiple_aggregate_signatures_device(mbls_ctx* c, const uint8_t* d_sigs, const uint8_t* d_apks, const uint8_t* d_msgs,
-        uint32_t msg_len, const uint64_t* d_moff, const uint64_t* d_rands, uint64_t n, int* result, void* stream) {
+        uint32_t msg_len, const uint64_t* d_moff, const uint64_t* d_rands, uint64_t n, uint8_t* d_result, uint32_t* d_status_or, void* stream) {
     if (!c) return MBLS_ERR_ARGUMENT;
     if (n && !d_apks) return MBLS_ERR_ARGUMENT;
-    return verify_multiple_impl(c, d_sigs, d_apks, nullptr, 0, nullptr, 0, d_msgs, msg_len, d_moff, d_rands, n, result, stream);
+    return verify_multiple_impl(c, d_sigs, d_apks, nullptr, 0, nullptr, 0, d_msgs, msg_len, d_moff, d_rands, n, d_result, d_status_or, stream);
 }
 extern "C" int mbls_verify_multiple_sets_device(mbls_ctx* c, const uint8_t* d_sigs, const uint8_t* d_pks, int pk_format, const uint32_t* d_pk_offsets,
-        uint32_t k, const uint8_t* d_msgs, uint32_t msg_len, const uint64_t* d_moff, const uint64_t* d_rands, uint64_t n, int* result, void* stream) {
+        uint32_t k, const uint8_t* d_msgs, uint32_t msg_len, const uint64_t* d_moff, const uint64_t* d_rands, uint64_t n, uint8_t* d_result,
+        uint32_t* d_status_or, void* stream) {
     if (!c) return MBLS_ERR_ARGUMENT;
     if (pk_format != MBLS_PK_COMPRESSED && pk_format != MBLS_PK_UNCOMPRESSED) return MBLS_ERR_ARGUMENT;
     if (n && !d_pks) return MBLS_ERR_ARGUMENT;
-    return verify_multiple_impl(c, d_sigs, nullptr, d_pks, pk_format, d_pk_offsets, k, d_msgs, msg_len, d_moff, d_rands, n, result, stream);
+    return verify_multiple_impl(c, d_sigs, nullptr, d_pks, pk_format, d_pk_offsets, k, d_msgs, msg_len, d_moff, d_rands, n, d_result, d_status_or, stream);
 }
 extern "C" int mbls_verify_multiple_aggregate_signatures(mbls_ctx* c, const uint8_t* sigs96, const uint8_t* apks96, const uint8_t* msgs,
         uint32_t msg_len, const uint64_t* moff, const uint64_t* rands, size_t n) {
@@ -1168,13 +1213,16 @@ extern "C" int mbls_verify_multiple_aggregate_signatures(mbls_ctx* c, const uint
     if (!sigs96 || !apks96 || !rands || (!msgs && msg_total)) return 0;
     mbls_lock lk(c->mu);
     if (hipSetDevice(c->device) != hipSuccess) return 0;
-    sbuf ds(c, 0), da(c, 1), dm(c, 2), dr(c, 3), dmo(c, 6);
+    sbuf ds(c, 0), da(c, 1), dm(c, 2), dr(c, 3), dmo(c, 6), dres(c, 4);
     if (ds.up(sigs96, 96 * n) != hipSuccess || da.up(apks96, 96 * n) != hipSuccess || dm.up(msgs ? msgs + msg_first : nullptr, msg_total) != hipSuccess ||
-        dr.up(rands, 8 * n) != hipSuccess || (moff && dmo.up(moff, 8 * (n + 1)) != hipSuccess)) return 0;
-    int result = 0;
+        dr.up(rands, 8 * n) != hipSuccess || (moff && dmo.up(moff, 8 * (n + 1)) != hipSuccess) || dres.alloc(8) != hipSuccess) return 0;
     if (mbls_verify_multiple_aggregate_signatures_device(c, ds.as<uint8_t>(), da.as<uint8_t>(), dm.as<uint8_t>() - msg_first, msg_len,
-                                                         moff ? dmo.as<uint64_t>() : nullptr, dr.as<uint64_t>(), n, &result, c->hs_a)) return 0;
-    return result;
+                                                         moff ? dmo.as<uint64_t>() : nullptr, dr.as<uint64_t>(), n, dres.as<uint8_t>(), nullptr, c->hs_a)) return 0;
+    uint8_t r = 0;
+    if (hipStreamSynchronize(c->hs_a) != hipSuccess) return 0;
+    c->ws_pending = false;
+    if (dres.down(&r, 1) != hipSuccess) return 0;
+    return r;
 }
 
 // ------------------------------------------------------------------------------------------------ several GPUs behind one handle

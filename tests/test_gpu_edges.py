@@ -131,12 +131,19 @@ def test_verify_multiple_scalar_requirements(N):
     dev = torch.device("cuda:0")
     t = lambda b: torch.frombuffer(bytearray(b), dtype=torch.uint8).to(dev)
     d_s, d_a, d_m = t(b"".join(sigs)), t(b"".join(pks)), t(b"".join(msgs))
-    res = C.c_int(7)
-    rc = N.lib().mbls_verify_multiple_aggregate_signatures_device(ctx.handle, d_s.data_ptr(), d_a.data_ptr(), d_m.data_ptr(), 32, None, None, 3, C.byref(res), None)
-    assert rc == N.ERR_ARGUMENT and res.value == 0
+    d_res = torch.full((8,), 7, dtype=torch.uint8, device=dev); d_st = torch.zeros(1, dtype=torch.int32, device=dev)
+    rc = N.lib().mbls_verify_multiple_aggregate_signatures_device(ctx.handle, d_s.data_ptr(), d_a.data_ptr(), d_m.data_ptr(), 32, None, None, 3, d_res.data_ptr(), d_st.data_ptr(), None)
+    assert rc == N.ERR_ARGUMENT                                  # no scalars at all: refused on the host
     d_r = torch.tensor([rands[0], 0, rands[2]], dtype=torch.int64, device=dev)
-    rc = N.lib().mbls_verify_multiple_aggregate_signatures_device(ctx.handle, d_s.data_ptr(), d_a.data_ptr(), d_m.data_ptr(), 32, None, d_r.data_ptr(), 3, C.byref(res), None)
-    assert rc == N.ERR_ARGUMENT and res.value == 0
+    rc = N.lib().mbls_verify_multiple_aggregate_signatures_device(ctx.handle, d_s.data_ptr(), d_a.data_ptr(), d_m.data_ptr(), 32, None, d_r.data_ptr(), 3, d_res.data_ptr(), d_st.data_ptr(), None)
+    torch.cuda.synchronize()
+    assert rc == 0 and int(d_res[0].item()) == 0 and (int(d_st[0].item()) & 0x80)      # a zero scalar: the device entry only enqueues; result 0 + MBLS_ST_BAD_SCALAR
+    rr0 = (C.c_uint64 * 3)(rands[0], 0, rands[2])
+    assert N.lib().mbls_verify_multiple_aggregate_signatures(ctx.handle, N.cbuf(b"".join(sigs)), N.cbuf(b"".join(pks)), N.cbuf(b"".join(msgs)), 32, None, rr0, 3) == 0
+    d_r = torch.tensor(rands, dtype=torch.int64, device=dev)
+    rc = N.lib().mbls_verify_multiple_aggregate_signatures_device(ctx.handle, d_s.data_ptr(), d_a.data_ptr(), d_m.data_ptr(), 32, None, d_r.data_ptr(), 3, d_res.data_ptr(), d_st.data_ptr(), None)
+    torch.cuda.synchronize()
+    assert rc == 0 and int(d_res[0].item()) == 1 and int(d_st[0].item()) & ~0x20 == 0
     # forged pair (sig1 + D, sig2 - D): passes an unblinded check, must fail the blinded one
     D = orc.sign(b"d" * 32, 12345)
     f1 = orc.g2_compress(orc.g2_add(orc.g2_from_compressed(sigs[0])[1], D))

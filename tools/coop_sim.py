@@ -129,9 +129,10 @@ def unpack_lane(w):
 
 
 class Sim:
-    def __init__(self, comp, ws):
-        """comp: gen_coop.compile_program output; ws: {workspace slot: integer (canonical 2^384-domain words)}"""
-        self.comp, self.ws = comp, dict(ws)
+    def __init__(self, comp, ws, partner=None):
+        """comp: gen_coop.compile_program output; ws: {workspace slot: integer (canonical 2^384-domain words)} of the wave's item;
+        partner: the same for the item partner_step further on"""
+        self.comp, self.ws, self.partner = comp, dict(ws), dict(partner or {})
         self.S = [[0] * 14 for _ in range(comp["n_slots"] + 1)]
         for slot, v in comp["consts"].items():
             self.S[slot] = G.T.digits_of(v)
@@ -187,7 +188,8 @@ class Sim:
                     else: raise ValueError(fop)
                     fwrites.append((fl, v))
                 elif kind == G.K_LOADW:
-                    writes.append((dst, reduce_digits(digits_shl8(self.ws[wslot]))))
+                    src = self.partner if wslot & 0x10000 else self.ws
+                    writes.append((dst, reduce_digits(digits_shl8(src[wslot & 0xFFFF]))))
                 elif kind == G.K_STOREW:
                     self.ws[wslot] = value(canonical(self.S[idx[0]]))
                 elif kind == G.K_RES:

@@ -156,9 +156,11 @@ class Block(T.Prog):
                 terms[i] = (big, sg * k_)
                 if r_:
                     terms.append((nd, sg * r_))
-        while len(terms) > 2 * MAXT:                         # more than a LIN step takes: partial sums first
-            part = LC(dict(terms[:2 * MAXT]))
-            terms = list(self.materialise(part, True).t.items()) + terms[2 * MAXT:]
+        while len(terms) > 2 * MAXT:                         # more than a LIN step takes: partial sums first, side by side (a tree, not a chain)
+            groups = [terms[i:i + 2 * MAXT] for i in range(0, len(terms), 2 * MAXT)]
+            terms = []
+            for g in groups:
+                terms += list(self.materialise(LC(dict(g)), True).t.items()) if len(g) > 1 else g
         lc = LC(dict(terms))
         B = lc.bound()
         # a LIN step sums in 64 bits, carries, estimates the quotient from the true top digit and subtracts: any digit bound below 2^50 works
@@ -275,9 +277,10 @@ class Block(T.Prog):
         node.pin = self.m.state_slot(name)
         self.outs.append((name, node))
 
-    def loadw(self, name, ws_slot):
-        """state[name] <- the 12 words of workspace slot ws_slot of this wave's item (2^384 domain) as 2^392-domain digits, reduced"""
-        n = self._node("loadw", REDUCED, aux=ws_slot)
+    def loadw(self, name, ws_slot, partner=False):
+        """state[name] <- the 12 words of workspace slot ws_slot of this wave's item (partner: of the item partner_step further on)
+        (2^384 domain) as 2^392-domain digits, reduced"""
+        n = self._node("loadw", REDUCED, aux=ws_slot | (0x10000 if partner else 0))
         n.pin = self.m.state_slot(name)
         self.items.append(n)
         self.in_nodes[name] = n
@@ -591,25 +594,25 @@ def pt_out(b, prefix, pt):
         b.out("%s%d" % (prefix, i), v)
 
 
-def masked_line(b, c0, c2, c3, skip):
-    """a pair with a member at infinity contributes 1: its line is replaced by (1, 0, 0)"""
+def masked_p(b, m, skip, npx, py, pz3, prefix):
+    """A pair with a member at infinity contributes 1: its lines must be (1, 0, 0). No selection inside the loop: the G1 argument is
+    masked ONCE -- (-px, py, pz3) <- 0 and `one` <- 1 on a skipped pair -- and every line is (c0 pz3 + one, c2 (-px), c3 py)."""
     one, zero = b.const(ONE_D), LC()
-    return ((b.sel(skip, c0[0], one), b.sel(skip, c0[1], zero)), (b.sel(skip, c2[0], zero), b.sel(skip, c2[1], zero)),
-            (b.sel(skip, c3[0], zero), b.sel(skip, c3[1], zero)))
+    b.out(prefix + "npx", b.sel(skip, npx, zero)); b.out(prefix + "py", b.sel(skip, py, zero))
+    b.out(prefix + "pz3", b.sel(skip, pz3, zero)); b.out(prefix + "one", b.sel(skip, zero, one))
 
 
 def dbl_step(b, Tn, pxyz):
     """T <- 2T and the line through it (formulas of prog_miller_dbl_d in tools/gen_tower_d.py / miller_dbl_step in mbls_pairing.h);
-    pxyz = (-px, py, pz3 or None): the G1 argument as an Fp value each"""
+    pxyz = (-px, py, pz3, one): the masked G1 argument (masked_p)"""
     Tx, Ty, Tz = Tn
     B = b.sqr2(Ty); C = b.sqr2(Tz)
     E = b.mul12_2(b.mul_xi2(C))
     F = b.mul3_2(E)
     X2 = b.sqr2(Tx)
     YZ2 = b.sub2(b.sub2(b.sqr2(b.add2(Ty, Tz)), B), C)
-    c0 = b.sub2(B, E)
-    if pxyz[2] is not None:
-        c0 = b.mulfp2(c0, pxyz[2])
+    c0 = b.mulfp2(b.sub2(B, E), pxyz[2])
+    c0 = (b.add(c0[0], pxyz[3]), c0[1])
     c2 = b.mulfp2(b.mul3_2(X2), pxyz[0])
     c3 = b.mulfp2(YZ2, pxyz[1])
     x3 = b.dbl2(b.mul2(b.mul2(Tx, Ty), b.sub2(B, F)))
@@ -628,9 +631,8 @@ def add_step(b, Tn, Q, pxyz):
         y1z2, x1z2, z1z2 = b.mul2(Ty, Qz), b.mul2(Tx, Qz), b.mul2(Tz, Qz)
     u = b.sub2(b.mul2(Qy, Tz), y1z2)
     v = b.sub2(b.mul2(Qx, Tz), x1z2)
-    c0 = b.sub2(b.mul2(u, Qx), b.mul2(v, Qy))
-    if pxyz[2] is not None:
-        c0 = b.mulfp2(c0, pxyz[2])
+    c0 = b.mulfp2(b.sub2(b.mul2(u, Qx), b.mul2(v, Qy)), pxyz[2])
+    c0 = (b.add(c0[0], pxyz[3]), c0[1])
     uq, vq = (u, v) if Qz is None else (b.mul2(u, Qz), b.mul2(v, Qz))
     c2 = b.mulfp2(uq, pxyz[0])
     c3 = b.mulfp2(vq, pxyz[1])
@@ -645,19 +647,16 @@ def add_step(b, Tn, Q, pxyz):
 
 def build_miller(m, pairs, prefix=""):
     """blocks `dbl` and `add` of the Miller loop over the listed pairs. Pair descriptor: dict(T=state prefix of the running point,
-    Q=state prefix of the fixed point, affine=bool, P=(name -px, name py, name pz3 | None) or constants, skip=flag)"""
+    Q=state prefix of the fixed point, affine=bool, P=state prefix of the masked G1 argument (masked_p))"""
     def parg(b, pr):
-        out = []
-        for x in pr["P"]:
-            out.append(None if x is None else (b.const(x) if isinstance(x, int) else b.inp(x)))
-        return out
+        return [b.inp(pr["P"] + x) for x in ("npx", "py", "pz3", "one")]
     b = m.block(prefix + "dbl")
     f = b.sqr12(ld12(b))
     lines = []
     for pr in pairs:
         Tn, line = dbl_step(b, pt_in(b, pr["T"]), parg(b, pr))
         pt_out(b, pr["T"], Tn)
-        lines.append(masked_line(b, *line, pr["skip"]))
+        lines.append(line)
     if len(lines) == 2:
         L0, L1 = T.mul_lines(b, lines[0], lines[1])
         f = T.mul12_by_lines(b, f, L0, L1)
@@ -671,7 +670,7 @@ def build_miller(m, pairs, prefix=""):
         Q = [(q[0], q[1]), (q[2], q[3]), None if pr["affine"] else (q[4], q[5])]
         Tn, line = add_step(b, pt_in(b, pr["T"]), Q, parg(b, pr))
         pt_out(b, pr["T"], Tn)
-        f = b.mul12_line(f, *masked_line(b, *line, pr["skip"]))
+        f = b.mul12_line(f, *line)
     st12(b, f)
 
 
@@ -795,11 +794,11 @@ def prog_pairing2():
     for i, v in enumerate([sig[0], sig[1], sig[2], sig[3], one, LC()]):      # T0 = (x, y, 1)
         b.out("t0_%d" % i, v)
     zz = b.mul(apk[2], apk[2])
-    b.out("npx", b.neg(b.mul(apk[0], apk[2]))); b.out("py", apk[1]); b.out("pz3", b.mul(zz, apk[2]))
+    masked_p(b, m, skip0, b.const(NPX0_D), b.const(PY0_D), one, "p0")
+    masked_p(b, m, skip1, b.neg(b.mul(apk[0], apk[2])), apk[1], b.mul(zz, apk[2]), "p1")
     for i in range(12):
         b.out("f%d" % i, one if i == 0 else LC())
-    pairs = [dict(T="t0_", Q="q0_", affine=True, P=(NPX0_D, PY0_D, None), skip=skip0),
-             dict(T="t1_", Q="q1_", affine=False, P=("npx", "py", "pz3"), skip=skip1)]
+    pairs = [dict(T="t0_", Q="q0_", affine=True, P="p0"), dict(T="t1_", Q="q1_", affine=False, P="p1")]
     build_miller(m, pairs)
     build_final_exp(m)
     ok = m.flag("ok")
@@ -824,9 +823,10 @@ def prog_vmtail():
     for i, v in enumerate([qx[0], qx[1], Sy[0], Sy[1], qz[0], qz[1]]):
         b.out("q%d" % i, v); b.out("t%d" % i, v)
     one = b.const(ONE_D)
+    masked_p(b, m, skip, b.const(NPX0_D), b.const(PY0_D), one, "p")
     for i in range(12):
         b.out("f%d" % i, one if i == 0 else LC())
-    build_miller(m, [dict(T="t", Q="q", affine=False, P=(NPX0_D, PY0_D, None), skip=skip)])
+    build_miller(m, [dict(T="t", Q="q", affine=False, P="p")])
     b = m.block("join")                                           # f <- F * conj(f)
     st12(b, T.mul12(b, ld12(b, "g"), ld12(b), conj_b=True))
     build_final_exp(m)
@@ -847,7 +847,7 @@ def prog_f12tree():
         b.loadw("f%d" % i, WS_F + i)
     b = m.block("loadg")
     for i in range(12):
-        b.loadw("g%d" % i, WS_F + i)
+        b.loadw("g%d" % i, WS_F + i, partner=True)
     b = m.block("mul")
     st12(b, T.mul12(b, ld12(b), ld12(b, "g")))
     b = m.block("store")
@@ -858,7 +858,62 @@ def prog_f12tree():
     return m
 
 
-PROGRAMS = {"pairing2": prog_pairing2, "vmtail": prog_vmtail, "f12mul": prog_f12tree}
+def g2_dbl_formula(b, X, Y, Z):
+    """Jacobian doubling on the twist (g2_dbl in mbls_curve.h / prog_g2_dbl_d in gen_tower_d.py; valid for every point incl. infinity)"""
+    A = b.sqr2(X); B = b.sqr2(Y); C = b.sqr2(B)
+    D = b.dbl2(b.sub2(b.sub2(b.sqr2(b.add2(X, B)), A), C))
+    E = b.mul3_2(A); F = b.sqr2(E)
+    Z3 = b.dbl2(b.mul2(Y, Z))
+    X3 = b.sub2(F, b.dbl2(D))
+    Y3 = b.sub2(b.mul2(E, b.sub2(D, X3)), b.mul8_2(C))
+    return [X3, Y3, Z3]
+
+
+def g2_add_formula(b, m, A, Q):
+    """A + Q in Jacobian coordinates with g2_add's case handling (mbls_curve.h; prog_g2_add in gen_tower_d.py): an operand at infinity
+    gives the other one, equal operands the doubling, opposite operands Z = 0 by the formulas"""
+    fh, fr, fi1, fi2, tmp = m.flag("h0"), m.flag("r0"), m.flag("inf1"), m.flag("inf2"), m.flag("tmp")
+    z1z1, z2z2 = b.sqr2(A[2]), b.sqr2(Q[2])
+    u1, u2 = b.mul2(A[0], z2z2), b.mul2(Q[0], z1z1)
+    s1 = b.mul2(b.mul2(A[1], Q[2]), z2z2)
+    s2 = b.mul2(b.mul2(Q[1], A[2]), z1z1)
+    h = b.sub2(u2, u1)
+    rr = b.dbl2(b.sub2(s2, s1))
+    b.iszero2(h, fh, tmp); b.iszero2(rr, fr, tmp)
+    b.iszero2(A[2], fi1, tmp); b.iszero2(Q[2], fi2, tmp)
+    i4 = b.sqr2(b.dbl2(h))
+    j, v = b.mul2(h, i4), b.mul2(u1, i4)
+    X3 = b.sub2(b.sub2(b.sqr2(rr), j), b.dbl2(v))
+    Y3 = b.sub2(b.mul2(rr, b.sub2(v, X3)), b.dbl2(b.mul2(s1, j)))
+    Z3 = b.mul2(b.sub2(b.sub2(b.sqr2(b.add2(A[2], Q[2])), z1z1), z2z2), h)
+    D = g2_dbl_formula(b, *A)
+    feq = m.flag("eq")
+    b.flagop(F_AND, feq, fh, fr); b.flagop(F_ANDN, feq, feq, fi1); b.flagop(F_ANDN, feq, feq, fi2)
+    out = [b.sel2(feq, o, d) for o, d in zip((X3, Y3, Z3), D)]
+    out = [b.sel2(fi1, o, q) for o, q in zip(out, Q)]
+    out = [b.sel2(fi2, o, a) for o, a in zip(out, A)]
+    return out
+
+
+def prog_g2add():
+    """slots 25..30 (Jacobian G2 accumulator of the n-pairing paths) of this wave's item += the same slots of its partner item: one level
+    of the sum tree of verify_multiple's sum r_i sig_i (reference src/aggregates.rs:303) on one wave"""
+    m = Machine("g2add")
+    b = m.block("load")
+    for i in range(6):
+        b.loadw("a%d" % i, WS_S + i)
+        b.loadw("q%d" % i, WS_S + i, partner=True)
+    b = m.block("add")
+    out = g2_add_formula(b, m, pt_in(b, "a"), pt_in(b, "q"))
+    pt_out(b, "a", out)
+    b = m.block("store")
+    for i, v in enumerate([x for c in pt_in(b, "a") for x in c]):
+        b.storew(v, WS_S + i)
+    m.run("load"); m.run("add"); m.run("store")
+    return m
+
+
+PROGRAMS = {"pairing2": prog_pairing2, "vmtail": prog_vmtail, "f12mul": prog_f12tree, "g2add": prog_g2add}
 
 
 def emit_c(name, comp):

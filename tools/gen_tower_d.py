@@ -188,6 +188,9 @@ class Prog:
     def mask_xor(self, dst, a, b):
         self.ops.append(("mask_xor", [], [], (dst, a, b)))
 
+    def mask_or(self, dst, a, b):
+        self.ops.append(("mask_or", [], [], (dst, a, b)))
+
     def neg2(self, a): return (self.neg(a[0]), self.neg(a[1]))
     def conj2(self, a): return (a[0], self.neg(a[1]))
     def neg6(self, a): return [self.neg2(c) for c in a]
@@ -287,6 +290,7 @@ GBASE, GSTRIDE, GADDR, GT0, GT1 = "s[68:69]", "s70", "s[74:75]", "s76", "s77"   
 
 
 GKOFF = "s71"                       # run-time byte offset added to the address of the slots of kind 'gk' (one record of several)
+VOFF = "v250"                       # slots of kind 'gv': the record is chosen PER LANE -- this register replaces LADDR as the lane offset
 
 
 def seq_gaddr(slot, koff=False):
@@ -307,12 +311,12 @@ def seq_gstore(reg, slot, koff=False):
     return L
 
 
-def seq_gload(reg, slot, aform=True, koff=False):
+def seq_gload(reg, slot, aform=True, koff=False, lane=None):
     """12 words of workspace slot `slot` (limb-major: word j of slot s at base + (12 s + j) * stride) into reg(2)..reg(13), then 14
     digits into reg(0)..reg(13): of words * 2^8 (aform: a 2^384-domain value enters the 2^392 domain) or of the words themselves"""
     L = seq_gaddr(slot, koff)
     for j in range(12):
-        L.append("global_load_dword %s, %s, %s" % (reg(j + 2), LADDR, GADDR))
+        L.append("global_load_dword %s, %s, %s" % (reg(j + 2), lane or LADDR, GADDR))
         if j < 11:
             L += ["s_add_u32 s74, s74, %s" % GSTRIDE, "s_addc_u32 s75, s75, 0"]
     if aform is None:                                # issue only: the caller waits and converts later (prefetch)
@@ -479,7 +483,7 @@ class AllocD:
         self.stats = dict(vmov=0, acc=0, lds=0, arith=0, norm=0, reduce=0, calls=0, unpack=0)
         # values whose live-in location is a packed LDS slot ('lp', s) keep it as a read-only home: evicting a register copy of
         # such a value costs nothing, fetching it again is 6 LDS reads + the conversion into digits
-        self.home = {v: l for v, l in prog.init_loc.items() if l[0] in ("lp", "g", "gd", "gk", "gka")}
+        self.home = {v: l for v, l in prog.init_loc.items() if l[0] in ("lp", "g", "gd", "gk", "gka", "gv")}
         self.home_bound = {v: in_bounds[v] for v in self.home}
         self.vm = 0                                          # vector-memory operations issued so far (they retire in issue order)
         self.vm_mark = {}                                    # value -> count after the last load of its prefetch
@@ -533,10 +537,10 @@ class AllocD:
             for l in lds_read_words([reg(j + 2) for j in range(12)], 12 * sb) + WAIT_LDS + seq_conv(reg, [reg(j + 2) for j in range(12)], False):
                 self.e(l)
             self.stats["unpack"] += 30
-        elif sk in ("g", "gd", "gk", "gka") and dk == "v":                 # gk / gka: gd / g in the record the run-time offset selects
+        elif sk in ("g", "gd", "gk", "gka", "gv") and dk == "v":           # gk / gka: gd / g in the record the run-time offset selects; gv: per lane
             reg = lambda j: "v%d" % (vb(db) + j)
             self.wait_lds()
-            for l in seq_gload(reg, sb, aform=(sk in ("g", "gka")), koff=(sk in ("gk", "gka"))):
+            for l in seq_gload(reg, sb, aform=(sk in ("g", "gka")), koff=(sk in ("gk", "gka")), lane=(VOFF if sk == "gv" else None)):
                 self.e(l)
             self.stats["unpack"] += 60
         elif sk == "l" and dk == "v":
@@ -654,7 +658,7 @@ class AllocD:
         while j < len(self.p.ops) and calls < horizon:
             kind, outs, ins, aux = self.p.ops[j]
             for v in ins:
-                if self.loc.get(v, ("", 0))[0] in ("g", "gd", "gk", "gka") and v in self.home:
+                if self.loc.get(v, ("", 0))[0] in ("g", "gd", "gk", "gka", "gv") and v in self.home:
                     b = self.free_block("v", self.free_v)
                     if b is None:                            # take the block whose value is needed last, if that is later than this use
                         best, bu = None, j
@@ -674,7 +678,7 @@ class AllocD:
                             self.spill(w)
                         b = best
                     reg = lambda q, b=b: "v%d" % (vb(b) + q)
-                    for x in seq_gload(reg, self.home[v][1], aform=None, koff=(self.home[v][0] in ("gk", "gka"))):
+                    for x in seq_gload(reg, self.home[v][1], aform=None, koff=(self.home[v][0] in ("gk", "gka")), lane=(VOFF if self.home[v][0] == "gv" else None)):
                         self.e(x)
                     self.vm_mark[v] = self.vm
                     self.loc[v] = ("vw", b); self.at[("vw", b)] = v
@@ -747,6 +751,8 @@ class AllocD:
                 self.do_sgn0(k, ins[0], ins[1], aux)
             elif kind == "mask_xor":
                 self.e("s_xor_b64 %s, %s, %s" % aux)
+            elif kind == "mask_or":
+                self.e("s_or_b64 %s, %s, %s" % aux)
             elif kind == "scale":
                 self.do_scale(k, outs[0], ins[0], aux)
             elif kind == "shadd":
@@ -2170,12 +2176,15 @@ def prog_sswu():
     return p
 
 
-def prog_g2_add(ad_slot, negate):
+def prog_g2_add(ad_slot, negate, table=False):
     """acc <- acc +- (the point in slots ad_slot..ad_slot+5); the old acc goes to AGPR blocks 6..11 for the doubling case; masks M_H0,
-    M_R0 (same x / same y), M_INF1, M_INF2 (an operand at infinity)"""
+    M_R0 (same x / same y), M_INF1, M_INF2 (an operand at infinity). table: the second operand is the record each LANE selects (kind
+    'gv', register VOFF) of a table that starts at ad_slot, negated on the lanes of M_NEGQ and ignored (as if infinite) on those of M_ZEROQ."""
     p = Prog()
     A = pt_live_in(p, "a", 0)
-    Q = pt_live_in(p, "gd", ad_slot)
+    Q = pt_live_in(p, "gv" if table else "gd", ad_slot)
+    if table:
+        Q = [Q[0], p.sel2(M_NEGQ, Q[1], p.neg2(Q[1])), Q[2]]
     if negate:
         Q = pt_neg(p, Q)
     z1z1, z2z2 = p.sqr2(A[2]), p.sqr2(Q[2])
@@ -2186,6 +2195,8 @@ def prog_g2_add(ad_slot, negate):
     rr = p.dbl2(p.sub2(s2, s1))
     p.iszero2(h, M_H0, G2M_TMP0); p.iszero2(rr, M_R0, G2M_TMP0)
     p.iszero2(A[2], M_INF1, G2M_TMP0); p.iszero2(Q[2], M_INF2, G2M_TMP0)
+    if table:
+        p.mask_or(M_INF2, M_INF2, M_ZEROQ)
     i4 = p.sqr2(p.dbl2(h))
     j, v = p.mul2(h, i4), p.mul2(u1, i4)
     X3 = p.sub2(p.sub2(p.sqr2(rr), j), p.dbl2(v))
@@ -2202,6 +2213,11 @@ def prog_g2_add(ad_slot, negate):
 # slots 0..12 hold the phases' results (sum of keys, signature, H) and 25..30 the n-pairing paths' G2 accumulator, which other kernels may be
 # writing or keeping meanwhile: the hash routine's scratch is 13..24 and 31..42, the signature routine's 43..48
 G2_SLOTS = dict(AD=19, P=31, T1=37, T2=13, T3=7, Q0=7, Q1=13, SIGAD=43, SIG=3, H=7, U=31)      # U: u0 in 31, 32; u1 in 37, 38
+# [r] sig of verify_multiple (g2_blind_routine): the table of 1..8 times the signature in slots 49..96 (the final exponentiation's records: not in
+# use while the signature phase runs), the result in the n-pairing paths' accumulator slots 25..30
+BL_TAB, BL_OUT = 49, 25
+BL_FREE_V = list(range(9, 17))       # block 17 (v238..v251) belongs to the shell: v[248:249] the scalar, v247 its top digit, v250 = VOFF, v251 status
+M_NEGQ, M_ZEROQ = "s[94:95]", "s[36:37]"
 
 
 def prog_g2_glue(which):
@@ -2237,6 +2253,15 @@ def prog_g2_glue(which):
         l = [prog_reduce(p, p.live_in(("g", S["SIG"] + i))) for i in range(4)]
         pt = [(l[0], l[1]), (l[2], l[3]), one()]
         pt_park(p, pt, S["SIGAD"]); pt_store_acc(p, pt)
+    elif which == "b_tab":                           # table record (the run-time offset selects it) <- acc; acc stays
+        a = acc()
+        for i, v in enumerate([x for c in a for x in c]):
+            p.ops.append(("storep", [], [v], ("k", BL_TAB + i)))
+        pt_store_acc(p, a)
+    elif which == "b_start":                         # acc = the signature again (x, y, 1)
+        pt_store_acc(p, gd("SIGAD"))
+    elif which == "b_inf":                           # acc = infinity
+        pt_store_acc(p, [(p.const(0), p.const(0)), one(), (p.const(0), p.const(0))])
     elif which == "s_compare":                       # g2_eq(psi(P), -acc) with P = (x, y, 1) -> mask M_H0
         b = pt_neg(p, acc())
         a = pt_psi(p, gd("SIGAD"))
@@ -2249,9 +2274,11 @@ def prog_g2_glue(which):
     return p
 
 
-def build_g2(which, ad_slot=None):
+def build_g2(which, ad_slot=None, free_v=None):
     if which in ("add", "sub"):
         p = prog_g2_add(ad_slot, which == "sub")
+    elif which == "addt":
+        p = prog_g2_add(BL_TAB, False, table=True)
     elif which == "dbl":
         p = prog_g2_dbl_d()
     elif which == "fix":
@@ -2260,8 +2287,8 @@ def build_g2(which, ad_slot=None):
         p = prog_sswu()
     else:
         p = prog_g2_glue(which)
-    inb = {v: (G2_IN if l[0] == "a" else PACKED if l[0] in ("gd", "gk") else G_IN) for v, l in p.init_loc.items()}      # g, gka: 2^384-domain words
-    al = AllocD(p, inb, n_lds=11, lds_base=0, a_pool=list(range(NA)))
+    inb = {v: (G2_IN if l[0] == "a" else PACKED if l[0] in ("gd", "gk", "gv") else G_IN) for v, l in p.init_loc.items()}      # g, gka: 2^384-domain words
+    al = AllocD(p, inb, n_lds=11, lds_base=0, a_pool=list(range(NA)), free_v=free_v)
     body = al.run()
     for dst, B in getattr(al, "stored", {}).items():
         assert B.vlo >= G2_IN.vlo and B.vhi <= G2_IN.vhi and B.dlo >= 0 and B.dhi <= M28, (which, dst, B)
@@ -2330,6 +2357,74 @@ def g2_group_routine(kind):
     return pro + main + expand_calls_d(epi) + ret + lad + subs, pieces, st          # every internal call is a forward jump
 
 
+def g2_blind_routine():
+    """The signature phase of verify_multiple_aggregate_signatures (reference src/aggregates.rs:274-276, :303) as ONE routine: the subgroup
+    test psi(P) = [x]P of the decoded signature, then [r] P for the lane's 64-bit blinding scalar r by signed 4-bit windows:
+    r + 0x8888888888888888 = sum e_j 16^j (+ a carry digit), r = sum (e_j - 8) 16^j + carry 2^64; the table 1 P .. 8 P lives in workspace
+    records (BL_TAB, one per multiple) and each lane fetches ITS record (kind 'gv'); 64 doublings + 17 additions instead of 64 + 64.
+    In:  slots 3..6 = the signature's affine x, y (2^384 domain); v[248:249] = r; v252 / s[68:69] / s70 as in the other routines.
+    Out: v251 = 1 iff psi(P) = [x]P; slots 25..30 = [r] P (Jacobian, canonical, 2^384 domain). Slots 43..48, 49..96 are scratch."""
+    S = G2_SLOTS
+    B, st = {}, {}
+    for nm in ["add", "addt", "dbl", "fix", "s_start", "s_compare", "b_tab", "b_start", "b_inf"]:
+        B[nm], st[nm] = build_g2(nm, S["SIGAD"], free_v=BL_FREE_V)
+    X = lambda nm: expand_calls_d(B[nm])
+    ADD, ADDT, LADDER, DBL4 = 50, 53, 52, 54
+    pro = ["s_mov_b64 s[80:81], s[30:31]", "s_waitcnt vmcnt(0)"] + shell_constants() + ["s_mov_b64 %s, exec" % EXEC_ALL,
+           "s_mul_i32 s72, %s, %d" % (GSTRIDE, 12 * 6)]
+    # r' = r + 0x8888888888888888, its carry is the 17th digit
+    pro += ["v_add_co_u32_e32 v248, vcc, 0x88888888, v248", "v_mov_b32_e32 v247, 0x88888888", "v_addc_co_u32_e32 v249, vcc, v249, v247, vcc",
+            "v_cndmask_b32_e64 v247, 0, 1, vcc"]
+
+    def fixup():
+        return ["s_and_b64 s[92:93], %s, %s" % (M_H0, M_R0), "s_andn2_b64 s[92:93], s[92:93], %s" % M_INF1, "s_andn2_b64 s[92:93], s[92:93], %s" % M_INF2,
+                "s_and_b64 s[92:93], s[92:93], exec", "s_cbranch_scc1 3f"] + far_fwd(6) + ["3:", "s_mov_b64 exec, s[92:93]"] + X("fix") + ["6:", "s_mov_b64 exec, %s" % EXEC_ALL]
+    subs = ["%d:" % ADD] + X("add") + fixup() + ["s_setpc_b64 s[98:99]"]
+    subs += ["%d:" % ADDT] + X("addt") + fixup() + ["s_setpc_b64 s[98:99]"]
+    lad = ["%d:" % LADDER, "s_mov_b32 s78, 0", "4:", "s_mov_b32 s39, %d" % RUNS[5]]
+    for ph in range(5):
+        lad += ["s_cmp_eq_u32 s78, %d" % ph, "s_cselect_b32 s39, %d, s39" % RUNS[ph]]
+    lad += [".p2align 6", "1:"] + X("dbl") + ["s_sub_u32 s39, s39, 1", "s_cmp_lg_u32 s39, 0", "s_cbranch_scc0 2f"] + far_back(1) + ["2:"]
+    lad += ["s_cmp_eq_u32 s78, 5", "s_cbranch_scc0 3f", "s_setpc_b64 s[96:97]", "3:"]
+    lad += call_sub(ADD) + ["s_add_u32 s78, s78, 1"] + far_back(4)
+    dbl4 = ["%d:" % DBL4, "s_mov_b32 s39, 4", ".p2align 6", "1:"] + X("dbl") + ["s_sub_u32 s39, s39, 1", "s_cmp_lg_u32 s39, 0", "s_cbranch_scc0 2f"] + far_back(1) + ["2:", "s_setpc_b64 s[96:97]"]
+
+    def call_far(label):
+        return ["s_getpc_b64 s[96:97]", "7:", "s_add_u32 s96, s96, 8f-7b", "s_addc_u32 s97, s97, 0"] + far_fwd(label) + ["8:"]
+    # the subgroup test
+    main = X("s_start") + call_far(LADDER) + X("s_compare")
+    main += ["s_and_b64 s[92:93], %s, %s" % (M_H0, M_R0), "s_andn2_b64 s[92:93], s[92:93], %s" % M_INF1, "s_andn2_b64 s[92:93], s[92:93], %s" % M_INF2,
+             "s_and_b64 %s, %s, %s" % (G2M_TMP0, M_INF1, M_INF2), "s_or_b64 s[92:93], s[92:93], %s" % G2M_TMP0, "v_cndmask_b32_e64 v251, 0, 1, s[92:93]"]
+    # the table: record e holds (e + 1) P
+    main += X("b_start") + ["s_mov_b32 %s, 0" % GKOFF] + X("b_tab") + X("dbl") + ["s_mov_b32 %s, s72" % GKOFF] + X("b_tab")
+    main += ["s_mov_b32 s79, 6", "5:"] + call_sub(ADD) + ["s_add_u32 %s, %s, s72" % (GKOFF, GKOFF)] + X("b_tab")
+    main += ["s_sub_u32 s79, s79, 1", "s_cmp_lg_u32 s79, 0", "s_cbranch_scc0 2f"] + far_back(5) + ["2:", "s_waitcnt vmcnt(0)"]
+    # the windows, top digit (0 or 1) first
+    main += X("b_inf")
+    main += ["s_mov_b64 %s, 0" % M_NEGQ, "v_cmp_eq_u32_e64 %s, 0, v247" % M_ZEROQ, "v_mov_b32_e32 %s, %s" % (VOFF, LADDR)] + call_sub(ADDT)
+    main += ["s_mov_b32 s38, 60", "5:"] + call_far(DBL4)
+    main += ["v_lshrrev_b64 v[246:247], s38, v[248:249]", "v_and_b32_e32 v246, 15, v246", "v_subrev_u32_e32 v246, 8, v246",          # d = e - 8 in [-8, 7]
+             "v_cmp_gt_i32_e64 %s, 0, v246" % M_NEGQ, "v_cmp_eq_u32_e64 %s, 0, v246" % M_ZEROQ,
+             "v_sub_u32_e32 v247, 0, v246", "v_max_i32_e32 v246, v246, v247", "v_max_i32_e32 v246, 1, v246", "v_subrev_u32_e32 v246, 1, v246",
+             "v_mul_lo_u32 v246, v246, s72", "v_add_u32_e32 %s, %s, v246" % (VOFF, LADDR)]
+    main += call_sub(ADDT)
+    main += ["s_cmp_eq_u32 s38, 0", "s_cbranch_scc1 2f", "s_sub_u32 s38, s38, 4"] + far_back(5) + ["2:"]
+    # [r] P -> slots 25..30, canonical words of the 2^384 domain
+    epi = ["s_waitcnt vmcnt(0)"]
+    B0, B1, B2, B5, B6 = (lambda j: "v%d" % j), (lambda j: "v%d" % (14 + j)), (lambda j: "v%d" % (28 + j)), (lambda j: "v%d" % (70 + j)), (lambda j: "v%d" % (84 + j))
+    epi += ["v_mov_b32_e32 %s, 0x%08x" % (B2(j), dgt) for j, dgt in enumerate(digits_of(K384))]
+    for i in range(3):
+        epi += ["v_accvgpr_read_b32 %s, a%d" % (B0(j), vb(2 * i) + j) for j in range(14)]
+        epi += ["v_accvgpr_read_b32 %s, a%d" % (B1(j), vb(2 * i + 1) + j) for j in range(14)]
+        epi += ["CALL mbls_fp2_mulfp_d_asm_fn"]
+        for h, Bk in ((0, B5), (1, B6)):
+            epi += seq_reduce(Bk) + seq_canonical(Bk) + seq_to32(Bk) + seq_gstore(Bk, BL_OUT + 2 * i + h)
+    epi += ["s_waitcnt vmcnt(0)", "s_mov_b64 s[30:31], s[80:81]"]
+    ret = ["s_setpc_b64 s[30:31]"]
+    pieces = dict(B, pro=pro, epi=epi)
+    return pro + main + expand_calls_d(epi) + ret + lad + dbl4 + subs, pieces, st
+
+
 def main():
     here = os.path.dirname(os.path.abspath(__file__))
     path = os.path.join(os.path.dirname(here), "milagro_bls_amd", "csrc", "mbls_towerd_asm.inc")
@@ -2365,6 +2460,12 @@ def main():
         full, pieces, st = g2_group_routine(kind)
         txt += emit(macro, full) + "\n"
         print("g2 group routine", kind, len(full), "lines; add", len(pieces["add"]), st["add"])
+    full, pieces, st = g2_blind_routine()
+    txt += emit("MBLS_G2_BLIND_D_ASM", full) + "\n"
+    print("g2 blind routine", len(full), "lines; addt", len(pieces["addt"]), st["addt"])
+    sgb = sgm.replace('"vcc"', ",".join('"s%d"' % i for i in [38] + list(range(50, 54)) + [71, 72] + list(range(79, 100))) + ',"vcc"')
+    txt += "#define MBLS_G2_BLIND_D_ASM_CLOBBERS %s,%s, \\\n    %s\n" % (
+        ",".join('"v%d"' % i for i in range(256) if i not in (248, 249, 251, 252) and i not in UNTOUCHED_V), ",".join('"a%d"' % i for i in range(252)), sgb)
     sgg = sgm.replace('"vcc"', ",".join('"s%d"' % i for i in list(range(50, 54)) + [71, 72] + list(range(79, 100))) + ',"vcc"')
     txt += "#define MBLS_G2_GROUP_D_ASM_CLOBBERS %s,%s, \\\n    %s\n" % (
         ",".join('"v%d"' % i for i in range(256) if i not in (251, 252) and i not in UNTOUCHED_V), ",".join('"a%d"' % i for i in range(252)), sgg)
