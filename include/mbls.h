@@ -64,7 +64,7 @@ typedef struct mbls_ctx mbls_ctx;
  * (on the device) for the workspace of the earlier one. For concurrent streams of work create one context per stream. */
 int mbls_ctx_create(mbls_ctx** out, int device_id);
 void mbls_ctx_destroy(mbls_ctx* ctx);
-/* pre-allocate the HBM workspace for batches of up to max_items items (5 232 bytes per item; avoids allocation in timed regions) */
+/* pre-allocate the HBM workspace for batches of up to max_items items (6 384 bytes per item; avoids allocation in timed regions) */
 int mbls_ctx_reserve(mbls_ctx* ctx, uint64_t max_items);
 /* pre-allocate the staging area for max_keys decompressed public keys (compressed wire format, 96 bytes per key) */
 int mbls_ctx_reserve_keys(mbls_ctx* ctx, uint64_t max_keys);

@@ -22,8 +22,10 @@
 #define MBLS_SLOT_S 25            // 6 Fp: Jacobian G2 accumulator for verify_multiple
 #define MBLS_SLOT_T 31            // 12 Fp: the running points of the generated Miller loop (packed, 2^392 domain; tools/gen_tower_d.py T_SLOT)
 #define MBLS_SLOT_G2TMP 43        // 6 Fp: scratch of the generated subgroup-test routine (tools/gen_tower_d.py G2_SLOTS)
-#define MBLS_SLOT_KREC 49         // 60 Fp: the six compressed powers of the final exponentiation (tools/gen_tower_d.py K_SLOT, K_REC)
-#define MBLS_SLOT_TOTAL 109
+#define MBLS_SLOT_KREC 49         // 60 Fp: the six compressed powers of the final exponentiation (tools/gen_tower_d.py K_SLOT, K_REC); verify_multiple's
+                                  // signature phase keeps its table of 1..8 times the signature in 49..96 (BL_TAB)
+#define MBLS_SLOT_G1TAB 109       // 24 Fp: verify_multiple's table of 1..8 times the aggregate key (tools/gen_tower_d.py G1B_TAB)
+#define MBLS_SLOT_TOTAL 133
 #define WG 64
 // The pipeline kernels are built for one wave per SIMD (512 registers per lane): a batch of 2^16 items is exactly one wave
 // per SIMD on 256 CUs, and the hot loops are generated straight-line routines that already issue at the VALU rate with a
@@ -202,6 +204,23 @@ __global__ void MBLS_LB k_blind_sig(mbls_ws ws, const uint8_t* sigs96, const uin
     g2_mul(&s, &s, k, 64);
     ws_st2(ws, MBLS_SLOT_S, i, s.x); ws_st2(ws, MBLS_SLOT_S + 2, i, s.y); ws_st2(ws, MBLS_SLOT_S + 4, i, s.z);
     if (st) atomicOr(status + i, st);
+}
+// [r_i] pk_i with the generated windowed routine (g1_blind_routine); pks96 == NULL: the aggregate key k_aggregate left in slots 0..2
+__global__ void MBLS_LB k_blind_g1_d(mbls_ws ws, const uint8_t* pks96, const uint64_t* rands, uint32_t* status, uint64_t n) {
+#if MBLS_DEVICE_ASM && !defined(MBLS_NO_FP2_ASM)
+    uint64_t i = gid(); if (i >= n) return;
+    uint32_t st = 0;
+    if (pks96) {
+        fp x, y; bool inf; int e = g1_decode_uncompressed(&x, &y, &inf, pks96 + 96 * i);
+        if (e) { st |= MBLS_ST_BAD_PK_ENCODING; inf = true; }
+        g1j p; p.x = x; p.y = y; p.z = fp_one(); if (inf) g1_set_inf(&p);
+        ws_st(ws, MBLS_SLOT_APK, i, p.x); ws_st(ws, MBLS_SLOT_APK + 1, i, p.y); ws_st(ws, MBLS_SLOT_APK + 2, i, p.z);
+    }
+    const uint64_t r = rands[i];
+    if (r == 0) st |= MBLS_ST_BAD_SCALAR;
+    g1_blind_d_call(ws, i, threadIdx.x, r);
+    if (st) atomicOr(status + i, st);
+#endif
 }
 // the same with the generated routines (decode inlined like k_sig; subgroup test + windowed [r] sig: g2_blind_routine): no lane-private memory
 __global__ void MBLS_LB k_blind_sig_d(mbls_ws ws, const uint8_t* sigs96, const uint64_t* rands, uint32_t* status, uint64_t n) {
@@ -1174,7 +1193,7 @@ static int verify_multiple_impl(mbls_ctx* c, const uint8_t* d_sigs, const uint8_
     if (fork) { HIPCHK(c, hipEventRecord(c->hs_ev, s)); HIPCHK(c, hipStreamWaitEvent(s_sig, c->hs_ev, 0)); HIPCHK(c, hipStreamWaitEvent(s_msg, c->hs_ev, 0)); }
     if (!d_apks)    // sets given by their wire-format keys: AggregatePublicKey::aggregate on the device first (src/aggregates.rs:29-39)
         launch_aggregate(ws, d_pks, d_pk_offsets, k, pk_format, MBLS_MODE_VERIFY, c->d_status, n, s);
-    hipLaunchKernelGGL(k_blind_g1, dim3(nblk(n)), dim3(WG), 0, s, ws, d_apks, d_rands, c->d_status, n);
+    hipLaunchKernelGGL(k_blind_g1_d, dim3(nblk(n)), dim3(WG), 0, s, ws, d_apks, d_rands, c->d_status, n);
     hipLaunchKernelGGL(k_blind_sig_d, dim3(nblk(n)), dim3(WG), 0, s_sig, ws, d_sigs, d_rands, c->d_status, n);
     g2_tree(c, ws, n, s_sig);
     hipLaunchKernelGGL(k_hash, dim3(nblk(n)), dim3(WG), 0, s_msg, ws, d_msgs, msg_len, d_moff, c->d_status, n);

@@ -208,6 +208,18 @@ MBLS_FN uint32_t g2_group_d_call(const mbls_ws& ws, uint64_t i, MBLS_LDS uint32_
         asm volatile(MBLS_ASM_CALL("mbls_g2_subgroup_d_asm_fn") : "+{v251}"(fl) : "{v252}"(addr), "{s68}"(gb_lo), "{s69}"(gb_hi), "{s70}"(st4) : MBLS_G2_GROUP_D_ASM_CLOBBERS);
     return fl;
 }
+// [r] P for the Jacobian G1 point in slots 0..2 (verify_multiple's g1mul(apk_i, r_i), reference src/aggregates.rs:293), back into slots 0..2:
+// the generated windowed routine (tools/gen_tower_d.py g1_blind_routine)
+extern "C" __device__ __attribute__((noinline, used, aligned(64))) void mbls_g1_blind_d_asm_fn() { asm volatile(MBLS_G1_BLIND_D_ASM); }
+MBLS_FN void g1_blind_d_call(const mbls_ws& ws, uint64_t i, uint32_t lane, uint64_t r) {
+    const uint32_t addr = 4u * lane;
+    const uint64_t gb = (uint64_t)(uintptr_t)ws.w + 4ull * (i - lane);
+    const uint32_t gb_lo = __builtin_amdgcn_readfirstlane((uint32_t)gb), gb_hi = __builtin_amdgcn_readfirstlane((uint32_t)(gb >> 32));
+    const uint32_t st4 = __builtin_amdgcn_readfirstlane((uint32_t)(ws.stride * 4));
+    uint32_t rlo = (uint32_t)r, rhi = (uint32_t)(r >> 32);
+    asm volatile(MBLS_ASM_CALL("mbls_g1_blind_d_asm_fn") : "+{v248}"(rlo), "+{v249}"(rhi) : "{v252}"(addr), "{s68}"(gb_lo), "{s69}"(gb_hi), "{s70}"(st4)
+                 : MBLS_G1_BLIND_D_ASM_CLOBBERS);
+}
 // verify_multiple's signature phase (reference src/aggregates.rs:274-276, :303) as one generated routine (tools/gen_tower_d.py g2_blind_routine): the
 // subgroup test of the signature in slots 3..6, then [r] sig by signed 4-bit windows into slots 25..30. Returns bit 0 = psi(P) = [x]P.
 extern "C" __device__ __attribute__((noinline, used, aligned(64))) void mbls_g2_blind_d_asm_fn() { asm volatile(MBLS_G2_BLIND_D_ASM); }

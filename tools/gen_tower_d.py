@@ -1858,10 +1858,11 @@ def prog_g1_step(mode):
     return p
 
 
-def prog_g1_dbl():
-    """the sum as it was before this key (AGPR blocks 5..7), doubled, into blocks 0..2: the key equals the running sum (g1_dbl's formulas)"""
+def prog_g1_dbl(src=5):
+    """the sum as it was before this key (AGPR blocks 5..7), doubled, into blocks 0..2: the key equals the running sum (g1_dbl's formulas);
+    src = 0: the running point doubled in place"""
     p = Prog()
-    X, Y, Z = [p.live_in(("a", 5 + i)) for i in range(3)]
+    X, Y, Z = [p.live_in(("a", src + i)) for i in range(3)]
     A, B = p.mulpair(X, X, Y, Y)
     XB = p.add(X, B)
     C, S = p.mulpair(B, B, XB, XB)
@@ -2357,6 +2358,128 @@ def g2_group_routine(kind):
     return pro + main + expand_calls_d(epi) + ret + lad + subs, pieces, st          # every internal call is a forward jump
 
 
+# ---- [r] apk for verify_multiple (reference src/aggregates.rs:293): the same signed 4-bit windows in G1
+G1B_TAB = 109                         # eight records of three slots: 1 P .. 8 P (slots 109..132, behind the final exponentiation's records)
+G1B_FREE_V = list(range(8, 17))
+
+
+def prog_g1_jadd(slot, table):
+    """acc <- acc + (the Jacobian point in slots slot..slot+2; table: the record each lane selects, negated / ignored by M_NEGQ / M_ZEROQ):
+    add-2007-bl with g1_add's case handling by selection; the old acc goes to AGPR blocks 5..7 for the doubling fix-up"""
+    p = Prog()
+    X1, Y1, Z1 = [p.live_in(("a", i)) for i in range(3)]
+    X2, Y2, Z2 = [p.live_in(("gv" if table else "gd", slot + i)) for i in range(3)]
+    if table:
+        Y2 = p.sel(M_NEGQ, Y2, p.neg(Y2))
+    Z1Z1, Z2Z2 = p.mulpair(Z1, Z1, Z2, Z2)
+    U1, U2 = p.mulpair(X1, Z2Z2, X2, Z1Z1)
+    T1, T2 = p.mulpair(Y1, Z2, Y2, Z1)
+    S1, S2 = p.mulpair(T1, Z2Z2, T2, Z1Z1)
+    H = p.sub(U2, U1)
+    RR = p.scale(p.sub(S2, S1), 2)
+    p.iszero(H, M_H0); p.iszero(RR, M_R0); p.iszero(Z1, M_INF1); p.iszero(Z2, M_INF2)
+    if table:
+        p.mask_or(M_INF2, M_INF2, M_ZEROQ)
+    H2 = p.scale(H, 2)
+    I, RR2 = p.mulpair(H2, H2, RR, RR)
+    J, V = p.mulpair(H, I, U1, I)
+    X3 = p.sub(p.sub(RR2, J), p.scale(V, 2))
+    ZZ = p.add(Z1, Z2)
+    M0, ZS = p.mulpair(RR, p.sub(V, X3), ZZ, ZZ)
+    M1, Z3 = p.mulpair(S1, J, p.sub(p.sub(ZS, Z1Z1), Z2Z2), H)
+    Y3 = p.sub(M0, p.scale(M1, 2))
+    out = [p.sel(M_INF1, o, q) for o, q in zip((X3, Y3, Z3), (X2, Y2, Z2))]
+    out = [p.sel(M_INF2, o, a) for o, a in zip(out, (X1, Y1, Z1))]
+    for i, v in enumerate((X1, Y1, Z1)):
+        p.store(v, ("a", 5 + i))
+    for i, v in enumerate(out):
+        p.store(prog_reduce(p, v), ("a", i))
+    return p
+
+
+def prog_g1b_glue(which):
+    p = Prog()
+    acc = lambda: [p.live_in(("a", i)) for i in range(3)]
+    if which == "start":                             # acc = the point in slots 0..2 (Jacobian, 2^384 domain words)
+        for i in range(3):
+            p.store(prog_reduce(p, p.live_in(("g", i))), ("a", i))
+    elif which == "tab":                             # table record (run-time offset) <- acc; acc stays
+        a = acc()
+        for i, v in enumerate(a):
+            p.ops.append(("storep", [], [v], ("k", G1B_TAB + i)))
+        for i, v in enumerate(a):
+            p.store(v, ("a", i))
+    elif which == "inf":
+        for i, c in enumerate((0, ONE_D, 0)):
+            p.store(prog_reduce(p, p.const(c)), ("a", i))
+    else:
+        raise ValueError(which)
+    return p
+
+
+def build_g1b(which):
+    p = {"add": lambda: prog_g1_jadd(G1B_TAB, False), "addt": lambda: prog_g1_jadd(G1B_TAB, True), "dbl": lambda: prog_g1_dbl(0),
+         "fix": lambda: prog_g1_dbl(5)}.get(which, lambda: prog_g1b_glue(which))()
+    inb = {v: (STATE_IN if l[0] == "a" else PACKED if l[0] in ("gd", "gv", "gk") else G_IN) for v, l in p.init_loc.items()}
+    al = AllocD(p, inb, n_lds=0, a_pool=list(range(8, NA)), free_v=G1B_FREE_V)
+    body = al.run()
+    for dst, B in getattr(al, "stored", {}).items():
+        assert B.vlo >= STATE_IN.vlo and B.vhi <= STATE_IN.vhi and B.dlo >= 0 and B.dhi <= M28, (which, dst, B)
+    return body, al.stats
+
+
+def g1_blind_routine():
+    """[r] P for the Jacobian G1 point in workspace slots 0..2 (2^384 domain) and the lane's 64-bit scalar r in v[248:249], back into slots 0..2
+    (canonical): signed 4-bit windows over a table 1 P .. 8 P in workspace records, each lane fetching its own (see g2_blind_routine).
+    v252 / s[68:69] / s70: workspace addressing of the other routines (no LDS: the lane offset in v252 may be any address the caller folds
+    into the base)."""
+    B, st = {}, {}
+    for nm in ["add", "addt", "dbl", "fix", "start", "tab", "inf"]:
+        B[nm], st[nm] = build_g1b(nm)
+    X = lambda nm: expand_calls_d(B[nm])
+    ADD, ADDT, DBL4 = 50, 53, 54
+    pro = ["s_mov_b64 s[80:81], s[30:31]", "s_waitcnt vmcnt(0)"] + shell_constants() + ["s_mov_b64 %s, exec" % EXEC_ALL,
+           "s_mul_i32 s72, %s, %d" % (GSTRIDE, 12 * 3)]
+    pro += ["v_add_co_u32_e32 v248, vcc, 0x88888888, v248", "v_mov_b32_e32 v247, 0x88888888", "v_addc_co_u32_e32 v249, vcc, v249, v247, vcc",
+            "v_cndmask_b32_e64 v247, 0, 1, vcc"]
+
+    def fixup():
+        return ["s_and_b64 s[92:93], %s, %s" % (M_H0, M_R0), "s_andn2_b64 s[92:93], s[92:93], %s" % M_INF1, "s_andn2_b64 s[92:93], s[92:93], %s" % M_INF2,
+                "s_and_b64 s[92:93], s[92:93], exec", "s_cbranch_scc1 3f"] + far_fwd(6) + ["3:", "s_mov_b64 exec, s[92:93]"] + X("fix") + ["6:", "s_mov_b64 exec, %s" % EXEC_ALL]
+    subs = ["%d:" % ADD] + X("add") + fixup() + ["s_setpc_b64 s[98:99]"]
+    subs += ["%d:" % ADDT] + X("addt") + fixup() + ["s_setpc_b64 s[98:99]"]
+    dbl4 = ["%d:" % DBL4, "s_mov_b32 s39, 4", ".p2align 6", "1:"] + X("dbl") + ["s_sub_u32 s39, s39, 1", "s_cmp_lg_u32 s39, 0", "s_cbranch_scc0 2f"] + far_back(1) + ["2:", "s_setpc_b64 s[96:97]"]
+
+    def call_far(label):
+        return ["s_getpc_b64 s[96:97]", "7:", "s_add_u32 s96, s96, 8f-7b", "s_addc_u32 s97, s97, 0"] + far_fwd(label) + ["8:"]
+    main = X("start") + ["s_mov_b32 %s, 0" % GKOFF] + X("tab") + X("dbl") + ["s_mov_b32 %s, s72" % GKOFF] + X("tab")
+    main += ["s_mov_b32 s79, 6", "5:"] + call_sub(ADD) + ["s_add_u32 %s, %s, s72" % (GKOFF, GKOFF)] + X("tab")
+    main += ["s_sub_u32 s79, s79, 1", "s_cmp_lg_u32 s79, 0", "s_cbranch_scc0 2f"] + far_back(5) + ["2:", "s_waitcnt vmcnt(0)"]
+    main += X("inf")
+    main += ["s_mov_b64 %s, 0" % M_NEGQ, "v_cmp_eq_u32_e64 %s, 0, v247" % M_ZEROQ, "v_mov_b32_e32 %s, %s" % (VOFF, LADDR)] + call_sub(ADDT)
+    main += ["s_mov_b32 s38, 60", "5:"] + call_far(DBL4)
+    main += ["v_lshrrev_b64 v[246:247], s38, v[248:249]", "v_and_b32_e32 v246, 15, v246", "v_subrev_u32_e32 v246, 8, v246",
+             "v_cmp_gt_i32_e64 %s, 0, v246" % M_NEGQ, "v_cmp_eq_u32_e64 %s, 0, v246" % M_ZEROQ,
+             "v_sub_u32_e32 v247, 0, v246", "v_max_i32_e32 v246, v246, v247", "v_max_i32_e32 v246, 1, v246", "v_subrev_u32_e32 v246, 1, v246",
+             "v_mul_lo_u32 v246, v246, s72", "v_add_u32_e32 %s, %s, v246" % (VOFF, LADDR)]
+    main += call_sub(ADDT)
+    main += ["s_cmp_eq_u32 s38, 0", "s_cbranch_scc1 2f", "s_sub_u32 s38, s38, 4"] + far_back(5) + ["2:"]
+    epi = ["s_waitcnt vmcnt(0)"]
+    B0, B1, B2, B5, B6 = (lambda j: "v%d" % j), (lambda j: "v%d" % (14 + j)), (lambda j: "v%d" % (28 + j)), (lambda j: "v%d" % (70 + j)), (lambda j: "v%d" % (84 + j))
+    epi += ["v_mov_b32_e32 %s, 0x%08x" % (B2(j), dgt) for j, dgt in enumerate(digits_of(K384))]
+    for half in range(2):
+        srcs = (0, 1) if half == 0 else (2, 2)
+        epi += ["v_accvgpr_read_b32 %s, a%d" % (B0(j), vb(srcs[0]) + j) for j in range(14)]
+        epi += ["v_accvgpr_read_b32 %s, a%d" % (B1(j), vb(srcs[1]) + j) for j in range(14)]
+        epi += ["CALL mbls_fp2_mulfp_d_asm_fn"]
+        for h, Bk in ((0, B5), (1, B6))[:2 if half == 0 else 1]:
+            epi += seq_reduce(Bk) + seq_canonical(Bk) + seq_to32(Bk) + seq_gstore(Bk, 2 * half + h)
+    epi += ["s_waitcnt vmcnt(0)", "s_mov_b64 s[30:31], s[80:81]"]
+    ret = ["s_setpc_b64 s[30:31]"]
+    pieces = dict(B, pro=pro, epi=epi)
+    return pro + main + expand_calls_d(epi) + ret + dbl4 + subs, pieces, st
+
+
 def g2_blind_routine():
     """The signature phase of verify_multiple_aggregate_signatures (reference src/aggregates.rs:274-276, :303) as ONE routine: the subgroup
     test psi(P) = [x]P of the decoded signature, then [r] P for the lane's 64-bit blinding scalar r by signed 4-bit windows:
@@ -2466,6 +2589,11 @@ def main():
     sgb = sgm.replace('"vcc"', ",".join('"s%d"' % i for i in [38] + list(range(50, 54)) + [71, 72] + list(range(79, 100))) + ',"vcc"')
     txt += "#define MBLS_G2_BLIND_D_ASM_CLOBBERS %s,%s, \\\n    %s\n" % (
         ",".join('"v%d"' % i for i in range(256) if i not in (248, 249, 251, 252) and i not in UNTOUCHED_V), ",".join('"a%d"' % i for i in range(252)), sgb)
+    full, pieces, st = g1_blind_routine()
+    txt += emit("MBLS_G1_BLIND_D_ASM", full) + "\n"
+    print("g1 blind routine", len(full), "lines; addt", len(pieces["addt"]), st["addt"], "dbl", len(pieces["dbl"]))
+    txt += "#define MBLS_G1_BLIND_D_ASM_CLOBBERS %s,%s, \\\n    %s\n" % (
+        ",".join('"v%d"' % i for i in range(256) if i not in (248, 249, 252) and i not in UNTOUCHED_V), ",".join('"a%d"' % i for i in range(252)), sgb)
     sgg = sgm.replace('"vcc"', ",".join('"s%d"' % i for i in list(range(50, 54)) + [71, 72] + list(range(79, 100))) + ',"vcc"')
     txt += "#define MBLS_G2_GROUP_D_ASM_CLOBBERS %s,%s, \\\n    %s\n" % (
         ",".join('"v%d"' % i for i in range(256) if i not in (251, 252) and i not in UNTOUCHED_V), ",".join('"a%d"' % i for i in range(252)), sgg)
