@@ -892,3 +892,89 @@ def test_paired_fp_products_and_squarings():
         m3.v[0:14], m3.v[14:28], m3.v[28:42], m3.v[42:56] = a_digits[0], a_digits[1], a_digits[0], a_digits[1]
         m3.run(d.fp_mulpair_d_body())
         assert list(m3.v[70:98]) == list(m2.v[70:98])
+
+
+# ---------------------------------------------------------------------------------------------- the blinding routines of verify_multiple
+def _blind_run(kind, r, ws_init, out_slots):
+    """the instruction streams of g1_blind_routine / g2_blind_routine in their control order (the skeleton's loops mirrored here: table
+    of 1 P .. 8 P, top digit, sixteen windows of four doublings + one table addition), returning the words left in out_slots"""
+    full, pieces, st = (t.g1_blind_routine if kind == "g1" else t.g2_blind_routine)()
+    assert not any("scratch" in l or "buffer_" in l for l in full)
+    m = miller_machine(0)
+    m.v[248], m.v[249] = r & 0xFFFFFFFF, r >> 32
+    for slot, x in ws_init.items():
+        ws_put(m, slot, x)
+    m.run(pieces["pro"])
+    rp = r + 0x8888888888888888
+    assert (m.v[248] | (m.v[249] << 32), m.v[247]) == (rp & 0xFFFFFFFFFFFFFFFF, rp >> 64)
+
+    def add(name):
+        m.run(pieces[name])
+        pr = lambda nm: m.s[("pair", int(nm[2:nm.index(":")]))]
+        if pr(t.M_H0) and pr(t.M_R0) and not pr(t.M_INF1) and not pr(t.M_INF2):
+            m.run(pieces["fix"])
+    verdict = None
+    if kind == "g2":
+        m.run(pieces["s_start"])
+        for ph, n_ in enumerate(t.RUNS):
+            for _ in range(n_):
+                m.run(pieces["dbl"])
+            if ph < 5:
+                add("add")
+        m.run(pieces["s_compare"])
+        pr = lambda nm: m.s[("pair", int(nm[2:nm.index(":")]))]
+        ex, ey, ia, ib = pr(t.M_H0), pr(t.M_R0), pr(t.M_INF1), pr(t.M_INF2)
+        verdict = bool((ia and ib) or (not ia and not ib and ex and ey))
+    start, tab, inf = ("start", "tab", "inf") if kind == "g1" else ("b_start", "b_tab", "b_inf")
+    m.run(pieces[start]); m.s[71] = 0; m.run(pieces[tab]); m.run(pieces["dbl"]); m.s[71] = m.s[72]; m.run(pieces[tab])
+    for _ in range(6):
+        add("add"); m.s[71] += m.s[72]; m.run(pieces[tab])
+    m.run(pieces[inf]); m.run(pieces["top"]); add("addt")
+    for shift in range(60, -4, -4):
+        for _ in range(4):
+            m.run(pieces["dbl"])
+        m.s[38] = shift
+        m.run(pieces["digit"])
+        d = ((rp >> shift) & 15) - 8
+        assert m.v[250] == LADDR + (max(abs(d), 1) - 1) * m.s[72]
+        add("addt")
+    m.run(pieces["epi"][:-1])
+    return [ws_get(m, sl) for sl in out_slots], verdict
+
+
+def test_g1_blinding_routine():
+    """[r] P in G1 by signed 4-bit windows over a per-lane table (g1_blind_routine) against the model's scalar multiplication: random 64-bit
+    scalars, scalars with zero / extreme digits, a point at infinity"""
+    M = _g2m()
+    rng = random.Random(31)
+    ri = pow(R384, -1, P)
+    pt = M.g1_mul(M.G1, rng.randrange(1, M.R))
+    z = rng.randrange(1, P)
+    jac = (pt[0] * z * z % P, pt[1] * z * z * z % P, z)
+    for r in (rng.randrange(1, 1 << 64), 1, (1 << 64) - 1, 0x8000000000000000, 0x0807060504030201, 0x7777777777777778):
+        out, _ = _blind_run("g1", r, {i: jac[i] * R384 % P for i in range(3)}, range(3))
+        X, Y, Z = [w * ri % P for w in out]
+        assert jac_affine(X, Y, Z) == M.g1_mul(pt, r), hex(r)
+    out, _ = _blind_run("g1", 12345, {0: 0, 1: R384 % P, 2: 0}, range(3))
+    assert out[2] == 0
+
+
+def test_g2_blinding_routine():
+    """the signature phase of verify_multiple (g2_blind_routine): subgroup verdict + [r] sig against the model, for a signature in G2 and a
+    curve point outside it"""
+    M = _g2m()
+    rng = random.Random(32)
+    ri = pow(R384, -1, P)
+    inside = M.g2_mul(M.G2, rng.randrange(1, M.R))
+    while True:
+        x = (rng.randrange(P), rng.randrange(P))
+        y = M.f2_sqrt(M.f2_add(M.f2_mul(M.f2_sqr(x), x), M.B2))
+        if y is not None:
+            outside = (x, y)
+            break
+    for pt, r in ((inside, rng.randrange(1, 1 << 64)), (outside, 0xF00000000000000F)):
+        ws = {t.G2_SLOTS["SIG"] + i: c * R384 % P for i, c in enumerate((pt[0][0], pt[0][1], pt[1][0], pt[1][1]))}
+        out, verdict = _blind_run("g2", r, ws, range(t.BL_OUT, t.BL_OUT + 6))
+        assert verdict == M.subgroup_check_g2(pt)
+        c = [w * ri % P for w in out]
+        assert jac2_affine(M, (c[0], c[1]), (c[2], c[3]), (c[4], c[5])) == M.g2_mul(pt, r)

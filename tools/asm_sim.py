@@ -186,6 +186,12 @@ class Machine:
                 self.wr(args[0], (self.rd(args[1]) << self.rd(args[2])) | self.rd(args[3]))
             elif op == "v_sub_u32_e32":
                 self.wr(args[0], self.rd(args[1]) - self.rd(args[2]))
+            elif op == "v_subrev_u32_e32":
+                self.wr(args[0], self.rd(args[2]) - self.rd(args[1]))
+            elif op == "v_max_i32_e32":
+                self.wr(args[0], max(s32(self.rd(args[1])), s32(self.rd(args[2]))))
+            elif op == "v_cmp_gt_i32_e64":
+                self.wr_carry(args[0], 1 if s32(self.rd(args[1])) > s32(self.rd(args[2])) else 0)
             elif op == "v_lshlrev_b32_e32":
                 self.wr(args[0], self.rd(args[2]) << self.rd(args[1]))
             elif op == "v_alignbit_b32":

@@ -2363,6 +2363,18 @@ G1B_TAB = 109                         # eight records of three slots: 1 P .. 8 P
 G1B_FREE_V = list(range(8, 17))
 
 
+# The scalar's signed 4-bit digits (shell code of both blinding routines): r' = r + 0x8888888888888888 = sum e_j 16^j + carry 2^64, so
+# r = sum (e_j - 8) 16^j + carry 2^64 with digits in [-8, 7] and a 17th digit 0 / 1 (v247). Per window: M_NEGQ = the digit is negative,
+# M_ZEROQ = it is zero, VOFF = lane offset of table record |digit| - 1.
+BLIND_RPRIME = ["v_add_co_u32_e32 v248, vcc, 0x88888888, v248", "v_mov_b32_e32 v247, 0x88888888", "v_addc_co_u32_e32 v249, vcc, v249, v247, vcc",
+                "v_cndmask_b32_e64 v247, 0, 1, vcc"]
+BLIND_TOP = ["s_mov_b64 %s, 0" % "s[94:95]", "v_cmp_eq_u32_e64 %s, 0, v247" % "s[36:37]", "v_mov_b32_e32 %s, %s" % (VOFF, LADDR)]
+BLIND_DIGIT = ["v_lshrrev_b64 v[246:247], s38, v[248:249]", "v_and_b32_e32 v246, 15, v246", "v_subrev_u32_e32 v246, 8, v246",          # d = e - 8 in [-8, 7]
+               "v_cmp_gt_i32_e64 %s, 0, v246" % "s[94:95]", "v_cmp_eq_u32_e64 %s, 0, v246" % "s[36:37]",
+               "v_sub_u32_e32 v247, 0, v246", "v_max_i32_e32 v246, v246, v247", "v_max_i32_e32 v246, 1, v246", "v_subrev_u32_e32 v246, 1, v246",
+               "v_mul_lo_u32 v246, v246, s72", "v_add_u32_e32 %s, %s, v246" % (VOFF, LADDR)]
+
+
 def prog_g1_jadd(slot, table):
     """acc <- acc + (the Jacobian point in slots slot..slot+2; table: the record each lane selects, negated / ignored by M_NEGQ / M_ZEROQ):
     add-2007-bl with g1_add's case handling by selection; the old acc goes to AGPR blocks 5..7 for the doubling fix-up"""
@@ -2440,8 +2452,7 @@ def g1_blind_routine():
     ADD, ADDT, DBL4 = 50, 53, 54
     pro = ["s_mov_b64 s[80:81], s[30:31]", "s_waitcnt vmcnt(0)"] + shell_constants() + ["s_mov_b64 %s, exec" % EXEC_ALL,
            "s_mul_i32 s72, %s, %d" % (GSTRIDE, 12 * 3)]
-    pro += ["v_add_co_u32_e32 v248, vcc, 0x88888888, v248", "v_mov_b32_e32 v247, 0x88888888", "v_addc_co_u32_e32 v249, vcc, v249, v247, vcc",
-            "v_cndmask_b32_e64 v247, 0, 1, vcc"]
+    pro += BLIND_RPRIME
 
     def fixup():
         return ["s_and_b64 s[92:93], %s, %s" % (M_H0, M_R0), "s_andn2_b64 s[92:93], s[92:93], %s" % M_INF1, "s_andn2_b64 s[92:93], s[92:93], %s" % M_INF2,
@@ -2456,12 +2467,9 @@ def g1_blind_routine():
     main += ["s_mov_b32 s79, 6", "5:"] + call_sub(ADD) + ["s_add_u32 %s, %s, s72" % (GKOFF, GKOFF)] + X("tab")
     main += ["s_sub_u32 s79, s79, 1", "s_cmp_lg_u32 s79, 0", "s_cbranch_scc0 2f"] + far_back(5) + ["2:", "s_waitcnt vmcnt(0)"]
     main += X("inf")
-    main += ["s_mov_b64 %s, 0" % M_NEGQ, "v_cmp_eq_u32_e64 %s, 0, v247" % M_ZEROQ, "v_mov_b32_e32 %s, %s" % (VOFF, LADDR)] + call_sub(ADDT)
+    main += BLIND_TOP + call_sub(ADDT)
     main += ["s_mov_b32 s38, 60", "5:"] + call_far(DBL4)
-    main += ["v_lshrrev_b64 v[246:247], s38, v[248:249]", "v_and_b32_e32 v246, 15, v246", "v_subrev_u32_e32 v246, 8, v246",
-             "v_cmp_gt_i32_e64 %s, 0, v246" % M_NEGQ, "v_cmp_eq_u32_e64 %s, 0, v246" % M_ZEROQ,
-             "v_sub_u32_e32 v247, 0, v246", "v_max_i32_e32 v246, v246, v247", "v_max_i32_e32 v246, 1, v246", "v_subrev_u32_e32 v246, 1, v246",
-             "v_mul_lo_u32 v246, v246, s72", "v_add_u32_e32 %s, %s, v246" % (VOFF, LADDR)]
+    main += BLIND_DIGIT
     main += call_sub(ADDT)
     main += ["s_cmp_eq_u32 s38, 0", "s_cbranch_scc1 2f", "s_sub_u32 s38, s38, 4"] + far_back(5) + ["2:"]
     epi = ["s_waitcnt vmcnt(0)"]
@@ -2476,7 +2484,7 @@ def g1_blind_routine():
             epi += seq_reduce(Bk) + seq_canonical(Bk) + seq_to32(Bk) + seq_gstore(Bk, 2 * half + h)
     epi += ["s_waitcnt vmcnt(0)", "s_mov_b64 s[30:31], s[80:81]"]
     ret = ["s_setpc_b64 s[30:31]"]
-    pieces = dict(B, pro=pro, epi=epi)
+    pieces = dict(B, pro=pro, epi=epi, rprime=BLIND_RPRIME, top=BLIND_TOP, digit=BLIND_DIGIT)
     return pro + main + expand_calls_d(epi) + ret + dbl4 + subs, pieces, st
 
 
@@ -2496,8 +2504,7 @@ def g2_blind_routine():
     pro = ["s_mov_b64 s[80:81], s[30:31]", "s_waitcnt vmcnt(0)"] + shell_constants() + ["s_mov_b64 %s, exec" % EXEC_ALL,
            "s_mul_i32 s72, %s, %d" % (GSTRIDE, 12 * 6)]
     # r' = r + 0x8888888888888888, its carry is the 17th digit
-    pro += ["v_add_co_u32_e32 v248, vcc, 0x88888888, v248", "v_mov_b32_e32 v247, 0x88888888", "v_addc_co_u32_e32 v249, vcc, v249, v247, vcc",
-            "v_cndmask_b32_e64 v247, 0, 1, vcc"]
+    pro += BLIND_RPRIME
 
     def fixup():
         return ["s_and_b64 s[92:93], %s, %s" % (M_H0, M_R0), "s_andn2_b64 s[92:93], s[92:93], %s" % M_INF1, "s_andn2_b64 s[92:93], s[92:93], %s" % M_INF2,
@@ -2524,12 +2531,9 @@ def g2_blind_routine():
     main += ["s_sub_u32 s79, s79, 1", "s_cmp_lg_u32 s79, 0", "s_cbranch_scc0 2f"] + far_back(5) + ["2:", "s_waitcnt vmcnt(0)"]
     # the windows, top digit (0 or 1) first
     main += X("b_inf")
-    main += ["s_mov_b64 %s, 0" % M_NEGQ, "v_cmp_eq_u32_e64 %s, 0, v247" % M_ZEROQ, "v_mov_b32_e32 %s, %s" % (VOFF, LADDR)] + call_sub(ADDT)
+    main += BLIND_TOP + call_sub(ADDT)
     main += ["s_mov_b32 s38, 60", "5:"] + call_far(DBL4)
-    main += ["v_lshrrev_b64 v[246:247], s38, v[248:249]", "v_and_b32_e32 v246, 15, v246", "v_subrev_u32_e32 v246, 8, v246",          # d = e - 8 in [-8, 7]
-             "v_cmp_gt_i32_e64 %s, 0, v246" % M_NEGQ, "v_cmp_eq_u32_e64 %s, 0, v246" % M_ZEROQ,
-             "v_sub_u32_e32 v247, 0, v246", "v_max_i32_e32 v246, v246, v247", "v_max_i32_e32 v246, 1, v246", "v_subrev_u32_e32 v246, 1, v246",
-             "v_mul_lo_u32 v246, v246, s72", "v_add_u32_e32 %s, %s, v246" % (VOFF, LADDR)]
+    main += BLIND_DIGIT
     main += call_sub(ADDT)
     main += ["s_cmp_eq_u32 s38, 0", "s_cbranch_scc1 2f", "s_sub_u32 s38, s38, 4"] + far_back(5) + ["2:"]
     # [r] P -> slots 25..30, canonical words of the 2^384 domain
@@ -2544,7 +2548,7 @@ def g2_blind_routine():
             epi += seq_reduce(Bk) + seq_canonical(Bk) + seq_to32(Bk) + seq_gstore(Bk, BL_OUT + 2 * i + h)
     epi += ["s_waitcnt vmcnt(0)", "s_mov_b64 s[30:31], s[80:81]"]
     ret = ["s_setpc_b64 s[30:31]"]
-    pieces = dict(B, pro=pro, epi=epi)
+    pieces = dict(B, pro=pro, epi=epi, rprime=BLIND_RPRIME, top=BLIND_TOP, digit=BLIND_DIGIT)
     return pro + main + expand_calls_d(epi) + ret + lad + dbl4 + subs, pieces, st
 
 
