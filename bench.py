@@ -36,6 +36,8 @@ P = 0x1a0111ea397fe69a4b1ba7b6434bacd764774b84f38512bf6730d2a0f6b0f6241eabfffeb1
 SEED = 0x6D626C73          # "mbls" 
 POOL = 4096
 HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s peak
+PHASE_REPS = 5             # calls of the per-kernel timing pass that count (after 2 discarded ones)
+PEAK_CLOCK_GHZ = 2.4       # MI355X peak engine clock (the guide's figure): only used to express ns per instruction as "clocks at peak"
 N_SIMD = 256 * 4           # 256 CUs x 4 SIMDs
 
 
@@ -327,8 +329,89 @@ def valu_issue_figure(lib, ctx, phase_ms, n_items, agg_kernel="k_aggregate"):
         total, mad = c["valu"], c["mad_u64_u32"]
         ach = total * n_items / 64.0 / (phase_ms[phase] * 1e-3) / N_SIMD
         ceil = total / (mad / rate["v_mad_u64_u32"] + (total - mad) / rate["plain_valu"])
-        out["kernels"][kern] = {"valu_wave_instr_per_item": total, "of_which_v_mad_u64_u32": mad, "achieved": ach, "ceiling": ceil, "frac": ach / ceil}
+        ns = 1e9 / ach                                                  # SIMD time per wave-instruction
+        out["kernels"][kern] = {"valu_wave_instr_per_item": total, "of_which_v_mad_u64_u32": mad, "achieved": ach, "ceiling": ceil, "frac": ach / ceil,
+                                "ns_per_valu_instr": ns, "clk_per_valu_instr": ns * PEAK_CLOCK_GHZ,
+                                "clk_note": "ns x %.1f GHz peak clock; the clock under this instruction mix is lower, see DESIGN.md section 4" % PEAK_CLOCK_GHZ}
     return out
+
+
+def _med_ms(f, reps=5, warm=2):
+    for _ in range(warm):
+        f()
+    ts = []
+    for _ in range(reps):
+        torch.cuda.synchronize(); t = time.perf_counter(); f(); torch.cuda.synchronize(); ts.append((time.perf_counter() - t) * 1e3)
+    return float(np.median(ts))
+
+
+def other_configs(ctx, lib, dev, sptr):
+    """BASELINE configs[1] (2^16 x Signature::verify) and configs[3] (verify_multiple, 2^14 sets x 128 keys, against the same sets one by
+    one), and the small-batch latency of the hot path: median of 5 enqueue + synchronise calls, inputs resident in HBM, results checked"""
+    from milagro_bls_amd import batch
+    out = {"_unit": "ms per call (median of 5 after 2 warm-ups), inputs resident in HBM"}
+    n = 1 << 16
+    c_sigs, c_msgs, c_pks, c_exp = build_inputs(ctx, dev, n, 1, N.PK_COMPRESSED, rank=11)
+    c_res = torch.zeros(n, dtype=torch.uint8, device=dev)
+
+    def f_c2():
+        ctx.check(lib.mbls_verify_batch_device(ctx.handle, c_sigs.data_ptr(), c_msgs.data_ptr(), 32, None, c_pks.data_ptr(), N.PK_COMPRESSED, n, c_res.data_ptr(), None, None, sptr))
+    t = _med_ms(f_c2)
+    out["configs[1] 2^16 x Signature::verify (compressed key)"] = {"ms": t, "verify_per_s": n / t * 1e3, "correct": bool(torch.equal(c_res.cpu(), c_exp))}
+    k = 128
+    for nn in (1 << 14, 1 << 16):
+        v_sigs, v_msgs, v_pks, v_exp = build_inputs(ctx, dev, nn, k, N.PK_UNCOMPRESSED, rank=12, negatives=False)
+        g = torch.Generator(device="cpu"); g.manual_seed(7)
+        rands = torch.randint(1, (1 << 62), (nn,), dtype=torch.int64, generator=g).to(dev)
+        d_r = torch.full((8,), 7, dtype=torch.uint8, device=dev)
+
+        def f_c4():
+            batch.verify_multiple_sets_device(v_sigs.data_ptr(), v_pks.data_ptr(), v_msgs.data_ptr(), rands.data_ptr(), nn, k, pk_format=N.PK_UNCOMPRESSED,
+                                              d_result=d_r.data_ptr(), stream=sptr)
+        t4 = _med_ms(f_c4)
+        ok_true = int(d_r[0].item()) == 1
+        v_msgs[nn // 3, 5] ^= 0x10; f_c4(); torch.cuda.synchronize(); ok_false = int(d_r[0].item()) == 0; v_msgs[nn // 3, 5] ^= 0x10
+        v_res = torch.zeros(nn, dtype=torch.uint8, device=dev)
+
+        def f_one():
+            ctx.check(lib.mbls_fast_aggregate_verify_batch_device(ctx.handle, v_sigs.data_ptr(), v_msgs.data_ptr(), 32, None, v_pks.data_ptr(), N.PK_UNCOMPRESSED, None, nn, k,
+                                                                  v_res.data_ptr(), None, None, sptr))
+        t1 = _med_ms(f_one)
+        name = "configs[3] verify_multiple 2^14 sets x 128 keys" if nn == (1 << 14) else "verify_multiple 2^16 sets x 128 keys"
+        out[name] = {"ms": t4, "sets_per_s": nn / t4 * 1e3, "same_sets_one_by_one_ms": t1, "correct": bool(ok_true and ok_false and v_res.all().item())}
+        if nn == (1 << 14):
+            lat = {}
+            for m in (1, 64, 1024, 4096):
+                l_res = torch.zeros(m, dtype=torch.uint8, device=dev)
+
+                def f_l():
+                    ctx.check(lib.mbls_fast_aggregate_verify_batch_device(ctx.handle, v_sigs.data_ptr(), v_msgs.data_ptr(), 32, None, v_pks.data_ptr(), N.PK_UNCOMPRESSED, None, m, k,
+                                                                          l_res.data_ptr(), None, None, sptr))
+                lat[str(m)] = _med_ms(f_l)
+                assert bool(l_res.all().item())
+            out["latency fast_aggregate_verify (128 keys) by batch size"] = lat
+    return out
+
+
+def config5_leg(ctx, lib, dev, sptr, rank, world, k):
+    """2^17 items on this rank (2^20 over 8 GPUs) + the bitmap gather: 3 timed steps"""
+    n = 1 << 17
+    d_sigs, d_msgs, d_pks, expect = build_inputs(ctx, dev, n, k, N.PK_UNCOMPRESSED, rank + 100)
+    ctx.reserve(n)
+    words = n // 64
+    d_res = torch.zeros(n, dtype=torch.uint8, device=dev); d_bm = torch.zeros(words, dtype=torch.int64, device=dev)
+    d_all = torch.zeros(words * world, dtype=torch.int64, device=dev)
+
+    def step():
+        ctx.check(lib.mbls_fast_aggregate_verify_batch_device(ctx.handle, d_sigs.data_ptr(), d_msgs.data_ptr(), 32, None, d_pks.data_ptr(), N.PK_UNCOMPRESSED, None,
+                                                              n, k, d_res.data_ptr(), d_bm.data_ptr(), None, sptr))
+        shard.all_gather_bitmap(d_bm, world, out=d_all)
+    steps = 3
+    elapsed = timed_steps(step, steps, 1, world, torch.cuda.synchronize)
+    ok = reduce_all_ok(check_bitmap(d_res, d_bm, expect) and check_gathered(d_all, world, words, d_bm, rank), world)
+    return {"workload": "configs[4]: 2^20 fast_aggregate_verify sharded over 8 GPUs (2^17 per rank), RCCL gather of the accept bitmap",
+            "value": n * world * steps / elapsed, "unit": "fast_aggregate_verify/s", "ms_per_step": elapsed / steps * 1e3, "steps": steps,
+            "bitmap_matches_expectation": ok}
 
 
 def git_head():
@@ -437,16 +520,17 @@ def main():
         if world > 1:
             ok = ok and check_gathered(d_all, world, words, d_bm, rank)
         ok = reduce_all_ok(ok, world)
-        # per-kernel timing with HIP events on the launch stream (separate, untimed pass)
+        # per-kernel timing with HIP events on the launch stream (separate, untimed pass): 2 discarded warm-ups (the events make every
+        # call synchronise, which lets the clocks settle differently from the free-running timed loop), then the median of 5
         lib.mbls_enable_phase_timing(ctx.handle, 1)
-        phase = np.zeros(N.N_PHASES, dtype=np.float64)
-        reps = max(1, min(3, steps))
-        for _ in range(reps):
+        rows = []
+        for it in range(2 + PHASE_REPS):
             verify()
             ms = (C.c_float * N.N_PHASES)()
             lib.mbls_last_phase_ms(ctx.handle, ms)
-            phase += np.array(list(ms))
-        phase /= reps
+            if it >= 2:
+                rows.append(list(ms))
+        phase = np.median(np.array(rows, dtype=np.float64), axis=0)
         lib.mbls_enable_phase_timing(ctx.handle, 0)
         return elapsed, ok, {nm: float(v) for nm, v in zip(N.PHASE_NAMES, phase)}
 
@@ -463,6 +547,15 @@ def main():
                               "algorithmic_bytes_per_item": pkb2 + 96 + 32 + 1, "phase_ms": ph2}
             ok = ok and ok2
 
+    other = {}
+    if not args.no_variants and world == 1:
+        other = other_configs(ctx, lib, dev, sptr)
+        ok = ok and all(v.get("correct", True) for v in other.values() if isinstance(v, dict))
+    shard_leg = None
+    if world == 8 and n == (1 << 16):
+        # BASELINE configs[4] as it is named: 2^20 items over 8 GPUs = 2^17 per rank (the default legs above are configs[2] per GPU)
+        shard_leg = config5_leg(ctx, lib, dev, sptr, rank, world, k)
+
     if rank == 0:
         pkb = {"compressed": 48 * k, "uncompressed": 96 * k, "indexed": 4 * k}[args.pk_format]
         bytes_per_item = pkb + 96 + 32 + 1          # algorithmic bytes in + 1 out
@@ -470,7 +563,10 @@ def main():
         value = n * world * args.steps / elapsed
         dom = max((nm for nm in phase_ms), key=lambda nm: phase_ms[nm])
         achieved = n * bytes_per_item / (phase_ms[dom] * 1e-3) / 1e9          # algorithmic GB/s through the dominant kernel
-        cfg_name = "configs[2]" if n == (1 << 16) else ("the configs[4] shard (2^20 items / 8 GPUs)" if n == (1 << 17) else "custom size")
+        cfg_name = ("configs[2]" if world == 1 else "configs[2] on every GPU (weak scaling: %d x 2^16 items)" % world) if n == (1 << 16) else (
+            "the configs[4] shard (2^20 items / 8 GPUs)" if n == (1 << 17) else "custom size")
+        phase_sum = sum(phase_ms.values())
+        phase_pass = "consistent" if abs(phase_sum - ms_per_step) <= 0.02 * ms_per_step or world > 1 else "inconsistent"
         out = {
             "metric": "fast_aggregate_verify/sec (128 pubkeys, 32B msg)", "value": value, "unit": "fast_aggregate_verify/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
@@ -489,7 +585,11 @@ def main():
             "traffic_from_profile": from_profile("hbm_traffic.json", dom),
             "valu_issue": valu_issue_figure(lib, ctx, phase_ms, n, {"uncompressed": "k_aggregate", "indexed": "k_aggregate_indexed"}.get(args.pk_format) if k == 128 else None),
             "phase_ms": phase_ms,
+            "phase_pass": {"verdict": phase_pass, "sum_phase_ms": phase_sum, "ms_per_step": ms_per_step,
+                           "method": "median of %d event-timed calls after 2 discarded ones; 'consistent' = the kernels of one in-order stream sum to the timed step within 2 %%" % PHASE_REPS},
             "variants": variants,
+            "other_configs": other,
+            "configs4_shard_leg": shard_leg,
             "input_build_s": t_in,
             "head": git_head(),
         }

@@ -5,6 +5,15 @@ import csv, collections, json, shutil, sys
 tag, stats, fetch, write, sq, bench = sys.argv[1:7]
 import glob
 shutil.copy(glob.glob(stats + "/*_kernel_stats.csv")[0], "profiles/%s_kernel_stats.csv" % tag)
+import os
+for cfg, name in (("c2", "config2"), ("c4", "config4"), ("clat", "latency_n64")):          # BASELINE configs[1], configs[3], the small-batch path
+    g = glob.glob(os.path.dirname(stats.rstrip("/")) + "/stats_%s/*_kernel_stats.csv" % cfg)
+    if g:
+        shutil.copy(g[0], "profiles/%s_%s_kernel_stats.csv" % (tag, name))
+for extra in ("latency.json", "kstats.txt", "bench_line_131072.json"):
+    src = os.path.join(os.path.dirname(stats.rstrip("/")), extra)
+    if os.path.exists(src):
+        shutil.copy(src, "profiles/%s_%s" % (tag, {"kstats.txt": "kernel_resources.txt"}.get(extra, extra)))
 PHASE = {"k_aggregate_raw_d": "aggregate", "k_aggregate": "aggregate", "k_sig": "sig", "k_hash": "hash", "k_miller": "miller", "k_final": "final"}
 shutil.copy(bench, "profiles/%s_bench_line.json" % tag)
 out = {"_units": "FETCH_SIZE/WRITE_SIZE raw counter values are KB per dispatch (rocprofv3); hbm bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 per the "

@@ -3,7 +3,7 @@
 #   bash scripts/profile_round.sh r02
 # 1. rocprofv3 kernel trace + stats of a bench run, 2./3. HBM traffic counters in separate passes (FETCH_SIZE, WRITE_SIZE cannot share
 # a pass), 4. SQ counters, 5. the bench line itself (with the CPU legs), 6. code-object metadata (registers, scratch).
-TAG=${1:-r02}
+TAG=${1:-r03}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
@@ -11,6 +11,9 @@ export TMPDIR=/tmp
 B="python3 $ROOT/bench.py --no-cpu-baseline --no-variants"
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o $TAG -- $B --steps 5 --warmup 1 > $OUT/stats_bench.json 2> $OUT/stats.err
+for CFG in 2 4 lat; do
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_c$CFG -o c$CFG -- python3 $ROOT/scripts/run_config.py $CFG > /dev/null 2> $OUT/stats_c$CFG.err
+done
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -o f -- $B --steps 2 --warmup 1 > /dev/null 2> $OUT/fetch.err
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -o w -- $B --steps 2 --warmup 1 > /dev/null 2> $OUT/write.err
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU --output-format csv -d $OUT/sq -o s -- $B --steps 2 --warmup 1 > /dev/null 2> $OUT/sq.err
@@ -18,6 +21,7 @@ rocprofv3 --pmc GRBM_GUI_ACTIVE --output-format csv -d $OUT/grbm -o g -- $B --st
 cd $ROOT
 python3 bench.py --steps 10 --warmup 2 > $OUT/bench_line.json 2> $OUT/bench.err
 python3 bench.py --items 131072 --steps 5 --warmup 1 --no-cpu-baseline > $OUT/bench_line_131072.json 2>> $OUT/bench.err
+python3 scripts/latency.py $OUT/latency.json > $OUT/latency.log 2>&1
 bash scripts/kstats.sh > $OUT/kstats.txt 2>&1
 find $OUT -name "*.csv" -size +20M -delete
 ls -la $OUT $OUT/stats $OUT/fetch 2>/dev/null | head -40
