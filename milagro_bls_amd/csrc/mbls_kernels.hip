@@ -282,6 +282,21 @@ __global__ void MBLS_LB k_g2_tree(mbls_ws ws, uint64_t m, uint64_t half) {
     g2_add(&a, &a, &b);
     ws_st2(ws, MBLS_SLOT_S, i, a.x); ws_st2(ws, MBLS_SLOT_S + 2, i, a.y); ws_st2(ws, MBLS_SLOT_S + 4, i, a.z);
 }
+// the same levels as generated routines (no lane-private memory)
+__global__ void MBLS_LB k_f12_tree_d(mbls_ws ws, uint64_t m, uint64_t half) {
+#if MBLS_DEVICE_ASM && !defined(MBLS_NO_FP2_ASM) && !defined(MBLS_NO_LDS_STATE)
+    __shared__ uint32_t spill[154 * 64];
+    uint64_t i = gid(); if (i + half >= m || i >= half) return;
+    tree_level_d_call<false>(ws, i, half, (MBLS_LDS uint32_t*)spill, threadIdx.x);
+#endif
+}
+__global__ void MBLS_LB k_g2_tree_d(mbls_ws ws, uint64_t m, uint64_t half) {
+#if MBLS_DEVICE_ASM && !defined(MBLS_NO_FP2_ASM) && !defined(MBLS_NO_LDS_STATE)
+    __shared__ uint32_t spill[154 * 64];
+    uint64_t i = gid(); if (i + half >= m || i >= half) return;
+    tree_level_d_call<true>(ws, i, half, (MBLS_LDS uint32_t*)spill, threadIdx.x);
+#endif
+}
 __global__ void MBLS_LB k_status_or(const uint32_t* status, uint64_t n, uint32_t* out) {
     uint64_t i = gid(); uint32_t v = (i < n) ? status[i] : 0;
     if (__ballot(v != 0)) { if (v) atomicOr(out, v); }
@@ -368,7 +383,7 @@ struct mbls_ctx {
     hipEvent_t ev[MBLS_N_PHASES + 1] = {};
     float phase_ms[MBLS_N_PHASES] = {};
     std::vector<struct mbls_keytable*> tables;     // the key tables created on this context (orphaned when it is destroyed)
-    coop_prog coop[4] = {};            // the cooperative engine's microprograms in HBM (mbls_coop.h): pairing2, vmtail, f12mul, g2add
+    coop_prog coop[6] = {};            // the cooperative engine's microprograms in HBM (mbls_coop.h): pairing2, vmtail, f12mul, g2add, smiller, vmfinal
     uint32_t* d_coop = nullptr;
     uint64_t coop_max_items = 4096;    // batches up to this size take the one-wave-per-item pairing check (latency path: 13 ms at 4096 against 22)
     char err[256] = {};
@@ -433,10 +448,11 @@ extern "C" int mbls_ctx_create(mbls_ctx** out, int device_id) {
     if (ok) {       // the cooperative engine's programs: one upload per context
 #define COOP_SRC(P) {MBLS_COOP_##P##_STEPS, MBLS_COOP_##P##_ROWS, MBLS_COOP_##P##_CONSTS}
 #define COOP_CNT(P) {2 * MBLS_COOP_##P##_NSTEPS, 512 * MBLS_COOP_##P##_NROWS, 15 * (MBLS_COOP_##P##_NCONSTS ? MBLS_COOP_##P##_NCONSTS : 1)}
-        const int NP = 4;
-        const uint32_t* src[NP][3] = {COOP_SRC(PAIRING2), COOP_SRC(VMTAIL), COOP_SRC(F12MUL), COOP_SRC(G2ADD)};
-        const size_t cnt[NP][3] = {COOP_CNT(PAIRING2), COOP_CNT(VMTAIL), COOP_CNT(F12MUL), COOP_CNT(G2ADD)};
-        const uint32_t nconst[NP] = {MBLS_COOP_PAIRING2_NCONSTS, MBLS_COOP_VMTAIL_NCONSTS, MBLS_COOP_F12MUL_NCONSTS, MBLS_COOP_G2ADD_NCONSTS};
+        const int NP = 6;
+        const uint32_t* src[NP][3] = {COOP_SRC(PAIRING2), COOP_SRC(VMTAIL), COOP_SRC(F12MUL), COOP_SRC(G2ADD), COOP_SRC(SMILLER), COOP_SRC(VMFINAL)};
+        const size_t cnt[NP][3] = {COOP_CNT(PAIRING2), COOP_CNT(VMTAIL), COOP_CNT(F12MUL), COOP_CNT(G2ADD), COOP_CNT(SMILLER), COOP_CNT(VMFINAL)};
+        const uint32_t nconst[NP] = {MBLS_COOP_PAIRING2_NCONSTS, MBLS_COOP_VMTAIL_NCONSTS, MBLS_COOP_F12MUL_NCONSTS, MBLS_COOP_G2ADD_NCONSTS, MBLS_COOP_SMILLER_NCONSTS,
+                                     MBLS_COOP_VMFINAL_NCONSTS};
         size_t total = 0;
         for (int p = 0; p < NP; p++) for (int a = 0; a < 3; a++) total += (cnt[p][a] + 3) & ~(size_t)3;       // 16-byte aligned pieces (the rows are read as uint4)
         ok = hipMalloc(&c->d_coop, total * 4) == hipSuccess;
@@ -1102,7 +1118,7 @@ extern "C" int mbls_fast_aggregate_verify_pre_aggregated(mbls_ctx* c, const uint
 static void f12_tree(mbls_ctx* c, mbls_ws ws, uint64_t m, hipStream_t s) {
     while (m > 1) {
         const uint64_t half = (m + 1) / 2, pairs = m - half;
-        if (pairs > MBLS_COOP_TREE_PAIRS) hipLaunchKernelGGL(k_f12_tree, dim3(nblk(half)), dim3(WG), 0, s, ws, m, half);
+        if (pairs > MBLS_COOP_TREE_PAIRS) hipLaunchKernelGGL(k_f12_tree_d, dim3(nblk(half)), dim3(WG), 0, s, ws, m, half);
         else hipLaunchKernelGGL(k_coop, dim3((unsigned)pairs), dim3(64), 0, s, c->coop[2], ws, (uint64_t)0, (uint64_t)1, half, pairs, (uint32_t*)nullptr, (uint8_t*)nullptr, COOP_RES_ITEM);
         m = half;
     }
@@ -1110,7 +1126,7 @@ static void f12_tree(mbls_ctx* c, mbls_ws ws, uint64_t m, hipStream_t s) {
 static void g2_tree(mbls_ctx* c, mbls_ws ws, uint64_t m, hipStream_t s) {
     while (m > 1) {
         const uint64_t half = (m + 1) / 2, pairs = m - half;
-        if (pairs > MBLS_COOP_TREE_PAIRS) hipLaunchKernelGGL(k_g2_tree, dim3(nblk(half)), dim3(WG), 0, s, ws, m, half);
+        if (pairs > MBLS_COOP_TREE_PAIRS) hipLaunchKernelGGL(k_g2_tree_d, dim3(nblk(half)), dim3(WG), 0, s, ws, m, half);
         else hipLaunchKernelGGL(k_coop, dim3((unsigned)pairs), dim3(64), 0, s, c->coop[3], ws, (uint64_t)0, (uint64_t)1, half, pairs, (uint32_t*)nullptr, (uint8_t*)nullptr, COOP_RES_ITEM);
         m = half;
     }
@@ -1119,11 +1135,14 @@ static void g2_tree(mbls_ctx* c, mbls_ws ws, uint64_t m, hipStream_t s) {
 // workspace holds, for items 0..n-1, H_i (slot H) and P_i (slot APK); S (the (S, -G1) pair's G2 point) in slot S of item 0; the OR of
 // every status word in d_scalar[0]. Everything is enqueued on s: one Miller loop per lane, the product tree, and ONE wave for the tail --
 // the Miller loop of (S, -G1), the product, the single final exponentiation, the comparison and the status bits (program vmtail).
-static int npairing_finish(mbls_ctx* c, uint64_t n, hipStream_t s, uint8_t* d_result) {
+static int npairing_finish(mbls_ctx* c, uint64_t n, hipStream_t s, uint8_t* d_result, hipEvent_t s_miller_ev = nullptr) {
+    const bool s_miller_done = s_miller_ev != nullptr;
     mbls_ws ws; ws.w = c->d_w; ws.stride = c->cap;
     hipLaunchKernelGGL(k_miller_single, dim3(nblk(n)), dim3(WG), 0, s, ws, n, 0, (uint64_t)0);
     f12_tree(c, ws, n, s);
-    hipLaunchKernelGGL(k_coop, dim3(1), dim3(64), 0, s, c->coop[1], ws, (uint64_t)0, (uint64_t)1, (uint64_t)0, (uint64_t)1, c->d_scalar, d_result, COOP_RES_BATCH);
+    // s_miller_done: the Miller value of (S, -G1) is left in slots 97..108 of item 0 by program smiller, running beside the chains
+    if (s_miller_done) HIPCHK(c, hipStreamWaitEvent(s, s_miller_ev, 0));
+    hipLaunchKernelGGL(k_coop, dim3(1), dim3(64), 0, s, c->coop[s_miller_done ? 5 : 1], ws, (uint64_t)0, (uint64_t)1, (uint64_t)0, (uint64_t)1, c->d_scalar, d_result, COOP_RES_BATCH);
     HIPCHK(c, hipGetLastError());
     return MBLS_OK;
 }
@@ -1196,15 +1215,20 @@ static int verify_multiple_impl(mbls_ctx* c, const uint8_t* d_sigs, const uint8_
     hipLaunchKernelGGL(k_blind_g1_d, dim3(nblk(n)), dim3(WG), 0, s, ws, d_apks, d_rands, c->d_status, n);
     hipLaunchKernelGGL(k_blind_sig_d, dim3(nblk(n)), dim3(WG), 0, s_sig, ws, d_sigs, d_rands, c->d_status, n);
     g2_tree(c, ws, n, s_sig);
+    if (fork) {     // S is complete: its Miller loop runs on one wave beside the other chains and the sets' Miller loops (most SIMDs are idle)
+        HIPCHK(c, hipEventRecord(c->hs_ev2, s_sig));                 // the status bits and S exist
+        hipLaunchKernelGGL(k_coop, dim3(1), dim3(64), 0, s_sig, c->coop[4], ws, (uint64_t)0, (uint64_t)1, (uint64_t)0, (uint64_t)1, (uint32_t*)nullptr, (uint8_t*)nullptr, COOP_RES_ITEM);
+        HIPCHK(c, hipEventRecord(c->hs_ev, s_sig));                  // ... and its Miller value (awaited just before the tail)
+    }
     hipLaunchKernelGGL(k_hash, dim3(nblk(n)), dim3(WG), 0, s_msg, ws, d_msgs, msg_len, d_moff, c->d_status, n);
     if (fork) {
-        HIPCHK(c, hipEventRecord(c->hs_ev2, s_sig)); HIPCHK(c, hipEventRecord(c->hs_ev3, s_msg));
+        HIPCHK(c, hipEventRecord(c->hs_ev3, s_msg));
         HIPCHK(c, hipStreamWaitEvent(s, c->hs_ev2, 0)); HIPCHK(c, hipStreamWaitEvent(s, c->hs_ev3, 0));
     }
     hipLaunchKernelGGL(k_status_or, dim3(nblk(n)), dim3(WG), 0, s, c->d_status, n, c->d_scalar);
     // a set whose signature is outside G2 (reference src/aggregates.rs:274-276), an undecodable member or a zero scalar makes the tail
     // answer false: the status bits are folded in on the device, the call only enqueues
-    rc = npairing_finish(c, n, s, d_result); if (rc) return rc;
+    rc = npairing_finish(c, n, s, d_result, fork ? c->hs_ev : nullptr); if (rc) return rc;
     if (d_status_or) HIPCHK(c, hipMemcpyAsync(d_status_or, c->d_scalar, 4, hipMemcpyDeviceToDevice, s));
     return ws_release(c, s);
 }

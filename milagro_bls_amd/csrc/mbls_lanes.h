@@ -208,6 +208,30 @@ MBLS_FN uint32_t g2_group_d_call(const mbls_ws& ws, uint64_t i, MBLS_LDS uint32_
         asm volatile(MBLS_ASM_CALL("mbls_g2_subgroup_d_asm_fn") : "+{v251}"(fl) : "{v252}"(addr), "{s68}"(gb_lo), "{s69}"(gb_hi), "{s70}"(st4) : MBLS_G2_GROUP_D_ASM_CLOBBERS);
     return fl;
 }
+// One level of the n-pairing paths' trees with one lane per product (tools/gen_tower_d.py f12_tree_routine / g2_tree_routine): the lane's
+// Miller value (slots 13..24) times / its G2 sum (slots 25..30) plus the one of the item `half` further on.
+extern "C" __device__ __attribute__((noinline, used, aligned(64))) void mbls_f12_tree_d_asm_fn() { asm volatile(MBLS_F12_TREE_D_ASM); }
+extern "C" __device__ __attribute__((noinline, used, aligned(64))) void mbls_g2_tree_d_asm_fn() { asm volatile(MBLS_G2_TREE_D_ASM); }
+template <bool G2>
+MBLS_FN void tree_level_d_call(const mbls_ws& ws, uint64_t i, uint64_t half, MBLS_LDS uint32_t* spill, uint32_t lane) {
+    const uint32_t addr = (uint32_t)(uintptr_t)(spill + lane);
+    const uint64_t gb = (uint64_t)(uintptr_t)ws.w + 4ull * (i - lane) - (uint64_t)(uint32_t)(uintptr_t)spill;
+    const uint32_t gb_lo = __builtin_amdgcn_readfirstlane((uint32_t)gb), gb_hi = __builtin_amdgcn_readfirstlane((uint32_t)(gb >> 32));
+    const uint32_t st4 = __builtin_amdgcn_readfirstlane((uint32_t)(ws.stride * 4));
+    const uint32_t poff = __builtin_amdgcn_readfirstlane((uint32_t)(half * 4));          // the partner's byte offset (half < 2^30 items)
+    if (G2) {
+        asm volatile(MBLS_ASM_CALL("mbls_g2_tree_d_asm_fn") : : "{v252}"(addr), "{s68}"(gb_lo), "{s69}"(gb_hi), "{s70}"(st4), "{s71}"(poff) : MBLS_G2_GROUP_D_ASM_CLOBBERS, "v251");
+    } else {
+        fp f0, f1, f2, f3, f4, f5, f6, f7, f8, f9, f10, f11;
+        asm volatile(MBLS_ASM_CALL("mbls_f12_tree_d_asm_fn")
+                     : MBLS_MILLER_D_OUT_REGS(f)
+                     : "{v252}"(addr), "{s68}"(gb_lo), "{s69}"(gb_hi), "{s70}"(st4), "{s71}"(poff)
+                     : MBLS_FINAL_EXP_D_ASM_CLOBBERS);
+        const fp c[12] = {f0, f1, f2, f3, f4, f5, f6, f7, f8, f9, f10, f11};
+#pragma unroll
+        for (int t = 0; t < 12; t++) ws_st(ws, MBLS_SLOT_F + t, i, c[t]);
+    }
+}
 // [r] P for the Jacobian G1 point in slots 0..2 (verify_multiple's g1mul(apk_i, r_i), reference src/aggregates.rs:293), back into slots 0..2:
 // the generated windowed routine (tools/gen_tower_d.py g1_blind_routine)
 extern "C" __device__ __attribute__((noinline, used, aligned(64))) void mbls_g1_blind_d_asm_fn() { asm volatile(MBLS_G1_BLIND_D_ASM); }

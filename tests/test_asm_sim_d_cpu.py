@@ -653,7 +653,8 @@ def g2_piece_runner(kind):
     m.run(pieces["pro"])
     state, masks = {}, {}
     ad = t.G2_SLOTS["AD"] if kind == "hash" else t.G2_SLOTS["SIGAD"]
-    progs = {"add": lambda: t.prog_g2_add(ad, False), "sub": lambda: t.prog_g2_add(ad, True), "dbl": t.prog_g2_dbl_d, "fix": lambda: t.prog_g2_dbl_d(6, 0)}
+    progs = {"add": lambda: t.prog_g2_add(ad, False), "sub": lambda: t.prog_g2_add(ad, True), "dbl": t.prog_g2_dbl_d, "fix": lambda: t.prog_g2_dbl_d(6, 0),
+             "madd": lambda: t.prog_g2_madd(ad)}
 
     def step(name):
         m.run(pieces[name])
@@ -678,7 +679,7 @@ def g2_piece_runner(kind):
             for _ in range(n_):
                 step("dbl")
             if ph < len(runs) - 1:
-                add()
+                add("add" if kind == "hash" else "madd")             # the signature routine adds its affine base point
     return m, state, masks, step, add, ladder
 
 
@@ -920,7 +921,7 @@ def _blind_run(kind, r, ws_init, out_slots):
             for _ in range(n_):
                 m.run(pieces["dbl"])
             if ph < 5:
-                add("add")
+                add("madd")
         m.run(pieces["s_compare"])
         pr = lambda nm: m.s[("pair", int(nm[2:nm.index(":")]))]
         ex, ey, ia, ib = pr(t.M_H0), pr(t.M_R0), pr(t.M_INF1), pr(t.M_INF2)
@@ -928,7 +929,7 @@ def _blind_run(kind, r, ws_init, out_slots):
     start, tab, inf = ("start", "tab", "inf") if kind == "g1" else ("b_start", "b_tab", "b_inf")
     m.run(pieces[start]); m.s[71] = 0; m.run(pieces[tab]); m.run(pieces["dbl"]); m.s[71] = m.s[72]; m.run(pieces[tab])
     for _ in range(6):
-        add("add"); m.s[71] += m.s[72]; m.run(pieces[tab])
+        add("add" if kind == "g1" else "madd"); m.s[71] += m.s[72]; m.run(pieces[tab])
     m.run(pieces[inf]); m.run(pieces["top"]); add("addt")
     for shift in range(60, -4, -4):
         for _ in range(4):

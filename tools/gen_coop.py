@@ -837,6 +837,52 @@ def prog_vmtail():
     return m
 
 
+WS_G = 97                                # slots 97..108 of item 0: the Miller value of (S, -G1) between `smiller` and `vmfinal`
+
+
+def prog_smiller():
+    """The first half of vmtail on its own, for batches that run their chains side by side: as soon as S = sum r_i sig_i exists (slots
+    25..30 of item 0), one wave walks the Miller loop of (S, -G1) and leaves its value in slots 97..108 -- beside the sets' Miller loops."""
+    m = Machine("smiller")
+    skip, tmp = m.flag("skip"), m.flag("tmp")
+    b = m.block("load")
+    s = [b.loadw("sj%d" % i, WS_S + i) for i in range(6)]
+    b.iszero2((s[4], s[5]), skip, tmp)
+    Sx, Sy, Sz = (s[0], s[1]), (s[2], s[3]), (s[4], s[5])
+    qx = b.mul2(Sx, Sz); qz = b.mul2(b.sqr2(Sz), Sz)
+    for i, v in enumerate([qx[0], qx[1], Sy[0], Sy[1], qz[0], qz[1]]):
+        b.out("q%d" % i, v); b.out("t%d" % i, v)
+    one = b.const(ONE_D)
+    masked_p(b, m, skip, b.const(NPX0_D), b.const(PY0_D), one, "p")
+    for i in range(12):
+        b.out("f%d" % i, one if i == 0 else LC())
+    build_miller(m, [dict(T="t", Q="q", affine=False, P="p")])
+    b = m.block("store")
+    f = flat12(ld12(b))
+    for i in range(12):
+        b.storew(f[i], WS_G + i)
+    m.run("load"); run_miller(m); m.run("store")
+    return m
+
+
+def prog_vmfinal():
+    """The second half: (product of the sets' Miller values, slots 13..24) * conj(the value `smiller` left in 97..108), ONE final
+    exponentiation, == 1, the batch's status bits"""
+    m = Machine("vmfinal")
+    b = m.block("load")
+    for i in range(12):
+        b.loadw("g%d" % i, WS_F + i)
+        b.loadw("f%d" % i, WS_G + i)
+    b = m.block("join")
+    st12(b, T.mul12(b, ld12(b, "g"), ld12(b), conj_b=True))
+    build_final_exp(m)
+    ok = m.flag("ok")
+    b = is_one_block(m, "isone", ok)
+    b.result(ok)
+    m.run("load"); m.run("join"); run_final_exp(m); m.run("isone")
+    return m
+
+
 def prog_f12tree():
     """item 0's Miller value <- the product of the Miller values of up to 64 consecutive items (workspace slots 13..24), for the product
     trees of the n-pairing paths: the kernel maps lane groups to items; here: state f <- f * g, a block the kernel runs log-many times with
@@ -913,7 +959,7 @@ def prog_g2add():
     return m
 
 
-PROGRAMS = {"pairing2": prog_pairing2, "vmtail": prog_vmtail, "f12mul": prog_f12tree, "g2add": prog_g2add}
+PROGRAMS = {"pairing2": prog_pairing2, "vmtail": prog_vmtail, "f12mul": prog_f12tree, "g2add": prog_g2add, "smiller": prog_smiller, "vmfinal": prog_vmfinal}
 
 
 def emit_c(name, comp):

@@ -2221,6 +2221,35 @@ BL_FREE_V = list(range(9, 17))       # block 17 (v238..v251) belongs to the shel
 M_NEGQ, M_ZEROQ = "s[94:95]", "s[36:37]"
 
 
+def prog_g2_madd(ad_slot):
+    """acc <- acc + (x, y, 1): the MIXED addition for a base point that is affine -- the signature in the ladder of its subgroup test and in
+    the table of its blinding (slots ad_slot..ad_slot+3 hold x, y; the Z = 1 in +4, +5 is not read): 11 products instead of 16
+    (madd-2007-bl). Same masks and old-acc copy as prog_g2_add; the affine operand is never infinite."""
+    p = Prog()
+    A = pt_live_in(p, "a", 0)
+    l = [p.live_in(("gd", ad_slot + i)) for i in range(4)]
+    Qx, Qy = (l[0], l[1]), (l[2], l[3])
+    z1z1 = p.sqr2(A[2])
+    u2 = p.mul2(Qx, z1z1)
+    s2 = p.mul2(p.mul2(Qy, A[2]), z1z1)
+    h = p.sub2(u2, A[0])
+    rr = p.dbl2(p.sub2(s2, A[1]))
+    p.iszero2(h, M_H0, G2M_TMP0); p.iszero2(rr, M_R0, G2M_TMP0)
+    p.iszero2(A[2], M_INF1, G2M_TMP0)
+    p.mask_and(M_INF2, M_INF1, M_INF1); p.mask_xor(M_INF2, M_INF2, M_INF1)           # the affine operand is finite: M_INF2 = 0
+    i4 = p.sqr2(p.dbl2(h))
+    j, v = p.mul2(h, i4), p.mul2(A[0], i4)
+    X3 = p.sub2(p.sub2(p.sqr2(rr), j), p.dbl2(v))
+    Y3 = p.sub2(p.mul2(rr, p.sub2(v, X3)), p.dbl2(p.mul2(A[1], j)))
+    Z3 = p.dbl2(p.mul2(A[2], h))
+    one = (p.const(ONE_D), p.const(0))
+    out = [p.sel2(M_INF1, o, q) for o, q in zip((X3, Y3, Z3), (Qx, Qy, one))]
+    for i, v_ in enumerate([x for c in A for x in c]):
+        p.store(v_, ("a", 6 + i))
+    pt_store_acc(p, out)
+    return p
+
+
 def prog_g2_glue(which):
     """the point moves between the additions / ladders of the two routines (see g2_hash_tail_d_routine, g2_subgroup_d_routine)"""
     p = Prog()
@@ -2280,6 +2309,8 @@ def build_g2(which, ad_slot=None, free_v=None):
         p = prog_g2_add(ad_slot, which == "sub")
     elif which == "addt":
         p = prog_g2_add(BL_TAB, False, table=True)
+    elif which == "madd":
+        p = prog_g2_madd(ad_slot)
     elif which == "dbl":
         p = prog_g2_dbl_d()
     elif which == "fix":
@@ -2309,7 +2340,7 @@ def g2_group_routine(kind):
     ad = S["AD"] if kind == "hash" else S["SIGAD"]
     B = {}
     st = {}
-    names = ["add", "dbl", "fix"] + (["sswu", "sub", "h_start", "h_base1", "h_after1", "h_psi2", "h_t3", "h_base2", "h_after2", "h_ad_t1", "h_ad_p"] if kind == "hash" else ["s_start", "s_compare"])
+    names = ["add", "dbl", "fix"] + (["sswu", "sub", "h_start", "h_base1", "h_after1", "h_psi2", "h_t3", "h_base2", "h_after2", "h_ad_t1", "h_ad_p"] if kind == "hash" else ["madd", "s_start", "s_compare"])
     for nm in names:
         B[nm], st[nm] = build_g2(nm, ad)
     X = lambda nm: expand_calls_d(B[nm])
@@ -2319,7 +2350,7 @@ def g2_group_routine(kind):
     def fixup():                                    # equal operands (same x, same y, neither at infinity): double the old acc on those lanes
         return ["s_and_b64 s[92:93], %s, %s" % (M_H0, M_R0), "s_andn2_b64 s[92:93], s[92:93], %s" % M_INF1, "s_andn2_b64 s[92:93], s[92:93], %s" % M_INF2,
                 "s_and_b64 s[92:93], s[92:93], exec", "s_cbranch_scc1 3f"] + far_fwd(6) + ["3:", "s_mov_b64 exec, s[92:93]"] + X("fix") + ["6:", "s_mov_b64 exec, %s" % EXEC_ALL]
-    subs = ["%d:" % ADD] + X("add") + fixup() + ["s_setpc_b64 s[98:99]"]
+    subs = ["%d:" % ADD] + X("add" if kind == "hash" else "madd") + fixup() + ["s_setpc_b64 s[98:99]"]      # sig: the base point is affine
     if kind == "hash":
         subs += ["%d:" % SUB] + X("sub") + fixup() + ["s_setpc_b64 s[98:99]"]
     # [|x|] acc with the base in AD: runs of doublings, an addition of the base after each run but the last
@@ -2356,6 +2387,69 @@ def g2_group_routine(kind):
     ret = ["s_setpc_b64 s[30:31]"]                  # the routine's own return: the subroutines follow it
     pieces = dict(B, pro=pro, epi=epi)
     return pro + main + expand_calls_d(epi) + ret + lad + subs, pieces, st          # every internal call is a forward jump
+
+
+# ---- one level of the n-pairing paths' trees with ONE LANE per product (the wide levels; the narrow ones run on the cooperative engine):
+# the lane's item <- its value (op) the value of the item `partner` further on; the partner's byte offset in GKOFF (kinds 'gka').
+def prog_f12_treemul():
+    p = Prog()
+    a = six([p.live_in(("g", FEXP_IN_SLOT + i)) for i in range(12)])            # rematerialisable from their workspace homes
+    b = six([p.live_in(("gka", FEXP_IN_SLOT + i)) for i in range(12)])
+    acc_store(p, mul12(p, a, b))
+    return p
+
+
+def f12_tree_routine():
+    """In:  slots 13..24 of this lane's item and of the item s71 bytes further on (Miller values, 2^384 domain); v252 / s[68:69] / s70 as in the
+    other routines (11 LDS spill slots). Out: their product in v108..v251 (twelve groups of 12 words, canonical, 2^384 domain)."""
+    p = prog_f12_treemul()
+    inb = {v: G_IN for v in p.init_loc}
+    al = AllocD(p, inb, n_lds=11, lds_base=0, a_pool=list(range(NA)))
+    body = al.run()
+    for dst, B in al.stored.items():
+        assert B.vlo >= STATE_IN.vlo and B.vhi <= STATE_IN.vhi and B.dhi <= M28, (dst, B)
+    pro = ["s_mov_b64 s[80:81], s[30:31]", "s_waitcnt vmcnt(0)"] + shell_constants()
+    epi = f_out_epilogue("s[80:81]")
+    return pro + expand_calls_d(body) + expand_calls_d(epi), dict(pro=pro, body=body, epi=epi), al.stats
+
+
+def prog_g2_tree_start():
+    """acc = the lane's own sum (slots 25..30), AD staging slots <- the partner's (both Jacobian, 2^384-domain words)"""
+    p = Prog()
+    own = [prog_reduce(p, p.live_in(("g", BL_OUT + i))) for i in range(6)]
+    oth = [prog_reduce(p, p.live_in(("gka", BL_OUT + i))) for i in range(6)]
+    pt_park(p, [(oth[0], oth[1]), (oth[2], oth[3]), (oth[4], oth[5])], G2_SLOTS["SIGAD"])
+    pt_store_acc(p, [(own[0], own[1]), (own[2], own[3]), (own[4], own[5])])
+    return p
+
+
+def g2_tree_routine():
+    """slots 25..30 of this lane's item <- that point + the same slots of the item s71 bytes further on (g2_add's case handling; slots
+    43..48 are scratch)"""
+    S = G2_SLOTS
+    inb = lambda p: {v: (G2_IN if l[0] == "a" else PACKED if l[0] in ("gd", "gk") else G_IN) for v, l in p.init_loc.items()}
+    bodies = {}
+    for nm, p in (("start", prog_g2_tree_start()), ("add", prog_g2_add(S["SIGAD"], False)), ("fix", prog_g2_dbl_d(6, 0))):
+        al = AllocD(p, inb(p), n_lds=11, lds_base=0, a_pool=list(range(NA)))
+        bodies[nm] = al.run()
+        for dst, B in getattr(al, "stored", {}).items():
+            assert B.vlo >= G2_IN.vlo and B.vhi <= G2_IN.vhi and B.dlo >= 0 and B.dhi <= M28, (nm, dst, B)
+    X = lambda nm: expand_calls_d(bodies[nm])
+    pro = ["s_mov_b64 s[80:81], s[30:31]", "s_waitcnt vmcnt(0)"] + shell_constants() + ["s_mov_b64 %s, exec" % EXEC_ALL]
+    main = X("start") + ["s_waitcnt vmcnt(0)"] + X("add")
+    main += ["s_and_b64 s[92:93], %s, %s" % (M_H0, M_R0), "s_andn2_b64 s[92:93], s[92:93], %s" % M_INF1, "s_andn2_b64 s[92:93], s[92:93], %s" % M_INF2,
+             "s_and_b64 s[92:93], s[92:93], exec", "s_cbranch_scc1 3f"] + far_fwd(6) + ["3:", "s_mov_b64 exec, s[92:93]"] + X("fix") + ["6:", "s_mov_b64 exec, %s" % EXEC_ALL]
+    epi = ["s_waitcnt vmcnt(0)"]
+    B0, B1, B2, B5, B6 = (lambda j: "v%d" % j), (lambda j: "v%d" % (14 + j)), (lambda j: "v%d" % (28 + j)), (lambda j: "v%d" % (70 + j)), (lambda j: "v%d" % (84 + j))
+    epi += ["v_mov_b32_e32 %s, 0x%08x" % (B2(j), dgt) for j, dgt in enumerate(digits_of(K384))]
+    for i in range(3):
+        epi += ["v_accvgpr_read_b32 %s, a%d" % (B0(j), vb(2 * i) + j) for j in range(14)]
+        epi += ["v_accvgpr_read_b32 %s, a%d" % (B1(j), vb(2 * i + 1) + j) for j in range(14)]
+        epi += ["CALL mbls_fp2_mulfp_d_asm_fn"]
+        for h, Bk in ((0, B5), (1, B6)):
+            epi += seq_reduce(Bk) + seq_canonical(Bk) + seq_to32(Bk) + seq_gstore(Bk, BL_OUT + 2 * i + h)
+    epi += ["s_waitcnt vmcnt(0)", "s_mov_b64 s[30:31], s[80:81]"]
+    return pro + main + expand_calls_d(epi), dict(bodies, pro=pro, epi=epi), {}
 
 
 # ---- [r] apk for verify_multiple (reference src/aggregates.rs:293): the same signed 4-bit windows in G1
@@ -2497,7 +2591,7 @@ def g2_blind_routine():
     Out: v251 = 1 iff psi(P) = [x]P; slots 25..30 = [r] P (Jacobian, canonical, 2^384 domain). Slots 43..48, 49..96 are scratch."""
     S = G2_SLOTS
     B, st = {}, {}
-    for nm in ["add", "addt", "dbl", "fix", "s_start", "s_compare", "b_tab", "b_start", "b_inf"]:
+    for nm in ["madd", "addt", "dbl", "fix", "s_start", "s_compare", "b_tab", "b_start", "b_inf"]:
         B[nm], st[nm] = build_g2(nm, S["SIGAD"], free_v=BL_FREE_V)
     X = lambda nm: expand_calls_d(B[nm])
     ADD, ADDT, LADDER, DBL4 = 50, 53, 52, 54
@@ -2509,7 +2603,7 @@ def g2_blind_routine():
     def fixup():
         return ["s_and_b64 s[92:93], %s, %s" % (M_H0, M_R0), "s_andn2_b64 s[92:93], s[92:93], %s" % M_INF1, "s_andn2_b64 s[92:93], s[92:93], %s" % M_INF2,
                 "s_and_b64 s[92:93], s[92:93], exec", "s_cbranch_scc1 3f"] + far_fwd(6) + ["3:", "s_mov_b64 exec, s[92:93]"] + X("fix") + ["6:", "s_mov_b64 exec, %s" % EXEC_ALL]
-    subs = ["%d:" % ADD] + X("add") + fixup() + ["s_setpc_b64 s[98:99]"]
+    subs = ["%d:" % ADD] + X("madd") + fixup() + ["s_setpc_b64 s[98:99]"]            # ladder and table: + P with P affine
     subs += ["%d:" % ADDT] + X("addt") + fixup() + ["s_setpc_b64 s[98:99]"]
     lad = ["%d:" % LADDER, "s_mov_b32 s78, 0", "4:", "s_mov_b32 s39, %d" % RUNS[5]]
     for ph in range(5):
@@ -2593,6 +2687,12 @@ def main():
     sgb = sgm.replace('"vcc"', ",".join('"s%d"' % i for i in [38] + list(range(50, 54)) + [71, 72] + list(range(79, 100))) + ',"vcc"')
     txt += "#define MBLS_G2_BLIND_D_ASM_CLOBBERS %s,%s, \\\n    %s\n" % (
         ",".join('"v%d"' % i for i in range(256) if i not in (248, 249, 251, 252) and i not in UNTOUCHED_V), ",".join('"a%d"' % i for i in range(252)), sgb)
+    full, pieces, st = f12_tree_routine()
+    txt += emit("MBLS_F12_TREE_D_ASM", full) + "\n"
+    print("f12 tree routine", len(full), "lines", st)
+    full, pieces, st = g2_tree_routine()
+    txt += emit("MBLS_G2_TREE_D_ASM", full) + "\n"
+    print("g2 tree routine", len(full), "lines")
     full, pieces, st = g1_blind_routine()
     txt += emit("MBLS_G1_BLIND_D_ASM", full) + "\n"
     print("g1 blind routine", len(full), "lines; addt", len(pieces["addt"]), st["addt"], "dbl", len(pieces["dbl"]))
