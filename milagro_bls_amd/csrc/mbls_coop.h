@@ -152,16 +152,19 @@ __global__ void __launch_bounds__(64) k_coop(coop_prog pg, mbls_ws ws, uint64_t 
             int32_t a[14], b[14], r[14];
 #pragma unroll
             for (int j = 0; j < 14; j++) { a[j] = cf[0] * S[ix[0] * COOP_SW + j]; b[j] = cf[4] * S[ix[4] * COOP_SW + j]; }
-            for (uint32_t t = 1; t < na; t++) {
+            // the term counts are the same for every lane of the step (uniform branches, statically indexed registers)
 #pragma unroll
-                for (int j = 0; j < 14; j++) a[j] += cf[t] * S[ix[t] * COOP_SW + j];
-            }
-            for (uint32_t t = 1; t < nb; t++) {
+            for (int t = 1; t < 4; t++) {
+                if ((uint32_t)t < na) {
 #pragma unroll
-                for (int j = 0; j < 14; j++) b[j] += cf[4 + t] * S[ix[4 + t] * COOP_SW + j];
+                    for (int j = 0; j < 14; j++) a[j] += cf[t] * S[ix[t] * COOP_SW + j];
+                }
+                if ((uint32_t)t < nb) {
+#pragma unroll
+                    for (int j = 0; j < 14; j++) b[j] += cf[4 + t] * S[ix[4 + t] * COOP_SW + j];
+                }
             }
             coop_mul(r, a, b);
-            __syncthreads();                       // every lane has read its operands
 #pragma unroll
             for (int j = 0; j < 14; j++) S[dst * COOP_SW + j] = r[j];
         } else if (kind == COOP_K_LIN) {
@@ -169,18 +172,20 @@ __global__ void __launch_bounds__(64) k_coop(coop_prog pg, mbls_ws ws, uint64_t 
             const bool second = fop == 1 && flags[fl] != 0;          // a selection: flag ? terms 4..7 : terms 0..3
 #pragma unroll
             for (int j = 0; j < 14; j++) s[j] = 0;
-            for (uint32_t t = 0; t < na; t++) {
-                const int64_t c = (fop == 1 && second) ? 0 : cf[t];
 #pragma unroll
-                for (int j = 0; j < 14; j++) s[j] += c * S[ix[t] * COOP_SW + j];
-            }
-            for (uint32_t t = 0; t < nb; t++) {
-                const int64_t c = (fop == 1 && !second) ? 0 : cf[4 + t];
+            for (int t = 0; t < 4; t++) {
+                if ((uint32_t)t < na) {
+                    const int32_t c = (fop == 1 && second) ? 0 : cf[t];
 #pragma unroll
-                for (int j = 0; j < 14; j++) s[j] += c * S[ix[4 + t] * COOP_SW + j];
+                    for (int j = 0; j < 14; j++) s[j] += (int64_t)c * S[ix[t] * COOP_SW + j];
+                }
+                if ((uint32_t)t < nb) {
+                    const int32_t c = (fop == 1 && !second) ? 0 : cf[4 + t];
+#pragma unroll
+                    for (int j = 0; j < 14; j++) s[j] += (int64_t)c * S[ix[4 + t] * COOP_SW + j];
+                }
             }
             coop_reduce(r, s);
-            __syncthreads();
 #pragma unroll
             for (int j = 0; j < 14; j++) S[dst * COOP_SW + j] = r[j];
         } else if (kind == COOP_K_INV) {
