@@ -220,13 +220,13 @@ MBLS_FN void tree_level_d_call(const mbls_ws& ws, uint64_t i, uint64_t half, MBL
     const uint32_t st4 = __builtin_amdgcn_readfirstlane((uint32_t)(ws.stride * 4));
     const uint32_t poff = __builtin_amdgcn_readfirstlane((uint32_t)(half * 4));          // the partner's byte offset (half < 2^30 items)
     if (G2) {
-        asm volatile(MBLS_ASM_CALL("mbls_g2_tree_d_asm_fn") : : "{v252}"(addr), "{s68}"(gb_lo), "{s69}"(gb_hi), "{s70}"(st4), "{s71}"(poff) : MBLS_G2_GROUP_D_ASM_CLOBBERS, "v251");
+        asm volatile(MBLS_ASM_CALL("mbls_g2_tree_d_asm_fn") : : "{v252}"(addr), "{s68}"(gb_lo), "{s69}"(gb_hi), "{s70}"(st4), "{s71}"(poff) : MBLS_G2_TREE_D_ASM_CLOBBERS);
     } else {
         fp f0, f1, f2, f3, f4, f5, f6, f7, f8, f9, f10, f11;
         asm volatile(MBLS_ASM_CALL("mbls_f12_tree_d_asm_fn")
                      : MBLS_MILLER_D_OUT_REGS(f)
                      : "{v252}"(addr), "{s68}"(gb_lo), "{s69}"(gb_hi), "{s70}"(st4), "{s71}"(poff)
-                     : MBLS_FINAL_EXP_D_ASM_CLOBBERS);
+                     : MBLS_F12_TREE_D_ASM_CLOBBERS);
         const fp c[12] = {f0, f1, f2, f3, f4, f5, f6, f7, f8, f9, f10, f11};
 #pragma unroll
         for (int t = 0; t < 12; t++) ws_st(ws, MBLS_SLOT_F + t, i, c[t]);

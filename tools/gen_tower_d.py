@@ -2693,11 +2693,16 @@ def main():
     full, pieces, st = g2_tree_routine()
     txt += emit("MBLS_G2_TREE_D_ASM", full) + "\n"
     print("g2 tree routine", len(full), "lines")
+    # the tree routines take the partner's byte offset in s71 (an input of the call, so it is not in their clobber lists)
+    txt += "#define MBLS_F12_TREE_D_ASM_CLOBBERS MBLS_MILLER_D_ASM_CLOBBERS, \"v253\", \"s50\", \"s51\", \"s52\", \"s53\", \"s79\", \"s72\", \"s80\", \"s81\", " + ", ".join('\"s%d\"' % i for i in range(84, 100)) + "\n"
     full, pieces, st = g1_blind_routine()
     txt += emit("MBLS_G1_BLIND_D_ASM", full) + "\n"
     print("g1 blind routine", len(full), "lines; addt", len(pieces["addt"]), st["addt"], "dbl", len(pieces["dbl"]))
     txt += "#define MBLS_G1_BLIND_D_ASM_CLOBBERS %s,%s, \\\n    %s\n" % (
         ",".join('"v%d"' % i for i in range(256) if i not in (248, 249, 252) and i not in UNTOUCHED_V), ",".join('"a%d"' % i for i in range(252)), sgb)
+    sgt = sgm.replace('"vcc"', ",".join('"s%d"' % i for i in list(range(50, 54)) + [72] + list(range(79, 100))) + ',"vcc"')
+    txt += "#define MBLS_G2_TREE_D_ASM_CLOBBERS %s,%s, \\\n    %s\n" % (
+        ",".join('"v%d"' % i for i in range(256) if i != 252 and i not in UNTOUCHED_V), ",".join('"a%d"' % i for i in range(252)), sgt)
     sgg = sgm.replace('"vcc"', ",".join('"s%d"' % i for i in list(range(50, 54)) + [71, 72] + list(range(79, 100))) + ',"vcc"')
     txt += "#define MBLS_G2_GROUP_D_ASM_CLOBBERS %s,%s, \\\n    %s\n" % (
         ",".join('"v%d"' % i for i in range(256) if i not in (251, 252) and i not in UNTOUCHED_V), ",".join('"a%d"' % i for i in range(252)), sgg)
