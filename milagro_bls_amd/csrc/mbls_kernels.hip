@@ -172,8 +172,9 @@ __global__ void MBLS_LB k_pack(const uint8_t* results, uint64_t* bitmap, uint64_
 // ------------------------------------------------------------------------------------------------ n-pairing kernels
 // (aggregate_verify, reference src/aggregates.rs:130-170; verify_multiple, src/aggregates.rs:261-316)
 // item i: f_i = Miller(H_i, P_i) with P_i = [r_i] pk_i (r_i = 1 when rands == NULL: aggregate_verify only); S_i = [r_i] sig_i.
-// Two kernels so that the G1 and the G2 halves can run side by side on two streams (sets below 2^14 leave most SIMDs idle);
-// both OR their bits into status[i] atomically. A zero scalar would drop set i from the check: it is flagged, never used.
+// The G1 and the G2 halves are kernels of their own so that they can run side by side on two streams (sets below 2^14 leave most SIMDs
+// idle); both OR their bits into status[i] atomically. A zero scalar would drop set i from the check: it is flagged, never used.
+// k_blind_g1 (compiled) serves aggregate_verify (rands == NULL: no multiplication); verify_multiple runs the generated k_blind_*_d.
 __global__ void MBLS_LB k_blind_g1(mbls_ws ws, const uint8_t* pks96, const uint64_t* rands, uint32_t* status, uint64_t n) {
     uint64_t i = gid(); if (i >= n) return;
     uint32_t st = 0;
@@ -191,18 +192,6 @@ __global__ void MBLS_LB k_blind_g1(mbls_ws ws, const uint8_t* pks96, const uint6
         g1_mul(&p, &p, k, 64);
     }
     ws_st(ws, MBLS_SLOT_APK, i, p.x); ws_st(ws, MBLS_SLOT_APK + 1, i, p.y); ws_st(ws, MBLS_SLOT_APK + 2, i, p.z);
-    if (st) atomicOr(status + i, st);
-}
-__global__ void MBLS_LB k_blind_sig(mbls_ws ws, const uint8_t* sigs96, const uint64_t* rands, uint32_t* status, uint64_t n) {
-    uint64_t i = gid(); if (i >= n) return;
-    uint32_t st = 0;
-    fp2 sx, sy; bool sinf; int e2 = g2_decode_compressed(&sx, &sy, &sinf, sigs96 + 96 * i);
-    if (e2) { st |= MBLS_ST_BAD_SIG_ENCODING; sinf = true; }
-    g2j s; s.x = sx; s.y = sy; s.z = fp2_one(); if (sinf) g2_set_inf(&s);
-    if (!g2_in_subgroup(&s)) st |= MBLS_ST_SIG_NOT_IN_G2;
-    uint32_t k[2] = {(uint32_t)rands[i], (uint32_t)(rands[i] >> 32)};
-    g2_mul(&s, &s, k, 64);
-    ws_st2(ws, MBLS_SLOT_S, i, s.x); ws_st2(ws, MBLS_SLOT_S + 2, i, s.y); ws_st2(ws, MBLS_SLOT_S + 4, i, s.z);
     if (st) atomicOr(status + i, st);
 }
 // [r_i] pk_i with the generated windowed routine (g1_blind_routine); pks96 == NULL: the aggregate key k_aggregate left in slots 0..2
@@ -266,23 +255,7 @@ __global__ void MBLS_LB k_miller_single(mbls_ws ws, uint64_t n, int with_sig, ui
     const fp2* c = &f.c0.c0;
     for (int s = 0; s < 6; s++) ws_st2(ws, MBLS_SLOT_F + 2 * s, i, c[s]);
 }
-// tree steps: item i <- item i (op) item i + half, for i + half < m
-__global__ void MBLS_LB k_f12_tree(mbls_ws ws, uint64_t m, uint64_t half) {
-    uint64_t i = gid(); if (i + half >= m || i >= half) return;
-    fp12 a, b; fp2* ca = &a.c0.c0; fp2* cb = &b.c0.c0;
-    for (int s = 0; s < 6; s++) { ca[s] = ws_ld2(ws, MBLS_SLOT_F + 2 * s, i); cb[s] = ws_ld2(ws, MBLS_SLOT_F + 2 * s, i + half); }
-    fp12_mul(&a, &a, &b);
-    for (int s = 0; s < 6; s++) ws_st2(ws, MBLS_SLOT_F + 2 * s, i, ca[s]);
-}
-__global__ void MBLS_LB k_g2_tree(mbls_ws ws, uint64_t m, uint64_t half) {
-    uint64_t i = gid(); if (i + half >= m || i >= half) return;
-    g2j a, b;
-    a.x = ws_ld2(ws, MBLS_SLOT_S, i); a.y = ws_ld2(ws, MBLS_SLOT_S + 2, i); a.z = ws_ld2(ws, MBLS_SLOT_S + 4, i);
-    b.x = ws_ld2(ws, MBLS_SLOT_S, i + half); b.y = ws_ld2(ws, MBLS_SLOT_S + 2, i + half); b.z = ws_ld2(ws, MBLS_SLOT_S + 4, i + half);
-    g2_add(&a, &a, &b);
-    ws_st2(ws, MBLS_SLOT_S, i, a.x); ws_st2(ws, MBLS_SLOT_S + 2, i, a.y); ws_st2(ws, MBLS_SLOT_S + 4, i, a.z);
-}
-// the same levels as generated routines (no lane-private memory)
+// tree levels with one lane per product: item i <- item i (op) item i + half, for i + half < m (generated routines, tools/gen_tower_d.py)
 __global__ void MBLS_LB k_f12_tree_d(mbls_ws ws, uint64_t m, uint64_t half) {
 #if MBLS_DEVICE_ASM && !defined(MBLS_NO_FP2_ASM) && !defined(MBLS_NO_LDS_STATE)
     __shared__ uint32_t spill[154 * 64];
@@ -1112,7 +1085,7 @@ extern "C" int mbls_fast_aggregate_verify_pre_aggregated(mbls_ctx* c, const uint
 }
 
 // Product / sum trees of the n-pairing paths: m values in slot F (slot S) of items 0..m-1 -> item 0. A level with many pairs is one lane
-// per product (k_f12_tree / k_g2_tree: the chip is full of them); below MBLS_COOP_TREE_PAIRS pairs a level is one WAVE per product
+// per product (k_f12_tree_d / k_g2_tree_d: the chip is full of them); below MBLS_COOP_TREE_PAIRS pairs a level is one WAVE per product
 // (mbls_coop.h, programs f12mul / g2add: 14 / 28 steps instead of a 25 k-instruction dependent chain).
 #define MBLS_COOP_TREE_PAIRS 2048
 static void f12_tree(mbls_ctx* c, mbls_ws ws, uint64_t m, hipStream_t s) {

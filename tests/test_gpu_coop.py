@@ -67,7 +67,7 @@ def test_cooperative_verify_with_infinite_members(mb, N):
 
 
 def test_tree_levels_on_both_engines(N):
-    """verify_multiple over 4 500 one-key sets: the first level of each tree has 2 250 pairs (one lane per product, k_f12_tree / k_g2_tree),
+    """verify_multiple over 4 500 one-key sets: the first level of each tree has 2 250 pairs (one lane per product, k_f12_tree_d / k_g2_tree_d),
     every level below runs one wave per product (programs f12mul / g2add). All valid -> true; any single corrupted set -> false; the
     first 40 sets also against the oracle with the same scalars."""
     import torch
