@@ -28,6 +28,8 @@
 #define COOP_K_LOADW 6
 #define COOP_K_STOREW 7
 #define COOP_K_RES 8
+#define COOP_K_POW 9                     // S[dst] <- S[src]^((p-3)/4) (the fixed-exponent routine; only in the k_coop<true> instance)
+#define COOP_K_SGN 10                    // flag <- sgn0 of the Fp2 value (S[a], S[b]) held as plain integers
 #define COOP_RES_ITEM 0                  // RES: fold the pairing bit into status[item], results[item] like lane_final
 #define COOP_RES_BATCH 1                 // RES: one bool for the whole batch: the pairing bit and no rejecting bit in the OR of all status words
 
@@ -116,7 +118,10 @@ MBLS_FN void coop_from_words(int32_t* out, fp w) {
 
 // One wave per workgroup; workgroup b runs the program on item first_item + b * item_step (workspace addressing of mbls_lanes.h).
 // partner_step: LOADW with bit 16 of its workspace slot set reads from item + partner_step instead (the other operand of a tree product).
-__global__ void __launch_bounds__(64) k_coop(coop_prog pg, mbls_ws ws, uint64_t first_item, uint64_t item_step, uint64_t partner_step, uint64_t n_items,
+// POW: the instance that also knows the fixed-exponent step (its routine keeps a window table in AGPRs: the plain instance stays small
+// enough for two waves per SIMD).
+template <bool POW>
+__global__ void __launch_bounds__(64) k_coop_t(coop_prog pg, mbls_ws ws, uint64_t first_item, uint64_t item_step, uint64_t partner_step, uint64_t n_items,
                                              uint32_t* status, uint8_t* results, int res_mode) {
 #if MBLS_DEVICE_ASM && !defined(MBLS_NO_FP2_ASM)
     __shared__ int32_t S[MBLS_COOP_MAX_SLOTS * COOP_SW];
@@ -195,14 +200,30 @@ __global__ void __launch_bounds__(64) k_coop(coop_prog pg, mbls_ws ws, uint64_t 
             coop_canonical(d);
             fp w = fp_inv(coop_to_words(d));           // the safegcd routine on 12 canonical words of the 2^384 domain (0 -> 0)
             coop_from_words(r, w);
-            __syncthreads();
 #pragma unroll
             for (int j = 0; j < 14; j++) S[dst * COOP_SW + j] = r[j];
+        } else if (POW && kind == COOP_K_POW) {
+            int32_t d[14], r[14];
+#pragma unroll
+            for (int j = 0; j < 14; j++) d[j] = S[ix[0] * COOP_SW + j];
+            coop_canonical(d);
+            fp w = fp_pow_pm3d4_w4(coop_to_words(d));      // a^((p-3)/4) on 12 canonical words of the 2^384 domain (8-entry window table)
+            coop_from_words(r, w);
+#pragma unroll
+            for (int j = 0; j < 14; j++) S[dst * COOP_SW + j] = r[j];
+        } else if (kind == COOP_K_SGN) {
+            int32_t d0[14], d1[14];
+#pragma unroll
+            for (int j = 0; j < 14; j++) { d0[j] = S[ix[0] * COOP_SW + j]; d1[j] = S[ix[1] * COOP_SW + j]; }
+            coop_canonical(d0); coop_canonical(d1);
+            uint32_t o = 0;
+#pragma unroll
+            for (int j = 0; j < 14; j++) o |= (uint32_t)d0[j];
+            if (active) flags[fl] = ((uint32_t)d0[0] & 1u) | ((o == 0 ? 1u : 0u) & ((uint32_t)d1[0] & 1u));
         } else if (kind == COOP_K_ISZ) {
             uint32_t o = 0;
 #pragma unroll
             for (int j = 0; j < 14; j++) o |= (uint32_t)S[ix[0] * COOP_SW + j];
-            __syncthreads();
             if (active) flags[fl] = o == 0 ? 1u : 0u;
         } else if (kind == COOP_K_FLG) {
             if (active) {
@@ -221,7 +242,6 @@ __global__ void __launch_bounds__(64) k_coop(coop_prog pg, mbls_ws ws, uint64_t 
             fp w = fp_zero();
             if (active) w = ws_ld(ws, (int)(wslot & 0xFFFF), it < ws.stride ? it : item);
             coop_from_words(r, w);
-            __syncthreads();
 #pragma unroll
             for (int j = 0; j < 14; j++) S[dst * COOP_SW + j] = r[j];
         } else if (kind == COOP_K_STOREW) {
@@ -248,3 +268,5 @@ __global__ void __launch_bounds__(64) k_coop(coop_prog pg, mbls_ws ws, uint64_t 
     }
 #endif
 }
+#define k_coop k_coop_t<false>
+#define k_coop_pow k_coop_t<true>

@@ -139,6 +139,21 @@ __global__ void MBLS_LB k_hash(mbls_ws ws, const uint8_t* msgs, uint32_t mlen, c
     lane_hash(ws, i, m, len);
 #endif
 }
+// hash_to_field alone (SHA-256 / expand_message_xmd, one lane per item): u0, u1 into slots 31, 32 / 37, 38 -- the input of the cooperative
+// engine's hashg2 program (small batches: one WAVE per item walks the maps, the addition and the cofactor clearing)
+__global__ void MBLS_LB k_hash_fields(mbls_ws ws, const uint8_t* msgs, uint32_t mlen, const uint64_t* moff, uint32_t* status, uint64_t n) {
+    uint64_t i = gid(); if (i >= n) return;
+    const uint8_t* m = msgs + (uint64_t)mlen * i; uint32_t len = mlen;
+    if (moff) {
+        const uint64_t a = moff[i], b = moff[i + 1];
+        const bool bad = b < a || b - a > 0xFFFFFFFFull;
+        m = msgs + (bad ? 0 : a); len = bad ? 0u : (uint32_t)(b - a);
+        if (bad) atomicOr(status + i, MBLS_ST_BAD_MSG_RANGE);
+    }
+#if MBLS_DEVICE_ASM && !defined(MBLS_NO_FP2_ASM)
+    hash_fields_to_ws(ws.w, ws.stride, i, m, len);
+#endif
+}
 __global__ void MBLS_LB k_miller(mbls_ws ws, uint64_t n) {
 #if !defined(MBLS_NO_LDS_STATE)
     // one wave per SIMD = 4 waves per CU: each wave can park 36 KB of loop state in LDS (144 of the 160 KB)
@@ -356,8 +371,9 @@ struct mbls_ctx {
     hipEvent_t ev[MBLS_N_PHASES + 1] = {};
     float phase_ms[MBLS_N_PHASES] = {};
     std::vector<struct mbls_keytable*> tables;     // the key tables created on this context (orphaned when it is destroyed)
-    coop_prog coop[6] = {};            // the cooperative engine's microprograms in HBM (mbls_coop.h): pairing2, vmtail, f12mul, g2add, smiller, vmfinal
+    coop_prog coop[7] = {};            // the cooperative engine's microprograms in HBM (mbls_coop.h): pairing2, vmtail, f12mul, g2add, smiller, vmfinal, hashg2
     uint32_t* d_coop = nullptr;
+    uint64_t coop_hash_max_items = 1024;   // ... and the message phase after hash_to_field as well (program hashg2: 2.7 ms against 4.5)
     uint64_t coop_max_items = 4096;    // batches up to this size take the one-wave-per-item pairing check (latency path: 13 ms at 4096 against 22)
     char err[256] = {};
 };
@@ -374,6 +390,8 @@ typedef std::lock_guard<std::recursive_mutex> mbls_lock;
 #define ARGFAIL(ctx, what) do { snprintf((ctx)->err, sizeof((ctx)->err), "invalid argument: %s", what); return MBLS_ERR_ARGUMENT; } while (0)
 
 static inline unsigned nblk(uint64_t n) { return (unsigned)((n + WG - 1) / WG); }
+// the message phase of n items on stream s: one lane per item (k_hash), or -- small batches -- hash_to_field per lane and the rest one wave per item
+static void launch_hash(mbls_ctx* c, mbls_ws ws, const uint8_t* d_msgs, uint32_t msg_len, const uint64_t* d_moff, uint32_t* st, uint64_t n, hipStream_t s);
 // the per-item key sum from wire-format keys: the generated routine for 96-byte keys (its 16-byte loads want 4-byte alignment),
 // the compiled lane body for 48-byte keys summed in place and for unaligned buffers
 static void launch_aggregate(mbls_ws ws, const uint8_t* d_pks, const uint32_t* d_off, uint32_t k, int fmt, int mode, uint32_t* st, uint64_t n, hipStream_t s) {
@@ -383,6 +401,13 @@ static void launch_aggregate(mbls_ws ws, const uint8_t* d_pks, const uint32_t* d
         hipLaunchKernelGGL(k_aggregate, dim3(nblk(n)), dim3(WG), 0, s, ws, d_pks, d_off, k, fmt, mode, st, n);
 }
 
+static void launch_hash(mbls_ctx* c, mbls_ws ws, const uint8_t* d_msgs, uint32_t msg_len, const uint64_t* d_moff, uint32_t* st, uint64_t n, hipStream_t s) {
+    if (n <= c->coop_hash_max_items && n <= c->coop_max_items) {
+        hipLaunchKernelGGL(k_hash_fields, dim3(nblk(n)), dim3(WG), 0, s, ws, d_msgs, msg_len, d_moff, st, n);
+        hipLaunchKernelGGL(k_coop_pow, dim3((unsigned)n), dim3(64), 0, s, c->coop[6], ws, (uint64_t)0, (uint64_t)1, (uint64_t)0, n, (uint32_t*)nullptr, (uint8_t*)nullptr, COOP_RES_ITEM);
+    } else
+        hipLaunchKernelGGL(k_hash, dim3(nblk(n)), dim3(WG), 0, s, ws, d_msgs, msg_len, d_moff, st, n);
+}
 static void ctx_free(mbls_ctx* c) {
     (void)hipSetDevice(c->device);
     if (c->d_w) (void)hipFree(c->d_w);
@@ -421,11 +446,11 @@ extern "C" int mbls_ctx_create(mbls_ctx** out, int device_id) {
     if (ok) {       // the cooperative engine's programs: one upload per context
 #define COOP_SRC(P) {MBLS_COOP_##P##_STEPS, MBLS_COOP_##P##_ROWS, MBLS_COOP_##P##_CONSTS}
 #define COOP_CNT(P) {2 * MBLS_COOP_##P##_NSTEPS, 512 * MBLS_COOP_##P##_NROWS, 15 * (MBLS_COOP_##P##_NCONSTS ? MBLS_COOP_##P##_NCONSTS : 1)}
-        const int NP = 6;
-        const uint32_t* src[NP][3] = {COOP_SRC(PAIRING2), COOP_SRC(VMTAIL), COOP_SRC(F12MUL), COOP_SRC(G2ADD), COOP_SRC(SMILLER), COOP_SRC(VMFINAL)};
-        const size_t cnt[NP][3] = {COOP_CNT(PAIRING2), COOP_CNT(VMTAIL), COOP_CNT(F12MUL), COOP_CNT(G2ADD), COOP_CNT(SMILLER), COOP_CNT(VMFINAL)};
+        const int NP = 7;
+        const uint32_t* src[NP][3] = {COOP_SRC(PAIRING2), COOP_SRC(VMTAIL), COOP_SRC(F12MUL), COOP_SRC(G2ADD), COOP_SRC(SMILLER), COOP_SRC(VMFINAL), COOP_SRC(HASHG2)};
+        const size_t cnt[NP][3] = {COOP_CNT(PAIRING2), COOP_CNT(VMTAIL), COOP_CNT(F12MUL), COOP_CNT(G2ADD), COOP_CNT(SMILLER), COOP_CNT(VMFINAL), COOP_CNT(HASHG2)};
         const uint32_t nconst[NP] = {MBLS_COOP_PAIRING2_NCONSTS, MBLS_COOP_VMTAIL_NCONSTS, MBLS_COOP_F12MUL_NCONSTS, MBLS_COOP_G2ADD_NCONSTS, MBLS_COOP_SMILLER_NCONSTS,
-                                     MBLS_COOP_VMFINAL_NCONSTS};
+                                     MBLS_COOP_VMFINAL_NCONSTS, MBLS_COOP_HASHG2_NCONSTS};
         size_t total = 0;
         for (int p = 0; p < NP; p++) for (int a = 0; a < 3; a++) total += (cnt[p][a] + 3) & ~(size_t)3;       // 16-byte aligned pieces (the rows are read as uint4)
         ok = hipMalloc(&c->d_coop, total * 4) == hipSuccess;
@@ -574,7 +599,7 @@ static int verify_pipeline(mbls_ctx* c, const uint8_t* d_sigs, const uint8_t* d_
     }
     if (part == 1) {
         hipLaunchKernelGGL(k_sig, dim3(g), dim3(WG), 0, s_sig, ws, d_sigs, st, n);
-        hipLaunchKernelGGL(k_hash, dim3(g), dim3(WG), 0, s_msg, ws, d_msgs, msg_len, d_moff, st, n);
+        launch_hash(c, ws, d_msgs, msg_len, d_moff, st, n, s_msg);
         HIPCHK(c, hipGetLastError());
         return MBLS_OK;
     }
@@ -590,7 +615,7 @@ static int verify_pipeline(mbls_ctx* c, const uint8_t* d_sigs, const uint8_t* d_
     if (tm) HIPCHK(c, hipEventRecord(c->ev[1], s));
     if (!keys_later) hipLaunchKernelGGL(k_sig, dim3(g), dim3(WG), 0, s_sig, ws, d_sigs, st, n);
     if (tm) HIPCHK(c, hipEventRecord(c->ev[2], s));
-    if (!keys_later) hipLaunchKernelGGL(k_hash, dim3(g), dim3(WG), 0, s_msg, ws, d_msgs, msg_len, d_moff, st, n);
+    if (!keys_later) launch_hash(c, ws, d_msgs, msg_len, d_moff, st, n, s_msg);
     if (tm) HIPCHK(c, hipEventRecord(c->ev[3], s));
     if (fork) {      // join
         if (s_sig != s) { HIPCHK(c, hipEventRecord(c->hs_ev2, s_sig)); HIPCHK(c, hipStreamWaitEvent(s, c->hs_ev2, 0)); }

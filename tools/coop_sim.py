@@ -174,6 +174,14 @@ class Sim:
                     w = value(canonical(self.S[idx[0]]))
                     r_ = pow(w, -1, P) * pow(2, 768, P) % P if w else 0
                     writes.append((dst, reduce_digits(digits_shl8(r_))))
+                elif kind == G.K_POW:
+                    w = value(canonical(self.S[idx[0]]))                       # x * 2^384 mod p
+                    x = w * pow(R384, -1, P) % P
+                    r_ = pow(x, (P - 3) // 4, P) * R384 % P
+                    writes.append((dst, reduce_digits(digits_shl8(r_))))
+                elif kind == G.K_SGN:
+                    c0, c1 = value(canonical(self.S[idx[0]])), value(canonical(self.S[idx[1]]))
+                    fwrites.append((fl, (c0 & 1) | ((1 if c0 == 0 else 0) & (c1 & 1))))
                 elif kind == G.K_ISZ:
                     fwrites.append((fl, 1 if all(x == 0 for x in self.S[idx[0]]) else 0))
                     assert (value(self.S[idx[0]]) % P == 0) == all(x == 0 for x in self.S[idx[0]])

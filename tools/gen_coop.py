@@ -32,8 +32,8 @@ from gen_fpd_asm import column_ok  # noqa: E402
 import gen_tower_d as T  # noqa: E402
 from gen_tower_d import Bound, product_bound, REDUCED, G_IN, R392, ONE_D, K384, D392  # noqa: E402
 
-K_END, K_MUL, K_LIN, K_INV, K_ISZ, K_FLG, K_LOADW, K_STOREW, K_RES = range(9)
-KIND_NAMES = ["END", "MUL", "LIN", "INV", "ISZ", "FLG", "LOADW", "STOREW", "RES"]
+K_END, K_MUL, K_LIN, K_INV, K_ISZ, K_FLG, K_LOADW, K_STOREW, K_RES, K_POW, K_SGN = range(11)
+KIND_NAMES = ["END", "MUL", "LIN", "INV", "ISZ", "FLG", "LOADW", "STOREW", "RES", "POW", "SGN"]
 NLANE = 64
 MAXT = 4                     # terms per product operand
 SLOT_ZERO = 0                # slot 0 holds zero: unused terms point there (coefficient 0), idle lanes write there
@@ -254,6 +254,28 @@ class Block(T.Prog):
         self.items.append(n)
         return LC({n: 1})
 
+    def pow34(self, a):
+        """a^((p-3)/4) by the fixed-exponent routine of tools/gen_fp_asm.py (same word interface as inv)"""
+        w = self.materialise(self.mul(a, self.const(K384)), True)
+        n = self._node("pow", REDUCED, a=w)
+        self.items.append(n)
+        return LC({n: 1})
+
+    def sgn0_2(self, a, flag, tmp):
+        """flag <- sgn0 of the Fp2 value a (RFC 9380 section 4.1: parity of the plain representative of c0, or of c1 when c0 = 0): the
+        plain integers come out of a Montgomery product with the constant whose representation is 1"""
+        one = self.const(1)
+        x0 = self.materialise(self.mul(a[0], one), True)
+        x1 = self.materialise(self.mul(a[1], one), True)
+        n = self._node("sgn", None, a=x0, b=x1, aux=flag)
+        self.items.append(n)
+
+    def mask_xor(self, dst, a, b):
+        self.flagop(F_XOR, dst, a, b)
+
+    def mask_and(self, dst, a, b):
+        self.flagop(F_AND, dst, a, b)
+
     def iszero(self, a, flag):
         """flag word <- (a = 0 mod p)"""
         w = self.materialise(a)
@@ -353,7 +375,8 @@ def node_inputs(n):
     return out
 
 
-STEP_KIND = {"mul": K_MUL, "lin": K_LIN, "sel": K_LIN, "inv": K_INV, "isz": K_ISZ, "flg": K_FLG, "loadw": K_LOADW, "storew": K_STOREW, "res": K_RES}
+STEP_KIND = {"mul": K_MUL, "lin": K_LIN, "sel": K_LIN, "inv": K_INV, "isz": K_ISZ, "flg": K_FLG, "loadw": K_LOADW, "storew": K_STOREW, "res": K_RES,
+             "pow": K_POW, "sgn": K_SGN}
 
 
 def schedule(block):
@@ -372,13 +395,14 @@ def schedule(block):
                 ready = max(ready, x.step + 1)
         if n.kind == "sel":
             ready = max(ready, flag_ready.get(n.aux, 0))
-        if n.kind == "isz":
+        if n.kind in ("isz", "sgn"):
             ready = max(ready, flag_last_read.get(n.aux, -1) + 0, flag_ready.get(n.aux, 0))
         if n.kind == "flg":
             op, d, a, b = n.aux
             srcs = list(range(a, a + b)) if op == F_ALL else [a, b]
             for f in srcs:
                 ready = max(ready, flag_ready.get(f, 0))
+            # every lane of a step reads its flags before any lane writes: an earlier reader of d may share the step, an earlier writer may not
             ready = max(ready, flag_last_read.get(d, -1), flag_ready.get(d, 0))
         if n.kind == "res":
             ready = max([ready, len(steps)] + [flag_ready.get(f, 0) for f in n.aux])
@@ -395,7 +419,7 @@ def schedule(block):
         # earliest step of this kind with a free lane; MUL / LIN steps take 64 operations, the serial kinds as well
         k = None
         for i in range(ready, len(steps)):
-            if steps[i].kind == kind and len(steps[i].lanes) < NLANE and not (kind == K_FLG and steps[i].lanes):
+            if steps[i].kind == kind and len(steps[i].lanes) < NLANE:
                 k = i
                 break
         if k is None:
@@ -406,7 +430,7 @@ def schedule(block):
             last_read[x] = max(last_read.get(x, -1), k)
         if n.kind == "sel":
             flag_last_read[n.aux] = max(flag_last_read.get(n.aux, -1), k)
-        if n.kind == "isz":
+        if n.kind in ("isz", "sgn"):
             flag_ready[n.aux] = k + 1
         if n.kind == "flg":
             op, d, a, b = n.aux
@@ -434,7 +458,7 @@ def assign_slots(machine, block, steps, temp_base):
         for n in release_at.pop(si, []):
             free.append(n.slot)
         for n in st.lanes:
-            if n.kind in ("isz", "flg", "storew", "res"):
+            if n.kind in ("isz", "flg", "storew", "res", "sgn"):
                 continue
             if n.pin is not None:
                 n.slot = n.pin
@@ -491,8 +515,10 @@ def lane_words(n):
     if n.kind == "sel":
         t = terms(n.a, 4) + terms(n.b, 4)
         return pack_lane([c for _, c in t], [s for s, _ in t], n.slot, flag=n.aux, fop=1)
-    if n.kind == "inv":
+    if n.kind in ("inv", "pow"):
         return pack_lane([1] + [0] * 7, [n.a.single().slot] + [0] * 7, n.slot)
+    if n.kind == "sgn":
+        return pack_lane([1, 1] + [0] * 6, [n.a.single().slot, n.b.single().slot] + [0] * 6, SLOT_ZERO, flag=n.aux)
     if n.kind == "isz":
         return pack_lane([1] + [0] * 7, [n.a.single().slot] + [0] * 7, SLOT_ZERO, flag=n.aux)
     if n.kind == "flg":
@@ -518,8 +544,10 @@ def step_info(st):
             na, nb = max(na, min(t, 4)), max(nb, max(0, t - 4))
         elif n.kind == "sel":
             na, nb = max(na, n.a.nterms()), max(nb, n.b.nterms())
-        elif n.kind in ("inv", "isz", "storew"):
+        elif n.kind in ("inv", "isz", "storew", "pow"):
             na = max(na, 1)
+        elif n.kind == "sgn":
+            na = max(na, 2)
     return st.kind | (na << 8) | (nb << 12)
 
 
@@ -959,7 +987,68 @@ def prog_g2add():
     return m
 
 
-PROGRAMS = {"pairing2": prog_pairing2, "vmtail": prog_vmtail, "f12mul": prog_f12tree, "g2add": prog_g2add, "smiller": prog_smiller, "vmfinal": prog_vmfinal}
+WS_U0, WS_U1 = 31, 37                   # hash_to_field leaves u0 in slots 31, 32 and u1 in 37, 38 (hash_fields_to_ws, mbls_lanes.h)
+
+
+def pt_psi(b, pt):
+    return [b.mul2(b.conj2(pt[0]), T.c2(b, T.PSI_CX)), b.mul2(b.conj2(pt[1]), T.c2(b, T.PSI_CY)), b.conj2(pt[2])]
+
+
+def prog_hashg2():
+    """hash_to_curve_g2 after hash_to_field (reference src/amcl_utils.rs:33-35; the generated one-lane routine is g2_group_routine('hash') in
+    tools/gen_tower_d.py) on ONE wave: both map_to_curve evaluations side by side (simplified SWU with its two fixed-exponent calls each,
+    3-isogeny), q0 + q1, and the Budroni-Pintore cofactor clearing [x^2 - x - 1] P + [x - 1] psi(P) + psi^2(2 P) with two ladders by |x|.
+    In: u0, u1 in workspace slots 31, 32 / 37, 38; out: H (Jacobian) in slots 7..12."""
+    m = Machine("hashg2")
+    b = m.block("sswu")
+    outs = []
+    for k, ws in enumerate((WS_U0, WS_U1)):
+        u = (b.loadw("u%d_0" % k, ws), b.loadw("u%d_1" % k, ws + 1))
+        masks = tuple(m.flag("%s%d" % (nm, k)) for nm in ("t0_", "sq1_", "chi_", "s0_", "s1_", "tmp_"))
+        outs.append(T.sswu_formula(b, u, masks))
+    pt_out(b, "a", outs[0]); pt_out(b, "bs", outs[1])
+    b = m.block("ladd")                                          # acc <- acc + base
+    pt_out(b, "a", g2_add_formula(b, m, pt_in(b, "a"), pt_in(b, "bs")))
+    b = m.block("lsub")                                          # acc <- acc - base
+    q = pt_in(b, "bs")
+    pt_out(b, "a", g2_add_formula(b, m, pt_in(b, "a"), [q[0], b.neg2(q[1]), q[2]]))
+    b = m.block("ldbl")
+    pt_out(b, "a", g2_dbl_formula(b, *pt_in(b, "a")))
+    b = m.block("h_base1")                                       # p = q0 + q1: remembered, and the first ladder's base
+    a = pt_in(b, "a"); pt_out(b, "pp", a); pt_out(b, "bs", a)
+    b = m.block("h_after1")                                      # t1 = -[|x|] p = [x] p; t2 = psi(p); acc = p (to be doubled)
+    a = pt_in(b, "a"); pp = pt_in(b, "pp")
+    pt_out(b, "ta", [a[0], b.neg2(a[1]), a[2]]); pt_out(b, "tb", pt_psi(b, pp)); pt_out(b, "a", pp)
+    b = m.block("h_psi2")                                        # acc = psi^2(2 p); base = t2
+    a = pt_in(b, "a")
+    pt_out(b, "a", [b.mulfp2(a[0], b.const(D392(T.PSI2_CX))), b.neg2(a[1]), a[2]]); pt_out(b, "bs", pt_in(b, "tb"))
+    b = m.block("h_t3")                                          # t3 = acc; acc = t1; base = t2
+    pt_out(b, "tc", pt_in(b, "a")); pt_out(b, "a", pt_in(b, "ta")); pt_out(b, "bs", pt_in(b, "tb"))
+    b = m.block("h_base2")                                       # t1 + t2 is the second ladder's base
+    pt_out(b, "bs", pt_in(b, "a"))
+    b = m.block("h_after2")                                      # acc = [x](t1 + t2); base = t3
+    a = pt_in(b, "a")
+    pt_out(b, "a", [a[0], b.neg2(a[1]), a[2]]); pt_out(b, "bs", pt_in(b, "tc"))
+    b = m.block("h_ad_t1")
+    pt_out(b, "bs", pt_in(b, "ta"))
+    b = m.block("h_ad_p")
+    pt_out(b, "bs", pt_in(b, "pp"))
+    b = m.block("store")
+    for i, v in enumerate([x for c in pt_in(b, "a") for x in c]):
+        b.storew(v, WS_H + i)
+
+    def ladder():
+        for ph in range(6):
+            m.run("ldbl", RUNS[ph])
+            if ph < 5:
+                m.run("ladd")
+    m.run("sswu"); m.run("ladd"); m.run("h_base1"); ladder(); m.run("h_after1"); m.run("ldbl"); m.run("h_psi2"); m.run("lsub")
+    m.run("h_t3"); m.run("ladd"); m.run("h_base2"); ladder(); m.run("h_after2"); m.run("ladd")
+    m.run("h_ad_t1"); m.run("lsub"); m.run("h_ad_p"); m.run("lsub"); m.run("store")
+    return m
+
+
+PROGRAMS = {"hashg2": prog_hashg2, "pairing2": prog_pairing2, "vmtail": prog_vmtail, "f12mul": prog_f12tree, "g2add": prog_g2add, "smiller": prog_smiller, "vmfinal": prog_vmfinal}
 
 
 def emit_c(name, comp):

@@ -2127,6 +2127,16 @@ def prog_sswu():
     p = Prog()
     S = G2_SLOTS
     u = tuple(prog_reduce(p, p.live_in(("gka", S["U"] + i))) for i in range(2))
+    out = sswu_formula(p, u)
+    for i, v in enumerate([c for pt in out for c in pt]):
+        p.ops.append(("storep", [], [v], ("k", S["Q0"] + i)))
+    return p
+
+
+def sswu_formula(p, u, masks=None):
+    """simplified SWU + 3-isogeny on the Fp2 value u -> Jacobian point [X, Y, Z] (formulas and case handling of map_to_curve_g2 in
+    mbls_hash.h); masks: the names of the six lane masks / flags it uses (M_T0, M_SQ1, M_CHI, M_S0, M_S1, tmp)"""
+    M_T0, M_SQ1, M_CHI, M_S0, M_S1, G2M_TMP0 = masks or (globals()["M_T0"], globals()["M_SQ1"], globals()["M_CHI"], globals()["M_S0"], globals()["M_S1"], globals()["G2M_TMP0"])
     A, B, Z = c2(p, SSWU_A), c2(p, SSWU_B), c2(p, SSWU_Z)
     fpc = lambda x: p.const(D392(x))
     norm = lambda a: (lambda sq: p.add(sq[0], sq[1]))(p.mulpair(a[0], a[0], a[1], a[1]))
@@ -2171,10 +2181,7 @@ def prog_sswu():
     for i in (2, 1, 0):
         xnum = p.add2(p.mul2(xnum, x), c2(p, ISO3_XNUM[i]))
         ynum = p.add2(p.mul2(ynum, x), c2(p, ISO3_YNUM[i]))
-    out = [xnum, p.mul2(y, ynum), p.add2(x, c2(p, ISO3_K))]
-    for i, v in enumerate([c for pt in out for c in pt]):
-        p.ops.append(("storep", [], [v], ("k", S["Q0"] + i)))
-    return p
+    return [xnum, p.mul2(y, ynum), p.add2(x, c2(p, ISO3_K))]
 
 
 def prog_g2_add(ad_slot, negate, table=False):
