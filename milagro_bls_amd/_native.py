@@ -73,6 +73,7 @@ SIGNATURES = {
     "mbls_sk_to_pk_batch": (C.c_int, [vp, vp, C.c_int, C.c_uint64, vp]),
     "mbls_sk_to_pk_batch_device": (C.c_int, [vp, vp, C.c_int, C.c_uint64, vp, vp]),
     "mbls_hash_to_g2_batch": (C.c_int, [vp, vp, C.c_uint32, C.c_uint64, vp]),
+    "mbls_hash_to_g2_batch_mode": (C.c_int, [vp, vp, C.c_uint32, C.c_uint64, vp, C.c_int]),
     "mbls_aggregate_public_keys_batch": (C.c_int, [vp, vp, C.c_int, vp, C.c_uint64, C.c_uint32, vp, vp]),
     "mbls_fp_mul_batch": (C.c_int, [vp, vp, vp, C.c_uint64, vp, C.c_int]),
     "mbls_fp_mul_bench": (C.c_int, [vp, C.c_uint64, C.c_uint32, C.POINTER(C.c_float)]),

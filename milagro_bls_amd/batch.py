@@ -100,10 +100,12 @@ def sk_to_pk_batch(sks32, n, out_format=N.PK_COMPRESSED, ctx=None):
     return bytes(out)[:sz * n]
 
 
-def hash_to_g2_batch(msgs, n, msg_len=32, ctx=None):
+def hash_to_g2_batch(msgs, n, msg_len=32, ctx=None, mode=0):
+    """n x hash_to_curve_g2, compressed; mode 0: the stand-alone lane body, 1 / 2: the verification pipeline's message phase with one lane /
+    one wave per item (include/mbls.h, mbls_hash_to_g2_batch_mode)"""
     ctx = ctx or _c()
     out = N.outbuf(96 * n)
-    ctx.check(N.lib().mbls_hash_to_g2_batch(ctx.handle, N.cbuf(msgs), msg_len, n, out))
+    ctx.check(N.lib().mbls_hash_to_g2_batch_mode(ctx.handle, N.cbuf(msgs), msg_len, n, out, mode))
     return bytes(out)[:96 * n]
 
 

@@ -313,6 +313,12 @@ __global__ void MBLS_LB k_sk_to_pk(const uint8_t* sks, int fmt, uint64_t n, uint
 __global__ void MBLS_LB k_hash_to_g2(const uint8_t* msgs, uint32_t mlen, uint64_t n, uint8_t* out96) { uint64_t i = gid(); if (i < n) op_hash_to_g2(i, msgs, mlen, out96); }
 __global__ void MBLS_LB k_fp_mul(const uint8_t* a, const uint8_t* b, uint64_t n, uint8_t* out, int op) { uint64_t i = gid(); if (i < n) op_fp_mul(i, n, a, b, out, op); }
 __global__ void MBLS_LB k_apk_export(mbls_ws ws, uint64_t n, uint8_t* out96) { uint64_t i = gid(); if (i < n) op_apk_export(ws, i, out96); }
+// H(m) as the message phase of the pipeline left it in workspace slots 7..12 (Jacobian) -> 96 compressed bytes (the probe mbls_hash_to_g2_batch)
+__global__ void MBLS_LB k_h_export(mbls_ws ws, uint64_t n, uint8_t* out96) {
+    uint64_t i = gid(); if (i >= n) return;
+    g2j h; h.x = ws_ld2(ws, MBLS_SLOT_H, i); h.y = ws_ld2(ws, MBLS_SLOT_H + 2, i); h.z = ws_ld2(ws, MBLS_SLOT_H + 4, i);
+    g2_encode_jacobian(out96 + 96 * i, &h);
+}
 __global__ void MBLS_LB k_fp_mul_bench(uint32_t* sink, uint32_t iters, uint64_t n) {
     uint64_t i = gid(); if (i >= n) return;
     fp a = fp_load_const(MBLS_G1_X), b = fp_load_const(MBLS_G1_Y);
@@ -909,14 +915,30 @@ extern "C" int mbls_sk_to_pk_batch(mbls_ctx* c, const uint8_t* sks, int fmt, uin
     int rc = mbls_sk_to_pk_batch_device(c, dk.as<uint8_t>(), fmt, n, dout.as<uint8_t>(), c->hs_a); if (rc) return rc;
     HIPCHK(c, hipStreamSynchronize(c->hs_a)); HIPCHK(c, dout.down(pks, (fmt ? 96 : 48) * n)); return MBLS_OK;
 }
+extern "C" int mbls_hash_to_g2_batch_mode(mbls_ctx* c, const uint8_t* msgs, uint32_t msg_len, uint64_t n, uint8_t* out96, int mode);
 extern "C" int mbls_hash_to_g2_batch(mbls_ctx* c, const uint8_t* msgs, uint32_t msg_len, uint64_t n, uint8_t* out96) {
-    if (!c || !out96 || (!msgs && msg_len)) return MBLS_ERR_ARGUMENT;
+    return mbls_hash_to_g2_batch_mode(c, msgs, msg_len, n, out96, 0);
+}
+extern "C" int mbls_hash_to_g2_batch_mode(mbls_ctx* c, const uint8_t* msgs, uint32_t msg_len, uint64_t n, uint8_t* out96, int mode) {
+    if (!c || !out96 || (!msgs && msg_len) || mode < 0 || mode > 2) return MBLS_ERR_ARGUMENT;
     mbls_lock lk(c->mu);
     if (!n) return MBLS_OK;
     HIPCHK(c, hipSetDevice(c->device));
     sbuf dm(c, 0), dout(c, 1); HIPCHK(c, dm.up(msgs, (size_t)msg_len * n)); HIPCHK(c, dout.alloc(96 * n));
-    hipLaunchKernelGGL(k_hash_to_g2, dim3(nblk(n)), dim3(WG), 0, c->hs_a, dm.as<uint8_t>(), msg_len, n, dout.as<uint8_t>());
-    HIPCHK(c, hipStreamSynchronize(c->hs_a)); HIPCHK(c, dout.down(out96, 96 * n)); return MBLS_OK;
+    if (mode == 0)        // the stand-alone compiled lane body
+        hipLaunchKernelGGL(k_hash_to_g2, dim3(nblk(n)), dim3(WG), 0, c->hs_a, dm.as<uint8_t>(), msg_len, n, dout.as<uint8_t>());
+    else {                // the pipeline's message phase (mode 1: one lane per item, the generated routine; mode 2: one wave per item, program hashg2), then its H
+        int rc = mbls_ctx_reserve(c, n); if (rc) return rc;
+        mbls_ws ws; ws.w = c->d_w; ws.stride = c->cap;
+        rc = ws_acquire(c, c->hs_a); if (rc) return rc;
+        HIPCHK(c, hipMemsetAsync(c->d_status, 0, 4 * n, c->hs_a));
+        const uint64_t keep_h = c->coop_hash_max_items, keep_p = c->coop_max_items;
+        if (mode == 1) c->coop_hash_max_items = 0; else { c->coop_hash_max_items = n; c->coop_max_items = n > keep_p ? n : keep_p; }
+        launch_hash(c, ws, dm.as<uint8_t>(), msg_len, nullptr, c->d_status, n, c->hs_a);
+        c->coop_hash_max_items = keep_h; c->coop_max_items = keep_p;
+        hipLaunchKernelGGL(k_h_export, dim3(nblk(n)), dim3(WG), 0, c->hs_a, ws, n, dout.as<uint8_t>());
+    }
+    HIPCHK(c, hipStreamSynchronize(c->hs_a)); c->ws_pending = false; HIPCHK(c, dout.down(out96, 96 * n)); return MBLS_OK;
 }
 extern "C" int mbls_aggregate_public_keys_batch(mbls_ctx* c, const uint8_t* pks, int fmt, const uint32_t* off, uint64_t n, uint32_t k,
                                                 uint8_t* apks96, uint32_t* status) {

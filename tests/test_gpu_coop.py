@@ -96,3 +96,17 @@ def test_tree_levels_on_both_engines(N):
     assert orc.verify_multiple(sets, rr2) is True                    # any nonzero scalars verify valid sets
     sets_bad = [(sets[1][0], sets[0][1], sets[0][2])] + sets[1:]
     assert orc.verify_multiple(sets_bad, rr) is False
+
+
+def test_message_phase_of_the_pipeline_against_golden_and_oracle(mb, vectors):
+    """H(m) as the verification pipeline's own message phase leaves it -- the generated one-lane routine (mode 1) and the cooperative
+    program hashg2 (mode 2) -- against the committed golden vectors (incl. the 133 700-byte message) and the oracle on 200 random messages"""
+    rnd = random.Random(17)
+    for v in vectors["model"]["hash_to_g2"]:
+        m = helpers.expand_msg(v["msg"])
+        for mode in (1, 2):
+            assert mb.hash_to_g2_batch(m, 1, msg_len=len(m), mode=mode).hex() == v["compressed"], (mode, v["msg"][:16])
+    msgs = rnd.randbytes(32 * 200)
+    want = orc.batch_hash_to_g2(msgs, 200)
+    assert mb.hash_to_g2_batch(msgs, 200, mode=1) == want
+    assert mb.hash_to_g2_batch(msgs, 200, mode=2) == want
