@@ -291,7 +291,11 @@ class Block(T.Prog):
 
     def out(self, name, a):
         """state[name] <- a (reduced) when the block ends"""
-        w = self.materialise(a, True)
+        fresh = a.single()
+        if fresh is not None and fresh.kind in ("lin", "sel", "inv", "pow") and fresh.pin is None and _is_reduced(fresh.bound) and not any(fresh is o for _, o in self.outs):
+            w = a                                                # a reduced value of its own that lives nowhere yet: it becomes the state slot's content
+        else:
+            w = self.materialise(a, True)
         node = w.single()
         if node.pin is not None or any(node is o for _, o in self.outs):       # one node cannot live in two pinned slots: a fresh copy
             node = self._node("lin", REDUCED, a=LC({node: 1}))
@@ -935,8 +939,8 @@ def prog_f12tree():
 def g2_dbl_formula(b, X, Y, Z):
     """Jacobian doubling on the twist (g2_dbl in mbls_curve.h / prog_g2_dbl_d in gen_tower_d.py; valid for every point incl. infinity)"""
     A = b.sqr2(X); B = b.sqr2(Y); C = b.sqr2(B)
-    D = b.dbl2(b.sub2(b.sub2(b.sqr2(b.add2(X, B)), A), C))
-    E = b.mul3_2(A); F = b.sqr2(E)
+    D = b.scale2(b.mul2(X, B), 4)                          # 2 ((X + B)^2 - A - C) = 4 X B as a product: no sum to materialise on the critical path
+    E = b.mul3_2(A); F = b.scale2(b.sqr2(A), 9)            # (3 A)^2 as 9 A^2: the operands of the squaring stay single products
     Z3 = b.dbl2(b.mul2(Y, Z))
     X3 = b.sub2(F, b.dbl2(D))
     Y3 = b.sub2(b.mul2(E, b.sub2(D, X3)), b.mul8_2(C))
@@ -946,15 +950,16 @@ def g2_dbl_formula(b, X, Y, Z):
 def g2_add_formula(b, m, A, Q):
     """A + Q in Jacobian coordinates with g2_add's case handling (mbls_curve.h; prog_g2_add in gen_tower_d.py): an operand at infinity
     gives the other one, equal operands the doubling, opposite operands Z = 0 by the formulas"""
-    fh, fr, fi1, fi2, tmp = m.flag("h0"), m.flag("r0"), m.flag("inf1"), m.flag("inf2"), m.flag("tmp")
+    fh, fr, fi1, fi2 = m.flag("h0"), m.flag("r0"), m.flag("inf1"), m.flag("inf2")
+    tmps = [m.flag("tmp%d" % i) for i in range(4)]               # one scratch flag per zero test: the four tests share their steps
     z1z1, z2z2 = b.sqr2(A[2]), b.sqr2(Q[2])
     u1, u2 = b.mul2(A[0], z2z2), b.mul2(Q[0], z1z1)
     s1 = b.mul2(b.mul2(A[1], Q[2]), z2z2)
     s2 = b.mul2(b.mul2(Q[1], A[2]), z1z1)
     h = b.sub2(u2, u1)
     rr = b.dbl2(b.sub2(s2, s1))
-    b.iszero2(h, fh, tmp); b.iszero2(rr, fr, tmp)
-    b.iszero2(A[2], fi1, tmp); b.iszero2(Q[2], fi2, tmp)
+    b.iszero2(h, fh, tmps[0]); b.iszero2(rr, fr, tmps[1])
+    b.iszero2(A[2], fi1, tmps[2]); b.iszero2(Q[2], fi2, tmps[3])
     i4 = b.sqr2(b.dbl2(h))
     j, v = b.mul2(h, i4), b.mul2(u1, i4)
     X3 = b.sub2(b.sub2(b.sqr2(rr), j), b.dbl2(v))
