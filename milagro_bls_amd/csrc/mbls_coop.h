@@ -18,7 +18,7 @@
 #include "mbls_lanes.h"
 #include "mbls_coop_prog.inc"
 
-#define COOP_SW 15                       // dwords per slot: 14 digits + 1 (an odd stride spreads the slots over the LDS banks)
+#define COOP_SW 16                       // dwords per slot: 14 digits + 2 (16-byte aligned: a slot moves with four 128-bit LDS accesses)
 #define COOP_K_END 0
 #define COOP_K_MUL 1
 #define COOP_K_LIN 2
@@ -124,7 +124,7 @@ template <bool POW>
 __global__ void __launch_bounds__(64) k_coop_t(coop_prog pg, mbls_ws ws, uint64_t first_item, uint64_t item_step, uint64_t partner_step, uint64_t n_items,
                                              uint32_t* status, uint8_t* results, int res_mode) {
 #if MBLS_DEVICE_ASM && !defined(MBLS_NO_FP2_ASM)
-    __shared__ int32_t S[MBLS_COOP_MAX_SLOTS * COOP_SW];
+    __shared__ __attribute__((aligned(16))) int32_t S[MBLS_COOP_MAX_SLOTS * COOP_SW];
     __shared__ uint32_t flags[64];
     const uint32_t lane = threadIdx.x;
     const uint64_t item = first_item + (uint64_t)blockIdx.x * item_step;
