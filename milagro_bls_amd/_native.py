@@ -32,6 +32,7 @@ SIGNATURES = {
     "mbls_ctx_reserve": (C.c_int, [vp, C.c_uint64]),
     "mbls_ctx_reserve_keys": (C.c_int, [vp, C.c_uint64]),
     "mbls_ctx_set_coop_max_items": (C.c_int, [vp, C.c_uint64]),
+    "mbls_ctx_set_coop_hash_max_items": (C.c_int, [vp, C.c_uint64]),
     "mbls_last_error": (C.c_char_p, [vp]),
     "mbls_fast_aggregate_verify_batch_device": (C.c_int, [vp, vp, vp, C.c_uint32, vp, vp, C.c_int, vp, C.c_uint64, C.c_uint32, vp, vp, vp, vp]),
     "mbls_fast_aggregate_verify_batch": (C.c_int, [vp, vp, vp, C.c_uint32, vp, vp, C.c_int, vp, C.c_uint64, C.c_uint32, vp, vp]),
@@ -163,6 +164,9 @@ class Context:
     def set_coop_max_items(self, n):
         """batches up to n items take the one-wave-per-item pairing check (0: never)"""
         self.check(lib().mbls_ctx_set_coop_max_items(self._h, n))
+
+    def set_coop_hash_max_items(self, n):
+        self.check(lib().mbls_ctx_set_coop_hash_max_items(self._h, n))
 
 
 class KeyTable:

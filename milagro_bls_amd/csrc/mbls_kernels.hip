@@ -379,8 +379,10 @@ struct mbls_ctx {
     std::vector<struct mbls_keytable*> tables;     // the key tables created on this context (orphaned when it is destroyed)
     coop_prog coop[7] = {};            // the cooperative engine's microprograms in HBM (mbls_coop.h): pairing2, vmtail, f12mul, g2add, smiller, vmfinal, hashg2
     uint32_t* d_coop = nullptr;
-    uint64_t coop_hash_max_items = 1024;   // ... and the message phase after hash_to_field as well (program hashg2: 2.7 ms against 4.5)
-    uint64_t coop_max_items = 4096;    // batches up to this size take the one-wave-per-item pairing check (latency path: 13 ms at 4096 against 22)
+    // measured crossovers (scripts/coop_sweep.py, 128 keys, device-resident): one wave per item for the pairing check wins up to ~10 k items
+    // (18.5 ms at 8 192 against 22.5), for the message phase as well up to ~1.5 k (7.7 ms at 1 536 against 8.3)
+    uint64_t coop_hash_max_items = 1536;
+    uint64_t coop_max_items = 8192;
     char err[256] = {};
 };
 struct mbls_keytable {
@@ -480,6 +482,10 @@ extern "C" int mbls_ctx_create(mbls_ctx** out, int device_id) {
 extern "C" int mbls_ctx_set_coop_max_items(mbls_ctx* c, uint64_t max_items) {
     if (!c) return MBLS_ERR_ARGUMENT;
     mbls_lock lk(c->mu); c->coop_max_items = max_items; return MBLS_OK;
+}
+extern "C" int mbls_ctx_set_coop_hash_max_items(mbls_ctx* c, uint64_t max_items) {
+    if (!c) return MBLS_ERR_ARGUMENT;
+    mbls_lock lk(c->mu); c->coop_hash_max_items = max_items; return MBLS_OK;
 }
 extern "C" void mbls_ctx_destroy(mbls_ctx* c) {
     if (!c) return;
