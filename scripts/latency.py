@@ -55,6 +55,18 @@ keys = [PublicKey(bytes(pks[0, j])) for j in range(k)]
 asig = AggregateSignature(bytes(sigs[0]))
 assert asig.fast_aggregate_verify(bytes(msgs[0]), keys)
 out["scalar_api"]["fast_aggregate_verify (128 keys)"] = med(lambda: asig.fast_aggregate_verify(bytes(msgs[0]), keys))
+# AggregateSignature::aggregate_verify (distinct messages), 3 and 128 signers
+import random as _r
+_rnd = _r.Random(5)
+for m in (3, 128):
+    sks_ = [SecretKey.from_bytes(_rnd.randrange(1, 1 << 250).to_bytes(32, "big")) for _ in range(m)]
+    pks_ = [PublicKey.from_secret_key(s_) for s_ in sks_]
+    ms_ = [_rnd.randbytes(32) for _ in range(m)]
+    ag = AggregateSignature.new()
+    for s_, mm in zip(sks_, ms_):
+        ag.add(Signature.new(mm, s_))
+    assert ag.aggregate_verify(ms_, pks_)
+    out["scalar_api"]["aggregate_verify (%d messages)" % m] = med(lambda: ag.aggregate_verify(ms_, pks_))
 print(out["scalar_api"], flush=True)
 # config 2: 2^16 x Signature::verify, compressed key, resident
 n = 1 << 16
