@@ -289,16 +289,13 @@ __global__ void MBLS_LB k_status_or(const uint32_t* status, uint64_t n, uint32_t
     uint64_t i = gid(); uint32_t v = (i < n) ? status[i] : 0;
     if (__ballot(v != 0)) { if (v) atomicOr(out, v); }
 }
-// decoded signature (compressed bytes) -> slot S of item `item` (for aggregate_verify's (sig, -G1) pair)
-__global__ void MBLS_LB k_sig_to_slot(mbls_ws ws, const uint8_t* sig96, uint64_t item, uint32_t* status_out) {
+// the signature k_sig decoded into slots 3..6 of item `item` (affine; y = 0: infinity) -> slot S of the same item in Jacobian form: the
+// (sig, -G1) pair of aggregate_verify (reference src/aggregates.rs:158-164)
+__global__ void MBLS_LB k_sigslot_to_s(mbls_ws ws, uint64_t item) {
     if (gid() != 0) return;
-    fp2 x, y; bool inf; uint32_t st = 0;
-    int e = g2_decode_compressed(&x, &y, &inf, sig96);
-    if (e) { st |= MBLS_ST_BAD_SIG_ENCODING; inf = true; }
-    g2j s; s.x = x; s.y = y; s.z = fp2_one(); if (inf) g2_set_inf(&s);
-    if (!g2_in_subgroup(&s)) st |= MBLS_ST_SIG_NOT_IN_G2;
+    g2j s; s.x = ws_ld2(ws, MBLS_SLOT_SIG, item); s.y = ws_ld2(ws, MBLS_SLOT_SIG + 2, item); s.z = fp2_one();
+    if (fp2_is_zero(s.y)) g2_set_inf(&s);
     ws_st2(ws, MBLS_SLOT_S, item, s.x); ws_st2(ws, MBLS_SLOT_S + 2, item, s.y); ws_st2(ws, MBLS_SLOT_S + 4, item, s.z);
-    atomicOr(status_out, st);
 }
 
 // ------------------------------------------------------------------------------------------------ auxiliary kernels
@@ -370,14 +367,14 @@ struct mbls_ctx {
     uint32_t* d_keys_xy = nullptr;     // [key_cap][24] affine Montgomery coordinates
     uint8_t* d_key_flags = nullptr;
     struct { void* p; size_t cap; } stage[MBLS_N_STAGE] = {};
-    hipStream_t hs_a = nullptr, hs_b = nullptr, hs_c = nullptr;      // streams of the host-buffer entry points
+    hipStream_t hs_a = nullptr, hs_b = nullptr, hs_c = nullptr, hs_d = nullptr;      // streams of the host-buffer entry points (hs_d: the signature phase while hs_b uploads keys)
     hipEvent_t hs_ev = nullptr, hs_ev2 = nullptr, hs_ev3 = nullptr;
     hipEvent_t ws_ev = nullptr; hipStream_t ws_stream = nullptr; bool ws_pending = false;   // last asynchronous user of the workspace
     bool timing = false;
     hipEvent_t ev[MBLS_N_PHASES + 1] = {};
     float phase_ms[MBLS_N_PHASES] = {};
     std::vector<struct mbls_keytable*> tables;     // the key tables created on this context (orphaned when it is destroyed)
-    coop_prog coop[7] = {};            // the cooperative engine's microprograms in HBM (mbls_coop.h): pairing2, vmtail, f12mul, g2add, smiller, vmfinal, hashg2
+    coop_prog coop[8] = {};            // the cooperative engine's microprograms in HBM (mbls_coop.h): pairing2, vmtail, f12mul, g2add, smiller, vmfinal, hashg2, miller1
     uint32_t* d_coop = nullptr;
     // measured crossovers (scripts/coop_sweep.py, 128 keys, device-resident): one wave per item for the pairing check wins up to ~10 k items
     // (18.5 ms at 8 192 against 22.5), for the message phase as well up to ~1.5 k (7.7 ms at 1 536 against 8.3)
@@ -434,6 +431,7 @@ static void ctx_free(mbls_ctx* c) {
     if (c->hs_a) (void)hipStreamDestroy(c->hs_a);
     if (c->hs_b) (void)hipStreamDestroy(c->hs_b);
     if (c->hs_c) (void)hipStreamDestroy(c->hs_c);
+    if (c->hs_d) (void)hipStreamDestroy(c->hs_d);
     delete c;
 }
 extern "C" int mbls_ctx_create(mbls_ctx** out, int device_id) {
@@ -448,17 +446,19 @@ extern "C" int mbls_ctx_create(mbls_ctx** out, int device_id) {
     for (int i = 0; i <= MBLS_N_PHASES; i++) ok = ok && hipEventCreate(&c->ev[i]) == hipSuccess;
     ok = ok && hipMalloc(&c->d_scalar, 64) == hipSuccess;
     ok = ok && hipStreamCreateWithFlags(&c->hs_a, hipStreamNonBlocking) == hipSuccess && hipStreamCreateWithFlags(&c->hs_b, hipStreamNonBlocking) == hipSuccess &&
-         hipStreamCreateWithFlags(&c->hs_c, hipStreamNonBlocking) == hipSuccess;
+         hipStreamCreateWithFlags(&c->hs_c, hipStreamNonBlocking) == hipSuccess && hipStreamCreateWithFlags(&c->hs_d, hipStreamNonBlocking) == hipSuccess;
     ok = ok && hipEventCreateWithFlags(&c->hs_ev, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&c->hs_ev2, hipEventDisableTiming) == hipSuccess &&
          hipEventCreateWithFlags(&c->hs_ev3, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&c->ws_ev, hipEventDisableTiming) == hipSuccess;
     if (ok) {       // the cooperative engine's programs: one upload per context
 #define COOP_SRC(P) {MBLS_COOP_##P##_STEPS, MBLS_COOP_##P##_ROWS, MBLS_COOP_##P##_CONSTS}
 #define COOP_CNT(P) {2 * MBLS_COOP_##P##_NSTEPS, 512 * MBLS_COOP_##P##_NROWS, 15 * (MBLS_COOP_##P##_NCONSTS ? MBLS_COOP_##P##_NCONSTS : 1)}
-        const int NP = 7;
-        const uint32_t* src[NP][3] = {COOP_SRC(PAIRING2), COOP_SRC(VMTAIL), COOP_SRC(F12MUL), COOP_SRC(G2ADD), COOP_SRC(SMILLER), COOP_SRC(VMFINAL), COOP_SRC(HASHG2)};
-        const size_t cnt[NP][3] = {COOP_CNT(PAIRING2), COOP_CNT(VMTAIL), COOP_CNT(F12MUL), COOP_CNT(G2ADD), COOP_CNT(SMILLER), COOP_CNT(VMFINAL), COOP_CNT(HASHG2)};
+        const int NP = 8;
+        const uint32_t* src[NP][3] = {COOP_SRC(PAIRING2), COOP_SRC(VMTAIL), COOP_SRC(F12MUL), COOP_SRC(G2ADD), COOP_SRC(SMILLER), COOP_SRC(VMFINAL), COOP_SRC(HASHG2),
+                                      COOP_SRC(MILLER1)};
+        const size_t cnt[NP][3] = {COOP_CNT(PAIRING2), COOP_CNT(VMTAIL), COOP_CNT(F12MUL), COOP_CNT(G2ADD), COOP_CNT(SMILLER), COOP_CNT(VMFINAL), COOP_CNT(HASHG2),
+                                   COOP_CNT(MILLER1)};
         const uint32_t nconst[NP] = {MBLS_COOP_PAIRING2_NCONSTS, MBLS_COOP_VMTAIL_NCONSTS, MBLS_COOP_F12MUL_NCONSTS, MBLS_COOP_G2ADD_NCONSTS, MBLS_COOP_SMILLER_NCONSTS,
-                                     MBLS_COOP_VMFINAL_NCONSTS, MBLS_COOP_HASHG2_NCONSTS};
+                                     MBLS_COOP_VMFINAL_NCONSTS, MBLS_COOP_HASHG2_NCONSTS, MBLS_COOP_MILLER1_NCONSTS};
         size_t total = 0;
         for (int p = 0; p < NP; p++) for (int a = 0; a < 3; a++) total += (cnt[p][a] + 3) & ~(size_t)3;       // 16-byte aligned pieces (the rows are read as uint4)
         ok = hipMalloc(&c->d_coop, total * 4) == hipSuccess;
@@ -599,7 +599,8 @@ static int verify_pipeline(mbls_ctx* c, const uint8_t* d_sigs, const uint8_t* d_
     // null), the caller then uploads the keys on another stream and makes this one wait, and part 2 queues the rest.
     const bool keys_later = part != 0;
     const bool fork = !tm && n <= 16384;
-    hipStream_t s_sig = (fork && part == 0) ? c->hs_b : s, s_msg = fork ? c->hs_c : s;
+    // (host-buffer entries: hs_b carries the key upload, so their signature phase has a stream of its own)
+    hipStream_t s_sig = fork ? (part == 0 ? c->hs_b : c->hs_d) : s, s_msg = fork ? c->hs_c : s;
     if (part != 2) {
         rc = ws_acquire(c, s); if (rc) return rc;
         HIPCHK(c, hipMemsetAsync(st, 0, 4 * n, s));
@@ -726,7 +727,8 @@ static int verify_host(mbls_ctx* c, const uint8_t* sigs, const uint8_t* msgs, ui
     }
     c->timing = tm;
     if (rc) {         // part 1 may be running on the context's streams: nothing of this call is left in flight when it returns an error
-        (void)hipStreamSynchronize(c->hs_a); (void)hipStreamSynchronize(c->hs_b); (void)hipStreamSynchronize(c->hs_c); c->ws_pending = false;
+        (void)hipStreamSynchronize(c->hs_a); (void)hipStreamSynchronize(c->hs_b); (void)hipStreamSynchronize(c->hs_c); (void)hipStreamSynchronize(c->hs_d);
+        c->ws_pending = false;
         return rc;
     }
     HIPCHK(c, hipStreamSynchronize(c->hs_a));
@@ -1164,7 +1166,10 @@ static void g2_tree(mbls_ctx* c, mbls_ws ws, uint64_t m, hipStream_t s) {
 static int npairing_finish(mbls_ctx* c, uint64_t n, hipStream_t s, uint8_t* d_result, hipEvent_t s_miller_ev = nullptr) {
     const bool s_miller_done = s_miller_ev != nullptr;
     mbls_ws ws; ws.w = c->d_w; ws.stride = c->cap;
-    hipLaunchKernelGGL(k_miller_single, dim3(nblk(n)), dim3(WG), 0, s, ws, n, 0, (uint64_t)0);
+    if (2 * n <= c->coop_max_items)     // few pairs: one WAVE per Miller loop (program miller1, ~0.9 ms) instead of one lane (6.6 ms)
+        hipLaunchKernelGGL(k_coop, dim3((unsigned)n), dim3(64), 0, s, c->coop[7], ws, (uint64_t)0, (uint64_t)1, (uint64_t)0, n, (uint32_t*)nullptr, (uint8_t*)nullptr, COOP_RES_ITEM);
+    else
+        hipLaunchKernelGGL(k_miller_single, dim3(nblk(n)), dim3(WG), 0, s, ws, n, 0, (uint64_t)0);
     f12_tree(c, ws, n, s);
     // s_miller_done: the Miller value of (S, -G1) is left in slots 97..108 of item 0 by program smiller, running beside the chains
     if (s_miller_done) HIPCHK(c, hipStreamWaitEvent(s, s_miller_ev, 0));
@@ -1198,10 +1203,15 @@ extern "C" int mbls_aggregate_verify(mbls_ctx* c, const uint8_t sig[96], const u
     if (ws_acquire(c, s)) return 0;
     (void)hipMemsetAsync(c->d_scalar, 0, 64, s);
     (void)hipMemsetAsync(c->d_status, 0, 4 * n, s);
-    hipLaunchKernelGGL(k_sig_to_slot, dim3(1), dim3(WG), 0, s, ws, dsig.as<uint8_t>(), (uint64_t)0, c->d_scalar);
+    // three chains side by side: the signature (decode + subgroup test: k_sig on item 0's slots, then into slot S), the keys, the messages
+    (void)hipEventRecord(c->hs_ev, s); (void)hipStreamWaitEvent(c->hs_b, c->hs_ev, 0); (void)hipStreamWaitEvent(c->hs_c, c->hs_ev, 0);
+    hipLaunchKernelGGL(k_sig, dim3(1), dim3(WG), 0, c->hs_b, ws, (const uint8_t*)dsig.as<uint8_t>(), c->d_status, (uint64_t)1);
+    hipLaunchKernelGGL(k_sigslot_to_s, dim3(1), dim3(WG), 0, c->hs_b, ws, (uint64_t)0);
     hipLaunchKernelGGL(k_blind_g1, dim3(nblk(n)), dim3(WG), 0, s, ws, dp.as<uint8_t>(), (const uint64_t*)nullptr, c->d_status, n);   // r_i = 1: no blinding in AggregateVerify
+    launch_hash(c, ws, dm.as<uint8_t>(), 0u, (const uint64_t*)doff.as<uint64_t>(), c->d_status, n, c->hs_c);
+    (void)hipEventRecord(c->hs_ev2, c->hs_b); (void)hipEventRecord(c->hs_ev3, c->hs_c);
+    (void)hipStreamWaitEvent(s, c->hs_ev2, 0); (void)hipStreamWaitEvent(s, c->hs_ev3, 0);
     hipLaunchKernelGGL(k_status_or, dim3(nblk(n)), dim3(WG), 0, s, c->d_status, n, c->d_scalar);
-    hipLaunchKernelGGL(k_hash, dim3(nblk(n)), dim3(WG), 0, s, ws, dm.as<uint8_t>(), 0u, (const uint64_t*)doff.as<uint64_t>(), c->d_status, n);
     // a signature outside G2 or an undecodable member makes the tail answer false (reference src/aggregates.rs:137-139): no host round trip
     if (npairing_finish(c, n, s, c->d_results)) return 0;
     uint8_t r = 0;
@@ -1246,7 +1256,7 @@ static int verify_multiple_impl(mbls_ctx* c, const uint8_t* d_sigs, const uint8_
         hipLaunchKernelGGL(k_coop, dim3(1), dim3(64), 0, s_sig, c->coop[4], ws, (uint64_t)0, (uint64_t)1, (uint64_t)0, (uint64_t)1, (uint32_t*)nullptr, (uint8_t*)nullptr, COOP_RES_ITEM);
         HIPCHK(c, hipEventRecord(c->hs_ev, s_sig));                  // ... and its Miller value (awaited just before the tail)
     }
-    hipLaunchKernelGGL(k_hash, dim3(nblk(n)), dim3(WG), 0, s_msg, ws, d_msgs, msg_len, d_moff, c->d_status, n);
+    launch_hash(c, ws, d_msgs, msg_len, d_moff, c->d_status, n, s_msg);
     if (fork) {
         HIPCHK(c, hipEventRecord(c->hs_ev3, s_msg));
         HIPCHK(c, hipStreamWaitEvent(s, c->hs_ev2, 0)); HIPCHK(c, hipStreamWaitEvent(s, c->hs_ev3, 0));

@@ -897,6 +897,35 @@ def prog_smiller():
     return m
 
 
+def prog_miller1():
+    """One pair of the n-pairing paths (aggregate_verify: (H(m_i), pk_i), reference src/aggregates.rs:144-155; verify_multiple: (H(m_i), [r_i] apk_i),
+    :290-300) on one wave, for small batches: the Miller loop of (H, P) from workspace slots 7..12 / 0..2 (both Jacobian), its conjugated
+    value into slots 13..24 -- what k_miller_single leaves with one lane per pair."""
+    m = Machine("miller1")
+    skip, tmp, tmp2 = m.flag("skip"), m.flag("tmp"), m.flag("tmp2")
+    b = m.block("load")
+    apk = [b.loadw("apk%d" % i, WS_APK + i) for i in range(3)]
+    h = [b.loadw("hj%d" % i, WS_H + i) for i in range(6)]
+    b.iszero2((h[4], h[5]), skip, tmp); b.iszero(apk[2], tmp2); b.flagop(F_OR, skip, skip, tmp2)
+    H = [(h[0], h[1]), (h[2], h[3]), (h[4], h[5])]
+    qx = b.mul2(H[0], H[2]); qz = b.mul2(b.sqr2(H[2]), H[2])
+    for i, v in enumerate([qx[0], qx[1], H[1][0], H[1][1], qz[0], qz[1]]):
+        b.out("q%d" % i, v); b.out("t%d" % i, v)
+    one = b.const(ONE_D)
+    zz = b.mul(apk[2], apk[2])
+    masked_p(b, m, skip, b.neg(b.mul(apk[0], apk[2])), apk[1], b.mul(zz, apk[2]), "p")
+    for i in range(12):
+        b.out("f%d" % i, one if i == 0 else LC())
+    build_miller(m, [dict(T="t", Q="q", affine=False, P="p")])
+    b = m.block("store")
+    f = ld12(b)
+    f = (f[0], b.neg6(f[1]))                                      # the conjugate (x < 0)
+    for i, v in enumerate(flat12(f)):
+        b.storew(v, WS_F + i)
+    m.run("load"); run_miller(m); m.run("store")
+    return m
+
+
 def prog_vmfinal():
     """The second half: (product of the sets' Miller values, slots 13..24) * conj(the value `smiller` left in 97..108), ONE final
     exponentiation, == 1, the batch's status bits"""
@@ -1053,7 +1082,8 @@ def prog_hashg2():
     return m
 
 
-PROGRAMS = {"hashg2": prog_hashg2, "pairing2": prog_pairing2, "vmtail": prog_vmtail, "f12mul": prog_f12tree, "g2add": prog_g2add, "smiller": prog_smiller, "vmfinal": prog_vmfinal}
+PROGRAMS = {"hashg2": prog_hashg2, "pairing2": prog_pairing2, "vmtail": prog_vmtail, "f12mul": prog_f12tree, "g2add": prog_g2add, "smiller": prog_smiller, "vmfinal": prog_vmfinal,
+            "miller1": prog_miller1}
 
 
 def emit_c(name, comp):
