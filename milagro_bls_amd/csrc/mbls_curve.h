@@ -98,12 +98,29 @@ MBLS_FN void g1_to_affine(fp* x, fp* y, bool* inf, const g1j* p) {
     fp zi = fp_inv(p->z), zi2 = fp_sqr(zi);
     *x = fp_mul(p->x, zi2); *y = fp_mul(fp_mul(p->y, zi2), zi);
 }
-// subgroup_check_g1: [r]P == O (reference src/keys.rs:182). Infinity passes.
+// [|x|]P for the curve parameter (64 bits, weight 6): the bits are compile-time constants, so no selects
+MBLS_NOINLINE void g1_mul_x_abs(g1j* r, const g1j* p) {
+    g1j acc = *p;
+    for (int i = 62; i >= 0; i--) {
+        g1_dbl(&acc, &acc);
+        if ((MBLS_X_ABS >> i) & 1ull) { g1j t; g1_add(&t, &acc, p); acc = t; }
+    }
+    *r = acc;
+}
+// subgroup_check_g1: [r]P == O (reference src/keys.rs:182), decided as phi(P) == [-x^2]P with phi(x, y) = (beta x, y):
+// phi^2 + phi + 1 = 0 on the curve, so phi(P) = [-x^2]P gives [x^4 - x^2 + 1]P = [r]P = O, and on the order-r subgroup phi IS
+// multiplication by -x^2 (oracle/gen_constants.py picks that beta) -- the same set of points as the 255-bit multiplication, for
+// 126 doublings + 10 additions. Infinity passes.
 MBLS_NOINLINE bool g1_in_subgroup(const g1j* p) {
-    g1j t; uint32_t k[8];
-    for (int i = 0; i < 8; i++) k[i] = MBLS_ORDER[i];
-    g1_mul(&t, p, k, 255);
-    return g1_is_inf(&t);
+    if (g1_is_inf(p)) return true;
+    g1j t, q;
+    g1_mul_x_abs(&t, p); g1_mul_x_abs(&q, &t);                       // q = [x^2]P; must equal -phi(P) = (beta x, -y)
+    fp zp2 = fp_sqr(p->z), zq2 = fp_sqr(q.z);
+    fp bx = fp_mul(fp_mul(fp_load_const(MBLS_G1_BETA), p->x), zq2);
+    fp ny = fp_mul(fp_mul(fp_neg(p->y), zq2), q.z);
+    bool ex = fp_eq(fp_mul(q.x, zp2), bx);
+    bool ey = fp_eq(fp_mul(fp_mul(q.y, zp2), p->z), ny);
+    return !g1_is_inf(&q) && ex && ey;
 }
 
 // ZCash codec. Decoders return 0 or a status/err and produce affine Montgomery coordinates.

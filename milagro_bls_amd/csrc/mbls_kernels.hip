@@ -305,12 +305,76 @@ __global__ void MBLS_LB k_g1_compress(const uint8_t* in96, uint64_t n, uint8_t* 
 __global__ void MBLS_LB k_g2_check(const uint8_t* in96, uint64_t n, uint8_t* err, uint8_t* in_g2) { uint64_t i = gid(); if (i < n) op_g2_check(i, in96, err, in_g2); }
 __global__ void MBLS_LB k_g2_add(const uint8_t* a, const uint8_t* b, uint64_t n, uint8_t* out, uint8_t* err) { uint64_t i = gid(); if (i < n) op_g2_add(i, a, b, out, err); }
 __global__ void MBLS_LB k_g1_add(const uint8_t* a, const uint8_t* b, uint64_t n, uint8_t* out, uint8_t* err) { uint64_t i = gid(); if (i < n) op_g1_add(i, a, b, out, err); }
-__global__ void MBLS_LB k_sign(const uint8_t* sks, const uint8_t* msgs, uint32_t mlen, uint64_t n, uint8_t* out96) { uint64_t i = gid(); if (i < n) op_sign(i, sks, msgs, mlen, out96); }
 __global__ void MBLS_LB k_sk_to_pk(const uint8_t* sks, int fmt, uint64_t n, uint8_t* out) { uint64_t i = gid(); if (i < n) op_sk_to_pk(i, sks, fmt, out); }
 __global__ void MBLS_LB k_hash_to_g2(const uint8_t* msgs, uint32_t mlen, uint64_t n, uint8_t* out96) { uint64_t i = gid(); if (i < n) op_hash_to_g2(i, msgs, mlen, out96); }
 __global__ void MBLS_LB k_fp_mul(const uint8_t* a, const uint8_t* b, uint64_t n, uint8_t* out, int op) { uint64_t i = gid(); if (i < n) op_fp_mul(i, n, a, b, out, op); }
+// PublicKey::from_secret_key as a key sum: [sk] G1 = sum_j [d_j 16^j] G1 over the 64 hexadecimal digits of sk, every term a record of a
+// fixed 64 x 16 table (record 16 j + d; d = 0 is the point at infinity) -- the indexed key-sum routine does the rest, no doubling at all
+__global__ void MBLS_LB k_sk_digits(const uint8_t* sks32, uint64_t n, uint32_t* idx) {
+    uint64_t i = gid(); if (i >= n) return;
+    const uint8_t* b = sks32 + 32 * i;
+    for (uint32_t j = 0; j < 64; j++) {
+        const uint32_t d = (b[31 - (j >> 1)] >> (4 * (j & 1))) & 15u;
+        idx[64 * i + j] = 16 * j + d;
+    }
+}
+__global__ void MBLS_LB k_apk_export_fmt(mbls_ws ws, uint64_t n, int fmt, uint8_t* out) {
+    uint64_t i = gid(); if (i >= n) return;
+    g1j a; a.x = ws_ld(ws, MBLS_SLOT_APK, i); a.y = ws_ld(ws, MBLS_SLOT_APK + 1, i); a.z = ws_ld(ws, MBLS_SLOT_APK + 2, i);
+    fp x, y; bool inf; g1_to_affine(&x, &y, &inf, &a);
+    if (fmt == MBLS_PK_COMPRESSED) g1_encode_compressed(out + 48 * i, x, y, inf); else g1_encode_uncompressed(out + 96 * i, x, y, inf);
+}
 __global__ void MBLS_LB k_apk_export(mbls_ws ws, uint64_t n, uint8_t* out96) { uint64_t i = gid(); if (i < n) op_apk_export(ws, i, out96); }
 // H(m) as the message phase of the pipeline left it in workspace slots 7..12 (Jacobian) -> 96 compressed bytes (the probe mbls_hash_to_g2_batch)
+// Signature::new (reference src/signature.rs:17-21) on the generated routines. psi acts on G2 as multiplication by the curve parameter
+// x = -y, y = 0xd201000000010000, and r = y^4 - y^2 + 1 < y^4: with sk mod r = a0 + a1 y + a2 y^2 + a3 y^3 (0 <= a_j < y < 2^64),
+// [sk] H = sum_j [a_j] (-1)^j psi^j(H) -- four 64-bit multiplications that run side by side on four lanes (items i, n + i, 2n + i, 3n + i)
+// with verify_multiple's windowed routine (g2_blind_routine without its subgroup test), then two levels of the G2 sum tree.
+MBLS_FN void scalar_base_y_digits(uint64_t a[4], const uint8_t* sk32) {
+    uint32_t k[8]; scalar_from_be32(k, sk32);
+    for (int rep = 0; rep < 4; rep++) {                            // any 32-byte value: 2^256 < 5 r, at most four subtractions
+        uint32_t d[8]; uint64_t bw = 0;
+        for (int j = 0; j < 8; j++) { uint64_t t = (uint64_t)k[j] - MBLS_ORDER[j] - bw; d[j] = (uint32_t)t; bw = (t >> 32) & 1u; }
+        for (int j = 0; j < 8; j++) k[j] = bw ? k[j] : d[j];
+    }
+    const uint64_t y = MBLS_X_ABS;
+    for (int t = 0; t < 4; t++) {                                  // k <- k / y, a[t] = k mod y: restoring division, one bit a step
+        uint64_t rem = 0;
+        for (int j = 7; j >= 0; j--) {
+            uint32_t q = 0;
+            for (int b = 31; b >= 0; b--) {
+                const uint32_t top = (uint32_t)(rem >> 63);
+                rem = (rem << 1) | ((k[j] >> b) & 1u);
+                const bool ge = top | (rem >= y);
+                rem = ge ? rem - y : rem; q = (q << 1) | (ge ? 1u : 0u);
+            }
+            k[j] = q;
+        }
+        a[t] = rem;
+    }
+}
+__global__ void MBLS_LB k_sign_blind(mbls_ws ws, const uint8_t* sks32, uint64_t n) {
+#if MBLS_DEVICE_ASM && !defined(MBLS_NO_FP2_ASM) && !defined(MBLS_NO_LDS_STATE)
+    __shared__ uint32_t spill[154 * 64];
+    uint64_t t = gid(); if (t >= 4 * n) return;
+    const uint64_t i = t % n; const uint32_t j = (uint32_t)(t / n);
+    g2j h; h.x = ws_ld2(ws, MBLS_SLOT_H, i); h.y = ws_ld2(ws, MBLS_SLOT_H + 2, i); h.z = ws_ld2(ws, MBLS_SLOT_H + 4, i);
+    fp2 x, y; bool inf; g2_to_affine(&x, &y, &inf, &h);           // H(m) is never infinity in practice; (0, 0) with the scalar 0 if it is
+    g2j q; q.x = x; q.y = y; q.z = fp2_one();
+    for (uint32_t e = 0; e < 3; e++) { g2j u; g2_psi(&u, &q); const bool on = e < j; q.x = fp2_select(on, u.x, q.x); q.y = fp2_select(on, u.y, q.y); }
+    q.y = fp2_select((j & 1u) != 0, fp2_neg(q.y), q.y);
+    if (inf) { q.x = fp2_zero(); q.y = fp2_zero(); }
+    ws_st2(ws, MBLS_SLOT_SIG, t, q.x); ws_st2(ws, MBLS_SLOT_SIG + 2, t, q.y);
+    uint64_t a[4]; scalar_base_y_digits(a, sks32 + 32 * i);
+    const uint64_t r = j == 0 ? a[0] : j == 1 ? a[1] : j == 2 ? a[2] : a[3];
+    (void)g2_blind_d_call(ws, t, (MBLS_LDS uint32_t*)spill, threadIdx.x, inf ? 0 : r, 1u);
+#endif
+}
+__global__ void MBLS_LB k_s_export(mbls_ws ws, uint64_t n, uint8_t* out96) {
+    uint64_t i = gid(); if (i >= n) return;
+    g2j h; h.x = ws_ld2(ws, MBLS_SLOT_S, i); h.y = ws_ld2(ws, MBLS_SLOT_S + 2, i); h.z = ws_ld2(ws, MBLS_SLOT_S + 4, i);
+    g2_encode_jacobian(out96 + 96 * i, &h);
+}
 __global__ void MBLS_LB k_h_export(mbls_ws ws, uint64_t n, uint8_t* out96) {
     uint64_t i = gid(); if (i >= n) return;
     g2j h; h.x = ws_ld2(ws, MBLS_SLOT_H, i); h.y = ws_ld2(ws, MBLS_SLOT_H + 2, i); h.z = ws_ld2(ws, MBLS_SLOT_H + 4, i);
@@ -363,6 +427,8 @@ struct mbls_ctx {
     uint32_t* d_status = nullptr;      // per-item status (when the caller passes none)
     uint8_t* d_results = nullptr;
     uint32_t* d_scalar = nullptr;      // small scratch words
+    uint32_t* d_gtab = nullptr;        // [64 * 16][MBLS_KEYREC_DWORDS]: [d 16^j] G1 (sk -> pk), built on first use
+    uint32_t* d_skidx = nullptr; uint64_t skidx_cap = 0;      // the table indices of a batch of secret keys
     uint64_t key_cap = 0;              // decompressed-key staging (compressed wire format): capacity in keys
     uint32_t* d_keys_xy = nullptr;     // [key_cap][24] affine Montgomery coordinates
     uint8_t* d_key_flags = nullptr;
@@ -419,6 +485,8 @@ static void ctx_free(mbls_ctx* c) {
     if (c->d_status) (void)hipFree(c->d_status);
     if (c->d_results) (void)hipFree(c->d_results);
     if (c->d_scalar) (void)hipFree(c->d_scalar);
+    if (c->d_gtab) (void)hipFree(c->d_gtab);
+    if (c->d_skidx) (void)hipFree(c->d_skidx);
     if (c->d_keys_xy) (void)hipFree(c->d_keys_xy);
     if (c->d_key_flags) (void)hipFree(c->d_key_flags);
     if (c->d_coop) (void)hipFree(c->d_coop);
@@ -889,13 +957,30 @@ extern "C" int mbls_sig_check_batch(mbls_ctx* c, const uint8_t* in96, uint64_t n
     for (uint64_t i = 0; i < n; i++) errs[i] = (uint8_t)map_dec_err_g2(errs[i]);
     return MBLS_OK;
 }
+static void g2_tree_levels(mbls_ctx* c, mbls_ws ws, uint64_t m, int levels, hipStream_t s);
+// [sk] H(msg) for n (secret key, message) pairs: the pipeline's message phase, the four-lane windowed multiplication (k_sign_blind), two
+// levels of the G2 sum tree, compression -- in chunks of MBLS_SIGN_CHUNK signatures (four workspace items each). Enqueues only.
+#define MBLS_SIGN_CHUNK 65536ull
 extern "C" int mbls_sign_batch_device(mbls_ctx* c, const uint8_t* d_sks, const uint8_t* d_msgs, uint32_t msg_len, uint64_t n, uint8_t* d_sigs, void* stream) {
     if (!c || !d_sks || !d_sigs || (!d_msgs && msg_len)) return MBLS_ERR_ARGUMENT;
     mbls_lock lk(c->mu);
     if (!n) return MBLS_OK;
     HIPCHK(c, hipSetDevice(c->device));
-    hipLaunchKernelGGL(k_sign, dim3(nblk(n)), dim3(WG), 0, (hipStream_t)stream, d_sks, d_msgs, msg_len, n, d_sigs);
-    HIPCHK(c, hipGetLastError()); return MBLS_OK;
+    hipStream_t s = (hipStream_t)stream;
+    const uint64_t chunk = n < MBLS_SIGN_CHUNK ? n : MBLS_SIGN_CHUNK;
+    int rc = mbls_ctx_reserve(c, 4 * chunk); if (rc) return rc;
+    mbls_ws ws; ws.w = c->d_w; ws.stride = c->cap;
+    rc = ws_acquire(c, s); if (rc) return rc;
+    for (uint64_t lo = 0; lo < n; lo += chunk) {
+        const uint64_t m = n - lo < chunk ? n - lo : chunk;
+        HIPCHK(c, hipMemsetAsync(c->d_status, 0, 4 * m, s));
+        launch_hash(c, ws, d_msgs + (uint64_t)msg_len * lo, msg_len, nullptr, c->d_status, m, s);
+        hipLaunchKernelGGL(k_sign_blind, dim3(nblk(4 * m)), dim3(WG), 0, s, ws, d_sks + 32 * lo, m);
+        g2_tree_levels(c, ws, 4 * m, 2, s);
+        hipLaunchKernelGGL(k_s_export, dim3(nblk(m)), dim3(WG), 0, s, ws, m, d_sigs + 96 * lo);
+    }
+    HIPCHK(c, hipGetLastError());
+    return ws_release(c, s);
 }
 extern "C" int mbls_sign_batch(mbls_ctx* c, const uint8_t* sks, const uint8_t* msgs, uint32_t msg_len, uint64_t n, uint8_t* sigs) {
     if (!c || !sks || !sigs || (!msgs && msg_len)) return MBLS_ERR_ARGUMENT;
@@ -906,13 +991,50 @@ extern "C" int mbls_sign_batch(mbls_ctx* c, const uint8_t* sks, const uint8_t* m
     int rc = mbls_sign_batch_device(c, dk.as<uint8_t>(), dm.as<uint8_t>(), msg_len, n, dout.as<uint8_t>(), c->hs_a); if (rc) return rc;
     HIPCHK(c, hipStreamSynchronize(c->hs_a)); HIPCHK(c, dout.down(sigs, 96 * n)); return MBLS_OK;
 }
+// the fixed table of sk -> pk: the 1 024 multiples come from the compiled ladder (k_sk_to_pk) once per context
+static int ensure_gtab(mbls_ctx* c) {
+    if (c->d_gtab) return MBLS_OK;
+    std::vector<uint8_t> sc(32 * 1024, 0);
+    for (int j = 0; j < 64; j++) for (int d = 0; d < 16; d++) sc[32 * (16 * j + d) + 31 - (j >> 1)] = (uint8_t)(d << (4 * (j & 1)));
+    sbuf dk(c, 7), dp(c, 8), de(c, 9);      // not the staging slots of the host entries that call this with their inputs already uploaded
+    HIPCHK(c, dk.up(sc.data(), sc.size())); HIPCHK(c, dp.alloc(96 * 1024)); HIPCHK(c, de.alloc(1024));
+    uint32_t* tab = nullptr; HIPCHK(c, hipMalloc(&tab, 1024 * MBLS_KEYREC_DWORDS * 4));
+    hipLaunchKernelGGL(k_sk_to_pk, dim3(nblk(1024)), dim3(WG), 0, c->hs_a, dk.as<uint8_t>(), MBLS_PK_UNCOMPRESSED, (uint64_t)1024, dp.as<uint8_t>());
+    hipLaunchKernelGGL(k_keytable_append, dim3(nblk(1024)), dim3(WG), 0, c->hs_a, dp.as<uint8_t>(), MBLS_PK_UNCOMPRESSED, 0, (uint64_t)1024, tab, de.as<uint8_t>());
+    hipError_t e = hipStreamSynchronize(c->hs_a);
+    std::vector<uint8_t> errs(1024, 1);
+    if (e == hipSuccess) e = de.down(errs.data(), 1024);
+    bool ok = e == hipSuccess;
+    for (int t = 0; ok && t < 1024; t++) ok = errs[t] == 0;
+    if (!ok) { (void)hipFree(tab); snprintf(c->err, sizeof(c->err), "building the generator table failed"); return MBLS_ERR_DEVICE; }
+    c->d_gtab = tab; return MBLS_OK;
+}
+#define MBLS_SKPK_CHUNK 131072ull
 extern "C" int mbls_sk_to_pk_batch_device(mbls_ctx* c, const uint8_t* d_sks, int fmt, uint64_t n, uint8_t* d_pks, void* stream) {
     if (!c || !d_sks || !d_pks || (fmt != 0 && fmt != 1)) return MBLS_ERR_ARGUMENT;
     mbls_lock lk(c->mu);
     if (!n) return MBLS_OK;
     HIPCHK(c, hipSetDevice(c->device));
-    hipLaunchKernelGGL(k_sk_to_pk, dim3(nblk(n)), dim3(WG), 0, (hipStream_t)stream, d_sks, fmt, n, d_pks);
-    HIPCHK(c, hipGetLastError()); return MBLS_OK;
+    hipStream_t s = (hipStream_t)stream;
+    int rc = ensure_gtab(c); if (rc) return rc;
+    const uint64_t chunk = n < MBLS_SKPK_CHUNK ? n : MBLS_SKPK_CHUNK;
+    rc = mbls_ctx_reserve(c, chunk); if (rc) return rc;
+    if (c->skidx_cap < chunk) {
+        if (c->d_skidx) { (void)hipFree(c->d_skidx); c->d_skidx = nullptr; c->skidx_cap = 0; }
+        HIPCHK(c, hipMalloc(&c->d_skidx, chunk * 64 * 4)); c->skidx_cap = chunk;
+    }
+    mbls_ws ws; ws.w = c->d_w; ws.stride = c->cap;
+    rc = ws_acquire(c, s); if (rc) return rc;
+    for (uint64_t lo = 0; lo < n; lo += chunk) {
+        const uint64_t m = n - lo < chunk ? n - lo : chunk;
+        HIPCHK(c, hipMemsetAsync(c->d_status, 0, 4 * m, s));
+        hipLaunchKernelGGL(k_sk_digits, dim3(nblk(m)), dim3(WG), 0, s, d_sks + 32 * lo, m, c->d_skidx);
+        hipLaunchKernelGGL(k_aggregate_indexed_d, dim3(nblk(m)), dim3(WG), 0, s, ws, (const uint32_t*)c->d_gtab, (uint64_t)1024, (const uint32_t*)c->d_skidx,
+                           (const uint32_t*)nullptr, 64u, MBLS_MODE_VERIFY, c->d_status, m);
+        hipLaunchKernelGGL(k_apk_export_fmt, dim3(nblk(m)), dim3(WG), 0, s, ws, m, fmt, d_pks + (uint64_t)(fmt ? 96 : 48) * lo);
+    }
+    HIPCHK(c, hipGetLastError());
+    return ws_release(c, s);
 }
 extern "C" int mbls_sk_to_pk_batch(mbls_ctx* c, const uint8_t* sks, int fmt, uint64_t n, uint8_t* pks) {
     if (!c || !sks || !pks || (fmt != 0 && fmt != 1)) return MBLS_ERR_ARGUMENT;
@@ -1151,14 +1273,15 @@ static void f12_tree(mbls_ctx* c, mbls_ws ws, uint64_t m, hipStream_t s) {
         m = half;
     }
 }
-static void g2_tree(mbls_ctx* c, mbls_ws ws, uint64_t m, hipStream_t s) {
-    while (m > 1) {
+static void g2_tree_levels(mbls_ctx* c, mbls_ws ws, uint64_t m, int levels, hipStream_t s) {
+    while (m > 1 && levels-- > 0) {
         const uint64_t half = (m + 1) / 2, pairs = m - half;
         if (pairs > MBLS_COOP_TREE_PAIRS) hipLaunchKernelGGL(k_g2_tree_d, dim3(nblk(half)), dim3(WG), 0, s, ws, m, half);
         else hipLaunchKernelGGL(k_coop, dim3((unsigned)pairs), dim3(64), 0, s, c->coop[3], ws, (uint64_t)0, (uint64_t)1, half, pairs, (uint32_t*)nullptr, (uint8_t*)nullptr, COOP_RES_ITEM);
         m = half;
     }
 }
+static void g2_tree(mbls_ctx* c, mbls_ws ws, uint64_t m, hipStream_t s) { g2_tree_levels(c, ws, m, 64, s); }
 // n-pairing product check shared by aggregate_verify and verify_multiple (reference src/aggregates.rs:158-169, :307-315). On entry the
 // workspace holds, for items 0..n-1, H_i (slot H) and P_i (slot APK); S (the (S, -G1) pair's G2 point) in slot S of item 0; the OR of
 // every status word in d_scalar[0]. Everything is enqueued on s: one Miller loop per lane, the product tree, and ONE wave for the tail --

@@ -126,18 +126,19 @@ MBLS_FN void op_apk_export(const mbls_ws& ws, uint64_t i, uint8_t* out96) {
 MBLS_FN void scalar_from_be32(uint32_t* k, const uint8_t* b) {
     for (int j = 0; j < 8; j++) { const uint8_t* q = b + 28 - 4 * j; k[j] = ((uint32_t)q[0] << 24) | ((uint32_t)q[1] << 16) | ((uint32_t)q[2] << 8) | q[3]; }
 }
-// Signature::new (reference src/signature.rs:17-21): sig = [sk] H(msg), compressed
+// Signature::new (reference src/signature.rs:17-21): sig = [sk] H(msg), compressed. The plain ladder: the host emulation's statement of the
+// operation (tests/host_emul); the library signs with k_sign_blind (mbls_kernels.hip)
 MBLS_FN void op_sign(uint64_t i, const uint8_t* sks32, const uint8_t* msgs, uint32_t mlen, uint8_t* out96) {
     uint32_t k[8]; scalar_from_be32(k, sks32 + 32 * i);
     g2j h; hash_to_g2(&h, msgs + (uint64_t)mlen * i, mlen, MBLS_DST_POP, MBLS_DST_POP_LEN);
-    g2_mul(&h, &h, k, 255);
+    g2_mul(&h, &h, k, 256);
     g2_encode_jacobian(out96 + 96 * i, &h);
 }
 // PublicKey::from_secret_key (reference src/keys.rs:124-137): pk = [sk] G1
 MBLS_FN void op_sk_to_pk(uint64_t i, const uint8_t* sks32, int fmt, uint8_t* out) {
     uint32_t k[8]; scalar_from_be32(k, sks32 + 32 * i);
     g1j g; g.x = fp_load_const(MBLS_G1_X); g.y = fp_load_const(MBLS_G1_Y); g.z = fp_one();
-    g1_mul(&g, &g, k, 255);
+    g1_mul(&g, &g, k, 256);
     fp x, y; bool inf; g1_to_affine(&x, &y, &inf, &g);
     if (fmt == MBLS_PK_COMPRESSED) g1_encode_compressed(out + 48 * i, x, y, inf); else g1_encode_uncompressed(out + 96 * i, x, y, inf);
 }

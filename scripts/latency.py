@@ -50,7 +50,8 @@ from milagro_bls_amd import AggregateSignature, PublicKey, Signature, SecretKey
 sk = SecretKey.from_bytes(bytes([1] * 32)); pk = PublicKey.from_secret_key(sk); msg = b"Some msg"; sig = Signature.new(msg, sk)
 assert sig.verify(msg, pk)
 out["scalar_api"] = {"Signature::verify": med(lambda: sig.verify(msg, pk)), "Signature::new": med(lambda: Signature.new(msg, sk)),
-                     "PublicKey::from_bytes (decode + KeyValidate)": med(lambda: PublicKey.from_bytes(pk.as_bytes()))}
+                     "PublicKey::from_bytes (decode + KeyValidate)": med(lambda: PublicKey.from_bytes(pk.as_bytes())),
+                     "PublicKey::from_secret_key": med(lambda: PublicKey.from_secret_key(sk))}
 keys = [PublicKey(bytes(pks[0, j])) for j in range(k)]
 asig = AggregateSignature(bytes(sigs[0]))
 assert asig.fast_aggregate_verify(bytes(msgs[0]), keys)

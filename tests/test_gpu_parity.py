@@ -108,6 +108,22 @@ def test_sign_and_keys_external_vectors(mb, vectors):
     sk = b"".join(rnd.randrange(1, helpers.R).to_bytes(32, "big") for _ in range(n)); msgs = rnd.randbytes(32 * n)
     assert mb.sign_batch(sk, msgs, n) == orc.batch_sign(sk, msgs, n, nthreads=8)
     assert mb.sk_to_pk_batch(sk, n, out_format=1) == orc.batch_sk_to_pk(sk, n, 1, nthreads=8)
+    # scalars at the edges of the base-|x| split of the signing path and of the 64 x 16 generator table: small, sparse, powers of the
+    # curve parameter, r - 1, and 32-byte values that are not below r (no SecretKey holds one; the product is [sk mod r] all the same)
+    y = 0xd201000000010000
+    edge = [1, 2, 15, 16, y - 1, y, y + 1, y * y, y ** 3, y ** 3 - 1, (y - 1) * (1 + y + y * y + y ** 3), helpers.R - 1, helpers.R - 2,
+            0, helpers.R, helpers.R + 1, 2 ** 255 - 1, 2 ** 255, 2 ** 256 - 1, 0x1111111111111111111111111111111111111111111111111111111111111111,
+            0xf0f0f0f0f0f0f0f0f0f0f0f0f0f0f0f0f0f0f0f0f0f0f0f0f0f0f0f0f0f0f0f0, 1 << 252, (1 << 128) - 1]
+    n = len(edge)
+    sk = b"".join(v.to_bytes(32, "big") for v in edge); msgs = rnd.randbytes(32 * n)
+    assert mb.sign_batch(sk, msgs, n) == orc.batch_sign(sk, msgs, n, nthreads=8)
+    assert mb.sk_to_pk_batch(sk, n, out_format=0) == orc.batch_sk_to_pk(sk, n, 0, nthreads=8)
+    n = 3000                                                               # more than one wave per SIMD row, one lane per item in the message phase
+    sk = b"".join(rnd.randrange(1, helpers.R).to_bytes(32, "big") for _ in range(n)); msgs = rnd.randbytes(32 * n)
+    got = mb.sign_batch(sk, msgs, n)
+    pick = rnd.sample(range(n), 48)
+    assert b"".join(got[96 * i:96 * i + 96] for i in pick) == orc.batch_sign(b"".join(sk[32 * i:32 * i + 32] for i in pick), b"".join(msgs[32 * i:32 * i + 32] for i in pick), 48, nthreads=8)
+    assert mb.sk_to_pk_batch(sk, n) == orc.batch_sk_to_pk(sk, n, 0, nthreads=8)
 
 
 def test_codec_parity(mb, vectors):
@@ -142,6 +158,41 @@ def test_codec_parity(mb, vectors):
     for i, bl in enumerate(blobs2):
         e, pt = orc.g2_from_compressed(bl)
         assert errs[i] == e and (e != 0 or in_g2[i] == orc.g2_subgroup_check(pt))
+
+
+def test_key_validate_outside_the_subgroup_vs_oracle(mb):
+    """KeyValidate (reference src/keys.rs:176-185: subgroup_check_g1 = [r]P == O) on curve points outside G1: points of every prime order
+    dividing the cofactor, G1 points shifted by them, random curve points -- the kernel decides by phi(P) == [-x^2]P, the oracle by [r]P."""
+    import bls12_381 as M
+    rnd = random.Random(77)
+    def curve_point():
+        while True:
+            x = rnd.randrange(M.P); y = M.fp_sqrt((x * x * x + 4) % M.P)
+            if y is not None:
+                return (x, y if rnd.getrandbits(1) else (-y) % M.P)
+    h = (M.X_ABS + 1) ** 2 // 3                                      # G1 cofactor (x - 1)^2 / 3, x = -X_ABS
+    assert h * M.R == M.P + 1 - (-M.X_ABS + 1)                      # #E(Fp) = p + 1 - t, t = x + 1
+    pts = []
+    for ell in (3, 11, 10177, 859267, 52437899):
+        assert h % ell == 0
+        for _ in range(2):
+            t = None
+            while t is None:
+                t = M.g1_mul(curve_point(), h * M.R // (ell if ell == 3 else ell * ell))   # E[ell] is rational for ell | x - 1, ell != 3
+            g = M.g1_mul(M.G1, rnd.randrange(1, M.R))
+            pts += [t, M.g1_add(g, t), M.g1_add(M.g1_mul(t, 2), g)]
+    pts.append((0, 2)); pts.append((0, M.P - 2))                     # the 3-torsion points with x = 0
+    pts += [curve_point() for _ in range(96)]
+    pts += [M.g1_mul(M.G1, rnd.randrange(1, M.R)) for _ in range(24)]
+    pts += [M.g1_mul(curve_point(), h) for _ in range(8)]            # cofactor-cleared: in G1
+    blobs = [M.g1_compress(pt) for pt in pts]
+    want = [orc.g1_key_validate(orc.g1_from_compressed(b)[1]) for b in blobs]
+    assert sum(want) >= 32 and want.count(False) >= 96
+    out, errs = mb.pk_decode_batch(b"".join(blobs), len(blobs), validate=True)
+    assert [e == 0 for e in errs] == want
+    from milagro_bls_amd import api
+    for i in (0, 1, 2, 30, 31, len(pts) - 1, len(pts) - 9):          # PublicKey::key_validate, one key per call
+        assert api.PublicKey(M.g1_serialize_uncompressed(pts[i])).key_validate() == want[i]
 
 
 @pytest.mark.parametrize("fmt", [0, 1])

@@ -2594,7 +2594,8 @@ def g2_blind_routine():
     test psi(P) = [x]P of the decoded signature, then [r] P for the lane's 64-bit blinding scalar r by signed 4-bit windows:
     r + 0x8888888888888888 = sum e_j 16^j (+ a carry digit), r = sum (e_j - 8) 16^j + carry 2^64; the table 1 P .. 8 P lives in workspace
     records (BL_TAB, one per multiple) and each lane fetches ITS record (kind 'gv'); 64 doublings + 17 additions instead of 64 + 64.
-    In:  slots 3..6 = the signature's affine x, y (2^384 domain); v[248:249] = r; v252 / s[68:69] / s70 as in the other routines.
+    In:  slots 3..6 = the signature's affine x, y (2^384 domain); v[248:249] = r; v251 = 0 (wave-uniform; non-zero skips the subgroup test and
+         is returned as is); v252 / s[68:69] / s70 as in the other routines.
     Out: v251 = 1 iff psi(P) = [x]P; slots 25..30 = [r] P (Jacobian, canonical, 2^384 domain). Slots 43..48, 49..96 are scratch."""
     S = G2_SLOTS
     B, st = {}, {}
@@ -2622,10 +2623,11 @@ def g2_blind_routine():
 
     def call_far(label):
         return ["s_getpc_b64 s[96:97]", "7:", "s_add_u32 s96, s96, 8f-7b", "s_addc_u32 s97, s97, 0"] + far_fwd(label) + ["8:"]
-    # the subgroup test
-    main = X("s_start") + call_far(LADDER) + X("s_compare")
+    # the subgroup test (skipped when the caller passes v251 != 0 in its first active lane: a point known to be in G2 -- signing)
+    main = X("s_start") + ["v_readfirstlane_b32 s38, v251", "s_cmp_lg_u32 s38, 0", "s_cbranch_scc0 3f"] + far_fwd(9) + ["3:"]
+    main += call_far(LADDER) + X("s_compare")
     main += ["s_and_b64 s[92:93], %s, %s" % (M_H0, M_R0), "s_andn2_b64 s[92:93], s[92:93], %s" % M_INF1, "s_andn2_b64 s[92:93], s[92:93], %s" % M_INF2,
-             "s_and_b64 %s, %s, %s" % (G2M_TMP0, M_INF1, M_INF2), "s_or_b64 s[92:93], s[92:93], %s" % G2M_TMP0, "v_cndmask_b32_e64 v251, 0, 1, s[92:93]"]
+             "s_and_b64 %s, %s, %s" % (G2M_TMP0, M_INF1, M_INF2), "s_or_b64 s[92:93], s[92:93], %s" % G2M_TMP0, "v_cndmask_b32_e64 v251, 0, 1, s[92:93]", "9:"]
     # the table: record e holds (e + 1) P
     main += X("b_start") + ["s_mov_b32 %s, 0" % GKOFF] + X("b_tab") + X("dbl") + ["s_mov_b32 %s, s72" % GKOFF] + X("b_tab")
     main += ["s_mov_b32 s79, 6", "5:"] + call_sub(ADD) + ["s_add_u32 %s, %s, s72" % (GKOFF, GKOFF)] + X("b_tab")
