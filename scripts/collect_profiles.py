@@ -10,7 +10,7 @@ for cfg, name in (("c2", "config2"), ("c4", "config4"), ("clat", "latency_n64"))
     g = glob.glob(os.path.dirname(stats.rstrip("/")) + "/stats_%s/*_kernel_stats.csv" % cfg)
     if g:
         shutil.copy(g[0], "profiles/%s_%s_kernel_stats.csv" % (tag, name))
-for extra in ("latency.json", "kstats.txt", "bench_line_131072.json"):
+for extra in ("latency.json", "kstats.txt", "bench_line_131072.json", "keyops.json"):
     src = os.path.join(os.path.dirname(stats.rstrip("/")), extra)
     if os.path.exists(src):
         shutil.copy(src, "profiles/%s_%s" % (tag, {"kstats.txt": "kernel_resources.txt"}.get(extra, extra)))

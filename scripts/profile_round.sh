@@ -22,6 +22,7 @@ cd $ROOT
 python3 bench.py --steps 10 --warmup 2 > $OUT/bench_line.json 2> $OUT/bench.err
 python3 bench.py --items 131072 --steps 5 --warmup 1 --no-cpu-baseline > $OUT/bench_line_131072.json 2>> $OUT/bench.err
 python3 scripts/latency.py $OUT/latency.json > $OUT/latency.log 2>&1
+python3 scripts/time_keyops.py > $OUT/keyops.log 2>&1; cp gpurun_out/keyops.json $OUT/keyops.json
 bash scripts/kstats.sh > $OUT/kstats.txt 2>&1
 find $OUT -name "*.csv" -size +20M -delete
 ls -la $OUT $OUT/stats $OUT/fetch 2>/dev/null | head -40
