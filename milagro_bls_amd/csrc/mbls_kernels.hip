@@ -996,6 +996,7 @@ static int ensure_gtab(mbls_ctx* c) {
     if (c->d_gtab) return MBLS_OK;
     std::vector<uint8_t> sc(32 * 1024, 0);
     for (int j = 0; j < 64; j++) for (int d = 0; d < 16; d++) sc[32 * (16 * j + d) + 31 - (j >> 1)] = (uint8_t)(d << (4 * (j & 1)));
+    HIPCHK(c, hipDeviceSynchronize());       // once per context: nothing in flight may still be reading the staging buffers used here
     sbuf dk(c, 7), dp(c, 8), de(c, 9);      // not the staging slots of the host entries that call this with their inputs already uploaded
     HIPCHK(c, dk.up(sc.data(), sc.size())); HIPCHK(c, dp.alloc(96 * 1024)); HIPCHK(c, de.alloc(1024));
     uint32_t* tab = nullptr; HIPCHK(c, hipMalloc(&tab, 1024 * MBLS_KEYREC_DWORDS * 4));
