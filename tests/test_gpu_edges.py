@@ -677,3 +677,33 @@ def test_multi_device_handle_matches_single_context_and_oracle(mb, N):
         assert got4 == [True]
         assert mb.multi_fast_aggregate_verify_batch(m, b"", b"", b"", 0, 1, pk_format=1)[0] == []
         tab.close(); m.close()
+
+
+def test_signing_in_chunks_other_message_lengths_and_streams(mb):
+    """mbls_sign_batch_device / mbls_sk_to_pk_batch_device (reference src/signature.rs:17-21, src/keys.rs:124-137) beyond one chunk of the
+    four-lane signing pipeline (65 536 signatures) and of the table-driven key derivation (131 072 keys), with a message length that is not
+    32, on a stream of the caller's: every signature verifies against its key, a sample is the oracle's, and the empty message signs too."""
+    import torch
+    from milagro_bls_amd import _native as N
+    ctx = N.default_context(); lib = N.lib(); dev = torch.device("cuda:0")
+    n, mlen = 131072 + 77, 45
+    g = torch.Generator(device="cpu"); g.manual_seed(99)
+    sks = torch.randint(0, 256, (n, 32), dtype=torch.uint8, generator=g); sks[:, 0] &= 0x3F; sks[:, 31] |= 1
+    msgs = torch.randint(0, 256, (n, mlen), dtype=torch.uint8, generator=g)
+    d_sk, d_msg = sks.to(dev), msgs.to(dev)
+    d_sig = torch.zeros((n, 96), dtype=torch.uint8, device=dev); d_pk = torch.zeros((n, 48), dtype=torch.uint8, device=dev)
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        ctx.check(lib.mbls_sign_batch_device(ctx.handle, d_sk.data_ptr(), d_msg.data_ptr(), mlen, n, d_sig.data_ptr(), C.c_void_p(st.cuda_stream)))
+        ctx.check(lib.mbls_sk_to_pk_batch_device(ctx.handle, d_sk.data_ptr(), 0, n, d_pk.data_ptr(), C.c_void_p(st.cuda_stream)))
+    st.synchronize()
+    d_res = torch.zeros(n, dtype=torch.uint8, device=dev)
+    ctx.check(lib.mbls_verify_batch_device(ctx.handle, d_sig.data_ptr(), d_msg.data_ptr(), mlen, None, d_pk.data_ptr(), 0, n, d_res.data_ptr(), None, None, None))
+    torch.cuda.synchronize()
+    assert bool(d_res.all().item())
+    pick = [0, 1, 65535, 65536, 65537, 131071, 131072, n - 1]
+    sub = lambda t: b"".join(bytes(t[i].cpu().numpy().tobytes()) for i in pick)
+    assert sub(d_sig) == orc.batch_sign(sub(d_sk), sub(d_msg), len(pick), msg_len=mlen, nthreads=8)
+    assert sub(d_pk) == orc.batch_sk_to_pk(sub(d_sk), len(pick), 0, nthreads=8)
+    sk1 = (12345).to_bytes(32, "big")
+    assert mb.sign_batch(sk1, b"", 1, msg_len=0) == orc.batch_sign(sk1, b"", 1, msg_len=0)
