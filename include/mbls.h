@@ -229,7 +229,9 @@ int mbls_pk_decode_batch(mbls_ctx* ctx, const uint8_t* in, int in_format, int va
 int mbls_pk_compress_batch(mbls_ctx* ctx, const uint8_t* in96, uint64_t n, uint8_t* out48, uint8_t* errs);
 /* n x Signature::from_bytes: errs[i]; in_g2 (optional) = subgroup_check_g2 per signature */
 int mbls_sig_check_batch(mbls_ctx* ctx, const uint8_t* in96, uint64_t n, uint8_t* errs, uint8_t* in_g2);
-/* n x Signature::new / PublicKey::from_secret_key (secret keys are NOT range-checked here) */
+/* n x Signature::new / PublicKey::from_secret_key. Secret keys are NOT range-checked here: any 32-byte big-endian value gives [sk mod r] H(msg) /
+ * [sk mod r] G1. The device entries use the context's workspace (four items per signature, in chunks of 65 536 signatures) and wait for its
+ * previous user like the verification entries; they only enqueue. */
 int mbls_sign_batch(mbls_ctx* ctx, const uint8_t* sks32, const uint8_t* msgs, uint32_t msg_len, uint64_t n, uint8_t* sigs96);
 int mbls_sign_batch_device(mbls_ctx* ctx, const uint8_t* d_sks32, const uint8_t* d_msgs, uint32_t msg_len, uint64_t n, uint8_t* d_sigs96, void* stream);
 int mbls_sk_to_pk_batch(mbls_ctx* ctx, const uint8_t* sks32, int out_format, uint64_t n, uint8_t* pks);
