@@ -72,7 +72,7 @@ const char* mbls_last_error(mbls_ctx* ctx);
 /* Small batches are latency-bound (one lane per item walks 14 M dependent instructions whatever the batch size), so batches of up to
  * max_items items run their pairing check -- Miller loop + final exponentiation -- with ONE WAVE per item, the item's field values
  * shared by the 64 lanes (mbls_coop.h); up to 1536 items the message phase after hash_to_field does the same. Same results, bit for bit.
- * Defaults 8192 / 1536: the measured crossovers (environment: MBLS_COOP_MAX_ITEMS); 0 = never. */
+ * Defaults 10240 / 1536: the measured crossovers (environment: MBLS_COOP_MAX_ITEMS); 0 = never. */
 int mbls_ctx_set_coop_max_items(mbls_ctx* ctx, uint64_t max_items);
 int mbls_ctx_set_coop_hash_max_items(mbls_ctx* ctx, uint64_t max_items);     /* the same for the message phase (never above the limit above) */
 

@@ -443,9 +443,9 @@ struct mbls_ctx {
     coop_prog coop[8] = {};            // the cooperative engine's microprograms in HBM (mbls_coop.h): pairing2, vmtail, f12mul, g2add, smiller, vmfinal, hashg2, miller1
     uint32_t* d_coop = nullptr;
     // measured crossovers (scripts/coop_sweep.py, 128 keys, device-resident): one wave per item for the pairing check wins up to ~10 k items
-    // (18.5 ms at 8 192 against 22.5), for the message phase as well up to ~1.5 k (7.7 ms at 1 536 against 8.3)
+    // (19.7 ms at 10 240 against 22.5), for the message phase as well up to ~1.5 k (7.7 ms at 1 536 against 8.3)
     uint64_t coop_hash_max_items = 1536;
-    uint64_t coop_max_items = 8192;
+    uint64_t coop_max_items = 10240;
     char err[256] = {};
 };
 struct mbls_keytable {

@@ -94,12 +94,52 @@ class Node:
         self.last_use = -1
 
 
+# Product shapes per (program, block): (Fp2 products schoolbook instead of Karatsuba, Fp6 products schoolbook instead of Karatsuba). A wave
+# has 64 product lanes a step and the formulas rarely fill them, while every operand that is a sum of more than four slots costs a LIN
+# operation first: spending idle product lanes on schoolbook forms (operands are the inputs themselves, results have fewer terms) shortens
+# the step lists. The table is the result of a search (tools/coop_shapes.py: per block the shape with the fewest steps, the program within
+# the slot budget of eight waves per CU); blocks not listed use Karatsuba at both levels.
+SHAPES = {
+    ('f12mul', 'mul'): (1, 1),
+    ('g2add', 'add'): (2, 0),
+    ('hashg2', 'ladd'): (1, 0),
+    ('hashg2', 'lsub'): (1, 0),
+    ('hashg2', 'sswu'): (2, 0),
+    ('miller1', 'add'): (2, 0),
+    ('miller1', 'dbl'): (2, 0),
+    ('pairing2', 'add'): (2, 0),
+    ('pairing2', 'dbl'): (0, 1),
+    ('pairing2', 'easy'): (2, 0),
+    ('pairing2', 'mulbase'): (1, 1),
+    ('pairing2', 'step_conj'): (1, 1),
+    ('pairing2', 'step_frob'): (1, 1),
+    ('pairing2', 'tail'): (2, 1),
+    ('smiller', 'add'): (2, 0),
+    ('smiller', 'dbl'): (2, 0),
+    ('vmfinal', 'easy'): (2, 0),
+    ('vmfinal', 'join'): (0, 1),
+    ('vmfinal', 'mulbase'): (1, 1),
+    ('vmfinal', 'step_conj'): (1, 1),
+    ('vmfinal', 'step_frob'): (1, 1),
+    ('vmfinal', 'tail'): (0, 1),
+    ('vmtail', 'add'): (2, 0),
+    ('vmtail', 'dbl'): (2, 0),
+    ('vmtail', 'easy'): (2, 0),
+    ('vmtail', 'join'): (0, 1),
+    ('vmtail', 'mulbase'): (1, 1),
+    ('vmtail', 'step_conj'): (1, 1),
+    ('vmtail', 'step_frob'): (1, 1),
+    ('vmtail', 'tail'): (2, 1),
+}
+
+
 class Block(T.Prog):
     """One block of a cooperative program: a DAG of Fp operations over lazy linear combinations, with the Fp2 / Fp6 / Fp12 layers of
     gen_tower_d.Prog on top (its primitives are overridden below). Live-in values are pinned slots of the program's state."""
 
     def __init__(self, machine, name):
         self.m, self.name = machine, name
+        self.shape = SHAPES.get((machine.name, name), (0, 0))
         self.nodes = []
         self.mat_cache, self.mul_cache, self.const_cache = {}, {}, {}
         self.items = []                  # schedulable operations in creation order
@@ -205,12 +245,16 @@ class Block(T.Prog):
         return LC({self.mul_cache[k]: 1})
 
     def call(self, kind, ins):
-        if kind == "mul":                                    # Karatsuba: 3 products
+        if kind == "mul":
             a0, a1, b0, b1 = ins
-            t0, t1, t2 = self.mul(a0, b0), self.mul(a1, b1), self.mul(a0 + a1, b0 + b1)
+            if self.shape[0]:                                # schoolbook: 4 products on the operands themselves, two-term results (see SHAPES)
+                return (self.mul(a0, b0) - self.mul(a1, b1), self.mul(a0, b1) + self.mul(a1, b0))
+            t0, t1, t2 = self.mul(a0, b0), self.mul(a1, b1), self.mul(a0 + a1, b0 + b1)      # Karatsuba: 3 products
             return (t0 - t1, t2 - t0 - t1)
         if kind == "sqr":
             a0, a1 = ins
+            if self.shape[0] == 2:                           # three products on the operands themselves
+                return (self.mul(a0, a0) - self.mul(a1, a1), self.mul(a0, a1).scaled(2))
             return (self.mul(a0 + a1, a0 - a1), self.mul(a0, a1).scaled(2))
         if kind == "mulfp":
             a0, a1, s = ins
@@ -232,6 +276,15 @@ class Block(T.Prog):
 
     def mul2(self, a, b):
         return self.sqr2(a) if (a[0] is b[0] and a[1] is b[1]) else self.call("mul", [a[0], a[1], b[0], b[1]])
+
+    def mul6(self, a, b):
+        if not self.shape[1]:
+            return T.Prog.mul6(self, a, b)                   # Karatsuba over Fp2: 6 products
+        m = self.mul2                                        # schoolbook: 9 products, no operand sums
+        c0 = self.add2(m(a[0], b[0]), self.mul_xi2(self.add2(m(a[1], b[2]), m(a[2], b[1]))))
+        c1 = self.add2(self.add2(m(a[0], b[1]), m(a[1], b[0])), self.mul_xi2(m(a[2], b[2])))
+        c2 = self.add2(self.add2(m(a[0], b[2]), m(a[1], b[1])), m(a[2], b[0]))
+        return [c0, c1, c2]
 
     def sel(self, flag, a, b):
         """flag ? b : a   (flag: a flag word index)"""
