@@ -71,10 +71,14 @@ int mbls_ctx_reserve_keys(mbls_ctx* ctx, uint64_t max_keys);
 const char* mbls_last_error(mbls_ctx* ctx);
 /* Small batches are latency-bound (one lane per item walks 14 M dependent instructions whatever the batch size), so batches of up to
  * max_items items run their pairing check -- Miller loop + final exponentiation -- with ONE WAVE per item, the item's field values
- * shared by the 64 lanes (mbls_coop.h); up to 1536 items the message phase after hash_to_field does the same. Same results, bit for bit.
- * Defaults 10240 / 1536: the measured crossovers (environment: MBLS_COOP_MAX_ITEMS); 0 = never. */
+ * shared by the 64 lanes (mbls_coop.h); up to 6144 items the message phase after hash_to_field does the same. Same results, bit for bit.
+ * Defaults 10240 / 6144: the measured crossovers (environment: MBLS_COOP_MAX_ITEMS); 0 = never. */
 int mbls_ctx_set_coop_max_items(mbls_ctx* ctx, uint64_t max_items);
 int mbls_ctx_set_coop_hash_max_items(mbls_ctx* ctx, uint64_t max_items);     /* the same for the message phase (never above the limit above) */
+/* Within those limits, batches of pairing_min_items < n <= pairing_max_items items run the pairing check with two items per wave, and of
+ * more than hash_min_items the message phase with four: more steps per wave, fewer per item -- it pays where it saves a round of waves.
+ * Defaults (1024, 2048] and 768 (measured); min = UINT64_MAX: never. */
+int mbls_ctx_set_coop_packing(mbls_ctx* ctx, uint64_t pairing_min_items, uint64_t pairing_max_items, uint64_t hash_min_items);
 
 /* ---- the hot path -------------------------------------------------------------------------------------
  * Batch of n independent AggregateSignature::fast_aggregate_verify calls (reference src/aggregates.rs:177-215):

@@ -33,6 +33,7 @@ SIGNATURES = {
     "mbls_ctx_reserve_keys": (C.c_int, [vp, C.c_uint64]),
     "mbls_ctx_set_coop_max_items": (C.c_int, [vp, C.c_uint64]),
     "mbls_ctx_set_coop_hash_max_items": (C.c_int, [vp, C.c_uint64]),
+    "mbls_ctx_set_coop_packing": (C.c_int, [vp, C.c_uint64, C.c_uint64, C.c_uint64]),
     "mbls_last_error": (C.c_char_p, [vp]),
     "mbls_fast_aggregate_verify_batch_device": (C.c_int, [vp, vp, vp, C.c_uint32, vp, vp, C.c_int, vp, C.c_uint64, C.c_uint32, vp, vp, vp, vp]),
     "mbls_fast_aggregate_verify_batch": (C.c_int, [vp, vp, vp, C.c_uint32, vp, vp, C.c_int, vp, C.c_uint64, C.c_uint32, vp, vp]),
@@ -167,6 +168,10 @@ class Context:
 
     def set_coop_hash_max_items(self, n):
         self.check(lib().mbls_ctx_set_coop_hash_max_items(self._h, n))
+
+    def set_coop_packing(self, pairing_min_items, pairing_max_items, hash_min_items):
+        """pairing_min < n <= pairing_max: two items per wave in the pairing check; n > hash_min: four per wave in the message phase"""
+        self.check(lib().mbls_ctx_set_coop_packing(self._h, pairing_min_items, pairing_max_items, hash_min_items))
 
 
 class KeyTable:

@@ -33,7 +33,9 @@
 #define COOP_RES_ITEM 0                  // RES: fold the pairing bit into status[item], results[item] like lane_final
 #define COOP_RES_BATCH 1                 // RES: one bool for the whole batch: the pairing bit and no rejecting bit in the OR of all status words
 
-struct coop_prog { const uint32_t* steps; const uint32_t* rows; const uint32_t* consts; uint32_t nconsts; };
+// lpi: lanes of a step one item uses (64, 32, 16: the wave serves 64 / lpi items side by side); nslots: LDS slots of one item
+struct coop_prog { const uint32_t* steps; const uint32_t* rows; const uint32_t* consts; uint32_t nconsts; uint32_t lpi; uint32_t nslots; };
+#define COOP_LDS_BYTES(pg) ((pg).lpi == 64 ? (size_t)0 : (size_t)(64 / (pg).lpi) * (((pg).nslots + 1) * COOP_SW * 4 + 64 * 4))      /* dynamic part */
 typedef int32_t coop_v16 __attribute__((ext_vector_type(16)));
 
 #define COOP_M28 0x0fffffff
@@ -120,29 +122,44 @@ MBLS_FN void coop_from_words(int32_t* out, fp w) {
 // partner_step: LOADW with bit 16 of its workspace slot set reads from item + partner_step instead (the other operand of a tree product).
 // POW: the instance that also knows the fixed-exponent step (its routine keeps a window table in AGPRs: the plain instance stays small
 // enough for two waves per SIMD).
-template <bool POW>
+// LPI: lanes of a step one item uses -- 64: one item per wave, its slots in a static allocation (the latency path); 32 / 16: two / four
+// items per wave side by side, each with its own slots and flag words in the dynamic allocation (COOP_LDS_BYTES).
+template <bool POW, int LPI>
 __global__ void __launch_bounds__(64) k_coop_t(coop_prog pg, mbls_ws ws, uint64_t first_item, uint64_t item_step, uint64_t partner_step, uint64_t n_items,
                                              uint32_t* status, uint8_t* results, int res_mode) {
 #if MBLS_DEVICE_ASM && !defined(MBLS_NO_FP2_ASM)
-    __shared__ __attribute__((aligned(16))) int32_t S[MBLS_COOP_MAX_SLOTS * COOP_SW];
-    __shared__ uint32_t flags[64];
+    extern __shared__ __attribute__((aligned(16))) int32_t coop_lds[];
+    __shared__ __attribute__((aligned(16))) int32_t S1[LPI == 64 ? MBLS_COOP_MAX_SLOTS * COOP_SW : 16];
+    __shared__ uint32_t flags1[64];
     const uint32_t lane = threadIdx.x;
-    const uint64_t item = first_item + (uint64_t)blockIdx.x * item_step;
-    for (uint32_t t = lane; t < MBLS_COOP_MAX_SLOTS * COOP_SW; t += 64) S[t] = 0;
-    flags[lane] = lane == 1 ? 1u : 0u;
+    constexpr uint32_t ipw = 64u / LPI;
+    const uint32_t sub = lane / LPI, ll = lane & (LPI - 1u);
+    const uint32_t slot_words = LPI == 64 ? MBLS_COOP_MAX_SLOTS * COOP_SW : (pg.nslots + 1u) * COOP_SW;
+    int32_t* const S = LPI == 64 ? S1 : coop_lds + sub * slot_words;         // this lane's item
+    uint32_t* const flags = LPI == 64 ? flags1 : (uint32_t*)(coop_lds + ipw * slot_words) + 64u * sub;
+    const uint64_t index = (uint64_t)blockIdx.x * ipw + sub;                   // the items beyond n_items (last wave) compute on item 0 and write nothing
+    const bool valid = LPI == 64 || index < n_items;
+    const uint64_t item = first_item + (valid ? index : 0) * item_step;
+    if (LPI == 64) {
+        for (uint32_t t = lane; t < MBLS_COOP_MAX_SLOTS * COOP_SW; t += 64) S1[t] = 0;
+        flags1[lane] = lane == 1 ? 1u : 0u;
+    } else {
+        for (uint32_t t = lane; t < ipw * slot_words; t += 64) coop_lds[t] = 0;
+        for (uint32_t t = lane; t < ipw * 64u; t += 64) ((uint32_t*)(coop_lds + ipw * slot_words))[t] = (t & 63u) == 1u ? 1u : 0u;
+    }
     __syncthreads();
-    for (uint32_t t = lane; t < pg.nconsts * 14; t += 64) S[pg.consts[15 * (t / 14)] * COOP_SW + (t % 14)] = (int32_t)pg.consts[15 * (t / 14) + 1 + (t % 14)];
+    for (uint32_t t = ll; t < pg.nconsts * 14; t += LPI) S[pg.consts[15 * (t / 14)] * COOP_SW + (t % 14)] = (int32_t)pg.consts[15 * (t / 14) + 1 + (t % 14)];
     __syncthreads();
     const uint4* rows = (const uint4*)pg.rows;
     uint32_t info = pg.steps[0], row = pg.steps[1];
-    uint4 m0 = rows[(uint64_t)row * 128 + 2 * lane], m1 = rows[(uint64_t)row * 128 + 2 * lane + 1];
+    uint4 m0 = rows[(uint64_t)row * 128 + 2 * ll], m1 = rows[(uint64_t)row * 128 + 2 * ll + 1];
     for (uint32_t step = 0;; step++) {
         const uint32_t kind = info & 0xFF, na = (info >> 8) & 0xF, nb = (info >> 12) & 0xF;
         if (kind == COOP_K_END) break;
         const uint4 c0 = m0, c1 = m1;
         // the next step's microcode is requested before this step runs (the rows are shared by every wave: L2 hits)
         info = pg.steps[2 * (step + 1)]; row = pg.steps[2 * (step + 1) + 1];
-        m0 = rows[(uint64_t)row * 128 + 2 * lane]; m1 = rows[(uint64_t)row * 128 + 2 * lane + 1];
+        m0 = rows[(uint64_t)row * 128 + 2 * ll]; m1 = rows[(uint64_t)row * 128 + 2 * ll + 1];
         int32_t cf[8]; uint32_t ix[8];
 #pragma unroll
         for (int t = 0; t < 4; t++) { cf[t] = (int32_t)(int8_t)(c0.x >> (8 * t)); cf[4 + t] = (int32_t)(int8_t)(c0.y >> (8 * t)); }
@@ -151,7 +168,7 @@ __global__ void __launch_bounds__(64) k_coop_t(coop_prog pg, mbls_ws ws, uint64_
         ix[6] = c1.x & 1023; ix[7] = (c1.x >> 10) & 1023;
         const uint32_t dst = (c1.x >> 20) & 1023;
         const uint32_t fl = c1.y & 0xFF, fl2 = (c1.y >> 8) & 0xFF, fop = (c1.y >> 16) & 0xFF;
-        const bool active = (c1.y >> 31) != 0;
+        const bool active = (c1.y >> 31) != 0, writes = active && valid;
         const uint32_t wslot = c1.z;
         if (kind == COOP_K_MUL) {
             int32_t a[14], b[14], r[14];
@@ -249,9 +266,9 @@ __global__ void __launch_bounds__(64) k_coop_t(coop_prog pg, mbls_ws ws, uint64_
 #pragma unroll
             for (int j = 0; j < 14; j++) d[j] = S[ix[0] * COOP_SW + j];
             coop_canonical(d);
-            if (active) ws_st(ws, (int)wslot, item, coop_to_words(d));
+            if (writes) ws_st(ws, (int)wslot, item, coop_to_words(d));
         } else if (kind == COOP_K_RES) {
-            if (active) {
+            if (writes) {
                 const bool ok = flags[fl] != 0 && flags[fl2] == 0;
                 if (res_mode == COOP_RES_ITEM) {
                     uint32_t st = status[item];
@@ -268,5 +285,7 @@ __global__ void __launch_bounds__(64) k_coop_t(coop_prog pg, mbls_ws ws, uint64_
     }
 #endif
 }
-#define k_coop k_coop_t<false>
-#define k_coop_pow k_coop_t<true>
+#define k_coop k_coop_t<false, 64>
+#define k_coop_pow k_coop_t<true, 64>
+#define k_coop_x2 k_coop_t<false, 32>
+#define k_coop_pow_x4 k_coop_t<true, 16>

@@ -440,12 +440,15 @@ struct mbls_ctx {
     hipEvent_t ev[MBLS_N_PHASES + 1] = {};
     float phase_ms[MBLS_N_PHASES] = {};
     std::vector<struct mbls_keytable*> tables;     // the key tables created on this context (orphaned when it is destroyed)
-    coop_prog coop[8] = {};            // the cooperative engine's microprograms in HBM (mbls_coop.h): pairing2, vmtail, f12mul, g2add, smiller, vmfinal, hashg2, miller1
+    coop_prog coop[10] = {};           // the cooperative engine's microprograms in HBM (mbls_coop.h): pairing2, vmtail, f12mul, g2add, smiller, vmfinal, hashg2, miller1,
+                                       // pairing2x2 (two items per wave), hashg2x4 (four)
     uint32_t* d_coop = nullptr;
     // measured crossovers (scripts/coop_sweep.py, 128 keys, device-resident): one wave per item for the pairing check wins up to ~10 k items
-    // (19.7 ms at 10 240 against 22.5), for the message phase as well up to ~1.5 k (7.7 ms at 1 536 against 8.3)
-    uint64_t coop_hash_max_items = 1536;
+    // (19.7 ms at 10 240 against 22.5), for the message phase as well up to ~6 k (13.3 ms at 6 144 against 14.0; four items per wave above 768)
+    uint64_t coop_hash_max_items = 6144;
     uint64_t coop_max_items = 10240;
+    // within (pack_min, pack_max] a wave serves two items (pairing check) / four items (message phase) side by side: more steps per wave, fewer per item
+    uint64_t coop_pack_min_items = 1024, coop_pack_max_items = 2048, coop_hash_pack_min_items = 768;
     char err[256] = {};
 };
 struct mbls_keytable {
@@ -472,10 +475,27 @@ static void launch_aggregate(mbls_ws ws, const uint8_t* d_pks, const uint32_t* d
         hipLaunchKernelGGL(k_aggregate, dim3(nblk(n)), dim3(WG), 0, s, ws, d_pks, d_off, k, fmt, mode, st, n);
 }
 
+// one launch of the cooperative kernel: program `prog` on n_items items (64 / lpi of them per wave)
+enum { COOP_PAIRING2 = 0, COOP_VMTAIL, COOP_F12MUL, COOP_G2ADD, COOP_SMILLER, COOP_VMFINAL, COOP_HASHG2, COOP_MILLER1, COOP_PAIRING2X2, COOP_HASHG2X4 };
+static void coop_run(mbls_ctx* c, int prog, mbls_ws ws, uint64_t first_item, uint64_t item_step, uint64_t partner_step, uint64_t n_items, uint32_t* st, uint8_t* res,
+                     int res_mode, hipStream_t s) {
+    const coop_prog& pg = c->coop[prog];
+    const uint64_t ipw = 64 / pg.lpi;
+    const dim3 grid((unsigned)((n_items + ipw - 1) / ipw));
+    const size_t lds = COOP_LDS_BYTES(pg);
+    if (prog == COOP_HASHG2X4)
+        hipLaunchKernelGGL(k_coop_pow_x4, grid, dim3(64), lds, s, pg, ws, first_item, item_step, partner_step, n_items, st, res, res_mode);
+    else if (prog == COOP_HASHG2)
+        hipLaunchKernelGGL(k_coop_pow, grid, dim3(64), lds, s, pg, ws, first_item, item_step, partner_step, n_items, st, res, res_mode);
+    else if (prog == COOP_PAIRING2X2)
+        hipLaunchKernelGGL(k_coop_x2, grid, dim3(64), lds, s, pg, ws, first_item, item_step, partner_step, n_items, st, res, res_mode);
+    else
+        hipLaunchKernelGGL(k_coop, grid, dim3(64), lds, s, pg, ws, first_item, item_step, partner_step, n_items, st, res, res_mode);
+}
 static void launch_hash(mbls_ctx* c, mbls_ws ws, const uint8_t* d_msgs, uint32_t msg_len, const uint64_t* d_moff, uint32_t* st, uint64_t n, hipStream_t s) {
     if (n <= c->coop_hash_max_items && n <= c->coop_max_items) {
         hipLaunchKernelGGL(k_hash_fields, dim3(nblk(n)), dim3(WG), 0, s, ws, d_msgs, msg_len, d_moff, st, n);
-        hipLaunchKernelGGL(k_coop_pow, dim3((unsigned)n), dim3(64), 0, s, c->coop[6], ws, (uint64_t)0, (uint64_t)1, (uint64_t)0, n, (uint32_t*)nullptr, (uint8_t*)nullptr, COOP_RES_ITEM);
+        coop_run(c, n > c->coop_hash_pack_min_items ? COOP_HASHG2X4 : COOP_HASHG2, ws, (uint64_t)0, (uint64_t)1, (uint64_t)0, n, (uint32_t*)nullptr, (uint8_t*)nullptr, COOP_RES_ITEM, s);
     } else
         hipLaunchKernelGGL(k_hash, dim3(nblk(n)), dim3(WG), 0, s, ws, d_msgs, msg_len, d_moff, st, n);
 }
@@ -520,13 +540,16 @@ extern "C" int mbls_ctx_create(mbls_ctx** out, int device_id) {
     if (ok) {       // the cooperative engine's programs: one upload per context
 #define COOP_SRC(P) {MBLS_COOP_##P##_STEPS, MBLS_COOP_##P##_ROWS, MBLS_COOP_##P##_CONSTS}
 #define COOP_CNT(P) {2 * MBLS_COOP_##P##_NSTEPS, 512 * MBLS_COOP_##P##_NROWS, 15 * (MBLS_COOP_##P##_NCONSTS ? MBLS_COOP_##P##_NCONSTS : 1)}
-        const int NP = 8;
+        const int NP = 10;
         const uint32_t* src[NP][3] = {COOP_SRC(PAIRING2), COOP_SRC(VMTAIL), COOP_SRC(F12MUL), COOP_SRC(G2ADD), COOP_SRC(SMILLER), COOP_SRC(VMFINAL), COOP_SRC(HASHG2),
-                                      COOP_SRC(MILLER1)};
+                                      COOP_SRC(MILLER1), COOP_SRC(PAIRING2X2), COOP_SRC(HASHG2X4)};
         const size_t cnt[NP][3] = {COOP_CNT(PAIRING2), COOP_CNT(VMTAIL), COOP_CNT(F12MUL), COOP_CNT(G2ADD), COOP_CNT(SMILLER), COOP_CNT(VMFINAL), COOP_CNT(HASHG2),
-                                   COOP_CNT(MILLER1)};
+                                   COOP_CNT(MILLER1), COOP_CNT(PAIRING2X2), COOP_CNT(HASHG2X4)};
         const uint32_t nconst[NP] = {MBLS_COOP_PAIRING2_NCONSTS, MBLS_COOP_VMTAIL_NCONSTS, MBLS_COOP_F12MUL_NCONSTS, MBLS_COOP_G2ADD_NCONSTS, MBLS_COOP_SMILLER_NCONSTS,
-                                     MBLS_COOP_VMFINAL_NCONSTS, MBLS_COOP_HASHG2_NCONSTS, MBLS_COOP_MILLER1_NCONSTS};
+                                     MBLS_COOP_VMFINAL_NCONSTS, MBLS_COOP_HASHG2_NCONSTS, MBLS_COOP_MILLER1_NCONSTS, MBLS_COOP_PAIRING2X2_NCONSTS, MBLS_COOP_HASHG2X4_NCONSTS};
+#define COOP_DIM(P) {MBLS_COOP_##P##_LPI, MBLS_COOP_##P##_NSLOTS}
+        const uint32_t dims[NP][2] = {COOP_DIM(PAIRING2), COOP_DIM(VMTAIL), COOP_DIM(F12MUL), COOP_DIM(G2ADD), COOP_DIM(SMILLER), COOP_DIM(VMFINAL), COOP_DIM(HASHG2),
+                                      COOP_DIM(MILLER1), COOP_DIM(PAIRING2X2), COOP_DIM(HASHG2X4)};
         size_t total = 0;
         for (int p = 0; p < NP; p++) for (int a = 0; a < 3; a++) total += (cnt[p][a] + 3) & ~(size_t)3;       // 16-byte aligned pieces (the rows are read as uint4)
         ok = hipMalloc(&c->d_coop, total * 4) == hipSuccess;
@@ -539,6 +562,7 @@ extern "C" int mbls_ctx_create(mbls_ctx** out, int device_id) {
                 at += (cnt[p][a] + 3) & ~(size_t)3;
             }
             c->coop[p].steps = dp[0]; c->coop[p].rows = dp[1]; c->coop[p].consts = dp[2]; c->coop[p].nconsts = nconst[p];
+            c->coop[p].lpi = dims[p][0]; c->coop[p].nslots = dims[p][1];
         }
         const char* e = getenv("MBLS_COOP_MAX_ITEMS");
         if (e) c->coop_max_items = strtoull(e, nullptr, 10);
@@ -554,6 +578,10 @@ extern "C" int mbls_ctx_set_coop_max_items(mbls_ctx* c, uint64_t max_items) {
 extern "C" int mbls_ctx_set_coop_hash_max_items(mbls_ctx* c, uint64_t max_items) {
     if (!c) return MBLS_ERR_ARGUMENT;
     mbls_lock lk(c->mu); c->coop_hash_max_items = max_items; return MBLS_OK;
+}
+extern "C" int mbls_ctx_set_coop_packing(mbls_ctx* c, uint64_t pairing_min_items, uint64_t pairing_max_items, uint64_t hash_min_items) {
+    if (!c) return MBLS_ERR_ARGUMENT;
+    mbls_lock lk(c->mu); c->coop_pack_min_items = pairing_min_items; c->coop_pack_max_items = pairing_max_items; c->coop_hash_pack_min_items = hash_min_items; return MBLS_OK;
 }
 extern "C" void mbls_ctx_destroy(mbls_ctx* c) {
     if (!c) return;
@@ -704,7 +732,7 @@ static int verify_pipeline(mbls_ctx* c, const uint8_t* d_sigs, const uint8_t* d_
     }
     if (n <= c->coop_max_items) {
         // small batch: one WAVE per item walks the Miller loop and the final exponentiation with its lanes side by side (mbls_coop.h)
-        hipLaunchKernelGGL(k_coop, dim3((unsigned)n), dim3(64), 0, s, c->coop[0], ws, (uint64_t)0, (uint64_t)1, (uint64_t)0, n, st, d_results, COOP_RES_ITEM);
+        coop_run(c, (n > c->coop_pack_min_items && n <= c->coop_pack_max_items) ? COOP_PAIRING2X2 : COOP_PAIRING2, ws, (uint64_t)0, (uint64_t)1, (uint64_t)0, n, st, d_results, COOP_RES_ITEM, s);
         if (tm) { HIPCHK(c, hipEventRecord(c->ev[4], s)); HIPCHK(c, hipEventRecord(c->ev[5], s)); }
     } else {
         hipLaunchKernelGGL(k_miller, dim3(g), dim3(WG), 0, s, ws, n);
@@ -1270,7 +1298,7 @@ static void f12_tree(mbls_ctx* c, mbls_ws ws, uint64_t m, hipStream_t s) {
     while (m > 1) {
         const uint64_t half = (m + 1) / 2, pairs = m - half;
         if (pairs > MBLS_COOP_TREE_PAIRS) hipLaunchKernelGGL(k_f12_tree_d, dim3(nblk(half)), dim3(WG), 0, s, ws, m, half);
-        else hipLaunchKernelGGL(k_coop, dim3((unsigned)pairs), dim3(64), 0, s, c->coop[2], ws, (uint64_t)0, (uint64_t)1, half, pairs, (uint32_t*)nullptr, (uint8_t*)nullptr, COOP_RES_ITEM);
+        else coop_run(c, COOP_F12MUL, ws, (uint64_t)0, (uint64_t)1, half, pairs, (uint32_t*)nullptr, (uint8_t*)nullptr, COOP_RES_ITEM, s);
         m = half;
     }
 }
@@ -1278,7 +1306,7 @@ static void g2_tree_levels(mbls_ctx* c, mbls_ws ws, uint64_t m, int levels, hipS
     while (m > 1 && levels-- > 0) {
         const uint64_t half = (m + 1) / 2, pairs = m - half;
         if (pairs > MBLS_COOP_TREE_PAIRS) hipLaunchKernelGGL(k_g2_tree_d, dim3(nblk(half)), dim3(WG), 0, s, ws, m, half);
-        else hipLaunchKernelGGL(k_coop, dim3((unsigned)pairs), dim3(64), 0, s, c->coop[3], ws, (uint64_t)0, (uint64_t)1, half, pairs, (uint32_t*)nullptr, (uint8_t*)nullptr, COOP_RES_ITEM);
+        else coop_run(c, COOP_G2ADD, ws, (uint64_t)0, (uint64_t)1, half, pairs, (uint32_t*)nullptr, (uint8_t*)nullptr, COOP_RES_ITEM, s);
         m = half;
     }
 }
@@ -1291,13 +1319,13 @@ static int npairing_finish(mbls_ctx* c, uint64_t n, hipStream_t s, uint8_t* d_re
     const bool s_miller_done = s_miller_ev != nullptr;
     mbls_ws ws; ws.w = c->d_w; ws.stride = c->cap;
     if (2 * n <= c->coop_max_items)     // few pairs: one WAVE per Miller loop (program miller1, ~0.9 ms) instead of one lane (6.6 ms)
-        hipLaunchKernelGGL(k_coop, dim3((unsigned)n), dim3(64), 0, s, c->coop[7], ws, (uint64_t)0, (uint64_t)1, (uint64_t)0, n, (uint32_t*)nullptr, (uint8_t*)nullptr, COOP_RES_ITEM);
+        coop_run(c, COOP_MILLER1, ws, (uint64_t)0, (uint64_t)1, (uint64_t)0, n, (uint32_t*)nullptr, (uint8_t*)nullptr, COOP_RES_ITEM, s);
     else
         hipLaunchKernelGGL(k_miller_single, dim3(nblk(n)), dim3(WG), 0, s, ws, n, 0, (uint64_t)0);
     f12_tree(c, ws, n, s);
     // s_miller_done: the Miller value of (S, -G1) is left in slots 97..108 of item 0 by program smiller, running beside the chains
     if (s_miller_done) HIPCHK(c, hipStreamWaitEvent(s, s_miller_ev, 0));
-    hipLaunchKernelGGL(k_coop, dim3(1), dim3(64), 0, s, c->coop[s_miller_done ? 5 : 1], ws, (uint64_t)0, (uint64_t)1, (uint64_t)0, (uint64_t)1, c->d_scalar, d_result, COOP_RES_BATCH);
+    coop_run(c, s_miller_done ? COOP_VMFINAL : COOP_VMTAIL, ws, (uint64_t)0, (uint64_t)1, (uint64_t)0, (uint64_t)1, c->d_scalar, d_result, COOP_RES_BATCH, s);
     HIPCHK(c, hipGetLastError());
     return MBLS_OK;
 }
@@ -1377,7 +1405,7 @@ static int verify_multiple_impl(mbls_ctx* c, const uint8_t* d_sigs, const uint8_
     g2_tree(c, ws, n, s_sig);
     if (fork) {     // S is complete: its Miller loop runs on one wave beside the other chains and the sets' Miller loops (most SIMDs are idle)
         HIPCHK(c, hipEventRecord(c->hs_ev2, s_sig));                 // the status bits and S exist
-        hipLaunchKernelGGL(k_coop, dim3(1), dim3(64), 0, s_sig, c->coop[4], ws, (uint64_t)0, (uint64_t)1, (uint64_t)0, (uint64_t)1, (uint32_t*)nullptr, (uint8_t*)nullptr, COOP_RES_ITEM);
+        coop_run(c, COOP_SMILLER, ws, (uint64_t)0, (uint64_t)1, (uint64_t)0, (uint64_t)1, (uint32_t*)nullptr, (uint8_t*)nullptr, COOP_RES_ITEM, s_sig);
         HIPCHK(c, hipEventRecord(c->hs_ev, s_sig));                  // ... and its Miller value (awaited just before the tail)
     }
     launch_hash(c, ws, d_msgs, msg_len, d_moff, c->d_status, n, s_msg);

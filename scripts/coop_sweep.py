@@ -1,4 +1,5 @@
-"""Where the one-wave-per-item paths stop paying: latency of the device-resident entry over n for (pairing, hash) in {lane, wave}^2 (dev script)."""
+"""Where the wave-cooperative paths stop paying: latency of the device-resident entry over n for the pairing check one lane per item / one
+wave per item / two items per wave, and the message phase one lane per item / one wave per item / four items per wave (dev script)."""
 import ctypes as C, json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -6,7 +7,7 @@ import torch
 import bench
 from milagro_bls_amd import _native as N
 ctx = N.default_context(); lib = N.lib(); dev = torch.device("cuda:0")
-nmax, k = 1 << 14, 128
+nmax, k = 3 << 13, 128
 d_sigs, d_msgs, d_pks, expect = bench.build_inputs(ctx, dev, nmax, k, N.PK_UNCOMPRESSED, rank=21)
 ctx.reserve(nmax)
 
@@ -20,7 +21,8 @@ def med(f, reps=5, warm=2):
     return float(np.median(ts))
 
 
-for n in (128, 256, 384, 512, 768, 1024, 1536, 2048, 3072, 4096, 6144, 8192, 10240, 12288, 16384):
+BIG = 1 << 62
+for n in (1, 64, 128, 256, 384, 512, 768, 1024, 1536, 2048, 3072, 4096, 6144, 8192, 10240, 12288, 16384, 20480, 24576):
     d_res = torch.zeros(n, dtype=torch.uint8, device=dev)
 
     def f_dev():
@@ -28,8 +30,12 @@ for n in (128, 256, 384, 512, 768, 1024, 1536, 2048, 3072, 4096, 6144, 8192, 102
                                                               d_res.data_ptr(), None, None, None))
         torch.cuda.synchronize()
     row = {}
-    for name, lp, lh in (("wave+wavehash", 1 << 20, 1 << 20), ("wave", 1 << 20, 0), ("lane", 0, 0)):
-        ctx.set_coop_max_items(lp); ctx.set_coop_hash_max_items(lh)
+    # (pairing limit, hash limit, pairing packed above, hash packed above)
+    for name, lp, lh, pp, ph in (("wave+wavehash", BIG, BIG, BIG, BIG), ("wave2+wavehash4", BIG, BIG, 0, 0), ("wave+wavehash4", BIG, BIG, BIG, 0), ("wave", BIG, 0, BIG, BIG),
+                                 ("wave2", BIG, 0, 0, BIG), ("lane", 0, 0, BIG, BIG)):
+        if n > 8192 and name in ("wave+wavehash", "wave+wavehash4"):
+            continue
+        ctx.set_coop_max_items(lp); ctx.set_coop_hash_max_items(lh); ctx.set_coop_packing(pp, BIG, ph)
         row[name] = round(med(f_dev), 2)
         assert torch.equal(d_res.cpu(), expect[:n]), (name, n)
     print(n, row, flush=True)

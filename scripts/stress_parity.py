@@ -23,9 +23,9 @@ for seed in range(100, 100 + nseeds):
             if engines == "lanes":
                 ctx.set_coop_max_items(0)
             elif engines == "waves":
-                ctx.set_coop_max_items(max(n, 8192)); ctx.set_coop_hash_max_items(max(n, 1536) if n <= 4096 else 1536)
+                ctx.set_coop_max_items(max(n, 10240)); ctx.set_coop_hash_max_items(max(n, 6144) if n <= 8192 else 6144)
             got, st = mb.fast_aggregate_verify_batch(b.sigs, b.msgs, b.pks, b.n, b.k, pk_format=fmt)
-            ctx.set_coop_max_items(10240); ctx.set_coop_hash_max_items(1536)
+            ctx.set_coop_max_items(10240); ctx.set_coop_hash_max_items(6144)
             total += n
             if not (got == want == b.expect):
                 bad += 1; print("MISMATCH fast_aggregate_verify seed", seed, n, k, fmt, engines)

@@ -110,3 +110,24 @@ def test_message_phase_of_the_pipeline_against_golden_and_oracle(mb, vectors):
     want = orc.batch_hash_to_g2(msgs, 200)
     assert mb.hash_to_g2_batch(msgs, 200, mode=1) == want
     assert mb.hash_to_g2_batch(msgs, 200, mode=2) == want
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 7, 130])
+def test_packed_programs_agree_with_the_oracle(mb, N, n):
+    """Two items per wave in the pairing check (pairing2x2) and four in the message phase (hashg2x4), forced for batch sizes that leave the
+    last wave partly empty (n odd, n mod 4 != 0): the verdicts and status words of the one-item-per-wave programs and of the oracle --
+    every rejection class of helpers.make_batch --, and H(m) itself through the message-phase probe."""
+    ctx = N.default_context()
+    b = helpers.make_batch(n, 3, fmt=1, seed=400 + n)
+    want = orc.batch_fast_aggregate_verify(b.sigs, b.msgs, b.pks, b.n, b.k, 1, nthreads=8)
+    assert want == b.expect
+    outs = {}
+    try:
+        for name, pack in (("packed", (0, 1 << 62, 0)), ("plain", (1 << 62, 1 << 62, 1 << 62)), ("pairing packed", (0, 1 << 62, 1 << 62)), ("hash packed", (1 << 62, 1 << 62, 0))):
+            ctx.set_coop_packing(*pack)
+            outs[name] = mb.fast_aggregate_verify_batch(b.sigs, b.msgs, b.pks, b.n, b.k, pk_format=1)
+            assert mb.hash_to_g2_batch(b.msgs, n, mode=2) == orc.batch_hash_to_g2(b.msgs, n), name
+    finally:
+        ctx.set_coop_packing(1024, 2048, 768)
+    for name, (got, st) in outs.items():
+        assert got == want and st == outs["plain"][1], name

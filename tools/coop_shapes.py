@@ -10,6 +10,8 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import gen_coop as G  # noqa: E402
 
 SLOT_BUDGET = 315
+DIMS = [(0, 1, 2), (0, 1), (0, 1), (0, 1), (0, 1)]      # Fp2 products, Fp6 products, Fp12 squaring, Fp12 products, line products
+NDIM = len(DIMS)
 
 
 def measure(name):
@@ -20,8 +22,8 @@ def measure(name):
 
 
 def main():
-    table = {}
-    for name in G.PROGRAMS:
+    table = dict(G.SHAPES)                 # start from the installed table
+    for name in (sys.argv[1:] or list(G.PROGRAMS)):
         G.SHAPES.clear(); G.SHAPES.update(table)
         m = G.PROGRAMS[name]()
         blocks = [b for b in m.blocks]
@@ -30,22 +32,26 @@ def main():
             runs[b] = runs.get(b, 0) + rep
         best = measure(name)
         print(name, "start", best, flush=True)
-        for sweep in range(2):
+        for sweep in range(3):
             changed = False
             for b in sorted(blocks, key=lambda x: -runs.get(x, 0)):
                 if not runs.get(b):
                     continue
-                cur = G.SHAPES.get((name, b), (0, 0))
-                for shape in itertools.product((0, 1, 2), (0, 1)):
-                    if shape == cur:
-                        continue
-                    G.SHAPES[(name, b)] = shape
-                    got = measure(name)
-                    ok = got[1] <= max(SLOT_BUDGET, best[1])
-                    if ok and (got[0] < best[0] or (got[0] == best[0] and got[1] < best[1])):
-                        best, cur, changed = got, shape, True
-                        print("  ", b, shape, got, flush=True)
-                if cur == (0, 0):
+                cur = (tuple(G.SHAPES.get((name, b), ())) + (0,) * NDIM)[:NDIM]
+                for dim, alts in enumerate(DIMS):
+                    for v in alts:
+                        if v == cur[dim]:
+                            continue
+                        shape = cur[:dim] + (v,) + cur[dim + 1:]
+                        G.SHAPES[(name, b)] = shape
+                        got = measure(name)
+                        ok = got[1] <= max(SLOT_BUDGET, best[1])
+                        if ok and (got[0] < best[0] or (got[0] == best[0] and got[1] < best[1])):
+                            best, cur, changed = got, shape, True
+                            print("  ", b, shape, got, flush=True)
+                while cur and cur[-1] == 0:
+                    cur = cur[:-1]
+                if not cur:
                     G.SHAPES.pop((name, b), None)
                 else:
                     G.SHAPES[(name, b)] = cur

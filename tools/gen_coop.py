@@ -97,34 +97,44 @@ class Node:
 # Product shapes per (program, block): (Fp2 products schoolbook instead of Karatsuba, Fp6 products schoolbook instead of Karatsuba). A wave
 # has 64 product lanes a step and the formulas rarely fill them, while every operand that is a sum of more than four slots costs a LIN
 # operation first: spending idle product lanes on schoolbook forms (operands are the inputs themselves, results have fewer terms) shortens
-# the step lists. The table is the result of a search (tools/coop_shapes.py: per block the shape with the fewest steps, the program within
-# the slot budget of eight waves per CU); blocks not listed use Karatsuba at both levels.
+# the step lists. A shape may go on with (Fp12 squaring as a^2 + v b^2 and 2ab instead of the complex form, Fp12 products -- also by
+# lines -- with four Fp6 products instead of three, the product of two lines with nine Fp2 products instead of six). The table is the result
+# of a search (tools/coop_shapes.py: per block the cheapest step list, the program within the slot budget of eight waves per CU); blocks not
+# listed use Karatsuba everywhere.
 SHAPES = {
     ('f12mul', 'mul'): (1, 1),
-    ('g2add', 'add'): (2, 0),
-    ('hashg2', 'ladd'): (1, 0),
-    ('hashg2', 'lsub'): (1, 0),
-    ('hashg2', 'sswu'): (2, 0),
-    ('miller1', 'add'): (2, 0),
-    ('miller1', 'dbl'): (2, 0),
-    ('pairing2', 'add'): (2, 0),
+    ('g2add', 'add'): (2,),
+    ('hashg2', 'ladd'): (1,),
+    ('hashg2', 'lsub'): (1,),
+    ('hashg2', 'sswu'): (2,),
+    ('hashg2x4', 'ladd'): (1,),
+    ('hashg2x4', 'lsub'): (1,),
+    ('hashg2x4', 'sswu'): (2,),
+    ('miller1', 'add'): (2,),
+    ('miller1', 'dbl'): (2, 0, 0, 1),
+    ('pairing2', 'add'): (2,),
     ('pairing2', 'dbl'): (0, 1),
-    ('pairing2', 'easy'): (2, 0),
+    ('pairing2', 'easy'): (2,),
     ('pairing2', 'mulbase'): (1, 1),
     ('pairing2', 'step_conj'): (1, 1),
     ('pairing2', 'step_frob'): (1, 1),
     ('pairing2', 'tail'): (2, 1),
-    ('smiller', 'add'): (2, 0),
-    ('smiller', 'dbl'): (2, 0),
-    ('vmfinal', 'easy'): (2, 0),
+    ('pairing2x2', 'add'): (1,),
+    ('pairing2x2', 'dbl'): (1, 1, 1),
+    ('pairing2x2', 'easy'): (0, 1, 0, 1),
+    ('pairing2x2', 'step_frob'): (1,),
+    ('pairing2x2', 'tail'): (2, 0, 0, 1),
+    ('smiller', 'add'): (2,),
+    ('smiller', 'dbl'): (2, 0, 0, 1),
+    ('vmfinal', 'easy'): (2,),
     ('vmfinal', 'join'): (0, 1),
     ('vmfinal', 'mulbase'): (1, 1),
     ('vmfinal', 'step_conj'): (1, 1),
     ('vmfinal', 'step_frob'): (1, 1),
-    ('vmfinal', 'tail'): (0, 1),
-    ('vmtail', 'add'): (2, 0),
-    ('vmtail', 'dbl'): (2, 0),
-    ('vmtail', 'easy'): (2, 0),
+    ('vmfinal', 'tail'): (0, 1, 0, 1),
+    ('vmtail', 'add'): (2,),
+    ('vmtail', 'dbl'): (2,),
+    ('vmtail', 'easy'): (2,),
     ('vmtail', 'join'): (0, 1),
     ('vmtail', 'mulbase'): (1, 1),
     ('vmtail', 'step_conj'): (1, 1),
@@ -139,7 +149,7 @@ class Block(T.Prog):
 
     def __init__(self, machine, name):
         self.m, self.name = machine, name
-        self.shape = SHAPES.get((machine.name, name), (0, 0))
+        self.shape = (tuple(SHAPES.get((machine.name, name), ())) + (0, 0, 0, 0, 0))[:5]
         self.nodes = []
         self.mat_cache, self.mul_cache, self.const_cache = {}, {}, {}
         self.items = []                  # schedulable operations in creation order
@@ -286,6 +296,20 @@ class Block(T.Prog):
         c2 = self.add2(self.add2(m(a[0], b[2]), m(a[1], b[1])), m(a[2], b[0]))
         return [c0, c1, c2]
 
+    def sqr12(self, f):
+        if not self.shape[2]:
+            return T.Prog.sqr12(self, f)                     # complex squaring: 2 Fp6 products of sums
+        a, b = f                                             # a^2 + v b^2, 2 a b: 3 Fp6 products of the coefficients themselves
+        ab = self.mul6(a, b)
+        return (self.add6(self.mul6(a, a), self.mul_v6(self.mul6(b, b))), self.add6(ab, ab))
+
+    def mul12_line(self, f, c0, c2, c3):
+        if not self.shape[3]:
+            return T.Prog.mul12_line(self, f, c0, c2, c3)
+        a, b = f                                             # four sparse products instead of three with a sum operand
+        t0, t1 = self.mul6_01(a, c0, c2), self.mul6_1(b, c3)
+        return (self.add6(t0, self.mul_v6(t1)), self.add6(self.mul6_1(a, c3), self.mul6_01(b, c0, c2)))
+
     def sel(self, flag, a, b):
         """flag ? b : a   (flag: a flag word index)"""
         if flag == FLAG_FALSE:
@@ -383,8 +407,9 @@ def _is_reduced(B):
 class Machine:
     """slot and flag numbering of one program; blocks are scheduled against it"""
 
-    def __init__(self, name, n_slots=600):
+    def __init__(self, name, n_slots=600, nlane=NLANE):
         self.name = name
+        self.nlane = nlane               # lanes of a step one item may use: 64 (one item per wave), 32 or 16 (two / four items per wave)
         self.state = {}                  # name -> slot
         self.consts = {}                 # value -> slot
         self.next_slot = 1               # slot 0 = zero
@@ -476,7 +501,7 @@ def schedule(block):
         # earliest step of this kind with a free lane; MUL / LIN steps take 64 operations, the serial kinds as well
         k = None
         for i in range(ready, len(steps)):
-            if steps[i].kind == kind and len(steps[i].lanes) < NLANE:
+            if steps[i].kind == kind and len(steps[i].lanes) < block.m.nlane:
                 k = i
                 break
         if k is None:
@@ -641,7 +666,7 @@ def compile_program(machine):
     steps.append((K_END, 0))
     stats = {name: dict(steps=len(sched[name]), mul=sum(1 for s in sched[name] if s.kind == K_MUL), lin=sum(1 for s in sched[name] if s.kind == K_LIN),
                         ops=len(machine.blocks[name].items)) for name in machine.blocks}
-    return dict(steps=steps, rows=rows, consts=dict((s, v) for v, s in machine.consts.items()), n_slots=peak, n_flags=len(machine.flags),
+    return dict(nlane=machine.nlane, steps=steps, rows=rows, consts=dict((s, v) for v, s in machine.consts.items()), n_slots=peak, n_flags=len(machine.flags),
                 stats=stats, total_steps=len(steps), sched=sched, block_rows=block_rows)
 
 
@@ -730,6 +755,35 @@ def add_step(b, Tn, Q, pxyz):
     return [x3, y3, z3], (c0, c2, c3)
 
 
+def mul_lines(b, la, lb):
+    """T.mul_lines, or (shape[4]) the nine plain products"""
+    if not b.shape[4]:
+        return T.mul_lines(b, la, lb)
+    (a0, a2, a3), (b0, b2, b3) = la, lb
+    m = b.mul2
+    return ([b.add2(m(a0, b0), b.mul_xi2(m(a3, b3))), b.add2(m(a0, b2), m(a2, b0)), m(a2, b2)],
+            [None, b.add2(m(a0, b3), m(a3, b0)), b.add2(m(a2, b3), m(a3, b2))])
+
+
+def mul12_by_lines(b, f, L0, L1):
+    """T.mul12_by_lines, or (shape[3]) four products without the sum operands"""
+    if not b.shape[3]:
+        return T.mul12_by_lines(b, f, L0, L1)
+    x, y = f
+    t0 = b.mul6(x, L0)
+    t1 = T.mul6_by_0yz(b, y, L1[1], L1[2])
+    return (b.add6(t0, b.mul_v6(t1)), b.add6(T.mul6_by_0yz(b, x, L1[1], L1[2]), b.mul6(y, L0)))
+
+
+def mul12(b, x, y, conj_b=False):
+    """T.mul12, or (shape[3]) the four Fp6 products"""
+    if not b.shape[3]:
+        return T.mul12(b, x, y, conj_b)
+    t0, t1 = b.mul6(x[0], y[0]), b.mul6(x[1], y[1])
+    cross = b.add6(b.mul6(x[0], y[1]), b.mul6(x[1], y[0])) if not conj_b else b.sub6(b.mul6(x[1], y[0]), b.mul6(x[0], y[1]))
+    return ((b.add6 if not conj_b else b.sub6)(t0, b.mul_v6(t1)), cross)
+
+
 def build_miller(m, pairs, prefix=""):
     """blocks `dbl` and `add` of the Miller loop over the listed pairs. Pair descriptor: dict(T=state prefix of the running point,
     Q=state prefix of the fixed point, affine=bool, P=state prefix of the masked G1 argument (masked_p))"""
@@ -743,8 +797,8 @@ def build_miller(m, pairs, prefix=""):
         pt_out(b, pr["T"], Tn)
         lines.append(line)
     if len(lines) == 2:
-        L0, L1 = T.mul_lines(b, lines[0], lines[1])
-        f = T.mul12_by_lines(b, f, L0, L1)
+        L0, L1 = mul_lines(b, lines[0], lines[1])
+        f = mul12_by_lines(b, f, L0, L1)
     else:
         f = b.mul12_line(f, *lines[0])
     st12(b, f)
@@ -793,20 +847,20 @@ def build_final_exp(m):
     Fi = b.mulfp2(b.conj2(F), ni)
     Tt = [b.mul2(A, Fi), b.mul2(Bv, Fi), b.mul2(C, Fi)]
     fi = (b.mul6(a0, Tt), b.neg6(b.mul6(a1, Tt)))
-    t = T.mul12(b, fi, f, conj_b=True)                          # f^(p^6 - 1)
-    mm = T.mul12(b, T.frob12_2(b, t), t)                        # ^(p^2 + 1)
+    t = mul12(b, fi, f, conj_b=True)                          # f^(p^6 - 1)
+    mm = mul12(b, T.frob12_2(b, t), t)                        # ^(p^2 + 1)
     st12(b, mm); st12(b, mm, "y"); st12(b, mm, "m")
     cyc_sqr_block(m)
     b = m.block("mulbase")                                       # f <- f * y
-    st12(b, T.mul12(b, ld12(b), ld12(b, "y")))
+    st12(b, mul12(b, ld12(b), ld12(b, "y")))
     b = m.block("pstart")                                        # f <- y
     st12(b, ld12(b, "y"))
     b = m.block("step_conj")                                     # after powers 1, 2: f <- conj(f) conj(y) = conj(f y); also the next base
-    r = T.mul12(b, ld12(b), ld12(b, "y"))
+    r = mul12(b, ld12(b), ld12(b, "y"))
     r = (r[0], b.neg6(r[1]))
     st12(b, r); st12(b, r, "y")
     b = m.block("step_frob")                                     # after power 3: b = conj(f) frob(y) -> f, y, bb
-    r = T.mul12(b, T.frob12(b, ld12(b, "y")), ld12(b), conj_b=True)
+    r = mul12(b, T.frob12(b, ld12(b, "y")), ld12(b), conj_b=True)
     st12(b, r); st12(b, r, "y"); st12(b, r, "b")
     b = m.block("step_base")                                     # after power 4: conj(f) is the base of the fifth
     a = ld12(b)
@@ -814,11 +868,11 @@ def build_final_exp(m):
     st12(b, r); st12(b, r, "y")
     b = m.block("tail")                                          # conj(f) * frob^2(b) * conj(b) * m^3
     a = ld12(b); bb = ld12(b, "b"); mmv = ld12(b, "m")
-    c = T.mul12(b, T.frob12_2(b, bb), a, conj_b=True)
-    c = T.mul12(b, c, bb, conj_b=True)
+    c = mul12(b, T.frob12_2(b, bb), a, conj_b=True)
+    c = mul12(b, c, bb, conj_b=True)
     m2 = [None] * 6
     T.cyc_sqr_formula(b, mmv[0] + mmv[1], lambda e, v: m2.__setitem__(e, v))
-    c = T.mul12(b, c, T.mul12(b, (m2[:3], m2[3:]), mmv))
+    c = mul12(b, c, mul12(b, (m2[:3], m2[3:]), mmv))
     st12(b, c)
 
 
@@ -857,12 +911,12 @@ def is_one_block(m, name, ok_flag, extra_ok=None):
     return b
 
 
-def prog_pairing2():
+def prog_pairing2(name="pairing2", nlane=NLANE):
     """The pairing check of ONE verification (Signature::verify / fast_aggregate_verify, reference src/amcl_utils.rs:38-42) on a wave:
     pair 0 = (signature, -G1), pair 1 = (H(m), apk), from the workspace slots the phase kernels filled (APK 0..2 Jacobian, SIG 3..6 affine,
     H 7..12 Jacobian): Miller loop over both pairs with a shared squaring, final exponentiation, == 1. Result flag; the status word
     receives MBLS_ST_PAIRING_FAILED through the kernel."""
-    m = Machine("pairing2")
+    m = Machine(name, nlane=nlane)
     skip0, skip1, tmp, tmp2 = m.flag("skip0"), m.flag("skip1"), m.flag("tmp"), m.flag("tmp2")
     b = m.block("load")
     apk = [b.loadw("apk%d" % i, WS_APK + i) for i in range(3)]
@@ -913,7 +967,7 @@ def prog_vmtail():
         b.out("f%d" % i, one if i == 0 else LC())
     build_miller(m, [dict(T="t", Q="q", affine=False, P="p")])
     b = m.block("join")                                           # f <- F * conj(f)
-    st12(b, T.mul12(b, ld12(b, "g"), ld12(b), conj_b=True))
+    st12(b, mul12(b, ld12(b, "g"), ld12(b), conj_b=True))
     build_final_exp(m)
     ok = m.flag("ok")
     b = is_one_block(m, "isone", ok)
@@ -988,7 +1042,7 @@ def prog_vmfinal():
         b.loadw("g%d" % i, WS_F + i)
         b.loadw("f%d" % i, WS_G + i)
     b = m.block("join")
-    st12(b, T.mul12(b, ld12(b, "g"), ld12(b), conj_b=True))
+    st12(b, mul12(b, ld12(b, "g"), ld12(b), conj_b=True))
     build_final_exp(m)
     ok = m.flag("ok")
     b = is_one_block(m, "isone", ok)
@@ -1009,7 +1063,7 @@ def prog_f12tree():
     for i in range(12):
         b.loadw("g%d" % i, WS_F + i, partner=True)
     b = m.block("mul")
-    st12(b, T.mul12(b, ld12(b), ld12(b, "g")))
+    st12(b, mul12(b, ld12(b), ld12(b, "g")))
     b = m.block("store")
     f = flat12(ld12(b))
     for i in range(12):
@@ -1081,12 +1135,12 @@ def pt_psi(b, pt):
     return [b.mul2(b.conj2(pt[0]), T.c2(b, T.PSI_CX)), b.mul2(b.conj2(pt[1]), T.c2(b, T.PSI_CY)), b.conj2(pt[2])]
 
 
-def prog_hashg2():
+def prog_hashg2(name="hashg2", nlane=NLANE):
     """hash_to_curve_g2 after hash_to_field (reference src/amcl_utils.rs:33-35; the generated one-lane routine is g2_group_routine('hash') in
     tools/gen_tower_d.py) on ONE wave: both map_to_curve evaluations side by side (simplified SWU with its two fixed-exponent calls each,
     3-isogeny), q0 + q1, and the Budroni-Pintore cofactor clearing [x^2 - x - 1] P + [x - 1] psi(P) + psi^2(2 P) with two ladders by |x|.
     In: u0, u1 in workspace slots 31, 32 / 37, 38; out: H (Jacobian) in slots 7..12."""
-    m = Machine("hashg2")
+    m = Machine(name, nlane=nlane)
     b = m.block("sswu")
     outs = []
     for k, ws in enumerate((WS_U0, WS_U1)):
@@ -1136,7 +1190,10 @@ def prog_hashg2():
 
 
 PROGRAMS = {"hashg2": prog_hashg2, "pairing2": prog_pairing2, "vmtail": prog_vmtail, "f12mul": prog_f12tree, "g2add": prog_g2add, "smiller": prog_smiller, "vmfinal": prog_vmfinal,
-            "miller1": prog_miller1}
+            "miller1": prog_miller1,
+            # the same programs for batches that fill the chip: a step serves two / four items side by side (mbls_coop.h), each on 32 / 16 lanes --
+            # more steps per wave, fewer per item (the formulas rarely use more than a third of a step's 64 lanes)
+            "pairing2x2": lambda: prog_pairing2("pairing2x2", 32), "hashg2x4": lambda: prog_hashg2("hashg2x4", 16)}
 
 
 def emit_c(name, comp):
@@ -1165,6 +1222,7 @@ def emit_c(name, comp):
     L.append("#define MBLS_COOP_%s_NROWS %d" % (U, len(comp["rows"])))
     L.append("#define MBLS_COOP_%s_NCONSTS %d" % (U, len(cs)))
     L.append("#define MBLS_COOP_%s_NSLOTS %d" % (U, comp["n_slots"]))
+    L.append("#define MBLS_COOP_%s_LPI %d" % (U, comp["nlane"]))
     return "\n".join(L) + "\n"
 
 
@@ -1191,7 +1249,8 @@ def main():
     mx = 0
     for name, comp in build_all().items():
         txt += emit_c(name, comp)
-        mx = max(mx, comp["n_slots"])
+        if comp["nlane"] == NLANE:                           # the static allocation of the one-item-per-wave kernel instances
+            mx = max(mx, comp["n_slots"])
         print(name, "steps", comp["total_steps"], "rows", len(comp["rows"]), "slots", comp["n_slots"], "flags", comp["n_flags"])
         for bn, s in comp["stats"].items():
             print("   ", bn, s)
