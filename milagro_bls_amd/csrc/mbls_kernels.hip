@@ -108,11 +108,11 @@ __global__ void MBLS_LB k_g2_sum(const uint32_t* xy, const uint8_t* flags, const
     if (offsets && offsets[i + 1] < offsets[i]) cnt = 0;
     op_g2_sum(i, xy + 48 * first, flags + first, cnt, out96, errs);
 }
-__global__ void MBLS_LB k_sig(mbls_ws ws, const uint8_t* sigs, uint32_t* status, uint64_t n) {
+__global__ void MBLS_LB k_sig(mbls_ws ws, const uint8_t* sigs, uint32_t* status, uint64_t n, int check) {
 #if !defined(MBLS_NO_LDS_STATE)
     __shared__ uint32_t spill[154 * 64];          // 11 spill slots of 14 dwords per lane for the generated subgroup test
     uint64_t i = gid(); if (i >= n) return;
-    uint32_t st = 0; lane_sig(ws, i, sigs + 96 * i, &st, (MBLS_LDS uint32_t*)spill, threadIdx.x, true);
+    uint32_t st = 0; lane_sig(ws, i, sigs + 96 * i, &st, (MBLS_LDS uint32_t*)spill, threadIdx.x, true, check != 0);
 #else
     uint64_t i = gid(); if (i >= n) return;
     uint32_t st = 0; lane_sig(ws, i, sigs + 96 * i, &st);
@@ -164,6 +164,12 @@ __global__ void MBLS_LB k_miller(mbls_ws ws, uint64_t n) {
     uint64_t i = gid(); if (i >= n) return;
     lane_miller(ws, i);
 #endif
+}
+// between k_miller and k_final when k_sig only decoded: the signature's subgroup test from the loop's running point (lane_sig_verdict)
+__global__ void MBLS_LB k_sig_verdict(mbls_ws ws, uint32_t* status, uint64_t n) {
+    uint64_t i = gid(); if (i >= n) return;
+    const uint32_t st = lane_sig_verdict(ws, i);
+    if (st) status[i] |= st;
 }
 __global__ void MBLS_LB k_final(mbls_ws ws, uint32_t* status, uint8_t* results, uint64_t n) {
 #if !defined(MBLS_NO_LDS_STATE)
@@ -694,6 +700,7 @@ static int verify_pipeline(mbls_ctx* c, const uint8_t* d_sigs, const uint8_t* d_
     // part 1 / part 2 (host-buffer entry points): the signature and message phases are queued first (part 1, the keys may be
     // null), the caller then uploads the keys on another stream and makes this one wait, and part 2 queues the rest.
     const bool keys_later = part != 0;
+    const bool fused_sig = n > c->coop_max_items;     // one lane per item: the subgroup test of the signature comes out of the Miller loop, k_sig only decodes
     const bool fork = !tm && n <= 16384;
     // (host-buffer entries: hs_b carries the key upload, so their signature phase has a stream of its own)
     hipStream_t s_sig = fork ? (part == 0 ? c->hs_b : c->hs_d) : s, s_msg = fork ? c->hs_c : s;
@@ -707,7 +714,7 @@ static int verify_pipeline(mbls_ctx* c, const uint8_t* d_sigs, const uint8_t* d_
         }
     }
     if (part == 1) {
-        hipLaunchKernelGGL(k_sig, dim3(g), dim3(WG), 0, s_sig, ws, d_sigs, st, n);
+        hipLaunchKernelGGL(k_sig, dim3(g), dim3(WG), 0, s_sig, ws, d_sigs, st, n, fused_sig ? 0 : 1);
         launch_hash(c, ws, d_msgs, msg_len, d_moff, st, n, s_msg);
         HIPCHK(c, hipGetLastError());
         return MBLS_OK;
@@ -722,7 +729,7 @@ static int verify_pipeline(mbls_ctx* c, const uint8_t* d_sigs, const uint8_t* d_
     } else
         launch_aggregate(ws, ks.d_pks, d_off, k, fmt, mode, st, n, s);
     if (tm) HIPCHK(c, hipEventRecord(c->ev[1], s));
-    if (!keys_later) hipLaunchKernelGGL(k_sig, dim3(g), dim3(WG), 0, s_sig, ws, d_sigs, st, n);
+    if (!keys_later) hipLaunchKernelGGL(k_sig, dim3(g), dim3(WG), 0, s_sig, ws, d_sigs, st, n, fused_sig ? 0 : 1);
     if (tm) HIPCHK(c, hipEventRecord(c->ev[2], s));
     if (!keys_later) launch_hash(c, ws, d_msgs, msg_len, d_moff, st, n, s_msg);
     if (tm) HIPCHK(c, hipEventRecord(c->ev[3], s));
@@ -736,6 +743,7 @@ static int verify_pipeline(mbls_ctx* c, const uint8_t* d_sigs, const uint8_t* d_
         if (tm) { HIPCHK(c, hipEventRecord(c->ev[4], s)); HIPCHK(c, hipEventRecord(c->ev[5], s)); }
     } else {
         hipLaunchKernelGGL(k_miller, dim3(g), dim3(WG), 0, s, ws, n);
+        if (fused_sig) hipLaunchKernelGGL(k_sig_verdict, dim3(g), dim3(WG), 0, s, ws, st, n);
         if (tm) HIPCHK(c, hipEventRecord(c->ev[4], s));
         hipLaunchKernelGGL(k_final, dim3(g), dim3(WG), 0, s, ws, st, d_results, n);
         if (tm) HIPCHK(c, hipEventRecord(c->ev[5], s));
@@ -1357,7 +1365,7 @@ extern "C" int mbls_aggregate_verify(mbls_ctx* c, const uint8_t sig[96], const u
     (void)hipMemsetAsync(c->d_status, 0, 4 * n, s);
     // three chains side by side: the signature (decode + subgroup test: k_sig on item 0's slots, then into slot S), the keys, the messages
     (void)hipEventRecord(c->hs_ev, s); (void)hipStreamWaitEvent(c->hs_b, c->hs_ev, 0); (void)hipStreamWaitEvent(c->hs_c, c->hs_ev, 0);
-    hipLaunchKernelGGL(k_sig, dim3(1), dim3(WG), 0, c->hs_b, ws, (const uint8_t*)dsig.as<uint8_t>(), c->d_status, (uint64_t)1);
+    hipLaunchKernelGGL(k_sig, dim3(1), dim3(WG), 0, c->hs_b, ws, (const uint8_t*)dsig.as<uint8_t>(), c->d_status, (uint64_t)1, 1);
     hipLaunchKernelGGL(k_sigslot_to_s, dim3(1), dim3(WG), 0, c->hs_b, ws, (uint64_t)0);
     hipLaunchKernelGGL(k_blind_g1, dim3(nblk(n)), dim3(WG), 0, s, ws, dp.as<uint8_t>(), (const uint64_t*)nullptr, c->d_status, n);   // r_i = 1: no blinding in AggregateVerify
     launch_hash(c, ws, dm.as<uint8_t>(), 0u, (const uint64_t*)doff.as<uint64_t>(), c->d_status, n, c->hs_c);

@@ -272,7 +272,9 @@ MBLS_NOINLINE void hash_fields_to_ws(uint32_t* w, uint64_t stride, uint64_t i, c
     }
 }
 // spill != nullptr (with use_lds): the subgroup test runs as the generated routine on the coordinates just stored
-MBLS_FN void lane_sig(const mbls_ws& ws, uint64_t i, const uint8_t* sig96, uint32_t* status, MBLS_LDS uint32_t* spill = nullptr, uint32_t lane = 0, bool use_lds = false) {
+// check = false: decode only -- the Miller loop that follows decides the subgroup test from its own running point (lane_miller)
+MBLS_FN void lane_sig(const mbls_ws& ws, uint64_t i, const uint8_t* sig96, uint32_t* status, MBLS_LDS uint32_t* spill = nullptr, uint32_t lane = 0, bool use_lds = false,
+                      bool check = true) {
     fp2 x, y; bool inf; uint32_t st = 0;
     // in the kernel (use_lds) the decoder is inlined: its operands then never have an address and stay out of lane-private memory
     int e = use_lds ? g2_decode_compressed_t<true>(&x, &y, &inf, sig96) : g2_decode_compressed(&x, &y, &inf, sig96);
@@ -280,6 +282,7 @@ MBLS_FN void lane_sig(const mbls_ws& ws, uint64_t i, const uint8_t* sig96, uint3
     // infinity is stored as y = 0 (no curve point has y = 0: there is no 2-torsion)
     if (inf) { x = fp2_zero(); y = fp2_zero(); }
     ws_st2(ws, MBLS_SLOT_SIG, i, x); ws_st2(ws, MBLS_SLOT_SIG + 2, i, y);
+    if (!check) { *status |= st; return; }
     bool in_g2;
 #if MBLS_DEVICE_ASM && !defined(MBLS_NO_FP2_ASM)
     if (use_lds) in_g2 = (g2_group_d_call<false>(ws, i, spill, lane) & 1u) | inf;       // infinity passes (psi(O) = [x]O)
@@ -327,6 +330,22 @@ MBLS_FN void lane_miller(const mbls_ws& ws, uint64_t i, MBLS_LDS uint32_t* tstor
 #endif
     const fp2* c = &f.c0.c0;
     for (int s = 0; s < 6; s++) ws_st2(ws, MBLS_SLOT_F + 2 * s, i, c[s]);
+}
+// The subgroup test of the signature out of the Miller loop (generated two-pair loop only; runs between k_miller and k_final). Pair 0's running
+// point starts at the signature and walks the bits of |x| -- the same doublings and additions as the ladder of psi(P) = [x]P --, so when the
+// loop ends it IS [|x|] sig (homogeneous X : Y : Z, workspace slots 31..36): sig is in G2 iff psi(sig) = -T. A signature outside G2 may drive
+// the loop's incomplete additions through T = +-sig or T = O (its order then divides a prefix of |x| or a neighbour): every such case ends with
+// Z = 0, which is a rejection, and cannot happen for a point of order r. Infinity passes, as in subgroup_check_g2 (reference src/signature.rs:29-31).
+MBLS_FN uint32_t lane_sig_verdict(const mbls_ws& ws, uint64_t i) {
+    const fp2 qx = ws_ld2(ws, MBLS_SLOT_SIG, i), qy = ws_ld2(ws, MBLS_SLOT_SIG + 2, i);
+    // the running point as the loop leaves it: packed words, representatives in (0.5 p, 1.5 p) of the 2^392-domain values -- read as
+    // 2^384-domain values they are 2^8 X, 2^8 Y, 2^8 Z: the same projective point
+    fp2 X = ws_ld2(ws, 31, i), Y = ws_ld2(ws, 33, i), Z = ws_ld2(ws, 35, i);
+    X.c0 = fp_reduce_once(X.c0, 0); X.c1 = fp_reduce_once(X.c1, 0); Y.c0 = fp_reduce_once(Y.c0, 0); Y.c1 = fp_reduce_once(Y.c1, 0);
+    Z.c0 = fp_reduce_once(Z.c0, 0); Z.c1 = fp_reduce_once(Z.c1, 0);
+    const fp2 px = fp2_mul(fp2_conj(qx), fp2_load_const(MBLS_PSI_CX)), py = fp2_mul(fp2_conj(qy), fp2_load_const(MBLS_PSI_CY));     // psi(sig), affine (g2_psi)
+    const bool same = !fp2_is_zero(Z) & fp2_eq(fp2_mul(px, Z), X) & fp2_eq(fp2_mul(py, Z), fp2_neg(Y));      // psi(sig) = [x] sig = -[|x|] sig
+    return (!same & !fp2_is_zero(qy)) ? MBLS_ST_SIG_NOT_IN_G2 : 0u;
 }
 MBLS_FN void lane_final(const mbls_ws& ws, uint64_t i, uint32_t* status, uint8_t* result, MBLS_LDS uint32_t* ls = nullptr, uint32_t lane = 0, bool use_lds = false) {
     fp12 f; fp2* c = &f.c0.c0;

@@ -195,6 +195,63 @@ def test_key_validate_outside_the_subgroup_vs_oracle(mb):
         assert api.PublicKey(M.g1_serialize_uncompressed(pts[i])).key_validate() == want[i]
 
 
+def test_signature_subgroup_verdict_out_of_the_miller_loop_vs_oracle(mb):
+    """subgroup_check_g2 of the signature (reference src/signature.rs:29-31) on the one-lane-per-item path is decided from the Miller loop's
+    own running point ([|x|] sig when the loop ends, lane_sig_verdict): curve points of every small prime order dividing the G2 cofactor
+    (order 13 sends the loop's incomplete addition through T = -sig at the prefix 13 of |x|, and on through infinity), G2 points shifted
+    by them, random curve points, and points of G2 that are no valid signature -- status bit 0x02 exactly where the oracle's [r]P says
+    so, on both engines."""
+    import bls12_381 as M
+    from milagro_bls_amd import _native as N
+    ctx = N.default_context()
+    rnd = random.Random(91)
+    h2 = 0x5d543a95414e7f1091d50792876a202cd91de4547085abaa68a205b2e5a7ddfa628f1cb4d9e82ef21537e293a6691ae1616ec6e786f0c70cf1c38e31c7238e5
+
+    def curve_point():
+        while True:
+            x = (rnd.randrange(M.P), rnd.randrange(M.P)); y = M.f2_sqrt(M.f2_add(M.f2_mul(M.f2_sqr(x), x), M.B2))
+            if y is not None:
+                return (x, y if rnd.getrandbits(1) else M.f2_neg(y))
+    assert M.g2_mul(curve_point(), h2 * M.R) is None
+    g2pt = lambda: M.g2_mul(M.G2, rnd.randrange(1, M.R))
+    pts = []
+    for ell in (13, 23, 2713, 11953, 262069):
+        for _ in range(2):
+            t = None
+            while t is None:
+                t = M.g2_mul(curve_point(), h2 * M.R // (ell * ell if h2 % (ell * ell) == 0 else ell))
+            assert M.g2_mul(t, ell) is None
+            pts += [t, M.g2_add(g2pt(), t), M.g2_add(M.g2_mul(t, 5), g2pt()), M.g2_neg(t)]
+    pts += [curve_point() for _ in range(40)]
+    pts += [g2pt() for _ in range(16)] + [M.g2_mul(curve_point(), h2) for _ in range(6)]
+    sigs = [M.g2_compress(pt) for pt in pts]
+    n = len(sigs)
+    want_in = [orc.g2_subgroup_check(orc.g2_from_compressed(b)[1]) for b in sigs]
+    assert want_in.count(True) == 22 and want_in.count(False) == n - 22
+    msgs = rnd.randbytes(32 * n)
+    pk = orc.sk_to_pk(12345)
+    want = orc.batch_verify(b"".join(sigs), msgs, orc.g1_compress(pk) * n, n, nthreads=8)
+    assert not any(want)
+    try:
+        for lim in (0, 1 << 20):
+            ctx.set_coop_max_items(lim)
+            got, st = mb.verify_batch(b"".join(sigs), msgs, pk * n, n, pk_format=1)
+            assert got == want, lim
+            assert [(x & 0x02) == 0 for x in st] == want_in, lim
+    finally:
+        ctx.set_coop_max_items(10240)
+    # a real signature next to them still verifies on the one-lane path, and the same signature shifted by a point of order 13 does not
+    sk = 777; msg = b"m" * 32
+    good = orc.g2_compress(orc.sign(msg, sk))
+    shifted = M.g2_compress(M.g2_add(M.g2_decompress(good)[1], pts[0]))
+    try:
+        ctx.set_coop_max_items(0)
+        got, st = mb.verify_batch(good + shifted, msg * 2, orc.sk_to_pk(sk) * 2, 2, pk_format=1)
+    finally:
+        ctx.set_coop_max_items(10240)
+    assert got == [True, False] and st[0] == 0 and st[1] & 0x02
+
+
 @pytest.mark.parametrize("fmt", [0, 1])
 def test_fast_aggregate_verify_batch_vs_oracle(mb, fmt):
     b = helpers.make_batch(96, 8, fmt=fmt, seed=40 + fmt)
