@@ -585,6 +585,7 @@ def main():
             "traffic_from_profile": from_profile("hbm_traffic.json", dom),
             "valu_issue": valu_issue_figure(lib, ctx, phase_ms, n, {"uncompressed": "k_aggregate", "indexed": "k_aggregate_indexed"}.get(args.pk_format) if k == 128 else None),
             "phase_ms": phase_ms,
+            "phase_notes": "sig = signature decoding: the subgroup test psi(sig) = [x] sig is read off the Miller loop's running point (k_sig_verdict, counted under miller)",
             "phase_pass": {"verdict": phase_pass, "sum_phase_ms": phase_sum, "ms_per_step": ms_per_step,
                            "method": "median of %d event-timed calls after 2 discarded ones; 'consistent' = the kernels of one in-order stream sum to the timed step within 2 %%" % PHASE_REPS},
             "variants": variants,
