@@ -61,7 +61,10 @@ typedef struct mbls_ctx mbls_ctx;
  * Thread safety: every entry point takes the context's lock, so a context may be shared by any number of threads (the
  * reference's functions are pure and re-entrant); calls on one context run one after the other.
  * Device-pointer entries only enqueue work (none of them synchronises with the host): a later call on another stream waits
- * (on the device) for the workspace of the earlier one. For concurrent streams of work create one context per stream. */
+ * (on the device) for the workspace of the earlier one. For concurrent streams of work create one context per stream.
+ * ONE EXCEPTION, by construction: a call whose batch is larger than any the context has seen first GROWS the workspace
+ * (hipFree + hipMalloc inside mbls_ctx_reserve: both drain the device). Reserve the largest batch up front with
+ * mbls_ctx_reserve / mbls_ctx_reserve_keys and no *_device entry ever synchronises. */
 int mbls_ctx_create(mbls_ctx** out, int device_id);
 void mbls_ctx_destroy(mbls_ctx* ctx);
 /* pre-allocate the HBM workspace for batches of up to max_items items (6 384 bytes per item; avoids allocation in timed regions) */
@@ -72,13 +75,19 @@ const char* mbls_last_error(mbls_ctx* ctx);
 /* Small batches are latency-bound (one lane per item walks 14 M dependent instructions whatever the batch size), so batches of up to
  * max_items items run their pairing check -- Miller loop + final exponentiation -- with ONE WAVE per item, the item's field values
  * shared by the 64 lanes (mbls_coop.h); up to 6144 items the message phase after hash_to_field does the same. Same results, bit for bit.
- * Defaults 10240 / 6144: the measured crossovers (environment: MBLS_COOP_MAX_ITEMS); 0 = never. */
+ * Defaults 10240 / 6144: the measured crossovers (environment, read by mbls_ctx_create and therefore also by every context of an
+ * mbls_multi handle: MBLS_COOP_MAX_ITEMS, MBLS_COOP_HASH_MAX_ITEMS); 0 = never. */
 int mbls_ctx_set_coop_max_items(mbls_ctx* ctx, uint64_t max_items);
 int mbls_ctx_set_coop_hash_max_items(mbls_ctx* ctx, uint64_t max_items);     /* the same for the message phase (never above the limit above) */
 /* Within those limits, batches of pairing_min_items < n <= pairing_max_items items run the pairing check with two items per wave, and of
  * more than hash_min_items the message phase with four: more steps per wave, fewer per item -- it pays where it saves a round of waves.
  * Defaults (1024, 2048] and 768 (measured); min = UINT64_MAX: never. */
 int mbls_ctx_set_coop_packing(mbls_ctx* ctx, uint64_t pairing_min_items, uint64_t pairing_max_items, uint64_t hash_min_items);
+/* One ROUND of the one-lane-per-item kernels is one wave on every SIMD: CUs x 4 x 64 items (65 536 on MI355X; the kernels hold 512 registers
+ * per lane, so a SIMD runs one wave at a time). A batch of q rounds + r items would cost q + 1 rounds of every kernel: the library runs the
+ * q rounds and then the r items as a batch of their own, which takes the route of an r-item batch (one wave per item up to the limits
+ * above). items = 0 restores the device's value; any multiple of 64 is accepted (tests use small rounds to exercise the cut). */
+int mbls_ctx_set_round_items(mbls_ctx* ctx, uint64_t items);
 
 /* ---- the hot path -------------------------------------------------------------------------------------
  * Batch of n independent AggregateSignature::fast_aggregate_verify calls (reference src/aggregates.rs:177-215):
@@ -164,7 +173,11 @@ typedef struct mbls_multi_keytable mbls_multi_keytable;
 int mbls_multi_keytable_create(mbls_multi* m, uint64_t capacity_hint, mbls_multi_keytable** out);
 void mbls_multi_keytable_destroy(mbls_multi_keytable* t);
 uint64_t mbls_multi_keytable_size(const mbls_multi_keytable* t);
+/* All or nothing: when one device fails (or the replicas disagree) the replicas that did append drop the new records again, the
+ * indices stay the same on every device and the error names the device (mbls_multi_last_error). */
 int mbls_multi_keytable_append(mbls_multi_keytable* t, const uint8_t* pks, int pk_format, int validate, uint64_t n, uint64_t* first_index, uint8_t* errs);
+/* replica i of the table (the table of mbls_multi_context(m, i)); owned by the handle */
+mbls_keytable* mbls_multi_keytable_replica(mbls_multi_keytable* t, int i);
 int mbls_multi_fast_aggregate_verify_batch_indexed(mbls_multi* m, const mbls_multi_keytable* t, const uint8_t* sigs, const uint8_t* msgs,
                                                    uint32_t msg_len, const uint64_t* msg_offsets, const uint32_t* key_idx, const uint32_t* offsets,
                                                    uint64_t n, uint32_t k, uint8_t* results, uint32_t* status);
@@ -233,7 +246,11 @@ int mbls_pk_decode_batch(mbls_ctx* ctx, const uint8_t* in, int in_format, int va
 int mbls_pk_compress_batch(mbls_ctx* ctx, const uint8_t* in96, uint64_t n, uint8_t* out48, uint8_t* errs);
 /* n x Signature::from_bytes: errs[i]; in_g2 (optional) = subgroup_check_g2 per signature */
 int mbls_sig_check_batch(mbls_ctx* ctx, const uint8_t* in96, uint64_t n, uint8_t* errs, uint8_t* in_g2);
-/* n x Signature::new / PublicKey::from_secret_key. Secret keys are NOT range-checked here: any 32-byte big-endian value gives [sk mod r] H(msg) /
+/* NOT CONSTANT-TIME: sk -> pk gathers table records at addresses that depend on the secret key's hexadecimal digits, and signing selects
+ * per-lane window-table records by digits of the key (amcl's g1mul / g2mul use constant-time selection). These batch entries exist to build
+ * inputs and caches; do not run them on keys an attacker can time. What they leave behind is wiped: the staged keys, the digit buffer and
+ * the workspace slots of the partial products are zeroed on the stream before the call's workspace is released.
+ * n x Signature::new / PublicKey::from_secret_key. Secret keys are NOT range-checked here: any 32-byte big-endian value gives [sk mod r] H(msg) /
  * [sk mod r] G1. The device entries use the context's workspace (four items per signature, in chunks of 65 536 signatures) and wait for its
  * previous user like the verification entries; they only enqueue. */
 int mbls_sign_batch(mbls_ctx* ctx, const uint8_t* sks32, const uint8_t* msgs, uint32_t msg_len, uint64_t n, uint8_t* sigs96);

@@ -34,6 +34,7 @@ SIGNATURES = {
     "mbls_ctx_set_coop_max_items": (C.c_int, [vp, C.c_uint64]),
     "mbls_ctx_set_coop_hash_max_items": (C.c_int, [vp, C.c_uint64]),
     "mbls_ctx_set_coop_packing": (C.c_int, [vp, C.c_uint64, C.c_uint64, C.c_uint64]),
+    "mbls_ctx_set_round_items": (C.c_int, [vp, C.c_uint64]),
     "mbls_last_error": (C.c_char_p, [vp]),
     "mbls_fast_aggregate_verify_batch_device": (C.c_int, [vp, vp, vp, C.c_uint32, vp, vp, C.c_int, vp, C.c_uint64, C.c_uint32, vp, vp, vp, vp]),
     "mbls_fast_aggregate_verify_batch": (C.c_int, [vp, vp, vp, C.c_uint32, vp, vp, C.c_int, vp, C.c_uint64, C.c_uint32, vp, vp]),
@@ -91,6 +92,7 @@ SIGNATURES = {
     "mbls_multi_keytable_create": (C.c_int, [vp, C.c_uint64, C.POINTER(vp)]),
     "mbls_multi_keytable_destroy": (None, [vp]),
     "mbls_multi_keytable_size": (C.c_uint64, [vp]),
+    "mbls_multi_keytable_replica": (vp, [vp, C.c_int]),
     "mbls_multi_keytable_append": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_uint64, C.POINTER(C.c_uint64), vp]),
     "mbls_multi_fast_aggregate_verify_batch_indexed": (C.c_int, [vp, vp, vp, vp, C.c_uint32, vp, vp, vp, C.c_uint64, C.c_uint32, vp, vp]),
     "mbls_enable_phase_timing": (C.c_int, [vp, C.c_int]),
@@ -168,6 +170,10 @@ class Context:
 
     def set_coop_hash_max_items(self, n):
         self.check(lib().mbls_ctx_set_coop_hash_max_items(self._h, n))
+
+    def set_round_items(self, items):
+        """items per round of the one-lane kernels (0: the device's CUs x 4 x 64); a batch's remainder above whole rounds is routed on its own"""
+        self.check(lib().mbls_ctx_set_round_items(self._h, items))
 
     def set_coop_packing(self, pairing_min_items, pairing_max_items, hash_min_items):
         """pairing_min < n <= pairing_max: two items per wave in the pairing check; n > hash_min: four per wave in the message phase"""

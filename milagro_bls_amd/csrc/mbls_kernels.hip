@@ -19,6 +19,17 @@
 #include "mbls_coop.h"
 #include "../../include/mbls.h"
 
+// The product library exists only with the generated routines: the host side below selects kernels (the fused subgroup verdict of
+// k_miller / k_sig_verdict, k_blind_*_d, the tree levels, k_coop) whose bodies ARE those routines. The development switches that used to
+// replace them by the compiled lane bodies would leave empty or unfused kernels behind the same launches -- wrong answers, not slower
+// ones -- so such a build is refused. (The compiled lane bodies remain what tests/host_emul compiles as plain C++.)
+#if defined(MBLS_NO_ASM) || defined(MBLS_NO_FP2_ASM) || defined(MBLS_NO_LDS_STATE)
+#error "libmbls_hip.so cannot be built with MBLS_NO_ASM / MBLS_NO_FP2_ASM / MBLS_NO_LDS_STATE: the host side depends on the generated routines"
+#endif
+#if defined(__HIP_DEVICE_COMPILE__) && !MBLS_DEVICE_ASM
+#error "device pass without the generated routines"
+#endif
+
 #define MBLS_SLOT_S 25            // 6 Fp: Jacobian G2 accumulator for verify_multiple
 #define MBLS_SLOT_T 31            // 12 Fp: the running points of the generated Miller loop (packed, 2^392 domain; tools/gen_tower_d.py T_SLOT)
 #define MBLS_SLOT_G2TMP 43        // 6 Fp: scratch of the generated subgroup-test routine (tools/gen_tower_d.py G2_SLOTS)
@@ -51,12 +62,10 @@ __global__ void MBLS_LB k_aggregate_raw_d(mbls_ws ws, const uint8_t* pks, const 
     uint64_t first = offsets ? offsets[i] : (uint64_t)k * i; uint32_t cnt = offsets ? offsets[i + 1] - offsets[i] : k;
     uint32_t bad = 0;
     if (offsets && offsets[i + 1] < offsets[i]) { cnt = 0; bad = MBLS_ST_BAD_PK_ENCODING; }
-#if MBLS_DEVICE_ASM && !defined(MBLS_NO_FP2_ASM)
+#if MBLS_DEVICE_ASM
     uint32_t st = lane_aggregate_d<false>(ws, i, pks + 96 * first, cnt, mode, threadIdx.x) | bad;
-#else
-    uint32_t st; lane_aggregate(ws, i, pks + 96 * first, cnt, MBLS_PK_UNCOMPRESSED, mode, &st); st |= bad;
-#endif
     if (st) atomicOr(status + i, st);
+#endif
 }
 __global__ void MBLS_LB k_aggregate_indexed_d(mbls_ws ws, const uint32_t* recs, uint64_t tsize, const uint32_t* idx, const uint32_t* offsets, uint32_t k,
                                               int mode, uint32_t* status, uint64_t n) {
@@ -64,12 +73,10 @@ __global__ void MBLS_LB k_aggregate_indexed_d(mbls_ws ws, const uint32_t* recs, 
     uint64_t first = offsets ? offsets[i] : (uint64_t)k * i; uint32_t cnt = offsets ? offsets[i + 1] - offsets[i] : k;
     uint32_t bad = 0;
     if (offsets && offsets[i + 1] < offsets[i]) { cnt = 0; bad = MBLS_ST_BAD_PK_ENCODING; }
-#if MBLS_DEVICE_ASM && !defined(MBLS_NO_FP2_ASM)
+#if MBLS_DEVICE_ASM
     uint32_t st = lane_aggregate_d<true>(ws, i, idx + first, cnt, mode, threadIdx.x, recs, tsize) | bad;
-#else
-    uint32_t st; lane_aggregate_indexed(ws, i, recs, tsize, idx + first, cnt, mode, &st); st |= bad;
-#endif
     if (st) atomicOr(status + i, st);
+#endif
 }
 // one key per lane, nothing but a square root: with the 8-entry window table (112 AGPRs) the kernel fits 256 registers and two
 // waves share a SIMD -- the plain 32-bit third of the instruction stream then issues at twice the rate (profiles/r02_ubench.txt)
@@ -109,22 +116,15 @@ __global__ void MBLS_LB k_g2_sum(const uint32_t* xy, const uint8_t* flags, const
     op_g2_sum(i, xy + 48 * first, flags + first, cnt, out96, errs);
 }
 __global__ void MBLS_LB k_sig(mbls_ws ws, const uint8_t* sigs, uint32_t* status, uint64_t n, int check) {
-#if !defined(MBLS_NO_LDS_STATE)
     __shared__ uint32_t spill[154 * 64];          // 11 spill slots of 14 dwords per lane for the generated subgroup test
     uint64_t i = gid(); if (i >= n) return;
     uint32_t st = 0; lane_sig(ws, i, sigs + 96 * i, &st, (MBLS_LDS uint32_t*)spill, threadIdx.x, true, check != 0);
-#else
-    uint64_t i = gid(); if (i >= n) return;
-    uint32_t st = 0; lane_sig(ws, i, sigs + 96 * i, &st);
-#endif
     if (st) atomicOr(status + i, st);             // may run beside k_aggregate on another stream
 }
 // item i's message: msgs[mlen i ..] or, with an offset table of n + 1 entries, msgs[moff[i] .. moff[i+1]) (any length below 2^32; a range
 // that runs backwards is never read: the item is rejected with MBLS_ST_BAD_MSG_RANGE)
 __global__ void MBLS_LB k_hash(mbls_ws ws, const uint8_t* msgs, uint32_t mlen, const uint64_t* moff, uint32_t* status, uint64_t n) {
-#if !defined(MBLS_NO_LDS_STATE)
     __shared__ uint32_t spill[154 * 64];          // the same for the addition / cofactor-clearing routine
-#endif
     uint64_t i = gid(); if (i >= n) return;
     const uint8_t* m = msgs + (uint64_t)mlen * i; uint32_t len = mlen;
     if (moff) {
@@ -133,11 +133,7 @@ __global__ void MBLS_LB k_hash(mbls_ws ws, const uint8_t* msgs, uint32_t mlen, c
         m = msgs + (bad ? 0 : a); len = bad ? 0u : (uint32_t)(b - a);
         if (bad) atomicOr(status + i, MBLS_ST_BAD_MSG_RANGE);
     }
-#if !defined(MBLS_NO_LDS_STATE)
     lane_hash(ws, i, m, len, (MBLS_LDS uint32_t*)spill, threadIdx.x, true);
-#else
-    lane_hash(ws, i, m, len);
-#endif
 }
 // hash_to_field alone (SHA-256 / expand_message_xmd, one lane per item): u0, u1 into slots 31, 32 / 37, 38 -- the input of the cooperative
 // engine's hashg2 program (small batches: one WAVE per item walks the maps, the addition and the cofactor clearing)
@@ -150,20 +146,15 @@ __global__ void MBLS_LB k_hash_fields(mbls_ws ws, const uint8_t* msgs, uint32_t 
         m = msgs + (bad ? 0 : a); len = bad ? 0u : (uint32_t)(b - a);
         if (bad) atomicOr(status + i, MBLS_ST_BAD_MSG_RANGE);
     }
-#if MBLS_DEVICE_ASM && !defined(MBLS_NO_FP2_ASM)
+#if MBLS_DEVICE_ASM
     hash_fields_to_ws(ws.w, ws.stride, i, m, len);
 #endif
 }
 __global__ void MBLS_LB k_miller(mbls_ws ws, uint64_t n) {
-#if !defined(MBLS_NO_LDS_STATE)
     // one wave per SIMD = 4 waves per CU: each wave can park 36 KB of loop state in LDS (144 of the 160 KB)
     __shared__ uint32_t tstore[154 * 64];         // 11 spill slots of 14 dwords per lane for the generated loop (the running points are in HBM)
     uint64_t i = gid(); if (i >= n) return;
     lane_miller(ws, i, (MBLS_LDS uint32_t*)tstore, threadIdx.x, true);
-#else
-    uint64_t i = gid(); if (i >= n) return;
-    lane_miller(ws, i);
-#endif
 }
 // between k_miller and k_final when k_sig only decoded: the signature's subgroup test from the loop's running point (lane_sig_verdict)
 __global__ void MBLS_LB k_sig_verdict(mbls_ws ws, uint32_t* status, uint64_t n) {
@@ -172,14 +163,9 @@ __global__ void MBLS_LB k_sig_verdict(mbls_ws ws, uint32_t* status, uint64_t n) 
     if (st) status[i] |= st;
 }
 __global__ void MBLS_LB k_final(mbls_ws ws, uint32_t* status, uint8_t* results, uint64_t n) {
-#if !defined(MBLS_NO_LDS_STATE)
     __shared__ uint32_t accstore[154 * 64];       // spill slots of the generated exponentiation routine / the Fp12 parked by the one-shot products
     uint64_t i = gid(); if (i >= n) return;
     uint32_t st = status[i]; uint8_t r; lane_final(ws, i, &st, &r, (MBLS_LDS uint32_t*)accstore, threadIdx.x, true); status[i] = st; results[i] = r;
-#else
-    uint64_t i = gid(); if (i >= n) return;
-    uint32_t st = status[i]; uint8_t r; lane_final(ws, i, &st, &r); status[i] = st; results[i] = r;
-#endif
 }
 
 // accept bitmap: one 64-bit word per wave via ballot
@@ -217,7 +203,7 @@ __global__ void MBLS_LB k_blind_g1(mbls_ws ws, const uint8_t* pks96, const uint6
 }
 // [r_i] pk_i with the generated windowed routine (g1_blind_routine); pks96 == NULL: the aggregate key k_aggregate left in slots 0..2
 __global__ void MBLS_LB k_blind_g1_d(mbls_ws ws, const uint8_t* pks96, const uint64_t* rands, uint32_t* status, uint64_t n) {
-#if MBLS_DEVICE_ASM && !defined(MBLS_NO_FP2_ASM)
+#if MBLS_DEVICE_ASM
     uint64_t i = gid(); if (i >= n) return;
     uint32_t st = 0;
     if (pks96) {
@@ -234,7 +220,7 @@ __global__ void MBLS_LB k_blind_g1_d(mbls_ws ws, const uint8_t* pks96, const uin
 }
 // the same with the generated routines (decode inlined like k_sig; subgroup test + windowed [r] sig: g2_blind_routine): no lane-private memory
 __global__ void MBLS_LB k_blind_sig_d(mbls_ws ws, const uint8_t* sigs96, const uint64_t* rands, uint32_t* status, uint64_t n) {
-#if MBLS_DEVICE_ASM && !defined(MBLS_NO_FP2_ASM) && !defined(MBLS_NO_LDS_STATE)
+#if MBLS_DEVICE_ASM
     __shared__ uint32_t spill[154 * 64];
     uint64_t i = gid(); if (i >= n) return;
     uint32_t st = 0;
@@ -268,7 +254,7 @@ __global__ void MBLS_LB k_miller_single(mbls_ws ws, uint64_t n, int with_sig, ui
     g2h_from_jacobian(&pr.q, &h); g1arg_from_jacobian(&pr.p, &a);
     pr.t = pr.q;
     fp12 f;
-#if MBLS_DEVICE_ASM && !defined(MBLS_NO_FP2_ASM) && !defined(MBLS_NO_LDS_STATE)
+#if MBLS_DEVICE_ASM
     miller_loop_single_d(&f, &pr, ws.w, ws.stride, i, (MBLS_LDS uint32_t*)spill, threadIdx.x);
 #else
     miller_loop(&f, &pr, 1);
@@ -278,14 +264,14 @@ __global__ void MBLS_LB k_miller_single(mbls_ws ws, uint64_t n, int with_sig, ui
 }
 // tree levels with one lane per product: item i <- item i (op) item i + half, for i + half < m (generated routines, tools/gen_tower_d.py)
 __global__ void MBLS_LB k_f12_tree_d(mbls_ws ws, uint64_t m, uint64_t half) {
-#if MBLS_DEVICE_ASM && !defined(MBLS_NO_FP2_ASM) && !defined(MBLS_NO_LDS_STATE)
+#if MBLS_DEVICE_ASM
     __shared__ uint32_t spill[154 * 64];
     uint64_t i = gid(); if (i + half >= m || i >= half) return;
     tree_level_d_call<false>(ws, i, half, (MBLS_LDS uint32_t*)spill, threadIdx.x);
 #endif
 }
 __global__ void MBLS_LB k_g2_tree_d(mbls_ws ws, uint64_t m, uint64_t half) {
-#if MBLS_DEVICE_ASM && !defined(MBLS_NO_FP2_ASM) && !defined(MBLS_NO_LDS_STATE)
+#if MBLS_DEVICE_ASM
     __shared__ uint32_t spill[154 * 64];
     uint64_t i = gid(); if (i + half >= m || i >= half) return;
     tree_level_d_call<true>(ws, i, half, (MBLS_LDS uint32_t*)spill, threadIdx.x);
@@ -360,7 +346,7 @@ MBLS_FN void scalar_base_y_digits(uint64_t a[4], const uint8_t* sk32) {
     }
 }
 __global__ void MBLS_LB k_sign_blind(mbls_ws ws, const uint8_t* sks32, uint64_t n) {
-#if MBLS_DEVICE_ASM && !defined(MBLS_NO_FP2_ASM) && !defined(MBLS_NO_LDS_STATE)
+#if MBLS_DEVICE_ASM
     __shared__ uint32_t spill[154 * 64];
     uint64_t t = gid(); if (t >= 4 * n) return;
     const uint64_t i = t % n; const uint32_t j = (uint32_t)(t / n);
@@ -455,6 +441,9 @@ struct mbls_ctx {
     uint64_t coop_max_items = 10240;
     // within (pack_min, pack_max] a wave serves two items (pairing check) / four items (message phase) side by side: more steps per wave, fewer per item
     uint64_t coop_pack_min_items = 1024, coop_pack_max_items = 2048, coop_hash_pack_min_items = 768;
+    // one ROUND of the one-lane kernels = one wave on every SIMD (512 registers per lane: one wave per SIMD) = CUs x 4 x 64 items. A batch of
+    // q rounds + r items would cost q + 1 rounds of every kernel; the r items are cut off and take the route of an r-item batch instead
+    uint64_t round_items = 65536;
     char err[256] = {};
 };
 struct mbls_keytable {
@@ -572,6 +561,10 @@ extern "C" int mbls_ctx_create(mbls_ctx** out, int device_id) {
         }
         const char* e = getenv("MBLS_COOP_MAX_ITEMS");
         if (e) c->coop_max_items = strtoull(e, nullptr, 10);
+        e = getenv("MBLS_COOP_HASH_MAX_ITEMS");
+        if (e) c->coop_hash_max_items = strtoull(e, nullptr, 10);
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0) c->round_items = (uint64_t)prop.multiProcessorCount * 4 * WG;
     }
     if (!ok) { ctx_free(c); return MBLS_ERR_DEVICE; }
     *out = c; return MBLS_OK;
@@ -588,6 +581,17 @@ extern "C" int mbls_ctx_set_coop_hash_max_items(mbls_ctx* c, uint64_t max_items)
 extern "C" int mbls_ctx_set_coop_packing(mbls_ctx* c, uint64_t pairing_min_items, uint64_t pairing_max_items, uint64_t hash_min_items) {
     if (!c) return MBLS_ERR_ARGUMENT;
     mbls_lock lk(c->mu); c->coop_pack_min_items = pairing_min_items; c->coop_pack_max_items = pairing_max_items; c->coop_hash_pack_min_items = hash_min_items; return MBLS_OK;
+}
+// items per round of the one-lane kernels (default: CUs x 4 SIMDs x 64 lanes); batches above it have their remainder routed as a batch of its own
+extern "C" int mbls_ctx_set_round_items(mbls_ctx* c, uint64_t items) {
+    if (!c || (items && items % WG)) return MBLS_ERR_ARGUMENT;
+    mbls_lock lk(c->mu);
+    if (!items) {
+        hipDeviceProp_t prop;
+        HIPCHK(c, hipGetDeviceProperties(&prop, c->device));
+        items = (uint64_t)prop.multiProcessorCount * 4 * WG;
+    }
+    c->round_items = items; return MBLS_OK;
 }
 extern "C" void mbls_ctx_destroy(mbls_ctx* c) {
     if (!c) return;
@@ -678,9 +682,9 @@ static int table_acquire(mbls_ctx* c, const mbls_keytable* t, hipStream_t s) {
     return MBLS_OK;
 }
 
-static int verify_pipeline(mbls_ctx* c, const uint8_t* d_sigs, const uint8_t* d_msgs, uint32_t msg_len, const uint64_t* d_moff, const keysrc& ks,
-                           uint64_t n, uint32_t k, int mode, uint8_t* d_results, uint64_t* d_bitmap,
-                           uint32_t* d_status, hipStream_t s, int part = 0) {
+static int verify_pipeline_one(mbls_ctx* c, const uint8_t* d_sigs, const uint8_t* d_msgs, uint32_t msg_len, const uint64_t* d_moff, const keysrc& ks,
+                               uint64_t n, uint32_t k, int mode, uint8_t* d_results, uint64_t* d_bitmap,
+                               uint32_t* d_status, hipStream_t s, int part = 0) {
     const int fmt = ks.fmt; const uint32_t* d_off = ks.d_off;
     if (!c || (fmt != MBLS_PK_COMPRESSED && fmt != MBLS_PK_UNCOMPRESSED)) return MBLS_ERR_ARGUMENT;
     if (n == 0) return MBLS_OK;
@@ -757,6 +761,31 @@ static int verify_pipeline(mbls_ctx* c, const uint8_t* d_sigs, const uint8_t* d_
     HIPCHK(c, hipGetLastError());
     return ws_release(c, s);
 }
+// Items [lo, n) of a batch as a batch of their own: uniform layouts advance the base pointers, offset tables are absolute (their slice goes
+// with the unmoved base); lo is a multiple of 64, so the bitmap advances by whole words.
+static int verify_pipeline_from(mbls_ctx* c, uint64_t lo, const uint8_t* d_sigs, const uint8_t* d_msgs, uint32_t msg_len, const uint64_t* d_moff, const keysrc& ks,
+                                uint64_t n, uint32_t k, int mode, uint8_t* d_results, uint64_t* d_bitmap, uint32_t* d_status, hipStream_t s) {
+    keysrc t = ks;
+    const size_t unit = ks.fmt == MBLS_PK_COMPRESSED ? 48 : 96;
+    if (ks.d_off) t.d_off = ks.d_off + lo;
+    else { if (ks.d_pks) t.d_pks = ks.d_pks + unit * (uint64_t)k * lo; if (ks.d_idx) t.d_idx = ks.d_idx + (uint64_t)k * lo; }
+    return verify_pipeline_one(c, d_sigs + 96 * lo, (d_moff || !d_msgs) ? d_msgs : d_msgs + (uint64_t)msg_len * lo, msg_len, d_moff ? d_moff + lo : nullptr, t,
+                               n - lo, k, mode, d_results + lo, d_bitmap ? d_bitmap + lo / 64 : nullptr, d_status ? d_status + lo : nullptr, s, 0);
+}
+// The batch as the caller sees it. n = q rounds + r items (0 < r < round): the q rounds run as one launch per kernel, the r items afterwards
+// as a batch of their own, which takes the route of its size (one wave per item up to coop_max_items) -- 1 + T(r) / T(round) rounds
+// instead of 2. (The phase timers describe a single pass: no cut while they are on.)
+static int verify_pipeline(mbls_ctx* c, const uint8_t* d_sigs, const uint8_t* d_msgs, uint32_t msg_len, const uint64_t* d_moff, const keysrc& ks,
+                           uint64_t n, uint32_t k, int mode, uint8_t* d_results, uint64_t* d_bitmap,
+                           uint32_t* d_status, hipStream_t s, int part = 0) {
+    const uint64_t R = c ? c->round_items : 0;
+    if (!c || part != 0 || c->timing || !R || n <= R || n % R == 0)
+        return verify_pipeline_one(c, d_sigs, d_msgs, msg_len, d_moff, ks, n, k, mode, d_results, d_bitmap, d_status, s, part);
+    const uint64_t lo = n - n % R;
+    int rc = mbls_ctx_reserve(c, lo); if (rc) return rc;          // one growth, not two
+    rc = verify_pipeline_one(c, d_sigs, d_msgs, msg_len, d_moff, ks, lo, k, mode, d_results, d_bitmap, d_status, s, 0); if (rc) return rc;
+    return verify_pipeline_from(c, lo, d_sigs, d_msgs, msg_len, d_moff, ks, n, k, mode, d_results, d_bitmap, d_status, s);
+}
 extern "C" int mbls_fast_aggregate_verify_batch_device(mbls_ctx* c, const uint8_t* d_sigs, const uint8_t* d_msgs, uint32_t msg_len,
         const uint64_t* d_moff, const uint8_t* d_pks, int fmt, const uint32_t* d_off, uint64_t n, uint32_t k, uint8_t* d_results, uint64_t* d_bitmap,
         uint32_t* d_status, void* stream) {
@@ -817,6 +846,9 @@ static int verify_host(mbls_ctx* c, const uint8_t* sigs, const uint8_t* msgs, ui
     bool tm = c->timing; c->timing = false;              // the phase timers assume the plain order
     keysrc ks; ks.fmt = fmt; ks.d_off = off ? doff.as<uint32_t>() : nullptr; ks.indexed = indexed;
     if (indexed) { ks.d_recs = tab->d_recs; ks.tsize = tab->size; ks.tab = tab; }
+    const uint64_t R = c->round_items;
+    const uint64_t n_all = n;
+    if (R && n > R && n % R) n -= n % R;                 // the rounds first (parts 1 and 2 below); the remainder as a full pass once the keys are there
     int rc = verify_pipeline(c, ds.as<uint8_t>(), d_msgs, msg_len, d_moff, ks, n, k, mode, dr.as<uint8_t>(), nullptr, dst.as<uint32_t>(), c->hs_a, 1);
     if (!rc) {
         hipError_t e1 = hipSuccess;      // issued after the first two phases were queued: a copy from pageable memory may block the host
@@ -827,8 +859,11 @@ static int verify_host(mbls_ctx* c, const uint8_t* sigs, const uint8_t* msgs, ui
         if (!rc) {
             if (indexed) ks.d_idx = dp.as<uint32_t>() - key_first; else ks.d_pks = dp.as<uint8_t>() - unit * key_first;     // the table's offsets are absolute
             rc = verify_pipeline(c, ds.as<uint8_t>(), d_msgs, msg_len, d_moff, ks, n, k, mode, dr.as<uint8_t>(), nullptr, dst.as<uint32_t>(), c->hs_a, 2);
+            if (!rc && n_all > n)
+                rc = verify_pipeline_from(c, n, ds.as<uint8_t>(), d_msgs, msg_len, d_moff, ks, n_all, k, mode, dr.as<uint8_t>(), nullptr, dst.as<uint32_t>(), c->hs_a);
         }
     }
+    n = n_all;
     c->timing = tm;
     if (rc) {         // part 1 may be running on the context's streams: nothing of this call is left in flight when it returns an error
         (void)hipStreamSynchronize(c->hs_a); (void)hipStreamSynchronize(c->hs_b); (void)hipStreamSynchronize(c->hs_c); (void)hipStreamSynchronize(c->hs_d);
@@ -876,6 +911,12 @@ extern "C" void mbls_keytable_destroy(mbls_keytable* t) {
     }
     delete t;
 }
+// undo of an append (mbls_multi_keytable_append: a replica failed): later appends overwrite the dropped records
+static void keytable_truncate(mbls_keytable* t, uint64_t size) {
+    if (!t || !t->c) return;
+    mbls_lock lk(t->c->mu);
+    if (size < t->size) t->size = size;
+}
 extern "C" uint64_t mbls_keytable_size(const mbls_keytable* t) { if (!t || !t->c) return 0; mbls_lock lk(t->c->mu); return t->size; }
 static int keytable_grow(mbls_keytable* t, uint64_t need, hipStream_t s) {
     mbls_ctx* c = t->c;
@@ -903,7 +944,6 @@ extern "C" int mbls_keytable_append_device(mbls_keytable* t, const uint8_t* d_pk
     HIPCHK(c, hipSetDevice(c->device));
     hipStream_t s = (hipStream_t)stream;
     int rc = keytable_grow(t, t->size + n, s); if (rc) return rc;
-    if (first_index) *first_index = t->size;
     if (n) {
         // an earlier append on another stream may still be writing its own records: nothing to order (disjoint), but the event below
         // replaces the earlier one, so this stream inherits the earlier append's completion first
@@ -912,6 +952,7 @@ extern "C" int mbls_keytable_append_device(mbls_keytable* t, const uint8_t* d_pk
         HIPCHK(c, hipGetLastError());
         HIPCHK(c, hipEventRecord(t->ev, s)); t->ev_stream = s; t->pending = true;     // readers on other streams wait for this (table_acquire)
     }
+    if (first_index) *first_index = t->size;      // published only once everything of the append is in the stream
     t->size += n; return MBLS_OK;
 }
 static int map_dec_err_g1(int e) { return e == MBLS_DEC_OK ? MBLS_OK : (e == MBLS_DEC_SIZE ? MBLS_ERR_INVALID_G1_SIZE : MBLS_ERR_INVALID_POINT); }
@@ -994,6 +1035,13 @@ extern "C" int mbls_sig_check_batch(mbls_ctx* c, const uint8_t* in96, uint64_t n
     return MBLS_OK;
 }
 static void g2_tree_levels(mbls_ctx* c, mbls_ws ws, uint64_t m, int levels, hipStream_t s);
+// Secret-dependent words do not outlive the call that made them: workspace slots [slot_lo, slot_hi) of items 0..m-1 are zeroed on the
+// stream (word-major layout: one row of `stride` items per word, so this is a 2-D fill of m items x 12 (slot_hi - slot_lo) rows).
+// NOTE the signing / key-derivation kernels are NOT constant-time: k_aggregate_indexed_d gathers table records at secret-dependent
+// addresses and the window digits of k_sign_blind select per-lane records (include/mbls.h says so at mbls_sign_batch).
+static hipError_t ws_wipe(mbls_ctx* c, int slot_lo, int slot_hi, uint64_t m, hipStream_t s) {
+    return hipMemset2DAsync(c->d_w + (size_t)slot_lo * 12 * c->cap, c->cap * 4, 0, m * 4, (size_t)(slot_hi - slot_lo) * 12, s);
+}
 // [sk] H(msg) for n (secret key, message) pairs: the pipeline's message phase, the four-lane windowed multiplication (k_sign_blind), two
 // levels of the G2 sum tree, compression -- in chunks of MBLS_SIGN_CHUNK signatures (four workspace items each). Enqueues only.
 #define MBLS_SIGN_CHUNK 65536ull
@@ -1016,6 +1064,10 @@ extern "C" int mbls_sign_batch_device(mbls_ctx* c, const uint8_t* d_sks, const u
         hipLaunchKernelGGL(k_s_export, dim3(nblk(m)), dim3(WG), 0, s, ws, m, d_sigs + 96 * lo);
     }
     HIPCHK(c, hipGetLastError());
+    // the four partial products [a_j] psi^j(H) (slots SIG, S) and their window tables (KREC..) are functions of the secret key
+    HIPCHK(c, ws_wipe(c, MBLS_SLOT_SIG, MBLS_SLOT_SIG + 4, 4 * chunk, s));
+    HIPCHK(c, ws_wipe(c, MBLS_SLOT_S, MBLS_SLOT_S + 6, 4 * chunk, s));
+    HIPCHK(c, ws_wipe(c, MBLS_SLOT_KREC, MBLS_SLOT_KREC + 48, 4 * chunk, s));
     return ws_release(c, s);
 }
 extern "C" int mbls_sign_batch(mbls_ctx* c, const uint8_t* sks, const uint8_t* msgs, uint32_t msg_len, uint64_t n, uint8_t* sigs) {
@@ -1025,6 +1077,7 @@ extern "C" int mbls_sign_batch(mbls_ctx* c, const uint8_t* sks, const uint8_t* m
     HIPCHK(c, hipSetDevice(c->device));
     sbuf dk(c, 0), dm(c, 1), dout(c, 2); HIPCHK(c, dk.up(sks, 32 * n)); HIPCHK(c, dm.up(msgs, (size_t)msg_len * n)); HIPCHK(c, dout.alloc(96 * n));
     int rc = mbls_sign_batch_device(c, dk.as<uint8_t>(), dm.as<uint8_t>(), msg_len, n, dout.as<uint8_t>(), c->hs_a); if (rc) return rc;
+    HIPCHK(c, hipMemsetAsync(dk.p, 0, 32 * n, c->hs_a));                  // the staged secret keys
     HIPCHK(c, hipStreamSynchronize(c->hs_a)); HIPCHK(c, dout.down(sigs, 96 * n)); return MBLS_OK;
 }
 // the fixed table of sk -> pk: the 1 024 multiples come from the compiled ladder (k_sk_to_pk) once per context
@@ -1071,6 +1124,7 @@ extern "C" int mbls_sk_to_pk_batch_device(mbls_ctx* c, const uint8_t* d_sks, int
         hipLaunchKernelGGL(k_apk_export_fmt, dim3(nblk(m)), dim3(WG), 0, s, ws, m, fmt, d_pks + (uint64_t)(fmt ? 96 : 48) * lo);
     }
     HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemsetAsync(c->d_skidx, 0, chunk * 64 * 4, s));            // the hexadecimal digits of the secret keys
     return ws_release(c, s);
 }
 extern "C" int mbls_sk_to_pk_batch(mbls_ctx* c, const uint8_t* sks, int fmt, uint64_t n, uint8_t* pks) {
@@ -1080,6 +1134,7 @@ extern "C" int mbls_sk_to_pk_batch(mbls_ctx* c, const uint8_t* sks, int fmt, uin
     HIPCHK(c, hipSetDevice(c->device));
     sbuf dk(c, 0), dout(c, 1); HIPCHK(c, dk.up(sks, 32 * n)); HIPCHK(c, dout.alloc((fmt ? 96 : 48) * n));
     int rc = mbls_sk_to_pk_batch_device(c, dk.as<uint8_t>(), fmt, n, dout.as<uint8_t>(), c->hs_a); if (rc) return rc;
+    HIPCHK(c, hipMemsetAsync(dk.p, 0, 32 * n, c->hs_a));                  // the staged secret keys
     HIPCHK(c, hipStreamSynchronize(c->hs_a)); HIPCHK(c, dout.down(pks, (fmt ? 96 : 48) * n)); return MBLS_OK;
 }
 extern "C" int mbls_hash_to_g2_batch_mode(mbls_ctx* c, const uint8_t* msgs, uint32_t msg_len, uint64_t n, uint8_t* out96, int mode);
@@ -1363,6 +1418,7 @@ extern "C" int mbls_aggregate_verify(mbls_ctx* c, const uint8_t sig[96], const u
     if (ws_acquire(c, s)) return 0;
     (void)hipMemsetAsync(c->d_scalar, 0, 64, s);
     (void)hipMemsetAsync(c->d_status, 0, 4 * n, s);
+    if (hipMemsetAsync(c->d_results, 0, 1, s) != hipSuccess) return 0;      // false until the tail kernel has spoken
     // three chains side by side: the signature (decode + subgroup test: k_sig on item 0's slots, then into slot S), the keys, the messages
     (void)hipEventRecord(c->hs_ev, s); (void)hipStreamWaitEvent(c->hs_b, c->hs_ev, 0); (void)hipStreamWaitEvent(c->hs_c, c->hs_ev, 0);
     hipLaunchKernelGGL(k_sig, dim3(1), dim3(WG), 0, c->hs_b, ws, (const uint8_t*)dsig.as<uint8_t>(), c->d_status, (uint64_t)1, 1);
@@ -1400,6 +1456,7 @@ static int verify_multiple_impl(mbls_ctx* c, const uint8_t* d_sigs, const uint8_
     rc = ws_acquire(c, s); if (rc) return rc;
     HIPCHK(c, hipMemsetAsync(c->d_scalar, 0, 64, s));
     HIPCHK(c, hipMemsetAsync(c->d_status, 0, 4 * n, s));
+    HIPCHK(c, hipMemsetAsync(d_result, 0, 1, s));                           // false until the tail kernel has spoken (fail closed)
     // Three independent chains: keys (aggregate, [r]apk), signatures (decode, subgroup check, [r]sig, sum tree), messages (hash). Below
     // 2^14 sets each of them leaves most SIMDs idle, so they run side by side on the context's streams and join before the
     // Miller loops; larger batches fill the chip by themselves and stay on the caller's stream.
@@ -1553,6 +1610,7 @@ extern "C" void mbls_multi_keytable_destroy(mbls_multi_keytable* t) {
     for (mbls_keytable* x : t->tab) mbls_keytable_destroy(x);
     delete t;
 }
+extern "C" mbls_keytable* mbls_multi_keytable_replica(mbls_multi_keytable* t, int i) { return (t && i >= 0 && i < (int)t->tab.size()) ? t->tab[i] : nullptr; }
 extern "C" uint64_t mbls_multi_keytable_size(const mbls_multi_keytable* t) { return (t && !t->tab.empty()) ? mbls_keytable_size(t->tab[0]) : 0; }
 // the same keys, decoded on every device side by side (the indices are the same everywhere); errs as mbls_keytable_append
 extern "C" int mbls_multi_keytable_append(mbls_multi_keytable* t, const uint8_t* pks, int fmt, int validate, uint64_t n, uint64_t* first_index, uint8_t* errs) {
@@ -1571,9 +1629,14 @@ extern "C" int mbls_multi_keytable_append(mbls_multi_keytable* t, const uint8_t*
     try { for (size_t g = 1; g < G; g++) th.emplace_back(work, g); } catch (...) { for (auto& x : th) x.join(); return MBLS_ERR_DEVICE; }
     work(0);
     for (auto& x : th) x.join();
-    for (size_t g = 0; g < G; g++) {
-        if (rcs[g]) { snprintf(m->err, sizeof(m->err), "device %d: %s", m->ctx[g]->device, m->ctx[g]->err); return rcs[g]; }
-        if (first[g] != first[0] || (g && n && memcmp(e[g].data(), errs, n) != 0)) { snprintf(m->err, sizeof(m->err), "replicas of the key table disagree"); return MBLS_ERR_DEVICE; }
+    int bad = MBLS_OK;
+    for (size_t g = 0; g < G && !bad; g++) {
+        if (rcs[g]) { snprintf(m->err, sizeof(m->err), "device %d: %s", m->ctx[g]->device, m->ctx[g]->err); bad = rcs[g]; }
+        else if (first[g] != first[0] || (g && n && memcmp(e[g].data(), errs, n) != 0)) { snprintf(m->err, sizeof(m->err), "replicas of the key table disagree (device %d)", m->ctx[g]->device); bad = MBLS_ERR_DEVICE; }
+    }
+    if (bad) {      // all or nothing: the replicas that did append drop the new records again (the size is host-side state), so the indices stay the same everywhere
+        for (size_t g = 0; g < G; g++) if (!rcs[g]) keytable_truncate(t->tab[g], first[g]);
+        return bad;
     }
     if (first_index) *first_index = first[0];
     return MBLS_OK;

@@ -340,7 +340,14 @@ MBLS_FN uint32_t lane_sig_verdict(const mbls_ws& ws, uint64_t i) {
     const fp2 qx = ws_ld2(ws, MBLS_SLOT_SIG, i), qy = ws_ld2(ws, MBLS_SLOT_SIG + 2, i);
     // the running point as the loop leaves it: packed words, representatives in (0.5 p, 1.5 p) of the 2^392-domain values -- read as
     // 2^384-domain values they are 2^8 X, 2^8 Y, 2^8 Z: the same projective point
-    fp2 X = ws_ld2(ws, 31, i), Y = ws_ld2(ws, 33, i), Z = ws_ld2(ws, 35, i);
+#if MBLS_DEVICE_ASM
+    // the generator says where it left the point and in which form (tools/gen_tower_d.py emits these next to the routine)
+    static_assert(MBLS_GEN_MILLER_T_DOMAIN_BITS == 392 && MBLS_GEN_MILLER_T_PACKED == 1, "lane_sig_verdict reads packed 2^392-domain words");
+    const int T0 = MBLS_GEN_MILLER_T0_SLOT;
+#else
+    const int T0 = 31;
+#endif
+    fp2 X = ws_ld2(ws, T0, i), Y = ws_ld2(ws, T0 + 2, i), Z = ws_ld2(ws, T0 + 4, i);
     X.c0 = fp_reduce_once(X.c0, 0); X.c1 = fp_reduce_once(X.c1, 0); Y.c0 = fp_reduce_once(Y.c0, 0); Y.c1 = fp_reduce_once(Y.c1, 0);
     Z.c0 = fp_reduce_once(Z.c0, 0); Z.c1 = fp_reduce_once(Z.c1, 0);
     const fp2 px = fp2_mul(fp2_conj(qx), fp2_load_const(MBLS_PSI_CX)), py = fp2_mul(fp2_conj(qy), fp2_load_const(MBLS_PSI_CY));     // psi(sig), affine (g2_psi)

@@ -11,6 +11,7 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tools"))
+sys.path.insert(0, os.path.join(ROOT, "oracle", "pymodel"))
 import gen_fpd_asm as d          # noqa: E402
 import gen_tower_d as t          # noqa: E402
 from asm_sim import Machine, s32, digits_signed, from_digits_signed, limbs, from_limbs   # noqa: E402
@@ -319,13 +320,17 @@ def test_miller_bodies(which):
             assert (got - x * R392) % P == 0 and t.PACKED.vlo <= got <= t.PACKED.vhi, (which, trial, slot)
 
 
-def miller_loop_sim(runs, seed, masks_bits=0, pairs=(0, 1)):
+def miller_loop_sim(runs, seed, masks_bits=0, pairs=(0, 1), q0=None):
+    """q0: an affine G2 point ((x0, x1), (y0, y1)) for pair 0's Q (workspace slots 3..6) instead of random field elements"""
     rng = random.Random(seed)
     full, pieces, st = t.miller_loop_d_routine(pairs)
     m = miller_machine(masks_bits)
     true = {}
     for sl in range(13):
-        x = rng.randrange(P); true[sl] = x; ws_put(m, sl, x * R384 % P)
+        x = rng.randrange(P)
+        if q0 is not None and 3 <= sl <= 6:
+            x = q0[(sl - 3) >> 1][(sl - 3) & 1]
+        true[sl] = x; ws_put(m, sl, x * R384 % P)
     m.run(pieces["pro"])
     masks = {"s[48:49]": masks_bits & 1, "s[54:55]": (masks_bits >> 1) & 1}
     f = [1] + [0] * 11
@@ -354,6 +359,12 @@ def miller_loop_sim(runs, seed, masks_bits=0, pairs=(0, 1)):
     for i in range(12):
         assert from_limbs(m.v[t.F_OUT[i]:t.F_OUT[i] + 12]) == f[i] * R384 % P, ("f", i)
     assert not any("scratch" in l or "buffer_" in l for l in full)
+    # the running points as the routine leaves them in the workspace: packed words of the 2^392 domain, representatives in (0.5 p, 1.5 p)
+    # -- what lane_sig_verdict (mbls_lanes.h) reads for pair 0 through MBLS_GEN_MILLER_T0_SLOT
+    for sl, x in T.items():
+        got = ws_get(m, sl)
+        assert (got - x * R392) % P == 0 and t.PACKED.vlo <= got <= t.PACKED.vhi, ("T", sl)
+    return T
 
 
 def test_miller_loop_routine_short_schedules():
@@ -390,7 +401,16 @@ def test_g2_doubling_runs():
 
 def test_miller_loop_routine_full_schedule():
     """the complete loop as the kernel runs it: 63 doubling iterations and 5 addition steps per pair, ~6 million interpreted instructions"""
-    miller_loop_sim(t.RUNS, 7)
+    import bls12_381 as M
+    q = M.g2_mul(M.G2, 0x1234567)
+    T = miller_loop_sim(t.RUNS, 7, q0=q)
+    # pair 0's running point starts at Q_0 and walks the bits of |x|: when the loop returns, slots T0 .. T0 + 5 hold [|x|] Q_0 (X : Y : Z)
+    t0 = t.T_SLOT(0, 0, 0)
+    X, Y, Z = ((T[t0], T[t0 + 1]), (T[t0 + 2], T[t0 + 3]), (T[t0 + 4], T[t0 + 5]))
+    zi = M.f2_inv(Z)
+    assert (M.f2_mul(X, zi), M.f2_mul(Y, zi)) == M.g2_mul(q, M.X_ABS)
+    gen = open(os.path.join(ROOT, "milagro_bls_amd", "csrc", "mbls_towerd_asm.inc")).read()
+    assert "#define MBLS_GEN_MILLER_T0_SLOT %d\n" % t0 in gen
 
 
 # ---------------------------------------------------------------------------------------------- the final exponentiation routine

@@ -125,3 +125,17 @@ def test_kernel_resources(lib_path):
     for k in ("_Z8k_miller", "_Z7k_final", "_Z15k_miller_single"):
         assert int(by(k)["group_segment_fixed_size"]) * 4 <= 160 * 1024, k
     assert int(by("_Z15k_pk_decompress")["vgpr_count"]) <= 256 and int(by("_Z15k_pk_decompress")["agpr_count"]) >= 112
+
+
+@pytest.mark.parametrize("flag", ["MBLS_NO_ASM", "MBLS_NO_FP2_ASM", "MBLS_NO_LDS_STATE"])
+def test_builds_without_the_generated_routines_are_refused(flag):
+    """The host side selects kernels whose bodies ARE the generated routines (the signature's subgroup verdict out of the generated
+    Miller loop, k_blind_*_d, the tree levels, k_coop): a build that swaps them for compiled lane bodies would leave empty or unfused
+    kernels behind the same launches. Such a build must not exist (#error at the top of mbls_kernels.hip)."""
+    src = os.path.join(helpers.ROOT, "milagro_bls_amd", "csrc", "mbls_kernels.hip")
+    r = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-std=c++17", "-E", "-D" + flag, src, "-o", os.devnull],
+                       capture_output=True, text=True)
+    assert r.returncode != 0 and "cannot be built with" in r.stderr
+    # and nothing in the kernels file still branches on those switches
+    txt = open(src).read().split("#endif", 1)[1]
+    assert flag not in txt

@@ -39,6 +39,7 @@ def test_compression_round_trips(api, vectors):
     assert api.AggregateSignature.from_bytes(helpers.G2_INF).as_bytes() == helpers.G2_INF
 
 
+@pytest.mark.usefixtures("engine")
 def test_basic_sign_verify(api):
     # src/signature.rs:63-86
     kp = keypair(api, random.Random(1))
@@ -49,6 +50,7 @@ def test_basic_sign_verify(api):
         assert new_sig.as_bytes() == sig.as_bytes() and new_sig.verify(m, kp.pk)
 
 
+@pytest.mark.usefixtures("engine")
 def test_verification_failure_message(api):
     # src/signature.rs:89-100
     kp = keypair(api, random.Random(2))
@@ -56,6 +58,7 @@ def test_verification_failure_message(api):
     assert sig.verify(b"Other msg", kp.pk) is False and sig.verify(b"", kp.pk) is False
 
 
+@pytest.mark.usefixtures("engine")
 def test_readme(api, vectors):
     # src/signature.rs:103-125, src/keys.rs:311-330
     rd = vectors["reference"]["readme_sk"]
@@ -118,6 +121,7 @@ def test_key_validate(api):
     assert e.value.code == api.AmclError.InvalidPoint
 
 
+@pytest.mark.usefixtures("engine")
 def test_empty_and_split_zero_fast_aggregate_verify(api):
     # src/aggregates.rs:384-410
     agg = api.AggregateSignature.new()
@@ -159,6 +163,7 @@ def helper_test_aggregate_public_keys(api, control_kp, signing_kps, non_signing_
     return agg, apk
 
 
+@pytest.mark.usefixtures("engine")
 def test_known_aggregate_public_keys(api, vectors):
     # src/aggregates.rs:555-609, including the 133 700-byte message, and the golden bytes of the model
     kk = vectors["reference"]["known_keys"]
@@ -207,6 +212,7 @@ def _sets(api, rnd, n, m, wrong_key=False):
     return sets
 
 
+@pytest.mark.usefixtures("engine")
 def test_verify_multiple_signatures(api, vectors):
     # src/aggregates.rs:688-805 (n = 10 sets x m = 3 keys) + the model's golden sets with pinned blinding scalars
     rnd = random.Random(9)
@@ -229,6 +235,7 @@ def test_verify_multiple_signatures(api, vectors):
     assert api.AggregateSignature.verify_multiple_aggregate_signatures(rnd, sets) is False
 
 
+@pytest.mark.usefixtures("engine")
 def test_aggregate_verify(api, vectors):
     # src/aggregates.rs:808-929
     rnd = random.Random(10)

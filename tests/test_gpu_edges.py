@@ -39,6 +39,7 @@ def _keys(rnd, n):
 
 
 # ------------------------------------------------------------------------------------------------ Signature::verify, pk = infinity
+@pytest.mark.usefixtures("engine")
 def test_verify_batch_with_infinite_public_keys(mb):
     """reference src/signature.rs:27-40 has no infinity check on the key: (sig, msg, pk = infinity) reaches the pairing, where an
     infinite argument contributes 1, so the item verifies iff e(sig, -G1) = 1 iff sig = infinity (and sig must be in G2)."""
@@ -91,6 +92,7 @@ def _vm_orc(sigs, apks, msgs, rands):
     return orc.verify_multiple([(d[1], a, m) for d, a, m in zip(dec, apks, msgs)], rands)
 
 
+@pytest.mark.usefixtures("engine")
 def test_verify_multiple_edge_members_vs_oracle(N, vectors):
     """reference src/aggregates.rs:261-316 with members its tests never contain: an infinite signature, an infinite
     aggregate key, both at once in one set, a signature outside G2, a wrong key -- against the oracle with the same scalars."""
@@ -155,6 +157,7 @@ def test_verify_multiple_scalar_requirements(N):
     assert _vm_gpu(N, sigs, pks, msgs, [1 << 63, (1 << 64) - 1, 1]) is True
 
 
+@pytest.mark.usefixtures("engine")
 def test_aggregate_verify_edge_members_vs_oracle(N, vectors):
     """reference src/aggregates.rs:130-170 with infinite / invalid members, against the oracle."""
     from milagro_bls_amd import AggregateSignature, PublicKey, Signature
@@ -216,6 +219,7 @@ def test_pk_decode_batch_validate_on_random_blobs(mb):
 
 
 # ------------------------------------------------------------------------------------------------ resident key table
+@pytest.mark.usefixtures("engine")
 def test_keytable_indexed_verification_matches_byte_path_and_oracle(mb, N):
     rnd = random.Random(16)
     pool_n, n, k = 40, 130, 6
@@ -336,6 +340,7 @@ def test_key_sum_routines_with_divergent_lanes(mb, N):
     assert sum(got_b) > n // 4
 
 
+@pytest.mark.usefixtures("engine")
 def test_keytable_device_entry_at_batch_size(N):
     """2^13 x 128 keys through the indexed device entry against the byte-format device entry: identical results, bitmap and status."""
     import torch
@@ -361,6 +366,7 @@ def test_keytable_device_entry_at_batch_size(N):
     assert torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][2], outs[1][2])
 
 
+@pytest.mark.usefixtures("engine")
 def test_key_buffer_alignment_paths_agree(N):
     """The generated key-sum routine fetches keys with 16-byte loads and is used for 4-byte aligned key buffers; any other address goes
     through the compiled lane body. The same 96-byte keys at offsets 0, 1, 2 and 4 inside a device buffer must give identical results."""
@@ -476,6 +482,7 @@ def test_config5_shard_2_17_items_128_keys(N):
 
 
 # ------------------------------------------------------------------------------------------------ seeded randomised sweep
+@pytest.mark.usefixtures("engine")
 @pytest.mark.parametrize("seed", [100, 101, 102])
 def test_randomised_sweep_vs_oracle(mb, seed):
     """scripts/stress_parity.py as a test: many shapes (n around the wave size, odd key counts, both formats), seven rejection
@@ -488,6 +495,7 @@ def test_randomised_sweep_vs_oracle(mb, seed):
 
 
 # ------------------------------------------------------------------------------------------------ per-item message lengths
+@pytest.mark.usefixtures("engine")
 def test_ragged_message_lengths_vs_oracle(mb, N):
     """The reference takes any `msg: &[u8]` per call (src/aggregates.rs:177; its tests sign 0 .. 133 700 bytes, :436): the batch entries
     take one message buffer + an offset table. Lengths 0 .. 300 and one 133 700-byte item, fast_aggregate_verify and Signature::verify,
@@ -567,6 +575,7 @@ def test_verify_multiple_ragged_messages(N):
 
 
 # ------------------------------------------------------------------------------------------------ key table: ordering across streams
+@pytest.mark.usefixtures("engine")
 def test_keytable_append_and_verify_on_different_streams(N):
     """An append made on stream A must be visible to a verification enqueued on stream B right behind it (no host synchronisation in
     between), also when the append makes the table grow (the records move): the library orders them with an event / drains the device
@@ -621,6 +630,31 @@ def test_keytable_outlives_its_context(N):
 
 
 # ------------------------------------------------------------------------------------------------ several devices behind one handle
+def test_multi_keytable_append_is_all_or_nothing(N):
+    """mbls_multi_keytable_append when one replica cannot follow: the replicas that did append drop the new records again, so a failed call
+    changes no table and the indices stay the same on every device. Forced here by appending to replica 1 alone first (through
+    mbls_multi_keytable_replica), which makes the replicas' first indices disagree."""
+    import ctypes as C
+    rnd = random.Random(31)
+    _, pks = _keys(rnd, 6)
+    m = N.MultiContext([0, 0])
+    tab = N.MultiKeyTable(m, capacity_hint=8)
+    first, errs = tab.append(b"".join(pks[:3]), 3, pk_format=1, validate=True)
+    assert first == 0 and not any(errs) and len(tab) == 3
+    rep = [N.lib().mbls_multi_keytable_replica(tab.handle, g) for g in (0, 1)]
+    assert rep[0] and rep[1] and not N.lib().mbls_multi_keytable_replica(tab.handle, 2)
+    size = lambda g: int(N.lib().mbls_keytable_size(rep[g]))
+    assert (size(0), size(1)) == (3, 3)
+    e1 = N.outbuf(1); f1 = C.c_uint64(0)
+    assert N.lib().mbls_keytable_append(rep[1], N.cbuf(pks[3]), 1, 1, 1, C.byref(f1), e1) == 0 and size(1) == 4
+    with pytest.raises(N.MblsError) as ei:
+        tab.append(b"".join(pks[4:6]), 2, pk_format=1, validate=True)
+    assert "disagree" in str(ei.value)
+    assert (size(0), size(1)) == (3, 4)          # both replicas are where they were before the failed call
+    tab.close(); m.close()
+
+
+@pytest.mark.usefixtures("engine")
 def test_multi_device_handle_matches_single_context_and_oracle(mb, N):
     """mbls_multi_* (device list + contiguous shards, one host thread per device) on the one GPU of this box with
     device_ids = {0, 0} and {0, 0, 0}: odd item counts, ragged key sets and ragged messages, byte keys and a replicated key table --

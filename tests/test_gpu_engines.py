@@ -1,0 +1,216 @@
+"""The one-lane-per-item kernels the headline number is measured on (k_hash, k_miller + k_sig_verdict, k_final) against the oracle at batch
+sizes where they are the default route, every routing boundary of the pipeline with the library's default settings, and the fuzz targets'
+invariant. One seeded batch of 20 480 items x 2 keys is signed and verified by the oracle once; the tests below verify prefixes of it.
+
+Routing (milagro_bls_amd/csrc/mbls_kernels.hip, verify_pipeline / launch_hash): n <= 768 hashg2 + pairing2, (768, 1024] hashg2x4 + pairing2,
+(1024, 2048] hashg2x4 + pairing2x2, (2048, 6144] hashg2x4 + pairing2, (6144, 10240] k_hash + pairing2, above 10240 k_hash + k_miller +
+k_sig_verdict + k_final with the signature's subgroup test fused into the Miller loop."""
+import random
+
+import pytest
+
+import helpers
+import orc
+
+pytestmark = pytest.mark.gpu
+
+N_BIG = 20480
+BOUNDARIES = [768, 769, 1024, 1025, 2048, 2049, 6144, 6145, 10240, 10241]
+FLAG = {"sig_not_in_g2": 0x02, "apk_infinity": 0x08, "bad_sig_bytes": 0x01, "bad_pk_bytes": 0x04, "flip_msg": 0x40, "wrong_key": 0x40}
+
+
+@pytest.fixture(scope="module")
+def mb():
+    from milagro_bls_amd import batch, _native
+    _native.default_context()
+    return batch
+
+
+@pytest.fixture(scope="module")
+def big():
+    """20 480 items x 2 uncompressed keys, every fourth item one of the seven rejection classes; the oracle's verdict for every item"""
+    import os
+    nt = min(32, os.cpu_count() or 8)
+    b = helpers.make_batch(N_BIG, 2, fmt=1, seed=4242, pool_n=64, nthreads=nt)
+    b.want = orc.batch_fast_aggregate_verify(b.sigs, b.msgs, b.pks, b.n, b.k, 1, nthreads=nt)
+    assert b.want == b.expect
+    assert set(b.kinds) == set(FLAG) | {"valid", "sig_infinity"}
+    return b
+
+
+def prefix(b, n):
+    return b.sigs[:96 * n], b.msgs[:32 * n], b.pks[:96 * b.k * n]
+
+
+def check(b, got, st, n):
+    assert got == b.want[:n]
+    for i in range(n):
+        f = FLAG.get(b.kinds[i])
+        if f:
+            assert st[i] & f, (i, b.kinds[i], st[i])
+        elif b.kinds[i] == "valid":
+            assert st[i] == 0, (i, st[i])
+
+
+@pytest.mark.parametrize("n", BOUNDARIES)
+def test_routing_boundaries_with_default_settings_vs_oracle(mb, big, n):
+    """either side of every crossover at which engine selection flips, default settings, every item compared with the oracle
+    (reference src/aggregates.rs:177-215: the same bool whatever the batch size)"""
+    from milagro_bls_amd import _native as N
+    ctx = N.default_context()
+    ctx.set_coop_max_items(10240); ctx.set_coop_hash_max_items(6144); ctx.set_coop_packing(1024, 2048, 768)
+    s, m, p = prefix(big, n)
+    got, st = mb.fast_aggregate_verify_batch(s, m, p, n, big.k, pk_format=1)
+    check(big, got, st, n)
+
+
+def test_lane_kernels_20k_items_vs_oracle(mb, big):
+    """the headline kernels (one lane per item; signature subgroup verdict out of the Miller loop) on 20 480 items, every one against the
+    oracle -- once forced (coop limits 0) and once as the default route of a batch this size; status words identical"""
+    from milagro_bls_amd import _native as N
+    ctx = N.default_context()
+    try:
+        ctx.set_coop_max_items(0); ctx.set_coop_hash_max_items(0)
+        got0, st0 = mb.fast_aggregate_verify_batch(big.sigs, big.msgs, big.pks, big.n, big.k, pk_format=1)
+    finally:
+        ctx.set_coop_max_items(10240); ctx.set_coop_hash_max_items(6144)
+    check(big, got0, st0, big.n)
+    got1, st1 = mb.fast_aggregate_verify_batch(big.sigs, big.msgs, big.pks, big.n, big.k, pk_format=1)
+    assert got1 == got0 and st1 == st0
+
+
+def test_lane_and_wave_engines_agree_item_by_item_on_status_words(mb, big):
+    """the first 4 096 items through both engines: identical accept bits AND identical status words (same rejection reason)"""
+    from milagro_bls_amd import _native as N
+    ctx = N.default_context()
+    n = 4096
+    s, m, p = prefix(big, n)
+    out = {}
+    try:
+        for name, lim in (("lanes", 0), ("waves", 1 << 20)):
+            ctx.set_coop_max_items(lim); ctx.set_coop_hash_max_items(lim)
+            out[name] = mb.fast_aggregate_verify_batch(s, m, p, n, big.k, pk_format=1)
+    finally:
+        ctx.set_coop_max_items(10240); ctx.set_coop_hash_max_items(6144)
+    assert out["lanes"] == out["waves"]
+    check(big, out["lanes"][0], out["lanes"][1], n)
+
+
+def test_tail_routing_above_one_round_of_lanes(mb, big):
+    """n = 65 536 + r: the library cuts the batch into a full round of one-lane kernels and a tail that takes the route of an r-item batch.
+    The oracle-checked 20 480 items are tiled (items are independent, src/aggregates.rs:177-215 keeps no state) to 65 537, 66 000 and 70 000
+    items; every item must come back with the oracle's verdict of its source item."""
+    for n in (65537, 66000, 70000):
+        reps = -(-n // big.n)
+        s = (big.sigs * reps)[:96 * n]; m = (big.msgs * reps)[:32 * n]; p = (big.pks * reps)[:96 * big.k * n]
+        got, st = mb.fast_aggregate_verify_batch(s, m, p, n, big.k, pk_format=1)
+        want = (big.want * reps)[:n]
+        assert got == want, n
+        assert all((x == 0) == w or not w for x, w in zip(st, want))
+
+
+def test_round_cut_with_small_rounds_every_layout(mb, big):
+    """the cut itself on small numbers (mbls_ctx_set_round_items(128)): n = 300 = two rounds + 44 items through the host entry (uniform
+    and ragged layouts, byte keys and table indices) and the device entry (bitmap words, caller's status array) -- against the oracle."""
+    import torch
+    from milagro_bls_amd import _native as N
+    ctx = N.default_context()
+    n = 300
+    s, m, p = prefix(big, n)
+    try:
+        ctx.set_round_items(128)
+        for lim in (10240, 0):                       # the remainder on waves / on lanes
+            ctx.set_coop_max_items(lim)
+            got, st = mb.fast_aggregate_verify_batch(s, m, p, n, big.k, pk_format=1)
+            check(big, got, st, n)
+        ctx.set_coop_max_items(10240)
+        # ragged: item i keeps its two keys, but through an offset table that starts at 5; messages through an offset table
+        koff = [5 + 2 * i for i in range(n + 1)]
+        moff = [32 * i for i in range(n + 1)]
+        got, st = mb.fast_aggregate_verify_batch(s, m, bytes(96 * 5) + p, n, pk_format=1, pk_offsets=koff, msg_offsets=moff)
+        check(big, got, st, n)
+        # table indices: the 2 n keys as a table, item i = entries (2 i, 2 i + 1)
+        tab = N.KeyTable(ctx, capacity_hint=2 * n)
+        first, errs = tab.append(p, 2 * n, pk_format=1, validate=False)
+        bad_keys = {2 * i for i in range(n) if big.kinds[i] == "bad_pk_bytes"}
+        assert first == 0 and {j for j, e in enumerate(errs) if e} == bad_keys
+        got, st = mb.fast_aggregate_verify_batch_indexed(tab, s, m, list(range(2 * n)), n, 2)
+        check(big, got, st, n)
+        # device entry with a bitmap
+        dev = torch.device("cuda:0")
+        t = lambda b: torch.frombuffer(bytearray(b), dtype=torch.uint8).to(dev)
+        d_s, d_m, d_p = t(s), t(m), t(p)
+        d_res = torch.full((n,), 9, dtype=torch.uint8, device=dev); d_bm = torch.zeros((n + 63) // 64, dtype=torch.int64, device=dev)
+        d_st = torch.full((n,), 0x7fffffff, dtype=torch.int32, device=dev)
+        ctx.check(N.lib().mbls_fast_aggregate_verify_batch_device(ctx.handle, d_s.data_ptr(), d_m.data_ptr(), 32, None, d_p.data_ptr(), 1, None, n, 2,
+                                                                  d_res.data_ptr(), d_bm.data_ptr(), d_st.data_ptr(), None))
+        torch.cuda.synchronize()
+        got = [bool(x) for x in d_res.cpu().tolist()]
+        check(big, got, [x & 0xffffffff for x in d_st.cpu().tolist()], n)
+        bits = [(int(w) >> b) & 1 for w in d_bm.cpu().tolist() for b in range(64)][:n]
+        assert bits == [int(x) for x in got]
+        tab.close()
+    finally:
+        ctx.set_round_items(0); ctx.set_coop_max_items(10240)
+
+
+def test_fuzz_invariant_accepted_encodings_reencode_to_themselves(mb):
+    """The reference's fuzz targets (fuzz/fuzz_targets/fuzz_serde_public_key.rs:5-10, fuzz_serde_signature.rs:5-10): from_bytes(data) is Ok
+    => as_bytes() == data. 4 096 G1 and 4 096 G2 blobs -- canonical field elements with random flag bits, fully random bytes, valid
+    encodings and single-bit mutations of them -- through decode and re-encode on the device; accept/reject classes against the oracle."""
+    rnd = random.Random(0xF022)
+    P = helpers.P
+    n = 4096
+    valid_pk = [orc.g1_compress(orc.sk_to_pk(rnd.randrange(1, helpers.R))) for _ in range(32)]
+    blobs = []
+    for i in range(n):
+        t = i % 4
+        if t == 0:                                   # x < p with random flags: about one in five decodes
+            b = bytearray(rnd.randrange(P).to_bytes(48, "big")); b[0] = (b[0] & 0x1F) | (rnd.randrange(8) << 5)
+        elif t == 1:
+            b = bytearray(rnd.randbytes(48))
+        elif t == 2:
+            b = bytearray(valid_pk[rnd.randrange(32)])
+        else:
+            b = bytearray(valid_pk[rnd.randrange(32)]); b[rnd.randrange(48)] ^= 1 << rnd.randrange(8)
+        blobs.append(bytes(b))
+    blobs[0] = bytes([0xC0]) + bytes(47)             # infinity
+    data = b"".join(blobs)
+    for validate in (False, True):
+        out96, errs = mb.pk_decode_batch(data, n, in_format=0, validate=validate)
+        ok = [i for i in range(n) if errs[i] == 0]
+        assert len(ok) > n // (4 if validate else 3)
+        back, e2 = mb.pk_compress_batch(b"".join(out96[96 * i:96 * i + 96] for i in ok), len(ok))
+        assert not any(e2)
+        assert all(back[48 * j:48 * j + 48] == blobs[i] for j, i in enumerate(ok)), validate
+        for i in range(0, n, 16):                    # the accept / reject class against the oracle on a subsample
+            e, pt = orc.g1_from_compressed(blobs[i])
+            good = e == 0 and (not validate or orc.g1_key_validate(pt))
+            assert (errs[i] == 0) == good, (i, validate)
+    # signatures: decode -> (one-member) aggregate -> compress
+    valid_sig = [orc.g2_compress(orc.sign(bytes([j]) * 32, rnd.randrange(1, helpers.R))) for j in range(16)]
+    blobs = []
+    for i in range(n):
+        t = i % 4
+        if t == 0:
+            b = bytearray(rnd.randrange(P).to_bytes(48, "big") + rnd.randrange(P).to_bytes(48, "big")); b[0] = (b[0] & 0x1F) | (rnd.randrange(8) << 5)
+        elif t == 1:
+            b = bytearray(rnd.randbytes(96))
+        elif t == 2:
+            b = bytearray(valid_sig[rnd.randrange(16)])
+        else:
+            b = bytearray(valid_sig[rnd.randrange(16)]); b[rnd.randrange(96)] ^= 1 << rnd.randrange(8)
+        blobs.append(bytes(b))
+    blobs[0] = helpers.G2_INF
+    data = b"".join(blobs)
+    errs, in_g2 = mb.sig_check_batch(data, n)
+    sums, e2 = mb.aggregate_signatures_batch(data, n, 1)
+    ok = [i for i in range(n) if errs[i] == 0]
+    assert len(ok) > n // 3
+    assert [x == 0 for x in e2] == [x == 0 for x in errs]
+    assert all(sums[96 * i:96 * i + 96] == blobs[i] for i in ok)
+    for i in range(0, n, 16):
+        e, pt = orc.g2_from_compressed(blobs[i])
+        assert (errs[i] == 0) == (e == 0), i
+        if e == 0:
+            assert in_g2[i] == orc.g2_subgroup_check(pt), i

@@ -88,6 +88,7 @@ def test_field_routines_structured_operands(mb):
     assert all(get(o, i) == pow(vals[i][1], (P - 3) // 4, P) for i in range(m))
 
 
+@pytest.mark.usefixtures("engine")
 def test_hash_to_g2_golden_and_oracle(mb, vectors):
     for v in vectors["model"]["hash_to_g2"]:
         m = helpers.expand_msg(v["msg"])
@@ -252,6 +253,7 @@ def test_signature_subgroup_verdict_out_of_the_miller_loop_vs_oracle(mb):
     assert got == [True, False] and st[0] == 0 and st[1] & 0x02
 
 
+@pytest.mark.usefixtures("engine")
 @pytest.mark.parametrize("fmt", [0, 1])
 def test_fast_aggregate_verify_batch_vs_oracle(mb, fmt):
     b = helpers.make_batch(96, 8, fmt=fmt, seed=40 + fmt)
@@ -264,6 +266,7 @@ def test_fast_aggregate_verify_batch_vs_oracle(mb, fmt):
             assert s & flag[kind], (kind, s)
 
 
+@pytest.mark.usefixtures("engine")
 def test_fast_aggregate_verify_128_keys_vs_oracle(mb):
     b = helpers.make_batch(192, 128, fmt=1, seed=50, pool_n=256)
     got, _ = mb.fast_aggregate_verify_batch(b.sigs, b.msgs, b.pks, b.n, b.k, pk_format=1)
@@ -273,6 +276,7 @@ def test_fast_aggregate_verify_128_keys_vs_oracle(mb):
     assert got == orc.batch_fast_aggregate_verify(b.sigs, b.msgs, b.pks, b.n, b.k, 0, nthreads=8) == b.expect
 
 
+@pytest.mark.usefixtures("engine")
 def test_golden_batch_and_edge_cases(mb, vectors):
     fb = vectors["model"]["fast_aggregate_verify_batch"]
     items = fb["items"]
@@ -296,6 +300,7 @@ def test_golden_batch_and_edge_cases(mb, vectors):
     assert mb.fast_aggregate_verify_batch(b.sigs, b.msgs, b.pks, b.n, b.k)[0] == b.expect
 
 
+@pytest.mark.usefixtures("engine")
 def test_verify_batch_vs_oracle(mb):
     b = helpers.make_batch(128, 1, fmt=0, seed=60)
     got, _ = mb.verify_batch(b.sigs, b.msgs, b.pks, b.n)
@@ -310,6 +315,7 @@ def test_aggregate_public_keys_vs_oracle(mb):
         assert apks[96 * i:96 * i + 96] == orc.aggregate_pks(keys)[1]
 
 
+@pytest.mark.usefixtures("engine")
 def test_differential_bit_flips_vs_oracle(mb):
     """Differential test in the spirit of the reference's fuzz targets (fuzz/fuzz_targets/*.rs): valid items with random
     single-bit flips anywhere in the signature, one key or the message; the accept bit must equal the oracle's for every item

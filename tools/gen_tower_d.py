@@ -2670,6 +2670,10 @@ def main():
     print("miller single pair: dbl", len(pieces["dbl"]), "lines", st["dbl"])
     sgm = '"s30","s31","s36","s37","s39","s40","s41","s42","s43","s44","s45","s46","s47","s48","s49","s54","s55","s56","s57","s58","s59","s60","s61","s62","s63","s64","s65","s66","s67","s73","s74","s75","s76","s77","s78","vcc","scc","memory"'
     fout = set(r for b in F_OUT for r in range(b, b + 12))
+    # what mbls_lanes.h (lane_sig_verdict) relies on: when the two-pair loop returns, pair 0's running point T = [|x|] Q_0 sits in these
+    # workspace slots (x.c0, x.c1, y.c0, y.c1, z.c0, z.c1) as packed words of the 2^392 domain, representatives in (0.5 p, 1.5 p)
+    txt += "#define MBLS_GEN_MILLER_T0_SLOT %d\n#define MBLS_GEN_MILLER_T_DOMAIN_BITS 392\n#define MBLS_GEN_MILLER_T_PACKED 1\n" % T_SLOT(0, 0, 0)
+    assert [T_SLOT(0, e, i) for e in range(3) for i in range(2)] == list(range(T_SLOT(0, 0, 0), T_SLOT(0, 0, 0) + 6))
     txt += "// the Miller-loop routine returns f in twelve register groups\n"
     txt += "#define MBLS_MILLER_D_OUT_REGS(x) " + ", ".join('"={v[%d:%d]}"(x##%d)' % (b, b + 11, i) for i, b in enumerate(F_OUT)) + "\n"
     txt += "#define MBLS_MILLER_D_ASM_CLOBBERS %s,%s, \\\n    %s\n" % (
