@@ -386,6 +386,10 @@ __global__ void MBLS_LB k_fp_mul_bench(uint32_t* sink, uint32_t iters, uint64_t 
 // mode 0: v_mad_u64_u32 with the carry-out alternating between VCC and SGPR pairs (what the multiplication routines issue);
 // mode 1: v_add_co / v_addc chains (the class every other integer instruction of the routines issues at).
 #define MBLS_REP4(x) x x x x
+#define MBLS_VB_V8(a) "v" #a "0", "v" #a "1", "v" #a "2", "v" #a "3", "v" #a "4", "v" #a "5", "v" #a "6", "v" #a "7", "v" #a "8", "v" #a "9"
+#define MBLS_VALU_BENCH_CLOBBERS "v0", "v1", "v2", "v3", "v4", "v5", "v6", "v7", "v8", "v9", MBLS_VB_V8(1), MBLS_VB_V8(2), MBLS_VB_V8(3), MBLS_VB_V8(4), MBLS_VB_V8(5), \
+    MBLS_VB_V8(6), MBLS_VB_V8(7), MBLS_VB_V8(8), MBLS_VB_V8(9), MBLS_VB_V8(10), MBLS_VB_V8(11), "v120", "v121", "v122", "v123", "v124", "v125", \
+    "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "vcc", "scc"
 #define MBLS_REP16(x) MBLS_REP4(MBLS_REP4(x))
 __global__ void __launch_bounds__(WG) k_valu_bench(uint32_t* sink, uint32_t iters, int mode) {
     uint32_t a = (threadIdx.x * 2654435761u + blockIdx.x) | 1u, b = a ^ 0x9e3779b9u;
@@ -396,6 +400,12 @@ __global__ void __launch_bounds__(WG) k_valu_bench(uint32_t* sink, uint32_t iter
             MBLS_REP16(asm volatile("v_mad_u64_u32 %0, vcc, %8, %9, %0\n v_mad_u64_u32 %1, s[20:21], %8, %9, %1\n v_mad_u64_u32 %2, vcc, %8, %9, %2\n v_mad_u64_u32 %3, s[22:23], %8, %9, %3\n"
                                     "v_mad_u64_u32 %4, vcc, %8, %9, %4\n v_mad_u64_u32 %5, s[20:21], %8, %9, %5\n v_mad_u64_u32 %6, vcc, %8, %9, %6\n v_mad_u64_u32 %7, s[22:23], %8, %9, %7\n"
                                     : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3), "+v"(c4), "+v"(c5), "+v"(c6), "+v"(c7) : "v"(a), "v"(b) : "vcc", "s20", "s21", "s22", "s23");)
+        } else if (mode == 2) {
+#if MBLS_DEVICE_ASM
+            // the Fp2 product routine itself, eight times back to back (8 x 1 281 instructions, 980 of them multiply-accumulates): what a kernel
+            // made of nothing but products would issue at -- the reference the generated kernels' rates are quoted against
+            MBLS_REP4(asm volatile(MBLS_FP2_MUL_D_ASM MBLS_FP2_MUL_D_ASM ::: MBLS_VALU_BENCH_CLOBBERS);)
+#endif
         } else {
             MBLS_REP16(asm volatile("v_add_co_u32_e64 %0, vcc, %4, %0\n v_add_co_u32_e64 %2, s[20:21], %5, %2\n v_addc_co_u32_e64 %1, vcc, %5, %1, vcc\n v_addc_co_u32_e64 %3, s[20:21], %4, %3, s[20:21]\n"
                                     "v_add_co_u32_e64 %0, vcc, %5, %0\n v_add_co_u32_e64 %2, s[20:21], %4, %2\n v_addc_co_u32_e64 %1, vcc, %4, %1, vcc\n v_addc_co_u32_e64 %3, s[20:21], %5, %3, s[20:21]\n"
@@ -1241,7 +1251,7 @@ extern "C" int mbls_fp_mul_bench(mbls_ctx* c, uint64_t n_lanes, uint32_t iters, 
 }
 
 extern "C" int mbls_valu_bench(mbls_ctx* c, int mode, uint32_t waves_per_simd, uint32_t iters, float* ms_out) {
-    if (!c || !ms_out || !waves_per_simd || waves_per_simd > 8 || (mode != 0 && mode != 1)) return MBLS_ERR_ARGUMENT;
+    if (!c || !ms_out || !waves_per_simd || waves_per_simd > 8 || mode < 0 || mode > 2) return MBLS_ERR_ARGUMENT;
     mbls_lock lk(c->mu);
     HIPCHK(c, hipSetDevice(c->device));
     hipDeviceProp_t prop; HIPCHK(c, hipGetDeviceProperties(&prop, c->device));

@@ -80,3 +80,44 @@ def test_single_rank_paths_need_no_process_group():
     n = []
     assert bench.timed_steps(lambda: n.append(1), 4, 1, 1, lambda: None) >= 0 and len(n) == 5
     assert bench.reduce_max(1.5, 1) == 1.5 and bench.reduce_all_ok(True, 1) is True
+
+
+def _bench(*argv, env=None):
+    import json, subprocess, sys
+    e = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        e.pop(k, None)
+    e.update(env or {})
+    r = subprocess.run([sys.executable, os.path.join(helpers.ROOT, "bench.py")] + list(argv), env=e, capture_output=True, text=True, timeout=600)
+    lines = []
+    for l in r.stdout.splitlines():
+        try:
+            lines.append(json.loads(l))
+        except ValueError:
+            pass
+    return r.returncode, lines, r.stderr
+
+
+def test_gpus_flag_without_a_launcher_spawns_the_ranks():
+    """`python bench.py --gpus 2` with no torchrun around it: the parent starts two rank processes itself (before touching any GPU) and relays
+    rank 0's line -- n_gpus = 2, one ms_per_step per rank (the stub's ranks sleep 5 and 10 ms a step, the job time is the slower one's)."""
+    rc, lines, err = _bench("--gpus", "2", "--steps", "3", "--warmup", "1", "--stub")
+    assert rc == 0, err
+    assert len(lines) == 1
+    d = lines[0]
+    assert d["n_gpus"] == 2 and d["stub"] is True and d["bitmap_matches_expectation"] is True
+    assert len(d["ms_per_step_per_rank"]) == 2 and d["ms_per_step_per_rank"][1] >= d["ms_per_step_per_rank"][0] * 0.9
+    assert d["ms_per_step"] >= 10.0 * 0.9 and d["ms_per_step"] >= max(d["ms_per_step_per_rank"]) * 0.95
+
+
+def test_a_failing_rank_or_a_wrong_world_size_is_an_error_exit_not_a_one_gpu_line():
+    rc, lines, err = _bench("--gpus", "2", "--steps", "2", "--warmup", "0", "--stub", env={"MBLS_STUB_FAIL_RANK": "1"})
+    assert rc == 3 and (not lines or lines[0]["bitmap_matches_expectation"] is False)
+    # a launcher that started a different number of ranks than --gpus says
+    rc, lines, err = _bench("--gpus", "4", "--stub", env={"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"})
+    assert rc == 5 and not lines and "WORLD_SIZE" in err
+    # more GPUs asked for than the machine has (no GPU here): refused before anything is started
+    import torch
+    if torch.cuda.device_count() < 2:
+        rc, lines, err = _bench("--gpus", "2")
+        assert rc == 4 and not lines and "visible" in err
