@@ -157,10 +157,39 @@ __global__ void MBLS_LB k_miller(mbls_ws ws, uint64_t n) {
     lane_miller(ws, i, (MBLS_LDS uint32_t*)tstore, threadIdx.x, true);
 }
 // between k_miller and k_final when k_sig only decoded: the signature's subgroup test from the loop's running point (lane_sig_verdict)
-__global__ void MBLS_LB k_sig_verdict(mbls_ws ws, uint32_t* status, uint64_t n) {
+__global__ void MBLS_LB k_sig_verdict(mbls_ws ws, uint32_t* status, uint64_t n, uint64_t t_item_offset, int t_pair) {
     uint64_t i = gid(); if (i >= n) return;
-    const uint32_t st = lane_sig_verdict(ws, i);
+    const uint32_t st = lane_sig_verdict(ws, i, i + t_item_offset, t_pair);
     if (st) status[i] |= st;
+}
+// Batches that fill at most half of the SIMDs (2 n <= one round): the two pairs of item i on TWO lanes -- lane i walks (H_i, apk_i), lane n + i
+// walks (sig_i, -G1) -- each with the generated one-pair loop (6.6 ms instead of 11.3 for the two-pair loop), workspace item = lane. The
+// product f_i f_(n+i) is one level of the generated product tree (k_f12_tree_d(2 n, n)), and the signature's subgroup verdict reads the running
+// point of lane n + i (k_sig_verdict with t_item_offset = n, t_pair = 1): the one-pair routine walks the same bits of |x| with the same
+// incomplete formulas (Q in homogeneous form with Z = 1), so it ends with [|x|] sig exactly like pair 0 of the two-pair loop.
+__global__ void MBLS_LB k_miller_split(mbls_ws ws, uint64_t n) {
+    __shared__ uint32_t spill[154 * 64];
+    uint64_t t = gid(); if (t >= 2 * n) return;
+    const bool sigpair = t >= n;                                   // branch-free operand selection: the routine is called from uniform control flow
+    const uint64_t i = sigpair ? t - n : t;
+    g2j h; h.x = ws_ld2(ws, MBLS_SLOT_H, i); h.y = ws_ld2(ws, MBLS_SLOT_H + 2, i); h.z = ws_ld2(ws, MBLS_SLOT_H + 4, i);
+    g1j a; a.x = ws_ld(ws, MBLS_SLOT_APK, i); a.y = ws_ld(ws, MBLS_SLOT_APK + 1, i); a.z = ws_ld(ws, MBLS_SLOT_APK + 2, i);
+    const fp2 sx = ws_ld2(ws, MBLS_SLOT_SIG, i), sy = ws_ld2(ws, MBLS_SLOT_SIG + 2, i);
+    mbls_pair pr, ps;
+    pr.skip = g2_is_inf(&h) | g1_is_inf(&a);
+    g2h_from_jacobian(&pr.q, &h); g1arg_from_jacobian(&pr.p, &a);
+    ps.skip = fp2_is_zero(sy);
+    g2h_from_affine(&ps.q, sx, sy); g1arg_from_affine(&ps.p, fp_load_const(MBLS_G1_X), fp_load_const(MBLS_G1_NEG_Y));
+    pr.skip = sigpair ? ps.skip : pr.skip;
+    pr.q.x = fp2_select(sigpair, ps.q.x, pr.q.x); pr.q.y = fp2_select(sigpair, ps.q.y, pr.q.y); pr.q.z = fp2_select(sigpair, ps.q.z, pr.q.z);
+    pr.p.px = fp_select(sigpair, ps.p.px, pr.p.px); pr.p.py = fp_select(sigpair, ps.p.py, pr.p.py); pr.p.pz3 = fp_select(sigpair, ps.p.pz3, pr.p.pz3);
+    pr.t = pr.q;
+    fp12 f;
+#if MBLS_DEVICE_ASM
+    miller_loop_single_d(&f, &pr, ws.w, ws.stride, t, (MBLS_LDS uint32_t*)spill, threadIdx.x);
+#endif
+    const fp2* c = &f.c0.c0;
+    for (int s = 0; s < 6; s++) ws_st2(ws, MBLS_SLOT_F + 2 * s, t, c[s]);
 }
 __global__ void MBLS_LB k_final(mbls_ws ws, uint32_t* status, uint8_t* results, uint64_t n) {
     __shared__ uint32_t accstore[154 * 64];       // spill slots of the generated exponentiation routine / the Fp12 parked by the one-shot products
@@ -454,6 +483,9 @@ struct mbls_ctx {
     // one ROUND of the one-lane kernels = one wave on every SIMD (512 registers per lane: one wave per SIMD) = CUs x 4 x 64 items. A batch of
     // q rounds + r items would cost q + 1 rounds of every kernel; the r items are cut off and take the route of an r-item batch instead
     uint64_t round_items = 65536;
+    // batches of at most split_max_items items (default: half a round) on the one-lane path walk their two Miller pairs on two lanes (k_miller_split);
+    // up to fork_max_items items the three front phases (keys | signature | message) run side by side on the context's streams
+    uint64_t split_max_items = 32768, fork_max_items = 65535;
     char err[256] = {};
 };
 struct mbls_keytable {
@@ -575,6 +607,11 @@ extern "C" int mbls_ctx_create(mbls_ctx** out, int device_id) {
         if (e) c->coop_hash_max_items = strtoull(e, nullptr, 10);
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0) c->round_items = (uint64_t)prop.multiProcessorCount * 4 * WG;
+        c->split_max_items = c->round_items / 2; c->fork_max_items = c->round_items - 1;
+        e = getenv("MBLS_SPLIT_MAX_ITEMS");
+        if (e) c->split_max_items = strtoull(e, nullptr, 10);
+        e = getenv("MBLS_FORK_MAX_ITEMS");
+        if (e) c->fork_max_items = strtoull(e, nullptr, 10);
     }
     if (!ok) { ctx_free(c); return MBLS_ERR_DEVICE; }
     *out = c; return MBLS_OK;
@@ -601,7 +638,15 @@ extern "C" int mbls_ctx_set_round_items(mbls_ctx* c, uint64_t items) {
         HIPCHK(c, hipGetDeviceProperties(&prop, c->device));
         items = (uint64_t)prop.multiProcessorCount * 4 * WG;
     }
-    c->round_items = items; return MBLS_OK;
+    c->round_items = items; c->split_max_items = items / 2; c->fork_max_items = items - 1; return MBLS_OK;
+}
+// one-lane path: batches of up to split_max_items items walk their two Miller pairs on two lanes (never above half a round); up to
+// fork_max_items items the three front phases run side by side. Defaults: round / 2 and round - 1; 0 = never.
+extern "C" int mbls_ctx_set_lane_shaping(mbls_ctx* c, uint64_t split_max_items, uint64_t fork_max_items) {
+    if (!c) return MBLS_ERR_ARGUMENT;
+    mbls_lock lk(c->mu);
+    c->split_max_items = split_max_items > c->round_items / 2 ? c->round_items / 2 : split_max_items;
+    c->fork_max_items = fork_max_items; return MBLS_OK;
 }
 extern "C" void mbls_ctx_destroy(mbls_ctx* c) {
     if (!c) return;
@@ -701,7 +746,8 @@ static int verify_pipeline_one(mbls_ctx* c, const uint8_t* d_sigs, const uint8_t
     const bool have_keys = ks.indexed ? (ks.d_idx != nullptr) : (ks.d_pks != nullptr);
     if (!d_sigs || (!d_msgs && msg_len && !d_moff) || !d_results || (!have_keys && (k || d_off) && part != 1)) ARGFAIL(c, "null buffer");
     HIPCHK(c, hipSetDevice(c->device));
-    int rc = mbls_ctx_reserve(c, n); if (rc) return rc;
+    const bool split = n > c->coop_max_items && n <= c->split_max_items && 2 * n <= c->round_items;     // two lanes per item in the Miller phase
+    int rc = mbls_ctx_reserve(c, split ? 2 * n : n); if (rc) return rc;
     mbls_ws ws; ws.w = c->d_w; ws.stride = c->cap;
     uint32_t* st = d_status ? d_status : c->d_status;
     unsigned g = nblk(n);
@@ -715,7 +761,7 @@ static int verify_pipeline_one(mbls_ctx* c, const uint8_t* d_sigs, const uint8_t
     // null), the caller then uploads the keys on another stream and makes this one wait, and part 2 queues the rest.
     const bool keys_later = part != 0;
     const bool fused_sig = n > c->coop_max_items;     // one lane per item: the subgroup test of the signature comes out of the Miller loop, k_sig only decodes
-    const bool fork = !tm && n <= 16384;
+    const bool fork = !tm && n <= c->fork_max_items;
     // (host-buffer entries: hs_b carries the key upload, so their signature phase has a stream of its own)
     hipStream_t s_sig = fork ? (part == 0 ? c->hs_b : c->hs_d) : s, s_msg = fork ? c->hs_c : s;
     if (part != 2) {
@@ -756,8 +802,14 @@ static int verify_pipeline_one(mbls_ctx* c, const uint8_t* d_sigs, const uint8_t
         coop_run(c, (n > c->coop_pack_min_items && n <= c->coop_pack_max_items) ? COOP_PAIRING2X2 : COOP_PAIRING2, ws, (uint64_t)0, (uint64_t)1, (uint64_t)0, n, st, d_results, COOP_RES_ITEM, s);
         if (tm) { HIPCHK(c, hipEventRecord(c->ev[4], s)); HIPCHK(c, hipEventRecord(c->ev[5], s)); }
     } else {
-        hipLaunchKernelGGL(k_miller, dim3(g), dim3(WG), 0, s, ws, n);
-        if (fused_sig) hipLaunchKernelGGL(k_sig_verdict, dim3(g), dim3(WG), 0, s, ws, st, n);
+        if (split) {
+            hipLaunchKernelGGL(k_miller_split, dim3(nblk(2 * n)), dim3(WG), 0, s, ws, n);
+            hipLaunchKernelGGL(k_f12_tree_d, dim3(g), dim3(WG), 0, s, ws, 2 * n, n);
+            hipLaunchKernelGGL(k_sig_verdict, dim3(g), dim3(WG), 0, s, ws, st, n, n, 1);
+        } else {
+            hipLaunchKernelGGL(k_miller, dim3(g), dim3(WG), 0, s, ws, n);
+            if (fused_sig) hipLaunchKernelGGL(k_sig_verdict, dim3(g), dim3(WG), 0, s, ws, st, n, (uint64_t)0, 0);
+        }
         if (tm) HIPCHK(c, hipEventRecord(c->ev[4], s));
         hipLaunchKernelGGL(k_final, dim3(g), dim3(WG), 0, s, ws, st, d_results, n);
         if (tm) HIPCHK(c, hipEventRecord(c->ev[5], s));

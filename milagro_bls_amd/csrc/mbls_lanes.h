@@ -336,18 +336,20 @@ MBLS_FN void lane_miller(const mbls_ws& ws, uint64_t i, MBLS_LDS uint32_t* tstor
 // loop ends it IS [|x|] sig (homogeneous X : Y : Z, workspace slots 31..36): sig is in G2 iff psi(sig) = -T. A signature outside G2 may drive
 // the loop's incomplete additions through T = +-sig or T = O (its order then divides a prefix of |x| or a neighbour): every such case ends with
 // Z = 0, which is a rejection, and cannot happen for a point of order r. Infinity passes, as in subgroup_check_g2 (reference src/signature.rs:29-31).
-MBLS_FN uint32_t lane_sig_verdict(const mbls_ws& ws, uint64_t i) {
+// t_item / t_pair: where the loop left the point -- the two-pair loop in pair 0's slots of the item itself; the split form (k_miller_split: the
+// signature's pair on a lane of its own, walked by the one-pair routine) in pair 1's slots of item t_item.
+MBLS_FN uint32_t lane_sig_verdict(const mbls_ws& ws, uint64_t i, uint64_t t_item, int t_pair) {
     const fp2 qx = ws_ld2(ws, MBLS_SLOT_SIG, i), qy = ws_ld2(ws, MBLS_SLOT_SIG + 2, i);
     // the running point as the loop leaves it: packed words, representatives in (0.5 p, 1.5 p) of the 2^392-domain values -- read as
     // 2^384-domain values they are 2^8 X, 2^8 Y, 2^8 Z: the same projective point
 #if MBLS_DEVICE_ASM
     // the generator says where it left the point and in which form (tools/gen_tower_d.py emits these next to the routine)
     static_assert(MBLS_GEN_MILLER_T_DOMAIN_BITS == 392 && MBLS_GEN_MILLER_T_PACKED == 1, "lane_sig_verdict reads packed 2^392-domain words");
-    const int T0 = MBLS_GEN_MILLER_T0_SLOT;
+    const int T0 = MBLS_GEN_MILLER_T0_SLOT + 6 * t_pair;
 #else
-    const int T0 = 31;
+    const int T0 = 31 + 6 * t_pair;
 #endif
-    fp2 X = ws_ld2(ws, T0, i), Y = ws_ld2(ws, T0 + 2, i), Z = ws_ld2(ws, T0 + 4, i);
+    fp2 X = ws_ld2(ws, T0, t_item), Y = ws_ld2(ws, T0 + 2, t_item), Z = ws_ld2(ws, T0 + 4, t_item);
     X.c0 = fp_reduce_once(X.c0, 0); X.c1 = fp_reduce_once(X.c1, 0); Y.c0 = fp_reduce_once(Y.c0, 0); Y.c1 = fp_reduce_once(Y.c1, 0);
     Z.c0 = fp_reduce_once(Z.c0, 0); Z.c1 = fp_reduce_once(Z.c1, 0);
     const fp2 px = fp2_mul(fp2_conj(qx), fp2_load_const(MBLS_PSI_CX)), py = fp2_mul(fp2_conj(qy), fp2_load_const(MBLS_PSI_CY));     // psi(sig), affine (g2_psi)

@@ -25,24 +25,29 @@ def emul():
     return helpers.load_emulator()
 
 
-COOP_ENV = ("MBLS_COOP_MAX_ITEMS", "MBLS_COOP_HASH_MAX_ITEMS")
+COOP_ENV = ("MBLS_COOP_MAX_ITEMS", "MBLS_COOP_HASH_MAX_ITEMS", "MBLS_SPLIT_MAX_ITEMS")
 
 
-@pytest.fixture(params=["waves", "lanes"])
+@pytest.fixture(params=["waves", "lanes", "lanes2pair"])
 def engine(request):
     """Every GPU test that compares with the oracle or the golden file runs once per engine:
     'waves' = the library's defaults (small batches take the cooperative one-wave-per-item programs, mbls_coop.h);
-    'lanes' = every batch forced onto the one-lane-per-item kernels that the headline number is measured on (k_hash, k_miller +
-    k_sig_verdict -- the signature's subgroup test read off the Miller loop --, k_final): mbls_ctx_set_coop_max_items(0) +
-    mbls_ctx_set_coop_hash_max_items(0) on the default context, and the same through the environment for contexts the test
-    creates itself (mbls_ctx_create reads it; mbls_multi_create makes its contexts that way)."""
+    'lanes' = every batch forced onto the one-lane-per-item kernels (k_hash, k_miller*, k_sig_verdict -- the signature's subgroup test read
+    off the Miller loop --, k_final) in the form a batch below half a round takes by default: the two pairs of an item on two lanes
+    (k_miller_split); 'lanes2pair' = the same with the two-pair loop k_miller, the kernel the headline number is measured on:
+    mbls_ctx_set_coop_max_items(0) + mbls_ctx_set_coop_hash_max_items(0) (+ mbls_ctx_set_lane_shaping(0, ...)) on the default context, and
+    the same through the environment for contexts the test creates itself (mbls_ctx_create reads it; mbls_multi_create makes its contexts
+    that way)."""
     from milagro_bls_amd import _native
     ctx = _native.default_context()
     old = {k: os.environ.get(k) for k in COOP_ENV}
-    if request.param == "lanes":
-        for k in COOP_ENV:
+    if request.param != "waves":
+        for k in COOP_ENV[:2]:
             os.environ[k] = "0"
         ctx.set_coop_max_items(0); ctx.set_coop_hash_max_items(0)
+    if request.param == "lanes2pair":
+        os.environ[COOP_ENV[2]] = "0"
+        ctx.set_lane_shaping(0, (1 << 64) - 1)
     try:
         yield request.param
     finally:
@@ -51,4 +56,4 @@ def engine(request):
                 os.environ.pop(k, None)
             else:
                 os.environ[k] = v
-        ctx.set_coop_max_items(10240); ctx.set_coop_hash_max_items(6144)
+        ctx.set_coop_max_items(10240); ctx.set_coop_hash_max_items(6144); ctx.set_round_items(0)       # (restores the lane shaping too)

@@ -290,12 +290,13 @@ def miller_machine(masks_bits):
     return m
 
 
-@pytest.mark.parametrize("which", ["dbl", 0, 1])
+@pytest.mark.parametrize("which", ["dbl", "first", "add01", 0, 1])
 def test_miller_bodies(which):
-    """one doubling iteration / one addition step per pair from random state at the edges of the declared bounds, with and without skipped pairs"""
+    """one doubling iteration / the first iteration (f = 1) / the addition steps (both pairs in one body, one pair each) from random state at the
+    edges of the declared bounds, with and without skipped pairs"""
     rng = random.Random(11)
     body, _ = t.build_miller(which)
-    progf = t.prog_miller_dbl_d if which == "dbl" else (lambda: t.prog_miller_add_d(which))
+    progf = lambda: t.prog_miller(which)
     for trial in range(3):
         masks = {"s[48:49]": 1 if trial == 1 else 0, "s[54:55]": 1 if trial == 2 else 0}
         m = miller_machine(0); m.run(t.shell_constants())
@@ -349,12 +350,18 @@ def miller_loop_sim(runs, seed, masks_bits=0, pairs=(0, 1), q0=None):
         for loc, x in mp.out_home.items():
             f[loc[1]] = x
         T.update(mp.out_g)
+    # the routine's control flow: the first iteration (f = 1: the lines are f), then per phase the addition step(s) and the next run of doublings
+    assert runs[0] == 1
+    add_name = "add01" if len(pairs) == 2 else "add1"
+    assert set(pieces) == {"pro", "first", "dbl", add_name, "epi"}
     for ph, n in enumerate(runs):
-        for _ in range(n):
-            m.run(pieces["dbl"]); step(lambda: t.prog_miller_dbl_d(pairs))
+        for it in range(n):
+            if ph == 0:
+                m.run(pieces["first"]); step(lambda: t.prog_miller("first", pairs))
+            else:
+                m.run(pieces["dbl"]); step(lambda: t.prog_miller("dbl", pairs))
         if ph < len(runs) - 1:
-            for k in pairs:
-                m.run(pieces["add%d" % k]); step(lambda k=k: t.prog_miller_add_d(k))
+            m.run(pieces[add_name]); step(lambda: t.prog_miller(add_name if len(pairs) == 2 else 1, pairs))
     m.run(pieces["epi"][:-1])
     for i in range(12):
         assert from_limbs(m.v[t.F_OUT[i]:t.F_OUT[i] + 12]) == f[i] * R384 % P, ("f", i)
@@ -372,10 +379,13 @@ def test_miller_loop_routine_short_schedules():
     the schedule of the real loop is the same sequence with runs of 1, 2, 3, 9, 32 and 16 iterations"""
     assert t.RUNS == [1, 2, 3, 9, 32, 16] and sum(t.RUNS) == 63
     miller_loop_sim([1, 2, 1], 5)
-    miller_loop_sim([2, 1], 6, masks_bits=1)          # pair 0 contributes 1 (infinite signature)
+    miller_loop_sim([1, 1], 6, masks_bits=1)          # pair 0 contributes 1 (infinite signature)
     miller_loop_sim([1, 1], 7, masks_bits=2)
-    miller_loop_sim([2, 1, 1], 8, pairs=(1,))           # the single-pair routine of the n-pairing paths
+    miller_loop_sim([1, 1, 1], 8, pairs=(1,))           # the single-pair routine of the n-pairing paths
     miller_loop_sim([1, 1], 9, masks_bits=2, pairs=(1,))
+    # the shell around the bodies: one forward exit, every far jump backwards, the phase counter picks RUNS[1..5]
+    full, pieces, _ = t.miller_loop_d_routine()
+    assert sum(1 for l in full if l.startswith("s_setpc_b64")) == 2 and "5:" in full and "4:" not in full
 
 
 def test_g2_doubling_runs():

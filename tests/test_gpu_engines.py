@@ -3,8 +3,9 @@ sizes where they are the default route, every routing boundary of the pipeline w
 invariant. One seeded batch of 20 480 items x 2 keys is signed and verified by the oracle once; the tests below verify prefixes of it.
 
 Routing (milagro_bls_amd/csrc/mbls_kernels.hip, verify_pipeline / launch_hash): n <= 768 hashg2 + pairing2, (768, 1024] hashg2x4 + pairing2,
-(1024, 2048] hashg2x4 + pairing2x2, (2048, 6144] hashg2x4 + pairing2, (6144, 10240] k_hash + pairing2, above 10240 k_hash + k_miller +
-k_sig_verdict + k_final with the signature's subgroup test fused into the Miller loop."""
+(1024, 2048] hashg2x4 + pairing2x2, (2048, 6144] hashg2x4 + pairing2, (6144, 10240] k_hash + pairing2, (10240, 32768] k_hash + k_miller_split (the two pairs of an item on two lanes) + product + k_sig_verdict + k_final,
+above 32768 k_hash + k_miller (two-pair loop) + k_sig_verdict + k_final; in both lane forms the signature's subgroup test is read off the
+Miller loop's running point. Above a round (65 536 items) the remainder is routed as a batch of its own."""
 import random
 
 import pytest
@@ -39,26 +40,32 @@ def big():
 
 
 def prefix(b, n):
-    return b.sigs[:96 * n], b.msgs[:32 * n], b.pks[:96 * b.k * n]
+    """the first n items (tiled beyond the batch: items are independent, reference src/aggregates.rs:177-215 keeps no state between calls)"""
+    reps = -(-n // b.n)
+    if reps == 1:
+        return b.sigs[:96 * n], b.msgs[:32 * n], b.pks[:96 * b.k * n]
+    return (b.sigs * reps)[:96 * n], (b.msgs * reps)[:32 * n], (b.pks * reps)[:96 * b.k * n]
 
 
 def check(b, got, st, n):
-    assert got == b.want[:n]
+    reps = -(-n // b.n)
+    assert got == (b.want * reps)[:n]
     for i in range(n):
-        f = FLAG.get(b.kinds[i])
+        kind = b.kinds[i % b.n]
+        f = FLAG.get(kind)
         if f:
-            assert st[i] & f, (i, b.kinds[i], st[i])
-        elif b.kinds[i] == "valid":
+            assert st[i] & f, (i, kind, st[i])
+        elif kind == "valid":
             assert st[i] == 0, (i, st[i])
 
 
-@pytest.mark.parametrize("n", BOUNDARIES)
+@pytest.mark.parametrize("n", BOUNDARIES + [32768, 32769])
 def test_routing_boundaries_with_default_settings_vs_oracle(mb, big, n):
     """either side of every crossover at which engine selection flips, default settings, every item compared with the oracle
     (reference src/aggregates.rs:177-215: the same bool whatever the batch size)"""
     from milagro_bls_amd import _native as N
     ctx = N.default_context()
-    ctx.set_coop_max_items(10240); ctx.set_coop_hash_max_items(6144); ctx.set_coop_packing(1024, 2048, 768)
+    ctx.set_coop_max_items(10240); ctx.set_coop_hash_max_items(6144); ctx.set_coop_packing(1024, 2048, 768); ctx.set_round_items(0)
     s, m, p = prefix(big, n)
     got, st = mb.fast_aggregate_verify_batch(s, m, p, n, big.k, pk_format=1)
     check(big, got, st, n)
@@ -66,14 +73,15 @@ def test_routing_boundaries_with_default_settings_vs_oracle(mb, big, n):
 
 def test_lane_kernels_20k_items_vs_oracle(mb, big):
     """the headline kernels (one lane per item; signature subgroup verdict out of the Miller loop) on 20 480 items, every one against the
-    oracle -- once forced (coop limits 0) and once as the default route of a batch this size; status words identical"""
+    oracle: the two-pair loop k_miller forced (lane shaping off, front phases one after the other -- the shape of a full round), then the
+    default route of a batch this size (two lanes per item in the Miller phase, front phases side by side); status words identical"""
     from milagro_bls_amd import _native as N
     ctx = N.default_context()
     try:
-        ctx.set_coop_max_items(0); ctx.set_coop_hash_max_items(0)
+        ctx.set_coop_max_items(0); ctx.set_coop_hash_max_items(0); ctx.set_lane_shaping(0, 0)
         got0, st0 = mb.fast_aggregate_verify_batch(big.sigs, big.msgs, big.pks, big.n, big.k, pk_format=1)
     finally:
-        ctx.set_coop_max_items(10240); ctx.set_coop_hash_max_items(6144)
+        ctx.set_coop_max_items(10240); ctx.set_coop_hash_max_items(6144); ctx.set_round_items(0)
     check(big, got0, st0, big.n)
     got1, st1 = mb.fast_aggregate_verify_batch(big.sigs, big.msgs, big.pks, big.n, big.k, pk_format=1)
     assert got1 == got0 and st1 == st0
@@ -100,13 +108,10 @@ def test_tail_routing_above_one_round_of_lanes(mb, big):
     """n = 65 536 + r: the library cuts the batch into a full round of one-lane kernels and a tail that takes the route of an r-item batch.
     The oracle-checked 20 480 items are tiled (items are independent, src/aggregates.rs:177-215 keeps no state) to 65 537, 66 000 and 70 000
     items; every item must come back with the oracle's verdict of its source item."""
-    for n in (65537, 66000, 70000):
-        reps = -(-n // big.n)
-        s = (big.sigs * reps)[:96 * n]; m = (big.msgs * reps)[:32 * n]; p = (big.pks * reps)[:96 * big.k * n]
+    for n in (65537, 66000, 70000, 80000):           # remainders on one wave per item (1, 464, 4 464) and on two lanes per item (14 464)
+        s, m, p = prefix(big, n)
         got, st = mb.fast_aggregate_verify_batch(s, m, p, n, big.k, pk_format=1)
-        want = (big.want * reps)[:n]
-        assert got == want, n
-        assert all((x == 0) == w or not w for x, w in zip(st, want))
+        check(big, got, st, n)
 
 
 def test_round_cut_with_small_rounds_every_layout(mb, big):

@@ -234,23 +234,24 @@ def test_signature_subgroup_verdict_out_of_the_miller_loop_vs_oracle(mb):
     want = orc.batch_verify(b"".join(sigs), msgs, orc.g1_compress(pk) * n, n, nthreads=8)
     assert not any(want)
     try:
-        for lim in (0, 1 << 20):
-            ctx.set_coop_max_items(lim)
+        for lim, split in ((0, 0), (0, 1 << 20), (1 << 20, 0)):       # two-pair loop / the two pairs on two lanes / one wave per item
+            ctx.set_coop_max_items(lim); ctx.set_lane_shaping(split, (1 << 64) - 1)
             got, st = mb.verify_batch(b"".join(sigs), msgs, pk * n, n, pk_format=1)
-            assert got == want, lim
-            assert [(x & 0x02) == 0 for x in st] == want_in, lim
+            assert got == want, (lim, split)
+            assert [(x & 0x02) == 0 for x in st] == want_in, (lim, split)
     finally:
-        ctx.set_coop_max_items(10240)
+        ctx.set_coop_max_items(10240); ctx.set_round_items(0)
     # a real signature next to them still verifies on the one-lane path, and the same signature shifted by a point of order 13 does not
     sk = 777; msg = b"m" * 32
     good = orc.g2_compress(orc.sign(msg, sk))
     shifted = M.g2_compress(M.g2_add(M.g2_decompress(good)[1], pts[0]))
-    try:
-        ctx.set_coop_max_items(0)
-        got, st = mb.verify_batch(good + shifted, msg * 2, orc.sk_to_pk(sk) * 2, 2, pk_format=1)
-    finally:
-        ctx.set_coop_max_items(10240)
-    assert got == [True, False] and st[0] == 0 and st[1] & 0x02
+    for split in (0, 1 << 20):
+        try:
+            ctx.set_coop_max_items(0); ctx.set_lane_shaping(split, (1 << 64) - 1)
+            got, st = mb.verify_batch(good + shifted, msg * 2, orc.sk_to_pk(sk) * 2, 2, pk_format=1)
+        finally:
+            ctx.set_coop_max_items(10240); ctx.set_round_items(0)
+        assert got == [True, False] and st[0] == 0 and st[1] & 0x02
 
 
 @pytest.mark.usefixtures("engine")

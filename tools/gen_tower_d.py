@@ -1313,58 +1313,52 @@ def f_store(p, f):
         p.store(prog_norm(p, v), h)
 
 
-def prog_miller_dbl_d(pairs=(0, 1)):
-    """One doubling iteration of the Miller loop for the two pairs of a verification (or, pairs = (1,), for a single general pair): f <- f^2, then for each pair T <- 2T and f <- f * line
-    (formulas of miller_dbl_step / fp12_sqr / fp12_mul_line in mbls_pairing.h / mbls_tower.h). f in AGPR homes; the running points and
-    the second G1 argument live in the HBM workspace as packed words (fetched when needed, the points written back at the end of their
-    step), which leaves the whole LDS allocation to the allocator as spill space."""
+def dbl_point_and_line(p, k, p1):
+    """T_k <- 2 T_k (written back to its packed slots) and the coefficients (c0, c2, c3) of the tangent line at P_k
+    (formulas of miller_dbl_step in mbls_pairing.h)"""
+    Tx, Ty, Tz = t_live_in(p, k)
+    B = p.sqr2(Ty); C = p.sqr2(Tz)
+    E = p.mul12_2(p.mul_xi2(C))
+    F = p.mul3_2(E)
+    X2 = p.sqr2(Tx)
+    YZ2 = p.sub2(p.sub2(p.sqr2(p.add2(Ty, Tz)), B), C)       # 2 Y Z = (Y + Z)^2 - Y^2 - Z^2: a squaring instead of a product
+    c0 = p.sub2(B, E)
+    if k == 0:
+        c2 = p.mulfp2(p.mul3_2(X2), p.const(NPX0_D))
+        c3 = p.mulfp2(YZ2, p.const(PY0_D))
+    else:
+        c0 = p.mulfp2(c0, p1[2])
+        c2 = p.mulfp2(p.mul3_2(X2), p1[0])
+        c3 = p.mulfp2(YZ2, p1[1])
+    x3 = p.dbl2(p.mul2(p.mul2(Tx, Ty), p.sub2(B, F)))
+    y3 = p.sub2(p.sqr2(p.add2(B, F)), p.mul12_2(p.sqr2(E)))
+    z3 = p.mul4_2(p.mul2(B, YZ2))
+    for e, v in enumerate((x3, y3, z3)):
+        storep2(p, v, k, e)
+    return c0, c2, c3
+
+
+def prog_miller_first_d(pairs=(0, 1)):
+    """The FIRST doubling iteration of the loop: f = 1, so f^2 = 1 and f * lines = the lines themselves -- the 12 products of the squaring and
+    the 17 of the product with the lines do not exist. A line c0 + c2 w^2 + c3 w^3 is (c0, c2, 0) + (0, c3, 0) w in the tower (w^2 = v)."""
     p = Prog()
-    f = f_live_in(p)
     p1 = [p.live_in(h) for h in P1_HOME]
-    merge = MERGE_LINES and len(pairs) == 2
-    if not merge:
-        f = p.sqr12(f)
-    lines = []
-    for k in pairs:
-        Tx, Ty, Tz = t_live_in(p, k)
-        B = p.sqr2(Ty); C = p.sqr2(Tz)
-        E = p.mul12_2(p.mul_xi2(C))
-        F = p.mul3_2(E)
-        X2 = p.sqr2(Tx)
-        YZ2 = p.sub2(p.sub2(p.sqr2(p.add2(Ty, Tz)), B), C)       # 2 Y Z = (Y + Z)^2 - Y^2 - Z^2: a squaring instead of a product
-        c0 = p.sub2(B, E)
-        if k == 0:
-            c2 = p.mulfp2(p.mul3_2(X2), p.const(NPX0_D))
-            c3 = p.mulfp2(YZ2, p.const(PY0_D))
-        else:
-            c0 = p.mulfp2(c0, p1[2])
-            c2 = p.mulfp2(p.mul3_2(X2), p1[0])
-            c3 = p.mulfp2(YZ2, p1[1])
-        x3 = p.dbl2(p.mul2(p.mul2(Tx, Ty), p.sub2(B, F)))
-        y3 = p.sub2(p.sqr2(p.add2(B, F)), p.mul12_2(p.sqr2(E)))
-        z3 = p.mul4_2(p.mul2(B, YZ2))
-        for e, v in enumerate((x3, y3, z3)):
-            storep2(p, v, k, e)
-        if merge:
-            lines.append(masked_line(p, c0, c2, c3, k))
-        else:
-            f = line_into_f(p, f, c0, c2, c3, k)
-    if merge:                                        # the two lines are multiplied together first: 6 + 17 instead of 13 + 13 products
+    lines = [masked_line(p, *dbl_point_and_line(p, k, p1), k) for k in pairs]
+    zero2 = lambda: (p.const(0), p.const(0))
+    if len(pairs) == 2:
         L0, L1 = mul_lines(p, lines[0], lines[1])
-        f = mul12_by_lines(p, p.sqr12(f), L0, L1)
+        f = (L0, [zero2(), L1[1], L1[2]])
+    else:
+        red2 = lambda a: (prog_reduce(p, a[0]), prog_reduce(p, a[1]))     # products with the unreduced G1 argument are a few dozen p wide
+        c0, c2, c3 = (red2(c) for c in lines[0])
+        f = ([c0, c2, zero2()], [zero2(), c3, zero2()])
     f_store(p, f)
     return p
 
 
-MERGE_LINES = True
-
-
-def prog_miller_add_d(k):
-    """The addition step T_k <- T_k + Q_k, f <- f * line for ONE pair (formulas of miller_add_step in mbls_pairing.h). Q_k comes from the
+def add_point_and_line(p, k, p1):
+    """T_k <- T_k + Q_k and the coefficients of the line through them at P_k (formulas of miller_add_step in mbls_pairing.h). Q_k comes from the
     HBM workspace (2^384 domain, converted on the way in); pair 0's Q is affine and its G1 argument the constant -G1."""
-    p = Prog()
-    f = f_live_in(p)
-    p1 = [p.live_in(h) for h in P1_HOME]
     Tx, Ty, Tz = t_live_in(p, k)
     Q = [None if sl is None else (p.live_in(("g", sl[0])), p.live_in(("g", sl[1]))) for sl in Q_SLOT[k]]
     Qx, Qy, Qz = Q
@@ -1390,13 +1384,68 @@ def prog_miller_add_d(k):
     z3 = p.mul2(vvv, z1z2)
     for e, w in enumerate((x3, y3, z3)):
         storep2(p, w, k, e)
+    return c0, c2, c3
+
+
+def prog_miller_add_both_d():
+    """The addition steps of BOTH pairs of a verification as one body: the two lines are multiplied together first (6 + 17 products instead
+    of 13 + 13, like the doubling body) and f is fetched and stored once."""
+    p = Prog()
+    f = f_live_in(p)
+    p1 = [p.live_in(h) for h in P1_HOME]
+    lines = {k: masked_line(p, *add_point_and_line(p, k, p1), k) for k in (1, 0)}      # pair 1 first: its step holds more temporaries
+    L0, L1 = mul_lines(p, lines[0], lines[1])
+    f_store(p, mul12_by_lines(p, f, L0, L1))
+    return p
+
+
+def prog_miller_dbl_d(pairs=(0, 1)):
+    """One doubling iteration of the Miller loop for the two pairs of a verification (or, pairs = (1,), for a single general pair): f <- f^2, then for each pair T <- 2T and f <- f * line
+    (formulas of miller_dbl_step / fp12_sqr / fp12_mul_line in mbls_pairing.h / mbls_tower.h). f in AGPR homes; the running points and
+    the second G1 argument live in the HBM workspace as packed words (fetched when needed, the points written back at the end of their
+    step), which leaves the whole LDS allocation to the allocator as spill space."""
+    p = Prog()
+    f = f_live_in(p)
+    p1 = [p.live_in(h) for h in P1_HOME]
+    merge = MERGE_LINES and len(pairs) == 2
+    if not merge:
+        f = p.sqr12(f)
+    lines = []
+    for k in pairs:
+        c0, c2, c3 = dbl_point_and_line(p, k, p1)
+        if merge:
+            lines.append(masked_line(p, c0, c2, c3, k))
+        else:
+            f = line_into_f(p, f, c0, c2, c3, k)
+    if merge:                                        # the two lines are multiplied together first: 6 + 17 instead of 13 + 13 products
+        L0, L1 = mul_lines(p, lines[0], lines[1])
+        f = mul12_by_lines(p, p.sqr12(f), L0, L1)
+    f_store(p, f)
+    return p
+
+
+MERGE_LINES = True
+
+
+def prog_miller_add_d(k):
+    """The addition step T_k <- T_k + Q_k, f <- f * line for ONE pair (formulas of miller_add_step in mbls_pairing.h). Q_k comes from the
+    HBM workspace (2^384 domain, converted on the way in); pair 0's Q is affine and its G1 argument the constant -G1."""
+    p = Prog()
+    f = f_live_in(p)
+    p1 = [p.live_in(h) for h in P1_HOME]
+    c0, c2, c3 = add_point_and_line(p, k, p1)
     f = line_into_f(p, f, c0, c2, c3, k)
     f_store(p, f)
     return p
 
 
+def prog_miller(which, pairs=(0, 1)):
+    return {"dbl": lambda: prog_miller_dbl_d(pairs), "first": lambda: prog_miller_first_d(pairs), "add01": prog_miller_add_both_d}.get(
+        which, lambda: prog_miller_add_d(which))()
+
+
 def build_miller(which, pairs=(0, 1)):
-    p = prog_miller_dbl_d(pairs) if which == "dbl" else prog_miller_add_d(which)
+    p = prog_miller(which, pairs)
     inb = {}
     for v, l in p.init_loc.items():
         inb[v] = PACKED if l[0] == "gd" else G_IN if l[0] == "g" else F_IN
@@ -1440,14 +1489,13 @@ def miller_loop_d_routine(pairs=(0, 1)):
          workspace slots 0..2 = (-px, py, pz^3) of pair 1, 3..6 = Q0 (affine x, y), 7..12 = Q1 (homogeneous x, y, z), 2^384 domain.
     Out: f in v108..v251 (twelve groups of 12 words, tower order, canonical, 2^384 domain). Workspace slots 31..42 are scratch."""
     dbl, st_dbl = build_miller("dbl", pairs)
-    add0, st_a0 = build_miller(0) if 0 in pairs else ([], {})
-    add1, st_a1 = build_miller(1)
+    first, st_first = build_miller("first", pairs)
+    two = len(pairs) == 2
+    add, st_add = build_miller("add01") if two else build_miller(1)
+    add_name = "add01" if two else "add1"
     W = lambda j: "v%d" % (vb(8) + j)              # work block of the shell
     pro = ["s_mov_b64 s[36:37], s[30:31]", "s_waitcnt vmcnt(0)"] + shell_constants()
     pro += ["v_and_b32_e64 v254, 1, v253", "v_cmp_ne_u32_e64 %s, 0, v254" % SKIP_MASK[0], "v_and_b32_e64 v254, 2, v253", "v_cmp_ne_u32_e64 %s, 0, v254" % SKIP_MASK[1]]
-    for i in range(12):                             # f = 1
-        for j, dgt in enumerate(digits_of(ONE_D if i == 0 else 0)):
-            pro += ["v_mov_b32_e32 v254, 0x%08x" % dgt, "v_accvgpr_write_b32 a%d, v254" % (vb(i) + j)]
     for k in pairs:                                 # T_k = Q_k, into the packed 2^392-domain slots
         for e in range(3):
             for i in range(2):
@@ -1457,18 +1505,22 @@ def miller_loop_d_routine(pairs=(0, 1)):
                 else:
                     pro += seq_gload(W, sl[i], True)
                 pro += seq_pack_pass(W) + seq_to32(W) + seq_gstore(W, T_SLOT(k, e, i))
+    # control flow (every far jump goes backwards): the first iteration (f = 1: the lines ARE f), then
+    #   5: addition step(s); phase += 1;  4: RUNS[phase] doubling iterations;  phase == 5 ? done : back to 5
+    assert RUNS[0] == 1
     pro += ["s_waitcnt vmcnt(0)", "s_mov_b32 s78, 0"]
-    top = ["4:", "s_mov_b32 s39, %d" % RUNS[5]]
-    for ph in range(5):
-        top += ["s_cmp_eq_u32 s78, %d" % ph, "s_cselect_b32 s39, %d, s39" % RUNS[ph]]
-    main = top + [".p2align 6", "1:"] + expand_calls_d(dbl)
+    main = expand_calls_d(first)
+    main += [".p2align 6", "5:"] + expand_calls_d(add) + ["s_add_u32 s78, s78, 1"]
+    main += ["s_mov_b32 s39, %d" % RUNS[5]]
+    for ph in range(1, 5):
+        main += ["s_cmp_eq_u32 s78, %d" % ph, "s_cselect_b32 s39, %d, s39" % RUNS[ph]]
+    main += [".p2align 6", "1:"] + expand_calls_d(dbl)
     main += ["s_sub_u32 s39, s39, 1", "s_cmp_lg_u32 s39, 0", "s_cbranch_scc0 2f"] + far_back(1) + ["2:"]
-    main += ["s_cmp_eq_u32 s78, 5", "s_cbranch_scc1 9f"]
-    main += expand_calls_d(add0) + expand_calls_d(add1)
-    main += ["s_add_u32 s78, s78, 1"] + far_back(4) + ["9:"]
+    main += ["s_cmp_eq_u32 s78, 5", "s_cbranch_scc1 9f"] + far_back(5) + ["9:"]
     epi = f_out_epilogue()
-    pieces = dict(pro=pro, dbl=dbl, add0=add0, add1=add1, epi=epi)
-    return pro + main + expand_calls_d(epi), pieces, dict(dbl=st_dbl, add0=st_a0, add1=st_a1)
+    pieces = dict(pro=pro, first=first, dbl=dbl, epi=epi)
+    pieces[add_name] = add
+    return pro + main + expand_calls_d(epi), pieces, {"first": st_first, "dbl": st_dbl, add_name: st_add}
 
 
 # ---------------------------------------------------------------------------------------------- the final exponentiation as ONE routine
@@ -2674,6 +2726,7 @@ def main():
     # workspace slots (x.c0, x.c1, y.c0, y.c1, z.c0, z.c1) as packed words of the 2^392 domain, representatives in (0.5 p, 1.5 p)
     txt += "#define MBLS_GEN_MILLER_T0_SLOT %d\n#define MBLS_GEN_MILLER_T_DOMAIN_BITS 392\n#define MBLS_GEN_MILLER_T_PACKED 1\n" % T_SLOT(0, 0, 0)
     assert [T_SLOT(0, e, i) for e in range(3) for i in range(2)] == list(range(T_SLOT(0, 0, 0), T_SLOT(0, 0, 0) + 6))
+    assert T_SLOT(1, 0, 0) == T_SLOT(0, 0, 0) + 6            # pair 1's point (the one the one-pair routine walks) follows pair 0's
     txt += "// the Miller-loop routine returns f in twelve register groups\n"
     txt += "#define MBLS_MILLER_D_OUT_REGS(x) " + ", ".join('"={v[%d:%d]}"(x##%d)' % (b, b + 11, i) for i, b in enumerate(F_OUT)) + "\n"
     txt += "#define MBLS_MILLER_D_ASM_CLOBBERS %s,%s, \\\n    %s\n" % (
