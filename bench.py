@@ -344,13 +344,15 @@ def valu_issue_figure(lib, ctx, phase_ms, n_items, agg_kernel="k_aggregate"):
         rate[name] = best
     # the rate of a bare loop of the Fp2 product routine (1 281 instructions, 980 multiply-accumulates) on ONE wave per SIMD -- the occupancy
     # the pipeline kernels run at: the reference for "how much does everything around the products cost in issue rate"
-    FP2_MUL_D_INSTR = 1281
     r_loop = 0.0
-    for _ in range(2):
-        ms = C.c_float()
-        ctx.check(lib.mbls_valu_bench(ctx.handle, 2, 1, 60, C.byref(ms)))
-        r_loop = max(r_loop, 60 * 8 * FP2_MUL_D_INSTR / (ms.value * 1e-3))
-    rate["fp2_product_loop@1w"] = r_loop
+    for mode, instr, name in ((2, 1281, "fp2_product_loop@1w"), (3, 923, "fp_pair_product_loop@1w")):
+        r_m = 0.0
+        for _ in range(3):                                          # ~10 ms each: long enough for the clock to settle under this load
+            ms = C.c_float()
+            ctx.check(lib.mbls_valu_bench(ctx.handle, mode, 1, 500, C.byref(ms)))
+            r_m = max(r_m, 500 * 8 * instr / (ms.value * 1e-3))
+        rate[name] = r_m
+        r_loop = max(r_loop, r_m)
     out = {"unit": "wave-instructions/s/SIMD", "ceiling_measured": rate, "ceiling_by_waves_per_simd": by_waves, "kernels": {},
            "note": "ceiling = the best rate mbls_valu_bench reaches at 1, 2, 4 or 8 waves per SIMD, measured live (a calibration stream of multiply-accumulates / "
                    "of add-with-carry pairs; a kernel whose mix runs at a higher clock can still come within a percent of 1); instruction counts = generated "

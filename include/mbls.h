@@ -287,7 +287,8 @@ int mbls_fp_mul_bench(mbls_ctx* ctx, uint64_t n_lanes, uint32_t iters, float* ms
 /* VALU issue-rate calibration for bench.py: every SIMD runs waves_per_simd (1..8) waves of `iters` x 128 instructions; mode 0:
  * v_mad_u64_u32, mode 1: v_add_co/v_addc chains. Returns elapsed ms (rate = waves_per_simd * iters * 128 / ms per SIMD).
  * mode 2: `iters` x 8 calls' worth of the generated Fp2 product routine inlined back to back (8 x 1 281 instructions per iteration, 980
- * multiply-accumulates each; use waves_per_simd <= 4): the rate of a kernel made of nothing but products. */
+ * multiply-accumulates each; use waves_per_simd <= 4): the rate of a kernel made of nothing but products. mode 3: the same with the paired
+ * Fp product of the key-sum routines (8 x 923 instructions, 784 multiply-accumulates each). */
 int mbls_valu_bench(mbls_ctx* ctx, int mode, uint32_t waves_per_simd, uint32_t iters, float* ms_out);
 
 /* ---- instrumentation: per-kernel HIP-event timing of the last *_device verify call (ms), for bench.py ---- */

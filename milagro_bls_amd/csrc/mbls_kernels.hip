@@ -435,6 +435,11 @@ __global__ void __launch_bounds__(WG) k_valu_bench(uint32_t* sink, uint32_t iter
             // made of nothing but products would issue at -- the reference the generated kernels' rates are quoted against
             MBLS_REP4(asm volatile(MBLS_FP2_MUL_D_ASM MBLS_FP2_MUL_D_ASM ::: MBLS_VALU_BENCH_CLOBBERS);)
 #endif
+        } else if (mode == 3) {
+#if MBLS_DEVICE_ASM
+            // the same with the paired Fp product of the key-sum routines (8 x 923 instructions, 784 multiply-accumulates each)
+            MBLS_REP4(asm volatile(MBLS_FP_MULPAIR_D_ASM MBLS_FP_MULPAIR_D_ASM ::: MBLS_VALU_BENCH_CLOBBERS);)
+#endif
         } else {
             MBLS_REP16(asm volatile("v_add_co_u32_e64 %0, vcc, %4, %0\n v_add_co_u32_e64 %2, s[20:21], %5, %2\n v_addc_co_u32_e64 %1, vcc, %5, %1, vcc\n v_addc_co_u32_e64 %3, s[20:21], %4, %3, s[20:21]\n"
                                     "v_add_co_u32_e64 %0, vcc, %5, %0\n v_add_co_u32_e64 %2, s[20:21], %4, %2\n v_addc_co_u32_e64 %1, vcc, %4, %1, vcc\n v_addc_co_u32_e64 %3, s[20:21], %5, %3, s[20:21]\n"
@@ -1303,7 +1308,7 @@ extern "C" int mbls_fp_mul_bench(mbls_ctx* c, uint64_t n_lanes, uint32_t iters, 
 }
 
 extern "C" int mbls_valu_bench(mbls_ctx* c, int mode, uint32_t waves_per_simd, uint32_t iters, float* ms_out) {
-    if (!c || !ms_out || !waves_per_simd || waves_per_simd > 8 || mode < 0 || mode > 2) return MBLS_ERR_ARGUMENT;
+    if (!c || !ms_out || !waves_per_simd || waves_per_simd > 8 || mode < 0 || mode > 3) return MBLS_ERR_ARGUMENT;
     mbls_lock lk(c->mu);
     HIPCHK(c, hipSetDevice(c->device));
     hipDeviceProp_t prop; HIPCHK(c, hipGetDeviceProperties(&prop, c->device));

@@ -66,13 +66,16 @@ def signed_scan(pairs, out, acc, cy):
     return S
 
 
-def fp2_mul_d_body():
-    """c0 = a0 b0 - a1 b1, c1 = a0 b1 + a1 b0 with THREE products: Karatsuba on the 64-bit column sums, in the subtractive form
+def fp2_mul_d_body(blocks=None):
+    """blocks: the register blocks (A0, A1, B0, B1, DA, C0, C1, DB) as functions digit index -> register name; default: the blocks of the called
+    routine (0, 1, 2, 3, 4, 5, 6, 8). tools/gen_tower_d.py inlines the scan at a call site with the blocks the allocator chose: the operands
+    are read where they are and the results land where they are wanted. The accumulators stay v98..v101 / v108..v111 (block 7).
+    c0 = a0 b0 - a1 b1, c1 = a0 b1 + a1 b0 with THREE products: Karatsuba on the 64-bit column sums, in the subtractive form
     c1 = (a0 - a1)(b1 - b0) + a0 b0 + a1 b1 (differences of non-negative digits are no larger than the digits, so the input limits stay
     those of four plain scans). Both scans walk the columns in lockstep; X_k = sum a0_i b0_(k-i) and Y_k = sum a1_i b1_(k-i) are formed
     once per column (fresh accumulators), the third product accumulates straight into c1's scan, and c0's scan receives X_k - Y_k, c1's
     X_k + Y_k: 3 n + 5 instructions per column instead of 4 n. Measured in isolation (scripts/dbg/fp2dbench.hip): 5 % faster."""
-    A0, A1, B0, B1, DA, C0, C1, DB = BLK(0), BLK(1), BLK(2), BLK(3), BLK(4), BLK(5), BLK(6), BLK(8)
+    A0, A1, B0, B1, DA, C0, C1, DB = blocks or (BLK(0), BLK(1), BLK(2), BLK(3), BLK(4), BLK(5), BLK(6), BLK(8))
     ACC0, ACC1, X, Y = "v[98:99]", "v[100:101]", "v[108:109]", "v[110:111]"          # v102..v107 stay untouched (see gen_tower_d.py)
     L = []
     for j in range(14):
@@ -112,8 +115,9 @@ def fp2_mul_d4_body():
     return L
 
 
-def fp2_sqr_d_body():
-    A0, A1, S, D, A1D, C0, C1 = BLK(0), BLK(1), BLK(2), BLK(3), BLK(4), BLK(5), BLK(6)
+def fp2_sqr_d_body(blocks=None):
+    """blocks: (A0, A1, S, D, A1D, C0, C1), default 0..6"""
+    A0, A1, S, D, A1D, C0, C1 = blocks or (BLK(0), BLK(1), BLK(2), BLK(3), BLK(4), BLK(5), BLK(6))
     L = []
     for j in range(14):                                                                          # c0 = (a0 + a1)(a0 - a1), c1 = a0 (2 a1)
         L += ["v_add_u32_e64 %s, %s, %s" % (S(j), A0(j), A1(j)), "v_sub_u32_e64 %s, %s, %s" % (D(j), A0(j), A1(j)),
@@ -122,8 +126,9 @@ def fp2_sqr_d_body():
     return L
 
 
-def fp2_mulfp_d_body():
-    A0, A1, SB, C0, C1 = BLK(0), BLK(1), BLK(2), BLK(5), BLK(6)
+def fp2_mulfp_d_body(blocks=None):
+    """blocks: (A0, A1, SB, C0, C1), default 0, 1, 2, 5, 6"""
+    A0, A1, SB, C0, C1 = blocks or (BLK(0), BLK(1), BLK(2), BLK(5), BLK(6))
     return zip2(signed_scan([(A0, SB)], C0, ACC_A, CARRY_A), signed_scan([(A1, SB)], C1, ACC_B, CARRY_B))
 
 

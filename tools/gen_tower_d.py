@@ -30,7 +30,7 @@ import sys
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from gen_fp_asm import P, P28, M28, SP28, SMASK28, emit  # noqa: E402
-from gen_fpd_asm import load_constants, column_ok  # noqa: E402
+from gen_fpd_asm import load_constants, column_ok, fp2_mul_d_body, fp2_sqr_d_body, fp2_mulfp_d_body  # noqa: E402
 
 
 class Prog:
@@ -465,8 +465,9 @@ WAIT_LDS = ["s_waitcnt lgkmcnt(0)", "s_nop 0"]
 class AllocD:
     """Walks a Prog and emits D-form code. Locations: ('v', blk), ('a', blk), ('l', k) = LDS digit slot k."""
 
-    def __init__(self, prog, in_bounds, n_lds=0, lds_base=0, a_pool=None, free_v=None):
+    def __init__(self, prog, in_bounds, n_lds=0, lds_base=0, a_pool=None, free_v=None, inline=False):
         self.p = prog
+        self.inline = inline                                 # Fp2 products as inlined scans on the blocks the values already live in (do_call_inline)
         self.free_v = list(FREE_V) if free_v is None else list(free_v)     # VGPR blocks outside the routines' window
         self.all_v = self.free_v + ([8] if 8 not in self.free_v else []) + [3, 2, 1, 0, 4, 6, 5]
         self.uses = {}
@@ -639,6 +640,8 @@ class AllocD:
         return b
 
     def hint_for(self, d, k):
+        if self.inline:
+            return None
         u = self.next_use(d, k + 1)
         if u == INF:
             return None
@@ -650,7 +653,7 @@ class AllocD:
             return ROUTINES[kind]["ins"][ins.index(d)]
         return None
 
-    def prefetch(self, k, horizon=3):
+    def prefetch(self, k, horizon=3, avoid=()):
         """before a multiplication call: issue the HBM loads of values that the next few operations need and that only live in their
         workspace home, into free blocks outside the routines' window (no eviction: a prefetch must not cost a spill)"""
         calls, j = 0, k + 1
@@ -659,12 +662,12 @@ class AllocD:
             kind, outs, ins, aux = self.p.ops[j]
             for v in ins:
                 if self.loc.get(v, ("", 0))[0] in ("g", "gd", "gk", "gka", "gv") and v in self.home:
-                    b = self.free_block("v", self.free_v)
+                    b = self.free_block("v", self.free_v, avoid)
                     if b is None:                            # take the block whose value is needed last, if that is later than this use
                         best, bu = None, j
                         for blk in self.free_v:
                             w = self.at.get(("v", blk))
-                            if w is None or w in ins_now:
+                            if w is None or w in ins_now or blk in avoid:
                                 continue
                             u = self.next_use(w, k)
                             if u > bu:
@@ -1065,7 +1068,67 @@ class AllocD:
             return column_ok([(m[0], m[1])])
         return column_ok([(m[0], m[2])]) and column_ok([(m[1], m[2])])
 
+    # kinds that can be inlined: (scratch blocks, body) -- block order of the bodies: operands, scratch, results (see gen_fpd_asm.py)
+    INLINE = {"mul": (2, lambda o, t, r: fp2_mul_d_body((o[0], o[1], o[2], o[3], t[0], r[0], r[1], t[1]))),
+              "sqr": (3, lambda o, t, r: fp2_sqr_d_body((o[0], o[1], t[0], t[1], t[2], r[0], r[1]))),
+              "mulfp": (0, lambda o, t, r: fp2_mulfp_d_body((o[0], o[1], o[2], r[0], r[1])))}
+
+    def call_bounds(self, kind, B):
+        if kind == "mul":
+            return [product_bound([(B[0], B[2]), (B[1], B[3])]), product_bound([(B[0], B[3]), (B[1], B[2])])]
+        if kind == "sqr":
+            return [product_bound([(B[0] + B[1], B[0] - B[1])]), product_bound([(B[0], B[1] + B[1])])]
+        if kind == "mulpair":
+            return [product_bound([(B[0], B[2])]), product_bound([(B[1], B[3])])]
+        if kind == "sqrpair":
+            return [product_bound([(B[0], B[0])]), product_bound([(B[1], B[1])])]
+        if kind == "mul1":
+            return [product_bound([(B[0], B[1])])]
+        return [product_bound([(B[0], B[2])]), product_bound([(B[1], B[2])])]
+
+    def do_call_inline(self, k, kind, outs, ins):
+        """The product scan emitted HERE, on the blocks its operands already occupy and into result blocks of the allocator's choice: no copies
+        into a fixed operand window, no call. Operands, scratch and results are pairwise distinct blocks (the operands are read until the
+        last column); block 7 holds the accumulators."""
+        nscratch, bodyf = self.INLINE[kind]
+        guard = 0
+        while not self.call_limits_ok(kind, [self.bound[v] for v in ins]):
+            v = max(ins, key=lambda x: (self.bound[x].mag(), -ins.index(x)))
+            before = self.bound[v].mag()
+            self.narrow(v, k)
+            guard += 1
+            assert self.bound[v].mag() < before or guard < 8, "cannot meet the routine's input limits"
+        uniq = list(dict.fromkeys(ins))
+        for attempt in range(4):                             # fetching one operand may evict another: repeat until all are in VGPR blocks
+            for v in uniq:
+                if self.loc[v][0] != "v":
+                    self.to_vgpr(v, k, avoid=tuple(self.loc[w][1] for w in uniq if w != v and self.loc[w][0] == "v"))
+            if all(self.loc[v][0] == "v" for v in uniq):
+                break
+        assert all(self.loc[v][0] == "v" for v in uniq), "operands do not fit the register blocks"
+        opb = [self.loc[v][1] for v in ins]
+        taken = list(dict.fromkeys(opb))
+        extra = []
+        for _ in range(nscratch + 2):
+            b = self.alloc_v(k, avoid=tuple(taken))
+            assert ("v", b) not in self.at and ("vw", b) not in self.at
+            taken.append(b); extra.append(b)
+        assert all(self.loc[v] == ("v", b) for v, b in zip(ins, opb)), "an operand moved while the result blocks were made"
+        self.wait_lds()
+        self.prefetch(k, avoid=tuple(taken))
+        reg = lambda b: (lambda j: "v%d" % (vb(b) + j))
+        for l in bodyf([reg(b) for b in opb], [reg(b) for b in extra[:nscratch]], [reg(b) for b in extra[nscratch:]]):
+            self.e(l)
+        self.stats["calls"] += 1
+        self.stats["inlined"] = self.stats.get("inlined", 0) + 1
+        ob = self.call_bounds(kind, [self.bound[v] for v in ins])
+        for i, o in enumerate(outs):
+            self.place(o, ("v", extra[nscratch + i]))
+            self.bound[o] = ob[i]
+
     def do_call(self, k, kind, outs, ins):
+        if self.inline and kind in self.INLINE:
+            return self.do_call_inline(k, kind, outs, ins)
         R = ROUTINES[kind]
         slots = R["ins"]
         # 1. operand limits: renormalise the largest operand until the product columns fit
@@ -1118,19 +1181,7 @@ class AllocD:
             if w is not None:
                 assert self.next_use(w, k + 1) == INF, "live value in a clobbered block across a call"
                 self.release(w)
-        B = [self.bound[v] for v in ins]
-        if kind == "mul":
-            ob = [product_bound([(B[0], B[2]), (B[1], B[3])]), product_bound([(B[0], B[3]), (B[1], B[2])])]
-        elif kind == "sqr":
-            ob = [product_bound([(B[0] + B[1], B[0] - B[1])]), product_bound([(B[0], B[1] + B[1])])]
-        elif kind == "mulpair":
-            ob = [product_bound([(B[0], B[2])]), product_bound([(B[1], B[3])])]
-        elif kind == "sqrpair":
-            ob = [product_bound([(B[0], B[0])]), product_bound([(B[1], B[1])])]
-        elif kind == "mul1":
-            ob = [product_bound([(B[0], B[1])])]
-        else:
-            ob = [product_bound([(B[0], B[2])]), product_bound([(B[1], B[2])])]
+        ob = self.call_bounds(kind, [self.bound[v] for v in ins])
         for i, o in enumerate(outs):
             self.place(o, ("v", R["outs"][i]))
             self.bound[o] = ob[i]
@@ -1449,13 +1500,14 @@ def build_miller(which, pairs=(0, 1)):
     inb = {}
     for v, l in p.init_loc.items():
         inb[v] = PACKED if l[0] == "gd" else G_IN if l[0] == "g" else F_IN
-    al = AllocD(p, inb, n_lds=11, lds_base=0, a_pool=list(range(NA)))
+    al = AllocD(p, inb, n_lds=11, lds_base=0, a_pool=list(range(NA)), inline=(which in INLINE_BODIES))
     body = al.run()
     for dst, B in al.stored.items():
         assert B.dlo >= F_IN.dlo and B.dhi <= F_IN.dhi and B.vlo >= F_IN.vlo and B.vhi <= F_IN.vhi and B.tlo >= F_IN.tlo and B.thi <= F_IN.thi, (dst, B)
     return body, al.stats
 
 
+INLINE_BODIES = ("dbl",)                           # the bodies whose Fp2 products are inlined scans (the loop body: 62 of the 63 iterations)
 F_OUT = [108 + 12 * i for i in range(12)]          # register groups (12 words each) in which the Miller routine returns f
 RUNS = [1, 2, 3, 9, 32, 16]                        # doubling iterations between the additions: |x| = 0xd201000000010000, bits 62..0
 
@@ -1800,10 +1852,13 @@ FEXP_BODIES = dict(easy=prog_fexp_easy, pstart=prog_fexp_pstart, csqr=prog_fexp_
                    step_base=prog_fexp_step_base, tail=prog_fexp_tail)
 
 
+FEXP_INLINE = ("csqr", "pmul", "pfirst")        # the bodies that run 315 / 25 / 5 times per item get their Fp2 products as inlined scans
+
+
 def build_fexp(which):
     p = FEXP_BODIES[which]()
     inb = {v: (STATE_IN if l[0] == "a" else PACKED if l[0] in ("gd", "gk") else G_IN) for v, l in p.init_loc.items()}
-    al = AllocD(p, inb, n_lds=11, lds_base=0, a_pool=list(range(NA)))
+    al = AllocD(p, inb, n_lds=11, lds_base=0, a_pool=list(range(NA)), inline=(which in FEXP_INLINE))
     body = al.run()
     for dst, B in getattr(al, "stored", {}).items():
         assert B.vlo >= STATE_IN.vlo and B.vhi <= STATE_IN.vhi and B.dhi <= M28, (dst, B)
