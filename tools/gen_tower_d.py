@@ -1507,7 +1507,12 @@ def build_miller(which, pairs=(0, 1)):
     return body, al.stats
 
 
-INLINE_BODIES = ("dbl",)                           # the bodies whose Fp2 products are inlined scans (the loop body: 62 of the 63 iterations)
+# Bodies whose Fp2 products are inlined scans. NONE for the Miller loop: measured on the MI355X, the inlined doubling body (82.7 k instructions
+# = 660 KB of straight-line code per iteration instead of 16.9 k of glue around three 8-10 KB product routines) issues 2.6 % fewer
+# instructions and runs 12 % SLOWER (k_miller 11.26 -> 12.62 ms, 2.00 -> 2.30 ns per instruction): the called routines stay resident in the
+# 64 KB instruction cache and 80 % of the executed instructions hit there, while straight-line code streams from L2 at ~2.4 ns per
+# instruction. Inlining pays only where the whole loop fits the cache (the compressed squaring of the final exponentiation: 57 KB).
+INLINE_BODIES = ()
 F_OUT = [108 + 12 * i for i in range(12)]          # register groups (12 words each) in which the Miller routine returns f
 RUNS = [1, 2, 3, 9, 32, 16]                        # doubling iterations between the additions: |x| = 0xd201000000010000, bits 62..0
 
@@ -1705,19 +1710,27 @@ ZMASK = ["s[48:49]", "s[50:51]", "s[52:53]", "s[54:55]", "s[84:85]", "s[86:87]"]
 TMASK, TMASK2 = "s[88:89]", "s[90:91]"
 
 
+# Homes of the compressed state (z2, z3, z4, z5) between the bodies of a power (pstart, csqr, psave): z2 and z3 stay in VGPR blocks 14..17 --
+# the squaring body reads them first and writes them last, so they never travel through the AGPRs (112 of the body's 7 182 instructions) --,
+# z4 and z5 in AGPR blocks 4..7. The three bodies withhold blocks 14..17 from their allocators.
+CSTATE_HOME = [("v", 17), ("v", 16), ("v", 15), ("v", 14), ("a", 4), ("a", 5), ("a", 6), ("a", 7)]
+CSTATE_BODIES = ("pstart", "csqr", "psave")
+CSTATE_FREE_V = [b for b in FREE_V if b not in (14, 15, 16, 17)]
+
+
 def prog_fexp_pstart():
     """compressed state <- the base Y"""
     p = Prog()
     y = [p.live_in(("gd", Y_SLOT + i)) for i in range(12)]
     for i, idx in enumerate(C_IDX):
-        p.store(prog_reduce(p, y[idx]), ("a", i))
+        p.store(prog_reduce(p, y[idx]), CSTATE_HOME[i])
     return p
 
 
 def prog_fexp_csqr():
     """one compressed squaring: (z2, z3, z4, z5) in AGPR blocks 0..7, in place"""
     p = Prog()
-    l = [p.live_in(("a", i)) for i in range(8)]
+    l = [p.live_in(CSTATE_HOME[i]) for i in range(8)]
     z2, z3, z4, z5 = (l[0], l[1]), (l[2], l[3]), (l[4], l[5]), (l[6], l[7])
 
     def fp4_sqr(a, b):
@@ -1726,7 +1739,7 @@ def prog_fexp_csqr():
 
     def out(base, v):
         for i in range(2):
-            p.store(prog_reduce(p, v[i]), ("a", base + i))
+            p.store(prog_reduce(p, v[i]), CSTATE_HOME[base + i])
     t0, t1 = fp4_sqr(z2, z3)
     out(4, p.shadd2(p.sub2(t0, z4), 1, t0))
     out(6, p.shadd2(p.add2(t1, z5), 1, t1))
@@ -1740,11 +1753,11 @@ def prog_fexp_csqr():
 def prog_fexp_psave():
     """the compressed state -> the record selected by the run-time offset (the state stays)"""
     p = Prog()
-    l = [p.live_in(("a", i)) for i in range(8)]
+    l = [p.live_in(CSTATE_HOME[i]) for i in range(8)]
     for i, v in enumerate(l):
         p.ops.append(("storep", [], [v], ("k", K_SLOT + i)))         # record 0's slot: the run-time offset selects the record
     for i, v in enumerate(l):
-        p.store(v, ("a", i))
+        p.store(v, CSTATE_HOME[i])
     return p
 
 
@@ -1852,13 +1865,14 @@ FEXP_BODIES = dict(easy=prog_fexp_easy, pstart=prog_fexp_pstart, csqr=prog_fexp_
                    step_base=prog_fexp_step_base, tail=prog_fexp_tail)
 
 
-FEXP_INLINE = ("csqr", "pmul", "pfirst")        # the bodies that run 315 / 25 / 5 times per item get their Fp2 products as inlined scans
+FEXP_INLINE = ("csqr",)                          # the loop body that runs 315 times per item and fits the instruction cache with its products inlined (57 KB)
 
 
 def build_fexp(which):
     p = FEXP_BODIES[which]()
-    inb = {v: (STATE_IN if l[0] == "a" else PACKED if l[0] in ("gd", "gk") else G_IN) for v, l in p.init_loc.items()}
-    al = AllocD(p, inb, n_lds=11, lds_base=0, a_pool=list(range(NA)), inline=(which in FEXP_INLINE))
+    inb = {v: (STATE_IN if l[0] in ("a", "v") else PACKED if l[0] in ("gd", "gk") else G_IN) for v, l in p.init_loc.items()}
+    al = AllocD(p, inb, n_lds=11, lds_base=0, a_pool=list(range(NA)), inline=(which in FEXP_INLINE),
+                free_v=(CSTATE_FREE_V if which in CSTATE_BODIES else None))
     body = al.run()
     for dst, B in getattr(al, "stored", {}).items():
         assert B.vlo >= STATE_IN.vlo and B.vhi <= STATE_IN.vhi and B.dhi <= M28, (dst, B)
