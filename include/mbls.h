@@ -222,6 +222,18 @@ int mbls_fast_aggregate_verify_pre_aggregated(mbls_ctx* ctx, const uint8_t sig[9
 /* AggregateSignature::aggregate_verify (src/aggregates.rs:130-170): n messages of msg_lens[i] bytes, concatenated */
 int mbls_aggregate_verify(mbls_ctx* ctx, const uint8_t sig[96], const uint8_t* msgs, const size_t* msg_lens, size_t n_msgs,
                           const uint8_t* pks96, size_t n_pks);
+/* n x AggregateSignature::aggregate_verify (src/aggregates.rs:130-170) in one call. The (message, key) pairs of all items lie back to back:
+ * pair j = (message j, key pks96 + 96 j); messages are msg_len bytes each or msgs[msg_offsets[j] .. msg_offsets[j+1]) (total_pairs + 1
+ * offsets); item i owns the pairs [pair_offsets[i], pair_offsets[i+1]) (n + 1 offsets starting at 0) or k each (pair_offsets == NULL) --
+ * "as many messages as keys" (src/aggregates.rs:131) holds by construction, an item without pairs is false (MBLS_ST_NO_KEYS). results[i] =
+ * 1/0, status[i] = the MBLS_ST_* bits of the item (its signature's and its pairs' ORed). One lane per pair walks the key decode, the
+ * message phase and a one-pair Miller loop; the (sig_i, -G1) pairs ride the same launch; a product tree per item; one final exponentiation
+ * per item. The device entry only enqueues (total_pairs = pair_offsets[n] must be given: it sizes the launches). */
+int mbls_aggregate_verify_batch(mbls_ctx* ctx, const uint8_t* sigs96, const uint8_t* msgs, uint32_t msg_len, const uint64_t* msg_offsets,
+                                const uint8_t* pks96, const uint32_t* pair_offsets, uint32_t k, uint64_t n, uint8_t* results, uint32_t* status);
+int mbls_aggregate_verify_batch_device(mbls_ctx* ctx, const uint8_t* d_sigs96, const uint8_t* d_msgs, uint32_t msg_len,
+                                       const uint64_t* d_msg_offsets, const uint8_t* d_pks96, const uint32_t* d_pair_offsets, uint32_t k,
+                                       uint64_t total_pairs, uint64_t n, uint8_t* d_results, uint32_t* d_status, void* stream);
 /* AggregateSignature::verify_multiple_aggregate_signatures (src/aggregates.rs:261-316): n sets of
  * (aggregate signature, aggregate public key, message); rands[i] = the NONZERO blinding scalars (63 bits in the
  * reference) drawn from the caller's RNG exactly as at src/aggregates.rs:280-287 -- the reference owns that loop, here

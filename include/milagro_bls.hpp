@@ -259,6 +259,29 @@ struct AggregateSignature {
 
 // Several GPUs behind one handle (mbls_multi_*; not part of the reference's API): contiguous shards, one context and one host thread per
 // device inside the library, results written in place. Items are independent (reference src/aggregates.rs:177-215 keeps no state).
+// n x AggregateSignature::aggregate_verify (src/aggregates.rs:130-170) in one launch chain: item i = (sigs[i], its messages, its keys); an item
+// with a different number of messages and keys, or with none, is false like the reference's early return (:131-133)
+inline std::vector<bool> aggregate_verify_batch(const std::vector<AggregateSignature>& sigs, const std::vector<std::vector<Bytes>>& msgs,
+                                                const std::vector<std::vector<const PublicKey*>>& keys) {
+    const size_t n = sigs.size();
+    if (msgs.size() != n || keys.size() != n) throw std::invalid_argument("one message list and one key list per signature");
+    Bytes s, m, p; std::vector<uint64_t> moff{0}; std::vector<uint32_t> poff{0}; std::vector<bool> mismatch(n, false);
+    for (size_t i = 0; i < n; i++) {
+        s.insert(s.end(), sigs[i].point.begin(), sigs[i].point.end());
+        if (msgs[i].size() != keys[i].size()) mismatch[i] = true;          // enters the batch without pairs: false
+        else for (size_t j = 0; j < keys[i].size(); j++) {
+            m.insert(m.end(), msgs[i][j].begin(), msgs[i][j].end()); moff.push_back(m.size());
+            p.insert(p.end(), keys[i][j]->point.begin(), keys[i][j]->point.end());
+        }
+        poff.push_back(uint32_t(p.size() / 96));
+    }
+    std::vector<uint8_t> res(n ? n : 1);
+    detail::check(mbls_aggregate_verify_batch(detail::ctx(), s.data(), m.data(), 0, moff.data(), p.data(), poff.data(), 0, n, res.data(), nullptr));
+    std::vector<bool> out(n);
+    for (size_t i = 0; i < n; i++) out[i] = res[i] == 1 && !mismatch[i];
+    return out;
+}
+
 class MultiGpu {
     mbls_multi* h_ = nullptr;
 public:

@@ -41,6 +41,8 @@ SIGNATURES = {
     "mbls_fast_aggregate_verify_batch": (C.c_int, [vp, vp, vp, C.c_uint32, vp, vp, C.c_int, vp, C.c_uint64, C.c_uint32, vp, vp]),
     "mbls_verify_batch_device": (C.c_int, [vp, vp, vp, C.c_uint32, vp, vp, C.c_int, C.c_uint64, vp, vp, vp, vp]),
     "mbls_verify_batch": (C.c_int, [vp, vp, vp, C.c_uint32, vp, vp, C.c_int, C.c_uint64, vp, vp]),
+    "mbls_aggregate_verify_batch": (C.c_int, [vp, vp, vp, C.c_uint32, vp, vp, vp, C.c_uint32, C.c_uint64, vp, vp]),
+    "mbls_aggregate_verify_batch_device": (C.c_int, [vp, vp, vp, C.c_uint32, vp, vp, vp, C.c_uint32, C.c_uint64, C.c_uint64, vp, vp, vp]),
     "mbls_keytable_create": (C.c_int, [vp, C.c_uint64, C.POINTER(vp)]),
     "mbls_keytable_destroy": (None, [vp]),
     "mbls_keytable_size": (C.c_uint64, [vp]),

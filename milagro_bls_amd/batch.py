@@ -55,6 +55,20 @@ def aggregate_signatures_batch(sigs96, n, k=None, offsets=None, ctx=None):
     return bytes(out)[:96 * n], list(bytes(errs)[:n])
 
 
+def aggregate_verify_batch(sigs, msgs, pks96, n, k=None, pair_offsets=None, msg_len=32, msg_offsets=None, ctx=None):
+    """n x AggregateSignature::aggregate_verify (reference src/aggregates.rs:130-170): the (message, key) pairs of all items back to back;
+    item i owns pairs [pair_offsets[i], pair_offsets[i+1]) or k each. Returns (results, status)."""
+    ctx = ctx or _c()
+    res = N.outbuf(n)
+    st = (C.c_uint32 * max(1, n))()
+    off = None
+    if pair_offsets is not None:
+        off = (C.c_uint32 * len(pair_offsets))(*pair_offsets)
+        k = 0
+    ctx.check(N.lib().mbls_aggregate_verify_batch(ctx.handle, N.cbuf(sigs), N.cbuf(msgs), msg_len, _moff(msg_offsets), N.cbuf(pks96), off, k, n, res, st))
+    return [bool(x) for x in bytes(res)[:n]], list(st)[:n]
+
+
 def verify_batch(sigs, msgs, pks, n, pk_format=N.PK_COMPRESSED, msg_len=32, ctx=None, msg_offsets=None):
     """n x Signature::verify (reference src/signature.rs:27-40)."""
     ctx = ctx or _c()

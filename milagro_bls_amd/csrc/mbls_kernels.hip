@@ -306,6 +306,52 @@ __global__ void MBLS_LB k_g2_tree_d(mbls_ws ws, uint64_t m, uint64_t half) {
     tree_level_d_call<true>(ws, i, half, (MBLS_LDS uint32_t*)spill, threadIdx.x);
 #endif
 }
+// ---- batched AggregateVerify (reference src/aggregates.rs:130-170, n calls at once). Workspace items: [0, n) the (sig_i, -G1) pairs,
+// [n, n + T) the T (message, key) pairs of all items back to back (item i owns pairs [off[i], off[i+1]) or k each), [n + T, 2 n + T) staging.
+// item i's signature (slots SIG of item i, written by k_sig: affine, y = 0 = infinity) -> the operands of its (sig, -G1) pair in the slots
+// k_miller_single reads: H = the signature (Jacobian), APK = -G1
+__global__ void MBLS_LB k_sigpair_setup(mbls_ws ws, uint64_t n) {
+    uint64_t i = gid(); if (i >= n) return;
+    g2j s; s.x = ws_ld2(ws, MBLS_SLOT_SIG, i); s.y = ws_ld2(ws, MBLS_SLOT_SIG + 2, i); s.z = fp2_one();
+    if (fp2_is_zero(s.y)) g2_set_inf(&s);
+    ws_st2(ws, MBLS_SLOT_H, i, s.x); ws_st2(ws, MBLS_SLOT_H + 2, i, s.y); ws_st2(ws, MBLS_SLOT_H + 4, i, s.z);
+    ws_st(ws, MBLS_SLOT_APK, i, fp_load_const(MBLS_G1_X)); ws_st(ws, MBLS_SLOT_APK + 1, i, fp_load_const(MBLS_G1_NEG_Y)); ws_st(ws, MBLS_SLOT_APK + 2, i, fp_one());
+}
+// pair j -> the item that owns it (ragged layouts; one lane per item walks its range)
+__global__ void MBLS_LB k_pair_item_map(const uint32_t* off, uint64_t n, uint64_t total, uint32_t* map) {
+    uint64_t i = gid(); if (i >= n) return;
+    const uint64_t a = off[i], b = off[i + 1];
+    if (b < a || b > total) return;
+    for (uint64_t j = a; j < b; j++) map[j] = (uint32_t)i;
+}
+// one level of the per-item product trees over the pairs' Miller values: pair j (workspace item j of the view `wp`) takes its partner j + half
+// when both lie in the same item's range and j is a multiple of 2 half from the start of that range. The generated tree routine, called with
+// the lanes of the wave that have no product this level switched off.
+__global__ void MBLS_LB k_f12_seg_tree_d(mbls_ws wp, const uint32_t* map, const uint32_t* off, uint32_t k, uint64_t total, uint64_t half) {
+#if MBLS_DEVICE_ASM
+    __shared__ uint32_t spill[154 * 64];
+    uint64_t j = gid(); if (j >= total) return;
+    uint64_t lo, hi;
+    if (off) { const uint32_t i = map[j]; lo = off[i]; hi = off[i + 1]; } else { lo = (j / k) * k; hi = lo + k; }
+    const uint64_t r = j - lo;
+    if (r % (2 * half) != 0 || j + half >= hi) return;
+    tree_level_d_call<false>(wp, j, half, (MBLS_LDS uint32_t*)spill, threadIdx.x);
+#endif
+}
+// item i: the product of its pairs (left in the first pair of its range by the tree) -> the staging item n + T + i (1 for an empty range);
+// and the item's status = its signature's | the OR of its pairs' | MBLS_ST_NO_KEYS for an empty range (src/aggregates.rs:131-133)
+__global__ void MBLS_LB k_f12_seg_gather(mbls_ws ws, const uint32_t* off, uint32_t k, uint64_t n, uint64_t total, uint32_t* st_item, const uint32_t* st_pair) {
+    uint64_t i = gid(); if (i >= n) return;
+    uint64_t lo = off ? off[i] : (uint64_t)k * i, hi = off ? off[i + 1] : lo + k;
+    uint32_t st = 0;
+    if (hi < lo || hi > total) { st |= MBLS_ST_BAD_PK_ENCODING; hi = lo; }        // an offset table that runs backwards never becomes a read
+    if (hi == lo) st |= MBLS_ST_NO_KEYS;
+    for (uint64_t j = lo; j < hi; j++) st |= st_pair[j];
+    fp12 f; fp12_set_one(&f);
+    const fp* one = &f.c0.c0.c0;
+    for (int t = 0; t < 12; t++) ws_st(ws, MBLS_SLOT_F + t, n + total + i, hi > lo ? ws_ld(ws, MBLS_SLOT_F + t, n + lo) : one[t]);
+    if (st) atomicOr(st_item + i, st);
+}
 __global__ void MBLS_LB k_status_or(const uint32_t* status, uint64_t n, uint32_t* out) {
     uint64_t i = gid(); uint32_t v = (i < n) ? status[i] : 0;
     if (__ballot(v != 0)) { if (v) atomicOr(out, v); }
@@ -1503,6 +1549,92 @@ extern "C" int mbls_aggregate_verify(mbls_ctx* c, const uint8_t sig[96], const u
     if (hipMemcpy(&r, c->d_results, 1, hipMemcpyDeviceToHost) != hipSuccess) return 0;
     result = r;
     return result;
+}
+// n x AggregateSignature::aggregate_verify (reference src/aggregates.rs:130-170): item i = (sig_i, its (message, key) pairs). The pairs of
+// all items lie back to back: pair j = (message j of d_msgs / d_moff, key d_pks96 + 96 j); item i owns pairs [d_pair_off[i], d_pair_off[i+1])
+// or k each. One lane per pair for the key, the message phase and the one-pair Miller loop; the (sig_i, -G1) pairs ride the same Miller
+// launch; a product tree per item; one final exponentiation per item. Enqueues only.
+extern "C" int mbls_aggregate_verify_batch_device(mbls_ctx* c, const uint8_t* d_sigs, const uint8_t* d_msgs, uint32_t msg_len, const uint64_t* d_moff,
+        const uint8_t* d_pks96, const uint32_t* d_pair_off, uint32_t k, uint64_t total, uint64_t n, uint8_t* d_results, uint32_t* d_status, void* stream) {
+    if (!c) return MBLS_ERR_ARGUMENT;
+    mbls_lock lk(c->mu);
+    if (n == 0) return MBLS_OK;
+    if (!d_sigs || !d_results || (total && (!d_pks96 || (!d_msgs && msg_len && !d_moff)))) ARGFAIL(c, "null buffer");
+    if (!d_pair_off && total != (uint64_t)k * n) ARGFAIL(c, "total_pairs != n * k");
+    if (total > 0xFFFFFFFFull) ARGFAIL(c, "pair indices are 32-bit");
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t s = (hipStream_t)stream;
+    const uint64_t M = 2 * n + total;
+    int rc = mbls_ctx_reserve(c, M); if (rc) return rc;
+    mbls_ws ws; ws.w = c->d_w; ws.stride = c->cap;
+    mbls_ws wp = ws; wp.w += n;                                   // the pairs' view: item j of wp = workspace item n + j
+    rc = ws_acquire(c, s); if (rc) return rc;
+    uint32_t* st_item = d_status ? d_status : c->d_status;
+    uint32_t* st_pair = c->d_status + n;                         // (cap >= 2 n + T words)
+    uint32_t* map = nullptr;
+    sbuf dmap(c, 9);
+    if (d_pair_off) { HIPCHK(c, dmap.alloc(4 * (total ? total : 1))); map = dmap.as<uint32_t>(); }
+    HIPCHK(c, hipMemsetAsync(st_item, 0, 4 * n, s));
+    if (st_item != c->d_status) HIPCHK(c, hipMemsetAsync(c->d_status, 0, 4 * n, s));
+    if (total) HIPCHK(c, hipMemsetAsync(st_pair, 0, 4 * total, s));
+    HIPCHK(c, hipMemsetAsync(d_results, 0, n, s));                // false until k_final has spoken
+    // three chains side by side while they leave SIMDs idle: signatures (items [0, n)), keys and messages (items [n, n + T) through wp)
+    const bool fork = n + 2 * total <= c->fork_max_items;
+    hipStream_t s_sig = fork ? c->hs_b : s, s_msg = fork ? c->hs_c : s;
+    if (fork) { HIPCHK(c, hipEventRecord(c->hs_ev, s)); HIPCHK(c, hipStreamWaitEvent(s_sig, c->hs_ev, 0)); HIPCHK(c, hipStreamWaitEvent(s_msg, c->hs_ev, 0)); }
+    hipLaunchKernelGGL(k_sig, dim3(nblk(n)), dim3(WG), 0, s_sig, ws, d_sigs, st_item, n, 1);
+    hipLaunchKernelGGL(k_sigpair_setup, dim3(nblk(n)), dim3(WG), 0, s_sig, ws, n);
+    if (total) {
+        if (d_pair_off) hipLaunchKernelGGL(k_pair_item_map, dim3(nblk(n)), dim3(WG), 0, s, d_pair_off, n, total, map);
+        hipLaunchKernelGGL(k_blind_g1, dim3(nblk(total)), dim3(WG), 0, s, wp, d_pks96, (const uint64_t*)nullptr, st_pair, total);      // decode only: r_i = 1
+        launch_hash(c, wp, d_msgs, msg_len, d_moff, st_pair, total, s_msg);
+    }
+    if (fork) {
+        HIPCHK(c, hipEventRecord(c->hs_ev2, s_sig)); HIPCHK(c, hipEventRecord(c->hs_ev3, s_msg));
+        HIPCHK(c, hipStreamWaitEvent(s, c->hs_ev2, 0)); HIPCHK(c, hipStreamWaitEvent(s, c->hs_ev3, 0));
+    }
+    // one Miller loop per pair, the signatures' pairs included: items [0, n + T)
+    if (2 * (n + total) <= c->coop_max_items)
+        coop_run(c, COOP_MILLER1, ws, (uint64_t)0, (uint64_t)1, (uint64_t)0, n + total, (uint32_t*)nullptr, (uint8_t*)nullptr, COOP_RES_ITEM, s);
+    else
+        hipLaunchKernelGGL(k_miller_single, dim3(nblk(n + total)), dim3(WG), 0, s, ws, n + total, 0, (uint64_t)0);
+    // per-item product trees over the pairs, then item i <- (sig pair) x (its pairs' product)
+    uint64_t kmax = d_pair_off ? total : k;                      // a ragged layout may hold one long range: levels up to the whole list
+    for (uint64_t half = 1; half < kmax; half *= 2)
+        hipLaunchKernelGGL(k_f12_seg_tree_d, dim3(nblk(total)), dim3(WG), 0, s, wp, (const uint32_t*)map, d_pair_off, k, total, half);
+    hipLaunchKernelGGL(k_f12_seg_gather, dim3(nblk(n)), dim3(WG), 0, s, ws, d_pair_off, k, n, total, st_item, (const uint32_t*)st_pair);
+    hipLaunchKernelGGL(k_f12_tree_d, dim3(nblk(n)), dim3(WG), 0, s, ws, 2 * n + total, n + total);
+    hipLaunchKernelGGL(k_final, dim3(nblk(n)), dim3(WG), 0, s, ws, st_item, d_results, n);
+    HIPCHK(c, hipGetLastError());
+    return ws_release(c, s);
+}
+extern "C" int mbls_aggregate_verify_batch(mbls_ctx* c, const uint8_t* sigs, const uint8_t* msgs, uint32_t msg_len, const uint64_t* moff,
+        const uint8_t* pks96, const uint32_t* pair_off, uint32_t k, uint64_t n, uint8_t* results, uint32_t* status) {
+    if (!c) return MBLS_ERR_ARGUMENT;
+    mbls_lock lk(c->mu);
+    if (n == 0) return MBLS_OK;
+    if (!sigs || !results) ARGFAIL(c, "null buffer");
+    if (pair_off && (!offsets_ok(pair_off, n) || pair_off[0] != 0)) ARGFAIL(c, "pair_offsets must start at 0 and be non-decreasing");
+    const uint64_t total = pair_off ? pair_off[n] : (uint64_t)k * n;
+    if (moff && !msg_offsets_ok(moff, total)) ARGFAIL(c, "msg_offsets must be non-decreasing, messages below 2^32 bytes");
+    const uint64_t msg_first = moff ? moff[0] : 0;
+    const size_t msg_total = moff ? (size_t)(moff[total] - moff[0]) : (size_t)msg_len * total;
+    if (total && (!pks96 || (!msgs && msg_total))) ARGFAIL(c, "null buffer");
+    HIPCHK(c, hipSetDevice(c->device));
+    sbuf ds(c, 0), dm(c, 1), dp(c, 2), doff(c, 3), dr(c, 4), dst(c, 5), dmo(c, 6);
+    HIPCHK(c, ds.up(sigs, 96 * n)); HIPCHK(c, dm.up(msgs ? msgs + msg_first : nullptr, msg_total)); HIPCHK(c, dp.up(pks96, 96 * total));
+    if (pair_off) HIPCHK(c, doff.up(pair_off, 4 * (n + 1)));
+    const uint8_t* d_msgs = dm.as<uint8_t>();
+    if (moff) { HIPCHK(c, dmo.up(moff, 8 * (total + 1))); d_msgs -= msg_first; }
+    HIPCHK(c, dr.alloc(n)); HIPCHK(c, dst.alloc(4 * n));
+    int rc = mbls_aggregate_verify_batch_device(c, ds.as<uint8_t>(), d_msgs, msg_len, moff ? dmo.as<uint64_t>() : nullptr, dp.as<uint8_t>(),
+                                                pair_off ? doff.as<uint32_t>() : nullptr, k, total, n, dr.as<uint8_t>(), dst.as<uint32_t>(), c->hs_a);
+    if (rc) { (void)hipStreamSynchronize(c->hs_a); (void)hipStreamSynchronize(c->hs_b); (void)hipStreamSynchronize(c->hs_c); c->ws_pending = false; return rc; }
+    HIPCHK(c, hipStreamSynchronize(c->hs_a));
+    c->ws_pending = false;
+    HIPCHK(c, dr.down(results, n));
+    if (status) HIPCHK(c, dst.down(status, 4 * n));
+    return MBLS_OK;
 }
 static int verify_multiple_impl(mbls_ctx* c, const uint8_t* d_sigs, const uint8_t* d_apks, const uint8_t* d_pks, int pk_format,
         const uint32_t* d_pk_offsets, uint32_t k, const uint8_t* d_msgs, uint32_t msg_len, const uint64_t* d_moff, const uint64_t* d_rands, uint64_t n,

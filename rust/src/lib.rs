@@ -67,6 +67,8 @@ extern "C" {
                                                  rands: *const u64, n: usize) -> c_int;
     fn mbls_fast_aggregate_verify_batch(ctx: *mut MblsCtx, sigs: *const u8, msgs: *const u8, msg_len: u32, msg_offsets: *const u64, pks: *const u8, pk_format: c_int,
                                         pk_offsets: *const u32, n: u64, k: u32, results: *mut u8, status: *mut u32) -> c_int;
+    fn mbls_aggregate_verify_batch(ctx: *mut MblsCtx, sigs96: *const u8, msgs: *const u8, msg_len: u32, msg_offsets: *const u64, pks96: *const u8,
+                                   pair_offsets: *const u32, k: u32, n: u64, results: *mut u8, status: *mut u32) -> c_int;
     fn mbls_verify_batch(ctx: *mut MblsCtx, sigs: *const u8, msgs: *const u8, msg_len: u32, msg_offsets: *const u64, pks: *const u8, pk_format: c_int, n: u64,
                          results: *mut u8, status: *mut u32) -> c_int;
     fn mbls_keytable_create(ctx: *mut MblsCtx, capacity_hint: u64, out: *mut *mut MblsKeyTable) -> c_int;
@@ -563,6 +565,37 @@ pub mod batch {
             err(rc);
         }
         res.into_iter().map(|b| b == 1).collect()
+    }
+    /// n x `AggregateSignature::aggregate_verify` (`src/aggregates.rs:130-170`): item i = (signatures[i], its messages, its keys), as many
+    /// messages as keys per item (an item where they differ, or with none, is false like the reference's early return).
+    pub fn aggregate_verify(signatures: &[AggregateSignature], messages: &[Vec<&[u8]>], public_keys: &[Vec<&PublicKey>]) -> Vec<bool> {
+        let n = signatures.len();
+        assert!(messages.len() == n && public_keys.len() == n);
+        let sigs: Vec<u8> = signatures.iter().flat_map(|s| s.point.iter().copied()).collect();
+        let mut pair_off: Vec<u32> = vec![0];
+        let mut msg_off: Vec<u64> = vec![0];
+        let (mut msgs, mut pks): (Vec<u8>, Vec<u8>) = (Vec::new(), Vec::new());
+        let mut mismatch = vec![false; n];
+        for i in 0..n {
+            if messages[i].len() != public_keys[i].len() {
+                mismatch[i] = true; // src/aggregates.rs:131-133: the item is false; it enters the batch without pairs
+            } else {
+                for (m, k) in messages[i].iter().zip(public_keys[i].iter()) {
+                    msgs.extend_from_slice(m);
+                    msg_off.push(msgs.len() as u64);
+                    pks.extend_from_slice(&k.point);
+                }
+            }
+            pair_off.push((pks.len() / 96) as u32);
+        }
+        let mut res = vec![0u8; n];
+        let rc = unsafe {
+            mbls_aggregate_verify_batch(ctx(), sigs.as_ptr(), msgs.as_ptr(), 0, msg_off.as_ptr(), pks.as_ptr(), pair_off.as_ptr(), 0, n as u64, res.as_mut_ptr(), std::ptr::null_mut())
+        };
+        if rc != 0 {
+            err(rc);
+        }
+        res.into_iter().zip(mismatch).map(|(b, bad)| b == 1 && !bad).collect()
     }
     /// n x `Signature::verify`.
     pub fn verify(signatures: &[Signature], messages: &[[u8; 32]], public_keys: &[&PublicKey]) -> Vec<bool> {

@@ -219,3 +219,85 @@ def test_fuzz_invariant_accepted_encodings_reencode_to_themselves(mb):
         assert (errs[i] == 0) == (e == 0), i
         if e == 0:
             assert in_g2[i] == orc.g2_subgroup_check(pt), i
+
+
+def test_aggregate_verify_batch_vs_oracle(mb):
+    """mbls_aggregate_verify_batch: n x AggregateSignature::aggregate_verify (reference src/aggregates.rs:130-170; its tests :808-929) in one
+    call -- ragged pair counts (0, 1, 2 ... 9 pairs, one item of 70), ragged message lengths, and per item one of: valid, repeated message
+    (:833-860), wrong signature (:864-891), a message swapped, a key at infinity whose signer is left out of / kept in the aggregate, an
+    undecodable key, a signature outside G2, the infinite signature, no pairs at all -- every item against the oracle."""
+    rnd = random.Random(77)
+    pool = 40
+    sks = [rnd.randrange(1, helpers.R) for _ in range(pool)]
+    pks = [orc.sk_to_pk(s) for s in sks]
+    inf_pk = bytes([0x40]) + bytes(95)
+    probe = bytes.fromhex(helpers.load_vectors()["model"]["g2_subgroup_probes"][1]["compressed"])
+    kinds = ["valid", "repeat", "wrong_sig", "swap_msg", "inf_key_out", "inf_key_in", "bad_key", "not_in_g2", "inf_sig", "empty", "valid", "valid"]
+    n = 96
+    sigs, all_msgs, all_keys, off, want, tags = [], [], [], [0], [], []
+    for i in range(n):
+        kind = kinds[i % len(kinds)]
+        cnt = 70 if i == 50 else 0 if kind == "empty" else max(2 if kind in ("swap_msg", "inf_key_out", "inf_key_in") else 1, rnd.randrange(1, 10))
+        who = [rnd.randrange(pool) for _ in range(cnt)]
+        msgs = [rnd.randbytes(rnd.randrange(0, 70)) for _ in range(cnt)]
+        if kind == "repeat" and cnt >= 2:
+            msgs[1] = msgs[0]
+        keys = [pks[j] for j in who]
+        signers = list(range(cnt))
+        if kind == "inf_key_out":
+            keys[-1] = inf_pk; signers = signers[:-1]
+        elif kind == "inf_key_in":
+            keys[-1] = inf_pk
+        agg = None
+        for t in signers:
+            p = orc.sign(msgs[t], sks[who[t]])
+            agg = p if agg is None else orc.g2_add(agg, p)
+        sigc = orc.g2_compress(agg) if agg is not None else helpers.G2_INF
+        if kind == "wrong_sig":
+            sigc = orc.g2_compress(orc.sign(b"something else", sks[who[0]]))
+        elif kind == "swap_msg":
+            msgs[0], msgs[1] = msgs[1], msgs[0]
+            if msgs[0] == msgs[1]:
+                msgs[0] = msgs[0] + b"x"
+        elif kind == "bad_key":
+            keys[0] = b"\xff" * 96
+        elif kind == "not_in_g2":
+            sigc = probe
+        elif kind == "inf_sig":
+            sigc = helpers.G2_INF
+        e, pt = orc.g2_from_compressed(sigc)
+        w = False if (e or cnt == 0 or kind == "bad_key") else orc.aggregate_verify(pt, msgs, keys)
+        sigs.append(sigc); all_msgs += msgs; all_keys += keys; off.append(off[-1] + cnt); want.append(w); tags.append(kind)
+    assert any(want) and want.count(False) > 30
+    for kind, w in zip(tags, want):
+        assert w == (kind in ("valid", "repeat", "inf_key_out")), kind
+    moff = [0]
+    for m in all_msgs:
+        moff.append(moff[-1] + len(m))
+    got, st = mb.aggregate_verify_batch(b"".join(sigs), b"".join(all_msgs), b"".join(all_keys), n, pair_offsets=off, msg_offsets=moff)
+    assert got == want
+    for i, kind in enumerate(tags):
+        if kind == "empty":
+            assert st[i] & 0x10
+        elif kind == "bad_key":
+            assert st[i] & 0x04
+        elif kind == "not_in_g2":
+            assert st[i] & 0x02
+        elif want[i]:
+            assert st[i] == 0
+    # uniform layout: k pairs and 32-byte messages per item, 300 items (the pairs fill more than one wave per level)
+    n2, k2 = 300, 4
+    who = [[rnd.randrange(pool) for _ in range(k2)] for _ in range(n2)]
+    msgs = [[rnd.randbytes(32) for _ in range(k2)] for _ in range(n2)]
+    sigs2, want2 = [], []
+    for i in range(n2):
+        agg = None
+        for t in range(k2):
+            p = orc.sign(msgs[i][t], sks[who[i][t]])
+            agg = p if agg is None else orc.g2_add(agg, p)
+        if i % 5 == 3:
+            msgs[i][2] = bytes([msgs[i][2][0] ^ 4]) + msgs[i][2][1:]
+        sigs2.append(orc.g2_compress(agg)); want2.append(i % 5 != 3)
+    got2, _ = mb.aggregate_verify_batch(b"".join(sigs2), b"".join(b"".join(m) for m in msgs), b"".join(pks[j] for w in who for j in w), n2, k=k2)
+    assert got2 == want2
+    assert mb.aggregate_verify_batch(b"", b"", b"", 0, k=3) == ([], [])
