@@ -6,11 +6,11 @@ tag, stats, fetch, write, sq, bench = sys.argv[1:7]
 import glob
 shutil.copy(glob.glob(stats + "/*_kernel_stats.csv")[0], "profiles/%s_kernel_stats.csv" % tag)
 import os
-for cfg, name in (("c2", "config2"), ("c4", "config4"), ("clat", "latency_n64")):          # BASELINE configs[1], configs[3], the small-batch path
+for cfg, name in (("c2", "config2"), ("c4", "config4"), ("clat", "latency_n64"), ("cmid", "n16384")):          # BASELINE configs[1], configs[3], the small-batch path
     g = glob.glob(os.path.dirname(stats.rstrip("/")) + "/stats_%s/*_kernel_stats.csv" % cfg)
     if g:
         shutil.copy(g[0], "profiles/%s_%s_kernel_stats.csv" % (tag, name))
-for extra in ("latency.json", "kstats.txt", "bench_line_131072.json", "keyops.json"):
+for extra in ("latency.json", "kstats.txt", "bench_line_131072.json", "keyops.json", "throughput_vs_n.json", "icache_footprint.txt"):
     src = os.path.join(os.path.dirname(stats.rstrip("/")), extra)
     if os.path.exists(src):
         shutil.copy(src, "profiles/%s_%s" % (tag, {"kstats.txt": "kernel_resources.txt"}.get(extra, extra)))

@@ -11,7 +11,7 @@ export TMPDIR=/tmp
 B="python3 $ROOT/bench.py --no-cpu-baseline --no-variants"
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o $TAG -- $B --steps 5 --warmup 1 > $OUT/stats_bench.json 2> $OUT/stats.err
-for CFG in 2 4 lat; do
+for CFG in 2 4 lat mid; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_c$CFG -o c$CFG -- python3 $ROOT/scripts/run_config.py $CFG > /dev/null 2> $OUT/stats_c$CFG.err
 done
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -o f -- $B --steps 2 --warmup 1 > /dev/null 2> $OUT/fetch.err
@@ -24,5 +24,7 @@ python3 bench.py --items 131072 --steps 5 --warmup 1 --no-cpu-baseline > $OUT/be
 python3 scripts/latency.py $OUT/latency.json > $OUT/latency.log 2>&1
 python3 scripts/time_keyops.py > $OUT/keyops.log 2>&1; cp gpurun_out/keyops.json $OUT/keyops.json
 bash scripts/kstats.sh > $OUT/kstats.txt 2>&1
+python3 scripts/throughput_vs_n.py $TAG > $OUT/sweep.log 2>&1; cp gpurun_out/${TAG}_throughput_vs_n.json $OUT/throughput_vs_n.json
+[ -x scripts/dbg/icbench ] && ./scripts/dbg/icbench > $OUT/icache_footprint.txt 2>&1
 find $OUT -name "*.csv" -size +20M -delete
 ls -la $OUT $OUT/stats $OUT/fetch 2>/dev/null | head -40

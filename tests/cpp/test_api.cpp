@@ -60,7 +60,12 @@ int main() {
     { AggregateSignature dbl = agg; dbl.add(Signature::new_(msg, kps[0].sk)); CHECK(!dbl.fast_aggregate_verify_pre_aggregated(msg, apk)); }
     // src/aggregates.rs:808-929: aggregate_verify, distinct messages; length mismatch -> false
     { std::vector<Bytes> msgs; AggregateSignature a; for (int i = 0; i < 4; i++) { msgs.push_back(Bytes(32, uint8_t(i))); a.add(Signature::new_(msgs[i], kps[i].sk)); }
-      CHECK(a.aggregate_verify(msgs, pks)); msgs.pop_back(); CHECK(!a.aggregate_verify(msgs, pks)); }
+      CHECK(a.aggregate_verify(msgs, pks));
+      // the batched form: the same item three times -- as is, with a message flipped, with one message missing (:131-133) -- and an item without pairs
+      { auto bad = msgs; bad[2][0] ^= 1; auto shortm = msgs; shortm.pop_back();
+        auto r = aggregate_verify_batch({a, a, a, a}, {msgs, bad, shortm, {}}, {pks, pks, pks, {}});
+        CHECK(r.size() == 4 && r[0] && !r[1] && !r[2] && !r[3]); }
+      msgs.pop_back(); CHECK(!a.aggregate_verify(msgs, pks)); }
     // src/aggregates.rs:688-805: verify_multiple_aggregate_signatures, valid then one set signed with the wrong key
     { std::vector<AggregateSignature> sigs(3); std::vector<AggregatePublicKey> apks; std::vector<std::tuple<const AggregateSignature*, const AggregatePublicKey*, Bytes>> sets;
       for (int i = 0; i < 3; i++) { Bytes m(32, uint8_t(i)); sigs[i].add(Signature::new_(m, kps[i].sk)); apks.push_back(AggregatePublicKey::from_public_key(kps[i].pk)); }

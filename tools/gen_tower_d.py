@@ -653,7 +653,7 @@ class AllocD:
             return ROUTINES[kind]["ins"][ins.index(d)]
         return None
 
-    def prefetch(self, k, horizon=3, avoid=()):
+    def prefetch(self, k, horizon=int(os.environ.get("MBLS_GEN_PREFETCH_HORIZON", "3")), avoid=()):
         """before a multiplication call: issue the HBM loads of values that the next few operations need and that only live in their
         workspace home, into free blocks outside the routines' window (no eviction: a prefetch must not cost a spill)"""
         calls, j = 0, k + 1
@@ -1461,6 +1461,8 @@ def prog_miller_dbl_d(pairs=(0, 1)):
     merge = MERGE_LINES and len(pairs) == 2
     if not merge:
         f = p.sqr12(f)
+    elif F2_FIRST:                                   # f^2 needs nothing from the workspace: the fetches of the running points travel under it
+        f2 = p.sqr12(f)
     lines = []
     for k in pairs:
         c0, c2, c3 = dbl_point_and_line(p, k, p1)
@@ -1470,12 +1472,13 @@ def prog_miller_dbl_d(pairs=(0, 1)):
             f = line_into_f(p, f, c0, c2, c3, k)
     if merge:                                        # the two lines are multiplied together first: 6 + 17 instead of 13 + 13 products
         L0, L1 = mul_lines(p, lines[0], lines[1])
-        f = mul12_by_lines(p, p.sqr12(f), L0, L1)
+        f = mul12_by_lines(p, f2 if F2_FIRST else p.sqr12(f), L0, L1)
     f_store(p, f)
     return p
 
 
 MERGE_LINES = True
+F2_FIRST = os.environ.get("MBLS_GEN_F2_FIRST", "0") == "1"
 
 
 def prog_miller_add_d(k):
