@@ -661,6 +661,13 @@ class AllocD:
         while j < len(self.p.ops) and calls < horizon:
             kind, outs, ins, aux = self.p.ops[j]
             for v in ins:
+                if LDS_PREFETCH and self.loc.get(v, ("", 0))[0] == "l" and v not in ins_now:
+                    # a value parked in LDS that one of the next operations needs: read it back now, into a free block, so that the read's
+                    # latency passes under the product scan instead of in front of the operation (no eviction, like the HBM prefetches)
+                    b = self.free_block("v", self.free_v, avoid)
+                    if b is not None:
+                        self.copy(self.loc[v], ("v", b)); self.place(v, ("v", b))
+                    continue
                 if self.loc.get(v, ("", 0))[0] in ("g", "gd", "gk", "gka", "gv") and v in self.home:
                     b = self.free_block("v", self.free_v, avoid)
                     if b is None:                            # take the block whose value is needed last, if that is later than this use
@@ -1159,7 +1166,8 @@ class AllocD:
                 b = self.alloc_v(k, avoid=busy)
                 self.copy(("v", s), ("v", b)); self.place(w, ("v", b))
         # 3. operands into their slots. The routines preserve blocks 0..3, so an operand that lives on simply stays tracked there.
-        for s, v in want.items():
+        # (operands that come from LDS first: their reads are in flight while the others are moved)
+        for s, v in sorted(want.items(), key=lambda sv: (0 if self.loc[sv[1]][0] == "l" else 1, sv[0])):
             if self.loc[v] == ("v", s):
                 continue
             if self.loc[v][0] == "vw":
@@ -1478,6 +1486,7 @@ def prog_miller_dbl_d(pairs=(0, 1)):
 
 
 MERGE_LINES = True
+LDS_PREFETCH = os.environ.get("MBLS_GEN_LDS_PREFETCH", "1") == "1"
 F2_FIRST = os.environ.get("MBLS_GEN_F2_FIRST", "0") == "1"
 
 
