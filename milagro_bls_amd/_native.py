@@ -35,6 +35,7 @@ SIGNATURES = {
     "mbls_ctx_set_coop_hash_max_items": (C.c_int, [vp, C.c_uint64]),
     "mbls_ctx_set_coop_packing": (C.c_int, [vp, C.c_uint64, C.c_uint64, C.c_uint64]),
     "mbls_ctx_set_round_items": (C.c_int, [vp, C.c_uint64]),
+    "mbls_ctx_reset_tuning": (C.c_int, [vp]),
     "mbls_ctx_set_lane_shaping": (C.c_int, [vp, C.c_uint64, C.c_uint64]),
     "mbls_last_error": (C.c_char_p, [vp]),
     "mbls_fast_aggregate_verify_batch_device": (C.c_int, [vp, vp, vp, C.c_uint32, vp, vp, C.c_int, vp, C.c_uint64, C.c_uint32, vp, vp, vp, vp]),
@@ -177,6 +178,10 @@ class Context:
     def set_lane_shaping(self, split_max_items, fork_max_items):
         """one-lane path below a full round: two lanes per item in the Miller phase up to split_max_items, front phases side by side up to fork_max_items"""
         self.check(lib().mbls_ctx_set_lane_shaping(self._h, split_max_items, fork_max_items))
+
+    def reset_tuning(self):
+        """every routing parameter (engine crossovers, packing, round, lane shaping) back to the library's defaults"""
+        self.check(lib().mbls_ctx_reset_tuning(self._h))
 
     def set_round_items(self, items):
         """items per round of the one-lane kernels (0: the device's CUs x 4 x 64); a batch's remainder above whole rounds is routed on its own"""

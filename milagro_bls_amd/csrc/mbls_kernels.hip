@@ -197,6 +197,19 @@ __global__ void MBLS_LB k_final(mbls_ws ws, uint32_t* status, uint8_t* results, 
     uint32_t st = status[i]; uint8_t r; lane_final(ws, i, &st, &r, (MBLS_LDS uint32_t*)accstore, threadIdx.x, true); status[i] = st; results[i] = r;
 }
 
+// The final exponentiation with TWO lanes per item (batches of at most half a round: the SIMDs a one-lane launch would leave idle do half of
+// every compressed squaring): lanes 2 j, 2 j + 1 of a workgroup = item 32 blockIdx + j. Both lanes end with the same value; the even one reports.
+__global__ void MBLS_LB k_final2(mbls_ws ws, uint32_t* status, uint8_t* results, uint64_t n) {
+    __shared__ uint32_t accstore[154 * 64];       // one column per ITEM: the two lanes of an item park identical values in it
+    const uint64_t t = gid(); if (t >= 2 * n) return;
+    const uint64_t i = t >> 1;
+#if MBLS_DEVICE_ASM
+    uint32_t st = status[i]; uint8_t r;
+    lane_final2(ws, i, &st, &r, (MBLS_LDS uint32_t*)accstore, threadIdx.x);
+    if ((t & 1) == 0) { status[i] = st; results[i] = r; }
+#endif
+}
+
 // accept bitmap: one 64-bit word per wave via ballot
 __global__ void MBLS_LB k_pack(const uint8_t* results, uint64_t* bitmap, uint64_t n) {
     uint64_t i = gid();
@@ -501,6 +514,11 @@ __global__ void __launch_bounds__(WG) k_valu_bench(uint32_t* sink, uint32_t iter
 // creation per call once the sizes have been seen); device-pointer entries only enqueue, and order their use of the
 // workspace against earlier calls on other streams with an event.
 #define MBLS_N_STAGE 10
+// measured crossovers (scripts/throughput_vs_n.py, 128 keys, device-resident): one wave per item for the pairing check wins up to ~8 k items
+// (16.7 ms at 8 192; the one-lane path with two lanes per item in the Miller loop and the final exponentiation needs 16.6 ms for anything up
+// to half a round), for the message phase as well up to ~6 k
+#define MBLS_DEFAULT_COOP_MAX_ITEMS 8192
+#define MBLS_DEFAULT_COOP_HASH_MAX_ITEMS 6144
 struct mbls_ctx {
     std::recursive_mutex mu;
     int device = 0;
@@ -527,8 +545,8 @@ struct mbls_ctx {
     uint32_t* d_coop = nullptr;
     // measured crossovers (scripts/coop_sweep.py, 128 keys, device-resident): one wave per item for the pairing check wins up to ~10 k items
     // (19.7 ms at 10 240 against 22.5), for the message phase as well up to ~6 k (13.3 ms at 6 144 against 14.0; four items per wave above 768)
-    uint64_t coop_hash_max_items = 6144;
-    uint64_t coop_max_items = 10240;
+    uint64_t coop_hash_max_items = MBLS_DEFAULT_COOP_HASH_MAX_ITEMS;
+    uint64_t coop_max_items = MBLS_DEFAULT_COOP_MAX_ITEMS;
     // within (pack_min, pack_max] a wave serves two items (pairing check) / four items (message phase) side by side: more steps per wave, fewer per item
     uint64_t coop_pack_min_items = 1024, coop_pack_max_items = 2048, coop_hash_pack_min_items = 768;
     // one ROUND of the one-lane kernels = one wave on every SIMD (512 registers per lane: one wave per SIMD) = CUs x 4 x 64 items. A batch of
@@ -610,6 +628,7 @@ static void ctx_free(mbls_ctx* c) {
     if (c->hs_d) (void)hipStreamDestroy(c->hs_d);
     delete c;
 }
+static void ctx_default_tuning(mbls_ctx* c);
 extern "C" int mbls_ctx_create(mbls_ctx** out, int device_id) {
     if (!out) return MBLS_ERR_ARGUMENT;
     int cnt = 0;
@@ -652,17 +671,7 @@ extern "C" int mbls_ctx_create(mbls_ctx** out, int device_id) {
             c->coop[p].steps = dp[0]; c->coop[p].rows = dp[1]; c->coop[p].consts = dp[2]; c->coop[p].nconsts = nconst[p];
             c->coop[p].lpi = dims[p][0]; c->coop[p].nslots = dims[p][1];
         }
-        const char* e = getenv("MBLS_COOP_MAX_ITEMS");
-        if (e) c->coop_max_items = strtoull(e, nullptr, 10);
-        e = getenv("MBLS_COOP_HASH_MAX_ITEMS");
-        if (e) c->coop_hash_max_items = strtoull(e, nullptr, 10);
-        hipDeviceProp_t prop;
-        if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0) c->round_items = (uint64_t)prop.multiProcessorCount * 4 * WG;
-        c->split_max_items = c->round_items / 2; c->fork_max_items = c->round_items - 1;
-        e = getenv("MBLS_SPLIT_MAX_ITEMS");
-        if (e) c->split_max_items = strtoull(e, nullptr, 10);
-        e = getenv("MBLS_FORK_MAX_ITEMS");
-        if (e) c->fork_max_items = strtoull(e, nullptr, 10);
+        ctx_default_tuning(c);
     }
     if (!ok) { ctx_free(c); return MBLS_ERR_DEVICE; }
     *out = c; return MBLS_OK;
@@ -679,6 +688,25 @@ extern "C" int mbls_ctx_set_coop_hash_max_items(mbls_ctx* c, uint64_t max_items)
 extern "C" int mbls_ctx_set_coop_packing(mbls_ctx* c, uint64_t pairing_min_items, uint64_t pairing_max_items, uint64_t hash_min_items) {
     if (!c) return MBLS_ERR_ARGUMENT;
     mbls_lock lk(c->mu); c->coop_pack_min_items = pairing_min_items; c->coop_pack_max_items = pairing_max_items; c->coop_hash_pack_min_items = hash_min_items; return MBLS_OK;
+}
+// every routing parameter back to its default (what mbls_ctx_create sets, environment included)
+static void ctx_default_tuning(mbls_ctx* c) {
+    c->coop_max_items = MBLS_DEFAULT_COOP_MAX_ITEMS; c->coop_hash_max_items = MBLS_DEFAULT_COOP_HASH_MAX_ITEMS;
+    c->coop_pack_min_items = 1024; c->coop_pack_max_items = 2048; c->coop_hash_pack_min_items = 768;
+    hipDeviceProp_t prop;
+    c->round_items = 65536;
+    if (hipGetDeviceProperties(&prop, c->device) == hipSuccess && prop.multiProcessorCount > 0) c->round_items = (uint64_t)prop.multiProcessorCount * 4 * WG;
+    c->split_max_items = c->round_items / 2; c->fork_max_items = c->round_items - 1;
+    const char* e;
+    if ((e = getenv("MBLS_COOP_MAX_ITEMS"))) c->coop_max_items = strtoull(e, nullptr, 10);
+    if ((e = getenv("MBLS_COOP_HASH_MAX_ITEMS"))) c->coop_hash_max_items = strtoull(e, nullptr, 10);
+    if ((e = getenv("MBLS_SPLIT_MAX_ITEMS"))) c->split_max_items = strtoull(e, nullptr, 10);
+    if ((e = getenv("MBLS_FORK_MAX_ITEMS"))) c->fork_max_items = strtoull(e, nullptr, 10);
+}
+extern "C" int mbls_ctx_reset_tuning(mbls_ctx* c) {
+    if (!c) return MBLS_ERR_ARGUMENT;
+    mbls_lock lk(c->mu);
+    ctx_default_tuning(c); return MBLS_OK;
 }
 // items per round of the one-lane kernels (default: CUs x 4 SIMDs x 64 lanes); batches above it have their remainder routed as a batch of its own
 extern "C" int mbls_ctx_set_round_items(mbls_ctx* c, uint64_t items) {
@@ -862,7 +890,8 @@ static int verify_pipeline_one(mbls_ctx* c, const uint8_t* d_sigs, const uint8_t
             if (fused_sig) hipLaunchKernelGGL(k_sig_verdict, dim3(g), dim3(WG), 0, s, ws, st, n, (uint64_t)0, 0);
         }
         if (tm) HIPCHK(c, hipEventRecord(c->ev[4], s));
-        hipLaunchKernelGGL(k_final, dim3(g), dim3(WG), 0, s, ws, st, d_results, n);
+        if (split) hipLaunchKernelGGL(k_final2, dim3(nblk(2 * n)), dim3(WG), 0, s, ws, st, d_results, n);      // two lanes per item here too
+        else hipLaunchKernelGGL(k_final, dim3(g), dim3(WG), 0, s, ws, st, d_results, n);
         if (tm) HIPCHK(c, hipEventRecord(c->ev[5], s));
     }
     if (d_bitmap) hipLaunchKernelGGL(k_pack, dim3(g), dim3(WG), 0, s, d_results, d_bitmap, n);
@@ -1604,7 +1633,8 @@ extern "C" int mbls_aggregate_verify_batch_device(mbls_ctx* c, const uint8_t* d_
         hipLaunchKernelGGL(k_f12_seg_tree_d, dim3(nblk(total)), dim3(WG), 0, s, wp, (const uint32_t*)map, d_pair_off, k, total, half);
     hipLaunchKernelGGL(k_f12_seg_gather, dim3(nblk(n)), dim3(WG), 0, s, ws, d_pair_off, k, n, total, st_item, (const uint32_t*)st_pair);
     hipLaunchKernelGGL(k_f12_tree_d, dim3(nblk(n)), dim3(WG), 0, s, ws, 2 * n + total, n + total);
-    hipLaunchKernelGGL(k_final, dim3(nblk(n)), dim3(WG), 0, s, ws, st_item, d_results, n);
+    if (n <= c->split_max_items && 2 * n <= c->round_items) hipLaunchKernelGGL(k_final2, dim3(nblk(2 * n)), dim3(WG), 0, s, ws, st_item, d_results, n);
+    else hipLaunchKernelGGL(k_final, dim3(nblk(n)), dim3(WG), 0, s, ws, st_item, d_results, n);
     HIPCHK(c, hipGetLastError());
     return ws_release(c, s);
 }

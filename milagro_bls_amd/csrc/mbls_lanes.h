@@ -356,6 +356,19 @@ MBLS_FN uint32_t lane_sig_verdict(const mbls_ws& ws, uint64_t i, uint64_t t_item
     const bool same = !fp2_is_zero(Z) & fp2_eq(fp2_mul(px, Z), X) & fp2_eq(fp2_mul(py, Z), fp2_neg(Y));      // psi(sig) = [x] sig = -[|x|] sig
     return (!same & !fp2_is_zero(qy)) ? MBLS_ST_SIG_NOT_IN_G2 : 0u;
 }
+#if MBLS_DEVICE_ASM && !defined(MBLS_NO_FP2_ASM)
+// two lanes per item (k_final2): both lanes come back with the same value; `result` / `status` as lane_final
+MBLS_FN void lane_final2(const mbls_ws& ws, uint64_t i, uint32_t* status, uint8_t* result, MBLS_LDS uint32_t* ls, uint32_t lane) {
+    fp12 f;
+    final_exp_ws_d2(&f, ws.w, ws.stride, i, ls, lane);
+    uint32_t st = *status;
+    if (!fp12_is_one(&f)) st |= MBLS_ST_PAIRING_FAILED;
+    *status = st;
+    const uint32_t reject = MBLS_ST_BAD_SIG_ENCODING | MBLS_ST_SIG_NOT_IN_G2 | MBLS_ST_BAD_PK_ENCODING |
+                            MBLS_ST_APK_INFINITY | MBLS_ST_NO_KEYS | MBLS_ST_PAIRING_FAILED | MBLS_ST_BAD_MSG_RANGE;
+    *result = (st & reject) ? 0 : 1;
+}
+#endif
 MBLS_FN void lane_final(const mbls_ws& ws, uint64_t i, uint32_t* status, uint8_t* result, MBLS_LDS uint32_t* ls = nullptr, uint32_t lane = 0, bool use_lds = false) {
     fp12 f; fp2* c = &f.c0.c0;
 #if MBLS_DEVICE_ASM && !defined(MBLS_NO_FP2_ASM)

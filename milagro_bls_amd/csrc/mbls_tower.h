@@ -248,6 +248,25 @@ MBLS_FN void final_exp_ws_d(fp12* r, uint32_t* ws_w, uint64_t ws_stride, uint64_
     fp* o = &r->c0.c0.c0;
     o[0] = f0; o[1] = f1; o[2] = f2; o[3] = f3; o[4] = f4; o[5] = f5; o[6] = f6; o[7] = f7; o[8] = f8; o[9] = f9; o[10] = f10; o[11] = f11;
 }
+// The same routine for lane PAIRS (tools/gen_tower_d.py, final_exp_d_routine(two_lane=True); kernel k_final2): lanes 2 j and 2 j + 1 of the wave
+// work on ONE item -- both get the item's workspace words and ONE LDS column (everything outside the squaring chains is computed twice, on
+// identical values, so the shared column and the doubled stores are benign) --, and in the 315 compressed squarings each lane does one of
+// the two Fp4 squarings, the roles swapping every iteration, the partner's coefficients through DPP. `item` = the item of THIS lane.
+extern "C" __device__ __attribute__((noinline, used, aligned(64))) void mbls_final_exp2_d_asm_fn() { asm volatile(MBLS_FINAL_EXP2_D_ASM); }
+MBLS_FN void final_exp_ws_d2(fp12* r, uint32_t* ws_w, uint64_t ws_stride, uint64_t item, MBLS_LDS uint32_t* spill, uint32_t lane) {
+    const uint32_t col = lane >> 1;
+    const uint32_t addr = (uint32_t)(uintptr_t)(spill + col);
+    const uint64_t gb = (uint64_t)(uintptr_t)ws_w + 4ull * (item - col) - (uint64_t)(uint32_t)(uintptr_t)spill;
+    const uint32_t gb_lo = __builtin_amdgcn_readfirstlane((uint32_t)gb), gb_hi = __builtin_amdgcn_readfirstlane((uint32_t)(gb >> 32));
+    const uint32_t st4 = __builtin_amdgcn_readfirstlane((uint32_t)(ws_stride * 4));
+    fp f0, f1, f2, f3, f4, f5, f6, f7, f8, f9, f10, f11;
+    asm volatile(MBLS_ASM_CALL("mbls_final_exp2_d_asm_fn")
+                 : MBLS_MILLER_D_OUT_REGS(f)
+                 : "{v252}"(addr), "{s68}"(gb_lo), "{s69}"(gb_hi), "{s70}"(st4)
+                 : MBLS_FINAL_EXP_D_ASM_CLOBBERS);
+    fp* o = &r->c0.c0.c0;
+    o[0] = f0; o[1] = f1; o[2] = f2; o[3] = f3; o[4] = f4; o[5] = f5; o[6] = f6; o[7] = f7; o[8] = f8; o[9] = f9; o[10] = f10; o[11] = f11;
+}
 #endif
 // f^x, x = -0xd201000000010000, f in the cyclotomic subgroup (the compiled version: host emulation and debug builds; the kernels run
 // final_exp_ws_d)

@@ -56,4 +56,4 @@ def engine(request):
                 os.environ.pop(k, None)
             else:
                 os.environ[k] = v
-        ctx.set_coop_max_items(10240); ctx.set_coop_hash_max_items(6144); ctx.set_round_items(0)       # (restores the lane shaping too)
+        ctx.reset_tuning()

@@ -504,6 +504,96 @@ def test_final_exponentiation_routine_full_schedule():
     assert M.f12_eq(wpow(tower), want)
 
 
+def fexp2_sim(runs, seed, lanes=(6, 7)):
+    """the two-lane variant (final_exp_d_routine(two_lane=True), k_final2): two machines in lockstep that share the LDS column and the workspace
+    item, as the kernel sets the two lanes of an item up; the cross-lane moves of the compressed squaring exchange their registers"""
+    from asm_sim import run_pair
+    full, pieces, st = t.final_exp_d_routine(two_lane=True)
+    assert not any("scratch" in l or "buffer_" in l for l in full)
+    rng = random.Random(seed)
+    f = [rng.randrange(P) for _ in range(12)]
+    ma, mb = Machine(FEXP_ROUT), Machine(FEXP_ROUT)
+    mb.lds = ma.lds; mb.mem = ma.mem
+    for m, lane in ((ma, lanes[0]), (mb, lanes[1])):
+        m.lane = lane; m.v[252] = LADDR
+        m.s[68] = GBASE & 0xFFFFFFFF; m.s[69] = GBASE >> 32; m.s[70] = STRIDE * 4
+    for i in range(12):
+        ws_put(ma, t.FEXP_IN_SLOT + i, f[i] * R384 % P)
+    run_pair(ma, mb, pieces["pro"])
+
+    def step(name, rec=0):
+        for m in (ma, mb):
+            m.s[71] = rec * m.s[72]
+        run_pair(ma, mb, pieces[name])
+
+    def power():
+        step("pstart")
+        for ph, n in enumerate(runs):
+            for _ in range(n):
+                step("csqr")
+            step("psave", ph)
+        step("pinv"); step("pfirst", 0)
+        for rec in range(1, 6):
+            step("pmul", rec)
+    step("easy")
+    for k in range(5):
+        power()
+        if k < 4:
+            step(["step_conj", "step_conj", "step_frob", "step_base"][k])
+    step("tail")
+    run_pair(ma, mb, pieces["epi"][:-1])
+    outs = [[from_limbs(m.v[t.F_OUT[i]:t.F_OUT[i] + 12]) for i in range(12)] for m in (ma, mb)]
+    assert outs[0] == outs[1], "the two lanes of an item must end with the same value"
+    return outs[0]
+
+
+def test_two_lane_compressed_squaring_body():
+    """csqr2_body on a lane pair against the Granger-Scott formulas (cyc_sqr_formula restricted to z2..z5) for several squarings in a row:
+    the roles swap every squaring and the pair's four values always make up the state of the one-lane body"""
+    from asm_sim import run_pair
+    rng = random.Random(77)
+    body = t.csqr2_body()
+    assert len(body) < 4000 and sum(1 for l in body if "v_mov_b32_dpp" in l) == 56
+    z = [rng.randrange(P) for _ in range(8)]                       # z2.0, z2.1, z3.0, z3.1, z4.0, z4.1, z5.0, z5.1 (true values)
+    ma, mb = Machine(ROUT), Machine(ROUT)
+    for m in (ma, mb):
+        m.run(t.shell_constants())
+    ma.s[("pair", 92)] = 0; mb.s[("pair", 92)] = 1
+    for k in range(4):
+        ma.v[14 * k:14 * k + 14] = normalised_digits(z[k] * R392 % P)
+        mb.v[14 * k:14 * k + 14] = normalised_digits((z[4 + k] * R392 % P) - (P if k % 2 else 0))      # reduced representatives of either sign
+    f2 = lambda a, b: ((a[0] * b[0] - a[1] * b[1]) % P, (a[0] * b[1] + a[1] * b[0]) % P)
+    xi2 = lambda a: ((a[0] - a[1]) % P, (a[0] + a[1]) % P)
+    for it in range(5):
+        z2, z3, z4, z5 = (z[0], z[1]), (z[2], z[3]), (z[4], z[5]), (z[6], z[7])
+        def fp4(a, b):
+            t0, t1 = f2(a, a), f2(b, b)
+            s_ = f2(((a[0] + b[0]) % P, (a[1] + b[1]) % P), ((a[0] + b[0]) % P, (a[1] + b[1]) % P))
+            return ((xi2(t1)[0] + t0[0]) % P, (xi2(t1)[1] + t0[1]) % P), ((s_[0] - t0[0] - t1[0]) % P, (s_[1] - t0[1] - t1[1]) % P)
+        t0, t1 = fp4(z2, z3); t2, t3 = fp4(z4, z5)
+        n4 = tuple((3 * t0[i] - 2 * z4[i]) % P for i in range(2)); n5 = tuple((3 * t1[i] + 2 * z5[i]) % P for i in range(2))
+        x = xi2(t3)
+        n2 = tuple((3 * x[i] + 2 * z2[i]) % P for i in range(2)); n3 = tuple((3 * t2[i] - 2 * z3[i]) % P for i in range(2))
+        z = [n2[0], n2[1], n3[0], n3[1], n4[0], n4[1], n5[0], n5[1]]
+        run_pair(ma, mb, body)
+        # the lane that was in role A now holds (z4', z5'), the other one (z2', z3'); the role bits have swapped
+        holder_a, holder_b = (mb, ma) if it % 2 == 0 else (ma, mb)          # holder_a: the lane that now holds (z2, z3)
+        assert holder_a.s[("pair", 92)] == 0 and holder_b.s[("pair", 92)] == 1
+        for k in range(4):
+            for m, base in ((holder_a, 0), (holder_b, 4)):
+                got = from_digits_signed(m.v[14 * k:14 * k + 14])
+                assert (got - z[base + k] * R392) % P == 0 and t.REDUCED.vlo <= got <= t.REDUCED.vhi, (it, k, base)
+                assert all(0 <= s32(w) < (1 << 28) for w in m.v[14 * k:14 * k + 13])
+
+
+def test_two_lane_final_exponentiation_routine():
+    """the whole two-lane routine on a lane pair (short schedule, then the real one) gives, on both lanes, what the one-lane routine gives"""
+    got, model, f = fexp_sim([1, 2, 1, 1, 1, 1], 41)
+    assert fexp2_sim([1, 2, 1, 1, 1, 1], 41) == got == model
+    got, model, f = fexp_sim(t.POW_RUNS, 43)
+    assert fexp2_sim(t.POW_RUNS, 43, lanes=(33, 32)) == got == model
+
+
 # ---------------------------------------------------------------------------------------------- the public-key sum
 def g1_model_masks(which, init, masks):
     """the program on field values; returns the model (its masks dictionary is updated in place by iszero / mask_orn2)"""

@@ -38,7 +38,7 @@ def test_both_pairing_paths_agree_with_the_oracle(mb, N, fmt):
             ctx.set_coop_max_items(lim)
             outs.append(mb.fast_aggregate_verify_batch(b.sigs, b.msgs, b.pks, b.n, b.k, pk_format=fmt))
     finally:
-        ctx.set_coop_max_items(10240)
+        ctx.reset_tuning()
     assert outs[0][0] == outs[1][0] == want
     assert outs[0][1] == outs[1][1]
 
@@ -63,7 +63,7 @@ def test_cooperative_verify_with_infinite_members(mb, N):
             got, _ = mb.verify_batch(b"".join(i[0] for i in items), b"".join(i[1] for i in items), b"".join(i[2] for i in items), len(items), pk_format=1)
             assert got == want, lim
     finally:
-        ctx.set_coop_max_items(10240)
+        ctx.reset_tuning()
 
 
 def test_tree_levels_on_both_engines(N):
@@ -128,6 +128,6 @@ def test_packed_programs_agree_with_the_oracle(mb, N, n):
             outs[name] = mb.fast_aggregate_verify_batch(b.sigs, b.msgs, b.pks, b.n, b.k, pk_format=1)
             assert mb.hash_to_g2_batch(b.msgs, n, mode=2) == orc.batch_hash_to_g2(b.msgs, n), name
     finally:
-        ctx.set_coop_packing(1024, 2048, 768)
+        ctx.reset_tuning()
     for name, (got, st) in outs.items():
         assert got == want and st == outs["plain"][1], name

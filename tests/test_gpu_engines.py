@@ -3,8 +3,8 @@ sizes where they are the default route, every routing boundary of the pipeline w
 invariant. One seeded batch of 20 480 items x 2 keys is signed and verified by the oracle once; the tests below verify prefixes of it.
 
 Routing (milagro_bls_amd/csrc/mbls_kernels.hip, verify_pipeline / launch_hash): n <= 768 hashg2 + pairing2, (768, 1024] hashg2x4 + pairing2,
-(1024, 2048] hashg2x4 + pairing2x2, (2048, 6144] hashg2x4 + pairing2, (6144, 10240] k_hash + pairing2, (10240, 32768] k_hash + k_miller_split (the two pairs of an item on two lanes) + product + k_sig_verdict + k_final,
-above 32768 k_hash + k_miller (two-pair loop) + k_sig_verdict + k_final; in both lane forms the signature's subgroup test is read off the
+(1024, 2048] hashg2x4 + pairing2x2, (2048, 6144] hashg2x4 + pairing2, (6144, 8192] k_hash + pairing2, (8192, 32768] k_hash + k_miller_split (the two pairs of an item on two lanes) + product + k_sig_verdict +
+k_final2 (two lanes per item in the compressed squarings), above 32768 k_hash + k_miller (two-pair loop) + k_sig_verdict + k_final; in both lane forms the signature's subgroup test is read off the
 Miller loop's running point. Above a round (65 536 items) the remainder is routed as a batch of its own."""
 import random
 
@@ -16,7 +16,7 @@ import orc
 pytestmark = pytest.mark.gpu
 
 N_BIG = 20480
-BOUNDARIES = [768, 769, 1024, 1025, 2048, 2049, 6144, 6145, 10240, 10241]
+BOUNDARIES = [768, 769, 1024, 1025, 2048, 2049, 6144, 6145, 8192, 8193, 10240, 10241]
 FLAG = {"sig_not_in_g2": 0x02, "apk_infinity": 0x08, "bad_sig_bytes": 0x01, "bad_pk_bytes": 0x04, "flip_msg": 0x40, "wrong_key": 0x40}
 
 
@@ -65,7 +65,7 @@ def test_routing_boundaries_with_default_settings_vs_oracle(mb, big, n):
     (reference src/aggregates.rs:177-215: the same bool whatever the batch size)"""
     from milagro_bls_amd import _native as N
     ctx = N.default_context()
-    ctx.set_coop_max_items(10240); ctx.set_coop_hash_max_items(6144); ctx.set_coop_packing(1024, 2048, 768); ctx.set_round_items(0)
+    ctx.reset_tuning()
     s, m, p = prefix(big, n)
     got, st = mb.fast_aggregate_verify_batch(s, m, p, n, big.k, pk_format=1)
     check(big, got, st, n)
@@ -81,7 +81,7 @@ def test_lane_kernels_20k_items_vs_oracle(mb, big):
         ctx.set_coop_max_items(0); ctx.set_coop_hash_max_items(0); ctx.set_lane_shaping(0, 0)
         got0, st0 = mb.fast_aggregate_verify_batch(big.sigs, big.msgs, big.pks, big.n, big.k, pk_format=1)
     finally:
-        ctx.set_coop_max_items(10240); ctx.set_coop_hash_max_items(6144); ctx.set_round_items(0)
+        ctx.reset_tuning()
     check(big, got0, st0, big.n)
     got1, st1 = mb.fast_aggregate_verify_batch(big.sigs, big.msgs, big.pks, big.n, big.k, pk_format=1)
     assert got1 == got0 and st1 == st0
@@ -99,7 +99,7 @@ def test_lane_and_wave_engines_agree_item_by_item_on_status_words(mb, big):
             ctx.set_coop_max_items(lim); ctx.set_coop_hash_max_items(lim)
             out[name] = mb.fast_aggregate_verify_batch(s, m, p, n, big.k, pk_format=1)
     finally:
-        ctx.set_coop_max_items(10240); ctx.set_coop_hash_max_items(6144)
+        ctx.reset_tuning()
     assert out["lanes"] == out["waves"]
     check(big, out["lanes"][0], out["lanes"][1], n)
 
@@ -124,11 +124,11 @@ def test_round_cut_with_small_rounds_every_layout(mb, big):
     s, m, p = prefix(big, n)
     try:
         ctx.set_round_items(128)
-        for lim in (10240, 0):                       # the remainder on waves / on lanes
+        for lim in (1 << 20, 0):                     # the remainder on waves / on lanes
             ctx.set_coop_max_items(lim)
             got, st = mb.fast_aggregate_verify_batch(s, m, p, n, big.k, pk_format=1)
             check(big, got, st, n)
-        ctx.set_coop_max_items(10240)
+        ctx.reset_tuning()
         # ragged: item i keeps its two keys, but through an offset table that starts at 5; messages through an offset table
         koff = [5 + 2 * i for i in range(n + 1)]
         moff = [32 * i for i in range(n + 1)]
@@ -156,7 +156,7 @@ def test_round_cut_with_small_rounds_every_layout(mb, big):
         assert bits == [int(x) for x in got]
         tab.close()
     finally:
-        ctx.set_round_items(0); ctx.set_coop_max_items(10240)
+        ctx.reset_tuning()
 
 
 def test_fuzz_invariant_accepted_encodings_reencode_to_themselves(mb):

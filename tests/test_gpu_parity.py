@@ -240,7 +240,7 @@ def test_signature_subgroup_verdict_out_of_the_miller_loop_vs_oracle(mb):
             assert got == want, (lim, split)
             assert [(x & 0x02) == 0 for x in st] == want_in, (lim, split)
     finally:
-        ctx.set_coop_max_items(10240); ctx.set_round_items(0)
+        ctx.reset_tuning()
     # a real signature next to them still verifies on the one-lane path, and the same signature shifted by a point of order 13 does not
     sk = 777; msg = b"m" * 32
     good = orc.g2_compress(orc.sign(msg, sk))
@@ -250,7 +250,7 @@ def test_signature_subgroup_verdict_out_of_the_miller_loop_vs_oracle(mb):
             ctx.set_coop_max_items(0); ctx.set_lane_shaping(split, (1 << 64) - 1)
             got, st = mb.verify_batch(good + shifted, msg * 2, orc.sk_to_pk(sk) * 2, 2, pk_format=1)
         finally:
-            ctx.set_coop_max_items(10240); ctx.set_round_items(0)
+            ctx.reset_tuning()
         assert got == [True, False] and st[0] == 0 and st[1] & 0x02
 
 

@@ -22,6 +22,8 @@ class Machine:
         self.count = 0
         self.calls = 0
         self.scc = 0
+        self.lane = 0                                # this lane's number within its wave (v_mbcnt_*)
+        self.pair_sync = False                       # set by run_pair
 
     # ---- operand helpers
     _TOK = {}                                        # operand text -> (kind, index / value): every distinct operand is parsed once
@@ -96,6 +98,12 @@ class Machine:
     _LINES = {}                                      # instruction text -> (op, args, rest): parsed once
 
     def run(self, lines):
+        for ev in self.run_gen(lines):
+            raise RuntimeError("cross-lane instruction outside a lane pair (use run_pair): %r" % (ev,))
+
+    def run_gen(self, lines):
+        """the interpreter proper, as a generator: it yields (dst, src) at every cross-lane move (v_mov_b32_dpp) and expects the driver to
+        have written dst before it is resumed (run_pair below); for single-lane code it simply runs to the end"""
         pending_call = None
         for line in lines:
             parsed = self._LINES.get(line)
@@ -111,9 +119,11 @@ class Machine:
                 continue
             op, args, rest, line = parsed
             self.count += 1
+            if self.pair_sync and op[:3] in ("glo", "ds_"):
+                yield None                        # a lane pair stays in step at every memory instruction (see run_pair)
             if op == "CALL":                      # pseudo-instruction of the generator: s_getpc/s_add/s_addc/s_swappc to a routine
                 self.calls += 1
-                self.run(self.routines[args[0]])
+                yield from self.run_gen(self.routines[args[0]])
             elif op in ("s_mov_b32",):
                 self.wr(args[0], self.rd(args[1]))
             elif op == "s_mov_b64":
@@ -182,6 +192,17 @@ class Machine:
                 self.wr(args[0], ((self.rd(args[1]) << self.rd(args[2])) + self.rd(args[3])) & 0xFFFFFFFFFFFFFFFF)
             elif op == "v_lshl_add_u32":
                 self.wr(args[0], (self.rd(args[1]) << self.rd(args[2])) + self.rd(args[3]))
+            elif op == "v_mbcnt_lo_u32_b32":      # with the mask -1: the number of lanes below this one among lanes 0..31
+                assert args[1] == "-1"
+                self.wr(args[0], min(self.lane, 32) + self.rd(args[2]))
+            elif op == "v_mbcnt_hi_u32_b32":      # ... among lanes 32..63, added to the operand: together the lane's number
+                assert args[1] == "-1"
+                self.wr(args[0], max(self.lane - 32, 0) + self.rd(args[2]))
+            elif op == "v_add3_u32":
+                self.wr(args[0], self.rd(args[1]) + self.rd(args[2]) + self.rd(args[3]))
+            elif op == "v_mov_b32_dpp":           # v_mov_b32_dpp vdst, vsrc quad_perm:[1,0,3,2] ...: the value of the NEIGHBOUR lane (lane ^ 1)
+                assert "quad_perm:[1,0,3,2]" in rest and "row_mask:0xf" in rest and "bank_mask:0xf" in rest, line
+                yield (args[0], args[1].split()[0])
             elif op == "v_lshl_or_b32":
                 self.wr(args[0], (self.rd(args[1]) << self.rd(args[2])) | self.rd(args[3]))
             elif op == "v_sub_u32_e32":
@@ -291,6 +312,26 @@ class Machine:
         if cur.strip():
             out.append(cur)
         return out
+
+
+def run_pair(ma, mb, lines):
+    """two lanes of one quad pair (lanes 2 i and 2 i + 1) in lockstep: the same instruction stream on both machines; at every v_mov_b32_dpp
+    with quad_perm [1,0,3,2] each lane receives the other's source register. The machines may share their `lds` / `mem` dictionaries (the
+    two-lane routines give both lanes of an item the same LDS column and workspace item)."""
+    DONE = ("done",)
+    ma.pair_sync = mb.pair_sync = True           # the lanes of a wave execute every instruction together: a load of lane B must not see the store
+    ga, gb = ma.run_gen(lines), mb.run_gen(lines)      # that lane A issues LATER in the stream, so the two machines meet at every memory instruction
+    while True:
+        ea, eb = next(ga, DONE), next(gb, DONE)
+        assert ea == eb, "the two lanes diverged"
+        if ea is DONE:
+            ma.pair_sync = mb.pair_sync = False
+            return
+        if ea is None:
+            continue
+        dst, src = ea
+        va, vb = ma.rd(src), mb.rd(src)
+        ma.wr(dst, vb); mb.wr(dst, va)
 
 
 def f32_bits(x):

@@ -301,11 +301,11 @@ def seq_gaddr(slot, koff=False):
     return L
 
 
-def seq_gstore(reg, slot, koff=False):
-    """12 packed words in reg(0)..reg(11) -> workspace slot"""
+def seq_gstore(reg, slot, koff=False, lane=None):
+    """12 packed words in reg(0)..reg(11) -> workspace slot (lane: a register that replaces LADDR as the lane's byte offset)"""
     L = seq_gaddr(slot, koff)
     for j in range(12):
-        L.append("global_store_dword %s, %s, %s" % (LADDR, reg(j), GADDR))
+        L.append("global_store_dword %s, %s, %s" % (lane or LADDR, reg(j), GADDR))
         if j < 11:
             L += ["s_add_u32 s74, s74, %s" % GSTRIDE, "s_addc_u32 s75, s75, 0"]
     return L
@@ -1895,14 +1895,95 @@ def far_fwd(label):
     return ["s_getpc_b64 s[66:67]", "7:", "s_add_u32 s66, s66, %df-7b" % label, "s_addc_u32 s67, s67, 0", "s_setpc_b64 s[66:67]"]
 
 
-def final_exp_d_routine():
+# ---- two lanes per item (batches that fill at most half of the SIMDs: k_final2). The two lanes of an item (lanes 2 i, 2 i + 1 of a wave: the
+# caller gives both the same LDS column and the same workspace item) run the whole routine side by side on identical values -- except the
+# 315 compressed squarings, 57 % of the routine: the two Fp4 squarings of a squaring do not depend on each other, so each lane does ONE.
+# A lane in role A holds (u, v) = (z2, z3), a lane in role B holds (z4, z5); with (first, second) = fp4_sqr(u, v) = (xi v^2 + u^2, 2 u v)
+#     role A:  z4' = 3 first - 2 z4,       z5' = 3 second + 2 z5      (the partner's u, v)
+#     role B:  z2' = 3 xi second + 2 z2,   z3' = 3 first - 2 z3
+# so after the step the lane that was A holds (z4', z5') and IS role B, and vice versa: the roles swap every squaring (ROLE = the lanes in
+# role B), the partner's (u, v) come through DPP (quad_perm [1,0,3,2]), and one instruction stream serves both roles through selections.
+# 3.7 k instructions per squaring and lane instead of 7.1 k. State: u in VGPR blocks 0, 1, v in 2, 3; everything is explicit (no allocator).
+ROLE = "s[92:93]"
+DPP_SWAP = "quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf"
+VBLK = lambda b: (lambda j: "v%d" % (vb(b) + j))
+CS2_CU, CS2_CV, CS2_LANE = "v84", "v85", "v86"          # block 6: scratch of the squarings, free between them
+
+
+def csqr2_body():
+    """one compressed squaring on a pair of lanes (see above); roles swap at the end"""
+    U0, U1, V0, V1 = VBLK(0), VBLK(1), VBLK(2), VBLK(3)
+    B = [VBLK(i) for i in range(18)]
+    L = []
+    L += fp2_sqr_d_body((U0, U1, B[4], B[5], B[6], B[8], B[9]))                  # t0 = u^2
+    L += fp2_sqr_d_body((V0, V1, B[4], B[5], B[6], B[10], B[11]))                # t1 = v^2
+    for j in range(14):                                                          # w = u + v (digits below 2^29: inside the squaring's limits)
+        L += ["v_add_u32_e64 %s, %s, %s" % (B[12](j), U0(j), V0(j)), "v_add_u32_e64 %s, %s, %s" % (B[13](j), U1(j), V1(j))]
+    L += fp2_sqr_d_body((B[12], B[13], B[4], B[5], B[6], B[14], B[15]))          # (u + v)^2
+    for j in range(14):                                                          # second = (u + v)^2 - t0 - t1 (in blocks 14, 15)
+        L += ["v_sub_u32_e64 %s, %s, %s" % (B[14](j), B[14](j), B[8](j)), "v_sub_u32_e64 %s, %s, %s" % (B[15](j), B[15](j), B[9](j)),
+              "v_sub_u32_e64 %s, %s, %s" % (B[14](j), B[14](j), B[10](j)), "v_sub_u32_e64 %s, %s, %s" % (B[15](j), B[15](j), B[11](j))]
+    for j in range(14):                                                          # first = xi t1 + t0 (blocks 12, 13); xi (c0, c1) = (c0 - c1, c0 + c1)
+        L += ["v_sub_u32_e64 %s, %s, %s" % (B[12](j), B[10](j), B[11](j)), "v_add_u32_e64 %s, %s, %s" % (B[12](j), B[12](j), B[8](j)),
+              "v_add3_u32 %s, %s, %s, %s" % (B[13](j), B[10](j), B[11](j), B[9](j))]
+    for j in range(14):                                                          # xi second (blocks 4, 5)
+        L += ["v_sub_u32_e64 %s, %s, %s" % (B[4](j), B[14](j), B[15](j)), "v_add_u32_e64 %s, %s, %s" % (B[5](j), B[14](j), B[15](j))]
+    for (dst, src) in ((B[16], U0), (B[17], U1), (B[10], V0), (B[11], V1)):      # the partner's u, v (both lanes still hold their old state here)
+        L += ["v_mov_b32_dpp %s, %s %s" % (dst(j), src(j), DPP_SWAP) for j in range(14)]
+    for j in range(14):                                                          # what is tripled: role B ? (xi second, first) : (first, second)
+        L += ["v_cndmask_b32_e64 %s, %s, %s, %s" % (B[8](j), B[12](j), B[4](j), ROLE), "v_cndmask_b32_e64 %s, %s, %s, %s" % (B[9](j), B[13](j), B[5](j), ROLE)]
+    for j in range(14):
+        L += ["v_cndmask_b32_e64 %s, %s, %s, %s" % (B[14](j), B[14](j), B[12](j), ROLE), "v_cndmask_b32_e64 %s, %s, %s, %s" % (B[15](j), B[15](j), B[13](j), ROLE)]
+    L += ["v_cndmask_b32_e64 %s, -2, 2, %s" % (CS2_CU, ROLE), "v_cndmask_b32_e64 %s, 2, -2, %s" % (CS2_CV, ROLE)]
+    for (w, part, dst, c) in ((B[8], B[16], U0, CS2_CU), (B[9], B[17], U1, CS2_CU), (B[14], B[10], V0, CS2_CV), (B[15], B[11], V1, CS2_CV)):
+        L += seq_norm(w)                                                         # digits into [0, 2^28): 3 w + 2 p stays far inside 32 bits
+        for j in range(14):
+            L += ["v_mul_lo_u32 %s, %s, %s" % (part(j), part(j), c), "v_lshl_add_u32 %s, %s, 1, %s" % (dst(j), w(j), part(j)),
+                  "v_add_u32_e64 %s, %s, %s" % (dst(j), dst(j), w(j))]
+        L += seq_reduce(dst)
+    L.append("s_not_b64 %s, %s" % (ROLE, ROLE))
+    return L
+
+
+def pstart2_body():
+    """u, v <- the lane's half of the compressed base Y: even lanes (role A) z2, z3, odd lanes (role B) z4, z5; ROLE <- the odd lanes"""
+    L = ["v_mbcnt_lo_u32_b32 %s, -1, 0" % CS2_LANE, "v_mbcnt_hi_u32_b32 %s, -1, %s" % (CS2_LANE, CS2_LANE),      # the lane's number: its parity is its first role
+         "v_and_b32_e64 %s, 1, %s" % (CS2_LANE, CS2_LANE), "v_cmp_ne_u32_e64 %s, 0, %s" % (ROLE, CS2_LANE)]
+    T = VBLK(4)
+    for k in range(4):
+        dst = VBLK(k)
+        L += seq_gload(dst, Y_SLOT + C_IDX[k], aform=False) + seq_gload(T, Y_SLOT + C_IDX[4 + k], aform=False)
+        L += ["v_cndmask_b32_e64 %s, %s, %s, %s" % (dst(j), dst(j), T(j), ROLE) for j in range(14)]
+        L += seq_reduce(dst)
+    return L
+
+
+def psave2_body():
+    """the lane's half of the compressed state -> the record the run-time offset selects: role A lanes write z2, z3 (slots 0..3 of the
+    record), role B lanes z4, z5 (slots 4..7): the lane offset of the stores carries the difference. The state stays."""
+    T = VBLK(4)
+    L = ["v_mov_b32_e32 %s, %s" % (CS2_LANE, GSTRIDE), "v_mul_lo_u32 %s, %s, 48" % (CS2_LANE, CS2_LANE),          # 4 slots x 12 words
+         "v_cndmask_b32_e64 %s, 0, %s, %s" % (CS2_LANE, CS2_LANE, ROLE), "v_add_u32_e64 %s, %s, %s" % (CS2_LANE, CS2_LANE, LADDR)]
+    for k in range(4):
+        src = VBLK(k)
+        L += ["v_mov_b64_e64 v[%d:%d], v[%d:%d]" % (vb(4) + j, vb(4) + j + 1, vb(k) + j, vb(k) + j + 1) for j in range(0, 14, 2)]
+        L += seq_pack_pass(T) + seq_to32(T) + seq_gstore(T, K_SLOT + k, koff=True, lane=CS2_LANE)
+    return L
+
+
+def final_exp_d_routine(two_lane=False):
     """In:  workspace slots 13..24 = f (2^384 domain, canonical); v252 LDS byte address of the lane's column (11 spill slots);
          s[68:69] workspace base adjusted so that v252 is the lane offset, s70 bytes between consecutive words of a value.
     Out: f^(3 (p^12 - 1) / r) in v108..v251 (twelve groups of 12 words, tower order, canonical, 2^384 domain).
-    Workspace slots 0..24, 31..42 and 49..108 are overwritten."""
+    Workspace slots 0..24, 31..42 and 49..108 are overwritten.
+    two_lane: the variant for lane PAIRS (see above): lanes 2 i and 2 i + 1 come with the same v252 and the same workspace item."""
     bodies, stats = {}, {}
     for name in FEXP_BODIES:
         bodies[name], stats[name] = build_fexp(name)
+    if two_lane:
+        bodies.update(pstart=pstart2_body(), csqr=csqr2_body(), psave=psave2_body())
+        for name in ("pstart", "csqr", "psave"):
+            stats[name] = dict(lines=len(bodies[name]))
     X = lambda name: expand_calls_d(bodies[name])
     POWER, CSQR = 60, 61
     next_rec = ["s_add_u32 %s, %s, s72" % (GKOFF, GKOFF)]
@@ -2816,6 +2897,9 @@ def main():
     txt += emit("MBLS_FINAL_EXP_D_ASM", full) + "\n"
     for kname, v in st.items():
         print("final_exp_d", kname, len(pieces[kname]), "lines", v)
+    full2, pieces2, st2 = final_exp_d_routine(two_lane=True)
+    txt += emit("MBLS_FINAL_EXP2_D_ASM", full2) + "\n"
+    print("final_exp_d two lanes per item: csqr", len(pieces2["csqr"]), "pstart", len(pieces2["pstart"]), "psave", len(pieces2["psave"]), "lines")
     txt += "#define MBLS_FINAL_EXP_D_ASM_CLOBBERS MBLS_MILLER_D_ASM_CLOBBERS, \"v253\", \"s50\", \"s51\", \"s52\", \"s53\", \"s79\", \"s71\", \"s72\", \"s80\", \"s81\", " + ", ".join('\"s%d\"' % i for i in range(84, 100)) + "\n"
     for mode in ("raw", "indexed"):
         full, pieces, st = g1_aggregate_d_routine(mode)
