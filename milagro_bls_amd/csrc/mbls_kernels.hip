@@ -135,6 +135,34 @@ __global__ void MBLS_LB k_hash(mbls_ws ws, const uint8_t* msgs, uint32_t mlen, c
     }
     lane_hash(ws, i, m, len, (MBLS_LDS uint32_t*)spill, threadIdx.x, true);
 }
+// The message phase with TWO lanes per message (batches of at most half a round): lane t = 2 i + e has workspace item t of its own, runs
+// hash_to_field of message i (both lanes: 19 SHA-256 compressions are 2 % of the phase) and ONE map_to_curve -- u_e --, then the even lane adds
+// the neighbour's point, clears the cofactor and leaves H in item 2 i; k_h_compact_a / _b move it to item i (through slots 19..24: item i's
+// slots 7..12 may still be the working slots of another pair's lane while this kernel runs).
+__global__ void MBLS_LB k_hash2(mbls_ws ws, const uint8_t* msgs, uint32_t mlen, const uint64_t* moff, uint32_t* status, uint64_t n) {
+    __shared__ uint32_t spill[154 * 64];
+    const uint64_t t = gid(); if (t >= 2 * n) return;
+    const uint64_t i = t >> 1;
+    const uint8_t* m = msgs + (uint64_t)mlen * i; uint32_t len = mlen;
+    if (moff) {
+        const uint64_t a = moff[i], b = moff[i + 1];
+        const bool bad = b < a || b - a > 0xFFFFFFFFull;
+        m = msgs + (bad ? 0 : a); len = bad ? 0u : (uint32_t)(b - a);
+        if (bad && !(t & 1)) atomicOr(status + i, MBLS_ST_BAD_MSG_RANGE);
+    }
+#if MBLS_DEVICE_ASM
+    hash_fields_to_ws(ws.w, ws.stride, t, m, len, (uint32_t)(t & 1));
+    g2_hash2_d_call(ws, t, (MBLS_LDS uint32_t*)spill, threadIdx.x);
+#endif
+}
+__global__ void __launch_bounds__(WG) k_h_compact_a(mbls_ws ws, uint64_t n) {
+    uint64_t i = gid(); if (i >= n) return;
+    for (int w = 0; w < 72; w++) ws.w[((uint64_t)(19 * 12 + w)) * ws.stride + i] = ws.w[((uint64_t)(MBLS_SLOT_H * 12 + w)) * ws.stride + 2 * i];
+}
+__global__ void __launch_bounds__(WG) k_h_compact_b(mbls_ws ws, uint64_t n) {
+    uint64_t i = gid(); if (i >= n) return;
+    for (int w = 0; w < 72; w++) ws.w[((uint64_t)(MBLS_SLOT_H * 12 + w)) * ws.stride + i] = ws.w[((uint64_t)(19 * 12 + w)) * ws.stride + i];
+}
 // hash_to_field alone (SHA-256 / expand_message_xmd, one lane per item): u0, u1 into slots 31, 32 / 37, 38 -- the input of the cooperative
 // engine's hashg2 program (small batches: one WAVE per item walks the maps, the addition and the cofactor clearing)
 __global__ void MBLS_LB k_hash_fields(mbls_ws ws, const uint8_t* msgs, uint32_t mlen, const uint64_t* moff, uint32_t* status, uint64_t n) {
@@ -571,7 +599,9 @@ typedef std::lock_guard<std::recursive_mutex> mbls_lock;
 
 static inline unsigned nblk(uint64_t n) { return (unsigned)((n + WG - 1) / WG); }
 // the message phase of n items on stream s: one lane per item (k_hash), or -- small batches -- hash_to_field per lane and the rest one wave per item
-static void launch_hash(mbls_ctx* c, mbls_ws ws, const uint8_t* d_msgs, uint32_t msg_len, const uint64_t* d_moff, uint32_t* st, uint64_t n, hipStream_t s);
+// pair_ok: the caller's workspace view holds 2 n items and nothing else uses slots 7..24 / 31..42 of items [0, 2 n) meanwhile -- batches of at most
+// half a round then take two lanes per message (k_hash2)
+static void launch_hash(mbls_ctx* c, mbls_ws ws, const uint8_t* d_msgs, uint32_t msg_len, const uint64_t* d_moff, uint32_t* st, uint64_t n, hipStream_t s, bool pair_ok = false);
 // the per-item key sum from wire-format keys: the generated routine for 96-byte keys (its 16-byte loads want 4-byte alignment),
 // the compiled lane body for 48-byte keys summed in place and for unaligned buffers
 static void launch_aggregate(mbls_ws ws, const uint8_t* d_pks, const uint32_t* d_off, uint32_t k, int fmt, int mode, uint32_t* st, uint64_t n, hipStream_t s) {
@@ -598,7 +628,13 @@ static void coop_run(mbls_ctx* c, int prog, mbls_ws ws, uint64_t first_item, uin
     else
         hipLaunchKernelGGL(k_coop, grid, dim3(64), lds, s, pg, ws, first_item, item_step, partner_step, n_items, st, res, res_mode);
 }
-static void launch_hash(mbls_ctx* c, mbls_ws ws, const uint8_t* d_msgs, uint32_t msg_len, const uint64_t* d_moff, uint32_t* st, uint64_t n, hipStream_t s) {
+static void launch_hash(mbls_ctx* c, mbls_ws ws, const uint8_t* d_msgs, uint32_t msg_len, const uint64_t* d_moff, uint32_t* st, uint64_t n, hipStream_t s, bool pair_ok) {
+    if (pair_ok && !(n <= c->coop_hash_max_items && n <= c->coop_max_items) && n <= c->split_max_items && 2 * n <= c->round_items) {
+        hipLaunchKernelGGL(k_hash2, dim3(nblk(2 * n)), dim3(WG), 0, s, ws, d_msgs, msg_len, d_moff, st, n);
+        hipLaunchKernelGGL(k_h_compact_a, dim3(nblk(n)), dim3(WG), 0, s, ws, n);
+        hipLaunchKernelGGL(k_h_compact_b, dim3(nblk(n)), dim3(WG), 0, s, ws, n);
+        return;
+    }
     if (n <= c->coop_hash_max_items && n <= c->coop_max_items) {
         hipLaunchKernelGGL(k_hash_fields, dim3(nblk(n)), dim3(WG), 0, s, ws, d_msgs, msg_len, d_moff, st, n);
         coop_run(c, n > c->coop_hash_pack_min_items ? COOP_HASHG2X4 : COOP_HASHG2, ws, (uint64_t)0, (uint64_t)1, (uint64_t)0, n, (uint32_t*)nullptr, (uint8_t*)nullptr, COOP_RES_ITEM, s);
@@ -854,7 +890,7 @@ static int verify_pipeline_one(mbls_ctx* c, const uint8_t* d_sigs, const uint8_t
     }
     if (part == 1) {
         hipLaunchKernelGGL(k_sig, dim3(g), dim3(WG), 0, s_sig, ws, d_sigs, st, n, fused_sig ? 0 : 1);
-        launch_hash(c, ws, d_msgs, msg_len, d_moff, st, n, s_msg);
+        launch_hash(c, ws, d_msgs, msg_len, d_moff, st, n, s_msg, split);
         HIPCHK(c, hipGetLastError());
         return MBLS_OK;
     }
@@ -870,7 +906,7 @@ static int verify_pipeline_one(mbls_ctx* c, const uint8_t* d_sigs, const uint8_t
     if (tm) HIPCHK(c, hipEventRecord(c->ev[1], s));
     if (!keys_later) hipLaunchKernelGGL(k_sig, dim3(g), dim3(WG), 0, s_sig, ws, d_sigs, st, n, fused_sig ? 0 : 1);
     if (tm) HIPCHK(c, hipEventRecord(c->ev[2], s));
-    if (!keys_later) launch_hash(c, ws, d_msgs, msg_len, d_moff, st, n, s_msg);
+    if (!keys_later) launch_hash(c, ws, d_msgs, msg_len, d_moff, st, n, s_msg, split);
     if (tm) HIPCHK(c, hipEventRecord(c->ev[3], s));
     if (fork) {      // join
         if (s_sig != s) { HIPCHK(c, hipEventRecord(c->hs_ev2, s_sig)); HIPCHK(c, hipStreamWaitEvent(s, c->hs_ev2, 0)); }
@@ -1680,7 +1716,9 @@ static int verify_multiple_impl(mbls_ctx* c, const uint8_t* d_sigs, const uint8_
     }
     if (!d_rands) ARGFAIL(c, "verify_multiple without blinding scalars is forgeable: rands must not be NULL");
     if (!d_sigs || (!d_msgs && msg_len && !d_moff)) ARGFAIL(c, "null buffer");
-    int rc = mbls_ctx_reserve(c, n); if (rc) return rc;
+    // batches of at most half a round: two lanes per message in the message phase (items [0, 2 n), slots no other chain touches)
+    const bool pair_hash = n <= c->split_max_items && 2 * n <= c->round_items;
+    int rc = mbls_ctx_reserve(c, pair_hash ? 2 * n : n); if (rc) return rc;
     mbls_ws ws; ws.w = c->d_w; ws.stride = c->cap;
     rc = ws_acquire(c, s); if (rc) return rc;
     HIPCHK(c, hipMemsetAsync(c->d_scalar, 0, 64, s));
@@ -1702,7 +1740,7 @@ static int verify_multiple_impl(mbls_ctx* c, const uint8_t* d_sigs, const uint8_
         coop_run(c, COOP_SMILLER, ws, (uint64_t)0, (uint64_t)1, (uint64_t)0, (uint64_t)1, (uint32_t*)nullptr, (uint8_t*)nullptr, COOP_RES_ITEM, s_sig);
         HIPCHK(c, hipEventRecord(c->hs_ev, s_sig));                  // ... and its Miller value (awaited just before the tail)
     }
-    launch_hash(c, ws, d_msgs, msg_len, d_moff, c->d_status, n, s_msg);
+    launch_hash(c, ws, d_msgs, msg_len, d_moff, c->d_status, n, s_msg, pair_hash);
     if (fork) {
         HIPCHK(c, hipEventRecord(c->hs_ev3, s_msg));
         HIPCHK(c, hipStreamWaitEvent(s, c->hs_ev2, 0)); HIPCHK(c, hipStreamWaitEvent(s, c->hs_ev3, 0));

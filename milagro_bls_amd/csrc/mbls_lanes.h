@@ -195,6 +195,17 @@ MBLS_FN void lane_aggregate_indexed(const mbls_ws& ws, uint64_t i, const uint32_
 // the workspace, the running point in AGPRs, `spill` = 11 x 14 dwords per lane of LDS, no lane-private memory.
 extern "C" __device__ __attribute__((noinline, used, aligned(64))) void mbls_g2_subgroup_d_asm_fn() { asm volatile(MBLS_G2_SUBGROUP_D_ASM); }
 extern "C" __device__ __attribute__((noinline, used, aligned(64))) void mbls_g2_hash_tail_d_asm_fn() { asm volatile(MBLS_G2_HASH_TAIL_D_ASM); }
+// two lanes per message (g2_group_routine("hash", two_lane=True); kernel k_hash2): every lane has a workspace item of its own, lanes 2 j and
+// 2 j + 1 are one message; H comes back in the EVEN lane's item
+extern "C" __device__ __attribute__((noinline, used, aligned(64))) void mbls_g2_hash_tail2_d_asm_fn() { asm volatile(MBLS_G2_HASH_TAIL2_D_ASM); }
+MBLS_FN void g2_hash2_d_call(const mbls_ws& ws, uint64_t t, MBLS_LDS uint32_t* spill, uint32_t lane) {
+    const uint32_t addr = (uint32_t)(uintptr_t)(spill + lane);
+    const uint64_t gb = (uint64_t)(uintptr_t)ws.w + 4ull * (t - lane) - (uint64_t)(uint32_t)(uintptr_t)spill;
+    const uint32_t gb_lo = __builtin_amdgcn_readfirstlane((uint32_t)gb), gb_hi = __builtin_amdgcn_readfirstlane((uint32_t)(gb >> 32));
+    const uint32_t st4 = __builtin_amdgcn_readfirstlane((uint32_t)(ws.stride * 4));
+    uint32_t fl = 0;
+    asm volatile(MBLS_ASM_CALL("mbls_g2_hash_tail2_d_asm_fn") : "+{v251}"(fl) : "{v252}"(addr), "{s68}"(gb_lo), "{s69}"(gb_hi), "{s70}"(st4) : MBLS_G2_GROUP_D_ASM_CLOBBERS);
+}
 template <bool HASH>
 MBLS_FN uint32_t g2_group_d_call(const mbls_ws& ws, uint64_t i, MBLS_LDS uint32_t* spill, uint32_t lane) {
     const uint32_t addr = (uint32_t)(uintptr_t)(spill + lane);
@@ -260,7 +271,8 @@ MBLS_FN uint32_t g2_blind_d_call(const mbls_ws& ws, uint64_t i, MBLS_LDS uint32_
 #endif
 // hash_to_field: u0 -> workspace slots 31, 32, u1 -> 37, 38 (2^384 domain); the generated routine takes them from there. A function of
 // its own: its message schedule and digest arrays then stay out of the kernel's frame.
-MBLS_NOINLINE void hash_fields_to_ws(uint32_t* w, uint64_t stride, uint64_t i, const uint8_t* msg, uint32_t mlen) {
+// swap (k_hash2's odd lanes): u1 into the slots of u0 and vice versa -- the lane's map_to_curve body reads the slots of u0.
+MBLS_NOINLINE void hash_fields_to_ws(uint32_t* w, uint64_t stride, uint64_t i, const uint8_t* msg, uint32_t mlen, uint32_t swap = 0) {
     mbls_ws ws; ws.w = w; ws.stride = stride;
     const mbls_u32x8 b0 = expand_xmd_b0(msg, mlen, MBLS_DST_POP, MBLS_DST_POP_LEN);
     mbls_u32x8 prev = 0;
@@ -268,7 +280,7 @@ MBLS_NOINLINE void hash_fields_to_ws(uint32_t* w, uint64_t stride, uint64_t i, c
         mbls_u32x8 hi = expand_xmd_block(b0, prev, 2 * k + 1, MBLS_DST_POP, MBLS_DST_POP_LEN);
         mbls_u32x8 lo = expand_xmd_block(b0, hi, 2 * k + 2, MBLS_DST_POP, MBLS_DST_POP_LEN);
         prev = lo;
-        ws_st(ws, (int)(31 + (k & 1) + 6 * (k >> 1)), i, fp_from_two_digests_v(hi, lo));
+        ws_st(ws, (int)(31 + (k & 1) + 6 * ((k >> 1) ^ swap)), i, fp_from_two_digests_v(hi, lo));
     }
 }
 // spill != nullptr (with use_lds): the subgroup test runs as the generated routine on the coordinates just stored

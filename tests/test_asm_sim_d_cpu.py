@@ -765,9 +765,9 @@ def test_g1_sum_routine_shell(mode):
 
 
 # ---------------------------------------------------------------------------------------------- G2 group routines
-def g2_piece_runner(kind):
+def g2_piece_runner(kind, two_lane=False):
     """(machine, state, step): step(name) runs a body of g2_group_routine(kind) on the machine and the same program on field values"""
-    full, pieces, st = t.g2_group_routine(kind)
+    full, pieces, st = t.g2_group_routine(kind, two_lane) if two_lane else t.g2_group_routine(kind)
     assert not any("scratch" in l or "buffer_" in l for l in full)
     m = miller_machine(0)
     m.run(pieces["pro"])
@@ -778,7 +778,8 @@ def g2_piece_runner(kind):
 
     def step(name):
         m.run(pieces[name])
-        mp = run_model(progs.get(name, lambda: t.prog_g2_glue(name)), state, masks)
+        model_name = "h_start" if name == "h_start2" else name         # the same step on field values: where q1 comes from is the machine's business
+        mp = run_model(progs.get(model_name, lambda: t.prog_g2_glue(model_name)), state, masks)
         for loc, v in mp.out_home.items():
             state[loc] = v
         for slot, v in mp.out_g.items():
@@ -903,6 +904,43 @@ def test_g2_hash_routine():
     got = [(ws_get(m, S["H"] + 2 * e) * ri % P, ws_get(m, S["H"] + 2 * e + 1) * ri % P) for e in range(3)]
     assert jac2_affine(M, *got) == want
 
+
+
+def test_g2_hash_routine_two_lanes_per_message():
+    """k_hash2's routine: the even lane maps u0, the odd lane (a workspace item of its own, 4 bytes further on, u1 in the slots of u0) maps
+    u1 with the SAME body; the even lane then takes q1 from the neighbour's item (h_start2) and goes on alone -- same H as the one-lane
+    routine's model, left in the even lane's item"""
+    M = _g2m()
+    import gen_fp_asm as gf
+    rng = random.Random(12)
+    S = t.G2_SLOTS
+    u = [(rng.randrange(P), rng.randrange(P)) for _ in range(2)]
+    m, state, masks, step, add, ladder = g2_piece_runner("hash", two_lane=True)
+    full, pieces, _ = t.g2_group_routine("hash", two_lane=True)
+    assert sum(1 for l in full if l == "s_and_b64 exec, exec, s[94:95]") == 1 and full.count("s_mov_b64 exec, %s" % t.EXEC_ACT) == 1
+    mb = miller_machine(0); mb.mem = m.mem                       # the odd lane: its own registers and LDS column, the same memory,
+    mb.s[68] = (GBASE + 4) & 0xFFFFFFFF; mb.s[69] = (GBASE + 4) >> 32      # its item one word further on
+    mb.run(pieces["pro"])
+    for mm_ in (m, mb):
+        mm_.routines.update(gf.pow_subroutines()); mm_.routines["mbls_fp_pow_pm3d4_asm_fn"] = gf.pow_body(gf.EXP_PM3D4)
+    for lane, mach in ((0, m), (1, mb)):
+        for i in range(2):
+            for j, w in enumerate(limbs(u[lane][i] * R384 % P)):
+                mach.mem[ws_addr(S["U"] + i, j) + 4 * lane] = w
+        mach.s[71] = 0
+        mach.run(pieces["sswu"])
+        mp = run_model(t.prog_sswu, {("gka", S["U"] + i): u[lane][i] for i in range(2)}, masks)
+        for slot, v in mp.out_g.items():
+            state[("gd", slot[1] + 6 * lane)] = v                # the model keeps q1 where the one-lane routine has it
+    m.s[71] = 4
+    step("h_start2"); add(); step("h_base1"); ladder(t.RUNS); step("h_after1"); step("dbl"); step("h_psi2"); add("sub")
+    step("h_t3"); add(); step("h_base2"); ladder(t.RUNS); step("h_after2"); add()
+    step("h_ad_t1"); add("sub"); step("h_ad_p"); add("sub")
+    want = M.clear_cofactor_g2(M.g2_add(M.iso3_g2(M.sswu_g2(u[0])), M.iso3_g2(M.sswu_g2(u[1]))))
+    m.run(pieces["epi"][:-2])
+    ri = pow(R384, -1, P)
+    got = [(ws_get(m, S["H"] + 2 * e) * ri % P, ws_get(m, S["H"] + 2 * e + 1) * ri % P) for e in range(3)]
+    assert jac2_affine(M, *got) == want
 
 
 def test_compressed_squaring_decompression_formulas():

@@ -2480,6 +2480,8 @@ def prog_g2_glue(which):
     one = lambda: (p.const(ONE_D), p.const(0))
     if which == "h_start":                           # acc = q0, AD = q1 (the map_to_curve outputs, packed by the sswu body)
         pt_park(p, gd("Q1"), S["AD"]); pt_store_acc(p, gd("Q0"))
+    elif which == "h_start2":                        # two lanes per message: q1 is what the NEIGHBOUR lane's map left in ITS item's q0 slots
+        pt_park(p, pt_live_in(p, "gk", S["Q0"]), S["AD"]); pt_store_acc(p, gd("Q0"))      # (the run-time offset = one item = 4 bytes)
     elif which == "h_base1":                         # p = q0 + q1: remember it, and it is the ladder's base
         a = acc(); pt_park(p, a, S["P"]); pt_park(p, a, S["AD"]); pt_store_acc(p, a)
     elif which == "h_after1":                        # t1 = -[|x|]p; t2 = psi(p); acc = p (to be doubled)
@@ -2553,20 +2555,25 @@ def call_sub(label):
     return ["s_getpc_b64 s[98:99]", "7:", "s_add_u32 s98, s98, 8f-7b", "s_addc_u32 s99, s99, 0"] + far_fwd(label) + ["8:"]
 
 
-def g2_group_routine(kind):
+def g2_group_routine(kind, two_lane=False):
     """kind 'hash': in  q0 in workspace slots 7..12, q1 in 19..24 (Jacobian, 2^384 domain, canonical); out: clear_cofactor(q0 + q1) in
     slots 7..12 (same form). kind 'sig': in  the signature's affine x, y in slots 3..6; out: v251 = 1 iff psi(P) = [x]P.
-    v252 / s[68:69] / s70: LDS column (11 spill slots) and workspace addressing as in the other routines."""
+    v252 / s[68:69] / s70: LDS column (11 spill slots) and workspace addressing as in the other routines.
+    kind 'hash', two_lane (k_hash2, batches of at most half a round): lanes 2 j and 2 j + 1 are ONE message with workspace items of their own,
+    next to each other; the even lane comes with u0, the odd one with u1 in the slots of u0, each runs ONE map_to_curve, then the odd lanes
+    are switched off and the even ones fetch q1 from the neighbour's item and go on alone: H in the EVEN lane's item."""
     S = G2_SLOTS
     ad = S["AD"] if kind == "hash" else S["SIGAD"]
     B = {}
     st = {}
-    names = ["add", "dbl", "fix"] + (["sswu", "sub", "h_start", "h_base1", "h_after1", "h_psi2", "h_t3", "h_base2", "h_after2", "h_ad_t1", "h_ad_p"] if kind == "hash" else ["madd", "s_start", "s_compare"])
+    names = ["add", "dbl", "fix"] + (["sswu", "sub", "h_start2" if two_lane else "h_start", "h_base1", "h_after1", "h_psi2", "h_t3", "h_base2", "h_after2", "h_ad_t1", "h_ad_p"] if kind == "hash" else ["madd", "s_start", "s_compare"])
     for nm in names:
         B[nm], st[nm] = build_g2(nm, ad)
     X = lambda nm: expand_calls_d(B[nm])
     ADD, SUB, LADDER = 50, 51, 52
     pro = ["s_mov_b64 s[80:81], s[30:31]", "s_waitcnt vmcnt(0)"] + shell_constants() + ["s_mov_b64 %s, exec" % EXEC_ALL]
+    if two_lane:
+        pro += ["s_mov_b64 %s, exec" % EXEC_ACT]    # the caller's exec mask: restored before the return
 
     def fixup():                                    # equal operands (same x, same y, neither at infinity): double the old acc on those lanes
         return ["s_and_b64 s[92:93], %s, %s" % (M_H0, M_R0), "s_andn2_b64 s[92:93], s[92:93], %s" % M_INF1, "s_andn2_b64 s[92:93], s[92:93], %s" % M_INF2,
@@ -2586,8 +2593,13 @@ def g2_group_routine(kind):
         return ["s_getpc_b64 s[96:97]", "7:", "s_add_u32 s96, s96, 8f-7b", "s_addc_u32 s97, s97, 0"] + far_fwd(LADDER) + ["8:"]
     if kind == "hash":
         # the two map_to_curve evaluations: u0 -> q0, u1 -> q1 (records six slots apart)
-        main = ["s_mul_i32 s72, %s, %d" % (GSTRIDE, 12 * 6), "s_mov_b32 %s, 0" % GKOFF] + X("sswu") + ["s_mov_b32 %s, s72" % GKOFF] + X("sswu")
-        main += X("h_start") + call_sub(ADD) + X("h_base1") + call_ladder() + X("h_after1") + X("dbl") + X("h_psi2") + call_sub(SUB)
+        if two_lane:                                # one map per lane; then the even lanes alone, their neighbour's point one item (4 bytes) further on
+            main = ["s_mov_b32 %s, 0" % GKOFF] + X("sswu") + ["s_waitcnt vmcnt(0)", "s_mov_b32 s94, 0x55555555", "s_mov_b32 s95, 0x55555555",
+                                                            "s_and_b64 exec, exec, s[94:95]", "s_mov_b64 %s, exec" % EXEC_ALL, "s_mov_b32 %s, 4" % GKOFF]
+            main += X("h_start2") + call_sub(ADD)
+        else:
+            main = ["s_mul_i32 s72, %s, %d" % (GSTRIDE, 12 * 6), "s_mov_b32 %s, 0" % GKOFF] + X("sswu") + ["s_mov_b32 %s, s72" % GKOFF] + X("sswu")
+            main += X("h_start") + call_sub(ADD) + X("h_base1") + call_ladder() + X("h_after1") + X("dbl") + X("h_psi2") + call_sub(SUB)
         main += X("h_t3") + call_sub(ADD) + X("h_base2") + call_ladder() + X("h_after2") + call_sub(ADD)
         main += X("h_ad_t1") + call_sub(SUB) + X("h_ad_p") + call_sub(SUB)
         epi = ["s_waitcnt vmcnt(0)"]
@@ -2605,6 +2617,8 @@ def g2_group_routine(kind):
         epi = ["s_and_b64 s[92:93], %s, %s" % (M_H0, M_R0), "s_andn2_b64 s[92:93], s[92:93], %s" % M_INF1, "s_andn2_b64 s[92:93], s[92:93], %s" % M_INF2,
                "s_and_b64 %s, %s, %s" % (G2M_TMP0, M_INF1, M_INF2), "s_or_b64 s[92:93], s[92:93], %s" % G2M_TMP0, "v_cndmask_b32_e64 v251, 0, 1, s[92:93]"]
     epi += ["s_waitcnt vmcnt(0)", "s_mov_b64 s[30:31], s[80:81]"]
+    if two_lane:
+        epi += ["s_mov_b64 exec, %s" % EXEC_ACT]
     ret = ["s_setpc_b64 s[30:31]"]                  # the routine's own return: the subroutines follow it
     pieces = dict(B, pro=pro, epi=epi)
     return pro + main + expand_calls_d(epi) + ret + lad + subs, pieces, st          # every internal call is a forward jump
@@ -2912,6 +2926,9 @@ def main():
         full, pieces, st = g2_group_routine(kind)
         txt += emit(macro, full) + "\n"
         print("g2 group routine", kind, len(full), "lines; add", len(pieces["add"]), st["add"])
+    full, pieces, st = g2_group_routine("hash", two_lane=True)
+    txt += emit("MBLS_G2_HASH_TAIL2_D_ASM", full) + "\n"
+    print("g2 hash routine, two lanes per message:", len(full), "lines")
     full, pieces, st = g2_blind_routine()
     txt += emit("MBLS_G2_BLIND_D_ASM", full) + "\n"
     print("g2 blind routine", len(full), "lines; addt", len(pieces["addt"]), st["addt"])
