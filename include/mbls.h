@@ -279,7 +279,8 @@ int mbls_sk_to_pk_batch_device(mbls_ctx* ctx, const uint8_t* d_sks32, int out_fo
 /* n x hash_to_curve_g2 (src/amcl_utils.rs:33-35), compressed output */
 int mbls_hash_to_g2_batch(mbls_ctx* ctx, const uint8_t* msgs, uint32_t msg_len, uint64_t n, uint8_t* out96);
 /* the same through the verification pipeline's own message phase, for the parity tests: mode 0 = the stand-alone lane body (as above),
- * 1 = the generated one-lane-per-item routine of the batch path, 2 = the one-wave-per-item program of small batches */
+ * 1 = the generated one-lane-per-item routine of the batch path, 2 = the one-wave-per-item program of small batches, 3 = two lanes per
+ * message (the form batches between the wave engine's limit and half a round take) */
 int mbls_hash_to_g2_batch_mode(mbls_ctx* ctx, const uint8_t* msgs, uint32_t msg_len, uint64_t n, uint8_t* out96, int mode);
 /* n x AggregateSignature::aggregate (src/aggregates.rs:100-106): set i sums its k signatures (or the signatures
  * [offsets[i], offsets[i+1]) of sigs96), starting from infinity (an empty set gives 0xC0 || 0..). errs[i] = MBLS_OK or the

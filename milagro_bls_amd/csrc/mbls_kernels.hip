@@ -629,7 +629,9 @@ static void coop_run(mbls_ctx* c, int prog, mbls_ws ws, uint64_t first_item, uin
         hipLaunchKernelGGL(k_coop, grid, dim3(64), lds, s, pg, ws, first_item, item_step, partner_step, n_items, st, res, res_mode);
 }
 static void launch_hash(mbls_ctx* c, mbls_ws ws, const uint8_t* d_msgs, uint32_t msg_len, const uint64_t* d_moff, uint32_t* st, uint64_t n, hipStream_t s, bool pair_ok) {
-    if (pair_ok && !(n <= c->coop_hash_max_items && n <= c->coop_max_items) && n <= c->split_max_items && 2 * n <= c->round_items) {
+    // (up to a quarter of a round: with 2 n lanes for the messages beside n for the keys and n for the signatures the three front chains still run
+    // side by side; above that the doubled message phase would push them behind it)
+    if (pair_ok && !(n <= c->coop_hash_max_items && n <= c->coop_max_items) && n <= c->split_max_items && 4 * n <= c->round_items) {
         hipLaunchKernelGGL(k_hash2, dim3(nblk(2 * n)), dim3(WG), 0, s, ws, d_msgs, msg_len, d_moff, st, n);
         hipLaunchKernelGGL(k_h_compact_a, dim3(nblk(n)), dim3(WG), 0, s, ws, n);
         hipLaunchKernelGGL(k_h_compact_b, dim3(nblk(n)), dim3(WG), 0, s, ws, n);
@@ -1320,7 +1322,7 @@ extern "C" int mbls_hash_to_g2_batch(mbls_ctx* c, const uint8_t* msgs, uint32_t 
     return mbls_hash_to_g2_batch_mode(c, msgs, msg_len, n, out96, 0);
 }
 extern "C" int mbls_hash_to_g2_batch_mode(mbls_ctx* c, const uint8_t* msgs, uint32_t msg_len, uint64_t n, uint8_t* out96, int mode) {
-    if (!c || !out96 || (!msgs && msg_len) || mode < 0 || mode > 2) return MBLS_ERR_ARGUMENT;
+    if (!c || !out96 || (!msgs && msg_len) || mode < 0 || mode > 3) return MBLS_ERR_ARGUMENT;
     mbls_lock lk(c->mu);
     if (!n) return MBLS_OK;
     HIPCHK(c, hipSetDevice(c->device));
@@ -1328,14 +1330,15 @@ extern "C" int mbls_hash_to_g2_batch_mode(mbls_ctx* c, const uint8_t* msgs, uint
     if (mode == 0)        // the stand-alone compiled lane body
         hipLaunchKernelGGL(k_hash_to_g2, dim3(nblk(n)), dim3(WG), 0, c->hs_a, dm.as<uint8_t>(), msg_len, n, dout.as<uint8_t>());
     else {                // the pipeline's message phase (mode 1: one lane per item, the generated routine; mode 2: one wave per item, program hashg2), then its H
-        int rc = mbls_ctx_reserve(c, n); if (rc) return rc;
+        int rc = mbls_ctx_reserve(c, mode == 3 ? 2 * n : n); if (rc) return rc;
         mbls_ws ws; ws.w = c->d_w; ws.stride = c->cap;
         rc = ws_acquire(c, c->hs_a); if (rc) return rc;
         HIPCHK(c, hipMemsetAsync(c->d_status, 0, 4 * n, c->hs_a));
-        const uint64_t keep_h = c->coop_hash_max_items, keep_p = c->coop_max_items;
-        if (mode == 1) c->coop_hash_max_items = 0; else { c->coop_hash_max_items = n; c->coop_max_items = n > keep_p ? n : keep_p; }
-        launch_hash(c, ws, dm.as<uint8_t>(), msg_len, nullptr, c->d_status, n, c->hs_a);
-        c->coop_hash_max_items = keep_h; c->coop_max_items = keep_p;
+        const uint64_t keep_h = c->coop_hash_max_items, keep_p = c->coop_max_items, keep_s = c->split_max_items;
+        if (mode == 1 || mode == 3) c->coop_hash_max_items = 0; else { c->coop_hash_max_items = n; c->coop_max_items = n > keep_p ? n : keep_p; }
+        if (mode == 3 && 2 * n <= c->round_items) c->split_max_items = n;             // mode 3: two lanes per message (k_hash2), whatever the batch size below half a round
+        launch_hash(c, ws, dm.as<uint8_t>(), msg_len, nullptr, c->d_status, n, c->hs_a, mode == 3);
+        c->coop_hash_max_items = keep_h; c->coop_max_items = keep_p; c->split_max_items = keep_s;
         hipLaunchKernelGGL(k_h_export, dim3(nblk(n)), dim3(WG), 0, c->hs_a, ws, n, dout.as<uint8_t>());
     }
     HIPCHK(c, hipStreamSynchronize(c->hs_a)); c->ws_pending = false; HIPCHK(c, dout.down(out96, 96 * n)); return MBLS_OK;
@@ -1556,7 +1559,9 @@ static void g2_tree(mbls_ctx* c, mbls_ws ws, uint64_t m, hipStream_t s) { g2_tre
 // workspace holds, for items 0..n-1, H_i (slot H) and P_i (slot APK); S (the (S, -G1) pair's G2 point) in slot S of item 0; the OR of
 // every status word in d_scalar[0]. Everything is enqueued on s: one Miller loop per lane, the product tree, and ONE wave for the tail --
 // the Miller loop of (S, -G1), the product, the single final exponentiation, the comparison and the status bits (program vmtail).
-static int npairing_finish(mbls_ctx* c, uint64_t n, hipStream_t s, uint8_t* d_result, hipEvent_t s_miller_ev = nullptr) {
+// late_status: fold the sets' status words into d_scalar[0] only HERE, after the wait for the signature chain -- the sets' Miller loops then start as
+// soon as the keys and the messages are ready and do not wait for the (longer) signature chain, whose bits only the tail needs
+static int npairing_finish(mbls_ctx* c, uint64_t n, hipStream_t s, uint8_t* d_result, hipEvent_t s_miller_ev = nullptr, bool late_status = false) {
     const bool s_miller_done = s_miller_ev != nullptr;
     mbls_ws ws; ws.w = c->d_w; ws.stride = c->cap;
     if (2 * n <= c->coop_max_items)     // few pairs: one WAVE per Miller loop (program miller1, ~0.9 ms) instead of one lane (6.6 ms)
@@ -1566,6 +1571,7 @@ static int npairing_finish(mbls_ctx* c, uint64_t n, hipStream_t s, uint8_t* d_re
     f12_tree(c, ws, n, s);
     // s_miller_done: the Miller value of (S, -G1) is left in slots 97..108 of item 0 by program smiller, running beside the chains
     if (s_miller_done) HIPCHK(c, hipStreamWaitEvent(s, s_miller_ev, 0));
+    if (late_status) hipLaunchKernelGGL(k_status_or, dim3(nblk(n)), dim3(WG), 0, s, c->d_status, n, c->d_scalar);
     coop_run(c, s_miller_done ? COOP_VMFINAL : COOP_VMTAIL, ws, (uint64_t)0, (uint64_t)1, (uint64_t)0, (uint64_t)1, c->d_scalar, d_result, COOP_RES_BATCH, s);
     HIPCHK(c, hipGetLastError());
     return MBLS_OK;
@@ -1741,14 +1747,14 @@ static int verify_multiple_impl(mbls_ctx* c, const uint8_t* d_sigs, const uint8_
         HIPCHK(c, hipEventRecord(c->hs_ev, s_sig));                  // ... and its Miller value (awaited just before the tail)
     }
     launch_hash(c, ws, d_msgs, msg_len, d_moff, c->d_status, n, s_msg, pair_hash);
-    if (fork) {
+    if (fork) {      // the sets' Miller loops need the keys (this stream) and the messages; the signature chain is awaited before the tail (hs_ev)
         HIPCHK(c, hipEventRecord(c->hs_ev3, s_msg));
-        HIPCHK(c, hipStreamWaitEvent(s, c->hs_ev2, 0)); HIPCHK(c, hipStreamWaitEvent(s, c->hs_ev3, 0));
-    }
-    hipLaunchKernelGGL(k_status_or, dim3(nblk(n)), dim3(WG), 0, s, c->d_status, n, c->d_scalar);
+        HIPCHK(c, hipStreamWaitEvent(s, c->hs_ev3, 0));
+    } else
+        hipLaunchKernelGGL(k_status_or, dim3(nblk(n)), dim3(WG), 0, s, c->d_status, n, c->d_scalar);
     // a set whose signature is outside G2 (reference src/aggregates.rs:274-276), an undecodable member or a zero scalar makes the tail
     // answer false: the status bits are folded in on the device, the call only enqueues
-    rc = npairing_finish(c, n, s, d_result, fork ? c->hs_ev : nullptr); if (rc) return rc;
+    rc = npairing_finish(c, n, s, d_result, fork ? c->hs_ev : nullptr, fork); if (rc) return rc;
     if (d_status_or) HIPCHK(c, hipMemcpyAsync(d_status_or, c->d_scalar, 4, hipMemcpyDeviceToDevice, s));
     return ws_release(c, s);
 }

@@ -918,6 +918,10 @@ def test_g2_hash_routine_two_lanes_per_message():
     m, state, masks, step, add, ladder = g2_piece_runner("hash", two_lane=True)
     full, pieces, _ = t.g2_group_routine("hash", two_lane=True)
     assert sum(1 for l in full if l == "s_and_b64 exec, exec, s[94:95]") == 1 and full.count("s_mov_b64 exec, %s" % t.EXEC_ACT) == 1
+    # the control skeleton is the one-lane routine's minus one map_to_curve body (a shape check: the bodies themselves are run piece by piece below)
+    full1, pieces1, _ = t.g2_group_routine("hash")
+    x = lambda b: len(t.expand_calls_d(b))
+    assert len(full1) - len(full) == x(pieces1["sswu"]) + x(pieces1["h_start"]) - x(pieces["h_start2"]) - 6
     mb = miller_machine(0); mb.mem = m.mem                       # the odd lane: its own registers and LDS column, the same memory,
     mb.s[68] = (GBASE + 4) & 0xFFFFFFFF; mb.s[69] = (GBASE + 4) >> 32      # its item one word further on
     mb.run(pieces["pro"])

@@ -99,17 +99,21 @@ def test_tree_levels_on_both_engines(N):
 
 
 def test_message_phase_of_the_pipeline_against_golden_and_oracle(mb, vectors):
-    """H(m) as the verification pipeline's own message phase leaves it -- the generated one-lane routine (mode 1) and the cooperative
-    program hashg2 (mode 2) -- against the committed golden vectors (incl. the 133 700-byte message) and the oracle on 200 random messages"""
+    """H(m) as the verification pipeline's own message phase leaves it -- the generated one-lane routine (mode 1), the cooperative
+    program hashg2 (mode 2) and the two-lanes-per-message form of batches below half a round (mode 3: k_hash2) -- against the committed
+    golden vectors (incl. the 133 700-byte message) and the oracle on 200 / 333 random messages"""
     rnd = random.Random(17)
     for v in vectors["model"]["hash_to_g2"]:
         m = helpers.expand_msg(v["msg"])
-        for mode in (1, 2):
+        for mode in (1, 2, 3):
             assert mb.hash_to_g2_batch(m, 1, msg_len=len(m), mode=mode).hex() == v["compressed"], (mode, v["msg"][:16])
     msgs = rnd.randbytes(32 * 200)
     want = orc.batch_hash_to_g2(msgs, 200)
     assert mb.hash_to_g2_batch(msgs, 200, mode=1) == want
     assert mb.hash_to_g2_batch(msgs, 200, mode=2) == want
+    assert mb.hash_to_g2_batch(msgs, 200, mode=3) == want
+    msgs = rnd.randbytes(32 * 333)                      # an odd count: the last workgroup holds 13 messages on 26 lanes
+    assert mb.hash_to_g2_batch(msgs, 333, mode=3) == orc.batch_hash_to_g2(msgs, 333)
 
 
 @pytest.mark.parametrize("n", [1, 2, 3, 7, 130])

@@ -2596,10 +2596,11 @@ def g2_group_routine(kind, two_lane=False):
         if two_lane:                                # one map per lane; then the even lanes alone, their neighbour's point one item (4 bytes) further on
             main = ["s_mov_b32 %s, 0" % GKOFF] + X("sswu") + ["s_waitcnt vmcnt(0)", "s_mov_b32 s94, 0x55555555", "s_mov_b32 s95, 0x55555555",
                                                             "s_and_b64 exec, exec, s[94:95]", "s_mov_b64 %s, exec" % EXEC_ALL, "s_mov_b32 %s, 4" % GKOFF]
-            main += X("h_start2") + call_sub(ADD)
+            main += X("h_start2")
         else:
             main = ["s_mul_i32 s72, %s, %d" % (GSTRIDE, 12 * 6), "s_mov_b32 %s, 0" % GKOFF] + X("sswu") + ["s_mov_b32 %s, s72" % GKOFF] + X("sswu")
-            main += X("h_start") + call_sub(ADD) + X("h_base1") + call_ladder() + X("h_after1") + X("dbl") + X("h_psi2") + call_sub(SUB)
+            main += X("h_start")
+        main += call_sub(ADD) + X("h_base1") + call_ladder() + X("h_after1") + X("dbl") + X("h_psi2") + call_sub(SUB)
         main += X("h_t3") + call_sub(ADD) + X("h_base2") + call_ladder() + X("h_after2") + call_sub(ADD)
         main += X("h_ad_t1") + call_sub(SUB) + X("h_ad_p") + call_sub(SUB)
         epi = ["s_waitcnt vmcnt(0)"]
