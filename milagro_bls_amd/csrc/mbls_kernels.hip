@@ -195,9 +195,11 @@ __global__ void MBLS_LB k_sig_verdict(mbls_ws ws, uint32_t* status, uint64_t n, 
 // product f_i f_(n+i) is one level of the generated product tree (k_f12_tree_d(2 n, n)), and the signature's subgroup verdict reads the running
 // point of lane n + i (k_sig_verdict with t_item_offset = n, t_pair = 1): the one-pair routine walks the same bits of |x| with the same
 // incomplete formulas (Q in homogeneous form with Z = 1), so it ends with [|x|] sig exactly like pair 0 of the two-pair loop.
-__global__ void MBLS_LB k_miller_split(mbls_ws ws, uint64_t n) {
-    __shared__ uint32_t spill[154 * 64];
-    uint64_t t = gid(); if (t >= 2 * n) return;
+// lpp = 2 (batches of at most a quarter of a round): TWO lanes per pair -- lanes 2 q, 2 q + 1 walk pair q together, their products in pairs
+// (miller_loop_single_pair_d): four lanes per item.
+template <int LPP> MBLS_FN void miller_split_body(const mbls_ws& ws, uint64_t n, uint32_t* spill) {
+    const uint64_t lane_id = gid();
+    uint64_t t = LPP == 2 ? lane_id >> 1 : lane_id; if (t >= 2 * n) return;
     const bool sigpair = t >= n;                                   // branch-free operand selection: the routine is called from uniform control flow
     const uint64_t i = sigpair ? t - n : t;
     g2j h; h.x = ws_ld2(ws, MBLS_SLOT_H, i); h.y = ws_ld2(ws, MBLS_SLOT_H + 2, i); h.z = ws_ld2(ws, MBLS_SLOT_H + 4, i);
@@ -214,10 +216,19 @@ __global__ void MBLS_LB k_miller_split(mbls_ws ws, uint64_t n) {
     pr.t = pr.q;
     fp12 f;
 #if MBLS_DEVICE_ASM
-    miller_loop_single_d(&f, &pr, ws.w, ws.stride, t, (MBLS_LDS uint32_t*)spill, threadIdx.x);
+    if (LPP == 2) miller_loop_single_pair_d(&f, &pr, ws.w, ws.stride, t, (MBLS_LDS uint32_t*)spill, threadIdx.x);
+    else miller_loop_single_d(&f, &pr, ws.w, ws.stride, t, (MBLS_LDS uint32_t*)spill, threadIdx.x);
 #endif
     const fp2* c = &f.c0.c0;
     for (int s = 0; s < 6; s++) ws_st2(ws, MBLS_SLOT_F + 2 * s, t, c[s]);
+}
+__global__ void MBLS_LB k_miller_split(mbls_ws ws, uint64_t n) {
+    __shared__ uint32_t spill[154 * 64];
+    miller_split_body<1>(ws, n, spill);
+}
+__global__ void MBLS_LB k_miller_split4(mbls_ws ws, uint64_t n) {      // four lanes per item: two per pair
+    __shared__ uint32_t spill[154 * 64];
+    miller_split_body<2>(ws, n, spill);
 }
 __global__ void MBLS_LB k_final(mbls_ws ws, uint32_t* status, uint8_t* results, uint64_t n) {
     __shared__ uint32_t accstore[154 * 64];       // spill slots of the generated exponentiation routine / the Fp12 parked by the one-shot products
@@ -309,9 +320,8 @@ __global__ void MBLS_LB k_blind_sig_d(mbls_ws ws, const uint8_t* sigs96, const u
 }
 // f_i = Miller(H_i, P_i) for i < n; lane n (if with_sig) computes Miller(S, -G1) with S read from slot S of item `s_item`.
 // The loop itself is the generated single-pair routine (mbls_pairing.h, miller_loop_single_d).
-__global__ void MBLS_LB k_miller_single(mbls_ws ws, uint64_t n, int with_sig, uint64_t s_item) {
-    __shared__ uint32_t spill[154 * 64];
-    uint64_t i = gid(); if (i > n || (i == n && !with_sig)) return;
+template <int LPP> MBLS_FN void miller_single_body(const mbls_ws& ws, uint64_t n, int with_sig, uint64_t s_item, uint32_t* spill) {
+    uint64_t i = LPP == 2 ? gid() >> 1 : gid(); if (i > n || (i == n && !with_sig)) return;
     // branch-free operand selection (lane n takes S and the constant -G1): the generated routine is called from uniform control flow
     const bool last = (i == n);
     const int qslot = last ? MBLS_SLOT_S : MBLS_SLOT_H;
@@ -325,12 +335,22 @@ __global__ void MBLS_LB k_miller_single(mbls_ws ws, uint64_t n, int with_sig, ui
     pr.t = pr.q;
     fp12 f;
 #if MBLS_DEVICE_ASM
-    miller_loop_single_d(&f, &pr, ws.w, ws.stride, i, (MBLS_LDS uint32_t*)spill, threadIdx.x);
+    if (LPP == 2) miller_loop_single_pair_d(&f, &pr, ws.w, ws.stride, i, (MBLS_LDS uint32_t*)spill, threadIdx.x);
+    else miller_loop_single_d(&f, &pr, ws.w, ws.stride, i, (MBLS_LDS uint32_t*)spill, threadIdx.x);
 #else
     miller_loop(&f, &pr, 1);
 #endif
     const fp2* c = &f.c0.c0;
     for (int s = 0; s < 6; s++) ws_st2(ws, MBLS_SLOT_F + 2 * s, i, c[s]);
+}
+__global__ void MBLS_LB k_miller_single(mbls_ws ws, uint64_t n, int with_sig, uint64_t s_item) {
+    __shared__ uint32_t spill[154 * 64];
+    miller_single_body<1>(ws, n, with_sig, s_item, spill);
+}
+// two lanes per Miller loop (half a round of pairs or less): lanes 2 i, 2 i + 1 walk pair i together, their products in pairs
+__global__ void MBLS_LB k_miller_single2(mbls_ws ws, uint64_t n, int with_sig, uint64_t s_item) {
+    __shared__ uint32_t spill[154 * 64];
+    miller_single_body<2>(ws, n, with_sig, s_item, spill);
 }
 // tree levels with one lane per product: item i <- item i (op) item i + half, for i + half < m (generated routines, tools/gen_tower_d.py)
 __global__ void MBLS_LB k_f12_tree_d(mbls_ws ws, uint64_t m, uint64_t half) {
@@ -542,10 +562,10 @@ __global__ void __launch_bounds__(WG) k_valu_bench(uint32_t* sink, uint32_t iter
 // creation per call once the sizes have been seen); device-pointer entries only enqueue, and order their use of the
 // workspace against earlier calls on other streams with an event.
 #define MBLS_N_STAGE 10
-// measured crossovers (scripts/throughput_vs_n.py, 128 keys, device-resident): one wave per item for the pairing check wins up to ~8 k items
-// (16.7 ms at 8 192; the one-lane path with two lanes per item in the Miller loop and the final exponentiation needs 16.6 ms for anything up
-// to half a round), for the message phase as well up to ~6 k
-#define MBLS_DEFAULT_COOP_MAX_ITEMS 8192
+// measured crossovers (scripts/throughput_vs_n.py, 128 keys, device-resident): one wave per item for the pairing check wins up to ~6 k items
+// (13.3 ms at 6 144; the lane path with four lanes per item in the Miller loop and two in the message phase and the final exponentiation needs
+// ~13.5 ms for anything up to a quarter of a round), for the message phase as well up to ~6 k
+#define MBLS_DEFAULT_COOP_MAX_ITEMS 6144
 #define MBLS_DEFAULT_COOP_HASH_MAX_ITEMS 6144
 struct mbls_ctx {
     std::recursive_mutex mu;
@@ -920,7 +940,9 @@ static int verify_pipeline_one(mbls_ctx* c, const uint8_t* d_sigs, const uint8_t
         if (tm) { HIPCHK(c, hipEventRecord(c->ev[4], s)); HIPCHK(c, hipEventRecord(c->ev[5], s)); }
     } else {
         if (split) {
-            hipLaunchKernelGGL(k_miller_split, dim3(nblk(2 * n)), dim3(WG), 0, s, ws, n);
+            const int lpp = 4 * n <= c->round_items ? 2 : 1;         // a quarter of a round or less: two lanes per pair, products in pairs
+            if (lpp == 2) hipLaunchKernelGGL(k_miller_split4, dim3(nblk(4 * n)), dim3(WG), 0, s, ws, n);
+            else hipLaunchKernelGGL(k_miller_split, dim3(nblk(2 * n)), dim3(WG), 0, s, ws, n);
             hipLaunchKernelGGL(k_f12_tree_d, dim3(g), dim3(WG), 0, s, ws, 2 * n, n);
             hipLaunchKernelGGL(k_sig_verdict, dim3(g), dim3(WG), 0, s, ws, st, n, n, 1);
         } else {
@@ -1567,7 +1589,11 @@ static int npairing_finish(mbls_ctx* c, uint64_t n, hipStream_t s, uint8_t* d_re
     if (2 * n <= c->coop_max_items)     // few pairs: one WAVE per Miller loop (program miller1, ~0.9 ms) instead of one lane (6.6 ms)
         coop_run(c, COOP_MILLER1, ws, (uint64_t)0, (uint64_t)1, (uint64_t)0, n, (uint32_t*)nullptr, (uint8_t*)nullptr, COOP_RES_ITEM, s);
     else
-        hipLaunchKernelGGL(k_miller_single, dim3(nblk(n)), dim3(WG), 0, s, ws, n, 0, (uint64_t)0);
+    {
+        const int lpp = 2 * n <= c->round_items ? 2 : 1;            // half a round or less: two lanes per Miller loop, products in pairs
+        if (lpp == 2) hipLaunchKernelGGL(k_miller_single2, dim3(nblk(2 * n)), dim3(WG), 0, s, ws, n, 0, (uint64_t)0);
+        else hipLaunchKernelGGL(k_miller_single, dim3(nblk(n)), dim3(WG), 0, s, ws, n, 0, (uint64_t)0);
+    }
     f12_tree(c, ws, n, s);
     // s_miller_done: the Miller value of (S, -G1) is left in slots 97..108 of item 0 by program smiller, running beside the chains
     if (s_miller_done) HIPCHK(c, hipStreamWaitEvent(s, s_miller_ev, 0));
@@ -1668,7 +1694,11 @@ extern "C" int mbls_aggregate_verify_batch_device(mbls_ctx* c, const uint8_t* d_
     if (2 * (n + total) <= c->coop_max_items)
         coop_run(c, COOP_MILLER1, ws, (uint64_t)0, (uint64_t)1, (uint64_t)0, n + total, (uint32_t*)nullptr, (uint8_t*)nullptr, COOP_RES_ITEM, s);
     else
-        hipLaunchKernelGGL(k_miller_single, dim3(nblk(n + total)), dim3(WG), 0, s, ws, n + total, 0, (uint64_t)0);
+    {
+        const int lpp = 2 * (n + total) <= c->round_items ? 2 : 1;
+        if (lpp == 2) hipLaunchKernelGGL(k_miller_single2, dim3(nblk(2 * (n + total))), dim3(WG), 0, s, ws, n + total, 0, (uint64_t)0);
+        else hipLaunchKernelGGL(k_miller_single, dim3(nblk(n + total)), dim3(WG), 0, s, ws, n + total, 0, (uint64_t)0);
+    }
     // per-item product trees over the pairs, then item i <- (sig pair) x (its pairs' product)
     uint64_t kmax = d_pair_off ? total : k;                      // a ragged layout may hold one long range: levels up to the whole list
     for (uint64_t half = 1; half < kmax; half *= 2)

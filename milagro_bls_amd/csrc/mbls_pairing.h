@@ -175,6 +175,40 @@ MBLS_FN void miller_loop_d_call(fp12* f_out, const mbls_pair* pr1, uint32_t flag
     c[0] = f0; c[1] = f1; c[2] = f2; c[3] = f3; c[4] = f4; c[5] = f5; c[6] = f6; c[7] = f7; c[8] = f8; c[9] = f9; c[10] = f10; c[11] = f11;
     fp12_conj(f_out, &f);
 }
+// The one-pair loop on TWO lanes (tools/gen_tower_d.py, pair_products; kernels k_miller_split / k_miller_single with two lanes per pair): lanes
+// 2 j and 2 j + 1 of the wave walk the SAME loop on the same values -- same workspace item, one LDS column -- and share its products: two
+// independent Fp2 products of one kind are one call, the even lane taking the first, the odd lane the second (20 calls per doubling
+// iteration instead of 37). `item` = the workspace item of THIS lane's pair; both lanes come back with the same f.
+extern "C" __device__ __attribute__((noinline, used, aligned(64))) void mbls_miller_loop_1p_pair_d_asm_fn() {
+    asm volatile(MBLS_MILLER_LOOP_1P_PAIR_D_ASM);
+}
+MBLS_FN void miller_loop_single_pair_d(fp12* f_out, const mbls_pair* pr, uint32_t* ws_w, uint64_t ws_stride, uint64_t item,
+                                       MBLS_LDS uint32_t* spill, uint32_t lane) {
+    uint32_t* w0 = ws_w + item;
+    const fp npx = fp_neg(pr->p.px);
+    const fp* src[9] = {&npx, &pr->p.py, &pr->p.pz3, &pr->q.x.c0, &pr->q.x.c1, &pr->q.y.c0, &pr->q.y.c1, &pr->q.z.c0, &pr->q.z.c1};
+    const int slot[9] = {MBLS_SLOT_QARG, MBLS_SLOT_QARG + 1, MBLS_SLOT_QARG + 2, MBLS_SLOT_Q1, MBLS_SLOT_Q1 + 1, MBLS_SLOT_Q1 + 2, MBLS_SLOT_Q1 + 3, MBLS_SLOT_Q1 + 4, MBLS_SLOT_Q1 + 5};
+#pragma unroll
+    for (int t = 0; t < 9; t++) {                   // (both lanes of the pair store the same words)
+        fp v = *src[t];
+#pragma unroll
+        for (int j = 0; j < 12; j++) w0[((uint64_t)slot[t] * 12 + j) * ws_stride] = v[j];
+    }
+    const uint32_t col = lane >> 1;
+    const uint32_t addr = (uint32_t)(uintptr_t)(spill + col);
+    const uint64_t gb = (uint64_t)(uintptr_t)ws_w + 4ull * (item - col) - (uint64_t)(uint32_t)(uintptr_t)spill;
+    const uint32_t gb_lo = __builtin_amdgcn_readfirstlane((uint32_t)gb), gb_hi = __builtin_amdgcn_readfirstlane((uint32_t)(gb >> 32));
+    const uint32_t st4 = __builtin_amdgcn_readfirstlane((uint32_t)(ws_stride * 4));
+    uint32_t flags = pr->skip ? 2u : 0u;
+    fp f0, f1, f2, f3, f4, f5, f6, f7, f8, f9, f10, f11;
+    asm volatile(MBLS_ASM_CALL("mbls_miller_loop_1p_pair_d_asm_fn")
+                 : MBLS_MILLER_D_OUT_REGS(f), "+{v253}"(flags)
+                 : "{v252}"(addr), "{s68}"(gb_lo), "{s69}"(gb_hi), "{s70}"(st4)
+                 : MBLS_MILLER_D_ASM_CLOBBERS, MBLS_PAIR_D_ASM_CLOBBERS);
+    fp12 f; fp* c = &f.c0.c0.c0;
+    c[0] = f0; c[1] = f1; c[2] = f2; c[3] = f3; c[4] = f4; c[5] = f5; c[6] = f6; c[7] = f7; c[8] = f8; c[9] = f9; c[10] = f10; c[11] = f11;
+    fp12_conj(f_out, &f);
+}
 // the verification shape: pair 0 = (signature, -G1) -- the signature already sits in workspace slots 3..6 --, pair 1 = (H(m), apk)
 MBLS_FN void miller_loop_verify_d(fp12* f_out, const mbls_pair* pairs, uint32_t* ws_w, uint64_t ws_stride, uint64_t item,
                                   MBLS_LDS uint32_t* spill, uint32_t lane) {

@@ -250,8 +250,9 @@ MBLS_FN void final_exp_ws_d(fp12* r, uint32_t* ws_w, uint64_t ws_stride, uint64_
 }
 // The same routine for lane PAIRS (tools/gen_tower_d.py, final_exp_d_routine(two_lane=True); kernel k_final2): lanes 2 j and 2 j + 1 of the wave
 // work on ONE item -- both get the item's workspace words and ONE LDS column (everything outside the squaring chains is computed twice, on
-// identical values, so the shared column and the doubled stores are benign) --, and in the 315 compressed squarings each lane does one of
-// the two Fp4 squarings, the roles swapping every iteration, the partner's coefficients through DPP. `item` = the item of THIS lane.
+// identical values, so the shared column and the doubled stores are benign) --, in the 315 compressed squarings each lane does one of
+// the two Fp4 squarings, the roles swapping every iteration, the partner's coefficients through DPP, and everywhere else independent
+// products of one kind share a call (pair_products: the even lane takes the first, the odd lane the second). `item` = the item of THIS lane.
 extern "C" __device__ __attribute__((noinline, used, aligned(64))) void mbls_final_exp2_d_asm_fn() { asm volatile(MBLS_FINAL_EXP2_D_ASM); }
 MBLS_FN void final_exp_ws_d2(fp12* r, uint32_t* ws_w, uint64_t ws_stride, uint64_t item, MBLS_LDS uint32_t* spill, uint32_t lane) {
     const uint32_t col = lane >> 1;
@@ -263,7 +264,7 @@ MBLS_FN void final_exp_ws_d2(fp12* r, uint32_t* ws_w, uint64_t ws_stride, uint64
     asm volatile(MBLS_ASM_CALL("mbls_final_exp2_d_asm_fn")
                  : MBLS_MILLER_D_OUT_REGS(f)
                  : "{v252}"(addr), "{s68}"(gb_lo), "{s69}"(gb_hi), "{s70}"(st4)
-                 : MBLS_FINAL_EXP_D_ASM_CLOBBERS);
+                 : MBLS_FINAL_EXP_D_ASM_CLOBBERS, MBLS_PAIR_EXEC_ASM_CLOBBERS);
     fp* o = &r->c0.c0.c0;
     o[0] = f0; o[1] = f1; o[2] = f2; o[3] = f3; o[4] = f4; o[5] = f5; o[6] = f6; o[7] = f7; o[8] = f8; o[9] = f9; o[10] = f10; o[11] = f11;
 }

@@ -321,11 +321,75 @@ def test_miller_bodies(which):
             assert (got - x * R392) % P == 0 and t.PACKED.vlo <= got <= t.PACKED.vhi, (which, trial, slot)
 
 
-def miller_loop_sim(runs, seed, masks_bits=0, pairs=(0, 1), q0=None):
-    """q0: an affine G2 point ((x0, x1), (y0, y1)) for pair 0's Q (workspace slots 3..6) instead of random field elements"""
+def pair_machines(masks_bits=0, routines=None):
+    """the two lanes of an item in pair mode (tools/gen_tower_d.py, pair_products): same LDS column and workspace item, lane numbers 2 j and
+    2 j + 1; PAIR_EXEC = both lanes, PAIR_ROLE = the odd one; the exec writes of the masked moves are modelled"""
+    ma, mb = miller_machine(masks_bits), miller_machine(masks_bits)
+    mb.lds = ma.lds; mb.mem = ma.mem
+    for m, lane in ((ma, 4), (mb, 5)):
+        if routines is not None:
+            m.routines = routines
+        m.lane = lane; m.model_exec = True
+        m.s[("pair", 82)] = 1; m.s[("pair", 94)] = lane & 1
+    return ma, mb
+
+
+@pytest.mark.parametrize("which", ["dbl", "first", 1])
+def test_miller_bodies_in_pair_mode(which):
+    """the one-pair Miller bodies with their products in pairs on two lanes (masked operand moves, DPP exchange, masked swap): both lanes must
+    end with the model's values in their AGPRs, and the pair's workspace slots with the model's running point"""
+    from asm_sim import run_pair
+    rng = random.Random(19)
+    body, st = t.build_miller(which, (1,), pair_mode=True)
+    assert st.get("pairs", 0) >= (4 if which == "first" else 14)
+    for trial in range(2):
+        masks = {"s[48:49]": 0, "s[54:55]": 1 if trial == 1 else 0}
+        ma, mb = pair_machines()
+        init = {}
+        for m in (ma, mb):
+            m.run(t.shell_constants())
+            m.s[("pair", 48)] = 0; m.s[("pair", 54)] = masks["s[54:55]"]
+        rng2 = random.Random(100 + trial)
+        for i in range(12):
+            x = rng2.randrange(P); rep = (x * R392 % P) + rng2.choice([-15, -1, 0, 14]) * P
+            init[("a", i)] = x
+            for m in (ma, mb):
+                m.a[14 * i:14 * i + 14] = normalised_digits(rep)
+        for sl in range(13):
+            x = rng2.randrange(P); init[("g", sl)] = x; ws_put(ma, sl, x * R384 % P)
+        for sl in range(31, 43):
+            x = rng2.randrange(P); rep = x * R392 % P
+            init[("gd", sl)] = x; ws_put(ma, sl, rep + P if rep < P // 2 else rep)
+        run_pair(ma, mb, body)
+        mp = run_model(lambda: t.prog_miller(which, (1,)), init, masks)
+        for m in (ma, mb):
+            for loc, x in mp.out_home.items():
+                got = from_digits_signed(m.a[14 * loc[1]:14 * loc[1] + 14])
+                assert (got - x * R392) % P == 0 and t.F_IN.vlo <= got <= t.F_IN.vhi, (which, trial, loc)
+        assert ma.a[:168] == mb.a[:168]
+        for slot, x in mp.out_g.items():
+            got = ws_get(ma, slot)
+            assert (got - x * R392) % P == 0 and t.PACKED.vlo <= got <= t.PACKED.vhi, (which, trial, slot)
+
+
+def miller_loop_sim(runs, seed, masks_bits=0, pairs=(0, 1), q0=None, pair_mode=False):
+    """q0: an affine G2 point ((x0, x1), (y0, y1)) for pair 0's Q (workspace slots 3..6) instead of random field elements.
+    pair_mode: the routine for lane pairs, on two machines in lockstep (both must come back with the model's value)"""
     rng = random.Random(seed)
-    full, pieces, st = t.miller_loop_d_routine(pairs)
-    m = miller_machine(masks_bits)
+    full, pieces, st = t.miller_loop_d_routine(pairs, pair_mode) if pair_mode else t.miller_loop_d_routine(pairs)
+    if pair_mode:
+        from asm_sim import run_pair
+        m, m_b = pair_machines(masks_bits)
+
+        class _Both:                                    # run(lines) on the pair; everything else is lane A's (shared memory, same values)
+            def __getattr__(self, name):
+                return getattr(m_a, name)
+
+            def run(self, lines):
+                run_pair(m_a, m_b, lines)
+        m_a = m; m = _Both()
+    else:
+        m = miller_machine(masks_bits)
     true = {}
     for sl in range(13):
         x = rng.randrange(P)
@@ -365,6 +429,8 @@ def miller_loop_sim(runs, seed, masks_bits=0, pairs=(0, 1), q0=None):
     m.run(pieces["epi"][:-1])
     for i in range(12):
         assert from_limbs(m.v[t.F_OUT[i]:t.F_OUT[i] + 12]) == f[i] * R384 % P, ("f", i)
+        if pair_mode:
+            assert m_b.v[t.F_OUT[i]:t.F_OUT[i] + 12] == m_a.v[t.F_OUT[i]:t.F_OUT[i] + 12]
     assert not any("scratch" in l or "buffer_" in l for l in full)
     # the running points as the routine leaves them in the workspace: packed words of the 2^392 domain, representatives in (0.5 p, 1.5 p)
     # -- what lane_sig_verdict (mbls_lanes.h) reads for pair 0 through MBLS_GEN_MILLER_T0_SLOT
@@ -383,6 +449,8 @@ def test_miller_loop_routine_short_schedules():
     miller_loop_sim([1, 1], 7, masks_bits=2)
     miller_loop_sim([1, 1, 1], 8, pairs=(1,))           # the single-pair routine of the n-pairing paths
     miller_loop_sim([1, 1], 9, masks_bits=2, pairs=(1,))
+    miller_loop_sim([1, 2, 1], 10, pairs=(1,), pair_mode=True)       # the same routine for lane pairs (products in pairs)
+    miller_loop_sim([1, 1], 11, masks_bits=2, pairs=(1,), pair_mode=True)
     # the shell around the bodies: one forward exit, every far jump backwards, the phase counter picks RUNS[1..5]
     full, pieces, _ = t.miller_loop_d_routine()
     assert sum(1 for l in full if l.startswith("s_setpc_b64")) == 2 and "5:" in full and "4:" not in full
@@ -515,7 +583,7 @@ def fexp2_sim(runs, seed, lanes=(6, 7)):
     ma, mb = Machine(FEXP_ROUT), Machine(FEXP_ROUT)
     mb.lds = ma.lds; mb.mem = ma.mem
     for m, lane in ((ma, lanes[0]), (mb, lanes[1])):
-        m.lane = lane; m.v[252] = LADDR
+        m.lane = lane; m.v[252] = LADDR; m.model_exec = True               # (the bodies outside the squaring chains have their products in pairs)
         m.s[68] = GBASE & 0xFFFFFFFF; m.s[69] = GBASE >> 32; m.s[70] = STRIDE * 4
     for i in range(12):
         ws_put(ma, t.FEXP_IN_SLOT + i, f[i] * R384 % P)

@@ -24,6 +24,8 @@ class Machine:
         self.scc = 0
         self.lane = 0                                # this lane's number within its wave (v_mbcnt_*)
         self.pair_sync = False                       # set by run_pair
+        self.model_exec = False                      # True: writes to exec switch THIS lane on / off (its bit = the value written, as for every
+        self.exec_on = 1                             # lane mask here) and an inactive lane skips vector and memory instructions
 
     # ---- operand helpers
     _TOK = {}                                        # operand text -> (kind, index / value): every distinct operand is parsed once
@@ -33,8 +35,8 @@ class Machine:
         tok = tok.strip()
         if tok == "vcc":
             r = ("vcc", 0)
-        elif tok == "exec":                          # one lane, always active
-            r = ("imm", 1)
+        elif tok == "exec":                          # one lane: active unless the exec model says otherwise
+            r = ("exec", 0)
         else:
             m = re.fullmatch(r"([vsa])(\d+)", tok)
             m2 = re.fullmatch(r"([vs])\[(\d+):(\d+)\]", tok)
@@ -65,11 +67,15 @@ class Machine:
             return self.vcc
         if k == "s2":
             return self.s.get(("pair", i), 0)
+        if k == "exec":
+            return self.exec_on if self.model_exec else 1
         return self.v[i] | (self.v[i + 1] << 32)     # v2
 
     def wr_carry(self, tok, val):
         tok = tok.strip()
-        if tok == "exec":                            # the one simulated lane stays active: masked regions are the caller's business
+        if tok == "exec":                            # by default the one simulated lane stays active: masked regions are the caller's business
+            if self.model_exec:
+                self.exec_on = val & 1
             return
         if tok == "vcc":
             self.vcc = val
@@ -121,6 +127,9 @@ class Machine:
             self.count += 1
             if self.pair_sync and op[:3] in ("glo", "ds_"):
                 yield None                        # a lane pair stays in step at every memory instruction (see run_pair)
+            if self.model_exec and not self.exec_on and op[:2] in ("v_", "ds", "gl"):
+                assert "dpp" not in op, "cross-lane move with a lane of the pair switched off"
+                continue                          # this lane is switched off: vector and memory instructions do nothing here
             if op == "CALL":                      # pseudo-instruction of the generator: s_getpc/s_add/s_addc/s_swappc to a routine
                 self.calls += 1
                 yield from self.run_gen(self.routines[args[0]])
@@ -198,6 +207,9 @@ class Machine:
             elif op == "v_mbcnt_hi_u32_b32":      # ... among lanes 32..63, added to the operand: together the lane's number
                 assert args[1] == "-1"
                 self.wr(args[0], max(self.lane - 32, 0) + self.rd(args[2]))
+            elif op == "v_swap_b32":
+                a_, b_ = self.rd(args[0]), self.rd(args[1])
+                self.wr(args[0], b_); self.wr(args[1], a_)
             elif op == "v_add3_u32":
                 self.wr(args[0], self.rd(args[1]) + self.rd(args[2]) + self.rd(args[3]))
             elif op == "v_mov_b32_dpp":           # v_mov_b32_dpp vdst, vsrc quad_perm:[1,0,3,2] ...: the value of the NEIGHBOUR lane (lane ^ 1)

@@ -203,6 +203,66 @@ class Prog:
     def mul12_2(self, a): return self.scale2(a, 12)
 
 
+# ---------------------------------------------------------------------------------------------- products in pairs (two lanes per item)
+# Batches that leave at least half of the SIMDs idle give every item TWO lanes (2 j and 2 j + 1 of a wave). Both lanes hold the same values and run
+# the same stream; what the second lane buys is the products: two independent Fp2 products of the same kind become ONE call -- the even
+# lane multiplies the first pair of operands, the odd lane the second (its operand slots are overwritten under an exec mask), the results
+# cross through DPP and a masked v_swap_b32 sorts them, so that afterwards both lanes hold both products again. pair_products() finds the
+# pairs in a recorded program: a later product of the same kind whose operands are ready, or become ready by hoisting carry-free
+# operations (the Karatsuba sums) in front of the earlier one.
+PAIR_ROLE, PAIR_EXEC = "s[94:95]", "s[82:83]"        # the odd lanes (of those that entered the routine) / every lane that entered the routine
+PAIRABLE = ("mul", "sqr", "mulfp")
+PURE_OPS = {"add", "sub", "pair", "scale", "shadd", "neg", "const", "norm", "reduce"}
+
+
+def pair_products(p, window=160):
+    ops = list(p.ops)
+    if not ops:                                      # (a model program computes as it records: nothing to pair)
+        return p
+    produced_at = {}
+    for i, op in enumerate(ops):
+        for o in op[1]:
+            produced_at[o] = i
+    emitted, out = set(), []
+
+    def chain(j, i):
+        """the not yet emitted operations in (i, j) that op j needs, in order -- or None if one of them is no carry-free operation"""
+        need, stack = set(), list(ops[j][2])
+        while stack:
+            k = produced_at.get(stack.pop(), -1)
+            if k < 0 or k in emitted or k in need:
+                continue
+            if k >= i and (k == i or ops[k][0] not in PURE_OPS):
+                return None
+            need.add(k); stack += list(ops[k][2])
+        return sorted(need)
+    for i in range(len(ops)):
+        if i in emitted:
+            continue
+        kind = ops[i][0]
+        if kind in PAIRABLE:
+            for j in range(i + 1, min(len(ops), i + window)):
+                if j in emitted or ops[j][0] != kind:
+                    continue
+                ch = chain(j, i)
+                if ch is None:
+                    continue
+                for k in ch:
+                    out.append(ops[k]); emitted.add(k)
+                out.append((kind + "x2", list(ops[i][1]) + list(ops[j][1]), list(ops[i][2]) + list(ops[j][2]), None))
+                emitted.add(i); emitted.add(j)
+                break
+            if i in emitted:
+                continue
+        out.append(ops[i]); emitted.add(i)
+    p.ops = out
+    return p
+
+
+def is_product(kind):
+    return kind in ROUTINES or (kind.endswith("x2") and kind[:-2] in ROUTINES)
+
+
 R392 = 1 << 392
 K384 = (1 << 384) % P                # multiplying by it in the 2^392 domain leaves a 2^384-domain value
 PTOP = P >> 364                      # top digit of p
@@ -646,11 +706,14 @@ class AllocD:
         if u == INF:
             return None
         for j in range(k + 1, u):
-            if self.p.ops[j][0] in ROUTINES:
+            if is_product(self.p.ops[j][0]):
                 return None
         kind, outs, ins, aux = self.p.ops[u]
         if kind in ROUTINES:
             return ROUTINES[kind]["ins"][ins.index(d)]
+        if is_product(kind):                                 # the first product of a pair sits in the operand slots like any call's
+            slots = ROUTINES[kind[:-2]]["ins"]
+            return slots[ins.index(d)] if ins.index(d) < len(slots) else None
         return None
 
     def prefetch(self, k, horizon=int(os.environ.get("MBLS_GEN_PREFETCH_HORIZON", "3")), avoid=()):
@@ -693,7 +756,7 @@ class AllocD:
                     self.vm_mark[v] = self.vm
                     self.loc[v] = ("vw", b); self.at[("vw", b)] = v
                     self.stats["unpack"] += 40
-            if kind in ROUTINES:
+            if is_product(kind):
                 calls += 1
             j += 1
 
@@ -741,6 +804,8 @@ class AllocD:
                 self.bound[outs[0]] = Bound(0, M28, aux >> 364, aux >> 364, aux, aux)
             elif kind in ROUTINES:
                 self.do_call(k, kind, outs, ins)
+            elif is_product(kind):
+                self.do_callx2(k, kind, outs, ins)
             elif kind == "store":
                 self.do_store(k, ins[0], aux)
             elif kind == "reduce":
@@ -1160,7 +1225,7 @@ class AllocD:
             u = self.next_use(w, k + 1 if w not in ins else k)
             nk = self.p.ops[u][0] if u != INF else None
             busy = clob | set(slots)
-            if w not in ins and nk in ROUTINES and self.free_block("a", self.a_pool) is not None:
+            if w not in ins and nk is not None and is_product(nk) and self.free_block("a", self.a_pool) is not None:
                 self.spill(w)                                    # next consumed as a call operand: waits in an AGPR for free
             else:
                 b = self.alloc_v(k, avoid=busy)
@@ -1193,6 +1258,108 @@ class AllocD:
         for i, o in enumerate(outs):
             self.place(o, ("v", R["outs"][i]))
             self.bound[o] = ob[i]
+
+    def do_callx2(self, k, kind, outs, ins):
+        """Two independent products of one kind as ONE call on a lane pair (see pair_products): the first product's operands go into the
+        routine's slots as for any call; the second product's operands overwrite them on the odd lanes (exec = PAIR_ROLE); after the call each
+        lane fetches its neighbour's result (DPP) and the odd lanes swap the two, so that blocks 5, 6 hold the first product and two more blocks
+        the second one on BOTH lanes. Everything outside the masked moves runs identically on both lanes: their states never differ."""
+        base = kind[:-2]
+        R = ROUTINES[base]
+        slots = R["ins"]
+        nin = len(slots)
+        insA, insB, outsA, outsB = ins[:nin], ins[nin:], outs[:2], outs[2:]
+        for half in (insA, insB):
+            guard = 0
+            while not self.call_limits_ok(base, [self.bound[v] for v in half]):
+                v = max(half, key=lambda x: (self.bound[x].mag(), -half.index(x)))
+                before = self.bound[v].mag()
+                self.narrow(v, k)
+                guard += 1
+                assert self.bound[v].mag() < before or guard < 8, "cannot meet the routine's input limits"
+        want = {slots[i]: insA[i] for i in range(nin)}
+        clob = set(R["clob"])
+        busy = clob | set(slots)
+        for s_ in sorted(busy):                              # vacate what the routine overwrites, and operand slots that hold something else
+            w = self.at.get(("v", s_))
+            if w is None or (s_ in want and want[s_] == w):
+                continue
+            if self.next_use(w, k) == INF:
+                self.release(w)
+                continue
+            u = self.next_use(w, k + 1 if w not in ins else k)
+            nk = self.p.ops[u][0] if u != INF else None
+            if w not in ins and nk is not None and is_product(nk) and self.free_block("a", self.a_pool) is not None:
+                self.spill(w)
+            else:
+                b = self.alloc_v(k, avoid=busy)
+                self.copy(("v", s_), ("v", b)); self.place(w, ("v", b))
+        overwritten = {slots[i] for i in range(nin) if insB[i] != insA[i]}       # slots that hold the second product's operand on the odd lanes
+        for s_, v in want.items():                           # the first product's operands into their slots
+            keeps = self.next_use(v, k + 1) != INF or v in insB                   # the value is needed again (the second product counts)
+            if self.loc[v] == ("v", s_):
+                if s_ in overwritten and keeps:              # it must survive somewhere the odd lanes do not overwrite
+                    self.spill(v)
+                continue
+            if self.loc[v][0] == "vw":
+                self.to_vgpr(v, k)
+            src = self.loc[v]
+            self.copy(src, ("v", s_))
+            if not (s_ in overwritten and keeps) and (src[0] != "v" or self.next_use(v, k + 1) == INF or src[1] in clob):
+                self.place(v, ("v", s_))
+        for v in insB:                                       # the second product's operands must be readable without side effects: registers or LDS
+            if self.loc[v][0] not in ("v", "a", "l"):
+                self.to_vgpr(v, k, avoid=tuple(busy))
+        self.wait_lds()
+        moves = [(slots[i], insB[i]) for i in range(nin) if insB[i] != insA[i]]
+        if moves:
+            self.e("s_mov_b64 exec, %s" % PAIR_ROLE)
+            for s_, v in moves:
+                src = self.loc[v]
+                assert src != ("v", s_) and src[0] in ("v", "a", "l"), (src, s_)
+                self.copy(src, ("v", s_))                    # (the odd lanes execute it; stats and pending-LDS bookkeeping as for any move)
+            self.wait_lds()
+            self.e("s_mov_b64 exec, %s" % PAIR_EXEC)
+        for s_ in slots[:nin]:
+            w = self.at.get(("v", s_))
+            assert w is None or (w == want[s_] and not (s_ in overwritten and self.next_use(w, k + 1) != INF)), "operand slot holds a foreign or a half-overwritten live value"
+        self.prefetch(k, avoid=tuple(busy))
+        self.e("CALL " + R["name"])
+        self.stats["calls"] += 1
+        self.stats["pairs"] = self.stats.get("pairs", 0) + 1
+        for s_ in clob:
+            w = self.at.get(("v", s_))
+            if w is not None:
+                assert self.next_use(w, k + 1) == INF, "live value in a clobbered block across a call"
+                self.release(w)
+        for s_, v in moves:                                  # ... and the slots the odd lanes overwrote hold nothing that may be read again
+            w = self.at.get(("v", s_))
+            if w is not None:
+                assert self.next_use(w, k + 1) == INF
+                self.release(w)
+        o5, o6 = R["outs"]
+        self.at[("v", o5)] = ("tmp", 0); self.at[("v", o6)] = ("tmp", 1)          # keep the allocator off the results while it finds two more blocks
+        p0 = self.alloc_v(k, avoid=tuple(busy))
+        self.at[("v", p0)] = ("tmp", 2)
+        p1 = self.alloc_v(k, avoid=tuple(busy) + (p0,))
+        for key in (("v", o5), ("v", o6), ("v", p0)):
+            del self.at[key]
+        self.wait_lds()
+        self.e("s_nop 1")                                    # the routine's last writes to blocks 5, 6 and the cross-lane reads below
+        for (dst, src) in ((p0, o5), (p1, o6)):
+            for j in range(14):
+                self.e("v_mov_b32_dpp v%d, v%d %s" % (vb(dst) + j, vb(src) + j, DPP_SWAP))
+        self.e("s_mov_b64 exec, %s" % PAIR_ROLE)
+        for (x, y) in ((o5, p0), (o6, p1)):
+            for j in range(14):
+                self.e("v_swap_b32 v%d, v%d" % (vb(x) + j, vb(y) + j))
+        self.e("s_mov_b64 exec, %s" % PAIR_EXEC)
+        self.stats["vmov"] += 56
+        obA = self.call_bounds(base, [self.bound[v] for v in insA])
+        obB = self.call_bounds(base, [self.bound[v] for v in insB])
+        for o, blk, bd in ((outsA[0], o5, obA[0]), (outsA[1], o6, obA[1]), (outsB[0], p0, obB[0]), (outsB[1], p1, obB[1])):
+            self.place(o, ("v", blk))
+            self.bound[o] = bd
 
     def do_store(self, k, a, dst):
         """dst: ('a', blk) home; the stored value must satisfy the routine's live-in bound (checked by the caller of run())"""
@@ -1502,13 +1669,15 @@ def prog_miller_add_d(k):
     return p
 
 
-def prog_miller(which, pairs=(0, 1)):
-    return {"dbl": lambda: prog_miller_dbl_d(pairs), "first": lambda: prog_miller_first_d(pairs), "add01": prog_miller_add_both_d}.get(
+def prog_miller(which, pairs=(0, 1), pair_mode=False):
+    p = {"dbl": lambda: prog_miller_dbl_d(pairs), "first": lambda: prog_miller_first_d(pairs), "add01": prog_miller_add_both_d}.get(
         which, lambda: prog_miller_add_d(which))()
+    return pair_products(p) if pair_mode else p
 
 
-def build_miller(which, pairs=(0, 1)):
-    p = prog_miller(which, pairs)
+def build_miller(which, pairs=(0, 1), pair_mode=False):
+    """pair_mode: the body for lane PAIRS (two lanes per Miller loop): independent products of one kind share a call (pair_products)"""
+    p = prog_miller(which, pairs, pair_mode)
     inb = {}
     for v, l in p.init_loc.items():
         inb[v] = PACKED if l[0] == "gd" else G_IN if l[0] == "g" else F_IN
@@ -1550,20 +1719,26 @@ def f_out_epilogue(ret="s[36:37]"):
     return epi
 
 
-def miller_loop_d_routine(pairs=(0, 1)):
+def pair_prologue():
+    """pair mode: PAIR_EXEC = the lanes that entered the routine, PAIR_ROLE = the odd ones among them"""
+    return ["s_mov_b64 %s, exec" % PAIR_EXEC, "v_mbcnt_lo_u32_b32 v254, -1, 0", "v_mbcnt_hi_u32_b32 v254, -1, v254", "v_and_b32_e64 v254, 1, v254",
+            "v_cmp_ne_u32_e64 %s, 0, v254" % PAIR_ROLE]
+
+
+def miller_loop_d_routine(pairs=(0, 1), pair_mode=False):
     """The whole two-pair Miller loop of a verification as ONE routine: f = prod_k f_{|x|,Q_k}(P_k) (the caller conjugates); with
     pairs = (1,) the loop of a single general pair (Q_1, P_1) for the n-pairing paths (pair 0's slots are then unused).
     In:  v252 LDS byte address of the lane's column (11 spill slots), v253 skip flags (bit k: pair k contributes 1),
          s[68:69] workspace base adjusted so that v252 is the lane offset, s70 bytes between consecutive words of a value;
          workspace slots 0..2 = (-px, py, pz^3) of pair 1, 3..6 = Q0 (affine x, y), 7..12 = Q1 (homogeneous x, y, z), 2^384 domain.
     Out: f in v108..v251 (twelve groups of 12 words, tower order, canonical, 2^384 domain). Workspace slots 31..42 are scratch."""
-    dbl, st_dbl = build_miller("dbl", pairs)
-    first, st_first = build_miller("first", pairs)
+    dbl, st_dbl = build_miller("dbl", pairs, pair_mode)
+    first, st_first = build_miller("first", pairs, pair_mode)
     two = len(pairs) == 2
-    add, st_add = build_miller("add01") if two else build_miller(1)
+    add, st_add = build_miller("add01", pairs, pair_mode) if two else build_miller(1, pairs, pair_mode)
     add_name = "add01" if two else "add1"
     W = lambda j: "v%d" % (vb(8) + j)              # work block of the shell
-    pro = ["s_mov_b64 s[36:37], s[30:31]", "s_waitcnt vmcnt(0)"] + shell_constants()
+    pro = ["s_mov_b64 s[36:37], s[30:31]", "s_waitcnt vmcnt(0)"] + shell_constants() + (pair_prologue() if pair_mode else [])
     pro += ["v_and_b32_e64 v254, 1, v253", "v_cmp_ne_u32_e64 %s, 0, v254" % SKIP_MASK[0], "v_and_b32_e64 v254, 2, v253", "v_cmp_ne_u32_e64 %s, 0, v254" % SKIP_MASK[1]]
     for k in pairs:                                 # T_k = Q_k, into the packed 2^392-domain slots
         for e in range(3):
@@ -1880,8 +2055,11 @@ FEXP_BODIES = dict(easy=prog_fexp_easy, pstart=prog_fexp_pstart, csqr=prog_fexp_
 FEXP_INLINE = ("csqr",)                          # the loop body that runs 315 times per item and fits the instruction cache with its products inlined (57 KB)
 
 
-def build_fexp(which):
+def build_fexp(which, pair_mode=False):
+    """pair_mode: the body for lane pairs -- independent products of one kind share a call (pair_products)"""
     p = FEXP_BODIES[which]()
+    if pair_mode:
+        pair_products(p)
     inb = {v: (STATE_IN if l[0] in ("a", "v") else PACKED if l[0] in ("gd", "gk") else G_IN) for v, l in p.init_loc.items()}
     al = AllocD(p, inb, n_lds=11, lds_base=0, a_pool=list(range(NA)), inline=(which in FEXP_INLINE),
                 free_v=(CSTATE_FREE_V if which in CSTATE_BODIES else None))
@@ -1979,7 +2157,7 @@ def final_exp_d_routine(two_lane=False):
     two_lane: the variant for lane PAIRS (see above): lanes 2 i and 2 i + 1 come with the same v252 and the same workspace item."""
     bodies, stats = {}, {}
     for name in FEXP_BODIES:
-        bodies[name], stats[name] = build_fexp(name)
+        bodies[name], stats[name] = build_fexp(name, pair_mode=two_lane)
     if two_lane:
         bodies.update(pstart=pstart2_body(), csqr=csqr2_body(), psave=psave2_body())
         for name in ("pstart", "csqr", "psave"):
@@ -1988,6 +2166,8 @@ def final_exp_d_routine(two_lane=False):
     POWER, CSQR = 60, 61
     next_rec = ["s_add_u32 %s, %s, s72" % (GKOFF, GKOFF)]
     pro = ["s_mov_b64 s[80:81], s[30:31]", "s_waitcnt vmcnt(0)"] + shell_constants() + ["s_mul_i32 s72, %s, %d" % (GSTRIDE, 12 * K_REC)]
+    if two_lane:
+        pro += pair_prologue()                      # the bodies outside the squaring chains have their products in pairs
     main = X("easy") + ["s_mov_b32 s79, 0", "5:"] + call_sub(POWER)
     main += ["s_cmp_lt_u32 s79, 2", "s_cbranch_scc1 13f"] + far_fwd(11) + ["13:"] + X("step_conj") + far_fwd(20)
     main += ["11:", "s_cmp_eq_u32 s79, 2", "s_cbranch_scc1 13f"] + far_fwd(12) + ["13:"] + X("step_frob") + far_fwd(20)
@@ -2896,6 +3076,11 @@ def main():
         print("miller", kname, len(pieces[kname]), "lines", v)
     full, pieces, st = miller_loop_d_routine((1,))
     txt += emit("MBLS_MILLER_LOOP_1P_D_ASM", full) + "\n"
+    full, pieces, st = miller_loop_d_routine((1,), pair_mode=True)
+    txt += emit("MBLS_MILLER_LOOP_1P_PAIR_D_ASM", full) + "\n"
+    print("miller single pair on TWO lanes: dbl", len(pieces["dbl"]), "lines", st["dbl"])
+    txt += "#define MBLS_PAIR_D_ASM_CLOBBERS \"s82\", \"s83\", \"s94\", \"s95\"\n"
+    txt += "#define MBLS_PAIR_EXEC_ASM_CLOBBERS \"s82\", \"s83\"\n"
     print("miller single pair: dbl", len(pieces["dbl"]), "lines", st["dbl"])
     sgm = '"s30","s31","s36","s37","s39","s40","s41","s42","s43","s44","s45","s46","s47","s48","s49","s54","s55","s56","s57","s58","s59","s60","s61","s62","s63","s64","s65","s66","s67","s73","s74","s75","s76","s77","s78","vcc","scc","memory"'
     fout = set(r for b in F_OUT for r in range(b, b + 12))
