@@ -562,11 +562,11 @@ __global__ void __launch_bounds__(WG) k_valu_bench(uint32_t* sink, uint32_t iter
 // creation per call once the sizes have been seen); device-pointer entries only enqueue, and order their use of the
 // workspace against earlier calls on other streams with an event.
 #define MBLS_N_STAGE 10
-// measured crossovers (scripts/throughput_vs_n.py, 128 keys, device-resident): one wave per item for the pairing check wins up to ~6 k items
-// (13.3 ms at 6 144; the lane path with four lanes per item in the Miller loop and two in the message phase and the final exponentiation needs
-// ~13.5 ms for anything up to a quarter of a round), for the message phase as well up to ~6 k
-#define MBLS_DEFAULT_COOP_MAX_ITEMS 6144
-#define MBLS_DEFAULT_COOP_HASH_MAX_ITEMS 6144
+// measured crossovers (scripts/throughput_vs_n.py, 128 keys, device-resident): one wave per item wins up to ~5 k items (10.3 ms at 4 096, ~11.8 at
+// 5 120); the lane path with four lanes per item in the Miller loop and two in the message phase and the final exponentiation (products in pairs)
+// needs 12.2-12.7 ms for anything up to a quarter of a round
+#define MBLS_DEFAULT_COOP_MAX_ITEMS 5120
+#define MBLS_DEFAULT_COOP_HASH_MAX_ITEMS 5120
 struct mbls_ctx {
     std::recursive_mutex mu;
     int device = 0;

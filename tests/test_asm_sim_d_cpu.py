@@ -975,44 +975,84 @@ def test_g2_hash_routine():
 
 
 def test_g2_hash_routine_two_lanes_per_message():
-    """k_hash2's routine: the even lane maps u0, the odd lane (a workspace item of its own, 4 bytes further on, u1 in the slots of u0) maps
-    u1 with the SAME body; the even lane then takes q1 from the neighbour's item (h_start2) and goes on alone -- same H as the one-lane
-    routine's model, left in the even lane's item"""
+    """k_hash2's routine on a lane pair: the even lane maps u0, the odd lane (a workspace item of its own, 4 bytes further on, u1 in the slots
+    of u0) maps u1 with the SAME body; then both fetch q0 / q1 from the even / odd lane's item (per-lane offsets) and walk the addition and
+    the cofactor clearing together, products in pairs -- the model's H in BOTH items"""
+    from asm_sim import run_pair
     M = _g2m()
     import gen_fp_asm as gf
     rng = random.Random(12)
     S = t.G2_SLOTS
     u = [(rng.randrange(P), rng.randrange(P)) for _ in range(2)]
-    m, state, masks, step, add, ladder = g2_piece_runner("hash", two_lane=True)
-    full, pieces, _ = t.g2_group_routine("hash", two_lane=True)
-    assert sum(1 for l in full if l == "s_and_b64 exec, exec, s[94:95]") == 1 and full.count("s_mov_b64 exec, %s" % t.EXEC_ACT) == 1
+    full, pieces, st = t.g2_group_routine("hash", two_lane=True)
+    assert st["dbl"].get("pairs") == 3 and st["add"].get("pairs") == 7 and "pairs" not in st["sswu"] and "pairs" not in st["fix"]
     # the control skeleton is the one-lane routine's minus one map_to_curve body (a shape check: the bodies themselves are run piece by piece below)
     full1, pieces1, _ = t.g2_group_routine("hash")
-    x = lambda b: len(t.expand_calls_d(b))
-    assert len(full1) - len(full) == x(pieces1["sswu"]) + x(pieces1["h_start"]) - x(pieces["h_start2"]) - 6
-    mb = miller_machine(0); mb.mem = m.mem                       # the odd lane: its own registers and LDS column, the same memory,
-    mb.s[68] = (GBASE + 4) & 0xFFFFFFFF; mb.s[69] = (GBASE + 4) >> 32      # its item one word further on
-    mb.run(pieces["pro"])
-    for mm_ in (m, mb):
-        mm_.routines.update(gf.pow_subroutines()); mm_.routines["mbls_fp_pow_pm3d4_asm_fn"] = gf.pow_body(gf.EXP_PM3D4)
-    for lane, mach in ((0, m), (1, mb)):
+    assert full.count("CALL") == 0 and sum(1 for l in full if l.startswith("s_mov_b64 exec, %s" % t.PAIR_ROLE)) >= 2 * (3 + 7 + 7)
+    ma, mb = miller_machine(0), miller_machine(0)
+    mb.mem = ma.mem                                                # own registers and LDS columns, the same memory
+    mb.s[68] = (GBASE + 4) & 0xFFFFFFFF; mb.s[69] = (GBASE + 4) >> 32   # the odd lane's item lies one word further on; v252 is the same column
+    for lane, mach in ((0, ma), (1, mb)):                          # address in both (LDS is per machine here)
+        mach.lane = 6 + lane; mach.model_exec = True
+        mach.routines = dict(ROUT); mach.routines.update(gf.pow_subroutines()); mach.routines["mbls_fp_pow_pm3d4_asm_fn"] = gf.pow_body(gf.EXP_PM3D4)
+    run_pair(ma, mb, pieces["pro"])
+    assert (ma.s[("pair", 94)], mb.s[("pair", 94)]) == (0, 1)
+    masks = {}
+    q = []
+    for lane, mach in ((0, ma), (1, mb)):
         for i in range(2):
             for j, w in enumerate(limbs(u[lane][i] * R384 % P)):
                 mach.mem[ws_addr(S["U"] + i, j) + 4 * lane] = w
         mach.s[71] = 0
-        mach.run(pieces["sswu"])
+    run_pair(ma, mb, pieces["sswu"])
+    # from here on the model of the one-lane routine applies to BOTH lanes: the machine's only own business is where q0 and q1 come from
+    state = {}
+    for lane in (0, 1):
         mp = run_model(t.prog_sswu, {("gka", S["U"] + i): u[lane][i] for i in range(2)}, masks)
         for slot, v in mp.out_g.items():
-            state[("gd", slot[1] + 6 * lane)] = v                # the model keeps q1 where the one-lane routine has it
-    m.s[71] = 4
-    step("h_start2"); add(); step("h_base1"); ladder(t.RUNS); step("h_after1"); step("dbl"); step("h_psi2"); add("sub")
+            state[("gd", slot[1] + 6 * lane)] = v
+    ad = S["AD"]
+    progs = {"add": lambda: t.prog_g2_add(ad, False), "sub": lambda: t.prog_g2_add(ad, True), "dbl": t.prog_g2_dbl_d, "fix": lambda: t.prog_g2_dbl_d(6, 0)}
+
+    def step(name, model=None):
+        run_pair(ma, mb, pieces[name])
+        model = model or name
+        if model == "none":
+            return
+        mp = run_model(progs.get(model, lambda: t.prog_g2_glue(model)), state, masks)
+        for loc, v in mp.out_home.items():
+            state[loc] = v
+        for slot, v in mp.out_g.items():
+            state[("gd", slot)] = v
+        for m_ in (ma, mb):
+            for i in range(6):
+                if ("a", i) in state:
+                    assert from_digits_signed(m_.a[14 * i:14 * i + 14]) * RI392 % P == state[("a", i)], (name, i)
+
+    def add(name="add"):
+        step(name)
+        for m_ in (ma, mb):
+            for nm, idx in ((t.M_H0, 52), (t.M_R0, 54), (t.M_INF1, 84), (t.M_INF2, 48)):
+                assert m_.s[("pair", idx)] == masks[nm], (name, nm)
+        if masks[t.M_H0] and masks[t.M_R0] and not masks[t.M_INF1] and not masks[t.M_INF2]:
+            step("fix")
+
+    def ladder(runs):
+        for ph, n_ in enumerate(runs):
+            for _ in range(n_):
+                step("dbl")
+            if ph < len(runs) - 1:
+                add("add")
+    step("voff_q1", "none"); step("h_q1", "none"); step("voff_q0", "none"); step("h_q0", "h_start")      # together they are the one-lane routine's h_start
+    add(); step("h_base1"); ladder(t.RUNS); step("h_after1"); step("dbl"); step("h_psi2"); add("sub")
     step("h_t3"); add(); step("h_base2"); ladder(t.RUNS); step("h_after2"); add()
     step("h_ad_t1"); add("sub"); step("h_ad_p"); add("sub")
     want = M.clear_cofactor_g2(M.g2_add(M.iso3_g2(M.sswu_g2(u[0])), M.iso3_g2(M.sswu_g2(u[1]))))
-    m.run(pieces["epi"][:-2])
+    run_pair(ma, mb, pieces["epi"][:-1])
     ri = pow(R384, -1, P)
-    got = [(ws_get(m, S["H"] + 2 * e) * ri % P, ws_get(m, S["H"] + 2 * e + 1) * ri % P) for e in range(3)]
-    assert jac2_affine(M, *got) == want
+    for lane in (0, 1):
+        got = [tuple(from_limbs([ma.mem[ws_addr(S["H"] + 2 * e + h, j) + 4 * lane] for j in range(12)]) * ri % P for h in range(2)) for e in range(3)]
+        assert jac2_affine(M, *got) == want, lane
 
 
 def test_compressed_squaring_decompression_formulas():

@@ -2660,8 +2660,10 @@ def prog_g2_glue(which):
     one = lambda: (p.const(ONE_D), p.const(0))
     if which == "h_start":                           # acc = q0, AD = q1 (the map_to_curve outputs, packed by the sswu body)
         pt_park(p, gd("Q1"), S["AD"]); pt_store_acc(p, gd("Q0"))
-    elif which == "h_start2":                        # two lanes per message: q1 is what the NEIGHBOUR lane's map left in ITS item's q0 slots
-        pt_park(p, pt_live_in(p, "gk", S["Q0"]), S["AD"]); pt_store_acc(p, gd("Q0"))      # (the run-time offset = one item = 4 bytes)
+    elif which == "h_q1":                            # two lanes per message: AD = q1 = what the ODD lane's map left in its item's q0 slots, and
+        pt_park(p, pt_live_in(p, "gv", S["Q0"]), S["AD"])      # (VOFF = that item's lane offset: the neighbour's for the even lane)
+    elif which == "h_q0":                            # acc = q0 = what the EVEN lane's map left in its item (VOFF = that item)
+        pt_store_acc(p, pt_live_in(p, "gv", S["Q0"]))
     elif which == "h_base1":                         # p = q0 + q1: remember it, and it is the ladder's base
         a = acc(); pt_park(p, a, S["P"]); pt_park(p, a, S["AD"]); pt_store_acc(p, a)
     elif which == "h_after1":                        # t1 = -[|x|]p; t2 = psi(p); acc = p (to be doubled)
@@ -2707,7 +2709,8 @@ def prog_g2_glue(which):
     return p
 
 
-def build_g2(which, ad_slot=None, free_v=None):
+def build_g2(which, ad_slot=None, free_v=None, pair_mode=False):
+    """pair_mode: the body for lane pairs -- independent products of one kind share a call (pair_products)"""
     if which in ("add", "sub"):
         p = prog_g2_add(ad_slot, which == "sub")
     elif which == "addt":
@@ -2722,6 +2725,8 @@ def build_g2(which, ad_slot=None, free_v=None):
         p = prog_sswu()
     else:
         p = prog_g2_glue(which)
+    if pair_mode:
+        pair_products(p)
     inb = {v: (G2_IN if l[0] == "a" else PACKED if l[0] in ("gd", "gk", "gv") else G_IN) for v, l in p.init_loc.items()}      # g, gka: 2^384-domain words
     al = AllocD(p, inb, n_lds=11, lds_base=0, a_pool=list(range(NA)), free_v=free_v)
     body = al.run()
@@ -2739,21 +2744,23 @@ def g2_group_routine(kind, two_lane=False):
     """kind 'hash': in  q0 in workspace slots 7..12, q1 in 19..24 (Jacobian, 2^384 domain, canonical); out: clear_cofactor(q0 + q1) in
     slots 7..12 (same form). kind 'sig': in  the signature's affine x, y in slots 3..6; out: v251 = 1 iff psi(P) = [x]P.
     v252 / s[68:69] / s70: LDS column (11 spill slots) and workspace addressing as in the other routines.
-    kind 'hash', two_lane (k_hash2, batches of at most half a round): lanes 2 j and 2 j + 1 are ONE message with workspace items of their own,
-    next to each other; the even lane comes with u0, the odd one with u1 in the slots of u0, each runs ONE map_to_curve, then the odd lanes
-    are switched off and the even ones fetch q1 from the neighbour's item and go on alone: H in the EVEN lane's item."""
+    kind 'hash', two_lane (k_hash2, batches of at most a quarter of a round): lanes 2 j and 2 j + 1 are ONE message with workspace items of
+    their own, next to each other; the even lane comes with u0, the odd one with u1 in the slots of u0, each runs ONE map_to_curve; then
+    both fetch q0 from the even lane's item and q1 from the odd lane's and walk the rest together on identical values -- the products of the
+    addition, the doublings and the glue in pairs (pair_products): H in BOTH items."""
     S = G2_SLOTS
     ad = S["AD"] if kind == "hash" else S["SIGAD"]
     B = {}
     st = {}
-    names = ["add", "dbl", "fix"] + (["sswu", "sub", "h_start2" if two_lane else "h_start", "h_base1", "h_after1", "h_psi2", "h_t3", "h_base2", "h_after2", "h_ad_t1", "h_ad_p"] if kind == "hash" else ["madd", "s_start", "s_compare"])
-    for nm in names:
-        B[nm], st[nm] = build_g2(nm, ad)
+    names = ["add", "dbl", "fix"] + (["sswu", "sub"] + (["h_q1", "h_q0"] if two_lane else ["h_start"]) + ["h_base1", "h_after1", "h_psi2", "h_t3", "h_base2", "h_after2", "h_ad_t1", "h_ad_p"] if kind == "hash" else ["madd", "s_start", "s_compare"])
+    for nm in names:                                # (the maps differ between the lanes, the doubling fix-up runs under its own exec mask: no pairs there)
+        B[nm], st[nm] = build_g2(nm, ad, free_v=(BL_FREE_V if nm in ("h_q1", "h_q0") else None), pair_mode=(two_lane and nm not in ("sswu", "fix")))
     X = lambda nm: expand_calls_d(B[nm])
     ADD, SUB, LADDER = 50, 51, 52
     pro = ["s_mov_b64 s[80:81], s[30:31]", "s_waitcnt vmcnt(0)"] + shell_constants() + ["s_mov_b64 %s, exec" % EXEC_ALL]
     if two_lane:
-        pro += ["s_mov_b64 %s, exec" % EXEC_ACT]    # the caller's exec mask: restored before the return
+        assert PAIR_EXEC == EXEC_ALL                # one register: the lanes that entered the routine
+        pro += pair_prologue()
 
     def fixup():                                    # equal operands (same x, same y, neither at infinity): double the old acc on those lanes
         return ["s_and_b64 s[92:93], %s, %s" % (M_H0, M_R0), "s_andn2_b64 s[92:93], s[92:93], %s" % M_INF1, "s_andn2_b64 s[92:93], s[92:93], %s" % M_INF2,
@@ -2774,9 +2781,12 @@ def g2_group_routine(kind, two_lane=False):
     if kind == "hash":
         # the two map_to_curve evaluations: u0 -> q0, u1 -> q1 (records six slots apart)
         if two_lane:                                # one map per lane; then the even lanes alone, their neighbour's point one item (4 bytes) further on
-            main = ["s_mov_b32 %s, 0" % GKOFF] + X("sswu") + ["s_waitcnt vmcnt(0)", "s_mov_b32 s94, 0x55555555", "s_mov_b32 s95, 0x55555555",
-                                                            "s_and_b64 exec, exec, s[94:95]", "s_mov_b64 %s, exec" % EXEC_ALL, "s_mov_b32 %s, 4" % GKOFF]
-            main += X("h_start2")
+            main = ["s_mov_b32 %s, 0" % GKOFF] + X("sswu") + ["s_waitcnt vmcnt(0)"]
+            # VOFF = the lane offset of the item that holds q1 (the odd lane's): own + 4 on even lanes, own on odd lanes; then of q0's: 4 less
+            B["voff_q1"] = ["v_mbcnt_lo_u32_b32 v254, -1, 0", "v_mbcnt_hi_u32_b32 v254, -1, v254", "v_and_b32_e64 v254, 1, v254", "v_lshlrev_b32_e64 v254, 2, v254",
+                            "v_sub_u32_e64 %s, %s, v254" % (VOFF, LADDR), "v_add_u32_e64 %s, 4, %s" % (VOFF, VOFF)]
+            B["voff_q0"] = ["v_sub_u32_e64 %s, %s, 4" % (VOFF, VOFF)]
+            main += B["voff_q1"] + X("h_q1") + B["voff_q0"] + X("h_q0")
         else:
             main = ["s_mul_i32 s72, %s, %d" % (GSTRIDE, 12 * 6), "s_mov_b32 %s, 0" % GKOFF] + X("sswu") + ["s_mov_b32 %s, s72" % GKOFF] + X("sswu")
             main += X("h_start")
@@ -2798,8 +2808,6 @@ def g2_group_routine(kind, two_lane=False):
         epi = ["s_and_b64 s[92:93], %s, %s" % (M_H0, M_R0), "s_andn2_b64 s[92:93], s[92:93], %s" % M_INF1, "s_andn2_b64 s[92:93], s[92:93], %s" % M_INF2,
                "s_and_b64 %s, %s, %s" % (G2M_TMP0, M_INF1, M_INF2), "s_or_b64 s[92:93], s[92:93], %s" % G2M_TMP0, "v_cndmask_b32_e64 v251, 0, 1, s[92:93]"]
     epi += ["s_waitcnt vmcnt(0)", "s_mov_b64 s[30:31], s[80:81]"]
-    if two_lane:
-        epi += ["s_mov_b64 exec, %s" % EXEC_ACT]
     ret = ["s_setpc_b64 s[30:31]"]                  # the routine's own return: the subroutines follow it
     pieces = dict(B, pro=pro, epi=epi)
     return pro + main + expand_calls_d(epi) + ret + lad + subs, pieces, st          # every internal call is a forward jump
