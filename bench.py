@@ -520,6 +520,46 @@ def config5_leg(ctx, lib, dev, sptr, rank, world, k):
             "bitmap_matches_expectation": ok}
 
 
+def sharded_verify_multiple_leg(ctx, lib, dev, sptr, rank, world, k, nn=1 << 14):
+    """BASELINE configs[3] cut into shards ("one exchange step"): every rank runs 2^14 sets x k keys up to its 896-byte
+    record (mbls_verify_multiple_partial_device), the records are all-gathered (RCCL), every rank joins them in rank order
+    (mbls_verify_multiple_finish_device) and holds the same bool. On one GPU the same sets go through as two shards + join, beside the one-call time."""
+    from milagro_bls_amd import batch
+    P = N.VM_PARTIAL_BYTES
+    v_sigs, v_msgs, v_pks, _ = build_inputs(ctx, dev, nn, k, N.PK_UNCOMPRESSED, rank=12 + 31 * rank, negatives=False)
+    g = torch.Generator(device="cpu"); g.manual_seed(7 + rank)
+    rands = torch.randint(1, (1 << 62), (nn,), dtype=torch.int64, generator=g).to(dev)
+    shards = world if world > 1 else 2
+    recs = torch.zeros(shards * P, dtype=torch.uint8, device=dev)
+    mine = torch.zeros(P, dtype=torch.uint8, device=dev)
+    d_r = torch.full((8,), 7, dtype=torch.uint8, device=dev)
+
+    def step():
+        if world > 1:
+            batch.verify_multiple_partial_device(v_sigs.data_ptr(), v_msgs.data_ptr(), rands.data_ptr(), nn, mine.data_ptr(), d_pks=v_pks.data_ptr(), k=k,
+                                                 pk_format=N.PK_UNCOMPRESSED, stream=sptr)
+            dist.all_gather_into_tensor(recs, mine)
+        else:
+            h = nn // 2
+            for j, (lo, cnt) in enumerate(((0, h), (h, nn - h))):
+                batch.verify_multiple_partial_device(v_sigs[lo:].data_ptr(), v_msgs[lo:].data_ptr(), rands[lo:].data_ptr(), cnt, recs.data_ptr() + j * P,
+                                                     d_pks=v_pks[lo:].data_ptr(), k=k, pk_format=N.PK_UNCOMPRESSED, stream=sptr)
+        batch.verify_multiple_finish_device(recs.data_ptr(), shards, d_result=d_r.data_ptr(), stream=sptr)
+    steps = 5
+    elapsed = timed_steps(step, steps, 2, world, torch.cuda.synchronize)
+    ok_true = int(d_r[0].item()) == 1
+    if rank == world - 1:                                                  # one corrupted set on the last rank must turn every rank's bool
+        v_msgs[nn // 3, 5] ^= 0x10
+    step(); torch.cuda.synchronize()
+    ok_false = int(d_r[0].item()) == 0
+    if rank == world - 1:
+        v_msgs[nn // 3, 5] ^= 0x10
+    ok = reduce_all_ok(ok_true and ok_false, world)
+    return {"workload": "verify_multiple_aggregate_signatures, %d sets x %d keys per GPU, %d shard(s) + one join%s" % (
+                nn, k, shards, " (RCCL all-gather of %d x %d bytes)" % (world, P) if world > 1 else " on one device"),
+            "ms_per_step": elapsed / steps * 1e3, "sets_per_s": nn * world * steps / elapsed, "steps": steps, "correct": ok}
+
+
 def _free_port():
     import socket
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
@@ -776,6 +816,10 @@ def main():
             leg = multi_handle_leg(lib, table, d_sigs, d_msgs, d_idx, expect, n, k, list(range(G)))
             multi_legs.append(leg)
             ok = ok and leg["results_match"]
+    vm_leg = None
+    if n == (1 << 16) and not args.no_variants:
+        vm_leg = sharded_verify_multiple_leg(ctx, lib, dev, sptr, rank, world, k)
+        ok = ok and vm_leg["correct"]
     shard_leg = None
     if world == 8 and n == (1 << 16):
         # BASELINE configs[4] as it is named: 2^20 items over 8 GPUs = 2^17 per rank (the default legs above are configs[2] per GPU)
@@ -818,6 +862,7 @@ def main():
             "other_configs": other,
             "multi_handle_leg": multi_legs,
             "configs4_shard_leg": shard_leg,
+            "sharded_verify_multiple_leg": vm_leg,
             "input_build_s": t_in,
             "head": git_head(),
         }

@@ -175,6 +175,11 @@ int mbls_multi_fast_aggregate_verify_batch(mbls_multi* m, const uint8_t* sigs, c
                                            uint64_t n, uint32_t k, uint8_t* results, uint32_t* status);
 int mbls_multi_verify_batch(mbls_multi* m, const uint8_t* sigs, const uint8_t* msgs, uint32_t msg_len, const uint64_t* msg_offsets,
                             const uint8_t* pks, int pk_format, uint64_t n, uint8_t* results, uint32_t* status);
+/* verify_multiple_aggregate_signatures over the devices of the handle: device g runs sets [n g / G, n (g + 1) / G) up to its partial record
+ * (mbls_verify_multiple_partial_device), the first device joins the G records and runs the tail: the same bool as
+ * mbls_verify_multiple_aggregate_signatures on one device, same arguments. */
+int mbls_multi_verify_multiple_aggregate_signatures(mbls_multi* m, const uint8_t* sigs96, const uint8_t* apks96, const uint8_t* msgs,
+                                                    uint32_t msg_len, const uint64_t* msg_offsets, const uint64_t* rands, size_t n);
 /* a key table replicated on every device of the handle: same indices everywhere */
 typedef struct mbls_multi_keytable mbls_multi_keytable;
 int mbls_multi_keytable_create(mbls_multi* m, uint64_t capacity_hint, mbls_multi_keytable** out);
@@ -258,6 +263,22 @@ int mbls_verify_multiple_sets_device(mbls_ctx* ctx, const uint8_t* d_sigs96, con
                                      const uint32_t* d_pk_offsets, uint32_t k, const uint8_t* d_msgs, uint32_t msg_len,
                                      const uint64_t* d_msg_offsets, const uint64_t* d_rands, uint64_t n, uint8_t* d_result,
                                      uint32_t* d_status, void* stream);
+
+/* verify_multiple over several devices or processes ("one exchange step"; the reference's function is one loop over
+ * one iterator, src/aggregates.rs:261-316 -- the product of pairings and the sum of blinded signatures it accumulates are associative, so
+ * the sets may be cut into shards): every participant runs mbls_verify_multiple_partial_device over ITS sets and gets one
+ * MBLS_VM_PARTIAL_BYTES record (the shard's Miller product, its sum of [r_i] sig_i, the OR of its status words; opaque, in the library's
+ * own number format: exchange it only between builds of the same library); the records are exchanged (RCCL all-gather of G x 896 bytes, or
+ * through the host), and mbls_verify_multiple_finish_device joins G records -- any G >= 0, in any order as long as every participant uses
+ * the same -- into the bool the one-device call returns for the concatenated sets. Keys: d_apks96 (one aggregate key per set) or, when
+ * that is NULL, d_pks / pk_format / d_pk_offsets / k as in mbls_verify_multiple_sets_device. An empty shard (n = 0) is a valid
+ * participant. Both entries only enqueue. */
+#define MBLS_VM_PARTIAL_BYTES 896
+int mbls_verify_multiple_partial_device(mbls_ctx* ctx, const uint8_t* d_sigs96, const uint8_t* d_apks96, const uint8_t* d_pks, int pk_format,
+                                        const uint32_t* d_pk_offsets, uint32_t k, const uint8_t* d_msgs, uint32_t msg_len,
+                                        const uint64_t* d_msg_offsets, const uint64_t* d_rands, uint64_t n, uint8_t* d_partial, void* stream);
+int mbls_verify_multiple_finish_device(mbls_ctx* ctx, const uint8_t* d_partials, uint64_t n_partials, uint8_t* d_result, uint32_t* d_status,
+                                       void* stream);
 
 /* ---- batch helpers used to build inputs and caches on the device ---- */
 /* n x PublicKey::from_bytes[_unchecked] / from_uncompressed_bytes: errs[i] = MBLS_OK / MBLS_ERR_* per key */

@@ -252,6 +252,22 @@ struct AggregateSignature {
         }
         return mbls_verify_multiple_aggregate_signatures(detail::ctx(), sigs.data(), apks.data(), msgs.data(), 0, moff.data(), rands.data(), sets.size()) == 1;
     }
+    // the same check with the sets cut into one shard per device of a multi-device handle (mbls_multi_create): same bool
+    template <typename Rng>
+    static bool verify_multiple_aggregate_signatures(mbls_multi* devices, Rng&& rng, const std::vector<std::tuple<const AggregateSignature*, const AggregatePublicKey*, Bytes>>& sets) {
+        if (sets.empty()) return true;
+        Bytes sigs, apks, msgs; std::vector<uint64_t> rands, moff{0};
+        for (auto& s : sets) {
+            uint64_t r = 0;
+            while (r == 0) { uint64_t v = 0; for (int i = 0; i < 8; i++) v = (v << 8) | uint8_t(rng()); r = (v >> 63) ? (uint64_t(0) - v) : v; }
+            rands.push_back(r);
+            sigs.insert(sigs.end(), std::get<0>(s)->point.begin(), std::get<0>(s)->point.end());
+            apks.insert(apks.end(), std::get<1>(s)->point.begin(), std::get<1>(s)->point.end());
+            msgs.insert(msgs.end(), std::get<2>(s).begin(), std::get<2>(s).end());
+            moff.push_back(msgs.size());
+        }
+        return mbls_multi_verify_multiple_aggregate_signatures(devices, sigs.data(), apks.data(), msgs.data(), 0, moff.data(), rands.data(), sets.size()) == 1;
+    }
     static AggregateSignature from_bytes(const Bytes& b) { AggregateSignature a; detail::check(mbls_sig_from_bytes(detail::ctx(), b.data(), b.size(), a.point.data())); return a; }
     std::array<uint8_t, 96> as_bytes() const { return point; }
     bool operator==(const AggregateSignature& o) const { return point == o.point; }

@@ -17,6 +17,7 @@ ERR_INVALID_SECRET_KEY_RANGE = 6
 ERR_DEVICE = 100
 ERR_ARGUMENT = 101
 PK_COMPRESSED, PK_UNCOMPRESSED = 0, 1
+VM_PARTIAL_BYTES = 896          # include/mbls.h MBLS_VM_PARTIAL_BYTES
 N_PHASES = 6
 PHASE_NAMES = ("aggregate", "sig", "hash", "miller", "final", "pack")
 
@@ -72,6 +73,9 @@ SIGNATURES = {
     "mbls_verify_multiple_aggregate_signatures": (C.c_int, [vp, vp, vp, vp, C.c_uint32, vp, vp, C.c_size_t]),
     "mbls_verify_multiple_aggregate_signatures_device": (C.c_int, [vp, vp, vp, vp, C.c_uint32, vp, vp, C.c_uint64, vp, vp, vp]),
     "mbls_verify_multiple_sets_device": (C.c_int, [vp, vp, vp, C.c_int, vp, C.c_uint32, vp, C.c_uint32, vp, vp, C.c_uint64, vp, vp, vp]),
+    "mbls_verify_multiple_partial_device": (C.c_int, [vp, vp, vp, vp, C.c_int, vp, C.c_uint32, vp, C.c_uint32, vp, vp, C.c_uint64, vp, vp]),
+    "mbls_verify_multiple_finish_device": (C.c_int, [vp, vp, C.c_uint64, vp, vp, vp]),
+    "mbls_multi_verify_multiple_aggregate_signatures": (C.c_int, [vp, vp, vp, vp, C.c_uint32, vp, vp, C.c_size_t]),
     "mbls_pk_decode_batch": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_uint64, vp, vp]),
     "mbls_pk_compress_batch": (C.c_int, [vp, vp, C.c_uint64, vp, vp]),
     "mbls_sig_check_batch": (C.c_int, [vp, vp, C.c_uint64, vp, vp]),

@@ -171,6 +171,36 @@ def verify_multiple_sets_device(d_sigs, d_pks, d_msgs, d_rands, n, k, pk_format=
     return bool(v)
 
 
+def verify_multiple_partial_device(d_sigs, d_msgs, d_rands, n, d_partial, d_apks=None, d_pks=None, k=0, pk_format=N.PK_COMPRESSED, msg_len=32, stream=None, ctx=None):
+    """One shard of a verify_multiple that is spread over several devices or processes (include/mbls.h): the shard's
+    Miller product, signature sum and status bits as one N.VM_PARTIAL_BYTES record at the device address d_partial. Enqueues only."""
+    ctx = ctx or _c()
+    ctx.check(N.lib().mbls_verify_multiple_partial_device(ctx.handle, d_sigs, d_apks, d_pks, pk_format, None, k, d_msgs, msg_len, None, d_rands, n, d_partial, stream))
+
+
+def verify_multiple_finish_device(d_partials, n_partials, d_result=None, d_status=None, stream=None, ctx=None):
+    """The records of all shards (n_partials x N.VM_PARTIAL_BYTES at d_partials, the same order on every participant) -> the bool of the
+    one-device call over the concatenated sets. With d_result the call only enqueues; without, it synchronises and returns the bool."""
+    ctx = ctx or _c()
+    if d_result is not None:
+        ctx.check(N.lib().mbls_verify_multiple_finish_device(ctx.handle, d_partials, n_partials, d_result, d_status, stream))
+        return None
+    import torch
+    res = torch.full((8,), 7, dtype=torch.uint8, device="cuda")
+    ctx.check(N.lib().mbls_verify_multiple_finish_device(ctx.handle, d_partials, n_partials, res.data_ptr(), d_status, stream))
+    torch.cuda.synchronize()
+    v = int(res[0].item())
+    assert v in (0, 1)
+    return bool(v)
+
+
+def multi_verify_multiple_aggregate_signatures(mctx, sigs, apks, msgs, rands, n, msg_len=32, msg_offsets=None):
+    """verify_multiple_aggregate_signatures (reference src/aggregates.rs:261-316) sharded over the devices of a MultiContext: host buffers
+    (sigs 96 B each, decoded aggregate keys 96 B each, messages, 64-bit scalars) -> bool"""
+    r = (C.c_uint64 * max(1, n))(*rands)
+    return bool(N.lib().mbls_multi_verify_multiple_aggregate_signatures(mctx.handle, N.cbuf(sigs), N.cbuf(apks), N.cbuf(msgs), msg_len, _moff(msg_offsets), r, n))
+
+
 def multi_fast_aggregate_verify_batch(mctx, sigs, msgs, pks, n, k=None, pk_format=N.PK_COMPRESSED, msg_len=32, pk_offsets=None, msg_offsets=None):
     """fast_aggregate_verify_batch sharded over the devices of a MultiContext (include/mbls.h, mbls_multi_*)"""
     res = N.outbuf(n)

@@ -417,6 +417,43 @@ __global__ void MBLS_LB k_status_or(const uint32_t* status, uint64_t n, uint32_t
     uint64_t i = gid(); uint32_t v = (i < n) ? status[i] : 0;
     if (__ballot(v != 0)) { if (v) atomicOr(out, v); }
 }
+// verify_multiple over several devices ("one exchange step"): what one shard contributes is the product of its
+// sets' Miller values (slot F of item 0), its sum of blinded signatures (slot S of item 0) and the OR of its status words -- a
+// MBLS_VM_PARTIAL_BYTES record in the workspace's own number format (opaque: only mbls_verify_multiple_finish_device of the same build reads
+// it). An empty shard contributes (1, infinity, 0).
+#define MBLS_VM_PARTIAL_WORDS (MBLS_VM_PARTIAL_BYTES / 4)
+#define MBLS_VM_MAGIC 0x4d564d31u
+static_assert(MBLS_VM_PARTIAL_WORDS >= 18 * 12 + 2, "partial record too small");
+__global__ void MBLS_LB k_vm_export(mbls_ws ws, const uint32_t* st_or, int empty, uint32_t* out) {
+    const uint32_t t = threadIdx.x;
+    if (blockIdx.x) return;
+    if (empty) {
+        if (t == 0) {
+            fp12 f; fp12_set_one(&f); const fp* one = &f.c0.c0.c0;
+            for (int a = 0; a < 12; a++) for (int j = 0; j < 12; j++) out[12 * a + j] = one[a][j];
+            for (int j = 144; j < 216; j++) out[j] = 0;                   // Z = 0: infinity
+            out[216] = 0; out[217] = MBLS_VM_MAGIC;
+            for (int j = 218; j < (int)MBLS_VM_PARTIAL_WORDS; j++) out[j] = 0;
+        }
+        return;
+    }
+    for (uint32_t j = t; j < 216; j += WG) {                             // word j of the record = limb j % 12 of slot F + j / 12 (F and S are adjacent)
+        const uint32_t slot = MBLS_SLOT_F + j / 12, limb = j % 12;
+        out[j] = ws.w[((uint64_t)slot * 12 + limb) * ws.stride];
+    }
+    if (t == 0) { out[216] = st_or[0]; out[217] = MBLS_VM_MAGIC; }
+    for (uint32_t j = 218 + t; j < MBLS_VM_PARTIAL_WORDS; j += WG) out[j] = 0;
+}
+static_assert(MBLS_SLOT_S == MBLS_SLOT_F + 12, "k_vm_export / k_vm_import copy slots F and S as one range");
+// record g -> slots F, S of item g; the status words ORed into st_or[0]; a record that is not one (wrong magic) makes the check fail
+__global__ void MBLS_LB k_vm_import(mbls_ws ws, const uint32_t* in, uint64_t G, uint32_t* st_or) {
+    const uint64_t g = gid(); if (g >= G) return;
+    const uint32_t* r = in + g * MBLS_VM_PARTIAL_WORDS;
+    for (uint32_t j = 0; j < 216; j++) ws.w[((uint64_t)(MBLS_SLOT_F + j / 12) * 12 + j % 12) * ws.stride + g] = r[j];
+    uint32_t st = r[216];
+    if (r[217] != MBLS_VM_MAGIC) st |= MBLS_ST_PAIRING_FAILED | MBLS_ST_BAD_SIG_ENCODING;
+    if (st) atomicOr(st_or, st);
+}
 // the signature k_sig decoded into slots 3..6 of item `item` (affine; y = 0: infinity) -> slot S of the same item in Jacobian form: the
 // (sig, -G1) pair of aggregate_verify (reference src/aggregates.rs:158-164)
 __global__ void MBLS_LB k_sigslot_to_s(mbls_ws ws, uint64_t item) {
@@ -1583,7 +1620,9 @@ static void g2_tree(mbls_ctx* c, mbls_ws ws, uint64_t m, hipStream_t s) { g2_tre
 // the Miller loop of (S, -G1), the product, the single final exponentiation, the comparison and the status bits (program vmtail).
 // late_status: fold the sets' status words into d_scalar[0] only HERE, after the wait for the signature chain -- the sets' Miller loops then start as
 // soon as the keys and the messages are ready and do not wait for the (longer) signature chain, whose bits only the tail needs
-static int npairing_finish(mbls_ctx* c, uint64_t n, hipStream_t s, uint8_t* d_result, hipEvent_t s_miller_ev = nullptr, bool late_status = false) {
+// d_partial: stop before the tail and write the shard's record instead (k_vm_export); s_miller_ev then only says "the signature chain is done"
+static int npairing_finish(mbls_ctx* c, uint64_t n, hipStream_t s, uint8_t* d_result, hipEvent_t s_miller_ev = nullptr, bool late_status = false,
+                           uint32_t* d_partial = nullptr) {
     const bool s_miller_done = s_miller_ev != nullptr;
     mbls_ws ws; ws.w = c->d_w; ws.stride = c->cap;
     if (2 * n <= c->coop_max_items)     // few pairs: one WAVE per Miller loop (program miller1, ~0.9 ms) instead of one lane (6.6 ms)
@@ -1598,7 +1637,8 @@ static int npairing_finish(mbls_ctx* c, uint64_t n, hipStream_t s, uint8_t* d_re
     // s_miller_done: the Miller value of (S, -G1) is left in slots 97..108 of item 0 by program smiller, running beside the chains
     if (s_miller_done) HIPCHK(c, hipStreamWaitEvent(s, s_miller_ev, 0));
     if (late_status) hipLaunchKernelGGL(k_status_or, dim3(nblk(n)), dim3(WG), 0, s, c->d_status, n, c->d_scalar);
-    coop_run(c, s_miller_done ? COOP_VMFINAL : COOP_VMTAIL, ws, (uint64_t)0, (uint64_t)1, (uint64_t)0, (uint64_t)1, c->d_scalar, d_result, COOP_RES_BATCH, s);
+    if (d_partial) hipLaunchKernelGGL(k_vm_export, dim3(1), dim3(WG), 0, s, ws, (const uint32_t*)c->d_scalar, 0, d_partial);
+    else coop_run(c, s_miller_done ? COOP_VMFINAL : COOP_VMTAIL, ws, (uint64_t)0, (uint64_t)1, (uint64_t)0, (uint64_t)1, c->d_scalar, d_result, COOP_RES_BATCH, s);
     HIPCHK(c, hipGetLastError());
     return MBLS_OK;
 }
@@ -1740,11 +1780,17 @@ extern "C" int mbls_aggregate_verify_batch(mbls_ctx* c, const uint8_t* sigs, con
 }
 static int verify_multiple_impl(mbls_ctx* c, const uint8_t* d_sigs, const uint8_t* d_apks, const uint8_t* d_pks, int pk_format,
         const uint32_t* d_pk_offsets, uint32_t k, const uint8_t* d_msgs, uint32_t msg_len, const uint64_t* d_moff, const uint64_t* d_rands, uint64_t n,
-        uint8_t* d_result, uint32_t* d_status_or, void* stream) {
-    if (!c || !d_result) return MBLS_ERR_ARGUMENT;
+        uint8_t* d_result, uint32_t* d_status_or, void* stream, uint32_t* d_partial = nullptr) {
+    if (!c || (!d_result && !d_partial)) return MBLS_ERR_ARGUMENT;
     mbls_lock lk(c->mu);
     hipStream_t s = (hipStream_t)stream;
     HIPCHK(c, hipSetDevice(c->device));
+    if (n == 0 && d_partial) {     // an empty shard contributes (1, infinity, no status bits)
+        mbls_ws none; none.w = nullptr; none.stride = 0;
+        hipLaunchKernelGGL(k_vm_export, dim3(1), dim3(WG), 0, s, none, (const uint32_t*)nullptr, 1, d_partial);
+        HIPCHK(c, hipGetLastError());
+        return MBLS_OK;
+    }
     if (n == 0) {     // empty iterator: S' = infinity, product of no pairings = 1 -> e(inf, -G1) = 1 -> true
         HIPCHK(c, hipMemsetAsync(d_result, 1, 1, s));
         if (d_status_or) HIPCHK(c, hipMemsetAsync(d_status_or, 0, 4, s));
@@ -1759,7 +1805,8 @@ static int verify_multiple_impl(mbls_ctx* c, const uint8_t* d_sigs, const uint8_
     rc = ws_acquire(c, s); if (rc) return rc;
     HIPCHK(c, hipMemsetAsync(c->d_scalar, 0, 64, s));
     HIPCHK(c, hipMemsetAsync(c->d_status, 0, 4 * n, s));
-    HIPCHK(c, hipMemsetAsync(d_result, 0, 1, s));                           // false until the tail kernel has spoken (fail closed)
+    if (d_partial) HIPCHK(c, hipMemsetAsync(d_partial, 0, MBLS_VM_PARTIAL_BYTES, s));       // not a record until k_vm_export has spoken
+    else HIPCHK(c, hipMemsetAsync(d_result, 0, 1, s));                      // false until the tail kernel has spoken (fail closed)
     // Three independent chains: keys (aggregate, [r]apk), signatures (decode, subgroup check, [r]sig, sum tree), messages (hash). Below
     // 2^14 sets each of them leaves most SIMDs idle, so they run side by side on the context's streams and join before the
     // Miller loops; larger batches fill the chip by themselves and stay on the caller's stream.
@@ -1773,7 +1820,8 @@ static int verify_multiple_impl(mbls_ctx* c, const uint8_t* d_sigs, const uint8_
     g2_tree(c, ws, n, s_sig);
     if (fork) {     // S is complete: its Miller loop runs on one wave beside the other chains and the sets' Miller loops (most SIMDs are idle)
         HIPCHK(c, hipEventRecord(c->hs_ev2, s_sig));                 // the status bits and S exist
-        coop_run(c, COOP_SMILLER, ws, (uint64_t)0, (uint64_t)1, (uint64_t)0, (uint64_t)1, (uint32_t*)nullptr, (uint8_t*)nullptr, COOP_RES_ITEM, s_sig);
+        if (!d_partial)                                              // (a shard's S joins the other shards' first: mbls_verify_multiple_finish_device)
+            coop_run(c, COOP_SMILLER, ws, (uint64_t)0, (uint64_t)1, (uint64_t)0, (uint64_t)1, (uint32_t*)nullptr, (uint8_t*)nullptr, COOP_RES_ITEM, s_sig);
         HIPCHK(c, hipEventRecord(c->hs_ev, s_sig));                  // ... and its Miller value (awaited just before the tail)
     }
     launch_hash(c, ws, d_msgs, msg_len, d_moff, c->d_status, n, s_msg, pair_hash);
@@ -1784,7 +1832,46 @@ static int verify_multiple_impl(mbls_ctx* c, const uint8_t* d_sigs, const uint8_
         hipLaunchKernelGGL(k_status_or, dim3(nblk(n)), dim3(WG), 0, s, c->d_status, n, c->d_scalar);
     // a set whose signature is outside G2 (reference src/aggregates.rs:274-276), an undecodable member or a zero scalar makes the tail
     // answer false: the status bits are folded in on the device, the call only enqueues
-    rc = npairing_finish(c, n, s, d_result, fork ? c->hs_ev : nullptr, fork); if (rc) return rc;
+    rc = npairing_finish(c, n, s, d_result, fork ? c->hs_ev : nullptr, fork, d_partial); if (rc) return rc;
+    if (d_status_or) HIPCHK(c, hipMemcpyAsync(d_status_or, c->d_scalar, 4, hipMemcpyDeviceToDevice, s));
+    return ws_release(c, s);
+}
+// One shard of a verify_multiple that is spread over several devices or processes: everything up to the shard's
+// Miller product and signature sum, left as one MBLS_VM_PARTIAL_BYTES record in device memory. Enqueues only.
+extern "C" int mbls_verify_multiple_partial_device(mbls_ctx* c, const uint8_t* d_sigs, const uint8_t* d_apks, const uint8_t* d_pks, int pk_format,
+        const uint32_t* d_pk_offsets, uint32_t k, const uint8_t* d_msgs, uint32_t msg_len, const uint64_t* d_moff, const uint64_t* d_rands, uint64_t n,
+        uint8_t* d_partial, void* stream) {
+    if (!c || !d_partial) return MBLS_ERR_ARGUMENT;
+    if (n && !d_apks && !d_pks) return MBLS_ERR_ARGUMENT;
+    if (!d_apks && pk_format != MBLS_PK_COMPRESSED && pk_format != MBLS_PK_UNCOMPRESSED) return MBLS_ERR_ARGUMENT;
+    if (((uintptr_t)d_partial) & 3) return MBLS_ERR_ARGUMENT;
+    return verify_multiple_impl(c, d_sigs, d_apks, d_apks ? nullptr : d_pks, pk_format, d_apks ? nullptr : d_pk_offsets, k, d_msgs, msg_len, d_moff, d_rands, n,
+                                nullptr, nullptr, stream, (uint32_t*)d_partial);
+}
+// The exchange step's second half: G records (the shards' in any fixed order -- every participant that uses the same order computes the same
+// bool) -> product and sum trees over the records, then the tail of the one-device check: the Miller loop of (S, -G1), the product, ONE final
+// exponentiation, the comparison, the status bits (program vmtail; reference src/aggregates.rs:307-315). Enqueues only.
+extern "C" int mbls_verify_multiple_finish_device(mbls_ctx* c, const uint8_t* d_partials, uint64_t G, uint8_t* d_result, uint32_t* d_status_or, void* stream) {
+    if (!c || !d_result) return MBLS_ERR_ARGUMENT;
+    mbls_lock lk(c->mu);
+    hipStream_t s = (hipStream_t)stream;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (G == 0) {      // no shards: the empty iterator
+        HIPCHK(c, hipMemsetAsync(d_result, 1, 1, s));
+        if (d_status_or) HIPCHK(c, hipMemsetAsync(d_status_or, 0, 4, s));
+        return MBLS_OK;
+    }
+    if (!d_partials || (((uintptr_t)d_partials) & 3)) ARGFAIL(c, "null or unaligned records");
+    int rc = mbls_ctx_reserve(c, G); if (rc) return rc;
+    mbls_ws ws; ws.w = c->d_w; ws.stride = c->cap;
+    rc = ws_acquire(c, s); if (rc) return rc;
+    HIPCHK(c, hipMemsetAsync(c->d_scalar, 0, 64, s));
+    HIPCHK(c, hipMemsetAsync(d_result, 0, 1, s));
+    hipLaunchKernelGGL(k_vm_import, dim3(nblk(G)), dim3(WG), 0, s, ws, (const uint32_t*)d_partials, G, c->d_scalar);
+    f12_tree(c, ws, G, s);
+    g2_tree(c, ws, G, s);
+    coop_run(c, COOP_VMTAIL, ws, (uint64_t)0, (uint64_t)1, (uint64_t)0, (uint64_t)1, c->d_scalar, d_result, COOP_RES_BATCH, s);
+    HIPCHK(c, hipGetLastError());
     if (d_status_or) HIPCHK(c, hipMemcpyAsync(d_status_or, c->d_scalar, 4, hipMemcpyDeviceToDevice, s));
     return ws_release(c, s);
 }
@@ -1894,6 +1981,53 @@ extern "C" int mbls_multi_fast_aggregate_verify_batch(mbls_multi* m, const uint8
 extern "C" int mbls_multi_verify_batch(mbls_multi* m, const uint8_t* sigs, const uint8_t* msgs, uint32_t msg_len, const uint64_t* moff, const uint8_t* pks, int fmt,
         uint64_t n, uint8_t* results, uint32_t* status) {
     return multi_run(m, nullptr, sigs, msgs, msg_len, moff, pks, fmt, nullptr, nullptr, n, 1, MBLS_MODE_VERIFY, results, status);
+}
+// verify_multiple over the devices of the handle: device g takes sets [n g / G, n (g + 1) / G) up to its partial record
+// (one host thread per device), the records meet on the first device, which joins them and runs the tail. The same bool as the one-device call.
+extern "C" int mbls_multi_verify_multiple_aggregate_signatures(mbls_multi* m, const uint8_t* sigs96, const uint8_t* apks96, const uint8_t* msgs,
+        uint32_t msg_len, const uint64_t* moff, const uint64_t* rands, size_t n) {
+    if (!m) return 0;
+    if (n == 0) return 1;
+    if (moff && !msg_offsets_ok(moff, n)) return 0;
+    if (!sigs96 || !apks96 || !rands || (!msgs && (moff ? moff[n] != moff[0] : msg_len != 0))) return 0;
+    std::lock_guard<std::mutex> lk(m->mu);
+    const uint64_t G = m->ctx.size();
+    std::vector<uint8_t> recs; std::vector<int> rcs(G, MBLS_OK); std::vector<std::thread> th;
+    try { recs.resize(G * MBLS_VM_PARTIAL_BYTES); } catch (...) { return 0; }
+    auto work = [&](uint64_t g) {
+        mbls_ctx* c = m->ctx[g];
+        const uint64_t lo = shard_lo(n, g, G), hi = shard_lo(n, g + 1, G), cnt = hi - lo;
+        mbls_lock lk2(c->mu);
+        if (hipSetDevice(c->device) != hipSuccess) { rcs[g] = MBLS_ERR_DEVICE; return; }
+        const uint64_t first = moff ? moff[lo] : (uint64_t)msg_len * lo;
+        const size_t mbytes = moff ? (size_t)(moff[hi] - moff[lo]) : (size_t)msg_len * cnt;
+        sbuf ds(c, 0), da(c, 1), dm(c, 2), dr(c, 3), dmo(c, 6), drec(c, 4);
+        if (ds.up(sigs96 + 96 * lo, 96 * cnt) != hipSuccess || da.up(apks96 + 96 * lo, 96 * cnt) != hipSuccess ||
+            dm.up(msgs ? msgs + first : nullptr, mbytes) != hipSuccess || dr.up(rands + lo, 8 * cnt) != hipSuccess ||
+            (moff && dmo.up(moff + lo, 8 * (cnt + 1)) != hipSuccess) || drec.alloc(MBLS_VM_PARTIAL_BYTES) != hipSuccess) { rcs[g] = MBLS_ERR_DEVICE; return; }
+        // offset tables are absolute: the staged message bytes start at the shard's first offset
+        rcs[g] = mbls_verify_multiple_partial_device(c, ds.as<uint8_t>(), da.as<uint8_t>(), nullptr, 0, nullptr, 0, dm.as<uint8_t>() - (moff ? first : 0), msg_len,
+                                                     moff ? dmo.as<uint64_t>() : nullptr, dr.as<uint64_t>(), cnt, drec.as<uint8_t>(), c->hs_a);
+        const bool synced = hipStreamSynchronize(c->hs_a) == hipSuccess;
+        (void)hipStreamSynchronize(c->hs_b); (void)hipStreamSynchronize(c->hs_c);
+        c->ws_pending = false;
+        if (!rcs[g] && (!synced || drec.down(recs.data() + g * MBLS_VM_PARTIAL_BYTES, MBLS_VM_PARTIAL_BYTES) != hipSuccess)) rcs[g] = MBLS_ERR_DEVICE;
+    };
+    try { for (uint64_t g = 1; g < G; g++) th.emplace_back(work, g); } catch (...) { for (auto& t : th) t.join(); snprintf(m->err, sizeof(m->err), "cannot start a host thread"); return 0; }
+    work(0);
+    for (auto& t : th) t.join();
+    for (uint64_t g = 0; g < G; g++)
+        if (rcs[g]) { snprintf(m->err, sizeof(m->err), "device %d (shard %llu): %s", m->ctx[g]->device, (unsigned long long)g, m->ctx[g]->err); return 0; }
+    mbls_ctx* c = m->ctx[0];
+    mbls_lock lk0(c->mu);
+    if (hipSetDevice(c->device) != hipSuccess) return 0;
+    sbuf dall(c, 0), dres(c, 4); uint8_t r = 0;
+    if (dall.up(recs.data(), recs.size()) != hipSuccess || dres.alloc(8) != hipSuccess) return 0;
+    if (mbls_verify_multiple_finish_device(c, dall.as<uint8_t>(), G, dres.as<uint8_t>(), nullptr, c->hs_a)) { (void)hipStreamSynchronize(c->hs_a); c->ws_pending = false; return 0; }
+    if (hipStreamSynchronize(c->hs_a) != hipSuccess) return 0;
+    c->ws_pending = false;
+    if (dres.down(&r, 1) != hipSuccess) return 0;
+    return r;
 }
 extern "C" int mbls_multi_keytable_create(mbls_multi* m, uint64_t capacity_hint, mbls_multi_keytable** out) {
     if (!m || !out) return MBLS_ERR_ARGUMENT;

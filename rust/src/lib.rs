@@ -89,6 +89,8 @@ extern "C" {
     fn mbls_multi_device_count(m: *const MblsMulti) -> c_int;
     fn mbls_multi_fast_aggregate_verify_batch(m: *mut MblsMulti, sigs: *const u8, msgs: *const u8, msg_len: u32, msg_offsets: *const u64, pks: *const u8,
                                               pk_format: c_int, pk_offsets: *const u32, n: u64, k: u32, results: *mut u8, status: *mut u32) -> c_int;
+    fn mbls_multi_verify_multiple_aggregate_signatures(m: *mut MblsMulti, sigs96: *const u8, apks96: *const u8, msgs: *const u8, msg_len: u32,
+                                                       msg_offsets: *const u64, rands: *const u64, n: usize) -> c_int;
 }
 const PK_COMPRESSED: c_int = 0;
 const PK_UNCOMPRESSED: c_int = 1;
@@ -660,6 +662,34 @@ impl MultiGpu {
             err(rc);
         }
         res.into_iter().map(|b| b == 1).collect()
+    }
+    /// `AggregateSignature::verify_multiple_aggregate_signatures` (`src/aggregates.rs:261-316`) with the sets cut into one shard per device:
+    /// every device runs its sets up to its Miller product and signature sum, the first device joins the records and finishes. Same bool.
+    pub fn verify_multiple_aggregate_signatures<'a, R, I>(&self, rng: &mut R, signature_sets: I) -> bool
+    where
+        R: Rng + ?Sized,
+        I: Iterator<Item = (&'a AggregateSignature, &'a AggregatePublicKey, &'a [u8])>,
+    {
+        let (mut sigs, mut apks, mut msgs, mut rands) = (Vec::new(), Vec::new(), Vec::new(), Vec::<u64>::new());
+        let mut moff: Vec<u64> = vec![0];
+        for (s, a, m) in signature_sets {
+            let mut rand = 0u64;
+            while rand == 0 {
+                let mut rand_bytes = [0u8; 8];
+                rng.fill(&mut rand_bytes);
+                rand = i64::from_be_bytes(rand_bytes).wrapping_abs() as u64;
+            }
+            rands.push(rand);
+            sigs.extend_from_slice(&s.point);
+            apks.extend_from_slice(&a.point);
+            msgs.extend_from_slice(m);
+            moff.push(msgs.len() as u64);
+        }
+        let n = rands.len();
+        if n == 0 {
+            return true;
+        }
+        unsafe { mbls_multi_verify_multiple_aggregate_signatures(self.h, sigs.as_ptr(), apks.as_ptr(), msgs.as_ptr(), 0, moff.as_ptr(), rands.as_ptr(), n) == 1 }
     }
 }
 impl Drop for MultiGpu {

@@ -1,6 +1,6 @@
 """Randomised GPU-vs-oracle stress over many seeds (dev tool; the same comparisons as tests/test_gpu_parity.py on more data):
 fast_aggregate_verify with batch sizes either side of every engine crossover -- each batch once with the default engines, once forced onto
-the one-lane kernels and once forced onto the cooperative engine --, signing and sk -> pk, verify_multiple with oracle-checked verdicts."""
+the lane-pair kernels, once onto the two-pair loop of the headline and once onto the cooperative engine --, signing and sk -> pk, verify_multiple with oracle-checked verdicts."""
 import os, random, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for q in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "oracle", "pymodel"), os.path.join(ROOT, "tests")):
@@ -19,13 +19,17 @@ for seed in range(100, 100 + nseeds):
     for n, k, fmt in shapes:
         b = helpers.make_batch(n, k, fmt=fmt, seed=seed * 7 + n, pool_n=64)
         want = orc.batch_fast_aggregate_verify(b.sigs, b.msgs, b.pks, b.n, b.k, fmt, nthreads=32)
-        for engines in ("default", "lanes", "waves"):
-            if engines == "lanes":
-                ctx.set_coop_max_items(0)
+        for engines in ("default", "pairs", "lanes2pair", "waves"):
+            if engines == "pairs":                                   # one-lane kernels in the form the batch size takes: lane pairs / split
+                ctx.set_coop_max_items(0); ctx.set_coop_hash_max_items(0)
+            elif engines == "lanes2pair":                            # the two-pair loop of the headline
+                ctx.set_coop_max_items(0); ctx.set_coop_hash_max_items(0); ctx.set_lane_shaping(0, (1 << 64) - 1)
             elif engines == "waves":
-                ctx.set_coop_max_items(max(n, 10240)); ctx.set_coop_hash_max_items(max(n, 6144) if n <= 8192 else 6144)
-            got, st = mb.fast_aggregate_verify_batch(b.sigs, b.msgs, b.pks, b.n, b.k, pk_format=fmt)
-            ctx.set_coop_max_items(10240); ctx.set_coop_hash_max_items(6144)
+                ctx.set_coop_max_items(1 << 20); ctx.set_coop_hash_max_items(1 << 20 if n <= 8192 else 6144)
+            try:
+                got, st = mb.fast_aggregate_verify_batch(b.sigs, b.msgs, b.pks, b.n, b.k, pk_format=fmt)
+            finally:
+                ctx.reset_tuning()
             total += n
             if not (got == want == b.expect):
                 bad += 1; print("MISMATCH fast_aggregate_verify seed", seed, n, k, fmt, engines)

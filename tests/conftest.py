@@ -33,8 +33,8 @@ def engine(request):
     """Every GPU test that compares with the oracle or the golden file runs once per engine:
     'waves' = the library's defaults (small batches take the cooperative one-wave-per-item programs, mbls_coop.h);
     'lanes' = every batch forced onto the one-lane-per-item kernels (k_hash, k_miller*, k_sig_verdict -- the signature's subgroup test read
-    off the Miller loop --, k_final) in the form a batch below half a round takes by default: the two pairs of an item on two lanes
-    (k_miller_split); 'lanes2pair' = the same with the two-pair loop k_miller, the kernel the headline number is measured on:
+    off the Miller loop --, k_final) in the form a batch of that size takes by default: lane pairs below a quarter of a round (k_hash2,
+    k_miller_split4, k_final2), the two pairs of an item on two lanes below half a round (k_miller_split); 'lanes2pair' = the same with the two-pair loop k_miller, the kernel the headline number is measured on:
     mbls_ctx_set_coop_max_items(0) + mbls_ctx_set_coop_hash_max_items(0) (+ mbls_ctx_set_lane_shaping(0, ...)) on the default context, and
     the same through the environment for contexts the test creates itself (mbls_ctx_create reads it; mbls_multi_create makes its contexts
     that way)."""

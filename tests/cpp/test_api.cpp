@@ -72,8 +72,13 @@ int main() {
       for (int i = 0; i < 3; i++) sets.emplace_back(&sigs[i], &apks[i], Bytes(32, uint8_t(i)));
       auto rng = [&] { return uint8_t(gen()); };
       CHECK(AggregateSignature::verify_multiple_aggregate_signatures(rng, sets));
+      // the same sets cut into one shard per context of a two-context handle
+      int devs[2] = {0, 0}; mbls_multi* m2 = nullptr; CHECK(mbls_multi_create(&m2, devs, 2) == MBLS_OK);
+      CHECK(AggregateSignature::verify_multiple_aggregate_signatures(m2, rng, sets));
       AggregateSignature wrong; wrong.add(Signature::new_(Bytes(32, 1), kps[3].sk)); std::get<0>(sets[1]) = &wrong;
-      CHECK(!AggregateSignature::verify_multiple_aggregate_signatures(rng, sets)); }
+      CHECK(!AggregateSignature::verify_multiple_aggregate_signatures(rng, sets));
+      CHECK(!AggregateSignature::verify_multiple_aggregate_signatures(m2, rng, sets));
+      mbls_multi_destroy(m2); }
     // src/aggregates.rs:100-106 AggregateSignature::aggregate (one batched launch) == repeated add; src/keys.rs:36-77 key generation
     { std::vector<Signature> ss; std::vector<const Signature*> ps; for (auto& kp : kps) ss.push_back(Signature::new_(msg, kp.sk)); for (auto& x : ss) ps.push_back(&x);
       CHECK(AggregateSignature::aggregate(ps) == agg); CHECK(AggregateSignature::aggregate({}) == AggregateSignature()); }
