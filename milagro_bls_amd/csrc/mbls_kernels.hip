@@ -1621,9 +1621,12 @@ static void g2_tree(mbls_ctx* c, mbls_ws ws, uint64_t m, hipStream_t s) { g2_tre
 // late_status: fold the sets' status words into d_scalar[0] only HERE, after the wait for the signature chain -- the sets' Miller loops then start as
 // soon as the keys and the messages are ready and do not wait for the (longer) signature chain, whose bits only the tail needs
 // d_partial: stop before the tail and write the shard's record instead (k_vm_export); s_miller_ev then only says "the signature chain is done"
+// side_s_chain (batches that fill the chip and run their chains one after the other): the signatures' sum tree and the Miller loop of (S, -G1) are
+// enqueued HERE on a second stream, beside the product tree -- both trees are short kernels on a shrinking number of lanes, and the one-wave
+// Miller loop hides behind them
 static int npairing_finish(mbls_ctx* c, uint64_t n, hipStream_t s, uint8_t* d_result, hipEvent_t s_miller_ev = nullptr, bool late_status = false,
-                           uint32_t* d_partial = nullptr) {
-    const bool s_miller_done = s_miller_ev != nullptr;
+                           uint32_t* d_partial = nullptr, bool side_s_chain = false) {
+    const bool s_miller_done = s_miller_ev != nullptr || side_s_chain;
     mbls_ws ws; ws.w = c->d_w; ws.stride = c->cap;
     if (2 * n <= c->coop_max_items)     // few pairs: one WAVE per Miller loop (program miller1, ~0.9 ms) instead of one lane (6.6 ms)
         coop_run(c, COOP_MILLER1, ws, (uint64_t)0, (uint64_t)1, (uint64_t)0, n, (uint32_t*)nullptr, (uint8_t*)nullptr, COOP_RES_ITEM, s);
@@ -1632,6 +1635,13 @@ static int npairing_finish(mbls_ctx* c, uint64_t n, hipStream_t s, uint8_t* d_re
         const int lpp = 2 * n <= c->round_items ? 2 : 1;            // half a round or less: two lanes per Miller loop, products in pairs
         if (lpp == 2) hipLaunchKernelGGL(k_miller_single2, dim3(nblk(2 * n)), dim3(WG), 0, s, ws, n, 0, (uint64_t)0);
         else hipLaunchKernelGGL(k_miller_single, dim3(nblk(n)), dim3(WG), 0, s, ws, n, 0, (uint64_t)0);
+    }
+    if (side_s_chain) {
+        HIPCHK(c, hipEventRecord(c->hs_ev2, s)); HIPCHK(c, hipStreamWaitEvent(c->hs_b, c->hs_ev2, 0));
+        g2_tree(c, ws, n, c->hs_b);
+        if (!d_partial) coop_run(c, COOP_SMILLER, ws, (uint64_t)0, (uint64_t)1, (uint64_t)0, (uint64_t)1, (uint32_t*)nullptr, (uint8_t*)nullptr, COOP_RES_ITEM, c->hs_b);
+        HIPCHK(c, hipEventRecord(c->hs_ev, c->hs_b));
+        s_miller_ev = c->hs_ev;
     }
     f12_tree(c, ws, n, s);
     // s_miller_done: the Miller value of (S, -G1) is left in slots 97..108 of item 0 by program smiller, running beside the chains
@@ -1808,16 +1818,18 @@ static int verify_multiple_impl(mbls_ctx* c, const uint8_t* d_sigs, const uint8_
     if (d_partial) HIPCHK(c, hipMemsetAsync(d_partial, 0, MBLS_VM_PARTIAL_BYTES, s));       // not a record until k_vm_export has spoken
     else HIPCHK(c, hipMemsetAsync(d_result, 0, 1, s));                      // false until the tail kernel has spoken (fail closed)
     // Three independent chains: keys (aggregate, [r]apk), signatures (decode, subgroup check, [r]sig, sum tree), messages (hash). Below
-    // 2^14 sets each of them leaves most SIMDs idle, so they run side by side on the context's streams and join before the
-    // Miller loops; larger batches fill the chip by themselves and stay on the caller's stream.
-    const bool fork = n <= 16384;
+    // half a round of lanes each of them leaves at least half the SIMDs idle, so they run side by side on the context's streams and join before
+    // the Miller loops (2^15 sets: 13.4 ms instead of 18.3 one after the other); closer to a full round the three chains only get in each
+    // other's way (65 535 sets: 24.7 ms side by side, 21.2 in a row) and stay on the caller's stream.
+    const bool fork = 2 * n <= c->round_items;
     hipStream_t s_sig = fork ? c->hs_b : s, s_msg = fork ? c->hs_c : s;
     if (fork) { HIPCHK(c, hipEventRecord(c->hs_ev, s)); HIPCHK(c, hipStreamWaitEvent(s_sig, c->hs_ev, 0)); HIPCHK(c, hipStreamWaitEvent(s_msg, c->hs_ev, 0)); }
     if (!d_apks)    // sets given by their wire-format keys: AggregatePublicKey::aggregate on the device first (src/aggregates.rs:29-39)
         launch_aggregate(ws, d_pks, d_pk_offsets, k, pk_format, MBLS_MODE_VERIFY, c->d_status, n, s);
     hipLaunchKernelGGL(k_blind_g1_d, dim3(nblk(n)), dim3(WG), 0, s, ws, d_apks, d_rands, c->d_status, n);
     hipLaunchKernelGGL(k_blind_sig_d, dim3(nblk(n)), dim3(WG), 0, s_sig, ws, d_sigs, d_rands, c->d_status, n);
-    g2_tree(c, ws, n, s_sig);
+    const bool side_s_chain = !fork && s != c->hs_b;                  // the sum tree waits for the product tree's company (npairing_finish)
+    if (!side_s_chain) g2_tree(c, ws, n, s_sig);
     if (fork) {     // S is complete: its Miller loop runs on one wave beside the other chains and the sets' Miller loops (most SIMDs are idle)
         HIPCHK(c, hipEventRecord(c->hs_ev2, s_sig));                 // the status bits and S exist
         if (!d_partial)                                              // (a shard's S joins the other shards' first: mbls_verify_multiple_finish_device)
@@ -1832,7 +1844,7 @@ static int verify_multiple_impl(mbls_ctx* c, const uint8_t* d_sigs, const uint8_
         hipLaunchKernelGGL(k_status_or, dim3(nblk(n)), dim3(WG), 0, s, c->d_status, n, c->d_scalar);
     // a set whose signature is outside G2 (reference src/aggregates.rs:274-276), an undecodable member or a zero scalar makes the tail
     // answer false: the status bits are folded in on the device, the call only enqueues
-    rc = npairing_finish(c, n, s, d_result, fork ? c->hs_ev : nullptr, fork, d_partial); if (rc) return rc;
+    rc = npairing_finish(c, n, s, d_result, fork ? c->hs_ev : nullptr, fork, d_partial, side_s_chain); if (rc) return rc;
     if (d_status_or) HIPCHK(c, hipMemcpyAsync(d_status_or, c->d_scalar, 4, hipMemcpyDeviceToDevice, s));
     return ws_release(c, s);
 }

@@ -164,3 +164,39 @@ def test_sharded_verify_multiple_4500_sets_from_their_keys(N):
         assert run() is False, i
         d_msgs[i, 3] ^= 4
     assert run() is True
+
+
+def test_verify_multiple_above_2_14_sets_side_stream_trees(N):
+    """more than 2^14 sets: the chains run one after the other on the caller's stream, and the signatures' sum tree + the Miller loop of (S, -G1)
+    run on a second stream beside the product tree (npairing_finish, side_s_chain) -- one call and one shard + join, valid and corrupted"""
+    import torch
+    import bench
+    from milagro_bls_amd import batch
+    ctx = N.default_context()
+    dev = torch.device("cuda:0")
+    n = 20000
+    d_sigs, d_msgs, d_pks, expect = bench.build_inputs(ctx, dev, n, 1, N.PK_UNCOMPRESSED, rank=6, negatives=False)
+    g = torch.Generator(device="cpu"); g.manual_seed(13)
+    rands = torch.randint(1, (1 << 62), (n,), dtype=torch.int64, generator=g).to(dev)
+    rec = torch.zeros(N.VM_PARTIAL_BYTES, dtype=torch.uint8, device=dev)
+
+    def one():
+        return batch.verify_multiple_sets_device(d_sigs.data_ptr(), d_pks.data_ptr(), d_msgs.data_ptr(), rands.data_ptr(), n, 1, pk_format=N.PK_UNCOMPRESSED)
+
+    def shard():
+        batch.verify_multiple_partial_device(d_sigs.data_ptr(), d_msgs.data_ptr(), rands.data_ptr(), n, rec.data_ptr(), d_pks=d_pks.data_ptr(), k=1, pk_format=N.PK_UNCOMPRESSED)
+        return batch.verify_multiple_finish_device(rec.data_ptr(), 1)
+    for f in (one, shard):
+        assert f() is True
+        for i in (0, 9999, 19999):
+            d_sigs_backup = d_msgs[i, 9].item()
+            d_msgs[i, 9] ^= 2
+            assert f() is False, (f.__name__, i)
+            d_msgs[i, 9] = d_sigs_backup
+        assert f() is True
+    # a signature swapped between two sets: the sum of the signatures is unchanged only without blinding
+    a, b = d_sigs[5].clone(), d_sigs[15000].clone()
+    d_sigs[5], d_sigs[15000] = b, a
+    assert one() is False and shard() is False
+    d_sigs[5], d_sigs[15000] = a, b
+    assert one() is True
