@@ -91,7 +91,7 @@ int mbls_ctx_set_coop_packing(mbls_ctx* ctx, uint64_t pairing_min_items, uint64_
 int mbls_ctx_set_round_items(mbls_ctx* ctx, uint64_t items);
 /* Shaping of the one-lane path below a full round. Up to split_max_items items (default and maximum: half a round) the two pairs of an item's
  * Miller loop are walked on TWO lanes by the one-pair routine (6.6 ms instead of 11.3 ms; the product and the signature's subgroup verdict
- * follow as separate small kernels); up to fork_max_items items (default: round - 1) the three front phases -- key sum, signature decoding,
+ * follow as separate small kernels); up to fork_max_items items (default: three quarters of a round) the three front phases -- key sum, signature decoding,
  * message hashing -- are enqueued side by side on the context's own streams instead of one after the other. 0 = never. Same results, bit for
  * bit (environment for new contexts: MBLS_SPLIT_MAX_ITEMS, MBLS_FORK_MAX_ITEMS). */
 int mbls_ctx_set_lane_shaping(mbls_ctx* ctx, uint64_t split_max_items, uint64_t fork_max_items);

@@ -443,6 +443,9 @@ class Machine:
 
 
 # ---------------------------------------------------------------------------------------------- scheduling
+BY_HEIGHT = os.environ.get("MBLS_COOP_BY_HEIGHT", "1") == "1"
+
+
 class Step:
     def __init__(self, kind):
         self.kind = kind
@@ -523,6 +526,71 @@ def schedule(block):
             for f in n.aux:
                 flag_last_read[f] = max(flag_last_read.get(f, -1), k)
     # a state write must not land before a LATER-scheduled read of the old value: verify (creation order makes this hold; assert it)
+    for name, node in block.outs:
+        old = block.in_nodes.get(name)
+        if old is not None and old is not node:
+            assert last_read.get(old, -1) <= node.step, ("state slot rewritten before its last read", block.name, name)
+    for n in block.nodes:
+        n.last_use = last_read.get(n, -1)
+    return steps
+
+
+def schedule_by_height(block):
+    """The same packing problem solved step by step for blocks of nothing but products and linear combinations (the loop bodies): at every
+    step the kind of the most urgent ready operation is chosen -- urgency = the longest chain of operations that still hangs on it -- and the
+    step is filled with the ready operations of that kind in that order. Creation-order scheduling (schedule) serves whichever chain was
+    written first and can leave the block's critical chain waiting for lanes. A state slot is written no earlier than the last read of the
+    value it held when the block started (a step reads before it writes: the same step is fine)."""
+    items = list(block.items)
+    if any(n.kind not in ("mul", "lin") for n in items):
+        return None
+    pos = {n: i for i, n in enumerate(items)}
+    preds = {n: [x for x in node_inputs(n) if x.kind != "in"] for n in items}
+    succs = {n: [] for n in items}
+    for n in items:
+        for x in preds[n]:
+            if x in succs:
+                succs[x].append(n)
+    readers = {}
+    for n in items:
+        for x in node_inputs(n):
+            if x.kind == "in":
+                readers.setdefault(x, []).append(n)
+    after = {n: [] for n in items}                     # zero-latency predecessors: the readers of the state value a node overwrites
+    for name, node in block.outs:
+        old = block.in_nodes.get(name)
+        if old is not None and old is not node and node in after:
+            after[node] += [r for r in readers.get(old, []) if r is not node]
+    height = {}
+    for n in reversed(items):                          # creation order is topological
+        height[n] = 1 + max([height[x] for x in succs[n]] + [0])
+    for n in items:                                    # a writer's urgency carries over to the readers it waits for
+        for r in after[n]:
+            height[r] = max(height[r], height[n])
+    done, steps = {}, []
+    left = set(items)
+    while left:
+        t = len(steps)
+        def ready(n):
+            return all(x in done and done[x] < t for x in preds[n]) and all(r in done for r in after[n])
+        cand = [n for n in left if ready(n)]
+        assert cand, "scheduling deadlock"
+        cand.sort(key=lambda n: (-height[n], pos[n]))
+        kind = STEP_KIND[cand[0].kind]
+        st = Step(kind)
+        while len(st.lanes) < block.m.nlane:
+            pick = [n for n in left if STEP_KIND[n.kind] == kind and ready(n)]
+            if not pick:
+                break
+            pick.sort(key=lambda n: (-height[n], pos[n]))
+            for n in pick[:block.m.nlane - len(st.lanes)]:
+                n.step, n.lane = t, len(st.lanes)
+                st.lanes.append(n); done[n] = t; left.discard(n)
+        steps.append(st)
+    last_read = {}
+    for n in items:
+        for x in node_inputs(n):
+            last_read[x] = max(last_read.get(x, -1), n.step)
     for name, node in block.outs:
         old = block.in_nodes.get(name)
         if old is not None and old is not node:
@@ -644,6 +712,14 @@ def compile_program(machine):
     peak = temp_base
     for name, blk in machine.blocks.items():
         peak = max(peak, assign_slots(machine, blk, sched[name], temp_base))
+    if BY_HEIGHT:       # a block takes the other schedule when that is shorter and needs no more LDS slots than the program already has
+        for name, blk in machine.blocks.items():
+            alt = schedule_by_height(blk)
+            if alt is not None and len(alt) < len(sched[name]) and assign_slots(machine, blk, alt, temp_base) <= peak:
+                sched[name] = alt
+            else:
+                sched[name] = schedule(blk)              # (the nodes carry their step / lane / last use / slot: assign them again)
+                assign_slots(machine, blk, sched[name], temp_base)
     rows, row_of = [], {}
     block_rows = {}
     for name, blk in machine.blocks.items():
@@ -784,9 +860,8 @@ def mul12(b, x, y, conj_b=False):
     return ((b.add6 if not conj_b else b.sub6)(t0, b.mul_v6(t1)), cross)
 
 
-def build_miller(m, pairs, prefix=""):
-    """blocks `dbl` and `add` of the Miller loop over the listed pairs. Pair descriptor: dict(T=state prefix of the running point,
-    Q=state prefix of the fixed point, affine=bool, P=state prefix of the masked G1 argument (masked_p))"""
+def build_miller_plain(m, pairs, prefix=""):
+    """blocks `dbl` and `add` of the Miller loop over the listed pairs, every block multiplying its own lines into f"""
     def parg(b, pr):
         return [b.inp(pr["P"] + x) for x in ("npx", "py", "pz3", "one")]
     b = m.block(prefix + "dbl")
@@ -813,11 +888,87 @@ def build_miller(m, pairs, prefix=""):
     st12(b, f)
 
 
+def build_miller(m, pairs, prefix="", pipelined=None):
+    """blocks `mlinit`, `dbl`, `add`, `flush` of the Miller loop over the listed pairs. Pair descriptor: dict(T=state prefix of the running
+    point, Q=state prefix of the fixed point, affine=bool, P=state prefix of the masked G1 argument (masked_p)).
+    The loop is software-pipelined by one block: the lines a block computes are NOT multiplied into f by that block but left as the pending
+    factor Lp (the merged lines of two pairs, or the one line), and every block starts with g = f * Lp -- the factor of the block before.
+    The state f is therefore the Miller value without its latest lines (F = f * Lp): a doubling block leaves f <- g^2, an addition block
+    f <- g, `flush` after the last block multiplies the last lines in. The chain through the running point (doubling -> line coefficients ->
+    merged lines: six steps) and the chain through f (f * Lp -> square: four steps) then run side by side instead of one after the other
+    (eleven steps a doubling block before)."""
+    two = len(pairs) == 2
+    npend = 10 if two else 6
+    if pipelined is None:      # measured in steps: two pairs on 64 lanes 1558 -> 1428; one pair (8 steps a doubling either way) and the 32-lane form lose
+        pipelined = two and m.nlane == NLANE
+    m.miller_pipelined = pipelined
+    if not pipelined:
+        return build_miller_plain(m, pairs, prefix)
+
+    def parg(b, pr):
+        return [b.inp(pr["P"] + x) for x in ("npx", "py", "pz3", "one")]
+
+    def pend_in(b):
+        l = [b.inp("%slp%d" % (prefix, i)) for i in range(npend)]
+        if two:
+            return [(l[0], l[1]), (l[2], l[3]), (l[4], l[5])], [None, (l[6], l[7]), (l[8], l[9])]
+        return [(l[0], l[1]), (l[2], l[3]), (l[4], l[5])]
+
+    def pend_out(b, L):
+        vals = [x for c in (L[0] + L[1][1:] if two else L) for x in c]
+        assert len(vals) == npend
+        for i, v in enumerate(vals):
+            b.out("%slp%d" % (prefix, i), v)
+
+    def times_pending(b, f, L=None):
+        L = L or pend_in(b)
+        return mul12_by_lines(b, f, L[0], L[1]) if two else b.mul12_line(f, *L)
+
+    def merged(b, lines):
+        return mul_lines(b, lines[0], lines[1]) if two else lines[0]
+
+    b = m.block(prefix + "mlinit")                                # Lp <- 1
+    one = b.const(ONE_D)
+    for i in range(npend):
+        b.out("%slp%d" % (prefix, i), one if i == 0 else LC())
+    # the operations of the longer chain (the points and their lines) are created first: the list scheduler serves them first
+    b = m.block(prefix + "dbl")
+    Lp = pend_in(b)
+    lines = []
+    for pr in pairs:
+        Tn, line = dbl_step(b, pt_in(b, pr["T"]), parg(b, pr))
+        pt_out(b, pr["T"], Tn)
+        lines.append(line)
+    Ln = merged(b, lines)
+    f = b.sqr12(times_pending(b, ld12(b), Lp))
+    pend_out(b, Ln)
+    st12(b, f)
+    b = m.block(prefix + "add")
+    Lp = pend_in(b)
+    lines = []
+    for pr in pairs:
+        q = [b.inp("%s%d" % (pr["Q"], i)) for i in range(4 if pr["affine"] else 6)]
+        Q = [(q[0], q[1]), (q[2], q[3]), None if pr["affine"] else (q[4], q[5])]
+        Tn, line = add_step(b, pt_in(b, pr["T"]), Q, parg(b, pr))
+        pt_out(b, pr["T"], Tn)
+        lines.append(line)
+    Ln = merged(b, lines)
+    f = times_pending(b, ld12(b), Lp)
+    pend_out(b, Ln)
+    st12(b, f)
+    b = m.block(prefix + "flush")
+    st12(b, times_pending(b, ld12(b)))
+
+
 def run_miller(m, prefix=""):
+    if m.miller_pipelined:
+        m.run(prefix + "mlinit")
     for ph in range(6):
         m.run(prefix + "dbl", RUNS[ph])
         if ph < 5:
             m.run(prefix + "add")
+    if m.miller_pipelined:
+        m.run(prefix + "flush")
 
 
 def cyc_sqr_block(m, name="csq"):
