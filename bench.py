@@ -538,7 +538,7 @@ def sharded_verify_multiple_leg(ctx, lib, dev, sptr, rank, world, k, nn=1 << 14)
         if world > 1:
             batch.verify_multiple_partial_device(v_sigs.data_ptr(), v_msgs.data_ptr(), rands.data_ptr(), nn, mine.data_ptr(), d_pks=v_pks.data_ptr(), k=k,
                                                  pk_format=N.PK_UNCOMPRESSED, stream=sptr)
-            dist.all_gather_into_tensor(recs, mine)
+            shard.all_gather_records(mine, world, out=recs)
         else:
             h = nn // 2
             for j, (lo, cnt) in enumerate(((0, h), (h, nn - h))):
@@ -639,6 +639,10 @@ def stub_rank(args, rank, world):
     elapsed = timed_steps(step, args.steps, args.warmup, world, lambda: None)
     per_rank = gather_per_rank(LAST_OWN_ELAPSED[0] / args.steps * 1e3, world)
     ok = check_bitmap(res, bm, expect) and (world == 1 or check_gathered(d_all, world, words, bm, rank))
+    # the exchange step of the sharded verify_multiple leg: one byte record per rank, gathered in rank order
+    mine = torch.full((N.VM_PARTIAL_BYTES,), rank + 1, dtype=torch.uint8)
+    recs = shard.all_gather_records(mine, world, out=torch.zeros(world * N.VM_PARTIAL_BYTES, dtype=torch.uint8))
+    ok = ok and all(bool((recs[r * N.VM_PARTIAL_BYTES:(r + 1) * N.VM_PARTIAL_BYTES] == r + 1).all()) for r in range(world))
     ok = reduce_all_ok(ok, world)
     if rank == 0:
         print(json.dumps({"metric": "fast_aggregate_verify/sec (128 pubkeys, 32B msg)", "stub": True, "value": n * world * args.steps / elapsed,

@@ -43,3 +43,11 @@ def all_gather_bitmap(local_words, world=None, out=None):
         out = torch.empty(local_words.numel() * world, dtype=local_words.dtype, device=local_words.device)
     dist.all_gather_into_tensor(out, local_words)
     return out
+
+
+def all_gather_records(mine, world=None, out=None):
+    """verify_multiple cut into shards (include/mbls.h, mbls_verify_multiple_partial_device): every rank contributes its one
+    MBLS_VM_PARTIAL_BYTES record (a uint8 tensor); returns the records of all ranks in rank order -- the order every rank hands to
+    mbls_verify_multiple_finish_device. The one exchange step of that path."""
+    return all_gather_bitmap(mine, world, out)
+
