@@ -200,3 +200,35 @@ def test_verify_multiple_above_2_14_sets_side_stream_trees(N):
     assert one() is False and shard() is False
     d_sigs[5], d_sigs[15000] = a, b
     assert one() is True
+
+
+def test_many_records_join_through_both_tree_engines(N):
+    """5 000 records -- four real shards among 4 996 empty ones (an empty shard contributes (1, infinity, 0)): the first levels of the join's
+    product and sum trees run one lane per product, the rest one wave per product; same bool as the four shards alone, and as one call"""
+    import torch
+    from milagro_bls_amd import batch
+    rnd = random.Random(79)
+    sks, pks, msgs, sigs, rands = _sets(rnd, 8)
+    dev = torch.device("cuda:0")
+    t = lambda b: torch.frombuffer(bytearray(b), dtype=torch.uint8).to(dev)
+    G = 5000
+    P = N.VM_PARTIAL_BYTES
+    for spoil in (False, True):
+        m = list(msgs)
+        if spoil:
+            m[5] = bytes(32)
+        recs = torch.zeros(G * P, dtype=torch.uint8, device=dev)
+        empty = torch.zeros(P, dtype=torch.uint8, device=dev)
+        batch.verify_multiple_partial_device(0, 0, 0, 0, empty.data_ptr(), d_apks=0)        # n = 0: no buffers needed
+        torch.cuda.synchronize()
+        recs.view(G, P)[:] = empty
+        where = [0, 1234, 2500, 4999]
+        keep = []
+        for j, g in enumerate(where):
+            lo, hi = 2 * j, 2 * j + 2
+            d = [t(b"".join(sigs[lo:hi])), t(b"".join(pks[lo:hi])), t(b"".join(m[lo:hi])),
+                 torch.tensor([x - (1 << 64) if x >= (1 << 63) else x for x in rands[lo:hi]], dtype=torch.int64, device=dev)]
+            keep += d
+            batch.verify_multiple_partial_device(d[0].data_ptr(), d[2].data_ptr(), d[3].data_ptr(), 2, recs.data_ptr() + g * P, d_apks=d[1].data_ptr())
+        assert batch.verify_multiple_finish_device(recs.data_ptr(), G) is (not spoil)
+        assert _one_device(N, sigs, pks, m, rands) is (not spoil)
