@@ -75,7 +75,7 @@ const char* mbls_last_error(mbls_ctx* ctx);
 /* Small batches are latency-bound (one lane per item walks 14 M dependent instructions whatever the batch size), so batches of up to
  * max_items items run their pairing check -- Miller loop + final exponentiation -- with ONE WAVE per item, the item's field values
  * shared by the 64 lanes (mbls_coop.h); the message phase after hash_to_field does the same. Same results, bit for bit.
- * Defaults 5120 / 5120: the measured crossovers (environment, read by mbls_ctx_create and therefore also by every context of an
+ * Defaults 5120 / 3584: the measured crossovers (between them the message phase runs on lane pairs; environment, read by mbls_ctx_create and therefore also by every context of an
  * mbls_multi handle: MBLS_COOP_MAX_ITEMS, MBLS_COOP_HASH_MAX_ITEMS); 0 = never. */
 int mbls_ctx_set_coop_max_items(mbls_ctx* ctx, uint64_t max_items);
 int mbls_ctx_reset_tuning(mbls_ctx* ctx);      /* every routing parameter of this section back to its default (environment overrides included) */

@@ -603,7 +603,7 @@ __global__ void __launch_bounds__(WG) k_valu_bench(uint32_t* sink, uint32_t iter
 // 5 120); the lane path with four lanes per item in the Miller loop and two in the message phase and the final exponentiation (products in pairs)
 // needs 12.2-12.7 ms for anything up to a quarter of a round
 #define MBLS_DEFAULT_COOP_MAX_ITEMS 5120
-#define MBLS_DEFAULT_COOP_HASH_MAX_ITEMS 5120
+#define MBLS_DEFAULT_COOP_HASH_MAX_ITEMS 3584           /* above n / 4 + 2 n / 64 > 1 024 waves: the four-per-wave message phase needs a second round beside the key sums and the signatures (3 600 items 8.0 ms, 3 648 items 9.9 ms); the lane-pair form takes 8.8 - 9.0 */
 struct mbls_ctx {
     std::recursive_mutex mu;
     int device = 0;
@@ -688,13 +688,15 @@ static void coop_run(mbls_ctx* c, int prog, mbls_ws ws, uint64_t first_item, uin
 static void launch_hash(mbls_ctx* c, mbls_ws ws, const uint8_t* d_msgs, uint32_t msg_len, const uint64_t* d_moff, uint32_t* st, uint64_t n, hipStream_t s, bool pair_ok) {
     // (up to a quarter of a round: with 2 n lanes for the messages beside n for the keys and n for the signatures the three front chains still run
     // side by side; above that the doubled message phase would push them behind it)
-    if (pair_ok && !(n <= c->coop_hash_max_items && n <= c->coop_max_items) && n <= c->split_max_items && 4 * n <= c->round_items) {
+    // the wave form's limit: where the lane-pair form is not on offer (pair_ok: the caller reserved 2 n items), waves serve every batch the pairing check's waves serve
+    const uint64_t hmax = (pair_ok || !c->coop_hash_max_items) ? c->coop_hash_max_items : (c->coop_hash_max_items > c->coop_max_items ? c->coop_hash_max_items : c->coop_max_items);
+    if (pair_ok && !(n <= hmax && n <= c->coop_max_items) && n <= c->split_max_items && 4 * n <= c->round_items) {
         hipLaunchKernelGGL(k_hash2, dim3(nblk(2 * n)), dim3(WG), 0, s, ws, d_msgs, msg_len, d_moff, st, n);
         hipLaunchKernelGGL(k_h_compact_a, dim3(nblk(n)), dim3(WG), 0, s, ws, n);
         hipLaunchKernelGGL(k_h_compact_b, dim3(nblk(n)), dim3(WG), 0, s, ws, n);
         return;
     }
-    if (n <= c->coop_hash_max_items && n <= c->coop_max_items) {
+    if (n <= hmax && n <= c->coop_max_items) {
         hipLaunchKernelGGL(k_hash_fields, dim3(nblk(n)), dim3(WG), 0, s, ws, d_msgs, msg_len, d_moff, st, n);
         coop_run(c, n > c->coop_hash_pack_min_items ? COOP_HASHG2X4 : COOP_HASHG2, ws, (uint64_t)0, (uint64_t)1, (uint64_t)0, n, (uint32_t*)nullptr, (uint8_t*)nullptr, COOP_RES_ITEM, s);
     } else
@@ -927,7 +929,9 @@ static int verify_pipeline_one(mbls_ctx* c, const uint8_t* d_sigs, const uint8_t
     if (!d_sigs || (!d_msgs && msg_len && !d_moff) || !d_results || (!have_keys && (k || d_off) && part != 1)) ARGFAIL(c, "null buffer");
     HIPCHK(c, hipSetDevice(c->device));
     const bool split = n > c->coop_max_items && n <= c->split_max_items && 2 * n <= c->round_items;     // two lanes per item in the Miller phase
-    int rc = mbls_ctx_reserve(c, split ? 2 * n : n); if (rc) return rc;
+    // (a batch whose pairing check runs on waves but whose message phase does not takes the lane-pair message phase too: 2 n items of workspace)
+    const bool hash_pairs = split || (n <= c->coop_max_items && n > c->coop_hash_max_items && n <= c->split_max_items && 4 * n <= c->round_items);
+    int rc = mbls_ctx_reserve(c, hash_pairs ? 2 * n : n); if (rc) return rc;
     mbls_ws ws; ws.w = c->d_w; ws.stride = c->cap;
     uint32_t* st = d_status ? d_status : c->d_status;
     unsigned g = nblk(n);
@@ -958,7 +962,7 @@ static int verify_pipeline_one(mbls_ctx* c, const uint8_t* d_sigs, const uint8_t
     }
     if (part == 1) {
         hipLaunchKernelGGL(k_sig, dim3(g), dim3(WG), 0, s_sig, ws, d_sigs, st, n, fused_sig ? 0 : 1);
-        launch_hash(c, ws, d_msgs, msg_len, d_moff, st, n, s_msg, split);
+        launch_hash(c, ws, d_msgs, msg_len, d_moff, st, n, s_msg, hash_pairs);
         HIPCHK(c, hipGetLastError());
         return MBLS_OK;
     }
@@ -974,7 +978,7 @@ static int verify_pipeline_one(mbls_ctx* c, const uint8_t* d_sigs, const uint8_t
     if (tm) HIPCHK(c, hipEventRecord(c->ev[1], s));
     if (!keys_later) hipLaunchKernelGGL(k_sig, dim3(g), dim3(WG), 0, s_sig, ws, d_sigs, st, n, fused_sig ? 0 : 1);
     if (tm) HIPCHK(c, hipEventRecord(c->ev[2], s));
-    if (!keys_later) launch_hash(c, ws, d_msgs, msg_len, d_moff, st, n, s_msg, split);
+    if (!keys_later) launch_hash(c, ws, d_msgs, msg_len, d_moff, st, n, s_msg, hash_pairs);
     if (tm) HIPCHK(c, hipEventRecord(c->ev[3], s));
     if (fork) {      // join
         if (s_sig != s) { HIPCHK(c, hipEventRecord(c->hs_ev2, s_sig)); HIPCHK(c, hipStreamWaitEvent(s, c->hs_ev2, 0)); }

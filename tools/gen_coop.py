@@ -131,7 +131,8 @@ SHAPES = {
     ('vmfinal', 'mulbase'): (1, 1),
     ('vmfinal', 'step_conj'): (1, 1),
     ('vmfinal', 'step_frob'): (1, 1),
-    ('vmfinal', 'tail'): (0, 1, 0, 1),
+    ('vmfinal', 'tail'): (0, 1, 0, 1),    # 288 slots, the largest of all programs = the static LDS of every 64-lane instance: 8 waves per CU, two per SIMD. (With 275 slots a CU takes
+                                          # 9 waves, one SIMD then holds three and sets the pace: 3 072 verifications 6.9 -> 7.8 ms. Measured, reverted.)
     ('vmtail', 'add'): (2,),
     ('vmtail', 'dbl'): (2,),
     ('vmtail', 'easy'): (2,),
