@@ -429,6 +429,38 @@ def other_configs(ctx, lib, dev, sptr):
     return out
 
 
+def aggregate_verify_leg(ctx, lib, dev, sptr, n=1 << 14, kp=4):
+    """n x AggregateSignature::aggregate_verify in one call (reference src/aggregates.rs:130-170; SURVEY section 8 (f)1): n items of kp (message, key)
+    pairs each, distinct 32-byte messages, signatures aggregated on the device. All valid, then one message flipped: only that item fails."""
+    pool = make_pool(SEED)
+    pool_b = np.frombuffer(b"".join(s.to_bytes(32, "big") for s in pool), dtype=np.uint8).reshape(POOL, 32)
+    d_pool_sk = torch.from_numpy(pool_b.copy()).to(dev)
+    d_pool_pk = torch.empty((POOL, 96), dtype=torch.uint8, device=dev)
+    ctx.check(lib.mbls_sk_to_pk_batch_device(ctx.handle, d_pool_sk.data_ptr(), N.PK_UNCOMPRESSED, POOL, d_pool_pk.data_ptr(), None))
+    rng = np.random.default_rng(SEED + 77)
+    total = n * kp
+    idx = torch.from_numpy(rng.integers(0, POOL, size=total, dtype=np.int64)).to(dev)
+    d_msgs = torch.from_numpy(rng.integers(0, 256, size=(total, 32), dtype=np.uint8)).to(dev)
+    d_sk = d_pool_sk[idx].contiguous(); d_pks = d_pool_pk[idx].contiguous()
+    d_psig = torch.empty((total, 96), dtype=torch.uint8, device=dev)
+    ctx.check(lib.mbls_sign_batch_device(ctx.handle, d_sk.data_ptr(), d_msgs.data_ptr(), 32, total, d_psig.data_ptr(), None))
+    d_sigs = torch.empty((n, 96), dtype=torch.uint8, device=dev); d_errs = torch.zeros(n, dtype=torch.uint8, device=dev)
+    ctx.check(lib.mbls_aggregate_signatures_batch_device(ctx.handle, d_psig.data_ptr(), None, n, kp, total, d_sigs.data_ptr(), d_errs.data_ptr(), None))
+    torch.cuda.synchronize()
+    d_res = torch.zeros(n, dtype=torch.uint8, device=dev)
+
+    def f():
+        ctx.check(lib.mbls_aggregate_verify_batch_device(ctx.handle, d_sigs.data_ptr(), d_msgs.data_ptr(), 32, None, d_pks.data_ptr(), None, kp, total, n,
+                                                         d_res.data_ptr(), None, sptr))
+    t = _med_ms(f)
+    ok = bool(d_res.all().item()) and int(d_errs.max().item()) == 0
+    j = n // 3
+    d_msgs[j * kp + 1, 4] ^= 8; f(); torch.cuda.synchronize()
+    ok = ok and int(d_res[j].item()) == 0 and int(d_res.sum().item()) == n - 1
+    d_msgs[j * kp + 1, 4] ^= 8
+    return {"ms": t, "aggregate_verify_per_s": n / t * 1e3, "pairs_per_s": total / t * 1e3, "correct": ok}
+
+
 def keyops_figures(ctx, lib, dev, n=1 << 16):
     """The operations either side of the path (the reference's criterion groups benches/bls381_benches.rs:10-84 (de)compression, :115-147
     signing, :247-268 key generation; KeyValidate = src/keys.rs:182): batches of n through the device entries where they exist (host
@@ -808,6 +840,7 @@ def main():
     multi_legs = None
     if not args.no_variants and world == 1:
         other = other_configs(ctx, lib, dev, sptr)
+        other["aggregate_verify_batch 2^14 items x 4 (message, key) pairs"] = aggregate_verify_leg(ctx, lib, dev, sptr)
         other["operations either side of the path (2^16 each)"] = keyops_figures(ctx, lib, dev)
         ok = ok and all(v.get("correct", True) for v in other.values() if isinstance(v, dict))
         ok = ok and all(v.get("correct", True) for v in other["operations either side of the path (2^16 each)"].values() if isinstance(v, dict))

@@ -301,3 +301,16 @@ def test_aggregate_verify_batch_vs_oracle(mb):
     got2, _ = mb.aggregate_verify_batch(b"".join(sigs2), b"".join(b"".join(m) for m in msgs), b"".join(pks[j] for w in who for j in w), n2, k=k2)
     assert got2 == want2
     assert mb.aggregate_verify_batch(b"", b"", b"", 0, k=3) == ([], [])
+
+
+@pytest.mark.parametrize("n,kp", [(13200, 4), (16384, 4), (20000, 3), (33000, 2)])
+def test_aggregate_verify_batch_above_a_round_of_pairs(n, kp):
+    """n + n kp one-pair Miller loops = more than a round of lanes (65 536): whole rounds first, what is left of the last round as a launch of its own --
+    on lane pairs when it is at most half a round (launch_miller_single). All items valid, then one message flipped: only that item fails
+    (bench.aggregate_verify_leg builds the signatures on the device)."""
+    import torch
+    import bench
+    from milagro_bls_amd import _native as N
+    ctx = N.default_context()
+    r = bench.aggregate_verify_leg(ctx, N.lib(), torch.device("cuda:0"), None, n=n, kp=kp)
+    assert r["correct"] is True, r
