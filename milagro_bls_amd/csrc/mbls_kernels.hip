@@ -639,7 +639,7 @@ struct mbls_ctx {
     uint64_t round_items = 65536;
     // batches of at most split_max_items items (default: half a round) on the one-lane path walk their two Miller pairs on two lanes (k_miller_split);
     // up to fork_max_items items the three front phases (keys | signature | message) run side by side on the context's streams
-    uint64_t split_max_items = 32768, fork_max_items = 49152;
+    uint64_t split_max_items = 32768, fork_max_items = 49152, hash2_max_items = 20480;
     char err[256] = {};
 };
 struct mbls_keytable {
@@ -686,11 +686,11 @@ static void coop_run(mbls_ctx* c, int prog, mbls_ws ws, uint64_t first_item, uin
         hipLaunchKernelGGL(k_coop, grid, dim3(64), lds, s, pg, ws, first_item, item_step, partner_step, n_items, st, res, res_mode);
 }
 static void launch_hash(mbls_ctx* c, mbls_ws ws, const uint8_t* d_msgs, uint32_t msg_len, const uint64_t* d_moff, uint32_t* st, uint64_t n, hipStream_t s, bool pair_ok) {
-    // (up to a quarter of a round: with 2 n lanes for the messages beside n for the keys and n for the signatures the three front chains still run
-    // side by side; above that the doubled message phase would push them behind it)
+    // (up to 5/16 of a round -- hash2_max_items --: 2 n lanes for the messages beside n for the keys, with the signatures behind them, are still resident
+    // together; at a third of a round and above the doubled message phase pushes the key sums behind it: 20 480 items 16.1 -> 14.6 ms, 21 845 items 16.3 -> 16.7)
     // the wave form's limit: where the lane-pair form is not on offer (pair_ok: the caller reserved 2 n items), waves serve every batch the pairing check's waves serve
     const uint64_t hmax = (pair_ok || !c->coop_hash_max_items) ? c->coop_hash_max_items : (c->coop_hash_max_items > c->coop_max_items ? c->coop_hash_max_items : c->coop_max_items);
-    if (pair_ok && !(n <= hmax && n <= c->coop_max_items) && n <= c->split_max_items && 4 * n <= c->round_items) {
+    if (pair_ok && !(n <= hmax && n <= c->coop_max_items) && n <= c->split_max_items && n <= c->hash2_max_items) {
         hipLaunchKernelGGL(k_hash2, dim3(nblk(2 * n)), dim3(WG), 0, s, ws, d_msgs, msg_len, d_moff, st, n);
         hipLaunchKernelGGL(k_h_compact_a, dim3(nblk(n)), dim3(WG), 0, s, ws, n);
         hipLaunchKernelGGL(k_h_compact_b, dim3(nblk(n)), dim3(WG), 0, s, ws, n);
@@ -798,12 +798,13 @@ static void ctx_default_tuning(mbls_ctx* c) {
     hipDeviceProp_t prop;
     c->round_items = 65536;
     if (hipGetDeviceProperties(&prop, c->device) == hipSuccess && prop.multiProcessorCount > 0) c->round_items = (uint64_t)prop.multiProcessorCount * 4 * WG;
-    c->split_max_items = c->round_items / 2; c->fork_max_items = c->round_items / 4 * 3;
+    c->split_max_items = c->round_items / 2; c->fork_max_items = c->round_items / 4 * 3; c->hash2_max_items = c->round_items / 16 * 5;
     const char* e;
     if ((e = getenv("MBLS_COOP_MAX_ITEMS"))) c->coop_max_items = strtoull(e, nullptr, 10);
     if ((e = getenv("MBLS_COOP_HASH_MAX_ITEMS"))) c->coop_hash_max_items = strtoull(e, nullptr, 10);
     if ((e = getenv("MBLS_SPLIT_MAX_ITEMS"))) c->split_max_items = strtoull(e, nullptr, 10);
     if ((e = getenv("MBLS_FORK_MAX_ITEMS"))) c->fork_max_items = strtoull(e, nullptr, 10);
+    if ((e = getenv("MBLS_HASH2_MAX_ITEMS"))) c->hash2_max_items = strtoull(e, nullptr, 10);
 }
 extern "C" int mbls_ctx_reset_tuning(mbls_ctx* c) {
     if (!c) return MBLS_ERR_ARGUMENT;
@@ -819,7 +820,7 @@ extern "C" int mbls_ctx_set_round_items(mbls_ctx* c, uint64_t items) {
         HIPCHK(c, hipGetDeviceProperties(&prop, c->device));
         items = (uint64_t)prop.multiProcessorCount * 4 * WG;
     }
-    c->round_items = items; c->split_max_items = items / 2; c->fork_max_items = items / 4 * 3; return MBLS_OK;
+    c->round_items = items; c->split_max_items = items / 2; c->fork_max_items = items / 4 * 3; c->hash2_max_items = items / 16 * 5; return MBLS_OK;
 }
 // one-lane path: batches of up to split_max_items items walk their two Miller pairs on two lanes (never above half a round); up to
 // fork_max_items items the three front phases run side by side. Defaults: round / 2 and 3/4 of a round (measured: side by side costs 26.6 ms

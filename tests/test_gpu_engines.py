@@ -4,7 +4,7 @@ invariant. One seeded batch of 20 480 items x 2 keys is signed and verified by t
 
 Routing (milagro_bls_amd/csrc/mbls_kernels.hip, verify_pipeline / launch_hash): n <= 768 hashg2 + pairing2, (768, 1024] hashg2x4 + pairing2,
 (1024, 2048] hashg2x4 + pairing2x2, (2048, 3584] hashg2x4 + pairing2, (3584, 5120] k_hash2 (two lanes per message) + pairing2, (5120, 16384] k_hash2 (two lanes per message) + k_miller_split4 (four lanes per item: two per pair, products in pairs) + product + k_sig_verdict +
-k_final2 (two lanes per item: the compressed squarings split, the other products in pairs), (16384, 32768] k_hash + k_miller_split (two lanes per item) + k_final2, above 32768 k_hash + k_miller (two-pair loop) + k_sig_verdict + k_final; in both lane forms the signature's subgroup test is read off the
+k_final2 (two lanes per item: the compressed squarings split, the other products in pairs), (16384, 20480] k_hash2 + k_miller_split (two lanes per item) + k_final2, (20480, 32768] k_hash + k_miller_split + k_final2, above 32768 k_hash + k_miller (two-pair loop) + k_sig_verdict + k_final; in both lane forms the signature's subgroup test is read off the
 Miller loop's running point. Above a round (65 536 items) the remainder is routed as a batch of its own."""
 import random
 
@@ -16,7 +16,7 @@ import orc
 pytestmark = pytest.mark.gpu
 
 N_BIG = 20480
-BOUNDARIES = [768, 769, 1024, 1025, 2048, 2049, 3584, 3585, 5120, 5121, 6144, 6145, 8192, 8193, 16384, 16385]
+BOUNDARIES = [768, 769, 1024, 1025, 2048, 2049, 3584, 3585, 5120, 5121, 6144, 6145, 8192, 8193, 16384, 16385, 20480, 20481]
 FLAG = {"sig_not_in_g2": 0x02, "apk_infinity": 0x08, "bad_sig_bytes": 0x01, "bad_pk_bytes": 0x04, "flip_msg": 0x40, "wrong_key": 0x40}
 
 
