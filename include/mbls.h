@@ -264,6 +264,15 @@ int mbls_verify_multiple_sets_device(mbls_ctx* ctx, const uint8_t* d_sigs96, con
                                      const uint64_t* d_msg_offsets, const uint64_t* d_rands, uint64_t n, uint8_t* d_result,
                                      uint32_t* d_status, void* stream);
 
+/* The same for sets named by indices into a resident key table (mbls_keytable_*; the deployment's form: a set is a list of validator indices):
+ * set i owns d_key_idx[d_offsets[i] .. d_offsets[i+1]) or k indices each; an index outside the table or an invalid record rejects the check
+ * (MBLS_ST_BAD_PK_ENCODING in the status word). With d_partial != NULL the call produces the shard record of the section below instead of
+ * d_result / d_status (which may then be NULL). Enqueues only. */
+int mbls_verify_multiple_sets_indexed_device(mbls_ctx* ctx, const mbls_keytable* t, const uint8_t* d_sigs96, const uint32_t* d_key_idx,
+                                             const uint32_t* d_offsets, uint32_t k, const uint8_t* d_msgs, uint32_t msg_len,
+                                             const uint64_t* d_msg_offsets, const uint64_t* d_rands, uint64_t n, uint8_t* d_result,
+                                             uint32_t* d_status, uint8_t* d_partial, void* stream);
+
 /* verify_multiple over several devices or processes ("one exchange step"; the reference's function is one loop over
  * one iterator, src/aggregates.rs:261-316 -- the product of pairings and the sum of blinded signatures it accumulates are associative, so
  * the sets may be cut into shards): every participant runs mbls_verify_multiple_partial_device over ITS sets and gets one

@@ -73,6 +73,7 @@ SIGNATURES = {
     "mbls_verify_multiple_aggregate_signatures": (C.c_int, [vp, vp, vp, vp, C.c_uint32, vp, vp, C.c_size_t]),
     "mbls_verify_multiple_aggregate_signatures_device": (C.c_int, [vp, vp, vp, vp, C.c_uint32, vp, vp, C.c_uint64, vp, vp, vp]),
     "mbls_verify_multiple_sets_device": (C.c_int, [vp, vp, vp, C.c_int, vp, C.c_uint32, vp, C.c_uint32, vp, vp, C.c_uint64, vp, vp, vp]),
+    "mbls_verify_multiple_sets_indexed_device": (C.c_int, [vp, vp, vp, vp, vp, C.c_uint32, vp, C.c_uint32, vp, vp, C.c_uint64, vp, vp, vp, vp]),
     "mbls_verify_multiple_partial_device": (C.c_int, [vp, vp, vp, vp, C.c_int, vp, C.c_uint32, vp, C.c_uint32, vp, vp, C.c_uint64, vp, vp]),
     "mbls_verify_multiple_finish_device": (C.c_int, [vp, vp, C.c_uint64, vp, vp, vp]),
     "mbls_multi_verify_multiple_aggregate_signatures": (C.c_int, [vp, vp, vp, vp, C.c_uint32, vp, vp, C.c_size_t]),

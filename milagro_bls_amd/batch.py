@@ -171,6 +171,24 @@ def verify_multiple_sets_device(d_sigs, d_pks, d_msgs, d_rands, n, k, pk_format=
     return bool(v)
 
 
+def verify_multiple_sets_indexed_device(table, d_sigs, d_key_idx, d_msgs, d_rands, n, k, msg_len=32, stream=None, ctx=None, d_result=None, d_status=None, d_partial=None,
+                                        d_offsets=None):
+    """verify_multiple over sets named by indices into a resident KeyTable (raw device pointers). With d_result or d_partial the call only enqueues;
+    without both it synchronises and returns the bool."""
+    ctx = ctx or _c()
+    f = N.lib().mbls_verify_multiple_sets_indexed_device
+    if d_result is not None or d_partial is not None:
+        ctx.check(f(ctx.handle, table.handle, d_sigs, d_key_idx, d_offsets, k, d_msgs, msg_len, None, d_rands, n, d_result, d_status, d_partial, stream))
+        return None
+    import torch
+    res = torch.full((8,), 7, dtype=torch.uint8, device="cuda")
+    ctx.check(f(ctx.handle, table.handle, d_sigs, d_key_idx, d_offsets, k, d_msgs, msg_len, None, d_rands, n, res.data_ptr(), d_status, None, stream))
+    torch.cuda.synchronize()
+    v = int(res[0].item())
+    assert v in (0, 1)
+    return bool(v)
+
+
 def verify_multiple_partial_device(d_sigs, d_msgs, d_rands, n, d_partial, d_apks=None, d_pks=None, k=0, pk_format=N.PK_COMPRESSED, msg_len=32, stream=None, ctx=None):
     """One shard of a verify_multiple that is spread over several devices or processes (include/mbls.h): the shard's
     Miller product, signature sum and status bits as one N.VM_PARTIAL_BYTES record at the device address d_partial. Enqueues only."""

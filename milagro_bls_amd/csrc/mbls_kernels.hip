@@ -1808,7 +1808,7 @@ extern "C" int mbls_aggregate_verify_batch(mbls_ctx* c, const uint8_t* sigs, con
 }
 static int verify_multiple_impl(mbls_ctx* c, const uint8_t* d_sigs, const uint8_t* d_apks, const uint8_t* d_pks, int pk_format,
         const uint32_t* d_pk_offsets, uint32_t k, const uint8_t* d_msgs, uint32_t msg_len, const uint64_t* d_moff, const uint64_t* d_rands, uint64_t n,
-        uint8_t* d_result, uint32_t* d_status_or, void* stream, uint32_t* d_partial = nullptr) {
+        uint8_t* d_result, uint32_t* d_status_or, void* stream, uint32_t* d_partial = nullptr, const mbls_keytable* tab = nullptr, const uint32_t* d_idx = nullptr) {
     if (!c || (!d_result && !d_partial)) return MBLS_ERR_ARGUMENT;
     mbls_lock lk(c->mu);
     hipStream_t s = (hipStream_t)stream;
@@ -1842,9 +1842,12 @@ static int verify_multiple_impl(mbls_ctx* c, const uint8_t* d_sigs, const uint8_
     const bool fork = 2 * n <= c->round_items;
     hipStream_t s_sig = fork ? c->hs_b : s, s_msg = fork ? c->hs_c : s;
     if (fork) { HIPCHK(c, hipEventRecord(c->hs_ev, s)); HIPCHK(c, hipStreamWaitEvent(s_sig, c->hs_ev, 0)); HIPCHK(c, hipStreamWaitEvent(s_msg, c->hs_ev, 0)); }
-    if (!d_apks)    // sets given by their wire-format keys: AggregatePublicKey::aggregate on the device first (src/aggregates.rs:29-39)
+    if (tab) {      // sets given by indices into a resident key table: the indexed key sum (the keys were decoded and validated once)
+        rc = table_acquire(c, tab, s); if (rc) return rc;
+        hipLaunchKernelGGL(k_aggregate_indexed_d, dim3(nblk(n)), dim3(WG), 0, s, ws, (const uint32_t*)tab->d_recs, tab->size, d_idx, d_pk_offsets, k, MBLS_MODE_VERIFY, c->d_status, n);
+    } else if (!d_apks)    // sets given by their wire-format keys: AggregatePublicKey::aggregate on the device first (src/aggregates.rs:29-39)
         launch_aggregate(ws, d_pks, d_pk_offsets, k, pk_format, MBLS_MODE_VERIFY, c->d_status, n, s);
-    hipLaunchKernelGGL(k_blind_g1_d, dim3(nblk(n)), dim3(WG), 0, s, ws, d_apks, d_rands, c->d_status, n);
+    hipLaunchKernelGGL(k_blind_g1_d, dim3(nblk(n)), dim3(WG), 0, s, ws, tab ? (const uint8_t*)nullptr : d_apks, d_rands, c->d_status, n);
     hipLaunchKernelGGL(k_blind_sig_d, dim3(nblk(n)), dim3(WG), 0, s_sig, ws, d_sigs, d_rands, c->d_status, n);
     const bool side_s_chain = !fork && s != c->hs_b;                  // the sum tree waits for the product tree's company (npairing_finish)
     if (!side_s_chain) g2_tree(c, ws, n, s_sig);
@@ -1865,6 +1868,21 @@ static int verify_multiple_impl(mbls_ctx* c, const uint8_t* d_sigs, const uint8_
     rc = npairing_finish(c, n, s, d_result, fork ? c->hs_ev : nullptr, fork, d_partial, side_s_chain); if (rc) return rc;
     if (d_status_or) HIPCHK(c, hipMemcpyAsync(d_status_or, c->d_scalar, 4, hipMemcpyDeviceToDevice, s));
     return ws_release(c, s);
+}
+// verify_multiple over sets named by indices into a resident key table (the deployment's form: validator keys are decoded once, a set is a list of
+// validator indices): set i owns indices [d_offsets[i], d_offsets[i+1]) of d_key_idx, or k each. d_partial (optional) instead of d_result: the shard form.
+extern "C" int mbls_verify_multiple_sets_indexed_device(mbls_ctx* c, const mbls_keytable* t, const uint8_t* d_sigs, const uint32_t* d_key_idx, const uint32_t* d_offsets,
+        uint32_t k, const uint8_t* d_msgs, uint32_t msg_len, const uint64_t* d_moff, const uint64_t* d_rands, uint64_t n, uint8_t* d_result, uint32_t* d_status_or,
+        uint8_t* d_partial, void* stream) {
+    if (!c || !t || (!d_result && !d_partial)) return MBLS_ERR_ARGUMENT;
+    if (n && !d_key_idx) return MBLS_ERR_ARGUMENT;
+    if (((uintptr_t)d_partial) & 3) return MBLS_ERR_ARGUMENT;
+    {
+        mbls_lock lk(c->mu);
+        if (t->c != c) ARGFAIL(c, "key table belongs to another context");
+    }
+    return verify_multiple_impl(c, d_sigs, nullptr, nullptr, MBLS_PK_UNCOMPRESSED, d_offsets, k, d_msgs, msg_len, d_moff, d_rands, n, d_partial ? nullptr : d_result,
+                                d_partial ? nullptr : d_status_or, stream, (uint32_t*)d_partial, t, d_key_idx);
 }
 // One shard of a verify_multiple that is spread over several devices or processes: everything up to the shard's
 // Miller product and signature sum, left as one MBLS_VM_PARTIAL_BYTES record in device memory. Enqueues only.

@@ -232,3 +232,39 @@ def test_many_records_join_through_both_tree_engines(N):
             batch.verify_multiple_partial_device(d[0].data_ptr(), d[2].data_ptr(), d[3].data_ptr(), 2, recs.data_ptr() + g * P, d_apks=d[1].data_ptr())
         assert batch.verify_multiple_finish_device(recs.data_ptr(), G) is (not spoil)
         assert _one_device(N, sigs, pks, m, rands) is (not spoil)
+
+
+def test_verify_multiple_over_key_table_indices(N):
+    """sets named by indices into a resident key table (mbls_verify_multiple_sets_indexed_device): the same bool as the sets given by their key
+    bytes -- one call and two shards + join --, an index outside the table rejects the check with MBLS_ST_BAD_PK_ENCODING"""
+    import torch
+    import bench
+    from milagro_bls_amd import batch
+    ctx = N.default_context()
+    dev = torch.device("cuda:0")
+    n, k = 3000, 3
+    d_sigs, d_msgs, d_pks, expect, d_idx, table = bench.build_inputs(ctx, dev, n, k, N.PK_UNCOMPRESSED, rank=8, negatives=False, return_indices=True)
+    d_idx = d_idx.to(torch.int32).contiguous()
+    g = torch.Generator(device="cpu"); g.manual_seed(14)
+    rands = torch.randint(1, (1 << 62), (n,), dtype=torch.int64, generator=g).to(dev)
+    args = (table, d_sigs.data_ptr(), d_idx.data_ptr(), d_msgs.data_ptr(), rands.data_ptr(), n, k)
+    by_bytes = lambda: batch.verify_multiple_sets_device(d_sigs.data_ptr(), d_pks.data_ptr(), d_msgs.data_ptr(), rands.data_ptr(), n, k, pk_format=N.PK_UNCOMPRESSED)
+    assert batch.verify_multiple_sets_indexed_device(*args) is True and by_bytes() is True
+    d_msgs[77, 1] ^= 1
+    assert batch.verify_multiple_sets_indexed_device(*args) is False and by_bytes() is False
+    d_msgs[77, 1] ^= 1
+    # two shards through the record form
+    recs = torch.zeros(2 * N.VM_PARTIAL_BYTES, dtype=torch.uint8, device=dev)
+    for j, (lo, hi) in enumerate(((0, 1000), (1000, n))):
+        batch.verify_multiple_sets_indexed_device(table, d_sigs[lo:].data_ptr(), d_idx[lo:].data_ptr(), d_msgs[lo:].data_ptr(), rands[lo:].data_ptr(), hi - lo, k,
+                                                  d_partial=recs.data_ptr() + j * N.VM_PARTIAL_BYTES)
+    assert batch.verify_multiple_finish_device(recs.data_ptr(), 2) is True
+    # an index outside the table
+    keep = int(d_idx[5, 1].item())
+    d_idx[5, 1] = 0x7FFFFFF0
+    st = torch.zeros(1, dtype=torch.int32, device=dev); res = torch.full((8,), 7, dtype=torch.uint8, device=dev)
+    batch.verify_multiple_sets_indexed_device(*args, d_result=res.data_ptr(), d_status=st.data_ptr())
+    torch.cuda.synchronize()
+    assert int(res[0].item()) == 0 and (int(st[0].item()) & 0x04)
+    d_idx[5, 1] = keep
+    assert batch.verify_multiple_sets_indexed_device(*args) is True
