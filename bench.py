@@ -686,10 +686,44 @@ def stub_rank(args, rank, world):
 
 
 def git_head():
+    """the commit this tree is at: from git where .git exists, else from .git_head (written by the post-commit hook scripts/post-commit.sh installs; the GPU
+    box receives the tree without .git) -- labelled, because a file can lag one commit behind"""
     try:
         return subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], text=True, stderr=subprocess.DEVNULL).strip()
     except Exception:
+        pass
+    try:
+        with open(os.path.join(ROOT, ".git_head")) as f:
+            return f.read().strip() + " (.git_head)"
+    except Exception:
         return None
+
+
+def library_source_hash():
+    """content hash of the sources the loaded libmbls_hip.so was built from (milagro_bls_amd/build.py writes it next to the library)"""
+    try:
+        with open(N.LIB_PATH + ".srchash") as f:
+            return f.read().strip()
+    except Exception:
+        return None
+
+
+def measured_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the PMC passes (scripts/profile_round.sh, separate FETCH_SIZE / WRITE_SIZE passes, corrected as the guide
+    prescribes) -- taken into roofline.traffic only when that profile was collected on THIS build (same source hash), else (None, reason)"""
+    p = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    try:
+        with open(p) as f:
+            d = json.load(f)
+    except Exception:
+        return None, "no profiles/hbm_traffic.json"
+    have, want = library_source_hash(), d.get("_source_hash")
+    if not want:
+        return None, "profiles/hbm_traffic.json carries no source hash (collected before round 5)"
+    if have != want:
+        return None, "profiles/hbm_traffic.json was collected on another build (source hash %s..., this library %s...)" % (want[:12], (have or "?")[:12])
+    v = d.get(kernel)
+    return (v, "PMC passes of this build (%s)" % d.get("_collected", "scripts/profile_round.sh")) if v is not None else (None, "kernel not in the profile")
 
 
 def from_profile(fname, key):
@@ -873,6 +907,7 @@ def main():
             "the configs[4] shard (2^20 items / 8 GPUs)" if n == (1 << 17) else "custom size")
         phase_sum = sum(phase_ms.values())
         phase_pass = "consistent" if worst_gap <= 0.02 + (0.02 if world > 1 else 0.0) else "inconsistent"
+        traffic, traffic_note = measured_traffic(dom)
         out = {
             "metric": "fast_aggregate_verify/sec (128 pubkeys, 32B msg)", "value": value, "unit": "fast_aggregate_verify/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "ms_per_step_per_rank": per_rank_ms, "higher_is_better": True,
@@ -884,10 +919,10 @@ def main():
                        "parallelism": "items sharded over %d GPU(s), RCCL all-gather of the accept bitmap" % world},
             "bitmap_matches_expectation": ok,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None, "kernel": "k_" + dom, "kernel_ms": phase_ms[dom],
+                         "traffic": traffic, "traffic_source": traffic_note, "kernel": "k_" + dom, "kernel_ms": phase_ms[dom],
                          "algorithmic_bytes_per_item": bytes_per_item,
-                         "note": "VALU-issue-bound path (see valu_issue): the HBM fraction is reported as measured; traffic (PMC counters) cannot "
-                                 "be collected inside a timed run, see traffic_from_profile"},
+                         "note": "VALU-issue-bound path (see valu_issue): the HBM fraction is reported as measured; traffic = HBM bytes per launch of the dominant "
+                                 "kernel from the PMC counters (separate passes, never inside a timed run), attached only when collected on this very build"},
             "traffic_from_profile": from_profile("hbm_traffic.json", dom),
             "valu_issue": valu_issue_figure(lib, ctx, phase_ms, n, {"uncompressed": "k_aggregate", "indexed": "k_aggregate_indexed"}.get(args.pk_format) if k == 128 else None),
             "phase_ms": phase_ms,
@@ -901,7 +936,7 @@ def main():
             "configs4_shard_leg": shard_leg,
             "sharded_verify_multiple_leg": vm_leg,
             "input_build_s": t_in,
-            "head": git_head(),
+            "head": git_head(), "library_source_hash": library_source_hash(),
         }
         if not args.no_cpu_baseline and world == 1:
             allc, one, cfg1 = cpu_baseline(d_sigs, d_msgs, d_pks, expect, k, N.PK_UNCOMPRESSED)

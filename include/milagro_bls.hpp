@@ -236,20 +236,35 @@ struct AggregateSignature {
     bool fast_aggregate_verify_pre_aggregated(const Bytes& msg, const AggregatePublicKey& apk) const {
         return mbls_fast_aggregate_verify_pre_aggregated(detail::ctx(), point.data(), msg.data(), msg.size(), apk.point.data()) == 1;
     }
-    // rng(): one random byte per call. Blinding scalars drawn as at reference src/aggregates.rs:280-287.
+    // rng(): one random byte per call. Blinding scalars drawn as at reference src/aggregates.rs:280-287 -- and in the reference's ORDER: its loop tests set i's
+    // signature for the subgroup (:272-275) before it draws rand[i] and returns at the first signature outside G2, so a rejected batch leaves the caller's
+    // generator where the reference would: one batched subgroup test up front (mbls_sig_check_batch) finds that set, scalars are drawn for the sets before it only.
+    // -> false if a set was rejected before the pairing check (the buffers are then incomplete), true if the batch is ready
+    template <typename Rng, typename Sets>
+    static bool draw_in_reference_order(Rng&& rng, const Sets& sets, Bytes& sigs, Bytes& apks, Bytes& msgs, std::vector<uint64_t>& rands, std::vector<uint64_t>& moff) {
+        for (auto& s : sets) sigs.insert(sigs.end(), std::get<0>(s)->point.begin(), std::get<0>(s)->point.end());
+        std::vector<uint8_t> errs(sets.size()), in_g2(sets.size());
+        detail::check(mbls_sig_check_batch(detail::ctx(), sigs.data(), sets.size(), errs.data(), in_g2.data()));
+        size_t n_ok = 0;
+        while (n_ok < sets.size() && errs[n_ok] == MBLS_OK && in_g2[n_ok]) n_ok++;
+        for (size_t i = 0; i < n_ok; i++) {
+            uint64_t r = 0;
+            while (r == 0) { uint64_t v = 0; for (int j = 0; j < 8; j++) v = (v << 8) | uint8_t(rng()); r = (v >> 63) ? (uint64_t(0) - v) : v; }      // i64::from_be_bytes(..).abs() as the release build wraps it
+            rands.push_back(r);
+        }
+        if (n_ok < sets.size()) return false;                              // :273-275
+        for (auto& s : sets) {
+            apks.insert(apks.end(), std::get<1>(s)->point.begin(), std::get<1>(s)->point.end());
+            msgs.insert(msgs.end(), std::get<2>(s).begin(), std::get<2>(s).end());
+            moff.push_back(msgs.size());                                   // messages of any length each: one buffer + an offset table
+        }
+        return true;
+    }
     template <typename Rng>
     static bool verify_multiple_aggregate_signatures(Rng&& rng, const std::vector<std::tuple<const AggregateSignature*, const AggregatePublicKey*, Bytes>>& sets) {
         if (sets.empty()) return mbls_verify_multiple_aggregate_signatures(detail::ctx(), nullptr, nullptr, nullptr, 0, nullptr, nullptr, 0) == 1;
-        Bytes sigs, apks, msgs; std::vector<uint64_t> rands, moff{0};      // messages of any length each: one buffer + an offset table
-        for (auto& s : sets) {
-            uint64_t r = 0;
-            while (r == 0) { uint64_t v = 0; for (int i = 0; i < 8; i++) v = (v << 8) | uint8_t(rng()); r = (v >> 63) ? (uint64_t(0) - v) : v; }      // i64::from_be_bytes(..).abs() as the release build wraps it
-            rands.push_back(r);
-            sigs.insert(sigs.end(), std::get<0>(s)->point.begin(), std::get<0>(s)->point.end());
-            apks.insert(apks.end(), std::get<1>(s)->point.begin(), std::get<1>(s)->point.end());
-            msgs.insert(msgs.end(), std::get<2>(s).begin(), std::get<2>(s).end());
-            moff.push_back(msgs.size());
-        }
+        Bytes sigs, apks, msgs; std::vector<uint64_t> rands, moff{0};
+        if (!draw_in_reference_order(rng, sets, sigs, apks, msgs, rands, moff)) return false;
         return mbls_verify_multiple_aggregate_signatures(detail::ctx(), sigs.data(), apks.data(), msgs.data(), 0, moff.data(), rands.data(), sets.size()) == 1;
     }
     // the same check with the sets cut into one shard per device of a multi-device handle (mbls_multi_create): same bool
@@ -257,15 +272,7 @@ struct AggregateSignature {
     static bool verify_multiple_aggregate_signatures(mbls_multi* devices, Rng&& rng, const std::vector<std::tuple<const AggregateSignature*, const AggregatePublicKey*, Bytes>>& sets) {
         if (sets.empty()) return true;
         Bytes sigs, apks, msgs; std::vector<uint64_t> rands, moff{0};
-        for (auto& s : sets) {
-            uint64_t r = 0;
-            while (r == 0) { uint64_t v = 0; for (int i = 0; i < 8; i++) v = (v << 8) | uint8_t(rng()); r = (v >> 63) ? (uint64_t(0) - v) : v; }
-            rands.push_back(r);
-            sigs.insert(sigs.end(), std::get<0>(s)->point.begin(), std::get<0>(s)->point.end());
-            apks.insert(apks.end(), std::get<1>(s)->point.begin(), std::get<1>(s)->point.end());
-            msgs.insert(msgs.end(), std::get<2>(s).begin(), std::get<2>(s).end());
-            moff.push_back(msgs.size());
-        }
+        if (!draw_in_reference_order(rng, sets, sigs, apks, msgs, rands, moff)) return false;
         return mbls_multi_verify_multiple_aggregate_signatures(devices, sigs.data(), apks.data(), msgs.data(), 0, moff.data(), rands.data(), sets.size()) == 1;
     }
     static AggregateSignature from_bytes(const Bytes& b) { AggregateSignature a; detail::check(mbls_sig_from_bytes(detail::ctx(), b.data(), b.size(), a.point.data())); return a; }
@@ -289,6 +296,7 @@ inline std::vector<bool> aggregate_verify_batch(const std::vector<AggregateSigna
             m.insert(m.end(), msgs[i][j].begin(), msgs[i][j].end()); moff.push_back(m.size());
             p.insert(p.end(), keys[i][j]->point.begin(), keys[i][j]->point.end());
         }
+        if (p.size() / 96 > 0xFFFFFFFFull) throw std::invalid_argument("aggregate_verify_batch: pair indices are 32-bit");
         poff.push_back(uint32_t(p.size() / 96));
     }
     std::vector<uint8_t> res(n ? n : 1);
@@ -316,6 +324,7 @@ public:
             s.insert(s.end(), sigs[i].point.begin(), sigs[i].point.end());
             m.insert(m.end(), msgs[i].begin(), msgs[i].end()); moff.push_back(m.size());
             for (auto* k : keys[i]) p.insert(p.end(), k->point.begin(), k->point.end());
+            if (p.size() / 96 > 0xFFFFFFFFull) throw std::invalid_argument("fast_aggregate_verify: key indices are 32-bit");
             koff.push_back(uint32_t(p.size() / 96));
         }
         std::vector<uint8_t> res(n ? n : 1);

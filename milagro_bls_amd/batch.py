@@ -62,9 +62,17 @@ def aggregate_verify_batch(sigs, msgs, pks96, n, k=None, pair_offsets=None, msg_
     res = N.outbuf(n)
     st = (C.c_uint32 * max(1, n))()
     off = None
+    if (k is None) == (pair_offsets is None):
+        raise ValueError("aggregate_verify_batch: give exactly one of k (pairs per item) and pair_offsets (n + 1 entries)")
     if pair_offsets is not None:
+        if len(pair_offsets) != n + 1:
+            raise ValueError("aggregate_verify_batch: pair_offsets must have n + 1 = %d entries, got %d" % (n + 1, len(pair_offsets)))
+        if pair_offsets and not 0 <= pair_offsets[-1] <= 0xFFFFFFFF:
+            raise ValueError("aggregate_verify_batch: pair indices are 32-bit")
         off = (C.c_uint32 * len(pair_offsets))(*pair_offsets)
         k = 0
+    elif not 0 <= k * n <= 0xFFFFFFFF:
+        raise ValueError("aggregate_verify_batch: pair indices are 32-bit")
     ctx.check(N.lib().mbls_aggregate_verify_batch(ctx.handle, N.cbuf(sigs), N.cbuf(msgs), msg_len, _moff(msg_offsets), N.cbuf(pks96), off, k, n, res, st))
     return [bool(x) for x in bytes(res)[:n]], list(st)[:n]
 

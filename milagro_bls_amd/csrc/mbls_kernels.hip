@@ -388,12 +388,17 @@ __global__ void MBLS_LB k_pair_item_map(const uint32_t* off, uint64_t n, uint64_
 // one level of the per-item product trees over the pairs' Miller values: pair j (workspace item j of the view `wp`) takes its partner j + half
 // when both lie in the same item's range and j is a multiple of 2 half from the start of that range. The generated tree routine, called with
 // the lanes of the wave that have no product this level switched off.
-__global__ void MBLS_LB k_f12_seg_tree_d(mbls_ws wp, const uint32_t* map, const uint32_t* off, uint32_t k, uint64_t total, uint64_t half) {
+__global__ void MBLS_LB k_f12_seg_tree_d(mbls_ws wp, const uint32_t* map, const uint32_t* off, uint32_t k, uint64_t n, uint64_t total, uint64_t half) {
 #if MBLS_DEVICE_ASM
     __shared__ uint32_t spill[154 * 64];
     uint64_t j = gid(); if (j >= total) return;
     uint64_t lo, hi;
-    if (off) { const uint32_t i = map[j]; lo = off[i]; hi = off[i + 1]; } else { lo = (j / k) * k; hi = lo + k; }
+    if (off) {
+        // map[j] = 0xFFFFFFFF: no item owns pair j (a table that does not start at 0, ends below total or runs backwards) -- never an index
+        const uint32_t i = map[j]; if (i >= n) return;
+        lo = off[i]; hi = off[i + 1];
+        if (!(lo <= j && j < hi && hi <= total)) return;
+    } else { lo = (j / k) * k; hi = lo + k; }
     const uint64_t r = j - lo;
     if (r % (2 * half) != 0 || j + half >= hi) return;
     tree_level_d_call<false>(wp, j, half, (MBLS_LDS uint32_t*)spill, threadIdx.x);
@@ -401,13 +406,15 @@ __global__ void MBLS_LB k_f12_seg_tree_d(mbls_ws wp, const uint32_t* map, const 
 }
 // item i: the product of its pairs (left in the first pair of its range by the tree) -> the staging item n + T + i (1 for an empty range);
 // and the item's status = its signature's | the OR of its pairs' | MBLS_ST_NO_KEYS for an empty range (src/aggregates.rs:131-133)
-__global__ void MBLS_LB k_f12_seg_gather(mbls_ws ws, const uint32_t* off, uint32_t k, uint64_t n, uint64_t total, uint32_t* st_item, const uint32_t* st_pair) {
+__global__ void MBLS_LB k_f12_seg_gather(mbls_ws ws, const uint32_t* off, const uint32_t* map, uint32_t k, uint64_t n, uint64_t total, uint32_t* st_item, const uint32_t* st_pair) {
     uint64_t i = gid(); if (i >= n) return;
     uint64_t lo = off ? off[i] : (uint64_t)k * i, hi = off ? off[i + 1] : lo + k;
     uint32_t st = 0;
     if (hi < lo || hi > total) { st |= MBLS_ST_BAD_PK_ENCODING; hi = lo; }        // an offset table that runs backwards never becomes a read
     if (hi == lo) st |= MBLS_ST_NO_KEYS;
-    for (uint64_t j = lo; j < hi; j++) st |= st_pair[j];
+    // a pair of this range that another item claims as well (ranges overlap where a table ran backwards): that item's tree may have raced with this one's,
+    // so the item is rejected -- an item that is NOT flagged owned every one of its pairs alone
+    for (uint64_t j = lo; j < hi; j++) { st |= st_pair[j]; if (map && map[j] != (uint32_t)i) st |= MBLS_ST_BAD_PK_ENCODING; }
     fp12 f; fp12_set_one(&f);
     const fp* one = &f.c0.c0.c0;
     for (int t = 0; t < 12; t++) ws_st(ws, MBLS_SLOT_F + t, n + total + i, hi > lo ? ws_ld(ws, MBLS_SLOT_F + t, n + lo) : one[t]);
@@ -604,6 +611,7 @@ __global__ void __launch_bounds__(WG) k_valu_bench(uint32_t* sink, uint32_t iter
 // needs 12.2-12.7 ms for anything up to a quarter of a round
 #define MBLS_DEFAULT_COOP_MAX_ITEMS 5120
 #define MBLS_DEFAULT_COOP_HASH_MAX_ITEMS 3584           /* above n / 4 + 2 n / 64 > 1 024 waves: the four-per-wave message phase needs a second round beside the key sums and the signatures (3 600 items 8.0 ms, 3 648 items 9.9 ms); the lane-pair form takes 8.8 - 9.0 */
+#define MBLS_DEFAULT_TRACKS_MIN_REST 6144
 struct mbls_ctx {
     std::recursive_mutex mu;
     int device = 0;
@@ -620,6 +628,10 @@ struct mbls_ctx {
     struct { void* p; size_t cap; } stage[MBLS_N_STAGE] = {};
     hipStream_t hs_a = nullptr, hs_b = nullptr, hs_c = nullptr, hs_d = nullptr;      // streams of the host-buffer entry points (hs_d: the signature phase while hs_b uploads keys)
     hipEvent_t hs_ev = nullptr, hs_ev2 = nullptr, hs_ev3 = nullptr;
+    // the second TRACK of the verification pipeline (verify_pipeline): a batch between one and two rounds runs as two halves side by side, each with its own part
+    // of the workspace, its own main stream and its own side streams for the front phases
+    hipStream_t t1_s = nullptr, t1_b = nullptr, t1_c = nullptr;
+    hipEvent_t t1_ev = nullptr, t1_ev2 = nullptr, t1_ev3 = nullptr;
     hipEvent_t ws_ev = nullptr; hipStream_t ws_stream = nullptr; bool ws_pending = false;   // last asynchronous user of the workspace
     bool timing = false;
     hipEvent_t ev[MBLS_N_PHASES + 1] = {};
@@ -640,6 +652,8 @@ struct mbls_ctx {
     // batches of at most split_max_items items (default: half a round) on the one-lane path walk their two Miller pairs on two lanes (k_miller_split);
     // up to fork_max_items items the three front phases (keys | signature | message) run side by side on the context's streams
     uint64_t split_max_items = 32768, fork_max_items = 49152, hash2_max_items = 20480;
+    // a batch of one to two rounds whose remainder over the round is at least tracks_min_rest items runs as two equal halves on two tracks (0: never)
+    uint64_t tracks_min_rest = MBLS_DEFAULT_TRACKS_MIN_REST;
     char err[256] = {};
 };
 struct mbls_keytable {
@@ -658,7 +672,9 @@ static inline unsigned nblk(uint64_t n) { return (unsigned)((n + WG - 1) / WG); 
 // the message phase of n items on stream s: one lane per item (k_hash), or -- small batches -- hash_to_field per lane and the rest one wave per item
 // pair_ok: the caller's workspace view holds 2 n items and nothing else uses slots 7..24 / 31..42 of items [0, 2 n) meanwhile -- batches of at most
 // half a round then take two lanes per message (k_hash2)
-static void launch_hash(mbls_ctx* c, mbls_ws ws, const uint8_t* d_msgs, uint32_t msg_len, const uint64_t* d_moff, uint32_t* st, uint64_t n, hipStream_t s, bool pair_ok = false);
+enum { HASH_FORM_AUTO = 0, HASH_FORM_LANE, HASH_FORM_WAVE, HASH_FORM_PAIR };
+static void launch_hash(mbls_ctx* c, mbls_ws ws, const uint8_t* d_msgs, uint32_t msg_len, const uint64_t* d_moff, uint32_t* st, uint64_t n, hipStream_t s, bool pair_ok = false,
+                        int form = HASH_FORM_AUTO);
 // the per-item key sum from wire-format keys: the generated routine for 96-byte keys (its 16-byte loads want 4-byte alignment),
 // the compiled lane body for 48-byte keys summed in place and for unaligned buffers
 static void launch_aggregate(mbls_ws ws, const uint8_t* d_pks, const uint32_t* d_off, uint32_t k, int fmt, int mode, uint32_t* st, uint64_t n, hipStream_t s) {
@@ -685,18 +701,22 @@ static void coop_run(mbls_ctx* c, int prog, mbls_ws ws, uint64_t first_item, uin
     else
         hipLaunchKernelGGL(k_coop, grid, dim3(64), lds, s, pg, ws, first_item, item_step, partner_step, n_items, st, res, res_mode);
 }
-static void launch_hash(mbls_ctx* c, mbls_ws ws, const uint8_t* d_msgs, uint32_t msg_len, const uint64_t* d_moff, uint32_t* st, uint64_t n, hipStream_t s, bool pair_ok) {
-    // (up to 5/16 of a round -- hash2_max_items --: 2 n lanes for the messages beside n for the keys, with the signatures behind them, are still resident
-    // together; at a third of a round and above the doubled message phase pushes the key sums behind it: 20 480 items 16.1 -> 14.6 ms, 21 845 items 16.3 -> 16.7)
-    // the wave form's limit: where the lane-pair form is not on offer (pair_ok: the caller reserved 2 n items), waves serve every batch the pairing check's waves serve
-    const uint64_t hmax = (pair_ok || !c->coop_hash_max_items) ? c->coop_hash_max_items : (c->coop_hash_max_items > c->coop_max_items ? c->coop_hash_max_items : c->coop_max_items);
-    if (pair_ok && !(n <= hmax && n <= c->coop_max_items) && n <= c->split_max_items && n <= c->hash2_max_items) {
+// which form the message phase of n items takes: lane pairs (k_hash2) where the caller reserved 2 n workspace items and the batch is above the wave engine's range
+// but at most hash2_max_items (5/16 of a round: 2 n lanes for the messages beside n for the keys, with the signatures behind them, are still resident together; at a
+// third of a round and above the doubled message phase pushes the key sums behind it: 20 480 items 16.1 -> 14.6 ms, 21 845 items 16.3 -> 16.7); one wave per item
+// (or four items per wave) up to coop_hash_max_items -- the measured crossover, for every caller --; one lane per item otherwise
+static int hash_form(const mbls_ctx* c, uint64_t n, bool pair_ok) {
+    const bool waves = n <= c->coop_hash_max_items && n <= c->coop_max_items;
+    if (pair_ok && !waves && n <= c->split_max_items && n <= c->hash2_max_items) return HASH_FORM_PAIR;
+    return waves ? HASH_FORM_WAVE : HASH_FORM_LANE;
+}
+static void launch_hash(mbls_ctx* c, mbls_ws ws, const uint8_t* d_msgs, uint32_t msg_len, const uint64_t* d_moff, uint32_t* st, uint64_t n, hipStream_t s, bool pair_ok, int form) {
+    if (form == HASH_FORM_AUTO) form = hash_form(c, n, pair_ok);
+    if (form == HASH_FORM_PAIR) {
         hipLaunchKernelGGL(k_hash2, dim3(nblk(2 * n)), dim3(WG), 0, s, ws, d_msgs, msg_len, d_moff, st, n);
         hipLaunchKernelGGL(k_h_compact_a, dim3(nblk(n)), dim3(WG), 0, s, ws, n);
         hipLaunchKernelGGL(k_h_compact_b, dim3(nblk(n)), dim3(WG), 0, s, ws, n);
-        return;
-    }
-    if (n <= hmax && n <= c->coop_max_items) {
+    } else if (form == HASH_FORM_WAVE) {
         hipLaunchKernelGGL(k_hash_fields, dim3(nblk(n)), dim3(WG), 0, s, ws, d_msgs, msg_len, d_moff, st, n);
         coop_run(c, n > c->coop_hash_pack_min_items ? COOP_HASHG2X4 : COOP_HASHG2, ws, (uint64_t)0, (uint64_t)1, (uint64_t)0, n, (uint32_t*)nullptr, (uint8_t*)nullptr, COOP_RES_ITEM, s);
     } else
@@ -718,6 +738,12 @@ static void ctx_free(mbls_ctx* c) {
     if (c->hs_ev) (void)hipEventDestroy(c->hs_ev);
     if (c->hs_ev2) (void)hipEventDestroy(c->hs_ev2);
     if (c->hs_ev3) (void)hipEventDestroy(c->hs_ev3);
+    if (c->t1_ev) (void)hipEventDestroy(c->t1_ev);
+    if (c->t1_ev2) (void)hipEventDestroy(c->t1_ev2);
+    if (c->t1_ev3) (void)hipEventDestroy(c->t1_ev3);
+    if (c->t1_s) (void)hipStreamDestroy(c->t1_s);
+    if (c->t1_b) (void)hipStreamDestroy(c->t1_b);
+    if (c->t1_c) (void)hipStreamDestroy(c->t1_c);
     if (c->ws_ev) (void)hipEventDestroy(c->ws_ev);
     if (c->hs_a) (void)hipStreamDestroy(c->hs_a);
     if (c->hs_b) (void)hipStreamDestroy(c->hs_b);
@@ -746,6 +772,10 @@ extern "C" int mbls_ctx_create(mbls_ctx** out, int device_id) {
          hipStreamCreateWithPriority(&c->hs_c, hipStreamNonBlocking, prio_hi) == hipSuccess && hipStreamCreateWithPriority(&c->hs_d, hipStreamNonBlocking, prio_lo) == hipSuccess;
     ok = ok && hipEventCreateWithFlags(&c->hs_ev, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&c->hs_ev2, hipEventDisableTiming) == hipSuccess &&
          hipEventCreateWithFlags(&c->hs_ev3, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&c->ws_ev, hipEventDisableTiming) == hipSuccess;
+    ok = ok && hipStreamCreateWithFlags(&c->t1_s, hipStreamNonBlocking) == hipSuccess && hipStreamCreateWithPriority(&c->t1_b, hipStreamNonBlocking, prio_lo) == hipSuccess &&
+         hipStreamCreateWithPriority(&c->t1_c, hipStreamNonBlocking, prio_hi) == hipSuccess;
+    ok = ok && hipEventCreateWithFlags(&c->t1_ev, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&c->t1_ev2, hipEventDisableTiming) == hipSuccess &&
+         hipEventCreateWithFlags(&c->t1_ev3, hipEventDisableTiming) == hipSuccess;
     if (ok) {       // the cooperative engine's programs: one upload per context
 #define COOP_SRC(P) {MBLS_COOP_##P##_STEPS, MBLS_COOP_##P##_ROWS, MBLS_COOP_##P##_CONSTS}
 #define COOP_CNT(P) {2 * MBLS_COOP_##P##_NSTEPS, 512 * MBLS_COOP_##P##_NROWS, 15 * (MBLS_COOP_##P##_NCONSTS ? MBLS_COOP_##P##_NCONSTS : 1)}
@@ -805,6 +835,8 @@ static void ctx_default_tuning(mbls_ctx* c) {
     if ((e = getenv("MBLS_SPLIT_MAX_ITEMS"))) c->split_max_items = strtoull(e, nullptr, 10);
     if ((e = getenv("MBLS_FORK_MAX_ITEMS"))) c->fork_max_items = strtoull(e, nullptr, 10);
     if ((e = getenv("MBLS_HASH2_MAX_ITEMS"))) c->hash2_max_items = strtoull(e, nullptr, 10);
+    c->tracks_min_rest = MBLS_DEFAULT_TRACKS_MIN_REST;
+    if ((e = getenv("MBLS_TRACKS_MIN_REST"))) c->tracks_min_rest = strtoull(e, nullptr, 10);
 }
 extern "C" int mbls_ctx_reset_tuning(mbls_ctx* c) {
     if (!c) return MBLS_ERR_ARGUMENT;
@@ -920,9 +952,19 @@ static int table_acquire(mbls_ctx* c, const mbls_keytable* t, hipStream_t s) {
     return MBLS_OK;
 }
 
+// A TRACK = what one pass of the pipeline owns besides the caller's stream: where its items start in the workspace (and in the status words / key staging that go
+// with it), the side streams of its front phases and the events that join them. Track 0 is the context's own set; verify_pipeline runs a second one beside it.
+struct track {
+    uint64_t ws_off = 0;
+    hipStream_t sb = nullptr, sc = nullptr, sd = nullptr;
+    hipEvent_t ev2 = nullptr, ev3 = nullptr;
+    bool ws_sync = true;              // order the pass against the workspace's previous user and record its own end (false: the caller does both around its tracks)
+    uint64_t fork_max = ~0ull;        // front phases side by side up to this many items (~0: the context's fork_max_items)
+};
+static track track0(mbls_ctx* c) { track t; t.sb = c->hs_b; t.sc = c->hs_c; t.sd = c->hs_d; t.ev2 = c->hs_ev2; t.ev3 = c->hs_ev3; return t; }
 static int verify_pipeline_one(mbls_ctx* c, const uint8_t* d_sigs, const uint8_t* d_msgs, uint32_t msg_len, const uint64_t* d_moff, const keysrc& ks,
                                uint64_t n, uint32_t k, int mode, uint8_t* d_results, uint64_t* d_bitmap,
-                               uint32_t* d_status, hipStream_t s, int part = 0) {
+                               uint32_t* d_status, hipStream_t s, int part = 0, const track* tkp = nullptr) {
     const int fmt = ks.fmt; const uint32_t* d_off = ks.d_off;
     if (!c || (fmt != MBLS_PK_COMPRESSED && fmt != MBLS_PK_UNCOMPRESSED)) return MBLS_ERR_ARGUMENT;
     if (n == 0) return MBLS_OK;
@@ -932,13 +974,16 @@ static int verify_pipeline_one(mbls_ctx* c, const uint8_t* d_sigs, const uint8_t
     const bool split = n > c->coop_max_items && n <= c->split_max_items && 2 * n <= c->round_items;     // two lanes per item in the Miller phase
     // (a batch whose pairing check runs on waves but whose message phase does not takes the lane-pair message phase too: 2 n items of workspace)
     const bool hash_pairs = split || (n <= c->coop_max_items && n > c->coop_hash_max_items && n <= c->split_max_items && 4 * n <= c->round_items);
-    int rc = mbls_ctx_reserve(c, hash_pairs ? 2 * n : n); if (rc) return rc;
-    mbls_ws ws; ws.w = c->d_w; ws.stride = c->cap;
-    uint32_t* st = d_status ? d_status : c->d_status;
+    const track tk = tkp ? *tkp : track0(c);
+    int rc = mbls_ctx_reserve(c, tk.ws_off + (hash_pairs ? 2 * n : n)); if (rc) return rc;        // (a pass on a second track finds its space reserved: no growth under the first)
+    mbls_ws ws; ws.w = c->d_w + tk.ws_off; ws.stride = c->cap;
+    uint32_t* st = d_status ? d_status : c->d_status + tk.ws_off;
     unsigned g = nblk(n);
     bool tm = c->timing;
     bool staged = !ks.indexed && (fmt == MBLS_PK_COMPRESSED) && !d_off && k > 1;   // lane-per-key decompression, then the per-item sums
-    if (staged) { rc = reserve_keys(c, n * (uint64_t)k); if (rc) return rc; }
+    if (staged) { rc = reserve_keys(c, (tk.ws_off + n) * (uint64_t)k); if (rc) return rc; }
+    uint32_t* const keys_xy = staged ? c->d_keys_xy + 24 * (uint64_t)k * tk.ws_off : nullptr;
+    uint8_t* const key_flags = staged ? c->d_key_flags + (uint64_t)k * tk.ws_off : nullptr;
     // The status words are zeroed and every phase ORs its bits in (atomically), so the three phases before the Miller loop can run in
     // any order -- and, for batches that leave most SIMDs idle (n <= 2^14: at most a quarter of the one-wave-per-SIMD slots), side by
     // side on the context's own streams: keys | signature | message, joined before the Miller loop (latency 35.7 -> ~30 ms).
@@ -946,19 +991,19 @@ static int verify_pipeline_one(mbls_ctx* c, const uint8_t* d_sigs, const uint8_t
     // null), the caller then uploads the keys on another stream and makes this one wait, and part 2 queues the rest.
     const bool keys_later = part != 0;
     const bool fused_sig = n > c->coop_max_items;     // one lane per item: the subgroup test of the signature comes out of the Miller loop, k_sig only decodes
-    const bool fork = !tm && n <= c->fork_max_items;
+    const bool fork = !tm && n <= (tk.fork_max == ~0ull ? c->fork_max_items : tk.fork_max);
     // (host-buffer entries: hs_b carries the key upload, so their signature phase has a stream of its own)
     // above a quarter of a round the three chains no longer fit the chip side by side (and the message phase runs on n lanes, its longest form): the
     // signature phase -- the shortest -- then follows the key sum on the caller's stream, beside the message phase: 32 768 items 17.1 -> 16.5 ms
     const bool sig_side = fork && (part != 0 || 4 * n <= c->round_items);
-    hipStream_t s_sig = sig_side ? (part == 0 ? c->hs_b : c->hs_d) : s, s_msg = fork ? c->hs_c : s;
+    hipStream_t s_sig = sig_side ? (part == 0 ? tk.sb : tk.sd) : s, s_msg = fork ? tk.sc : s;
     if (part != 2) {
-        rc = ws_acquire(c, s); if (rc) return rc;
+        if (tk.ws_sync) { rc = ws_acquire(c, s); if (rc) return rc; }
         HIPCHK(c, hipMemsetAsync(st, 0, 4 * n, s));
         if (fork) {
-            HIPCHK(c, hipEventRecord(c->hs_ev2, s));
-            if (s_sig != s) HIPCHK(c, hipStreamWaitEvent(s_sig, c->hs_ev2, 0));
-            HIPCHK(c, hipStreamWaitEvent(s_msg, c->hs_ev2, 0));
+            HIPCHK(c, hipEventRecord(tk.ev2, s));
+            if (s_sig != s) HIPCHK(c, hipStreamWaitEvent(s_sig, tk.ev2, 0));
+            HIPCHK(c, hipStreamWaitEvent(s_msg, tk.ev2, 0));
         }
     }
     if (part == 1) {
@@ -972,8 +1017,8 @@ static int verify_pipeline_one(mbls_ctx* c, const uint8_t* d_sigs, const uint8_t
     if (ks.indexed)
         hipLaunchKernelGGL(k_aggregate_indexed_d, dim3(g), dim3(WG), 0, s, ws, ks.d_recs, ks.tsize, ks.d_idx, d_off, k, mode, st, n);
     else if (staged) {
-        hipLaunchKernelGGL(k_pk_decompress, dim3(nblk(n * (uint64_t)k)), dim3(WG), 0, s, ks.d_pks, n * (uint64_t)k, c->d_keys_xy, c->d_key_flags);
-        hipLaunchKernelGGL(k_aggregate_decoded, dim3(g), dim3(WG), 0, s, ws, (const uint32_t*)c->d_keys_xy, (const uint8_t*)c->d_key_flags, k, mode, st, n);
+        hipLaunchKernelGGL(k_pk_decompress, dim3(nblk(n * (uint64_t)k)), dim3(WG), 0, s, ks.d_pks, n * (uint64_t)k, keys_xy, key_flags);
+        hipLaunchKernelGGL(k_aggregate_decoded, dim3(g), dim3(WG), 0, s, ws, (const uint32_t*)keys_xy, (const uint8_t*)key_flags, k, mode, st, n);
     } else
         launch_aggregate(ws, ks.d_pks, d_off, k, fmt, mode, st, n, s);
     if (tm) HIPCHK(c, hipEventRecord(c->ev[1], s));
@@ -982,8 +1027,8 @@ static int verify_pipeline_one(mbls_ctx* c, const uint8_t* d_sigs, const uint8_t
     if (!keys_later) launch_hash(c, ws, d_msgs, msg_len, d_moff, st, n, s_msg, hash_pairs);
     if (tm) HIPCHK(c, hipEventRecord(c->ev[3], s));
     if (fork) {      // join
-        if (s_sig != s) { HIPCHK(c, hipEventRecord(c->hs_ev2, s_sig)); HIPCHK(c, hipStreamWaitEvent(s, c->hs_ev2, 0)); }
-        HIPCHK(c, hipEventRecord(c->hs_ev3, s_msg)); HIPCHK(c, hipStreamWaitEvent(s, c->hs_ev3, 0));
+        if (s_sig != s) { HIPCHK(c, hipEventRecord(tk.ev2, s_sig)); HIPCHK(c, hipStreamWaitEvent(s, tk.ev2, 0)); }
+        HIPCHK(c, hipEventRecord(tk.ev3, s_msg)); HIPCHK(c, hipStreamWaitEvent(s, tk.ev3, 0));
     }
     if (n <= c->coop_max_items) {
         // small batch: one WAVE per item walks the Miller loop and the final exponentiation with its lanes side by side (mbls_coop.h)
@@ -1012,32 +1057,67 @@ static int verify_pipeline_one(mbls_ctx* c, const uint8_t* d_sigs, const uint8_t
         for (int i = 0; i < MBLS_N_PHASES; i++) HIPCHK(c, hipEventElapsedTime(&c->phase_ms[i], c->ev[i], c->ev[i + 1]));
     }
     HIPCHK(c, hipGetLastError());
-    return ws_release(c, s);
+    return tk.ws_sync ? ws_release(c, s) : MBLS_OK;
 }
 // Items [lo, n) of a batch as a batch of their own: uniform layouts advance the base pointers, offset tables are absolute (their slice goes
 // with the unmoved base); lo is a multiple of 64, so the bitmap advances by whole words.
 static int verify_pipeline_from(mbls_ctx* c, uint64_t lo, const uint8_t* d_sigs, const uint8_t* d_msgs, uint32_t msg_len, const uint64_t* d_moff, const keysrc& ks,
-                                uint64_t n, uint32_t k, int mode, uint8_t* d_results, uint64_t* d_bitmap, uint32_t* d_status, hipStream_t s) {
+                                uint64_t n, uint32_t k, int mode, uint8_t* d_results, uint64_t* d_bitmap, uint32_t* d_status, hipStream_t s, const track* tk = nullptr) {
     keysrc t = ks;
     const size_t unit = ks.fmt == MBLS_PK_COMPRESSED ? 48 : 96;
     if (ks.d_off) t.d_off = ks.d_off + lo;
     else { if (ks.d_pks) t.d_pks = ks.d_pks + unit * (uint64_t)k * lo; if (ks.d_idx) t.d_idx = ks.d_idx + (uint64_t)k * lo; }
     return verify_pipeline_one(c, d_sigs + 96 * lo, (d_moff || !d_msgs) ? d_msgs : d_msgs + (uint64_t)msg_len * lo, msg_len, d_moff ? d_moff + lo : nullptr, t,
-                               n - lo, k, mode, d_results + lo, d_bitmap ? d_bitmap + lo / 64 : nullptr, d_status ? d_status + lo : nullptr, s, 0);
+                               n - lo, k, mode, d_results + lo, d_bitmap ? d_bitmap + lo / 64 : nullptr, d_status ? d_status + lo : nullptr, s, 0, tk);
 }
 // The batch as the caller sees it. n = q rounds + r items (0 < r < round): the q rounds run as one launch per kernel, the r items afterwards
 // as a batch of their own, which takes the route of its size (one wave per item up to coop_max_items) -- 1 + T(r) / T(round) rounds
 // instead of 2. (The phase timers describe a single pass: no cut while they are on.)
+// TWO TRACKS (round 5): the last round and a remainder of at least tracks_min_rest items -- R + r items, which would cost a round and then the route of r items
+// (a second, mostly empty round when r is above half a round) -- run as two halves of (R + r) / 2 items SIDE BY SIDE instead, each on its own part of the workspace
+// and its own streams: their kernels are in different phases most of the time, and whichever SIMDs one half leaves idle take waves of the other. Measured with two
+// contexts (scripts/dbg/overlap_probe.py): 73 728 items 40.0 -> 36.2 ms, 100 000 items 51.6 -> 45.9, 98 304 items 42.7 -> 40.5; a remainder below ~6 000 items is
+// better off on the wave engine after the round (69 632 items: 35.3 either way).
 static int verify_pipeline(mbls_ctx* c, const uint8_t* d_sigs, const uint8_t* d_msgs, uint32_t msg_len, const uint64_t* d_moff, const keysrc& ks,
                            uint64_t n, uint32_t k, int mode, uint8_t* d_results, uint64_t* d_bitmap,
                            uint32_t* d_status, hipStream_t s, int part = 0) {
     const uint64_t R = c ? c->round_items : 0;
     if (!c || part != 0 || c->timing || !R || n <= R || n % R == 0)
         return verify_pipeline_one(c, d_sigs, d_msgs, msg_len, d_moff, ks, n, k, mode, d_results, d_bitmap, d_status, s, part);
-    const uint64_t lo = n - n % R;
-    int rc = mbls_ctx_reserve(c, lo); if (rc) return rc;          // one growth, not two
-    rc = verify_pipeline_one(c, d_sigs, d_msgs, msg_len, d_moff, ks, lo, k, mode, d_results, d_bitmap, d_status, s, 0); if (rc) return rc;
-    return verify_pipeline_from(c, lo, d_sigs, d_msgs, msg_len, d_moff, ks, n, k, mode, d_results, d_bitmap, d_status, s);
+    const uint64_t r = n % R;
+    const bool two = c->tracks_min_rest && r >= c->tracks_min_rest && (R + r) / 2 > c->split_max_items && (R + r) / 2 > c->coop_max_items;   // (halves that take one workspace item per item)
+    const uint64_t lo = two ? n - r - R : n - r;                 // the whole rounds in front: one launch per kernel
+    int rc;
+    if (!two) {
+        rc = mbls_ctx_reserve(c, lo); if (rc) return rc;         // one growth, not two
+        rc = verify_pipeline_one(c, d_sigs, d_msgs, msg_len, d_moff, ks, lo, k, mode, d_results, d_bitmap, d_status, s, 0); if (rc) return rc;
+        return verify_pipeline_from(c, lo, d_sigs, d_msgs, msg_len, d_moff, ks, n, k, mode, d_results, d_bitmap, d_status, s);
+    }
+    const uint64_t half = ((R + r) / 2 + WG - 1) / WG * WG, mid = lo + half;           // items [lo, mid) on track 0, [mid, n) on track 1 (cut at a bitmap word)
+    rc = mbls_ctx_reserve(c, lo > 2 * half ? lo : 2 * half); if (rc) return rc;       // (halves above half a round take one lane per item: no doubled workspace)
+    if (!ks.indexed && ks.fmt == MBLS_PK_COMPRESSED && !ks.d_off && k > 1) { rc = reserve_keys(c, (lo > 2 * half ? lo : 2 * half) * (uint64_t)k); if (rc) return rc; }
+    if (lo) { rc = verify_pipeline_one(c, d_sigs, d_msgs, msg_len, d_moff, ks, lo, k, mode, d_results, d_bitmap, d_status, s, 0); if (rc) return rc; }
+    rc = ws_acquire(c, s); if (rc) return rc;
+    HIPCHK(c, hipEventRecord(c->t1_ev, s)); HIPCHK(c, hipStreamWaitEvent(c->t1_s, c->t1_ev, 0));
+    track ta = track0(c); ta.ws_sync = false;
+    // the halves' front phases side by side only while a half is at most 19/32 of a round and no round runs in front (scripts/dbg/tracks_probe.py: r = 6 144 ... 10 240
+    // 36.7 against 37.7 ms; r = 18 432 ... 30 720 in a row 38.0 ... 40.1 against 38.8 ... 42.0; behind a round 64.4 against 67.1 at r = 10 240 ... 20 480)
+    ta.fork_max = (lo == 0 && half <= R / 32 * 19) ? c->fork_max_items : 0;
+    track tb; tb.fork_max = ta.fork_max; tb.ws_off = half; tb.sb = c->t1_b; tb.sc = c->t1_c; tb.sd = c->t1_b; tb.ev2 = c->t1_ev2; tb.ev3 = c->t1_ev3; tb.ws_sync = false;
+    rc = verify_pipeline_from(c, mid, d_sigs, d_msgs, msg_len, d_moff, ks, n, k, mode, d_results, d_bitmap, d_status, c->t1_s, &tb);
+    if (!rc) {
+        keysrc kh = ks;      // items [lo, mid): the same cut with an upper end
+        rc = verify_pipeline_from(c, lo, d_sigs, d_msgs, msg_len, d_moff, kh, mid, k, mode, d_results, d_bitmap, d_status, s, &ta);
+    }
+    // join: the caller's stream ends when both tracks have (also on an error path: nothing of the call stays in flight unordered)
+    hipError_t e1 = hipEventRecord(c->t1_ev, c->t1_s), e2 = hipStreamWaitEvent(s, c->t1_ev, 0);
+    if (rc) return rc;
+    HIPCHK(c, e1); HIPCHK(c, e2);
+    return ws_release(c, s);
+}
+extern "C" int mbls_ctx_set_tracks(mbls_ctx* c, uint64_t min_rest_items) {
+    if (!c) return MBLS_ERR_ARGUMENT;
+    mbls_lock lk(c->mu); c->tracks_min_rest = min_rest_items; return MBLS_OK;
 }
 extern "C" int mbls_fast_aggregate_verify_batch_device(mbls_ctx* c, const uint8_t* d_sigs, const uint8_t* d_msgs, uint32_t msg_len,
         const uint64_t* d_moff, const uint8_t* d_pks, int fmt, const uint32_t* d_off, uint64_t n, uint32_t k, uint8_t* d_results, uint64_t* d_bitmap,
@@ -1407,11 +1487,8 @@ extern "C" int mbls_hash_to_g2_batch_mode(mbls_ctx* c, const uint8_t* msgs, uint
         mbls_ws ws; ws.w = c->d_w; ws.stride = c->cap;
         rc = ws_acquire(c, c->hs_a); if (rc) return rc;
         HIPCHK(c, hipMemsetAsync(c->d_status, 0, 4 * n, c->hs_a));
-        const uint64_t keep_h = c->coop_hash_max_items, keep_p = c->coop_max_items, keep_s = c->split_max_items;
-        if (mode == 1 || mode == 3) c->coop_hash_max_items = 0; else { c->coop_hash_max_items = n; c->coop_max_items = n > keep_p ? n : keep_p; }
-        if (mode == 3 && 2 * n <= c->round_items) c->split_max_items = n;             // mode 3: two lanes per message (k_hash2), whatever the batch size below half a round
-        launch_hash(c, ws, dm.as<uint8_t>(), msg_len, nullptr, c->d_status, n, c->hs_a, mode == 3);
-        c->coop_hash_max_items = keep_h; c->coop_max_items = keep_p; c->split_max_items = keep_s;
+        // the form is named, not routed: mode 1 one lane per item, mode 2 one wave per item (four items per wave above the packing limit), mode 3 two lanes per item
+        launch_hash(c, ws, dm.as<uint8_t>(), msg_len, nullptr, c->d_status, n, c->hs_a, mode == 3, mode == 1 ? HASH_FORM_LANE : mode == 2 ? HASH_FORM_WAVE : HASH_FORM_PAIR);
         hipLaunchKernelGGL(k_h_export, dim3(nblk(n)), dim3(WG), 0, c->hs_a, ws, n, dout.as<uint8_t>());
     }
     HIPCHK(c, hipStreamSynchronize(c->hs_a)); c->ws_pending = false; HIPCHK(c, dout.down(out96, 96 * n)); return MBLS_OK;
@@ -1742,7 +1819,10 @@ extern "C" int mbls_aggregate_verify_batch_device(mbls_ctx* c, const uint8_t* d_
     uint32_t* st_pair = c->d_status + n;                         // (cap >= 2 n + T words)
     uint32_t* map = nullptr;
     sbuf dmap(c, 9);
-    if (d_pair_off) { HIPCHK(c, dmap.alloc(4 * (total ? total : 1))); map = dmap.as<uint32_t>(); }
+    if (d_pair_off) {      // the staging buffer is reused between calls: every entry the map kernel does not write must read as "no owner"
+        HIPCHK(c, dmap.alloc(4 * (total ? total : 1))); map = dmap.as<uint32_t>();
+        HIPCHK(c, hipMemsetAsync(map, 0xFF, 4 * (total ? total : 1), s));
+    }
     HIPCHK(c, hipMemsetAsync(st_item, 0, 4 * n, s));
     if (st_item != c->d_status) HIPCHK(c, hipMemsetAsync(c->d_status, 0, 4 * n, s));
     if (total) HIPCHK(c, hipMemsetAsync(st_pair, 0, 4 * total, s));
@@ -1770,8 +1850,8 @@ extern "C" int mbls_aggregate_verify_batch_device(mbls_ctx* c, const uint8_t* d_
     // per-item product trees over the pairs, then item i <- (sig pair) x (its pairs' product)
     uint64_t kmax = d_pair_off ? total : k;                      // a ragged layout may hold one long range: levels up to the whole list
     for (uint64_t half = 1; half < kmax; half *= 2)
-        hipLaunchKernelGGL(k_f12_seg_tree_d, dim3(nblk(total)), dim3(WG), 0, s, wp, (const uint32_t*)map, d_pair_off, k, total, half);
-    hipLaunchKernelGGL(k_f12_seg_gather, dim3(nblk(n)), dim3(WG), 0, s, ws, d_pair_off, k, n, total, st_item, (const uint32_t*)st_pair);
+        hipLaunchKernelGGL(k_f12_seg_tree_d, dim3(nblk(total)), dim3(WG), 0, s, wp, (const uint32_t*)map, d_pair_off, k, n, total, half);
+    hipLaunchKernelGGL(k_f12_seg_gather, dim3(nblk(n)), dim3(WG), 0, s, ws, d_pair_off, (const uint32_t*)map, k, n, total, st_item, (const uint32_t*)st_pair);
     hipLaunchKernelGGL(k_f12_tree_d, dim3(nblk(n)), dim3(WG), 0, s, ws, 2 * n + total, n + total);
     if (n <= c->split_max_items && 2 * n <= c->round_items) hipLaunchKernelGGL(k_final2, dim3(nblk(2 * n)), dim3(WG), 0, s, ws, st_item, d_results, n);
     else hipLaunchKernelGGL(k_final, dim3(nblk(n)), dim3(WG), 0, s, ws, st_item, d_results, n);
@@ -2106,12 +2186,18 @@ extern "C" int mbls_multi_keytable_append(mbls_multi_keytable* t, const uint8_t*
     std::vector<int> rcs(G, MBLS_OK); std::vector<uint64_t> first(G, 0);
     std::vector<std::vector<uint8_t>> e(G);
     std::vector<std::thread> th;
+    // all or nothing: every replica's size as it is now -- whatever fails below (a worker that could not be started, an append that failed after its records
+    // were already published: the stream synchronisation or the download of errs), ALL replicas go back to it, so that indices stay equal everywhere
+    std::vector<uint64_t> size0(G);
+    for (size_t g = 0; g < G; g++) size0[g] = t->tab[g]->size;
+    auto rollback = [&]() { for (size_t g = 0; g < G; g++) if (t->tab[g]->size > size0[g]) keytable_truncate(t->tab[g], size0[g]); };
     auto work = [&](size_t g) {
         uint8_t* eg = errs;
         if (g) { try { e[g].resize(n ? n : 1); } catch (...) { rcs[g] = MBLS_ERR_DEVICE; return; } eg = e[g].data(); }
         rcs[g] = mbls_keytable_append(t->tab[g], pks, fmt, validate, n, &first[g], eg);
     };
-    try { for (size_t g = 1; g < G; g++) th.emplace_back(work, g); } catch (...) { for (auto& x : th) x.join(); return MBLS_ERR_DEVICE; }
+    try { for (size_t g = 1; g < G; g++) th.emplace_back(work, g); }
+    catch (...) { for (auto& x : th) x.join(); rollback(); snprintf(m->err, sizeof(m->err), "could not start a worker thread"); return MBLS_ERR_DEVICE; }
     work(0);
     for (auto& x : th) x.join();
     int bad = MBLS_OK;
@@ -2119,10 +2205,7 @@ extern "C" int mbls_multi_keytable_append(mbls_multi_keytable* t, const uint8_t*
         if (rcs[g]) { snprintf(m->err, sizeof(m->err), "device %d: %s", m->ctx[g]->device, m->ctx[g]->err); bad = rcs[g]; }
         else if (first[g] != first[0] || (g && n && memcmp(e[g].data(), errs, n) != 0)) { snprintf(m->err, sizeof(m->err), "replicas of the key table disagree (device %d)", m->ctx[g]->device); bad = MBLS_ERR_DEVICE; }
     }
-    if (bad) {      // all or nothing: the replicas that did append drop the new records again (the size is host-side state), so the indices stay the same everywhere
-        for (size_t g = 0; g < G; g++) if (!rcs[g]) keytable_truncate(t->tab[g], first[g]);
-        return bad;
-    }
+    if (bad) { rollback(); return bad; }      // (the size is host-side state: the dropped records are simply overwritten by the next append)
     if (first_index) *first_index = first[0];
     return MBLS_OK;
 }

@@ -65,6 +65,7 @@ extern "C" {
     fn mbls_aggregate_verify(ctx: *mut MblsCtx, sig: *const u8, msgs: *const u8, msg_lens: *const usize, n_msgs: usize, pks96: *const u8, n_pks: usize) -> c_int;
     fn mbls_verify_multiple_aggregate_signatures(ctx: *mut MblsCtx, sigs96: *const u8, apks96: *const u8, msgs: *const u8, msg_len: u32, msg_offsets: *const u64,
                                                  rands: *const u64, n: usize) -> c_int;
+    fn mbls_sig_check_batch(ctx: *mut MblsCtx, in96: *const u8, n: u64, errs: *mut u8, in_g2: *mut u8) -> c_int;
     fn mbls_fast_aggregate_verify_batch(ctx: *mut MblsCtx, sigs: *const u8, msgs: *const u8, msg_len: u32, msg_offsets: *const u64, pks: *const u8, pk_format: c_int,
                                         pk_offsets: *const u32, n: u64, k: u32, results: *mut u8, status: *mut u32) -> c_int;
     fn mbls_aggregate_verify_batch(ctx: *mut MblsCtx, sigs96: *const u8, msgs: *const u8, msg_len: u32, msg_offsets: *const u64, pks96: *const u8,
@@ -463,7 +464,7 @@ impl AggregateSignature {
         let flat: Vec<u8> = signatures.iter().flat_map(|s| s.point.iter().copied()).collect();
         let mut out = [0u8; G2_BYTES];
         let mut e = 0u8;
-        check(unsafe { mbls_aggregate_signatures_batch(ctx(), flat.as_ptr(), std::ptr::null(), 1, signatures.len() as u32, out.as_mut_ptr(), &mut e) })
+        check(unsafe { mbls_aggregate_signatures_batch(ctx(), flat.as_ptr(), std::ptr::null(), 1, u32::try_from(signatures.len()).expect("signature counts are 32-bit"), out.as_mut_ptr(), &mut e) })
             .and_then(|_| check(e as c_int))
             .expect("Signature objects hold decodable points");
         Self { point: out }
@@ -501,15 +502,28 @@ impl AggregateSignature {
         unsafe { mbls_fast_aggregate_verify_pre_aggregated(ctx(), self.point.as_ptr(), msg.as_ptr(), msg.len(), aggregate_public_key.point.as_ptr()) == 1 }
     }
     /// `src/aggregates.rs:261-316`. The blinding scalars are drawn from `rng` exactly as the reference does (8 random bytes,
-    /// big-endian i64, absolute value, retry on zero, `:280-287`); all messages must have the same length (the kernel's layout).
+    /// big-endian i64, absolute value, retry on zero, `:280-287`) -- and in the reference's ORDER: its loop tests set i's signature for
+    /// the subgroup (`:272-275`) before it draws `rand[i]` and returns at the first signature outside G2, so a rejected batch leaves the
+    /// caller's generator where the reference would. One batched subgroup test up front finds that set; scalars are drawn for the sets
+    /// before it only. (The iterator is collected first: the reference stops pulling from it at the rejected set.)
     pub fn verify_multiple_aggregate_signatures<'a, R, I>(rng: &mut R, signature_sets: I) -> bool
     where
         R: Rng + ?Sized,
         I: Iterator<Item = (&'a AggregateSignature, &'a AggregatePublicKey, &'a [u8])>,
     {
-        let (mut sigs, mut apks, mut msgs, mut rands) = (Vec::new(), Vec::new(), Vec::new(), Vec::<u64>::new());
-        let mut moff: Vec<u64> = vec![0]; // messages of any length each (`&[u8]` per set): one buffer + an offset table
-        for (s, a, m) in signature_sets {
+        let sets: Vec<(&AggregateSignature, &AggregatePublicKey, &[u8])> = signature_sets.collect();
+        let n = sets.len();
+        if n == 0 {
+            return true; // e(infinity, -G1) = 1
+        }
+        let sigs: Vec<u8> = sets.iter().flat_map(|s| s.0.point.iter().copied()).collect();
+        let (mut errs, mut in_g2) = (vec![0u8; n], vec![0u8; n]);
+        if unsafe { mbls_sig_check_batch(ctx(), sigs.as_ptr(), n as u64, errs.as_mut_ptr(), in_g2.as_mut_ptr()) } != 0 {
+            return false;
+        }
+        let n_ok = (0..n).find(|&i| errs[i] != 0 || in_g2[i] == 0).unwrap_or(n);
+        let mut rands = Vec::<u64>::with_capacity(n_ok);
+        for _ in 0..n_ok {
             let mut rand = 0u64;
             while rand == 0 {
                 let mut rand_bytes = [0u8; 8];
@@ -517,14 +531,16 @@ impl AggregateSignature {
                 rand = i64::from_be_bytes(rand_bytes).wrapping_abs() as u64;
             }
             rands.push(rand);
-            sigs.extend_from_slice(&s.point);
+        }
+        if n_ok < n {
+            return false; // `:273-275`
+        }
+        let (mut apks, mut msgs) = (Vec::new(), Vec::new());
+        let mut moff: Vec<u64> = vec![0]; // messages of any length each (`&[u8]` per set): one buffer + an offset table
+        for (_, a, m) in &sets {
             apks.extend_from_slice(&a.point);
             msgs.extend_from_slice(m);
             moff.push(msgs.len() as u64);
-        }
-        let n = rands.len();
-        if n == 0 {
-            return true; // e(infinity, -G1) = 1
         }
         unsafe { mbls_verify_multiple_aggregate_signatures(ctx(), sigs.as_ptr(), apks.as_ptr(), msgs.as_ptr(), 0, moff.as_ptr(), rands.as_ptr(), n) == 1 }
     }
@@ -557,7 +573,7 @@ pub mod batch {
             for k in set {
                 pks.extend_from_slice(&k.point);
             }
-            offsets.push((pks.len() / 96) as u32);
+            offsets.push(u32::try_from(pks.len() / 96).expect("key indices are 32-bit"));
         }
         let mut res = vec![0u8; n];
         let rc = unsafe {
@@ -588,7 +604,7 @@ pub mod batch {
                     pks.extend_from_slice(&k.point);
                 }
             }
-            pair_off.push((pks.len() / 96) as u32);
+            pair_off.push(u32::try_from(pks.len() / 96).expect("pair indices are 32-bit"));
         }
         let mut res = vec![0u8; n];
         let rc = unsafe {
@@ -651,7 +667,7 @@ impl MultiGpu {
             for k in set {
                 pks.extend_from_slice(&k.point);
             }
-            offsets.push((pks.len() / 96) as u32);
+            offsets.push(u32::try_from(pks.len() / 96).expect("key indices are 32-bit"));
         }
         let mut res = vec![0u8; n];
         let rc = unsafe {

@@ -25,7 +25,13 @@ for name, f in (("FETCH_SIZE", fetch + "/f_counter_collection.csv"), ("WRITE_SIZ
         if k.startswith("k_"):
             agg[k].append(float(r["Counter_Value"]))
     out["raw"][name] = {k: sum(v) / len(v) for k, v in agg.items()}
-tr = {"_collected": "round %s, scripts/profile_round.sh + scripts/collect_profiles.py" % tag}
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from milagro_bls_amd import build as _build
+# the build the counters belong to: scripts/profile_round.sh writes the hash of the library it ran next to its outputs (source_hash.txt); bench.py attaches the
+# figures to roofline.traffic only for that build
+_hf = os.path.join(os.path.dirname(stats.rstrip("/")), "source_hash.txt")
+tr = {"_collected": "round %s, scripts/profile_round.sh + scripts/collect_profiles.py" % tag,
+      "_source_hash": open(_hf).read().strip() if os.path.exists(_hf) else _build.source_hash()}
 for k in ("k_aggregate_raw_d", "k_sig", "k_hash", "k_miller", "k_final"):
     if k not in out["raw"]["FETCH_SIZE"]:
         continue

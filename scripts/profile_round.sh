@@ -8,6 +8,7 @@ ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
+cp milagro_bls_amd/libmbls_hip.so.srchash $OUT/source_hash.txt      # the build every counter below belongs to
 B="python3 $ROOT/bench.py --no-cpu-baseline --no-variants"
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o $TAG -- $B --steps 5 --warmup 1 > $OUT/stats_bench.json 2> $OUT/stats.err
@@ -25,6 +26,7 @@ python3 scripts/latency.py $OUT/latency.json > $OUT/latency.log 2>&1
 python3 scripts/time_keyops.py > $OUT/keyops.log 2>&1; cp gpurun_out/keyops.json $OUT/keyops.json
 bash scripts/kstats.sh > $OUT/kstats.txt 2>&1
 python3 scripts/throughput_vs_n.py $TAG > $OUT/sweep.log 2>&1; cp gpurun_out/${TAG}_throughput_vs_n.json $OUT/throughput_vs_n.json
-[ -x scripts/dbg/icbench ] && ./scripts/dbg/icbench > $OUT/icache_footprint.txt 2>&1
+# the instruction-cache probe is built from its source on the box (no binary in the repository)
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o /tmp/icbench scripts/dbg/icbench.hip > $OUT/icbench_build.log 2>&1 && /tmp/icbench > $OUT/icache_footprint.txt 2>&1
 find $OUT -name "*.csv" -size +20M -delete
 ls -la $OUT $OUT/stats $OUT/fetch 2>/dev/null | head -40

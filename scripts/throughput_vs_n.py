@@ -11,8 +11,8 @@ ctx = N.default_context(); lib = N.lib(); dev = torch.device("cuda:0")
 tag = sys.argv[1] if len(sys.argv) > 1 else "dev"
 nbase, k = 1 << 16, 128
 d_sigs, d_msgs, d_pks, expect = bench.build_inputs(ctx, dev, nbase, k, N.PK_UNCOMPRESSED, rank=21)
-sizes = [1024, 2048, 4096, 8192, 10240, 12288, 16384, 24576, 32768, 49152, 65536, 65537, 65600, 66560, 67584, 69632, 73728, 75776, 76000, 81920, 98304,
-         100000, 131072, 135168, 196608, 200000, 262144]
+sizes = [1024, 2048, 4096, 8192, 10240, 12288, 16384, 24576, 32768, 40960, 49152, 57344, 65536, 65537, 65600, 66560, 67584, 69632, 71680, 73728, 75776, 76000, 81920, 90112,
+         98304, 100000, 114688, 131072, 135168, 150000, 163840, 196608, 200000, 262144]
 nmax = max(sizes)
 reps = -(-nmax // nbase)
 # items are independent: larger batches are the 2^16 items repeated

@@ -78,6 +78,15 @@ int main() {
       AggregateSignature wrong; wrong.add(Signature::new_(Bytes(32, 1), kps[3].sk)); std::get<0>(sets[1]) = &wrong;
       CHECK(!AggregateSignature::verify_multiple_aggregate_signatures(rng, sets));
       CHECK(!AggregateSignature::verify_multiple_aggregate_signatures(m2, rng, sets));
+      // src/aggregates.rs:272-287: scalars are drawn in the reference's order -- set i's subgroup test comes before rand[i], the first signature outside G2 ends the
+      // loop: with such a signature (tests/golden/vectors.json, model.g2_subgroup_probes[0]: on the curve, not in G2) at position 1 exactly 8 bytes are consumed
+      AggregateSignature outside = AggregateSignature::from_bytes(hex("b45fa214ab17cf53c091f28b93366978b5bc9e5251694f40655cede2738b21a47dcee1c2a45074b93ed0f03b5257eba201d88a9447cba04689cc1c5677a33b102be41a5a1d59ad97b755f61ee540409b4df949219cbbec5e826e63c151cf2a8a"));
+      int drawn = 0; auto counting = [&] { drawn++; return uint8_t(gen()); };
+      std::get<0>(sets[1]) = &sigs[1];
+      CHECK(AggregateSignature::verify_multiple_aggregate_signatures(counting, sets) && drawn == 24);
+      std::get<0>(sets[1]) = &outside; drawn = 0;
+      CHECK(!AggregateSignature::verify_multiple_aggregate_signatures(counting, sets) && drawn == 8);
+      drawn = 0; CHECK(!AggregateSignature::verify_multiple_aggregate_signatures(m2, counting, sets) && drawn == 8);
       mbls_multi_destroy(m2); }
     // src/aggregates.rs:100-106 AggregateSignature::aggregate (one batched launch) == repeated add; src/keys.rs:36-77 key generation
     { std::vector<Signature> ss; std::vector<const Signature*> ps; for (auto& kp : kps) ss.push_back(Signature::new_(msg, kp.sk)); for (auto& x : ss) ps.push_back(&x);

@@ -84,14 +84,24 @@ def lds_get(m, base, slot):
 
 
 def test_generated_files_up_to_date():
+    """the imported generator module (the one the tests below simulate) emits exactly the tracked file -- into a temporary directory, never in place"""
     import io
     import contextlib
+    import tempfile
     for mod, name in ((g, "mbls_fp_asm.inc"),):
         path = os.path.join(ROOT, "milagro_bls_amd", "csrc", name)
-        before = open(path).read()
-        with contextlib.redirect_stdout(io.StringIO()):
-            mod.main()
-        assert open(path).read() == before, name + " is stale: run tools/" + mod.__name__ + ".py"
+        with tempfile.TemporaryDirectory() as d:
+            old = os.environ.get("MBLS_GEN_OUT_DIR")
+            os.environ["MBLS_GEN_OUT_DIR"] = d
+            try:
+                with contextlib.redirect_stdout(io.StringIO()):
+                    mod.main()
+            finally:
+                if old is None:
+                    os.environ.pop("MBLS_GEN_OUT_DIR")
+                else:
+                    os.environ["MBLS_GEN_OUT_DIR"] = old
+            assert open(os.path.join(d, name)).read() == open(path).read(), name + " is stale: run tools/" + mod.__name__ + ".py"
 
 
 @pytest.mark.parametrize("which", ["pm3d4", "pm2"])

@@ -45,10 +45,12 @@ def test_library_exports_every_declared_symbol(lib_path):
 
 
 def test_generated_asm_is_up_to_date():
+    """the generator's output, written to a temporary directory (never over the tracked file), equals what the build compiles"""
     inc = os.path.join(helpers.ROOT, "milagro_bls_amd", "csrc", "mbls_fp_asm.inc")
-    before = open(inc).read()
-    subprocess.check_call([__import__("sys").executable, os.path.join(helpers.ROOT, "tools", "gen_fp_asm.py")], stdout=subprocess.DEVNULL)
-    assert open(inc).read() == before
+    with tempfile.TemporaryDirectory() as d:
+        subprocess.check_call([__import__("sys").executable, os.path.join(helpers.ROOT, "tools", "gen_fp_asm.py")], stdout=subprocess.DEVNULL,
+                              env=dict(os.environ, MBLS_GEN_OUT_DIR=d))
+        assert open(os.path.join(d, "mbls_fp_asm.inc")).read() == open(inc).read(), "mbls_fp_asm.inc is stale: run tools/gen_fp_asm.py"
 
 
 def test_no_oracle_in_product(lib_path):
@@ -139,3 +141,109 @@ def test_builds_without_the_generated_routines_are_refused(flag):
     # and nothing in the kernels file still branches on those switches
     txt = open(src).read().split("#endif", 1)[1]
     assert flag not in txt
+
+
+# ---- the Rust facade (never compiled here: no toolchain) and the binding INTEGRATION.md shows must stay in lock-step with include/mbls.h
+_C2CANON = {"uint8_t": "u8", "uint32_t": "u32", "uint64_t": "u64", "size_t": "usize", "int": "c_int", "char": "c_char", "void": "c_void",
+            "mbls_ctx": "MblsCtx", "mbls_keytable": "MblsKeyTable", "mbls_multi": "MblsMulti", "mbls_multi_keytable": "MblsMultiKeyTable"}
+
+
+def _split_params(txt):
+    out, depth, cur = [], 0, ""
+    for ch in txt:
+        if ch in "([":
+            depth += 1
+        elif ch in ")]":
+            depth -= 1
+        if ch == "," and depth == 0:
+            out.append(cur.strip()); cur = ""
+        else:
+            cur += ch
+    if cur.strip():
+        out.append(cur.strip())
+    return out
+
+
+def _canon_c(param):
+    """'const uint8_t* d_sigs' / 'uint8_t pk_out[96]' / 'mbls_ctx** out' -> ('const'|'mut', base, pointer depth) with arrays as pointers"""
+    p = param.strip()
+    arr = "[" in p
+    p = re.sub(r"\[[^\]]*\]", "", p)
+    const = bool(re.search(r"\bconst\b", p))
+    p = re.sub(r"\bconst\b|\bstruct\b", " ", p)
+    depth = p.count("*") + (1 if arr else 0)
+    toks = p.replace("*", " ").split()
+    base = toks[0]
+    return ("const" if const and depth else "mut" if depth else "val", _C2CANON.get(base, base), depth)
+
+
+def _canon_rust(ty):
+    t = ty.strip()
+    depth, kind = 0, "val"
+    first = True
+    while t.startswith("*"):
+        m = re.match(r"\*(const|mut)\s+", t)
+        if first:
+            kind = m.group(1); first = False
+        depth += 1; t = t[m.end():]
+    return (kind if depth else "val", t, depth)
+
+
+def _c_prototypes():
+    txt = re.sub(r"/\*.*?\*/", "", open(HDR).read(), flags=re.S)
+    txt = re.sub(r"//[^\n]*", "", txt)
+    protos = {}
+    for m in re.finditer(r"([A-Za-z_][\w\s\*]*?)\b(mbls_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", txt):
+        params = [] if m.group(3).strip() in ("", "void") else _split_params(m.group(3))
+        protos[m.group(2)] = [_canon_c(p) for p in params]
+    return protos
+
+
+def _rust_decls(path):
+    txt = open(path).read()
+    decls = {}
+    for m in re.finditer(r"\bfn\s+(mbls_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*(?:->\s*[^;{]+)?;", txt, flags=re.S):
+        params = _split_params(" ".join(m.group(2).split()))
+        decls.setdefault(m.group(1), []).append([_canon_rust(p.split(":", 1)[1]) for p in params])
+    return decls
+
+
+@pytest.mark.parametrize("src", ["rust/src/lib.rs", "INTEGRATION.md"])
+def test_rust_bindings_match_the_header(src):
+    """every `fn mbls_*` the Rust side declares exists in include/mbls.h with the same parameter list (count, pointer depth, constness, base type;
+    `void* stream` = `*mut c_void`); the crate has never met rustc in this image, so this is what keeps it from drifting"""
+    protos = _c_prototypes()
+    decls = _rust_decls(os.path.join(helpers.ROOT, src))
+    assert len(decls) >= 10, "no declarations found in " + src
+    for name, variants in decls.items():
+        assert name in protos, "%s declares %s, which include/mbls.h does not" % (src, name)
+        for got in variants:
+            want = protos[name]
+            assert len(got) == len(want), "%s: %s has %d parameters, the header %d" % (src, name, len(got), len(want))
+            for j, (g, w) in enumerate(zip(got, want)):
+                # a pointer the C side does not write through may be *const or *mut on the Rust side only if the header says so: compare exactly
+                assert g == w, "%s: %s parameter %d is %s, the header says %s" % (src, name, j, g, w)
+
+
+def test_every_c_call_in_integration_md_has_the_header_arity():
+    """the C snippets of INTEGRATION.md call the entries with as many arguments as the header declares"""
+    protos = _c_prototypes()
+    txt = open(os.path.join(helpers.ROOT, "INTEGRATION.md")).read()
+    seen = 0
+    for m in re.finditer(r"\b(mbls_[a-z0-9_]+)\s*\(", txt):
+        name = m.group(1)
+        if name not in protos:
+            continue
+        # the argument text up to the matching parenthesis
+        i, depth = m.end(), 1
+        while i < len(txt) and depth:
+            depth += txt[i] == "("; depth -= txt[i] == ")"; i += 1
+        args = re.sub(r"/\*.*?\*/", "", txt[m.end():i - 1], flags=re.S)
+        if re.search(r":\s*\*", args) or "->" in txt[i:i + 12]:
+            continue                                   # a Rust declaration (checked above), not a call
+        if "..." in args:
+            continue
+        seen += 1
+        assert len(_split_params(args)) == len(protos[name]), "INTEGRATION.md calls %s with %d arguments, the header declares %d" % (
+            name, len(_split_params(args)), len(protos[name]))
+    assert seen >= 10

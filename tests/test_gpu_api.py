@@ -235,6 +235,43 @@ def test_verify_multiple_signatures(api, vectors):
     assert api.AggregateSignature.verify_multiple_aggregate_signatures(rnd, sets) is False
 
 
+class _CountingRng:
+    """random.Random that counts the bytes drawn through getrandbits(8) (what the mirror's scalar loop uses)"""
+
+    def __init__(self, seed, zero_first=0):
+        self.r = random.Random(seed); self.n = 0; self.zero_first = zero_first
+
+    def getrandbits(self, k):
+        assert k == 8
+        self.n += 1
+        if self.zero_first:                      # the first draws come out as the all-zero scalar: retried (src/aggregates.rs:281)
+            self.zero_first -= 1
+            return 0
+        return self.r.getrandbits(8)
+
+
+def test_verify_multiple_draws_scalars_in_the_reference_order(api, vectors):
+    """src/aggregates.rs:272-287: the reference tests set i's signature for the subgroup BEFORE it draws rand[i] and returns at the first
+    signature outside G2 -- a rejected batch of 5 sets with the bad signature at position 2 has consumed exactly 2 x 8 random bytes; an accepted
+    or pairing-rejected batch 8 bytes per set; a zero draw is retried (8 more bytes)."""
+    rnd = random.Random(31)
+    sets = _sets(api, rnd, 5, 2)
+    rng = _CountingRng(1)
+    assert api.AggregateSignature.verify_multiple_aggregate_signatures(rng, sets) is True and rng.n == 5 * 8
+    rng = _CountingRng(2, zero_first=8)
+    assert api.AggregateSignature.verify_multiple_aggregate_signatures(rng, sets) is True and rng.n == 6 * 8
+    bad = list(sets)
+    bad[2] = (api.AggregateSignature.from_bytes(bytes.fromhex(vectors["model"]["g2_subgroup_probes"][0]["compressed"])), sets[2][1], sets[2][2])
+    rng = _CountingRng(3)
+    assert api.AggregateSignature.verify_multiple_aggregate_signatures(rng, bad) is False and rng.n == 2 * 8
+    bad[0] = bad[2]
+    rng = _CountingRng(4)
+    assert api.AggregateSignature.verify_multiple_aggregate_signatures(rng, bad) is False and rng.n == 0
+    wrong = list(sets); wrong[4] = (sets[3][0], sets[4][1], sets[4][2])          # in G2, wrong signature: rejected by the pairing check, every scalar drawn
+    rng = _CountingRng(5)
+    assert api.AggregateSignature.verify_multiple_aggregate_signatures(rng, wrong) is False and rng.n == 5 * 8
+
+
 @pytest.mark.usefixtures("engine")
 def test_aggregate_verify(api, vectors):
     # src/aggregates.rs:808-929

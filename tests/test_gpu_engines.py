@@ -5,7 +5,8 @@ invariant. One seeded batch of 20 480 items x 2 keys is signed and verified by t
 Routing (milagro_bls_amd/csrc/mbls_kernels.hip, verify_pipeline / launch_hash): n <= 768 hashg2 + pairing2, (768, 1024] hashg2x4 + pairing2,
 (1024, 2048] hashg2x4 + pairing2x2, (2048, 3584] hashg2x4 + pairing2, (3584, 5120] k_hash2 (two lanes per message) + pairing2, (5120, 16384] k_hash2 (two lanes per message) + k_miller_split4 (four lanes per item: two per pair, products in pairs) + product + k_sig_verdict +
 k_final2 (two lanes per item: the compressed squarings split, the other products in pairs), (16384, 20480] k_hash2 + k_miller_split (two lanes per item) + k_final2, (20480, 32768] k_hash + k_miller_split + k_final2, above 32768 k_hash + k_miller (two-pair loop) + k_sig_verdict + k_final; in both lane forms the signature's subgroup test is read off the
-Miller loop's running point. Above a round (65 536 items) the remainder is routed as a batch of its own."""
+Miller loop's running point. Above a round (65 536 items) the remainder is routed as a batch of its own -- or, from 6 144 items up, the last round and the remainder run as two halves
+side by side on two tracks (device entries)."""
 import random
 
 import pytest
@@ -155,6 +156,87 @@ def test_round_cut_with_small_rounds_every_layout(mb, big):
         bits = [(int(w) >> b) & 1 for w in d_bm.cpu().tolist() for b in range(64)][:n]
         assert bits == [int(x) for x in got]
         tab.close()
+    finally:
+        ctx.reset_tuning()
+
+
+def _device_call(N, ctx, dev, s, m, p, n, k, *, koff=None, moff=None, table=None, idx=None, fmt=1):
+    """mbls_fast_aggregate_verify_batch[_indexed]_device with a bitmap and the caller's status array -> (results, status, bitmap bits)"""
+    import torch
+    t = lambda b, dt=torch.uint8: torch.frombuffer(bytearray(b), dtype=dt).to(dev)
+    d_s, d_m = t(s), t(m)
+    d_res = torch.full((n,), 9, dtype=torch.uint8, device=dev); d_bm = torch.zeros((n + 63) // 64, dtype=torch.int64, device=dev)
+    d_st = torch.full((n,), 0x7fffffff, dtype=torch.int32, device=dev)
+    d_ko = torch.tensor(koff, dtype=torch.int32, device=dev) if koff is not None else None
+    d_mo = torch.tensor(moff, dtype=torch.int64, device=dev) if moff is not None else None
+    ptr = lambda x: x.data_ptr() if x is not None else None
+    if table is not None:
+        d_i = torch.tensor(idx, dtype=torch.int32, device=dev)
+        ctx.check(N.lib().mbls_fast_aggregate_verify_batch_indexed_device(ctx.handle, table.handle, d_s.data_ptr(), d_m.data_ptr(), 32, ptr(d_mo), d_i.data_ptr(), ptr(d_ko),
+                                                                          n, 0 if koff is not None else k, d_res.data_ptr(), d_bm.data_ptr(), d_st.data_ptr(), None))
+    else:
+        d_p = t(p)
+        ctx.check(N.lib().mbls_fast_aggregate_verify_batch_device(ctx.handle, d_s.data_ptr(), d_m.data_ptr(), 32, ptr(d_mo), d_p.data_ptr(), fmt, ptr(d_ko),
+                                                                  n, 0 if koff is not None else k, d_res.data_ptr(), d_bm.data_ptr(), d_st.data_ptr(), None))
+    torch.cuda.synchronize()
+    got = [bool(x) for x in d_res.cpu().tolist()]
+    bits = [(int(w) >> b) & 1 for w in d_bm.cpu().tolist() for b in range(64)][:n]
+    return got, [x & 0xffffffff for x in d_st.cpu().tolist()], bits
+
+
+def test_two_tracks_above_a_round_vs_oracle(mb, big):
+    """n = q rounds + r with r >= mbls_ctx_set_tracks' limit (default 6 144): the last round and the remainder run as two halves SIDE BY SIDE, each on its own part
+    of the workspace and its own streams (verify_pipeline). The oracle-checked items, tiled (items are independent, src/aggregates.rs:177-215): 73 728 and 100 000
+    items (two halves), 150 000 (a whole round in front of the halves), and 70 000 with the limit lowered (remainder 4 464) -- results, status words and bitmap
+    words of every item, through the device entry."""
+    import torch
+    from milagro_bls_amd import _native as N
+    ctx = N.default_context(); dev = torch.device("cuda:0")
+    try:
+        for n, lim in ((73728, None), (100000, None), (150000, None), (70000, 4000)):
+            if lim:
+                ctx.set_tracks(lim)
+            s, m, p = prefix(big, n)
+            got, st, bits = _device_call(N, ctx, dev, s, m, p, n, big.k)
+            check(big, got, st, n)
+            assert bits == [int(x) for x in got]
+            ctx.set_tracks(0)                        # the same batch as rounds + remainder: identical status words
+            got0, st0, _ = _device_call(N, ctx, dev, s, m, p, n, big.k)
+            assert (got0, st0) == (got, st)
+            ctx.reset_tuning()
+    finally:
+        ctx.reset_tuning()
+
+
+def test_two_tracks_with_small_rounds_every_layout(mb, big):
+    """the two-track cut on small numbers (rounds of 128 items, limit 1, one lane per item): n = 300 = one round in front + halves of 128 and 44 items; n = 200 =
+    halves of 128 and 72 -- uniform keys, ragged keys + ragged messages through offset tables that do not start at 0, table indices, and 48-byte keys (the staged
+    decompression buffer is cut like the workspace) -- against the oracle."""
+    import torch
+    from milagro_bls_amd import _native as N
+    ctx = N.default_context(); dev = torch.device("cuda:0")
+    try:
+        for n in (300, 200):
+            ctx.reset_tuning(); ctx.set_round_items(128); ctx.set_coop_max_items(0); ctx.set_coop_hash_max_items(0); ctx.set_tracks(1)
+            s, m, p = prefix(big, n)
+            got, st, bits = _device_call(N, ctx, dev, s, m, p, n, big.k)
+            check(big, got, st, n); assert bits == [int(x) for x in got]
+            koff = [5 + 2 * i for i in range(n + 1)]
+            moff = [7 + 32 * i for i in range(n + 1)]
+            got, st, bits = _device_call(N, ctx, dev, s, bytes(7) + m, bytes(96 * 5) + p, n, big.k, koff=koff, moff=moff)
+            check(big, got, st, n); assert bits == [int(x) for x in got]
+            tab = N.KeyTable(ctx, capacity_hint=2 * n)
+            first, errs = tab.append(p, 2 * n, pk_format=1, validate=False)
+            assert first == 0
+            got, st, bits = _device_call(N, ctx, dev, s, m, None, n, 2, table=tab, idx=list(range(2 * n)))
+            check(big, got, st, n); assert bits == [int(x) for x in got]
+            tab.close()
+        # 48-byte keys: a batch of its own (the big fixture holds 96-byte keys)
+        b = helpers.make_batch(300, 3, fmt=0, seed=77, nthreads=8)
+        want = orc.batch_fast_aggregate_verify(b.sigs, b.msgs, b.pks, b.n, b.k, 0, nthreads=8)
+        assert want == b.expect
+        got, st, bits = _device_call(N, ctx, dev, b.sigs, b.msgs, b.pks, b.n, b.k, fmt=0)
+        assert got == want and bits == [int(x) for x in got]
     finally:
         ctx.reset_tuning()
 

@@ -1396,7 +1396,8 @@ def build_all():
 
 def main():
     here = os.path.dirname(os.path.abspath(__file__))
-    path = os.path.join(os.path.dirname(here), "milagro_bls_amd", "csrc", "mbls_coop_prog.inc")
+    # MBLS_GEN_OUT_DIR: write there instead of over the tracked file (the freshness tests generate into a temporary directory and compare)
+    path = os.path.join(os.environ.get("MBLS_GEN_OUT_DIR") or os.path.join(os.path.dirname(here), "milagro_bls_amd", "csrc"), "mbls_coop_prog.inc")
     txt = "// GENERATED by tools/gen_coop.py -- do not edit. Microprograms of the wave-cooperative engine (mbls_coop.h).\n"
     mx = 0
     for name, comp in build_all().items():

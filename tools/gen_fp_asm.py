@@ -593,7 +593,8 @@ def emit(name, lines):
 
 def main():
     here = os.path.dirname(os.path.abspath(__file__))
-    path = os.path.join(os.path.dirname(here), "milagro_bls_amd", "csrc", "mbls_fp_asm.inc")
+    # MBLS_GEN_OUT_DIR: write there instead of over the tracked file (the freshness tests generate into a temporary directory and compare)
+    path = os.path.join(os.environ.get("MBLS_GEN_OUT_DIR") or os.path.join(os.path.dirname(here), "milagro_bls_amd", "csrc"), "mbls_fp_asm.inc")
     txt = "// GENERATED by tools/gen_fp_asm.py -- do not edit.\n// gfx950 Montgomery multiplication, one asm statement, registers per the AMDGPU calling convention.\n"
     txt += emit("MBLS_FP_MUL_ASM", fp_mul_body()) + "\n"
     txt += '#define MBLS_FP_MUL_CLOBBERS "v24","v25","v26","v27","v28","v29","v30","v31","v32","v33","v34","v35","v36","v37","v38","v39", \\\n'

@@ -195,7 +195,8 @@ def column_ok(products):
 
 def main():
     here = os.path.dirname(os.path.abspath(__file__))
-    path = os.path.join(os.path.dirname(here), "milagro_bls_amd", "csrc", "mbls_fpd_asm.inc")
+    # MBLS_GEN_OUT_DIR: write there instead of over the tracked file (the freshness tests generate into a temporary directory and compare)
+    path = os.path.join(os.environ.get("MBLS_GEN_OUT_DIR") or os.path.join(os.path.dirname(here), "milagro_bls_amd", "csrc"), "mbls_fpd_asm.inc")
     txt = "// GENERATED by tools/gen_fpd_asm.py -- do not edit.\n// gfx950 Fp2 multiplication routines on 14 signed 28-bit digits (D-form), private calling convention.\n"
     for sym, fn in ROUTINE_BODIES.items():
         body = fn()

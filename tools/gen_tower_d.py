@@ -3074,7 +3074,8 @@ def g2_blind_routine():
 
 def main():
     here = os.path.dirname(os.path.abspath(__file__))
-    path = os.path.join(os.path.dirname(here), "milagro_bls_amd", "csrc", "mbls_towerd_asm.inc")
+    # MBLS_GEN_OUT_DIR: write there instead of over the tracked file (the freshness tests generate into a temporary directory and compare)
+    path = os.path.join(os.environ.get("MBLS_GEN_OUT_DIR") or os.path.join(os.path.dirname(here), "milagro_bls_amd", "csrc"), "mbls_towerd_asm.inc")
     txt = "// GENERATED by tools/gen_tower_d.py -- do not edit.\n"
     body, stats = build_cyc_sqr_d()
     print("cyc_sqr_d", len(body), "lines", stats)
