@@ -429,6 +429,37 @@ def other_configs(ctx, lib, dev, sptr):
     return out
 
 
+def criterion_shapes():
+    """The reference's own criterion points for the path, through the API mirror (host objects in, bool out: PCIe and synchronisation included, like a caller of
+    the drop-in sees them): `Verify a Signature` (benches/bls381_benches.rs:104-112) and `multiple-signatures-verification-30` (:179-245: n = 10 aggregate
+    signatures x m = 3 keys through verify_multiple_aggregate_signatures with a fresh rng per iteration), beside the same 10 sets verified one by one."""
+    import random
+    import milagro_bls_amd as m
+    rnd = random.Random(20)
+    sk = m.SecretKey.from_bytes(rnd.randrange(1, R).to_bytes(32, "big")); pk = m.PublicKey.from_secret_key(sk)
+    msg = b"Some msg"; sig = m.Signature.new(msg, sk)                  # benches/bls381_benches.rs:86-90
+    out = {"_unit": "ms per call, median of 5 after 2 warm-ups, host objects in / bool out (PCIe + synchronisation included)"}
+    ok = sig.verify(msg, pk)
+    out["Signature::verify (one signature)"] = _med_ms(lambda: sig.verify(msg, pk))
+    n, mk = 10, 3
+    sets = []
+    for i in range(n):
+        agg = m.AggregateSignature.new(); pks = []
+        mi = bytes([i]) * 32
+        for _ in range(mk):
+            s1 = m.SecretKey.from_bytes(rnd.randrange(1, R).to_bytes(32, "big"))
+            agg.add(m.Signature.new(mi, s1)); pks.append(m.PublicKey.from_secret_key(s1))
+        sets.append((agg, m.AggregatePublicKey.into_aggregate(pks), mi))
+    ok = ok and m.AggregateSignature.verify_multiple_aggregate_signatures(random.Random(1), sets)
+    out["verify_multiple_aggregate_signatures (10 sets x 3 keys)"] = _med_ms(lambda: m.AggregateSignature.verify_multiple_aggregate_signatures(random.Random(1), sets))
+    ok = ok and all(a.fast_aggregate_verify_pre_aggregated(mm, apk) for a, apk, mm in sets)
+    out["the same 10 sets one by one (fast_aggregate_verify_pre_aggregated)"] = _med_ms(lambda: [a.fast_aggregate_verify_pre_aggregated(mm, apk) for a, apk, mm in sets])
+    bad = list(sets); bad[4] = (sets[3][0], sets[4][1], sets[4][2])
+    ok = ok and not m.AggregateSignature.verify_multiple_aggregate_signatures(random.Random(1), bad)
+    out["correct"] = bool(ok)
+    return out
+
+
 def aggregate_verify_leg(ctx, lib, dev, sptr, n=1 << 14, kp=4):
     """n x AggregateSignature::aggregate_verify in one call (reference src/aggregates.rs:130-170; SURVEY section 8 (f)1): n items of kp (message, key)
     pairs each, distinct 32-byte messages, signatures aggregated on the device. All valid, then one message flipped: only that item fails."""
@@ -876,6 +907,7 @@ def main():
         other = other_configs(ctx, lib, dev, sptr)
         other["aggregate_verify_batch 2^14 items x 4 (message, key) pairs"] = aggregate_verify_leg(ctx, lib, dev, sptr)
         other["operations either side of the path (2^16 each)"] = keyops_figures(ctx, lib, dev)
+        other["the reference's criterion shapes (benches/bls381_benches.rs:104-112, 179-245)"] = criterion_shapes()
         ok = ok and all(v.get("correct", True) for v in other.values() if isinstance(v, dict))
         ok = ok and all(v.get("correct", True) for v in other["operations either side of the path (2^16 each)"].values() if isinstance(v, dict))
         # the in-process multi-GPU entry over 1, 2, 4, 8 of the visible devices (one process, host buffers: PCIe included)

@@ -34,6 +34,9 @@ def test_sign_and_sk_to_pk(emul, vectors):
     e = vectors["external"]["eth2_sign"]
     o = ob(96); emul.emul_sign(cb(bytes.fromhex(e["sk"])), cb(bytes.fromhex(e["msg"])), 32, C.c_uint64(1), o)
     assert bytes(o).hex() == e["sig"]
+    for e in vectors["external"]["eth2_sign_cases"]:
+        o = ob(96); emul.emul_sign(cb(bytes.fromhex(e["sk"])), cb(bytes.fromhex(e["msg"])), 32, C.c_uint64(1), o)
+        assert bytes(o).hex() == e["sig"]
     for kp in vectors["external"]["eth2_sk_to_pk"]:
         o = ob(48); emul.emul_sk_to_pk(cb(bytes.fromhex(kp["sk"])), 0, C.c_uint64(1), o)
         assert bytes(o).hex() == kp["pk"]

@@ -235,6 +235,53 @@ def test_verify_multiple_signatures(api, vectors):
     assert api.AggregateSignature.verify_multiple_aggregate_signatures(rnd, sets) is False
 
 
+@pytest.mark.usefixtures("engine")
+def test_external_eth2_spec_cases_on_the_gpu(api, vectors):
+    """round 5: the published Eth2 BLS cases (sign, verify, aggregate, fast_aggregate_verify, aggregate_verify on the three standard keys; tests/golden/vectors.json
+    "external", each string reproduced by the big-integer model) through the API mirror on the GPU, on every engine"""
+    ext = vectors["external"]
+    sks = [api.SecretKey.from_bytes(bytes.fromhex(kp["sk"])) for kp in ext["eth2_sk_to_pk"]]
+    pks = [api.PublicKey.from_secret_key(sk) for sk in sks]
+    assert [pk.as_bytes().hex() for pk in pks] == [kp["pk"] for kp in ext["eth2_sk_to_pk"]]
+    by_hex = {kp["sk"]: i for i, kp in enumerate(ext["eth2_sk_to_pk"])}
+    tampered = lambda h: bytes.fromhex(h)[:-4] + b"\xff" * 4
+
+    def decode(cls, b):
+        try:
+            return cls.from_bytes(b)
+        except api.AmclError:
+            return None
+    sig_ab = []
+    for e in ext["eth2_sign_cases"] + [ext["eth2_sign"]]:
+        i, msg = by_hex[e["sk"]], bytes.fromhex(e["msg"])
+        sig = api.Signature.new(msg, sks[i])
+        assert sig.as_bytes().hex() == e["sig"]
+        assert sig.verify(msg, pks[i]) is True and sig.verify(msg, pks[(i + 1) % 3]) is False
+        bad = decode(api.Signature, tampered(e["sig"]))
+        assert bad is None or bad.verify(msg, pks[i]) is False
+        if e["msg"] == "ab" * 32:
+            sig_ab.append((i, sig))
+    for e in ext["eth2_fast_aggregate_verify"]:
+        k, msg = e["n_keys"], bytes.fromhex(e["msg"])
+        agg = api.AggregateSignature.from_bytes(bytes.fromhex(e["sig"]))
+        assert agg.fast_aggregate_verify(msg, pks[:k]) is True
+        if k < 3:
+            assert agg.fast_aggregate_verify(msg, pks[:k + 1]) is False
+        bad = decode(api.AggregateSignature, tampered(e["sig"]))
+        assert bad is None or bad.fast_aggregate_verify(msg, pks[:k]) is False
+    assert api.AggregateSignature.new().fast_aggregate_verify(bytes.fromhex("ab" * 32), []) is False
+    agg = api.AggregateSignature.new()
+    for _, sg in sorted(sig_ab, key=lambda t: t[0]):
+        agg.add(sg)
+    assert agg.as_bytes().hex() == ext["eth2_fast_aggregate_verify"][2]["sig"]                    # aggregate_0xabab...
+    av = ext["eth2_aggregate_verify"]
+    msgs = [bytes.fromhex(m) for m in av["msgs"]]
+    assert api.AggregateSignature.from_bytes(bytes.fromhex(av["sig"])).aggregate_verify(msgs, pks) is True
+    bad = decode(api.AggregateSignature, tampered(av["sig"]))
+    assert bad is None or bad.aggregate_verify(msgs, pks) is False
+    assert api.AggregateSignature.new().aggregate_verify([], []) is False
+
+
 class _CountingRng:
     """random.Random that counts the bytes drawn through getrandbits(8) (what the mirror's scalar loop uses)"""
 

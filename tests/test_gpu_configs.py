@@ -21,12 +21,13 @@ def env():
 
 
 def test_config3_fast_aggregate_verify_128_keys_both_formats(env):
-    # configs[2]: fast_aggregate_verify with 128 public keys per item (2^13 items per format here; bench.py runs 2^16)
+    # configs[2] AS NAMED: 2^16 items x 128 public keys in the 96-byte form the headline is measured on (26 ms of GPU time; building and signing the batch
+    # on the device takes longer); the 48-byte wire form at 2^13 items (its decompression is 8 x the work per item)
     torch, bench, N, ctx = env
     import orc
     dev = torch.device("cuda:0")
     for fmt in (N.PK_UNCOMPRESSED, N.PK_COMPRESSED):
-        n, k = 1 << 13, 128
+        n, k = (1 << 16) if fmt == N.PK_UNCOMPRESSED else (1 << 13), 128
         d_sigs, d_msgs, d_pks, expect = bench.build_inputs(ctx, dev, n, k, fmt, rank=3)
         d_res = torch.zeros(n, dtype=torch.uint8, device=dev); d_bm = torch.zeros(n // 64, dtype=torch.int64, device=dev)
         d_st = torch.zeros(n, dtype=torch.int32, device=dev)

@@ -385,6 +385,60 @@ def test_aggregate_verify_batch_vs_oracle(mb):
     assert mb.aggregate_verify_batch(b"", b"", b"", 0, k=3) == ([], [])
 
 
+def test_aggregate_verify_batch_device_with_malformed_pair_offsets(mb):
+    """The device entry takes the pair offset table as it is (the host entry refuses a bad one): a table that does not start at 0, ends below the total, runs
+    backwards or makes two items' ranges overlap must never become an out-of-range index -- pairs no item owns are skipped, an item whose range is invalid or
+    shares a pair with another item is rejected (status bit 0x04), and every OTHER item still gets the oracle's verdict. The staging buffer behind the
+    pair -> item map is reused between calls: a first call with a long table leaves stale indices behind for the second (src/aggregates.rs:130-170)."""
+    import torch
+    from milagro_bls_amd import _native as N
+    ctx = N.default_context(); dev = torch.device("cuda:0")
+    rnd = random.Random(5)
+    sks = [rnd.randrange(1, helpers.R) for _ in range(12)]
+    pks = [orc.sk_to_pk(s) for s in sks]
+    n, k = 8, 3
+    who = [[rnd.randrange(12) for _ in range(k)] for _ in range(n)]
+    msgs = [[rnd.randbytes(32) for _ in range(k)] for _ in range(n)]
+    sigs = []
+    for i in range(n):
+        agg = None
+        for t in range(k):
+            p = orc.sign(msgs[i][t], sks[who[i][t]])
+            agg = p if agg is None else orc.g2_add(agg, p)
+        sigs.append(orc.g2_compress(agg))
+    total = n * k
+    t8 = lambda b: torch.frombuffer(bytearray(b), dtype=torch.uint8).to(dev)
+    d_s, d_m, d_p = t8(b"".join(sigs)), t8(b"".join(b"".join(m) for m in msgs)), t8(b"".join(pks[j] for w in who for j in w))
+
+    def run(off, nn=n, tot=total):
+        d_off = torch.tensor(off, dtype=torch.int32, device=dev)
+        d_res = torch.full((nn,), 9, dtype=torch.uint8, device=dev); d_st = torch.zeros(nn, dtype=torch.int32, device=dev)
+        ctx.check(N.lib().mbls_aggregate_verify_batch_device(ctx.handle, d_s.data_ptr(), d_m.data_ptr(), 32, None, d_p.data_ptr(), d_off.data_ptr(), 0, tot, nn,
+                                                             d_res.data_ptr(), d_st.data_ptr(), None))
+        torch.cuda.synchronize()
+        return [bool(x) for x in d_res.cpu().tolist()], [x & 0xffffffff for x in d_st.cpu().tolist()]
+    good = [k * i for i in range(n + 1)]
+    got, st = run(good)
+    assert got == [True] * n and st == [0] * n
+    # a table that covers only pairs [6, 18): items 0, 1 empty (false: no pairs), items 2..5 as before, items 6, 7 empty; pairs [0, 6) and [18, 24) have no owner
+    off = [6, 6, 6, 9, 12, 15, 18, 18, 18]
+    got, st = run(off)
+    assert got == [False, False, True, True, True, True, False, False]
+    assert all(st[i] & 0x10 for i in (0, 1, 6, 7)) and st[2:6] == [0] * 4
+    # item 3 runs backwards (rejected, never read); item 4 then starts below item 2's end: items 2 and 4 overlap in pairs [6, 9) -- at least one of them is rejected and
+    # whichever is not rejected holds the right verdict for ITS range (item 4 over pairs [6, 15) with item 4's signature: false either way); the rest are untouched
+    off = [0, 3, 6, 9, 6, 15, 18, 21, 24]
+    got, st = run(off)
+    assert st[3] & 0x04 and not got[3]
+    assert (st[2] & 0x04) or (st[4] & 0x04)
+    assert not got[4] and (got[2] or st[2] & 0x04)
+    assert got[0] and got[1] and got[5] and got[6] and got[7]
+    # offsets beyond the total: rejected without a read
+    off = [0, 3, 6, 9, 12, 15, 18, 21, 99]
+    got, st = run(off)
+    assert got[:7] == [True] * 7 and not got[7] and st[7] & 0x04
+
+
 @pytest.mark.parametrize("n,kp", [(13200, 4), (16384, 4), (20000, 3), (33000, 2)])
 def test_aggregate_verify_batch_above_a_round_of_pairs(n, kp):
     """n + n kp one-pair Miller loops = more than a round of lanes (65 536): whole rounds first, what is left of the last round as a launch of its own --

@@ -90,6 +90,51 @@ def test_external_rfc9380_and_eth2(vectors):
         assert orc.g1_compress(orc.sk_to_pk(int(kp["sk"], 16))).hex() == kp["pk"]
 
 
+def _tampered(sig_hex):
+    return bytes.fromhex(sig_hex)[:-4] + b"\xff" * 4          # the Eth2 cases' "tampered signature": last four bytes replaced
+
+
+def test_external_eth2_spec_cases(vectors):
+    """round 5: the published Eth2 BLS cases sign / verify / aggregate / fast_aggregate_verify / aggregate_verify on the three standard keys, where the reference's
+    semantics and the specification's coincide (the specification's extra KeyValidate of every key is not part of src/aggregates.rs:177-215)"""
+    ext = vectors["external"]
+    std = [int(kp["sk"], 16) for kp in ext["eth2_sk_to_pk"]]
+    pks = [orc.sk_to_pk(sk) for sk in std]
+    sigs = {}
+    for e in ext["eth2_sign_cases"] + [ext["eth2_sign"]]:
+        sk, msg = int(e["sk"], 16), bytes.fromhex(e["msg"])
+        sig = orc.sign(msg, sk)
+        assert orc.g2_compress(sig).hex() == e["sig"]
+        sigs[(sk, msg)] = sig
+        # verify_valid / verify_wrong_pubkey / verify_tampered_signature
+        assert orc.verify(sig, msg, orc.sk_to_pk(sk)) is True
+        assert orc.verify(sig, msg, orc.sk_to_pk(std[(std.index(sk) + 1) % 3])) is False
+        err, bad = orc.g2_from_compressed(_tampered(e["sig"]))
+        assert err != 0 or orc.verify(bad, msg, orc.sk_to_pk(sk)) is False
+    for e in ext["eth2_fast_aggregate_verify"]:
+        k, msg = e["n_keys"], bytes.fromhex(e["msg"])
+        err, sig = orc.g2_from_compressed(bytes.fromhex(e["sig"])); assert err == 0
+        assert orc.fast_aggregate_verify(sig, msg, pks[:k]) is True
+        if k < 3:
+            assert orc.fast_aggregate_verify(sig, msg, pks[:k + 1]) is False                  # fast_aggregate_verify_extra_pubkey
+        err, bad = orc.g2_from_compressed(_tampered(e["sig"]))
+        assert err != 0 or orc.fast_aggregate_verify(bad, msg, pks[:k]) is False               # ..._tampered_signature
+    assert orc.fast_aggregate_verify(orc.g2_from_compressed(helpers.G2_INF)[1], bytes.fromhex("ab" * 32), []) is False   # ..._na_pubkeys_and_infinity_signature
+    # aggregate_0xabab...: the sum of the three signatures on ab.. IS the three-key fast_aggregate_verify signature
+    agg = None
+    for sk in std:
+        s1 = sigs[(sk, bytes.fromhex("ab" * 32))]
+        agg = s1 if agg is None else orc.g2_add(agg, s1)
+    assert orc.g2_compress(agg).hex() == ext["eth2_fast_aggregate_verify"][2]["sig"]
+    av = ext["eth2_aggregate_verify"]
+    msgs = [bytes.fromhex(m) for m in av["msgs"]]
+    err, sig = orc.g2_from_compressed(bytes.fromhex(av["sig"])); assert err == 0
+    assert orc.aggregate_verify(sig, msgs, pks) is True                                         # aggregate_verify_valid
+    err, bad = orc.g2_from_compressed(_tampered(av["sig"]))
+    assert err != 0 or orc.aggregate_verify(bad, msgs, pks) is False                            # aggregate_verify_tampered_signature
+    assert orc.aggregate_verify(orc.g2_from_compressed(helpers.G2_INF)[1], [], []) is False       # aggregate_verify_na_pubkeys_and_infinity_signature
+
+
 def test_model_hash_to_g2(vectors):
     for v in vectors["model"]["hash_to_g2"]:
         assert orc.g2_compress(orc.hash_to_g2(helpers.expand_msg(v["msg"]))).hex() == v["compressed"], v["msg"][:20]
