@@ -164,8 +164,13 @@ int mbls_fast_aggregate_verify_batch_indexed(mbls_ctx* ctx, const mbls_keytable*
 /* ---- several GPUs behind one handle ------------------------------------------------------------------------
  * Items are independent (reference src/aggregates.rs:177-215 keeps no state between calls), so a batch shards embarrassingly:
  * device g of G verifies items [n g / G, n (g + 1) / G). One context and one host thread per listed device; every thread stages its
- * own shard from the caller's buffers and writes its results into them in place; no device talks to another (in a one-process-
- * per-GPU deployment -- bench.py -- the same partition is milagro_bls_amd/shard.py and the accept bitmap is gathered with RCCL).
+ * own shard from the caller's buffers and writes its results into them in place (in a one-process-per-GPU deployment -- bench.py --
+ * the same partition is milagro_bls_amd/shard.py and the accept bitmap is gathered with RCCL through torch.distributed).
+ * THE EXCHANGE STEPS of the handle -- the packed accept bitmap of mbls_multi_fast_aggregate_verify_bitmap, the partial records of
+ * mbls_multi_verify_multiple_aggregate_signatures -- are RCCL all-gathers between the devices' buffers (over xGMI on an MI355X node): the
+ * handle opens librccl.so.1 at run time (no link-time dependency) and makes one communicator over its devices (ncclCommInitAll). Where
+ * that is not possible -- RCCL absent, the same device listed twice (RCCL wants one rank per device), MBLS_MULTI_NO_RCCL set -- the same
+ * records travel through host memory instead: same results, never a restart; mbls_multi_rccl_active / mbls_multi_exchange_note tell which.
  * A device id may be listed more than once (two contexts then share that GPU). Calls on one handle are serialised. */
 typedef struct mbls_multi mbls_multi;
 int mbls_multi_create(mbls_multi** out, const int* device_ids, int n_devices);
@@ -174,15 +179,26 @@ int mbls_multi_device_count(const mbls_multi* m);
 const char* mbls_multi_last_error(mbls_multi* m);
 mbls_ctx* mbls_multi_context(mbls_multi* m, int i);            /* the i-th device's context (for the scalar API, reserve, ...) */
 int mbls_multi_reserve(mbls_multi* m, uint64_t max_items);     /* workspace for batches of up to max_items items in total */
+int mbls_multi_rccl_active(const mbls_multi* m);               /* 1: exchange steps are RCCL all-gathers between the devices; 0: through host memory */
+const char* mbls_multi_exchange_note(mbls_multi* m);           /* which, and why (e.g. "host join: device 0 is listed more than once ...") */
 /* same arguments, results and status words as mbls_fast_aggregate_verify_batch / mbls_verify_batch (host buffers) */
 int mbls_multi_fast_aggregate_verify_batch(mbls_multi* m, const uint8_t* sigs, const uint8_t* msgs, uint32_t msg_len,
                                            const uint64_t* msg_offsets, const uint8_t* pks, int pk_format, const uint32_t* pk_offsets,
                                            uint64_t n, uint32_t k, uint8_t* results, uint32_t* status);
 int mbls_multi_verify_batch(mbls_multi* m, const uint8_t* sigs, const uint8_t* msgs, uint32_t msg_len, const uint64_t* msg_offsets,
                             const uint8_t* pks, int pk_format, uint64_t n, uint8_t* results, uint32_t* status);
+/* n x fast_aggregate_verify with the results as ONE packed accept bitmap that EVERY device of the handle ends up holding (bit i % 64 of word i / 64 =
+ * item i): device g verifies the items of words [g W, (g + 1) W), W = ceil(ceil(n / 64) / G), packs them on the device, and the words are all-gathered
+ * between the devices (RCCL when active, see above). `bitmap` (host, ceil(n / 64) words; may be NULL) receives the first device's copy;
+ * mbls_multi_device_bitmap(m, g) is device g's own copy (a device pointer to G W words, valid until the next call on the handle). Other arguments
+ * as mbls_multi_fast_aggregate_verify_batch. */
+int mbls_multi_fast_aggregate_verify_bitmap(mbls_multi* m, const uint8_t* sigs, const uint8_t* msgs, uint32_t msg_len,
+                                            const uint64_t* msg_offsets, const uint8_t* pks, int pk_format, const uint32_t* pk_offsets,
+                                            uint64_t n, uint32_t k, uint64_t* bitmap, uint32_t* status);
+const uint64_t* mbls_multi_device_bitmap(mbls_multi* m, int g);
 /* verify_multiple_aggregate_signatures over the devices of the handle: device g runs sets [n g / G, n (g + 1) / G) up to its partial record
- * (mbls_verify_multiple_partial_device), the first device joins the G records and runs the tail: the same bool as
- * mbls_verify_multiple_aggregate_signatures on one device, same arguments. */
+ * (mbls_verify_multiple_partial_device), the G records are all-gathered between the devices (RCCL when active), the first device joins them and
+ * runs the tail: the same bool as mbls_verify_multiple_aggregate_signatures on one device, same arguments. */
 int mbls_multi_verify_multiple_aggregate_signatures(mbls_multi* m, const uint8_t* sigs96, const uint8_t* apks96, const uint8_t* msgs,
                                                     uint32_t msg_len, const uint64_t* msg_offsets, const uint64_t* rands, size_t n);
 /* a key table replicated on every device of the handle: same indices everywhere */

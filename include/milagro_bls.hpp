@@ -315,6 +315,28 @@ public:
     MultiGpu(const MultiGpu&) = delete; MultiGpu& operator=(const MultiGpu&) = delete;
     ~MultiGpu() { mbls_multi_destroy(h_); }
     int devices() const { return mbls_multi_device_count(h_); }
+    // the handle's exchange steps as RCCL all-gathers between the devices (true) or through host memory (false; exchange_note() says why)
+    bool rccl_active() const { return mbls_multi_rccl_active(h_) == 1; }
+    std::string exchange_note() const { return mbls_multi_exchange_note(h_); }
+    mbls_multi* handle() const { return h_; }
+    // n x fast_aggregate_verify with the results as one packed accept bitmap that every device ends up holding (bit i % 64 of word i / 64 = item i)
+    std::vector<uint64_t> fast_aggregate_verify_bitmap(const std::vector<AggregateSignature>& sigs, const std::vector<Bytes>& msgs, const std::vector<std::vector<const PublicKey*>>& keys) const {
+        const size_t n = sigs.size();
+        if (msgs.size() != n || keys.size() != n) throw std::invalid_argument("one message and one key set per signature");
+        Bytes s, m, p; std::vector<uint64_t> moff{0}; std::vector<uint32_t> koff{0};
+        for (size_t i = 0; i < n; i++) {
+            s.insert(s.end(), sigs[i].point.begin(), sigs[i].point.end());
+            m.insert(m.end(), msgs[i].begin(), msgs[i].end()); moff.push_back(m.size());
+            for (auto* k : keys[i]) p.insert(p.end(), k->point.begin(), k->point.end());
+            if (p.size() / 96 > 0xFFFFFFFFull) throw std::invalid_argument("fast_aggregate_verify_bitmap: key indices are 32-bit");
+            koff.push_back(uint32_t(p.size() / 96));
+        }
+        std::vector<uint64_t> words((n + 63) / 64 ? (n + 63) / 64 : 1);
+        int rc = mbls_multi_fast_aggregate_verify_bitmap(h_, s.data(), m.data(), 0, moff.data(), p.data(), MBLS_PK_UNCOMPRESSED, koff.data(), n, 0, words.data(), nullptr);
+        if (rc != MBLS_OK) throw DeviceError(std::string("mbls_multi: ") + mbls_multi_last_error(h_));
+        words.resize((n + 63) / 64);
+        return words;
+    }
     // n x AggregateSignature::fast_aggregate_verify; messages of any length each
     std::vector<bool> fast_aggregate_verify(const std::vector<AggregateSignature>& sigs, const std::vector<Bytes>& msgs, const std::vector<std::vector<const PublicKey*>>& keys) const {
         const size_t n = sigs.size();

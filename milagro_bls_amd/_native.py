@@ -97,6 +97,10 @@ SIGNATURES = {
     "mbls_multi_last_error": (C.c_char_p, [vp]),
     "mbls_multi_context": (vp, [vp, C.c_int]),
     "mbls_multi_reserve": (C.c_int, [vp, C.c_uint64]),
+    "mbls_multi_rccl_active": (C.c_int, [vp]),
+    "mbls_multi_exchange_note": (C.c_char_p, [vp]),
+    "mbls_multi_fast_aggregate_verify_bitmap": (C.c_int, [vp, vp, vp, C.c_uint32, vp, vp, C.c_int, vp, C.c_uint64, C.c_uint32, vp, vp]),
+    "mbls_multi_device_bitmap": (vp, [vp, C.c_int]),
     "mbls_multi_fast_aggregate_verify_batch": (C.c_int, [vp, vp, vp, C.c_uint32, vp, vp, C.c_int, vp, C.c_uint64, C.c_uint32, vp, vp]),
     "mbls_multi_verify_batch": (C.c_int, [vp, vp, vp, C.c_uint32, vp, vp, C.c_int, C.c_uint64, vp, vp]),
     "mbls_multi_keytable_create": (C.c_int, [vp, C.c_uint64, C.POINTER(vp)]),
@@ -280,6 +284,15 @@ class MultiContext:
 
     def reserve(self, n):
         self.check(lib().mbls_multi_reserve(self._h, n))
+
+    @property
+    def rccl_active(self):
+        """True: the handle's exchange steps (accept bitmap, verify_multiple's partial records) are RCCL all-gathers between the devices"""
+        return bool(lib().mbls_multi_rccl_active(self._h))
+
+    @property
+    def exchange_note(self):
+        return lib().mbls_multi_exchange_note(self._h).decode()
 
 
 class MultiKeyTable:

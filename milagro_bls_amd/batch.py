@@ -240,6 +240,21 @@ def multi_fast_aggregate_verify_batch(mctx, sigs, msgs, pks, n, k=None, pk_forma
     return [bool(x) for x in bytes(res)[:n]], list(st)[:n]
 
 
+def multi_fast_aggregate_verify_bitmap(mctx, sigs, msgs, pks, n, k=None, pk_format=N.PK_COMPRESSED, msg_len=32, pk_offsets=None, msg_offsets=None):
+    """The same with the results as ONE packed accept bitmap that every device of the handle ends up holding (all-gather between the devices: RCCL when
+    mctx.rccl_active, host memory otherwise). -> (bits, status, words): bits[i] = item i accepted, words = the ceil(n / 64) bitmap words of the first device."""
+    words = (C.c_uint64 * max(1, (n + 63) // 64))()
+    st = (C.c_uint32 * max(1, n))()
+    off = None
+    if pk_offsets is not None:
+        off = (C.c_uint32 * len(pk_offsets))(*pk_offsets)
+        k = 0
+    mctx.check(N.lib().mbls_multi_fast_aggregate_verify_bitmap(mctx.handle, N.cbuf(sigs), N.cbuf(msgs), msg_len, _moff(msg_offsets), N.cbuf(pks), pk_format,
+                                                               off, n, k, words, st))
+    w = list(words)[:(n + 63) // 64]
+    return [bool((w[i // 64] >> (i % 64)) & 1) for i in range(n)], list(st)[:n], w
+
+
 def multi_verify_batch(mctx, sigs, msgs, pks, n, pk_format=N.PK_COMPRESSED, msg_len=32, msg_offsets=None):
     res = N.outbuf(n)
     st = (C.c_uint32 * max(1, n))()

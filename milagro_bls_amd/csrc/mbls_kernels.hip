@@ -15,6 +15,8 @@
 #include <new>
 #include <mutex>
 #include <vector>
+#include <dlfcn.h>
+#include <rccl/rccl.h>        // types and enumerators only: the library itself is opened at run time (mbls_multi_create), never linked
 #include "mbls_ops.h"
 #include "mbls_coop.h"
 #include "../../include/mbls.h"
@@ -2044,9 +2046,60 @@ extern "C" int mbls_verify_multiple_aggregate_signatures(mbls_ctx* c, const uint
 // into contiguous shards, one per device; each device has its own context, and one host thread per device stages and verifies its
 // shard, writing results straight into the caller's buffers. No device talks to another. Key tables are replicated on every device.
 #include <thread>
-struct mbls_multi { std::vector<mbls_ctx*> ctx; char err[256] = {}; std::mutex mu; };
+// RCCL, opened at run time: libmbls_hip.so has no link-time dependency on it (a host without RCCL, or a one-device handle that never exchanges anything, loads
+// the library all the same). dlopen finds the copy the process already holds (PyTorch-ROCm ships its own librccl.so.1) before the one under /opt/rocm.
+struct rccl_api {
+    void* h = nullptr;
+    ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+static bool rccl_open(rccl_api* a, char* why, size_t why_len) {
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char* nm : names) { a->h = dlopen(nm, RTLD_NOW | RTLD_NOLOAD); if (a->h) break; }       // a copy the process holds already
+    for (const char* nm : names) { if (a->h) break; a->h = dlopen(nm, RTLD_NOW | RTLD_LOCAL); }
+    if (!a->h) { snprintf(why, why_len, "librccl.so.1 not found (%s)", dlerror()); return false; }
+    a->CommInitAll = (decltype(a->CommInitAll))dlsym(a->h, "ncclCommInitAll");
+    a->CommDestroy = (decltype(a->CommDestroy))dlsym(a->h, "ncclCommDestroy");
+    a->GroupStart = (decltype(a->GroupStart))dlsym(a->h, "ncclGroupStart");
+    a->GroupEnd = (decltype(a->GroupEnd))dlsym(a->h, "ncclGroupEnd");
+    a->AllGather = (decltype(a->AllGather))dlsym(a->h, "ncclAllGather");
+    a->GetErrorString = (decltype(a->GetErrorString))dlsym(a->h, "ncclGetErrorString");
+    if (!a->CommInitAll || !a->CommDestroy || !a->GroupStart || !a->GroupEnd || !a->AllGather || !a->GetErrorString) {
+        snprintf(why, why_len, "librccl.so.1 lacks an entry point"); return false;
+    }
+    return true;
+}
+// Several devices behind one handle. The exchange step of the paths that have one (the accept bitmap of mbls_multi_fast_aggregate_verify_bitmap, the partial
+// records of mbls_multi_verify_multiple_aggregate_signatures) is an RCCL all-gather between the devices' buffers -- over xGMI on an MI355X node -- when the
+// handle could set up a communicator; otherwise (RCCL absent, the same device listed twice: RCCL refuses duplicates, MBLS_MULTI_NO_RCCL set) the records travel
+// through host memory and `rccl_note` says why. Never a restart, never a different result.
+struct mbls_multi {
+    std::vector<mbls_ctx*> ctx; char err[256] = {}; std::mutex mu;
+    rccl_api rccl; std::vector<ncclComm_t> comms; bool rccl_on = false; char rccl_note[256] = {};
+    std::vector<uint64_t*> d_bm_send, d_bm_all; uint64_t bm_words_cap = 0;        // per device: this shard's bitmap words / the gathered bitmap
+    std::vector<uint8_t*> d_rec_all;                                              // per device: G partial records of verify_multiple
+};
 struct mbls_multi_keytable { mbls_multi* m = nullptr; std::vector<mbls_keytable*> tab; };
 
+static void multi_rccl_setup(mbls_multi* m, const int* device_ids, int G) {
+    if (getenv("MBLS_MULTI_NO_RCCL")) { snprintf(m->rccl_note, sizeof(m->rccl_note), "host join: MBLS_MULTI_NO_RCCL is set"); return; }
+    for (int a = 0; a < G; a++) for (int b = a + 1; b < G; b++) if (device_ids[a] == device_ids[b]) {
+        snprintf(m->rccl_note, sizeof(m->rccl_note), "host join: device %d is listed more than once (RCCL wants one rank per device)", device_ids[a]); return;
+    }
+    char why[160] = {};
+    if (!rccl_open(&m->rccl, why, sizeof(why))) { snprintf(m->rccl_note, sizeof(m->rccl_note), "host join: %s", why); return; }
+    m->comms.assign((size_t)G, nullptr);
+    const ncclResult_t r = m->rccl.CommInitAll(m->comms.data(), G, device_ids);
+    if (r != ncclSuccess) {
+        snprintf(m->rccl_note, sizeof(m->rccl_note), "host join: ncclCommInitAll failed: %s", m->rccl.GetErrorString(r)); m->comms.clear(); return;
+    }
+    m->rccl_on = true;
+    snprintf(m->rccl_note, sizeof(m->rccl_note), "RCCL all-gather over a communicator of %d device(s)", G);
+}
 extern "C" int mbls_multi_create(mbls_multi** out, const int* device_ids, int n_devices) {
     if (!out || !device_ids || n_devices <= 0) return MBLS_ERR_ARGUMENT;
     mbls_multi* m = new (std::nothrow) mbls_multi();
@@ -2057,12 +2110,53 @@ extern "C" int mbls_multi_create(mbls_multi** out, const int* device_ids, int n_
         if (rc) { for (mbls_ctx* x : m->ctx) mbls_ctx_destroy(x); delete m; return rc; }
         m->ctx.push_back(c);
     }
+    try {
+        m->d_bm_send.assign((size_t)n_devices, nullptr); m->d_bm_all.assign((size_t)n_devices, nullptr); m->d_rec_all.assign((size_t)n_devices, nullptr);
+        multi_rccl_setup(m, device_ids, n_devices);
+    } catch (...) { for (mbls_ctx* x : m->ctx) mbls_ctx_destroy(x); delete m; return MBLS_ERR_DEVICE; }
     *out = m; return MBLS_OK;
 }
 extern "C" void mbls_multi_destroy(mbls_multi* m) {
     if (!m) return;
+    for (size_t g = 0; g < m->ctx.size(); g++) {
+        (void)hipSetDevice(m->ctx[g]->device); (void)hipDeviceSynchronize();
+        if (g < m->comms.size() && m->comms[g]) (void)m->rccl.CommDestroy(m->comms[g]);
+        if (m->d_bm_send[g]) (void)hipFree(m->d_bm_send[g]);
+        if (m->d_bm_all[g]) (void)hipFree(m->d_bm_all[g]);
+        if (m->d_rec_all[g]) (void)hipFree(m->d_rec_all[g]);
+    }
     for (mbls_ctx* c : m->ctx) mbls_ctx_destroy(c);
     delete m;
+}
+// 1: the handle's exchange steps run as RCCL all-gathers between the devices; 0: through host memory (mbls_multi_exchange_note says why)
+extern "C" int mbls_multi_rccl_active(const mbls_multi* m) { return m && m->rccl_on ? 1 : 0; }
+extern "C" const char* mbls_multi_exchange_note(mbls_multi* m) { return m ? m->rccl_note : "null handle"; }
+// Exchange `bytes` bytes per device: device g contributes d_send[g] and ends with all G contributions, in device order, in d_recv[g] (G * bytes). The devices'
+// streams `st[g]` carry the operation; on return it has completed everywhere. RCCL when the handle has a communicator, host memory otherwise.
+static int multi_allgather(mbls_multi* m, const std::vector<const void*>& d_send, const std::vector<void*>& d_recv, size_t bytes, const std::vector<hipStream_t>& st) {
+    const size_t G = m->ctx.size();
+    if (m->rccl_on) {
+        ncclResult_t r = m->rccl.GroupStart();
+        for (size_t g = 0; g < G && r == ncclSuccess; g++) {
+            if (hipSetDevice(m->ctx[g]->device) != hipSuccess) { (void)m->rccl.GroupEnd(); snprintf(m->err, sizeof(m->err), "hipSetDevice failed"); return MBLS_ERR_DEVICE; }
+            r = m->rccl.AllGather(d_send[g], d_recv[g], bytes, ncclUint8, m->comms[g], st[g]);
+        }
+        const ncclResult_t r2 = m->rccl.GroupEnd();
+        if (r == ncclSuccess) r = r2;
+        if (r != ncclSuccess) { snprintf(m->err, sizeof(m->err), "RCCL all-gather failed: %s", m->rccl.GetErrorString(r)); return MBLS_ERR_DEVICE; }
+        for (size_t g = 0; g < G; g++) {
+            if (hipSetDevice(m->ctx[g]->device) != hipSuccess || hipStreamSynchronize(st[g]) != hipSuccess) { snprintf(m->err, sizeof(m->err), "all-gather: device %d did not complete", m->ctx[g]->device); return MBLS_ERR_DEVICE; }
+        }
+        return MBLS_OK;
+    }
+    std::vector<uint8_t> host;
+    try { host.resize(G * bytes); } catch (...) { snprintf(m->err, sizeof(m->err), "out of host memory"); return MBLS_ERR_DEVICE; }
+    for (size_t g = 0; g < G; g++)
+        if (hipSetDevice(m->ctx[g]->device) != hipSuccess || hipStreamSynchronize(st[g]) != hipSuccess ||
+            hipMemcpy(host.data() + g * bytes, d_send[g], bytes, hipMemcpyDeviceToHost) != hipSuccess) { snprintf(m->err, sizeof(m->err), "host join: download from device %d failed", m->ctx[g]->device); return MBLS_ERR_DEVICE; }
+    for (size_t g = 0; g < G; g++)
+        if (hipSetDevice(m->ctx[g]->device) != hipSuccess || hipMemcpy(d_recv[g], host.data(), G * bytes, hipMemcpyHostToDevice) != hipSuccess) { snprintf(m->err, sizeof(m->err), "host join: upload to device %d failed", m->ctx[g]->device); return MBLS_ERR_DEVICE; }
+    return MBLS_OK;
 }
 extern "C" int mbls_multi_device_count(const mbls_multi* m) { return m ? (int)m->ctx.size() : 0; }
 extern "C" const char* mbls_multi_last_error(mbls_multi* m) { return m ? m->err : "null handle"; }
@@ -2120,13 +2214,14 @@ extern "C" int mbls_multi_verify_multiple_aggregate_signatures(mbls_multi* m, co
     if (!sigs96 || !apks96 || !rands || (!msgs && (moff ? moff[n] != moff[0] : msg_len != 0))) return 0;
     std::lock_guard<std::mutex> lk(m->mu);
     const uint64_t G = m->ctx.size();
-    std::vector<uint8_t> recs; std::vector<int> rcs(G, MBLS_OK); std::vector<std::thread> th;
-    try { recs.resize(G * MBLS_VM_PARTIAL_BYTES); } catch (...) { return 0; }
+    std::vector<int> rcs(G, MBLS_OK); std::vector<std::thread> th;
+    std::vector<const void*> d_send(G, nullptr); std::vector<void*> d_recv(G, nullptr); std::vector<hipStream_t> st(G, nullptr);
     auto work = [&](uint64_t g) {
         mbls_ctx* c = m->ctx[g];
         const uint64_t lo = shard_lo(n, g, G), hi = shard_lo(n, g + 1, G), cnt = hi - lo;
         mbls_lock lk2(c->mu);
         if (hipSetDevice(c->device) != hipSuccess) { rcs[g] = MBLS_ERR_DEVICE; return; }
+        if (!m->d_rec_all[g] && hipMalloc(&m->d_rec_all[g], G * MBLS_VM_PARTIAL_BYTES) != hipSuccess) { m->d_rec_all[g] = nullptr; rcs[g] = MBLS_ERR_DEVICE; return; }
         const uint64_t first = moff ? moff[lo] : (uint64_t)msg_len * lo;
         const size_t mbytes = moff ? (size_t)(moff[hi] - moff[lo]) : (size_t)msg_len * cnt;
         sbuf ds(c, 0), da(c, 1), dm(c, 2), dr(c, 3), dmo(c, 6), drec(c, 4);
@@ -2139,24 +2234,81 @@ extern "C" int mbls_multi_verify_multiple_aggregate_signatures(mbls_multi* m, co
         const bool synced = hipStreamSynchronize(c->hs_a) == hipSuccess;
         (void)hipStreamSynchronize(c->hs_b); (void)hipStreamSynchronize(c->hs_c);
         c->ws_pending = false;
-        if (!rcs[g] && (!synced || drec.down(recs.data() + g * MBLS_VM_PARTIAL_BYTES, MBLS_VM_PARTIAL_BYTES) != hipSuccess)) rcs[g] = MBLS_ERR_DEVICE;
+        if (!rcs[g] && !synced) rcs[g] = MBLS_ERR_DEVICE;
+        d_send[g] = drec.p; d_recv[g] = m->d_rec_all[g]; st[g] = c->hs_a;       // the shard's record stays on its device: the exchange step follows
     };
     try { for (uint64_t g = 1; g < G; g++) th.emplace_back(work, g); } catch (...) { for (auto& t : th) t.join(); snprintf(m->err, sizeof(m->err), "cannot start a host thread"); return 0; }
     work(0);
     for (auto& t : th) t.join();
     for (uint64_t g = 0; g < G; g++)
         if (rcs[g]) { snprintf(m->err, sizeof(m->err), "device %d (shard %llu): %s", m->ctx[g]->device, (unsigned long long)g, m->ctx[g]->err); return 0; }
+    // THE exchange step: every device ends with all G records -- an RCCL all-gather of G x 896 bytes between the devices when the handle
+    // has a communicator, host memory otherwise; the join then runs on the first device (any of them would reach the same bool)
+    if (multi_allgather(m, d_send, d_recv, MBLS_VM_PARTIAL_BYTES, st)) return 0;
     mbls_ctx* c = m->ctx[0];
     mbls_lock lk0(c->mu);
     if (hipSetDevice(c->device) != hipSuccess) return 0;
-    sbuf dall(c, 0), dres(c, 4); uint8_t r = 0;
-    if (dall.up(recs.data(), recs.size()) != hipSuccess || dres.alloc(8) != hipSuccess) return 0;
-    if (mbls_verify_multiple_finish_device(c, dall.as<uint8_t>(), G, dres.as<uint8_t>(), nullptr, c->hs_a)) { (void)hipStreamSynchronize(c->hs_a); c->ws_pending = false; return 0; }
+    sbuf dres(c, 4); uint8_t r = 0;
+    if (dres.alloc(8) != hipSuccess) return 0;
+    if (mbls_verify_multiple_finish_device(c, m->d_rec_all[0], G, dres.as<uint8_t>(), nullptr, c->hs_a)) { (void)hipStreamSynchronize(c->hs_a); c->ws_pending = false; return 0; }
     if (hipStreamSynchronize(c->hs_a) != hipSuccess) return 0;
     c->ws_pending = false;
     if (dres.down(&r, 1) != hipSuccess) return 0;
     return r;
 }
+// n x fast_aggregate_verify over the handle's devices with the results as ONE packed accept bitmap that every device ends up holding (north_star: "RCCL over
+// xGMI used only to gather the final accept bitmap"): device g verifies the items of bitmap words [g W, (g + 1) W), W = ceil(ceil(n / 64) / G), packs its W words
+// on the device, and the words are all-gathered between the devices (multi_allgather). `bitmap` (host, ceil(n / 64) words, optional) receives device 0's copy;
+// mbls_multi_device_bitmap(m, g) is device g's copy (G W words, valid until the next call on the handle). Host buffers in, like the other handle entries.
+extern "C" int mbls_multi_fast_aggregate_verify_bitmap(mbls_multi* m, const uint8_t* sigs, const uint8_t* msgs, uint32_t msg_len, const uint64_t* moff,
+        const uint8_t* pks, int fmt, const uint32_t* off, uint64_t n, uint32_t k, uint64_t* bitmap, uint32_t* status) {
+    if (!m) return MBLS_ERR_ARGUMENT;
+    if (n == 0) return MBLS_OK;
+    std::lock_guard<std::mutex> lk(m->mu);
+    const uint64_t G = m->ctx.size();
+    const uint64_t words = (n + 63) / 64, W = (words + G - 1) / G;
+    const size_t unit = fmt == MBLS_PK_COMPRESSED ? 48 : 96;
+    std::vector<int> rcs(G, MBLS_OK); std::vector<std::thread> th;
+    std::vector<const void*> d_send(G, nullptr); std::vector<void*> d_recv(G, nullptr); std::vector<hipStream_t> st(G, nullptr);
+    auto work = [&](uint64_t g) {
+        mbls_ctx* c = m->ctx[g];
+        const uint64_t lo = 64 * W * g < n ? 64 * W * g : n, hi = 64 * W * (g + 1) < n ? 64 * W * (g + 1) : n, cnt = hi - lo;
+        mbls_lock lk2(c->mu);
+        if (hipSetDevice(c->device) != hipSuccess) { rcs[g] = MBLS_ERR_DEVICE; return; }
+        if (m->bm_words_cap < W || !m->d_bm_send[g]) {      // (bm_words_cap is raised after the workers have joined)
+            if (m->d_bm_send[g]) { (void)hipFree(m->d_bm_send[g]); m->d_bm_send[g] = nullptr; }
+            if (m->d_bm_all[g]) { (void)hipFree(m->d_bm_all[g]); m->d_bm_all[g] = nullptr; }
+            if (hipMalloc(&m->d_bm_send[g], 8 * W) != hipSuccess || hipMalloc(&m->d_bm_all[g], 8 * W * G) != hipSuccess) { rcs[g] = MBLS_ERR_DEVICE; return; }
+        }
+        d_send[g] = m->d_bm_send[g]; d_recv[g] = m->d_bm_all[g]; st[g] = c->hs_a;
+        if (hipMemsetAsync(m->d_bm_send[g], 0, 8 * W, c->hs_a) != hipSuccess) { rcs[g] = MBLS_ERR_DEVICE; return; }
+        if (!cnt) return;
+        const uint8_t* s_msgs = (moff || !msgs) ? msgs : msgs + (uint64_t)msg_len * lo;
+        const uint8_t* s_pks = (off || !pks) ? pks : pks + unit * (uint64_t)k * lo;
+        std::vector<uint8_t> res;
+        try { res.resize(cnt); } catch (...) { rcs[g] = MBLS_ERR_DEVICE; return; }
+        rcs[g] = verify_host(c, sigs ? sigs + 96 * lo : nullptr, s_msgs, msg_len, moff ? moff + lo : nullptr, s_pks, fmt, nullptr, nullptr, off ? off + lo : nullptr, cnt, k,
+                             MBLS_MODE_FAST_AGGREGATE, res.data(), status ? status + lo : nullptr);
+        if (rcs[g]) return;
+        // the shard's result bytes are still in the context's staging buffer (slot 4 of verify_host): pack them where they are
+        hipLaunchKernelGGL(k_pack, dim3(nblk(cnt)), dim3(WG), 0, c->hs_a, (const uint8_t*)c->stage[4].p, m->d_bm_send[g], cnt);
+        if (hipGetLastError() != hipSuccess) rcs[g] = MBLS_ERR_DEVICE;
+    };
+    try { for (uint64_t g = 1; g < G; g++) th.emplace_back(work, g); } catch (...) { for (auto& t : th) t.join(); snprintf(m->err, sizeof(m->err), "cannot start a host thread"); return MBLS_ERR_DEVICE; }
+    work(0);
+    for (auto& t : th) t.join();
+    for (uint64_t g = 0; g < G; g++)
+        if (rcs[g]) { snprintf(m->err, sizeof(m->err), "device %d (shard %llu): %s", m->ctx[g]->device, (unsigned long long)g, m->ctx[g]->err); m->bm_words_cap = 0; return rcs[g]; }
+    if (m->bm_words_cap < W) m->bm_words_cap = W;
+    int rc = multi_allgather(m, d_send, d_recv, 8 * W, st); if (rc) return rc;
+    if (bitmap) {
+        if (hipSetDevice(m->ctx[0]->device) != hipSuccess || hipMemcpy(bitmap, m->d_bm_all[0], 8 * words, hipMemcpyDeviceToHost) != hipSuccess) {
+            snprintf(m->err, sizeof(m->err), "bitmap download failed"); return MBLS_ERR_DEVICE;
+        }
+    }
+    return MBLS_OK;
+}
+extern "C" const uint64_t* mbls_multi_device_bitmap(mbls_multi* m, int g) { return (m && g >= 0 && g < (int)m->ctx.size()) ? m->d_bm_all[g] : nullptr; }
 extern "C" int mbls_multi_keytable_create(mbls_multi* m, uint64_t capacity_hint, mbls_multi_keytable** out) {
     if (!m || !out) return MBLS_ERR_ARGUMENT;
     mbls_multi_keytable* t = new (std::nothrow) mbls_multi_keytable();

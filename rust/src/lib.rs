@@ -90,6 +90,9 @@ extern "C" {
     fn mbls_multi_device_count(m: *const MblsMulti) -> c_int;
     fn mbls_multi_fast_aggregate_verify_batch(m: *mut MblsMulti, sigs: *const u8, msgs: *const u8, msg_len: u32, msg_offsets: *const u64, pks: *const u8,
                                               pk_format: c_int, pk_offsets: *const u32, n: u64, k: u32, results: *mut u8, status: *mut u32) -> c_int;
+    fn mbls_multi_rccl_active(m: *const MblsMulti) -> c_int;
+    fn mbls_multi_fast_aggregate_verify_bitmap(m: *mut MblsMulti, sigs: *const u8, msgs: *const u8, msg_len: u32, msg_offsets: *const u64, pks: *const u8,
+                                               pk_format: c_int, pk_offsets: *const u32, n: u64, k: u32, bitmap: *mut u64, status: *mut u32) -> c_int;
     fn mbls_multi_verify_multiple_aggregate_signatures(m: *mut MblsMulti, sigs96: *const u8, apks96: *const u8, msgs: *const u8, msg_len: u32,
                                                        msg_offsets: *const u64, rands: *const u64, n: usize) -> c_int;
 }
@@ -678,6 +681,41 @@ impl MultiGpu {
             err(rc);
         }
         res.into_iter().map(|b| b == 1).collect()
+    }
+    /// Whether the handle's exchange steps (the accept bitmap below, `verify_multiple`'s partial records) run as RCCL all-gathers between the
+    /// devices -- over xGMI on an MI355X node -- or, where RCCL could not set up a communicator, through host memory.
+    pub fn rccl_active(&self) -> bool {
+        unsafe { mbls_multi_rccl_active(self.h) == 1 }
+    }
+    /// The same verifications with the results as one packed accept bitmap (bit i % 64 of word i / 64 = item i) that every device of the
+    /// handle ends up holding: each device packs its shard's bits, the words are all-gathered between the devices. Returns the words.
+    pub fn fast_aggregate_verify_bitmap(&self, signatures: &[AggregateSignature], messages: &[&[u8]], public_keys: &[Vec<&PublicKey>]) -> Vec<u64> {
+        let n = signatures.len();
+        assert!(messages.len() == n && public_keys.len() == n);
+        let sigs: Vec<u8> = signatures.iter().flat_map(|s| s.point.iter().copied()).collect();
+        let mut msgs: Vec<u8> = Vec::new();
+        let mut moff: Vec<u64> = vec![0];
+        for m in messages {
+            msgs.extend_from_slice(m);
+            moff.push(msgs.len() as u64);
+        }
+        let mut offsets: Vec<u32> = vec![0];
+        let mut pks: Vec<u8> = Vec::new();
+        for set in public_keys {
+            for k in set {
+                pks.extend_from_slice(&k.point);
+            }
+            offsets.push(u32::try_from(pks.len() / 96).expect("key indices are 32-bit"));
+        }
+        let mut words = vec![0u64; (n + 63) / 64];
+        let rc = unsafe {
+            mbls_multi_fast_aggregate_verify_bitmap(self.h, sigs.as_ptr(), msgs.as_ptr(), 0, moff.as_ptr(), pks.as_ptr(), PK_UNCOMPRESSED, offsets.as_ptr(), n as u64, 0,
+                                                    words.as_mut_ptr(), std::ptr::null_mut())
+        };
+        if rc != 0 {
+            err(rc);
+        }
+        words
     }
     /// `AggregateSignature::verify_multiple_aggregate_signatures` (`src/aggregates.rs:261-316`) with the sets cut into one shard per device:
     /// every device runs its sets up to its Miller product and signature sum, the first device joins the records and finishes. Same bool.
