@@ -100,6 +100,8 @@ int mbls_ctx_set_lane_shaping(mbls_ctx* ctx, uint64_t split_max_items, uint64_t 
  * q - 1 whole rounds in front; below it the remainder follows the rounds as a batch of its own (mbls_ctx_set_round_items). Default 6 144 (measured:
  * 73 728 items 40.0 -> 36 ms, 100 000 items 51.6 -> 46 ms); 0 = never. Same results, bit for bit (environment for new contexts: MBLS_TRACKS_MIN_REST). */
 int mbls_ctx_set_tracks(mbls_ctx* ctx, uint64_t min_rest_items);
+/* 0 (default): lookups that depend on a secret key are scans with selection; 1: the variable-time forms (see "SECRET KEYS ON THE DEVICE" below) */
+int mbls_ctx_set_secret_ops(mbls_ctx* ctx, int variable_time);
 
 /* ---- the hot path -------------------------------------------------------------------------------------
  * Batch of n independent AggregateSignature::fast_aggregate_verify calls (reference src/aggregates.rs:177-215):
@@ -316,10 +318,15 @@ int mbls_pk_decode_batch(mbls_ctx* ctx, const uint8_t* in, int in_format, int va
 int mbls_pk_compress_batch(mbls_ctx* ctx, const uint8_t* in96, uint64_t n, uint8_t* out48, uint8_t* errs);
 /* n x Signature::from_bytes: errs[i]; in_g2 (optional) = subgroup_check_g2 per signature */
 int mbls_sig_check_batch(mbls_ctx* ctx, const uint8_t* in96, uint64_t n, uint8_t* errs, uint8_t* in_g2);
-/* NOT CONSTANT-TIME: sk -> pk gathers table records at addresses that depend on the secret key's hexadecimal digits, and signing selects
- * per-lane window-table records by digits of the key (amcl's g1mul / g2mul use constant-time selection). These batch entries exist to build
- * inputs and caches; do not run them on keys an attacker can time. What they leave behind is wiped: the staged keys, the digit buffer and
- * the workspace slots of the partial products are zeroed on the stream before the call's workspace is released.
+/* SECRET KEYS ON THE DEVICE (signing, sk -> pk; reference src/signature.rs:17-21, src/keys.rs:124-137 -- amcl's g1mul / g2mul select table entries in
+ * constant time). Every table lookup that depends on a key is a SCAN WITH SELECTION: signing reads all eight records of the lane's window table in every
+ * window and keeps its own with v_cndmask (the generated routine's constant-time form, tools/gen_tower_d.py blind_scan_ct), sk -> pk reads all 16 multiples
+ * [d 16^j] G1 of every window and keeps record d_j (k_sk_select) -- no address, no instruction stream and no memory-operation count depends on a key; the
+ * scalar's other uses (digit extraction, sign / zero handling) are selections as well. mbls_ctx_set_secret_ops(ctx, 1) (environment MBLS_UNSAFE_SECRET_OPS
+ * for new contexts) switches both to the faster forms that read ONE record at a key-dependent address -- for building test and bench inputs from throw-away
+ * keys only (measured at 2^16: signing 14.5 instead of 15.3 ms, sk -> pk 0.87 instead of 2.15 ms). This is NOT a claim of resistance against power or fault analysis, and a GPU shared with an attacker's kernels
+ * is not a place for long-term keys either way. What the calls leave behind is wiped: the staged keys, the digit / selection buffers and the workspace slots
+ * of the partial products and tables are zeroed on the stream before the call's workspace is released.
  * n x Signature::new / PublicKey::from_secret_key. Secret keys are NOT range-checked here: any 32-byte big-endian value gives [sk mod r] H(msg) /
  * [sk mod r] G1. The device entries use the context's workspace (four items per signature, in chunks of 65 536 signatures) and wait for its
  * previous user like the verification entries; they only enqueue. */

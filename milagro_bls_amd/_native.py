@@ -39,6 +39,7 @@ SIGNATURES = {
     "mbls_ctx_reset_tuning": (C.c_int, [vp]),
     "mbls_ctx_set_lane_shaping": (C.c_int, [vp, C.c_uint64, C.c_uint64]),
     "mbls_ctx_set_tracks": (C.c_int, [vp, C.c_uint64]),
+    "mbls_ctx_set_secret_ops": (C.c_int, [vp, C.c_int]),
     "mbls_last_error": (C.c_char_p, [vp]),
     "mbls_fast_aggregate_verify_batch_device": (C.c_int, [vp, vp, vp, C.c_uint32, vp, vp, C.c_int, vp, C.c_uint64, C.c_uint32, vp, vp, vp, vp]),
     "mbls_fast_aggregate_verify_batch": (C.c_int, [vp, vp, vp, C.c_uint32, vp, vp, C.c_int, vp, C.c_uint64, C.c_uint32, vp, vp]),
@@ -192,6 +193,10 @@ class Context:
     def set_tracks(self, min_rest_items):
         """batches of q rounds + r items with r >= min_rest_items: the last round + remainder as two halves side by side (0: never)"""
         self.check(lib().mbls_ctx_set_tracks(self._h, min_rest_items))
+
+    def set_secret_ops(self, variable_time):
+        """False (default): signing / sk -> pk look their tables up by scan + selection (constant-time access); True: by key-dependent address (throw-away keys only)"""
+        self.check(lib().mbls_ctx_set_secret_ops(self._h, int(bool(variable_time))))
 
     def reset_tuning(self):
         """every routing parameter (engine crossovers, packing, round, lane shaping) back to the library's defaults"""

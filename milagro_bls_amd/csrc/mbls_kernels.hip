@@ -492,6 +492,30 @@ __global__ void MBLS_LB k_sk_digits(const uint8_t* sks32, uint64_t n, uint32_t* 
         idx[64 * i + j] = 16 * j + d;
     }
 }
+// CONSTANT-TIME sk -> pk (the default; reference src/keys.rs:124-137 -- amcl's g1mul selects in constant time): lane (key i, window j) reads ALL 16 records
+// [d 16^j] G1 of its window and keeps record d_j by selection, so neither an address nor the instruction stream depends on the key; the selected records form a
+// per-batch table sel[64 i + j] that the key-sum routine then walks with the public indices 64 i + j (idx).
+__global__ void __launch_bounds__(WG) k_sk_select(const uint8_t* sks32, uint64_t n, const uint32_t* gtab, uint32_t* sel, uint32_t* idx) {
+    const uint64_t t = gid(); if (t >= 64 * n) return;
+    const uint64_t i = t >> 6; const uint32_t j = (uint32_t)(t & 63);
+    const uint32_t d = (sks32[32 * i + 31 - (j >> 1)] >> (4 * (j & 1))) & 15u;
+    const uint4* rec = (const uint4*)(gtab + (size_t)16 * j * MBLS_KEYREC_DWORDS);
+    uint4 acc[MBLS_KEYREC_DWORDS / 4];
+#pragma unroll
+    for (int q = 0; q < MBLS_KEYREC_DWORDS / 4; q++) acc[q] = rec[q];
+    for (uint32_t e = 1; e < 16; e++) {
+        const bool take = e == d;
+#pragma unroll
+        for (int q = 0; q < MBLS_KEYREC_DWORDS / 4; q++) {
+            const uint4 v = rec[(size_t)e * (MBLS_KEYREC_DWORDS / 4) + q];
+            acc[q].x = take ? v.x : acc[q].x; acc[q].y = take ? v.y : acc[q].y; acc[q].z = take ? v.z : acc[q].z; acc[q].w = take ? v.w : acc[q].w;
+        }
+    }
+    uint4* out = (uint4*)(sel + t * MBLS_KEYREC_DWORDS);
+#pragma unroll
+    for (int q = 0; q < MBLS_KEYREC_DWORDS / 4; q++) out[q] = acc[q];
+    idx[t] = (uint32_t)t;
+}
 __global__ void MBLS_LB k_apk_export_fmt(mbls_ws ws, uint64_t n, int fmt, uint8_t* out) {
     uint64_t i = gid(); if (i >= n) return;
     g1j a; a.x = ws_ld(ws, MBLS_SLOT_APK, i); a.y = ws_ld(ws, MBLS_SLOT_APK + 1, i); a.z = ws_ld(ws, MBLS_SLOT_APK + 2, i);
@@ -527,7 +551,7 @@ MBLS_FN void scalar_base_y_digits(uint64_t a[4], const uint8_t* sk32) {
         a[t] = rem;
     }
 }
-__global__ void MBLS_LB k_sign_blind(mbls_ws ws, const uint8_t* sks32, uint64_t n) {
+__global__ void MBLS_LB k_sign_blind(mbls_ws ws, const uint8_t* sks32, uint64_t n, int ct) {
 #if MBLS_DEVICE_ASM
     __shared__ uint32_t spill[154 * 64];
     uint64_t t = gid(); if (t >= 4 * n) return;
@@ -541,7 +565,9 @@ __global__ void MBLS_LB k_sign_blind(mbls_ws ws, const uint8_t* sks32, uint64_t 
     ws_st2(ws, MBLS_SLOT_SIG, t, q.x); ws_st2(ws, MBLS_SLOT_SIG + 2, t, q.y);
     uint64_t a[4]; scalar_base_y_digits(a, sks32 + 32 * i);
     const uint64_t r = j == 0 ? a[0] : j == 1 ? a[1] : j == 2 ? a[2] : a[3];
-    (void)g2_blind_d_call(ws, t, (MBLS_LDS uint32_t*)spill, threadIdx.x, inf ? 0 : r, 1u);
+    // ct (the default): the window tables are read by scan + selection, never at an address that depends on the key (mbls_ctx_set_secret_ops)
+    if (ct) (void)g2_blind_ct_d_call(ws, t, (MBLS_LDS uint32_t*)spill, threadIdx.x, inf ? 0 : r, 1u);
+    else (void)g2_blind_d_call(ws, t, (MBLS_LDS uint32_t*)spill, threadIdx.x, inf ? 0 : r, 1u);
 #endif
 }
 __global__ void MBLS_LB k_s_export(mbls_ws ws, uint64_t n, uint8_t* out96) {
@@ -624,6 +650,8 @@ struct mbls_ctx {
     uint32_t* d_scalar = nullptr;      // small scratch words
     uint32_t* d_gtab = nullptr;        // [64 * 16][MBLS_KEYREC_DWORDS]: [d 16^j] G1 (sk -> pk), built on first use
     uint32_t* d_skidx = nullptr; uint64_t skidx_cap = 0;      // the table indices of a batch of secret keys
+    uint32_t* d_sksel = nullptr; uint64_t sksel_cap = 0;      // constant-time sk -> pk: the records each (key, window) selected, [chunk * 64][MBLS_KEYREC_DWORDS]
+    bool secret_ops_fast = false;      // false (default): table lookups that depend on a secret key are scans with selection (mbls_ctx_set_secret_ops)
     uint64_t key_cap = 0;              // decompressed-key staging (compressed wire format): capacity in keys
     uint32_t* d_keys_xy = nullptr;     // [key_cap][24] affine Montgomery coordinates
     uint8_t* d_key_flags = nullptr;
@@ -732,6 +760,7 @@ static void ctx_free(mbls_ctx* c) {
     if (c->d_scalar) (void)hipFree(c->d_scalar);
     if (c->d_gtab) (void)hipFree(c->d_gtab);
     if (c->d_skidx) (void)hipFree(c->d_skidx);
+    if (c->d_sksel) (void)hipFree(c->d_sksel);
     if (c->d_keys_xy) (void)hipFree(c->d_keys_xy);
     if (c->d_key_flags) (void)hipFree(c->d_key_flags);
     if (c->d_coop) (void)hipFree(c->d_coop);
@@ -837,6 +866,7 @@ static void ctx_default_tuning(mbls_ctx* c) {
     if ((e = getenv("MBLS_SPLIT_MAX_ITEMS"))) c->split_max_items = strtoull(e, nullptr, 10);
     if ((e = getenv("MBLS_FORK_MAX_ITEMS"))) c->fork_max_items = strtoull(e, nullptr, 10);
     if ((e = getenv("MBLS_HASH2_MAX_ITEMS"))) c->hash2_max_items = strtoull(e, nullptr, 10);
+    c->secret_ops_fast = getenv("MBLS_UNSAFE_SECRET_OPS") != nullptr;
     c->tracks_min_rest = MBLS_DEFAULT_TRACKS_MIN_REST;
     if ((e = getenv("MBLS_TRACKS_MIN_REST"))) c->tracks_min_rest = strtoull(e, nullptr, 10);
 }
@@ -1394,7 +1424,7 @@ extern "C" int mbls_sign_batch_device(mbls_ctx* c, const uint8_t* d_sks, const u
         const uint64_t m = n - lo < chunk ? n - lo : chunk;
         HIPCHK(c, hipMemsetAsync(c->d_status, 0, 4 * m, s));
         launch_hash(c, ws, d_msgs + (uint64_t)msg_len * lo, msg_len, nullptr, c->d_status, m, s);
-        hipLaunchKernelGGL(k_sign_blind, dim3(nblk(4 * m)), dim3(WG), 0, s, ws, d_sks + 32 * lo, m);
+        hipLaunchKernelGGL(k_sign_blind, dim3(nblk(4 * m)), dim3(WG), 0, s, ws, d_sks + 32 * lo, m, c->secret_ops_fast ? 0 : 1);
         g2_tree_levels(c, ws, 4 * m, 2, s);
         hipLaunchKernelGGL(k_s_export, dim3(nblk(m)), dim3(WG), 0, s, ws, m, d_sigs + 96 * lo);
     }
@@ -1402,7 +1432,7 @@ extern "C" int mbls_sign_batch_device(mbls_ctx* c, const uint8_t* d_sks, const u
     // the four partial products [a_j] psi^j(H) (slots SIG, S) and their window tables (KREC..) are functions of the secret key
     HIPCHK(c, ws_wipe(c, MBLS_SLOT_SIG, MBLS_SLOT_SIG + 4, 4 * chunk, s));
     HIPCHK(c, ws_wipe(c, MBLS_SLOT_S, MBLS_SLOT_S + 6, 4 * chunk, s));
-    HIPCHK(c, ws_wipe(c, MBLS_SLOT_KREC, MBLS_SLOT_KREC + 48, 4 * chunk, s));
+    HIPCHK(c, ws_wipe(c, MBLS_SLOT_KREC, MBLS_SLOT_KREC + 48 + 6, 4 * chunk, s));        // the tables and (constant-time form) the record each window selected: 49..102
     return ws_release(c, s);
 }
 extern "C" int mbls_sign_batch(mbls_ctx* c, const uint8_t* sks, const uint8_t* msgs, uint32_t msg_len, uint64_t n, uint8_t* sigs) {
@@ -1435,6 +1465,7 @@ static int ensure_gtab(mbls_ctx* c) {
     c->d_gtab = tab; return MBLS_OK;
 }
 #define MBLS_SKPK_CHUNK 131072ull
+#define MBLS_SKPK_CT_CHUNK 32768ull          /* constant-time form: 64 selected records of 128 bytes per key are staged (256 MB per chunk) */
 extern "C" int mbls_sk_to_pk_batch_device(mbls_ctx* c, const uint8_t* d_sks, int fmt, uint64_t n, uint8_t* d_pks, void* stream) {
     if (!c || !d_sks || !d_pks || (fmt != 0 && fmt != 1)) return MBLS_ERR_ARGUMENT;
     mbls_lock lk(c->mu);
@@ -1442,25 +1473,45 @@ extern "C" int mbls_sk_to_pk_batch_device(mbls_ctx* c, const uint8_t* d_sks, int
     HIPCHK(c, hipSetDevice(c->device));
     hipStream_t s = (hipStream_t)stream;
     int rc = ensure_gtab(c); if (rc) return rc;
-    const uint64_t chunk = n < MBLS_SKPK_CHUNK ? n : MBLS_SKPK_CHUNK;
+    const bool ct = !c->secret_ops_fast;
+    const uint64_t cmax = ct ? MBLS_SKPK_CT_CHUNK : MBLS_SKPK_CHUNK;
+    const uint64_t chunk = n < cmax ? n : cmax;
     rc = mbls_ctx_reserve(c, chunk); if (rc) return rc;
     if (c->skidx_cap < chunk) {
         if (c->d_skidx) { (void)hipFree(c->d_skidx); c->d_skidx = nullptr; c->skidx_cap = 0; }
         HIPCHK(c, hipMalloc(&c->d_skidx, chunk * 64 * 4)); c->skidx_cap = chunk;
+    }
+    if (ct && c->sksel_cap < chunk) {
+        if (c->d_sksel) { (void)hipFree(c->d_sksel); c->d_sksel = nullptr; c->sksel_cap = 0; }
+        HIPCHK(c, hipMalloc(&c->d_sksel, chunk * 64 * MBLS_KEYREC_DWORDS * 4)); c->sksel_cap = chunk;
     }
     mbls_ws ws; ws.w = c->d_w; ws.stride = c->cap;
     rc = ws_acquire(c, s); if (rc) return rc;
     for (uint64_t lo = 0; lo < n; lo += chunk) {
         const uint64_t m = n - lo < chunk ? n - lo : chunk;
         HIPCHK(c, hipMemsetAsync(c->d_status, 0, 4 * m, s));
-        hipLaunchKernelGGL(k_sk_digits, dim3(nblk(m)), dim3(WG), 0, s, d_sks + 32 * lo, m, c->d_skidx);
-        hipLaunchKernelGGL(k_aggregate_indexed_d, dim3(nblk(m)), dim3(WG), 0, s, ws, (const uint32_t*)c->d_gtab, (uint64_t)1024, (const uint32_t*)c->d_skidx,
-                           (const uint32_t*)nullptr, 64u, MBLS_MODE_VERIFY, c->d_status, m);
+        if (ct) {
+            // the records are chosen by scan + selection (k_sk_select), the key sum then walks sel[64 i + j]: public indices, public addresses
+            hipLaunchKernelGGL(k_sk_select, dim3(nblk(64 * m)), dim3(WG), 0, s, d_sks + 32 * lo, m, (const uint32_t*)c->d_gtab, c->d_sksel, c->d_skidx);
+            hipLaunchKernelGGL(k_aggregate_indexed_d, dim3(nblk(m)), dim3(WG), 0, s, ws, (const uint32_t*)c->d_sksel, (uint64_t)(64 * m), (const uint32_t*)c->d_skidx,
+                               (const uint32_t*)nullptr, 64u, MBLS_MODE_VERIFY, c->d_status, m);
+        } else {
+            hipLaunchKernelGGL(k_sk_digits, dim3(nblk(m)), dim3(WG), 0, s, d_sks + 32 * lo, m, c->d_skidx);
+            hipLaunchKernelGGL(k_aggregate_indexed_d, dim3(nblk(m)), dim3(WG), 0, s, ws, (const uint32_t*)c->d_gtab, (uint64_t)1024, (const uint32_t*)c->d_skidx,
+                               (const uint32_t*)nullptr, 64u, MBLS_MODE_VERIFY, c->d_status, m);
+        }
         hipLaunchKernelGGL(k_apk_export_fmt, dim3(nblk(m)), dim3(WG), 0, s, ws, m, fmt, d_pks + (uint64_t)(fmt ? 96 : 48) * lo);
     }
     HIPCHK(c, hipGetLastError());
-    HIPCHK(c, hipMemsetAsync(c->d_skidx, 0, chunk * 64 * 4, s));            // the hexadecimal digits of the secret keys
+    if (ct) HIPCHK(c, hipMemsetAsync(c->d_sksel, 0, chunk * 64 * MBLS_KEYREC_DWORDS * 4, s));            // the selected multiples are functions of the keys
+    else HIPCHK(c, hipMemsetAsync(c->d_skidx, 0, chunk * 64 * 4, s));            // the hexadecimal digits of the secret keys
     return ws_release(c, s);
+}
+// 1: table lookups that depend on a secret key (the window tables of signing, the generator table of sk -> pk) go back to the faster forms that read ONE record
+// at an address computed from the key's digits -- for building test and bench inputs from throw-away keys only. 0 (default): scan + selection.
+extern "C" int mbls_ctx_set_secret_ops(mbls_ctx* c, int variable_time) {
+    if (!c) return MBLS_ERR_ARGUMENT;
+    mbls_lock lk(c->mu); c->secret_ops_fast = variable_time != 0; return MBLS_OK;
 }
 extern "C" int mbls_sk_to_pk_batch(mbls_ctx* c, const uint8_t* sks, int fmt, uint64_t n, uint8_t* pks) {
     if (!c || !sks || !pks || (fmt != 0 && fmt != 1)) return MBLS_ERR_ARGUMENT;

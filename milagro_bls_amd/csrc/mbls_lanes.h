@@ -258,6 +258,19 @@ MBLS_FN void g1_blind_d_call(const mbls_ws& ws, uint64_t i, uint32_t lane, uint6
 // verify_multiple's signature phase (reference src/aggregates.rs:274-276, :303) as one generated routine (tools/gen_tower_d.py g2_blind_routine): the
 // subgroup test of the signature in slots 3..6, then [r] sig by signed 4-bit windows into slots 25..30. Returns bit 0 = psi(P) = [x]P.
 extern "C" __device__ __attribute__((noinline, used, aligned(64))) void mbls_g2_blind_d_asm_fn() { asm volatile(MBLS_G2_BLIND_D_ASM); }
+// the same routine with CONSTANT-TIME table access (tools/gen_tower_d.py blind_scan_ct): every window reads all eight records of the lane's table and keeps its
+// own by selection -- what signing uses, where the scalar is a secret key (amcl's g2mul selects in constant time, reference src/signature.rs:17-21)
+extern "C" __device__ __attribute__((noinline, used, aligned(64))) void mbls_g2_blind_ct_d_asm_fn() { asm volatile(MBLS_G2_BLIND_CT_D_ASM); }
+MBLS_FN uint32_t g2_blind_ct_d_call(const mbls_ws& ws, uint64_t i, MBLS_LDS uint32_t* spill, uint32_t lane, uint64_t r, uint32_t skip_test = 0) {
+    const uint32_t addr = (uint32_t)(uintptr_t)(spill + lane);
+    const uint64_t gb = (uint64_t)(uintptr_t)ws.w + 4ull * (i - lane) - (uint64_t)(uint32_t)(uintptr_t)spill;
+    const uint32_t gb_lo = __builtin_amdgcn_readfirstlane((uint32_t)gb), gb_hi = __builtin_amdgcn_readfirstlane((uint32_t)(gb >> 32));
+    const uint32_t st4 = __builtin_amdgcn_readfirstlane((uint32_t)(ws.stride * 4));
+    uint32_t fl = skip_test, rlo = (uint32_t)r, rhi = (uint32_t)(r >> 32);
+    asm volatile(MBLS_ASM_CALL("mbls_g2_blind_ct_d_asm_fn") : "+{v251}"(fl), "+{v248}"(rlo), "+{v249}"(rhi) : "{v252}"(addr), "{s68}"(gb_lo), "{s69}"(gb_hi), "{s70}"(st4)
+                 : MBLS_G2_BLIND_D_ASM_CLOBBERS);
+    return fl;
+}
 MBLS_FN uint32_t g2_blind_d_call(const mbls_ws& ws, uint64_t i, MBLS_LDS uint32_t* spill, uint32_t lane, uint64_t r, uint32_t skip_test = 0) {
     const uint32_t addr = (uint32_t)(uintptr_t)(spill + lane);
     const uint64_t gb = (uint64_t)(uintptr_t)ws.w + 4ull * (i - lane) - (uint64_t)(uint32_t)(uintptr_t)spill;

@@ -1169,11 +1169,15 @@ def test_paired_fp_products_and_squarings():
 
 
 # ---------------------------------------------------------------------------------------------- the blinding routines of verify_multiple
-def _blind_run(kind, r, ws_init, out_slots):
+def _blind_run(kind, r, ws_init, out_slots, ct=False):
     """the instruction streams of g1_blind_routine / g2_blind_routine in their control order (the skeleton's loops mirrored here: table
     of 1 P .. 8 P, top digit, sixteen windows of four doublings + one table addition), returning the words left in out_slots"""
-    full, pieces, st = (t.g1_blind_routine if kind == "g1" else t.g2_blind_routine)()
+    full, pieces, st = t.g1_blind_routine() if kind == "g1" else t.g2_blind_routine(ct=ct)
     assert not any("scratch" in l or "buffer_" in l for l in full)
+    if ct:      # constant-time table access: no memory instruction takes its lane offset from anything but the item's own (LADDR), no per-lane record offset
+        mem = [l for l in full if l.startswith("global_")]
+        assert mem and all(("%s, s[74:75]" % t.LADDR in l) or (l.startswith("global_store") and l.split()[1].rstrip(",") == t.LADDR) for l in mem)
+        assert not any(t.VOFF in l.replace(",", " ").split() for l in full)
     m = miller_machine(0)
     m.v[248], m.v[249] = r & 0xFFFFFFFF, r >> 32
     for slot, x in ws_init.items():
@@ -1203,14 +1207,25 @@ def _blind_run(kind, r, ws_init, out_slots):
     m.run(pieces[start]); m.s[71] = 0; m.run(pieces[tab]); m.run(pieces["dbl"]); m.s[71] = m.s[72]; m.run(pieces[tab])
     for _ in range(6):
         add("add" if kind == "g1" else "madd"); m.s[71] += m.s[72]; m.run(pieces[tab])
-    m.run(pieces[inf]); m.run(pieces["top"]); add("addt")
+    def selected(e):
+        """ct: the scan left record e of the table in the BL_SEL slots, bit for bit"""
+        m.run(pieces["scan"])
+        assert [ws_get(m, t.BL_SEL + i) for i in range(6)] == [ws_get(m, t.BL_TAB + 6 * e + i) for i in range(6)]
+    m.run(pieces[inf]); m.run(pieces["top"])
+    if ct:
+        selected(0)
+    add("addt")
     for shift in range(60, -4, -4):
         for _ in range(4):
             m.run(pieces["dbl"])
         m.s[38] = shift
         m.run(pieces["digit"])
         d = ((rp >> shift) & 15) - 8
-        assert m.v[250] == LADDR + (max(abs(d), 1) - 1) * m.s[72]
+        if ct:
+            assert m.v[246] == max(abs(d), 1) - 1
+            selected(max(abs(d), 1) - 1)
+        else:
+            assert m.v[250] == LADDR + (max(abs(d), 1) - 1) * m.s[72]
         add("addt")
     m.run(pieces["epi"][:-1])
     return [ws_get(m, sl) for sl in out_slots], verdict
@@ -1252,3 +1267,19 @@ def test_g2_blinding_routine():
         assert verdict == M.subgroup_check_g2(pt)
         c = [w * ri % P for w in out]
         assert jac2_affine(M, (c[0], c[1]), (c[2], c[3]), (c[4], c[5])) == M.g2_mul(pt, r)
+
+
+def test_g2_blinding_routine_constant_time_table_access():
+    """the form signing uses (g2_blind_routine(ct=True), reference src/signature.rs:17-21 -- amcl's g2mul selects in constant time): every window reads all eight
+    table records and keeps its own by selection. Same [r] P as the model (digits 0, +-8, +-1 and random ones), the selected record checked bit for bit per window,
+    and no memory instruction of the routine takes a per-lane record offset."""
+    M = _g2m()
+    rng = random.Random(33)
+    ri = pow(R384, -1, P)
+    pt = M.g2_mul(M.G2, rng.randrange(1, M.R))
+    ws = {t.G2_SLOTS["SIG"] + i: c * R384 % P for i, c in enumerate((pt[0][0], pt[0][1], pt[1][0], pt[1][1]))}
+    for r in (rng.randrange(1, 1 << 64), 0x0807060504030201, 0xF00000000000000F):
+        out, verdict = _blind_run("g2", r, dict(ws), range(t.BL_OUT, t.BL_OUT + 6), ct=True)
+        assert verdict is True
+        c = [w * ri % P for w in out]
+        assert jac2_affine(M, (c[0], c[1]), (c[2], c[3]), (c[4], c[5])) == M.g2_mul(pt, r), hex(r)

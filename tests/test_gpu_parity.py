@@ -127,6 +127,39 @@ def test_sign_and_keys_external_vectors(mb, vectors):
     assert mb.sk_to_pk_batch(sk, n) == orc.batch_sk_to_pk(sk, n, 0, nthreads=8)
 
 
+def test_secret_key_paths_constant_time_and_variable_time_forms(mb, vectors):
+    """signing and sk -> pk look their tables up by scan + selection by default (include/mbls.h "SECRET KEYS ON THE DEVICE"; reference src/signature.rs:17-21,
+    src/keys.rs:124-137: amcl selects in constant time); mbls_ctx_set_secret_ops(1) restores the key-dependent addresses. Same bytes either way, equal to the
+    oracle's and to the Eth2 vectors -- edge scalars (zero / extreme window digits, the base-|x| split) included, across chunk boundaries of the staged selection."""
+    from milagro_bls_amd import _native as N
+    ctx = N.default_context()
+    rnd = random.Random(17)
+    y = 0xd201000000010000
+    edge = [1, 2, 15, 16, y - 1, y, y + 1, y * y, y ** 3 - 1, helpers.R - 1, 0, helpers.R, 2 ** 256 - 1, 0x8888888888888888888888888888888888888888888888888888888888888888,
+            0x0807060504030201080706050403020108070605040302010807060504030201, 0xf0f0f0f0f0f0f0f0f0f0f0f0f0f0f0f0f0f0f0f0f0f0f0f0f0f0f0f0f0f0f0f0]
+    n = len(edge) + 200
+    sk = b"".join(v.to_bytes(32, "big") for v in edge) + b"".join(rnd.randrange(1, helpers.R).to_bytes(32, "big") for _ in range(200))
+    msgs = rnd.randbytes(32 * n)
+    out = {}
+    try:
+        for vt in (False, True):
+            ctx.set_secret_ops(vt)
+            e = vectors["external"]["eth2_sign"]
+            assert mb.sign_batch(bytes.fromhex(e["sk"]), bytes.fromhex(e["msg"]), 1).hex() == e["sig"]
+            out[vt] = (mb.sign_batch(sk, msgs, n), mb.sk_to_pk_batch(sk, n, out_format=0), mb.sk_to_pk_batch(sk, n, out_format=1))
+    finally:
+        ctx.set_secret_ops(False)
+    assert out[False] == out[True]
+    assert out[False][0] == orc.batch_sign(sk, msgs, n, nthreads=8)
+    assert out[False][1] == orc.batch_sk_to_pk(sk, n, 0, nthreads=8) and out[False][2] == orc.batch_sk_to_pk(sk, n, 1, nthreads=8)
+    # more keys than one staged chunk of the constant-time sk -> pk (32 768 keys): the chunk boundary
+    m = 33000
+    skb = b"".join(((7919 * i + 1) % helpers.R).to_bytes(32, "big") for i in range(m))
+    got = mb.sk_to_pk_batch(skb, m, out_format=0)
+    pick = [0, 1, 32767, 32768, 32769, m - 1]
+    assert b"".join(got[48 * i:48 * i + 48] for i in pick) == orc.batch_sk_to_pk(b"".join(skb[32 * i:32 * i + 32] for i in pick), len(pick), 0, nthreads=4)
+
+
 def test_codec_parity(mb, vectors):
     ref = vectors["reference"]
     g1 = [bytes.fromhex(h) for h in ref["g1_compressed_round_trip"]["hex"]]

@@ -2578,13 +2578,13 @@ def sswu_formula(p, u, masks=None):
     return [xnum, p.mul2(y, ynum), p.add2(x, c2(p, ISO3_K))]
 
 
-def prog_g2_add(ad_slot, negate, table=False):
+def prog_g2_add(ad_slot, negate, table=False, table_kind="gv"):
     """acc <- acc +- (the point in slots ad_slot..ad_slot+5); the old acc goes to AGPR blocks 6..11 for the doubling case; masks M_H0,
     M_R0 (same x / same y), M_INF1, M_INF2 (an operand at infinity). table: the second operand is the record each LANE selects (kind
     'gv', register VOFF) of a table that starts at ad_slot, negated on the lanes of M_NEGQ and ignored (as if infinite) on those of M_ZEROQ."""
     p = Prog()
     A = pt_live_in(p, "a", 0)
-    Q = pt_live_in(p, "gv" if table else "gd", ad_slot)
+    Q = pt_live_in(p, table_kind if table else "gd", ad_slot)
     if table:
         Q = [Q[0], p.sel2(M_NEGQ, Q[1], p.neg2(Q[1])), Q[2]]
     if negate:
@@ -2618,6 +2618,7 @@ G2_SLOTS = dict(AD=19, P=31, T1=37, T2=13, T3=7, Q0=7, Q1=13, SIGAD=43, SIG=3, H
 # [r] sig of verify_multiple (g2_blind_routine): the table of 1..8 times the signature in slots 49..96 (the final exponentiation's records: not in
 # use while the signature phase runs), the result in the n-pairing paths' accumulator slots 25..30
 BL_TAB, BL_OUT = 49, 25
+BL_SEL = 97                          # constant-time form (signing): the record the window selected, copied here by a scan over all eight (slots 97..102)
 BL_FREE_V = list(range(9, 17))       # block 17 (v238..v251) belongs to the shell: v[248:249] the scalar, v247 its top digit, v250 = VOFF, v251 status
 M_NEGQ, M_ZEROQ = "s[94:95]", "s[36:37]"
 
@@ -2715,6 +2716,8 @@ def build_g2(which, ad_slot=None, free_v=None, pair_mode=False):
         p = prog_g2_add(ad_slot, which == "sub")
     elif which == "addt":
         p = prog_g2_add(BL_TAB, False, table=True)
+    elif which == "addt_ct":         # the constant-time form: the window's record was selected into BL_SEL by a scan over ALL records (blind_scan_ct)
+        p = prog_g2_add(BL_SEL, False, table=True, table_kind="gd")
     elif which == "madd":
         p = prog_g2_madd(ad_slot)
     elif which == "dbl":
@@ -2893,6 +2896,36 @@ BLIND_DIGIT = ["v_lshrrev_b64 v[246:247], s38, v[248:249]", "v_and_b32_e32 v246,
                "v_mul_lo_u32 v246, v246, s72", "v_add_u32_e32 %s, %s, v246" % (VOFF, LADDR)]
 
 
+# CONSTANT-TIME table access (signing: the scalar is a secret key). The variable-time form above reads ONE record at an address computed from the
+# window digit. Here every window reads ALL eight records of the lane's table in the same order and keeps the one it needs by selection
+# (v_cndmask on |digit| - 1 = v246): addresses, instruction stream and the number of memory operations do not depend on the scalar. The selected
+# record goes to slots BL_SEL.. of the lane's own item, where the table addition (build_g2 "addt_ct") fetches it like any other operand.
+BLIND_TOP_CT = BLIND_TOP[:2] + ["v_mov_b32_e32 v246, 0"]
+BLIND_DIGIT_CT = BLIND_DIGIT[:-2]                      # ... v246 = max(|d|, 1) - 1; no address arithmetic
+
+
+def blind_scan_ct(tab=None, sel=None, words=6):
+    """v246 = record index 0..7 per lane -> record (tab + 6 e .. + 5) of every e read, the lane's one written to sel.. (packed words, bit for bit).
+    Between the routine's programs nothing lives in VGPR blocks 0..6 (v0..v97): v0..v83 take records 1..7 of one slot, v84..v95 record 0 and the result."""
+    tab = BL_TAB if tab is None else tab
+    sel = BL_SEL if sel is None else sel
+    L = []
+    for w in range(words):
+        for e in range(8):
+            base = 84 if e == 0 else 12 * (e - 1)
+            L += seq_gaddr(tab + 6 * e + w)
+            for j in range(12):
+                L.append("global_load_dword v%d, %s, %s" % (base + j, LADDR, GADDR))
+                if j < 11:
+                    L += ["s_add_u32 s74, s74, %s" % GSTRIDE, "s_addc_u32 s75, s75, 0"]
+        L += ["s_waitcnt vmcnt(0)"]
+        for e in range(1, 8):
+            L += ["v_cmp_eq_u32_e64 vcc, %d, v246" % e]
+            L += ["v_cndmask_b32_e32 v%d, v%d, v%d, vcc" % (84 + j, 84 + j, 12 * (e - 1) + j) for j in range(12)]
+        L += seq_gstore(lambda j: "v%d" % (84 + j), sel + w) + ["s_waitcnt vmcnt(0)"]
+    return L
+
+
 def prog_g1_jadd(slot, table):
     """acc <- acc + (the Jacobian point in slots slot..slot+2; table: the record each lane selects, negated / ignored by M_NEGQ / M_ZEROQ):
     add-2007-bl with g1_add's case handling by selection; the old acc goes to AGPR blocks 5..7 for the doubling fix-up"""
@@ -3006,8 +3039,9 @@ def g1_blind_routine():
     return pro + main + expand_calls_d(epi) + ret + dbl4 + subs, pieces, st
 
 
-def g2_blind_routine():
-    """The signature phase of verify_multiple_aggregate_signatures (reference src/aggregates.rs:274-276, :303) as ONE routine: the subgroup
+def g2_blind_routine(ct=False):
+    """ct: the constant-time form used by signing (blind_scan_ct) -- same arithmetic, table records by scan + selection instead of by address.
+    The signature phase of verify_multiple_aggregate_signatures (reference src/aggregates.rs:274-276, :303) as ONE routine: the subgroup
     test psi(P) = [x]P of the decoded signature, then [r] P for the lane's 64-bit blinding scalar r by signed 4-bit windows:
     r + 0x8888888888888888 = sum e_j 16^j (+ a carry digit), r = sum (e_j - 8) 16^j + carry 2^64; the table 1 P .. 8 P lives in workspace
     records (BL_TAB, one per multiple) and each lane fetches ITS record (kind 'gv'); 64 doublings + 17 additions instead of 64 + 64.
@@ -3017,7 +3051,9 @@ def g2_blind_routine():
     S = G2_SLOTS
     B, st = {}, {}
     for nm in ["madd", "addt", "dbl", "fix", "s_start", "s_compare", "b_tab", "b_start", "b_inf"]:
-        B[nm], st[nm] = build_g2(nm, S["SIGAD"], free_v=BL_FREE_V)
+        B[nm], st[nm] = build_g2("addt_ct" if (ct and nm == "addt") else nm, S["SIGAD"], free_v=BL_FREE_V)
+    top, digit = (BLIND_TOP_CT, BLIND_DIGIT_CT) if ct else (BLIND_TOP, BLIND_DIGIT)
+    scan = blind_scan_ct() if ct else []
     X = lambda nm: expand_calls_d(B[nm])
     ADD, ADDT, LADDER, DBL4 = 50, 53, 52, 54
     pro = ["s_mov_b64 s[80:81], s[30:31]", "s_waitcnt vmcnt(0)"] + shell_constants() + ["s_mov_b64 %s, exec" % EXEC_ALL,
@@ -3051,9 +3087,9 @@ def g2_blind_routine():
     main += ["s_sub_u32 s79, s79, 1", "s_cmp_lg_u32 s79, 0", "s_cbranch_scc0 2f"] + far_back(5) + ["2:", "s_waitcnt vmcnt(0)"]
     # the windows, top digit (0 or 1) first
     main += X("b_inf")
-    main += BLIND_TOP + call_sub(ADDT)
+    main += top + scan + call_sub(ADDT)
     main += ["s_mov_b32 s38, 60", "5:"] + call_far(DBL4)
-    main += BLIND_DIGIT
+    main += digit + scan
     main += call_sub(ADDT)
     main += ["s_cmp_eq_u32 s38, 0", "s_cbranch_scc1 2f", "s_sub_u32 s38, s38, 4"] + far_back(5) + ["2:"]
     # [r] P -> slots 25..30, canonical words of the 2^384 domain
@@ -3068,7 +3104,7 @@ def g2_blind_routine():
             epi += seq_reduce(Bk) + seq_canonical(Bk) + seq_to32(Bk) + seq_gstore(Bk, BL_OUT + 2 * i + h)
     epi += ["s_waitcnt vmcnt(0)", "s_mov_b64 s[30:31], s[80:81]"]
     ret = ["s_setpc_b64 s[30:31]"]
-    pieces = dict(B, pro=pro, epi=epi, rprime=BLIND_RPRIME, top=BLIND_TOP, digit=BLIND_DIGIT)
+    pieces = dict(B, pro=pro, epi=epi, rprime=BLIND_RPRIME, top=top, digit=digit, scan=scan)
     return pro + main + expand_calls_d(epi) + ret + lad + dbl4 + subs, pieces, st
 
 
@@ -3127,6 +3163,9 @@ def main():
     full, pieces, st = g2_blind_routine()
     txt += emit("MBLS_G2_BLIND_D_ASM", full) + "\n"
     print("g2 blind routine", len(full), "lines; addt", len(pieces["addt"]), st["addt"])
+    full, pieces, st = g2_blind_routine(ct=True)
+    txt += emit("MBLS_G2_BLIND_CT_D_ASM", full) + "\n"
+    print("g2 blind routine, constant-time table access:", len(full), "lines; scan", len(pieces["scan"]))
     sgb = sgm.replace('"vcc"', ",".join('"s%d"' % i for i in [38] + list(range(50, 54)) + [71, 72] + list(range(79, 100))) + ',"vcc"')
     txt += "#define MBLS_G2_BLIND_D_ASM_CLOBBERS %s,%s, \\\n    %s\n" % (
         ",".join('"v%d"' % i for i in range(256) if i not in (248, 249, 251, 252) and i not in UNTOUCHED_V), ",".join('"a%d"' % i for i in range(252)), sgb)

@@ -18,23 +18,49 @@ import gen_fpd_asm as FD  # noqa: E402
 import gen_tower_d as TD  # noqa: E402
 
 
+# VALU classes by how their issue rate depends on occupancy (profiles/r02_ubench.txt, scripts/dbg/ubench.hip): "simple2" = plain 32-bit two-operand operations and
+# AGPR moves, which issue every ~2.3 clocks once TWO waves share a SIMD but every ~4.6 from one wave; "carry3" = everything else that is not a multiply-accumulate
+# (64-bit shifts / moves / adds, carry chains, three-operand VOP3 forms, v_mul_lo_u32, compares, selections, conversions): ~4.2-4.9 clocks at any occupancy, like the
+# multiply-accumulate itself. `valu` = mad_u64_u32 + carry3 + simple2.
+SIMPLE2 = ("v_and_b32", "v_or_b32", "v_xor_b32", "v_add_u32", "v_sub_u32", "v_subrev_u32", "v_mov_b32", "v_lshlrev_b32", "v_lshrrev_b32", "v_ashrrev_i32",
+           "v_accvgpr_read_b32", "v_accvgpr_write_b32", "v_max_i32", "v_min_i32", "v_max_u32", "v_min_u32", "v_not_b32", "v_add_f32", "v_mul_f32")
+
+
 def classify(lines):
-    c = dict(valu=0, mad_u64_u32=0, salu=0, lds=0)
+    c = dict(valu=0, mad_u64_u32=0, carry3=0, simple2=0, salu=0, lds=0, lds_only=0, global_mem=0)
     for l in lines:
         l = l.strip()
         if not l or l.startswith(".") or l.endswith(":") or l.startswith("CALL "):
             continue
+        op = l.split()[0]
+        base = op[:-4] if op.endswith(("_e32", "_e64")) else op
         if l.startswith("v_mad_u64_u32") or l.startswith("v_mad_i64_i32"):       # the 32 x 32 + 64 multiply-accumulate, either signedness
             c["mad_u64_u32"] += 1; c["valu"] += 1
         elif l.startswith("v_"):
             c["valu"] += 1
+            c["simple2" if base in SIMPLE2 else "carry3"] += 1
         elif l.startswith("ds_") or l.startswith("global_"):
             c["lds"] += 1                                                       # memory instructions (LDS and the workspace loads / stores)
+            c["lds_only" if l.startswith("ds_") else "global_mem"] += 1
         elif l.startswith("s_"):
             c["salu"] += 1
         else:
             raise ValueError(l)
     return c
+
+
+# What a second wave per SIMD could buy, COMPUTED from the class counts instead of guessed: clocks per wave-instruction with one wave / with two or more
+# (profiles/r02_ubench.txt; the multiply-accumulate in the scan pattern: scripts/dbg/icbench.hip) -- an upper bound that ignores what halving the registers and the
+# LDS space per wave would add in spill traffic.
+CLK_ONE_WAVE = dict(mad_u64_u32=4.4, carry3=4.7, simple2=4.6)
+CLK_TWO_WAVES = dict(mad_u64_u32=4.4, carry3=4.2, simple2=2.3)
+
+
+def two_wave_model(c):
+    t1 = sum(c[k] * CLK_ONE_WAVE[k] for k in CLK_ONE_WAVE)
+    t2 = sum(c[k] * CLK_TWO_WAVES[k] for k in CLK_TWO_WAVES)
+    return {"clocks_per_item_one_wave": round(t1), "clocks_per_item_two_waves": round(t2), "upper_bound_gain": round(1 - t2 / t1, 4),
+            "share_mad": round(c["mad_u64_u32"] / c["valu"], 4), "share_carry3": round(c["carry3"] / c["valu"], 4), "share_simple2": round(c["simple2"] / c["valu"], 4)}
 
 
 def add(a, b, times=1):
@@ -68,7 +94,7 @@ def main():
         routines["miller_d_" + k] = with_calls(pieces[k], leaf)
     _, gp, _ = TD.g2_dbl_d_routine()
     routines["g2_dbl_d"] = with_calls(gp["body"], leaf)
-    zero = dict(valu=0, mad_u64_u32=0, salu=0, lds=0)
+    zero = dict(valu=0, mad_u64_u32=0, carry3=0, simple2=0, salu=0, lds=0, lds_only=0, global_mem=0)
     km = add(add(add(zero, routines["miller_d_first"]), routines["miller_d_dbl"], 62), routines["miller_d_add01"], 5)
     km = add(add(km, routines["miller_d_pro"]), routines["miller_d_epi"])
     kf = zero
@@ -85,8 +111,12 @@ def main():
         for k in ("decode", "nxt", "step", "post"):
             ka = add(ka, routines["g1_sum_%s_%s" % (mode, k)], 128)
         per_item[kern] = ka
-    out = {"_note": "generated by tools/instr_census.py from tools/gen_fp_asm.py, gen_fpd_asm.py, gen_tower_d.py; calls expanded; cold compiler-scheduled paths excluded",
-           "routines": routines, "per_item": per_item}
+    out = {"_note": "generated by tools/instr_census.py from tools/gen_fp_asm.py, gen_fpd_asm.py, gen_tower_d.py; calls expanded; cold compiler-scheduled paths excluded; "
+                    "valu = mad_u64_u32 + carry3 + simple2, lds = lds_only + global_mem (classes: see the tool)",
+           "routines": routines, "per_item": per_item,
+           "two_wave_model": dict({k: two_wave_model(v) for k, v in per_item.items()},
+                                  _assumptions={"clocks_per_wave_instruction_one_wave": CLK_ONE_WAVE, "clocks_per_wave_instruction_two_or_more_waves": CLK_TWO_WAVES,
+                                                "source": "profiles/r02_ubench.txt, scripts/dbg/icbench.hip", "ignores": "spill traffic of a 256-register allocation"})}
     path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "instr_census.json")
     with open(path, "w") as f:
         json.dump(out, f, indent=1, sort_keys=True)
