@@ -633,7 +633,7 @@ def spawn_ranks(n, argv, stub=False, timeout_s=3600):
     environment), relay rank 0's JSON line, return the worst exit code. The parent never touches a GPU (torch.cuda.device_count() does not
     initialise one on this image) and never re-executes itself. Fewer devices than ranks, a rank that cannot start or a missing line is an
     error exit -- never a silent one-GPU run."""
-    if not stub:
+    if not stub and os.environ.get("MBLS_BENCH_SHARE_GPU") != "1":
         have = torch.cuda.device_count()
         if have < n:
             print("bench.py: --gpus %d but only %d device(s) visible" % (n, have), file=sys.stderr)
@@ -676,7 +676,7 @@ def spawn_ranks(n, argv, stub=False, timeout_s=3600):
     if line is None:
         print("bench.py: rank 0 printed no result line for %d GPUs (exit codes %s)" % (n, codes), file=sys.stderr)
         return worst or 7
-    print(line, flush=True)
+    emit_result(line)
     return worst
 
 
@@ -708,12 +708,30 @@ def stub_rank(args, rank, world):
     ok = ok and all(bool((recs[r * N.VM_PARTIAL_BYTES:(r + 1) * N.VM_PARTIAL_BYTES] == r + 1).all()) for r in range(world))
     ok = reduce_all_ok(ok, world)
     if rank == 0:
-        print(json.dumps({"metric": "fast_aggregate_verify/sec (128 pubkeys, 32B msg)", "stub": True, "value": n * world * args.steps / elapsed,
+        emit_result(json.dumps({"metric": "fast_aggregate_verify/sec (128 pubkeys, 32B msg)", "stub": True, "value": n * world * args.steps / elapsed,
                           "unit": "fast_aggregate_verify/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-                          "ms_per_step_per_rank": per_rank, "bitmap_matches_expectation": ok}), flush=True)
+                          "ms_per_step_per_rank": per_rank, "bitmap_matches_expectation": ok}))
     if world > 1:
         dist.barrier(); dist.destroy_process_group()
     return 0 if ok else 3
+
+
+_RESULT_FD = None
+
+
+def protect_stdout():
+    """stdout carries ONE JSON line (the driver parses it). Libraries under this process write to the C stdout as well -- RCCL prints a version banner when a
+    communicator is made, buffered until exit --, so file descriptor 1 is pointed at stderr for the whole run and the result line goes to the original one."""
+    global _RESULT_FD
+    if _RESULT_FD is None:
+        sys.stdout.flush()
+        _RESULT_FD = os.dup(1)
+        os.dup2(2, 1)
+
+
+def emit_result(line):
+    sys.stdout.flush()
+    os.write(_RESULT_FD if _RESULT_FD is not None else 1, (line + "\n").encode())
 
 
 def git_head():
@@ -788,6 +806,7 @@ def main():
     ap.add_argument("--stub", action="store_true", help="CPU test of the multi-rank plumbing only: gloo backend and a stand-in verifier; the line it prints is "
                                                          "labelled a stub and is not a measurement")
     args = ap.parse_args()
+    protect_stdout()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # no launcher: this process only starts the ranks (before anything here has touched a GPU) and relays rank 0's line
@@ -800,10 +819,18 @@ def main():
         sys.exit(5)
     if args.stub:
         sys.exit(stub_rank(args, rank, world))
+    # MBLS_BENCH_SHARE_GPU=1 (test mode, labelled in the line): every rank on device 0 and the gathers through gloo -- RCCL wants one rank per device, and the
+    # builder's GPU box has one; this runs the real verifier through the whole multi-rank path (per-rank inputs, gather, checks, reductions) without RCCL
+    share_gpu = world > 1 and os.environ.get("MBLS_BENCH_SHARE_GPU") == "1"
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if share_gpu:
+            local_rank = 0
+            torch.cuda.set_device(0)
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     else:
         torch.cuda.set_device(0)
     dev = torch.device("cuda", local_rank if world > 1 else 0)
@@ -970,6 +997,8 @@ def main():
             "input_build_s": t_in,
             "head": git_head(), "library_source_hash": library_source_hash(),
         }
+        if share_gpu:
+            out["share_gpu_test"] = "all %d ranks on ONE device, gathers through gloo: a functional test of the multi-rank path, not a scaling measurement" % world
         if not args.no_cpu_baseline and world == 1:
             allc, one, cfg1 = cpu_baseline(d_sigs, d_msgs, d_pks, expect, k, N.PK_UNCOMPRESSED)
             out["cpu_baseline"] = allc
@@ -977,7 +1006,7 @@ def main():
             out["cpu_config1"] = cfg1
         elif not args.no_cpu_baseline:
             out["cpu_baseline"] = None
-        print(json.dumps(out), flush=True)
+        emit_result(json.dumps(out))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -16,6 +16,7 @@
 #include <mutex>
 #include <vector>
 #include <dlfcn.h>
+#include <unistd.h>
 #include <rccl/rccl.h>        // types and enumerators only: the library itself is opened at run time (mbls_multi_create), never linked
 #include "mbls_ops.h"
 #include "mbls_coop.h"
@@ -2144,7 +2145,14 @@ static void multi_rccl_setup(mbls_multi* m, const int* device_ids, int G) {
     char why[160] = {};
     if (!rccl_open(&m->rccl, why, sizeof(why))) { snprintf(m->rccl_note, sizeof(m->rccl_note), "host join: %s", why); return; }
     m->comms.assign((size_t)G, nullptr);
+    // RCCL prints a version banner to the C stdout when the first communicator of a process is made. A verification library must not write to its host's
+    // stdout (a caller may be emitting a protocol there): descriptor 1 points at stderr while the communicator is set up, and what RCCL buffered is flushed there.
+    fflush(stdout);
+    const int saved = dup(1);
+    if (saved >= 0) (void)dup2(2, 1);
     const ncclResult_t r = m->rccl.CommInitAll(m->comms.data(), G, device_ids);
+    fflush(stdout);
+    if (saved >= 0) { (void)dup2(saved, 1); (void)close(saved); }
     if (r != ncclSuccess) {
         snprintf(m->rccl_note, sizeof(m->rccl_note), "host join: ncclCommInitAll failed: %s", m->rccl.GetErrorString(r)); m->comms.clear(); return;
     }

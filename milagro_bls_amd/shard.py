@@ -41,6 +41,12 @@ def all_gather_bitmap(local_words, world=None, out=None):
         return local_words
     if out is None:
         out = torch.empty(local_words.numel() * world, dtype=local_words.dtype, device=local_words.device)
+    if local_words.is_cuda and dist.get_backend() == "gloo":
+        # several ranks sharing ONE GPU (bench.py's MBLS_BENCH_SHARE_GPU test mode: RCCL wants one rank per device): gloo gathers host tensors
+        host = torch.empty(out.numel(), dtype=out.dtype)
+        dist.all_gather_into_tensor(host, local_words.cpu())
+        out.copy_(host)
+        return out
     dist.all_gather_into_tensor(out, local_words)
     return out
 

@@ -78,3 +78,27 @@ def test_config4_verify_multiple_2_14_sets_128_keys(env):
     rr = [int(x) for x in rands[:m].cpu().tolist()]
     assert orc.verify_multiple(sets, rr) is True
     assert batch.verify_multiple_sets_device(d_sigs.data_ptr(), d_pks.data_ptr(), d_msgs.data_ptr(), rands.data_ptr(), m, k, pk_format=N.PK_UNCOMPRESSED) is True
+
+
+def test_bench_two_ranks_sharing_the_gpu_real_verifier():
+    """bench.py's multi-rank path with the REAL verifier: two rank processes on this box's one GPU (MBLS_BENCH_SHARE_GPU=1: both on device 0, gathers through
+    gloo because RCCL wants one rank per device) -- per-rank inputs, the bitmap gather inside the step, the gathered-bitmap check, MAX / MIN reductions, the
+    launcher-free spawn -- and stdout carries exactly ONE line (libraries that print to the C stdout, like RCCL's banner, are kept off it)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, MBLS_BENCH_SHARE_GPU="1")
+    p = subprocess.run([sys.executable, os.path.join(helpers.ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--items", "4096",
+                        "--no-cpu-baseline", "--no-variants"], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["bitmap_matches_expectation"] is True and len(d["ms_per_step_per_rank"]) == 2 and "share_gpu_test" in d
+    # one rank, with the in-process multi-device leg (it makes an RCCL communicator): still one line on stdout
+    p = subprocess.run([sys.executable, os.path.join(helpers.ROOT, "bench.py"), "--steps", "1", "--warmup", "1", "--items", "4096", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1 and json.loads(lines[0])["n_gpus"] == 1
