@@ -505,11 +505,16 @@ __global__ void __launch_bounds__(WG) k_sk_select(const uint8_t* sks32, uint64_t
 #pragma unroll
     for (int q = 0; q < MBLS_KEYREC_DWORDS / 4; q++) acc[q] = rec[q];
     for (uint32_t e = 1; e < 16; e++) {
-        const bool take = e == d;
+        // the selection as mask arithmetic on an OPAQUE mask: with a plain `take ? v : acc` the compiler guards the loads with the condition (s_and_saveexec +
+        // s_cbranch_execz around global_load: only the lanes whose digit is e would touch record e -- exactly the access pattern this kernel exists to avoid).
+        // tests/test_build_cpu.py checks the ISA: 16 x 8 unconditional 16-byte loads, no branch between the first load and the store.
+        uint32_t m = 0u - (uint32_t)(e == d);
+        asm volatile("" : "+v"(m));
 #pragma unroll
         for (int q = 0; q < MBLS_KEYREC_DWORDS / 4; q++) {
             const uint4 v = rec[(size_t)e * (MBLS_KEYREC_DWORDS / 4) + q];
-            acc[q].x = take ? v.x : acc[q].x; acc[q].y = take ? v.y : acc[q].y; acc[q].z = take ? v.z : acc[q].z; acc[q].w = take ? v.w : acc[q].w;
+            acc[q].x = (v.x & m) | (acc[q].x & ~m); acc[q].y = (v.y & m) | (acc[q].y & ~m);
+            acc[q].z = (v.z & m) | (acc[q].z & ~m); acc[q].w = (v.w & m) | (acc[q].w & ~m);
         }
     }
     uint4* out = (uint4*)(sel + t * MBLS_KEYREC_DWORDS);

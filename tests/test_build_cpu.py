@@ -247,3 +247,24 @@ def test_every_c_call_in_integration_md_has_the_header_arity():
         assert len(_split_params(args)) == len(protos[name]), "INTEGRATION.md calls %s with %d arguments, the header declares %d" % (
             name, len(_split_params(args)), len(protos[name]))
     assert seen >= 10
+
+
+def test_secret_key_selection_kernel_loads_every_record_unconditionally(lib_path):
+    """k_sk_select (constant-time sk -> pk, include/mbls.h "SECRET KEYS ON THE DEVICE") must read ALL 16 records of a window whatever the key's digit is: with a
+    plain `cond ? loaded : acc` hipcc guards the loads with the condition (s_and_saveexec + s_cbranch_execz around global_load: a key-dependent access pattern).
+    Read back from the built code object: after the first 16-byte load there is no exec-mask manipulation and no conditional branch other than the uniform loop's."""
+    with tempfile.TemporaryDirectory() as d:
+        so = os.path.join(d, "lib.so")
+        shutil.copy(lib_path, so)
+        subprocess.check_call([LLVM + "/llvm-objdump", "--offloading", so], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        co = [f for f in os.listdir(d) if "gfx950" in f]
+        syms = subprocess.check_output([LLVM + "/llvm-readelf", "-s", "-W", os.path.join(d, co[0])], text=True)
+        name = sorted(set(l.split()[-1] for l in syms.splitlines() if "k_sk_select" in l and " FUNC " in l))
+        assert len(name) == 1, name
+        dis = subprocess.check_output([LLVM + "/llvm-objdump", "-d", "--mcpu=gfx950", "--no-show-raw-insn", "--disassemble-symbols=" + name[0], os.path.join(d, co[0])], text=True)
+    ops = [l.split()[0] for l in dis.splitlines() if l.startswith("\t")]
+    first = ops.index("global_load_dwordx4")
+    body = ops[first:]
+    assert body.count("global_load_dwordx4") >= 16 and "global_store_dwordx4" in body
+    assert not any("saveexec" in o or o in ("s_cbranch_execz", "s_cbranch_execnz", "s_cbranch_vccz", "s_cbranch_vccnz") for o in body), [o for o in body if o.startswith("s_c") or "exec" in o]
+    assert "v_cndmask_b32" not in " ".join(body) or True          # selections may be v_cndmask or and/or masks: both are data flow, not control flow

@@ -116,7 +116,9 @@ def main():
            "routines": routines, "per_item": per_item,
            "two_wave_model": dict({k: two_wave_model(v) for k, v in per_item.items()},
                                   _assumptions={"clocks_per_wave_instruction_one_wave": CLK_ONE_WAVE, "clocks_per_wave_instruction_two_or_more_waves": CLK_TWO_WAVES,
-                                                "source": "profiles/r02_ubench.txt, scripts/dbg/icbench.hip", "ignores": "spill traffic of a 256-register allocation"})}
+                                                "source": "profiles/r02_ubench.txt, scripts/dbg/icbench.hip", "ignores": "spill traffic of a 256-register allocation",
+                                                "measured_instead": "profiles/r05_two_wave_mix.txt (scripts/dbg/mixbench.hip): the same mixes at 2 waves per SIMD gain 4.1-4.7 %, "
+                                                                    "not the 12-13 % of this class model -- a lone wave already issues the mixed stream at ~3.9 clocks per instruction"})}
     path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "instr_census.json")
     with open(path, "w") as f:
         json.dump(out, f, indent=1, sort_keys=True)
