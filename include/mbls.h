@@ -324,7 +324,7 @@ int mbls_sig_check_batch(mbls_ctx* ctx, const uint8_t* in96, uint64_t n, uint8_t
  * [d 16^j] G1 of every window and keeps record d_j (k_sk_select) -- no address, no instruction stream and no memory-operation count depends on a key; the
  * scalar's other uses (digit extraction, sign / zero handling) are selections as well. mbls_ctx_set_secret_ops(ctx, 1) (environment MBLS_UNSAFE_SECRET_OPS
  * for new contexts) switches both to the faster forms that read ONE record at a key-dependent address -- for building test and bench inputs from throw-away
- * keys only (measured at 2^16: signing 14.5 instead of 15.3 ms, sk -> pk 0.87 instead of 2.15 ms). This is NOT a claim of resistance against power or fault analysis, and a GPU shared with an attacker's kernels
+ * keys only (measured at 2^16: signing 14.5 instead of 15.3 ms, sk -> pk 0.9 instead of 2.7 ms). This is NOT a claim of resistance against power or fault analysis, and a GPU shared with an attacker's kernels
  * is not a place for long-term keys either way. What the calls leave behind is wiped: the staged keys, the digit / selection buffers and the workspace slots
  * of the partial products and tables are zeroed on the stream before the call's workspace is released.
  * n x Signature::new / PublicKey::from_secret_key. Secret keys are NOT range-checked here: any 32-byte big-endian value gives [sk mod r] H(msg) /

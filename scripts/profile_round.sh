@@ -20,6 +20,10 @@ rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -o w -- $B --steps 
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU --output-format csv -d $OUT/sq -o s -- $B --steps 2 --warmup 1 > /dev/null 2> $OUT/sq.err
 rocprofv3 --pmc GRBM_GUI_ACTIVE --output-format csv -d $OUT/grbm -o g -- $B --steps 2 --warmup 1 > /dev/null 2> $OUT/grbm.err
 cd $ROOT
+# the traffic figures of THIS build into profiles/hbm_traffic.json (stamped with the library's source hash) before the bench line is taken: bench.py attaches them to
+# roofline.traffic only when the hash matches the library it loaded. (The same collection is repeated in the container on the merged files, for the commit.)
+echo '{}' > $OUT/bench_line.json
+python3 scripts/collect_profiles.py $TAG $OUT/stats $OUT/fetch $OUT/write $OUT/sq $OUT/bench_line.json > $OUT/collect_on_box.log 2>&1
 python3 bench.py --steps 10 --warmup 2 > $OUT/bench_line.json 2> $OUT/bench.err
 python3 bench.py --items 131072 --steps 5 --warmup 1 --no-cpu-baseline > $OUT/bench_line_131072.json 2>> $OUT/bench.err
 python3 scripts/latency.py $OUT/latency.json > $OUT/latency.log 2>&1
