@@ -554,12 +554,27 @@ def multi_handle_leg(lib, table, d_sigs, d_msgs, d_idx, expect, n, k, devices):
         for _ in range(3):
             t = time.perf_counter(); call(); ts.append(time.perf_counter() - t)
         t = float(np.median(ts))
+        # the handle's exchange step: the accept bitmap packed on every device and all-gathered BETWEEN the devices (native RCCL when the handle has a communicator:
+        # one rank on a one-GPU box, xGMI on a node), on a small batch of byte keys -- every device ends with the whole bitmap, the first one's copy is checked
+        nb = min(4096, n) * G
+        pk96 = keys96[idx[:nb].reshape(-1)].reshape(nb, -1)
+        words = np.zeros((nb + 63) // 64, dtype=np.uint64)
+
+        def gather():
+            m.check(lib.mbls_multi_fast_aggregate_verify_bitmap(m.handle, vp(sigs), vp(msgs), 32, None, vp(pk96), N.PK_UNCOMPRESSED, None, nb, k, vp(words), None))
+        gather()
+        tg = time.perf_counter(); gather(); tg = time.perf_counter() - tg
+        bits = np.unpackbits(words.view(np.uint8), bitorder="little")[:nb]
+        gathered_ok = bool((bits == want[:nb]).all())
+        note, active = m.exchange_note, m.rccl_active
         tab.close()
     finally:
         m.close()
     return {"devices": list(devices), "items": n * G, "ms_per_call": t * 1e3, "value": n * G / t, "unit": "fast_aggregate_verify/s",
             "what": "mbls_multi_fast_aggregate_verify_batch_indexed: one process, host buffers in, results out (PCIe included), %d items per device" % n,
-            "results_match": bool((res == want).all())}
+            "results_match": bool((res == want).all()) and gathered_ok,
+            "bitmap_gather": {"entry": "mbls_multi_fast_aggregate_verify_bitmap", "items": nb, "ms_per_call": tg * 1e3, "rccl_active": active, "exchange": note,
+                              "gathered_bitmap_matches": gathered_ok}}
 
 
 def config5_leg(ctx, lib, dev, sptr, rank, world, k):
