@@ -38,7 +38,7 @@ SIGNATURES = {
     "mbls_ctx_set_round_items": (C.c_int, [vp, C.c_uint64]),
     "mbls_ctx_reset_tuning": (C.c_int, [vp]),
     "mbls_ctx_set_lane_shaping": (C.c_int, [vp, C.c_uint64, C.c_uint64]),
-    "mbls_ctx_set_tracks": (C.c_int, [vp, C.c_uint64]),
+    "mbls_ctx_set_tracks": (C.c_int, [vp, C.c_uint64, C.c_uint64]),
     "mbls_ctx_set_secret_ops": (C.c_int, [vp, C.c_int]),
     "mbls_last_error": (C.c_char_p, [vp]),
     "mbls_fast_aggregate_verify_batch_device": (C.c_int, [vp, vp, vp, C.c_uint32, vp, vp, C.c_int, vp, C.c_uint64, C.c_uint32, vp, vp, vp, vp]),
@@ -190,9 +190,10 @@ class Context:
         """one-lane path below a full round: two lanes per item in the Miller phase up to split_max_items, front phases side by side up to fork_max_items"""
         self.check(lib().mbls_ctx_set_lane_shaping(self._h, split_max_items, fork_max_items))
 
-    def set_tracks(self, min_rest_items):
-        """batches of q rounds + r items with r >= min_rest_items: the last round + remainder as two halves side by side (0: never)"""
-        self.check(lib().mbls_ctx_set_tracks(self._h, min_rest_items))
+    def set_tracks(self, min_rest_items, side_max_items=16384):
+        """batches of q rounds + r items with r >= min_rest_items: the last round and the remainder on two tracks side by side -- the remainder beside the round
+        up to side_max_items, two equal halves above (min_rest_items = 0: never)"""
+        self.check(lib().mbls_ctx_set_tracks(self._h, min_rest_items, side_max_items))
 
     def set_secret_ops(self, variable_time):
         """False (default): signing / sk -> pk look their tables up by scan + selection (constant-time access); True: by key-dependent address (throw-away keys only)"""

@@ -690,6 +690,7 @@ struct mbls_ctx {
     uint64_t split_max_items = 32768, fork_max_items = 49152, hash2_max_items = 20480;
     // a batch of one to two rounds whose remainder over the round is at least tracks_min_rest items runs as two equal halves on two tracks (0: never)
     uint64_t tracks_min_rest = MBLS_DEFAULT_TRACKS_MIN_REST;
+    uint64_t tracks_side_max = 16384;  // remainders up to this many items run BESIDE the last round (a track of their own) instead of as one of two equal halves
     char err[256] = {};
 };
 struct mbls_keytable {
@@ -873,8 +874,9 @@ static void ctx_default_tuning(mbls_ctx* c) {
     if ((e = getenv("MBLS_FORK_MAX_ITEMS"))) c->fork_max_items = strtoull(e, nullptr, 10);
     if ((e = getenv("MBLS_HASH2_MAX_ITEMS"))) c->hash2_max_items = strtoull(e, nullptr, 10);
     c->secret_ops_fast = getenv("MBLS_UNSAFE_SECRET_OPS") != nullptr;
-    c->tracks_min_rest = MBLS_DEFAULT_TRACKS_MIN_REST;
+    c->tracks_min_rest = MBLS_DEFAULT_TRACKS_MIN_REST; c->tracks_side_max = c->round_items / 4;
     if ((e = getenv("MBLS_TRACKS_MIN_REST"))) c->tracks_min_rest = strtoull(e, nullptr, 10);
+    if ((e = getenv("MBLS_TRACKS_SIDE_MAX"))) c->tracks_side_max = strtoull(e, nullptr, 10);
 }
 extern "C" int mbls_ctx_reset_tuning(mbls_ctx* c) {
     if (!c) return MBLS_ERR_ARGUMENT;
@@ -890,7 +892,7 @@ extern "C" int mbls_ctx_set_round_items(mbls_ctx* c, uint64_t items) {
         HIPCHK(c, hipGetDeviceProperties(&prop, c->device));
         items = (uint64_t)prop.multiProcessorCount * 4 * WG;
     }
-    c->round_items = items; c->split_max_items = items / 2; c->fork_max_items = items / 4 * 3; c->hash2_max_items = items / 16 * 5; return MBLS_OK;
+    c->round_items = items; c->split_max_items = items / 2; c->fork_max_items = items / 4 * 3; c->hash2_max_items = items / 16 * 5; c->tracks_side_max = items / 4; return MBLS_OK;
 }
 // one-lane path: batches of up to split_max_items items walk their two Miller pairs on two lanes (never above half a round); up to
 // fork_max_items items the three front phases run side by side. Defaults: round / 2 and 3/4 of a round (measured: side by side costs 26.6 ms
@@ -1124,6 +1126,9 @@ static int verify_pipeline(mbls_ctx* c, const uint8_t* d_sigs, const uint8_t* d_
         return verify_pipeline_one(c, d_sigs, d_msgs, msg_len, d_moff, ks, n, k, mode, d_results, d_bitmap, d_status, s, part);
     const uint64_t r = n % R;
     const bool two = c->tracks_min_rest && r >= c->tracks_min_rest && (R + r) / 2 > c->split_max_items && (R + r) / 2 > c->coop_max_items;   // (halves that take one workspace item per item)
+    // SIDE mode (remainders up to tracks_side_max, default a quarter of a round): the last round on track 0 and the remainder -- on the lane-pair forms of its size --
+    // on track 1 beside it, instead of two equal halves: 71 680 ... 75 776 items 33.8 ms against 36.9 (scripts/dbg/rest_probe.py); above, equal halves win
+    const bool side = two && r <= c->tracks_side_max && r > c->coop_max_items;
     const uint64_t lo = two ? n - r - R : n - r;                 // the whole rounds in front: one launch per kernel
     int rc;
     if (!two) {
@@ -1131,21 +1136,26 @@ static int verify_pipeline(mbls_ctx* c, const uint8_t* d_sigs, const uint8_t* d_
         rc = verify_pipeline_one(c, d_sigs, d_msgs, msg_len, d_moff, ks, lo, k, mode, d_results, d_bitmap, d_status, s, 0); if (rc) return rc;
         return verify_pipeline_from(c, lo, d_sigs, d_msgs, msg_len, d_moff, ks, n, k, mode, d_results, d_bitmap, d_status, s);
     }
-    const uint64_t half = ((R + r) / 2 + WG - 1) / WG * WG, mid = lo + half;           // items [lo, mid) on track 0, [mid, n) on track 1 (cut at a bitmap word)
-    rc = mbls_ctx_reserve(c, lo > 2 * half ? lo : 2 * half); if (rc) return rc;       // (halves above half a round take one lane per item: no doubled workspace)
-    if (!ks.indexed && ks.fmt == MBLS_PK_COMPRESSED && !ks.d_off && k > 1) { rc = reserve_keys(c, (lo > 2 * half ? lo : 2 * half) * (uint64_t)k); if (rc) return rc; }
+    // items [lo, mid) on track 0, [mid, n) on track 1 (cut at a bitmap word); track 1's part of the workspace starts at item `half`
+    const uint64_t half = side ? R : ((R + r) / 2 + WG - 1) / WG * WG, mid = lo + half;
+    const uint64_t need = side ? R + 2 * r : 2 * half;           // (a remainder on lane pairs takes two workspace items per item; halves above half a round take one)
+    rc = mbls_ctx_reserve(c, lo > need ? lo : need); if (rc) return rc;
+    if (!ks.indexed && ks.fmt == MBLS_PK_COMPRESSED && !ks.d_off && k > 1) { rc = reserve_keys(c, (lo > need ? lo : need) * (uint64_t)k); if (rc) return rc; }
     if (lo) { rc = verify_pipeline_one(c, d_sigs, d_msgs, msg_len, d_moff, ks, lo, k, mode, d_results, d_bitmap, d_status, s, 0); if (rc) return rc; }
     rc = ws_acquire(c, s); if (rc) return rc;
     HIPCHK(c, hipEventRecord(c->t1_ev, s)); HIPCHK(c, hipStreamWaitEvent(c->t1_s, c->t1_ev, 0));
     track ta = track0(c); ta.ws_sync = false;
     // the halves' front phases side by side only while a half is at most 19/32 of a round and no round runs in front (scripts/dbg/tracks_probe.py: r = 6 144 ... 10 240
-    // 36.7 against 37.7 ms; r = 18 432 ... 30 720 in a row 38.0 ... 40.1 against 38.8 ... 42.0; behind a round 64.4 against 67.1 at r = 10 240 ... 20 480)
-    ta.fork_max = (lo == 0 && half <= R / 32 * 19) ? c->fork_max_items : 0;
+    // 36.7 against 37.7 ms; r = 18 432 ... 30 720 in a row 38.0 ... 40.1 against 38.8 ... 42.0; behind a round 64.4 against 67.1 at r = 10 240 ... 20 480); in side
+    // mode each part follows the rule of its own size
+    if (!side) ta.fork_max = (lo == 0 && half <= R / 32 * 19) ? c->fork_max_items : 0;
     track tb; tb.fork_max = ta.fork_max; tb.ws_off = half; tb.sb = c->t1_b; tb.sc = c->t1_c; tb.sd = c->t1_b; tb.ev2 = c->t1_ev2; tb.ev3 = c->t1_ev3; tb.ws_sync = false;
-    rc = verify_pipeline_from(c, mid, d_sigs, d_msgs, msg_len, d_moff, ks, n, k, mode, d_results, d_bitmap, d_status, c->t1_s, &tb);
-    if (!rc) {
-        keysrc kh = ks;      // items [lo, mid): the same cut with an upper end
-        rc = verify_pipeline_from(c, lo, d_sigs, d_msgs, msg_len, d_moff, kh, mid, k, mode, d_results, d_bitmap, d_status, s, &ta);
+    if (side) {          // the round first: its kernels fill the chip, the remainder's waves take what they leave between them
+        rc = verify_pipeline_from(c, lo, d_sigs, d_msgs, msg_len, d_moff, ks, mid, k, mode, d_results, d_bitmap, d_status, s, &ta);
+        if (!rc) rc = verify_pipeline_from(c, mid, d_sigs, d_msgs, msg_len, d_moff, ks, n, k, mode, d_results, d_bitmap, d_status, c->t1_s, &tb);
+    } else {
+        rc = verify_pipeline_from(c, mid, d_sigs, d_msgs, msg_len, d_moff, ks, n, k, mode, d_results, d_bitmap, d_status, c->t1_s, &tb);
+        if (!rc) rc = verify_pipeline_from(c, lo, d_sigs, d_msgs, msg_len, d_moff, ks, mid, k, mode, d_results, d_bitmap, d_status, s, &ta);
     }
     // join: the caller's stream ends when both tracks have (also on an error path: nothing of the call stays in flight unordered)
     hipError_t e1 = hipEventRecord(c->t1_ev, c->t1_s), e2 = hipStreamWaitEvent(s, c->t1_ev, 0);
@@ -1153,9 +1163,9 @@ static int verify_pipeline(mbls_ctx* c, const uint8_t* d_sigs, const uint8_t* d_
     HIPCHK(c, e1); HIPCHK(c, e2);
     return ws_release(c, s);
 }
-extern "C" int mbls_ctx_set_tracks(mbls_ctx* c, uint64_t min_rest_items) {
+extern "C" int mbls_ctx_set_tracks(mbls_ctx* c, uint64_t min_rest_items, uint64_t side_max_items) {
     if (!c) return MBLS_ERR_ARGUMENT;
-    mbls_lock lk(c->mu); c->tracks_min_rest = min_rest_items; return MBLS_OK;
+    mbls_lock lk(c->mu); c->tracks_min_rest = min_rest_items; c->tracks_side_max = side_max_items; return MBLS_OK;
 }
 extern "C" int mbls_fast_aggregate_verify_batch_device(mbls_ctx* c, const uint8_t* d_sigs, const uint8_t* d_msgs, uint32_t msg_len,
         const uint64_t* d_moff, const uint8_t* d_pks, int fmt, const uint32_t* d_off, uint64_t n, uint32_t k, uint8_t* d_results, uint64_t* d_bitmap,

@@ -185,22 +185,22 @@ def _device_call(N, ctx, dev, s, m, p, n, k, *, koff=None, moff=None, table=None
 
 
 def test_two_tracks_above_a_round_vs_oracle(mb, big):
-    """n = q rounds + r with r >= mbls_ctx_set_tracks' limit (default 6 144): the last round and the remainder run as two halves SIDE BY SIDE, each on its own part
-    of the workspace and its own streams (verify_pipeline). The oracle-checked items, tiled (items are independent, src/aggregates.rs:177-215): 73 728 and 100 000
-    items (two halves), 150 000 (a whole round in front of the halves), and 70 000 with the limit lowered (remainder 4 464) -- results, status words and bitmap
-    words of every item, through the device entry."""
+    """n = q rounds + r with r >= mbls_ctx_set_tracks' limit (default 6 144): the last round and the remainder run on two tracks SIDE BY SIDE, each on its own part
+    of the workspace and its own streams (verify_pipeline) -- the remainder beside the round up to a quarter of a round (73 728, 81 920 items; 150 000 with a whole
+    round in front), two equal halves above (100 000) or when the side mode is off. The oracle-checked items, tiled (items are independent,
+    src/aggregates.rs:177-215); 70 000 with the limit lowered (remainder 4 464) -- results, status words and bitmap words of every item, through the device entry."""
     import torch
     from milagro_bls_amd import _native as N
     ctx = N.default_context(); dev = torch.device("cuda:0")
     try:
-        for n, lim in ((73728, None), (100000, None), (150000, None), (70000, 4000)):
-            if lim:
-                ctx.set_tracks(lim)
+        for n, lim in ((73728, None), (81920, None), (100000, None), (150000, None), (70000, 4000), (73728, (6144, 0))):
+            if lim:                                  # (.., 0): no side mode -- 73 728 items as two equal halves; default: the remainder beside the round
+                ctx.set_tracks(*lim) if isinstance(lim, tuple) else ctx.set_tracks(lim)
             s, m, p = prefix(big, n)
             got, st, bits = _device_call(N, ctx, dev, s, m, p, n, big.k)
             check(big, got, st, n)
             assert bits == [int(x) for x in got]
-            ctx.set_tracks(0)                        # the same batch as rounds + remainder: identical status words
+            ctx.reset_tuning(); ctx.set_tracks(0)   # the same batch as rounds + remainder: identical status words
             got0, st0, _ = _device_call(N, ctx, dev, s, m, p, n, big.k)
             assert (got0, st0) == (got, st)
             ctx.reset_tuning()
@@ -210,14 +210,14 @@ def test_two_tracks_above_a_round_vs_oracle(mb, big):
 
 def test_two_tracks_with_small_rounds_every_layout(mb, big):
     """the two-track cut on small numbers (rounds of 128 items, limit 1, one lane per item): n = 300 = one round in front + halves of 128 and 44 items; n = 200 =
-    halves of 128 and 72 -- uniform keys, ragged keys + ragged messages through offset tables that do not start at 0, table indices, and 48-byte keys (the staged
+    halves of 128 and 72; the same with the remainder BESIDE the round (side mode: 44 items on lane pairs next to a round of 128) -- uniform keys, ragged keys + ragged messages through offset tables that do not start at 0, table indices, and 48-byte keys (the staged
     decompression buffer is cut like the workspace) -- against the oracle."""
     import torch
     from milagro_bls_amd import _native as N
     ctx = N.default_context(); dev = torch.device("cuda:0")
     try:
-        for n in (300, 200):
-            ctx.reset_tuning(); ctx.set_round_items(128); ctx.set_coop_max_items(0); ctx.set_coop_hash_max_items(0); ctx.set_tracks(1)
+        for n, side_max in ((300, 0), (200, 0), (300, 64), (172, 64)):          # halves (128 + 44 behind a round; 128 + 72) / the remainder beside the round (44 items, behind a round and not)
+            ctx.reset_tuning(); ctx.set_round_items(128); ctx.set_coop_max_items(0); ctx.set_coop_hash_max_items(0); ctx.set_tracks(1, side_max)
             s, m, p = prefix(big, n)
             got, st, bits = _device_call(N, ctx, dev, s, m, p, n, big.k)
             check(big, got, st, n); assert bits == [int(x) for x in got]
@@ -235,8 +235,10 @@ def test_two_tracks_with_small_rounds_every_layout(mb, big):
         b = helpers.make_batch(300, 3, fmt=0, seed=77, nthreads=8)
         want = orc.batch_fast_aggregate_verify(b.sigs, b.msgs, b.pks, b.n, b.k, 0, nthreads=8)
         assert want == b.expect
-        got, st, bits = _device_call(N, ctx, dev, b.sigs, b.msgs, b.pks, b.n, b.k, fmt=0)
-        assert got == want and bits == [int(x) for x in got]
+        for side_max in (0, 64):
+            ctx.set_tracks(1, side_max)
+            got, st, bits = _device_call(N, ctx, dev, b.sigs, b.msgs, b.pks, b.n, b.k, fmt=0)
+            assert got == want and bits == [int(x) for x in got]
     finally:
         ctx.reset_tuning()
 
