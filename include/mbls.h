@@ -98,8 +98,8 @@ int mbls_ctx_set_lane_shaping(mbls_ctx* ctx, uint64_t split_max_items, uint64_t 
 /* Batches above a round, n = q rounds + r items. r < min_rest_items: the remainder follows the rounds as a batch of its own (mbls_ctx_set_round_items).
  * r >= min_rest_items: after the q - 1 whole rounds in front, the LAST round and the remainder run on TWO TRACKS side by side -- each on its own part of the
  * workspace and its own streams, so that the SIMDs one leaves idle take waves of the other --: up to side_max_items the round on one track and the remainder (on
- * the lane-pair forms of its size) on the other, above it two equal halves of (round + r) / 2 items. Defaults 6 144 and a quarter of a round (measured: 73 728
- * items 40.0 -> 33.8 ms, 100 000 items 51.6 -> 46.5 ms); min_rest_items = 0: never. Same results, bit for bit (environment for new contexts:
+ * the lane-pair forms, whatever its size) on the other, above it two equal halves of (round + r) / 2 items. Defaults 3 584 and a quarter of a round (measured:
+ * 69 632 items 35.0 -> 33.7 ms, 73 728 items 40.0 -> 33.8 ms, 100 000 items 51.6 -> 46.5 ms); min_rest_items = 0: never. Same results, bit for bit (environment for new contexts:
  * MBLS_TRACKS_MIN_REST, MBLS_TRACKS_SIDE_MAX). */
 int mbls_ctx_set_tracks(mbls_ctx* ctx, uint64_t min_rest_items, uint64_t side_max_items);
 /* 0 (default): lookups that depend on a secret key are scans with selection; 1: the variable-time forms (see "SECRET KEYS ON THE DEVICE" below) */

@@ -645,7 +645,7 @@ __global__ void __launch_bounds__(WG) k_valu_bench(uint32_t* sink, uint32_t iter
 // needs 12.2-12.7 ms for anything up to a quarter of a round
 #define MBLS_DEFAULT_COOP_MAX_ITEMS 5120
 #define MBLS_DEFAULT_COOP_HASH_MAX_ITEMS 3584           /* above n / 4 + 2 n / 64 > 1 024 waves: the four-per-wave message phase needs a second round beside the key sums and the signatures (3 600 items 8.0 ms, 3 648 items 9.9 ms); the lane-pair form takes 8.8 - 9.0 */
-#define MBLS_DEFAULT_TRACKS_MIN_REST 6144
+#define MBLS_DEFAULT_TRACKS_MIN_REST 3584
 struct mbls_ctx {
     std::recursive_mutex mu;
     int device = 0;
@@ -742,8 +742,8 @@ static void coop_run(mbls_ctx* c, int prog, mbls_ws ws, uint64_t first_item, uin
 // but at most hash2_max_items (5/16 of a round: 2 n lanes for the messages beside n for the keys, with the signatures behind them, are still resident together; at a
 // third of a round and above the doubled message phase pushes the key sums behind it: 20 480 items 16.1 -> 14.6 ms, 21 845 items 16.3 -> 16.7); one wave per item
 // (or four items per wave) up to coop_hash_max_items -- the measured crossover, for every caller --; one lane per item otherwise
-static int hash_form(const mbls_ctx* c, uint64_t n, bool pair_ok) {
-    const bool waves = n <= c->coop_hash_max_items && n <= c->coop_max_items;
+static int hash_form(const mbls_ctx* c, uint64_t n, bool pair_ok, bool no_waves = false) {
+    const bool waves = !no_waves && n <= c->coop_hash_max_items && n <= c->coop_max_items;
     if (pair_ok && !waves && n <= c->split_max_items && n <= c->hash2_max_items) return HASH_FORM_PAIR;
     return waves ? HASH_FORM_WAVE : HASH_FORM_LANE;
 }
@@ -1000,6 +1000,8 @@ struct track {
     hipEvent_t ev2 = nullptr, ev3 = nullptr;
     bool ws_sync = true;              // order the pass against the workspace's previous user and record its own end (false: the caller does both around its tracks)
     uint64_t fork_max = ~0ull;        // front phases side by side up to this many items (~0: the context's fork_max_items)
+    bool no_waves = false;            // the pass stays on the lane kernels whatever its size (a remainder BESIDE a round: the wave engine's 40 KB-of-LDS waves would wait
+                                      // for SIMDs the round's 512-register waves hold, and its latency advantage is worth nothing next to a 26 ms round)
 };
 static track track0(mbls_ctx* c) { track t; t.sb = c->hs_b; t.sc = c->hs_c; t.sd = c->hs_d; t.ev2 = c->hs_ev2; t.ev3 = c->hs_ev3; return t; }
 static int verify_pipeline_one(mbls_ctx* c, const uint8_t* d_sigs, const uint8_t* d_msgs, uint32_t msg_len, const uint64_t* d_moff, const keysrc& ks,
@@ -1011,10 +1013,11 @@ static int verify_pipeline_one(mbls_ctx* c, const uint8_t* d_sigs, const uint8_t
     const bool have_keys = ks.indexed ? (ks.d_idx != nullptr) : (ks.d_pks != nullptr);
     if (!d_sigs || (!d_msgs && msg_len && !d_moff) || !d_results || (!have_keys && (k || d_off) && part != 1)) ARGFAIL(c, "null buffer");
     HIPCHK(c, hipSetDevice(c->device));
-    const bool split = n > c->coop_max_items && n <= c->split_max_items && 2 * n <= c->round_items;     // two lanes per item in the Miller phase
-    // (a batch whose pairing check runs on waves but whose message phase does not takes the lane-pair message phase too: 2 n items of workspace)
-    const bool hash_pairs = split || (n <= c->coop_max_items && n > c->coop_hash_max_items && n <= c->split_max_items && 4 * n <= c->round_items);
     const track tk = tkp ? *tkp : track0(c);
+    const uint64_t coop_max = tk.no_waves ? 0 : c->coop_max_items, coop_hash_max = tk.no_waves ? 0 : c->coop_hash_max_items;
+    const bool split = n > coop_max && n <= c->split_max_items && 2 * n <= c->round_items;     // two lanes per item in the Miller phase
+    // (a batch whose pairing check runs on waves but whose message phase does not takes the lane-pair message phase too: 2 n items of workspace)
+    const bool hash_pairs = split || (n <= coop_max && n > coop_hash_max && n <= c->split_max_items && 4 * n <= c->round_items);
     int rc = mbls_ctx_reserve(c, tk.ws_off + (hash_pairs ? 2 * n : n)); if (rc) return rc;        // (a pass on a second track finds its space reserved: no growth under the first)
     mbls_ws ws; ws.w = c->d_w + tk.ws_off; ws.stride = c->cap;
     uint32_t* st = d_status ? d_status : c->d_status + tk.ws_off;
@@ -1030,7 +1033,7 @@ static int verify_pipeline_one(mbls_ctx* c, const uint8_t* d_sigs, const uint8_t
     // part 1 / part 2 (host-buffer entry points): the signature and message phases are queued first (part 1, the keys may be
     // null), the caller then uploads the keys on another stream and makes this one wait, and part 2 queues the rest.
     const bool keys_later = part != 0;
-    const bool fused_sig = n > c->coop_max_items;     // one lane per item: the subgroup test of the signature comes out of the Miller loop, k_sig only decodes
+    const bool fused_sig = n > coop_max;     // one lane per item: the subgroup test of the signature comes out of the Miller loop, k_sig only decodes
     const bool fork = !tm && n <= (tk.fork_max == ~0ull ? c->fork_max_items : tk.fork_max);
     // (host-buffer entries: hs_b carries the key upload, so their signature phase has a stream of its own)
     // above a quarter of a round the three chains no longer fit the chip side by side (and the message phase runs on n lanes, its longest form): the
@@ -1048,7 +1051,7 @@ static int verify_pipeline_one(mbls_ctx* c, const uint8_t* d_sigs, const uint8_t
     }
     if (part == 1) {
         hipLaunchKernelGGL(k_sig, dim3(g), dim3(WG), 0, s_sig, ws, d_sigs, st, n, fused_sig ? 0 : 1);
-        launch_hash(c, ws, d_msgs, msg_len, d_moff, st, n, s_msg, hash_pairs);
+        launch_hash(c, ws, d_msgs, msg_len, d_moff, st, n, s_msg, hash_pairs, hash_form(c, n, hash_pairs, tk.no_waves));
         HIPCHK(c, hipGetLastError());
         return MBLS_OK;
     }
@@ -1064,13 +1067,13 @@ static int verify_pipeline_one(mbls_ctx* c, const uint8_t* d_sigs, const uint8_t
     if (tm) HIPCHK(c, hipEventRecord(c->ev[1], s));
     if (!keys_later) hipLaunchKernelGGL(k_sig, dim3(g), dim3(WG), 0, s_sig, ws, d_sigs, st, n, fused_sig ? 0 : 1);
     if (tm) HIPCHK(c, hipEventRecord(c->ev[2], s));
-    if (!keys_later) launch_hash(c, ws, d_msgs, msg_len, d_moff, st, n, s_msg, hash_pairs);
+    if (!keys_later) launch_hash(c, ws, d_msgs, msg_len, d_moff, st, n, s_msg, hash_pairs, hash_form(c, n, hash_pairs, tk.no_waves));
     if (tm) HIPCHK(c, hipEventRecord(c->ev[3], s));
     if (fork) {      // join
         if (s_sig != s) { HIPCHK(c, hipEventRecord(tk.ev2, s_sig)); HIPCHK(c, hipStreamWaitEvent(s, tk.ev2, 0)); }
         HIPCHK(c, hipEventRecord(tk.ev3, s_msg)); HIPCHK(c, hipStreamWaitEvent(s, tk.ev3, 0));
     }
-    if (n <= c->coop_max_items) {
+    if (n <= coop_max) {
         // small batch: one WAVE per item walks the Miller loop and the final exponentiation with its lanes side by side (mbls_coop.h)
         coop_run(c, (n > c->coop_pack_min_items && n <= c->coop_pack_max_items) ? COOP_PAIRING2X2 : COOP_PAIRING2, ws, (uint64_t)0, (uint64_t)1, (uint64_t)0, n, st, d_results, COOP_RES_ITEM, s);
         if (tm) { HIPCHK(c, hipEventRecord(c->ev[4], s)); HIPCHK(c, hipEventRecord(c->ev[5], s)); }
@@ -1126,9 +1129,10 @@ static int verify_pipeline(mbls_ctx* c, const uint8_t* d_sigs, const uint8_t* d_
         return verify_pipeline_one(c, d_sigs, d_msgs, msg_len, d_moff, ks, n, k, mode, d_results, d_bitmap, d_status, s, part);
     const uint64_t r = n % R;
     const bool two = c->tracks_min_rest && r >= c->tracks_min_rest && (R + r) / 2 > c->split_max_items && (R + r) / 2 > c->coop_max_items;   // (halves that take one workspace item per item)
-    // SIDE mode (remainders up to tracks_side_max, default a quarter of a round): the last round on track 0 and the remainder -- on the lane-pair forms of its size --
-    // on track 1 beside it, instead of two equal halves: 71 680 ... 75 776 items 33.8 ms against 36.9 (scripts/dbg/rest_probe.py); above, equal halves win
-    const bool side = two && r <= c->tracks_side_max && r > c->coop_max_items;
+    // SIDE mode (remainders up to tracks_side_max, default a quarter of a round): the last round on track 0 and the remainder -- on the lane-pair forms, whatever its
+    // size: no_waves -- on track 1 beside it, instead of two equal halves: 69 120 ... 76 000 items 33.7 ms against 34.5 ... 40 in a row and 36.9 as halves
+    // (scripts/dbg/rest_probe.py, rest_probe2.py); above a quarter of a round equal halves win
+    const bool side = two && r <= c->tracks_side_max && 4 * r <= R;
     const uint64_t lo = two ? n - r - R : n - r;                 // the whole rounds in front: one launch per kernel
     int rc;
     if (!two) {
@@ -1149,7 +1153,7 @@ static int verify_pipeline(mbls_ctx* c, const uint8_t* d_sigs, const uint8_t* d_
     // 36.7 against 37.7 ms; r = 18 432 ... 30 720 in a row 38.0 ... 40.1 against 38.8 ... 42.0; behind a round 64.4 against 67.1 at r = 10 240 ... 20 480); in side
     // mode each part follows the rule of its own size
     if (!side) ta.fork_max = (lo == 0 && half <= R / 32 * 19) ? c->fork_max_items : 0;
-    track tb; tb.fork_max = ta.fork_max; tb.ws_off = half; tb.sb = c->t1_b; tb.sc = c->t1_c; tb.sd = c->t1_b; tb.ev2 = c->t1_ev2; tb.ev3 = c->t1_ev3; tb.ws_sync = false;
+    track tb; tb.no_waves = side; tb.fork_max = ta.fork_max; tb.ws_off = half; tb.sb = c->t1_b; tb.sc = c->t1_c; tb.sd = c->t1_b; tb.ev2 = c->t1_ev2; tb.ev3 = c->t1_ev3; tb.ws_sync = false;
     if (side) {          // the round first: its kernels fill the chip, the remainder's waves take what they leave between them
         rc = verify_pipeline_from(c, lo, d_sigs, d_msgs, msg_len, d_moff, ks, mid, k, mode, d_results, d_bitmap, d_status, s, &ta);
         if (!rc) rc = verify_pipeline_from(c, mid, d_sigs, d_msgs, msg_len, d_moff, ks, n, k, mode, d_results, d_bitmap, d_status, c->t1_s, &tb);

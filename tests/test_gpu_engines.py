@@ -5,7 +5,7 @@ invariant. One seeded batch of 20 480 items x 2 keys is signed and verified by t
 Routing (milagro_bls_amd/csrc/mbls_kernels.hip, verify_pipeline / launch_hash): n <= 768 hashg2 + pairing2, (768, 1024] hashg2x4 + pairing2,
 (1024, 2048] hashg2x4 + pairing2x2, (2048, 3584] hashg2x4 + pairing2, (3584, 5120] k_hash2 (two lanes per message) + pairing2, (5120, 16384] k_hash2 (two lanes per message) + k_miller_split4 (four lanes per item: two per pair, products in pairs) + product + k_sig_verdict +
 k_final2 (two lanes per item: the compressed squarings split, the other products in pairs), (16384, 20480] k_hash2 + k_miller_split (two lanes per item) + k_final2, (20480, 32768] k_hash + k_miller_split + k_final2, above 32768 k_hash + k_miller (two-pair loop) + k_sig_verdict + k_final; in both lane forms the signature's subgroup test is read off the
-Miller loop's running point. Above a round (65 536 items) the remainder is routed as a batch of its own -- or, from 6 144 items up, the last round and the remainder run as two halves
+Miller loop's running point. Above a round (65 536 items) the remainder is routed as a batch of its own -- or, from 3 584 items up, the last round and the remainder run as two halves
 side by side on two tracks (device entries)."""
 import random
 
@@ -185,15 +185,15 @@ def _device_call(N, ctx, dev, s, m, p, n, k, *, koff=None, moff=None, table=None
 
 
 def test_two_tracks_above_a_round_vs_oracle(mb, big):
-    """n = q rounds + r with r >= mbls_ctx_set_tracks' limit (default 6 144): the last round and the remainder run on two tracks SIDE BY SIDE, each on its own part
+    """n = q rounds + r with r >= mbls_ctx_set_tracks' limit (default 3 584): the last round and the remainder run on two tracks SIDE BY SIDE, each on its own part
     of the workspace and its own streams (verify_pipeline) -- the remainder beside the round up to a quarter of a round (73 728, 81 920 items; 150 000 with a whole
     round in front), two equal halves above (100 000) or when the side mode is off. The oracle-checked items, tiled (items are independent,
-    src/aggregates.rs:177-215); 70 000 with the limit lowered (remainder 4 464) -- results, status words and bitmap words of every item, through the device entry."""
+    src/aggregates.rs:177-215); 69 632 (remainder 4 096: beside the round on lane pairs, not on waves), 67 000 with the limit lowered (remainder 1 464) -- results, status words and bitmap words of every item, through the device entry."""
     import torch
     from milagro_bls_amd import _native as N
     ctx = N.default_context(); dev = torch.device("cuda:0")
     try:
-        for n, lim in ((73728, None), (81920, None), (100000, None), (150000, None), (70000, 4000), (73728, (6144, 0))):
+        for n, lim in ((69632, None), (73728, None), (81920, None), (100000, None), (150000, None), (67000, 1000), (73728, (6144, 0))):
             if lim:                                  # (.., 0): no side mode -- 73 728 items as two equal halves; default: the remainder beside the round
                 ctx.set_tracks(*lim) if isinstance(lim, tuple) else ctx.set_tracks(lim)
             s, m, p = prefix(big, n)
