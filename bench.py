@@ -426,6 +426,22 @@ def other_configs(ctx, lib, dev, sptr):
                 lat[str(m)] = _med_ms(f_l)
                 assert bool(l_res.all().item())
             out["latency fast_aggregate_verify (128 keys) by batch size"] = lat
+        else:
+            # batches ABOVE a round (nn = 2^16 here): the two-track routes of verify_pipeline -- the remainder beside the last round, equal halves -- on the same
+            # items repeated (items are independent); every result checked
+            above = {}
+            for m in (69632, 73728, 100000, 150000):
+                rep = -(-m // nn)
+                b_s = v_sigs.repeat(rep, 1)[:m].contiguous(); b_m = v_msgs.repeat(rep, 1)[:m].contiguous(); b_p = v_pks.repeat(rep, 1, 1)[:m].contiguous()
+                b_res = torch.zeros(m, dtype=torch.uint8, device=dev)
+
+                def f_b():
+                    ctx.check(lib.mbls_fast_aggregate_verify_batch_device(ctx.handle, b_s.data_ptr(), b_m.data_ptr(), 32, None, b_p.data_ptr(), N.PK_UNCOMPRESSED, None, m, k,
+                                                                          b_res.data_ptr(), None, None, sptr))
+                t_b = _med_ms(f_b)
+                above[str(m)] = {"ms": t_b, "per_s": m / t_b * 1e3, "correct": bool(b_res.all().item())}
+                del b_s, b_m, b_p
+            out["batches above a round (two tracks), 128 keys"] = dict(above, correct=all(v["correct"] for v in above.values()))
     return out
 
 
