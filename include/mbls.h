@@ -105,6 +105,37 @@ int mbls_ctx_set_tracks(mbls_ctx* ctx, uint64_t min_rest_items, uint64_t side_ma
 /* 0 (default): lookups that depend on a secret key are scans with selection; 1: the variable-time forms (see "SECRET KEYS ON THE DEVICE" below) */
 int mbls_ctx_set_secret_ops(mbls_ctx* ctx, int variable_time);
 
+/* ---- routing, as data (pure functions: no GPU, no context) -------------------------------------------------
+ * Which kernels a batch of n items takes is decided by the limits above; mbls_plan_batch states the decision without running anything -- the SAME
+ * function the verification entries call (verify_pipeline), so the table in DESIGN.md section 5 is checkable on a machine without a GPU
+ * (tests/test_plan_cpu.py). mbls_default_limits fills the defaults for a device with round_items = CUs x 4 x 64 (65 536 on MI355X);
+ * mbls_ctx_get_limits reads a context's current ones (setters and environment applied). */
+typedef struct mbls_limits {
+    uint64_t round_items, coop_max_items, coop_hash_max_items, coop_pack_min_items, coop_pack_max_items, coop_hash_pack_min_items,
+             split_max_items, fork_max_items, hash2_max_items, tracks_min_rest, tracks_side_max;
+} mbls_limits;
+enum { MBLS_PAIRING_WAVE = 0,        /* one wave per item walks Miller loop + final exponentiation (program pairing2) */
+       MBLS_PAIRING_WAVE_X2 = 5,     /* ... two items per wave (pairing2x2) */
+       MBLS_PAIRING_LANE = 1,        /* one lane per item: k_miller (two-pair loop) + k_final -- the headline kernels */
+       MBLS_PAIRING_LANES2 = 2,      /* two lanes per item: k_miller_split + k_final2 */
+       MBLS_PAIRING_LANES4 = 4 };    /* four lanes per item in the Miller phase (k_miller_split4), two in the final exponentiation (k_final2) */
+enum { MBLS_MESSAGE_LANE = 1, MBLS_MESSAGE_LANES2 = 2, MBLS_MESSAGE_WAVE = 3, MBLS_MESSAGE_WAVE_X4 = 4 };   /* k_hash / k_hash2 / hashg2 / hashg2x4 */
+enum { MBLS_FRONT_IN_A_ROW = 0,      /* key sum -> signature -> message phase on one stream */
+       MBLS_FRONT_MESSAGE_BESIDE = 1,/* message phase on a side stream beside key sum -> signature */
+       MBLS_FRONT_ALL_BESIDE = 2 };  /* all three side by side */
+typedef struct mbls_pass_plan {      /* one pass of the pipeline over a contiguous range of items */
+    uint64_t first_item, items, workspace_first, workspace_items;
+    uint32_t track;                  /* 0: the caller's stream; 1: the second track, side by side with track 0 of the same stage */
+    uint32_t stage;                  /* passes of one stage run side by side, stages one after the other */
+    uint32_t pairing, message, front, sig_subgroup_from_miller_loop;
+} mbls_pass_plan;
+enum { MBLS_BATCH_ONE_PASS = 0, MBLS_BATCH_ROUNDS_THEN_REST = 1, MBLS_BATCH_ROUND_BESIDE_REST = 2, MBLS_BATCH_TWO_HALVES = 3 };
+typedef struct mbls_batch_plan { uint32_t mode, n_passes; mbls_pass_plan pass[3]; } mbls_batch_plan;
+void mbls_default_limits(uint64_t round_items, mbls_limits* out);
+int mbls_ctx_get_limits(mbls_ctx* ctx, mbls_limits* out);
+/* the plan of mbls_fast_aggregate_verify_batch[_indexed]_device / mbls_verify_batch_device for n items (MBLS_ERR_ARGUMENT for n = 0 or null pointers) */
+int mbls_plan_batch(const mbls_limits* limits, uint64_t n, mbls_batch_plan* out);
+
 /* ---- the hot path -------------------------------------------------------------------------------------
  * Batch of n independent AggregateSignature::fast_aggregate_verify calls (reference src/aggregates.rs:177-215):
  * item i = (sigs[96 i..], its message, its public keys). The reference takes any `msg: &[u8]` per call: messages are

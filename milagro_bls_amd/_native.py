@@ -27,6 +27,46 @@ u8p = C.POINTER(C.c_uint8)
 u32p = C.POINTER(C.c_uint32)
 u64p = C.POINTER(C.c_uint64)
 vp = C.c_void_p
+class Limits(C.Structure):
+    """include/mbls.h mbls_limits"""
+    _fields_ = [(n, C.c_uint64) for n in ("round_items", "coop_max_items", "coop_hash_max_items", "coop_pack_min_items", "coop_pack_max_items", "coop_hash_pack_min_items",
+                                          "split_max_items", "fork_max_items", "hash2_max_items", "tracks_min_rest", "tracks_side_max")]
+
+
+class PassPlan(C.Structure):
+    """include/mbls.h mbls_pass_plan"""
+    _fields_ = [(n, C.c_uint64) for n in ("first_item", "items", "workspace_first", "workspace_items")] + \
+               [(n, C.c_uint32) for n in ("track", "stage", "pairing", "message", "front", "sig_subgroup_from_miller_loop")]
+
+
+class BatchPlan(C.Structure):
+    """include/mbls.h mbls_batch_plan"""
+    _fields_ = [("mode", C.c_uint32), ("n_passes", C.c_uint32), ("passes", PassPlan * 3)]
+
+
+PAIRING_WAVE, PAIRING_LANE, PAIRING_LANES2, PAIRING_LANES4, PAIRING_WAVE_X2 = 0, 1, 2, 4, 5
+MESSAGE_LANE, MESSAGE_LANES2, MESSAGE_WAVE, MESSAGE_WAVE_X4 = 1, 2, 3, 4
+FRONT_IN_A_ROW, FRONT_MESSAGE_BESIDE, FRONT_ALL_BESIDE = 0, 1, 2
+BATCH_ONE_PASS, BATCH_ROUNDS_THEN_REST, BATCH_ROUND_BESIDE_REST, BATCH_TWO_HALVES = 0, 1, 2, 3
+
+
+def default_limits(round_items=65536):
+    """the library's default routing limits for a device whose round is round_items lanes (pure: no GPU)"""
+    L = Limits()
+    lib().mbls_default_limits(round_items, C.byref(L))
+    return L
+
+
+def plan_batch(n, limits=None):
+    """what mbls_fast_aggregate_verify_batch_device would do with n items under `limits` (pure: no GPU) -> (mode, [pass dicts])"""
+    L = limits if limits is not None else default_limits()
+    b = BatchPlan()
+    rc = lib().mbls_plan_batch(C.byref(L), n, C.byref(b))
+    if rc != OK:
+        raise MblsError(rc, "mbls_plan_batch")
+    return b.mode, [{f: getattr(b.passes[i], f) for f, _ in PassPlan._fields_} for i in range(b.n_passes)]
+
+
 SIGNATURES = {
     "mbls_ctx_create": (C.c_int, [C.POINTER(vp), C.c_int]),
     "mbls_ctx_destroy": (None, [vp]),
@@ -40,6 +80,9 @@ SIGNATURES = {
     "mbls_ctx_set_lane_shaping": (C.c_int, [vp, C.c_uint64, C.c_uint64]),
     "mbls_ctx_set_tracks": (C.c_int, [vp, C.c_uint64, C.c_uint64]),
     "mbls_ctx_set_secret_ops": (C.c_int, [vp, C.c_int]),
+    "mbls_default_limits": (None, [C.c_uint64, vp]),
+    "mbls_ctx_get_limits": (C.c_int, [vp, vp]),
+    "mbls_plan_batch": (C.c_int, [vp, C.c_uint64, vp]),
     "mbls_last_error": (C.c_char_p, [vp]),
     "mbls_fast_aggregate_verify_batch_device": (C.c_int, [vp, vp, vp, C.c_uint32, vp, vp, C.c_int, vp, C.c_uint64, C.c_uint32, vp, vp, vp, vp]),
     "mbls_fast_aggregate_verify_batch": (C.c_int, [vp, vp, vp, C.c_uint32, vp, vp, C.c_int, vp, C.c_uint64, C.c_uint32, vp, vp]),
@@ -194,6 +237,12 @@ class Context:
         """batches of q rounds + r items with r >= min_rest_items: the last round and the remainder on two tracks side by side -- the remainder beside the round
         up to side_max_items, two equal halves above (min_rest_items = 0: never)"""
         self.check(lib().mbls_ctx_set_tracks(self._h, min_rest_items, side_max_items))
+
+    def limits(self):
+        """the context's current routing limits (setters and environment applied)"""
+        L = Limits()
+        self.check(lib().mbls_ctx_get_limits(self._h, C.byref(L)))
+        return L
 
     def set_secret_ops(self, variable_time):
         """False (default): signing / sk -> pk look their tables up by scan + selection (constant-time access); True: by key-dependent address (throw-away keys only)"""

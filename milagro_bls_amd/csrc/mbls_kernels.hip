@@ -992,6 +992,94 @@ static int table_acquire(mbls_ctx* c, const mbls_keytable* t, hipStream_t s) {
     return MBLS_OK;
 }
 
+// ---- routing as data (include/mbls.h, mbls_plan_batch): the decisions of the verification pipeline as pure functions of the limits and the batch size. The
+// pipeline below acts on exactly these structures, so what mbls_plan_batch reports is what runs.
+static mbls_limits ctx_limits(const mbls_ctx* c) {
+    mbls_limits L;
+    L.round_items = c->round_items; L.coop_max_items = c->coop_max_items; L.coop_hash_max_items = c->coop_hash_max_items;
+    L.coop_pack_min_items = c->coop_pack_min_items; L.coop_pack_max_items = c->coop_pack_max_items; L.coop_hash_pack_min_items = c->coop_hash_pack_min_items;
+    L.split_max_items = c->split_max_items; L.fork_max_items = c->fork_max_items; L.hash2_max_items = c->hash2_max_items;
+    L.tracks_min_rest = c->tracks_min_rest; L.tracks_side_max = c->tracks_side_max;
+    return L;
+}
+extern "C" void mbls_default_limits(uint64_t round_items, mbls_limits* out) {
+    if (!out) return;
+    if (!round_items) round_items = 65536;
+    out->round_items = round_items; out->coop_max_items = MBLS_DEFAULT_COOP_MAX_ITEMS; out->coop_hash_max_items = MBLS_DEFAULT_COOP_HASH_MAX_ITEMS;
+    out->coop_pack_min_items = 1024; out->coop_pack_max_items = 2048; out->coop_hash_pack_min_items = 768;
+    out->split_max_items = round_items / 2; out->fork_max_items = round_items / 4 * 3; out->hash2_max_items = round_items / 16 * 5;
+    out->tracks_min_rest = MBLS_DEFAULT_TRACKS_MIN_REST; out->tracks_side_max = round_items / 4;
+}
+// one pass over n items. no_waves: the pass stays on the lane kernels (a remainder beside a round); fork_max: front phases side by side up to this many items
+// (~0: the limits' own); keys_later: the host entries' two-part form (their signature phase always has a stream of its own)
+static void plan_pass(const mbls_limits& L, uint64_t n, bool no_waves, uint64_t fork_max, bool keys_later, bool timing, mbls_pass_plan* p) {
+    const uint64_t coop_max = no_waves ? 0 : L.coop_max_items, coop_hash_max = no_waves ? 0 : L.coop_hash_max_items;
+    const bool split = n > coop_max && n <= L.split_max_items && 2 * n <= L.round_items;       // two lanes per item in the Miller phase
+    // (a batch whose pairing check runs on waves but whose message phase does not takes the lane-pair message phase too: 2 n items of workspace)
+    const bool hash_pairs = split || (n <= coop_max && n > coop_hash_max && n <= L.split_max_items && 4 * n <= L.round_items);
+    p->items = n; p->workspace_items = hash_pairs ? 2 * n : n;
+    if (n <= coop_max) p->pairing = (n > L.coop_pack_min_items && n <= L.coop_pack_max_items) ? MBLS_PAIRING_WAVE_X2 : MBLS_PAIRING_WAVE;
+    else if (split) p->pairing = 4 * n <= L.round_items ? MBLS_PAIRING_LANES4 : MBLS_PAIRING_LANES2;
+    else p->pairing = MBLS_PAIRING_LANE;
+    // the message phase: lane pairs (k_hash2) where 2 n workspace items are there and the batch is above the wave engine's range but at most hash2_max_items (5/16 of
+    // a round: 2 n lanes for the messages beside n for the keys, with the signatures behind them, are still resident together; at a third of a round and above the
+    // doubled message phase pushes the key sums behind it: 20 480 items 16.1 -> 14.6 ms, 21 845 items 16.3 -> 16.7); one wave per item (four items per wave above the
+    // packing limit) up to coop_hash_max_items -- the measured crossover, for every caller --; one lane per item otherwise
+    const bool waves = n <= coop_hash_max && n <= coop_max;
+    if (hash_pairs && !waves && n <= L.split_max_items && n <= L.hash2_max_items) p->message = MBLS_MESSAGE_LANES2;
+    else if (waves) p->message = n > L.coop_hash_pack_min_items ? MBLS_MESSAGE_WAVE_X4 : MBLS_MESSAGE_WAVE;
+    else p->message = MBLS_MESSAGE_LANE;
+    p->sig_subgroup_from_miller_loop = n > coop_max ? 1u : 0u;     // one lane (or lane pairs) per item: the signature's subgroup test comes out of the Miller loop
+    const bool fork = !timing && n <= (fork_max == ~0ull ? L.fork_max_items : fork_max);
+    // above a quarter of a round the three chains no longer fit the chip side by side (and the message phase runs on n lanes, its longest form): the signature
+    // phase -- the shortest -- then follows the key sum on the caller's stream, beside the message phase: 32 768 items 17.1 -> 16.5 ms
+    const bool sig_side = fork && (keys_later || 4 * n <= L.round_items);
+    p->front = !fork ? MBLS_FRONT_IN_A_ROW : sig_side ? MBLS_FRONT_ALL_BESIDE : MBLS_FRONT_MESSAGE_BESIDE;
+}
+// The batch as the caller sees it. n = q rounds + r items (0 < r < round): a batch of q rounds + r items would cost q + 1 rounds of every kernel, so
+//   r < tracks_min_rest: the q rounds as one launch per kernel, then the r items as a batch of their own that takes the route of its size (wave engine up to coop_max_items);
+//   r >= tracks_min_rest: the q - 1 rounds in front, then the LAST round and the remainder on TWO TRACKS side by side, each with its own part of the workspace and its
+//   own streams, so that the SIMDs one leaves idle take waves of the other -- up to tracks_side_max (and a quarter of a round) the round on track 0 and the remainder,
+//   on the lane-pair forms whatever its size, on track 1 (69 120 ... 76 000 items 33.7 ms against 34.5 ... 40 in a row; scripts/dbg/rest_probe.py, rest_probe2.py),
+//   above it two equal halves of (R + r) / 2 items (100 000 items 51.6 -> 46.5 ms; scripts/dbg/tracks_probe.py).
+// (The phase timers describe a single pass: no cut while they are on -- the caller passes one_pass.)
+static void plan_batch(const mbls_limits& L, uint64_t n, bool one_pass, bool timing, mbls_batch_plan* b) {
+    memset(b, 0, sizeof(*b));
+    const uint64_t R = L.round_items;
+    auto pass = [&](int i, uint64_t first, uint64_t items, uint32_t stage, uint32_t trk, uint64_t ws_first, bool no_waves, uint64_t fork_max) {
+        plan_pass(L, items, no_waves, fork_max, false, timing, &b->pass[i]);
+        b->pass[i].first_item = first; b->pass[i].stage = stage; b->pass[i].track = trk; b->pass[i].workspace_first = ws_first;
+    };
+    if (one_pass || !R || n <= R || n % R == 0) { b->mode = MBLS_BATCH_ONE_PASS; b->n_passes = 1; pass(0, 0, n, 0, 0, 0, false, ~0ull); return; }
+    const uint64_t r = n % R;
+    const bool two = L.tracks_min_rest && r >= L.tracks_min_rest && (R + r) / 2 > L.split_max_items && (R + r) / 2 > L.coop_max_items;   // (halves take one workspace item per item)
+    if (!two) {
+        b->mode = MBLS_BATCH_ROUNDS_THEN_REST; b->n_passes = 2;
+        pass(0, 0, n - r, 0, 0, 0, false, ~0ull); pass(1, n - r, r, 1, 0, 0, false, ~0ull);
+        return;
+    }
+    const bool side = r <= L.tracks_side_max && 4 * r <= R;
+    const uint64_t lo = n - r - R;                                   // the whole rounds in front: one launch per kernel
+    const uint64_t half = side ? R : ((R + r) / 2 + WG - 1) / WG * WG;   // items [lo, lo + half) on track 0, the rest on track 1 (cut at a bitmap word)
+    int i = 0; uint32_t stage = 0;
+    if (lo) { pass(i++, 0, lo, stage++, 0, 0, false, ~0ull); }
+    b->mode = side ? MBLS_BATCH_ROUND_BESIDE_REST : MBLS_BATCH_TWO_HALVES;
+    // the halves' front phases side by side only while a half is at most 19/32 of a round and no round runs in front (scripts/dbg/tracks_probe.py: r = 6 144 ... 10 240
+    // 36.7 against 37.7 ms; r = 18 432 ... 30 720 in a row 38.0 ... 40.1 against 38.8 ... 42.0; behind a round 64.4 against 67.1 at r = 10 240 ... 20 480); in side
+    // mode each part follows the rule of its own size
+    const uint64_t fm = side ? ~0ull : ((lo == 0 && half <= R / 32 * 19) ? L.fork_max_items : 0);
+    pass(i++, lo, half, stage, 0, 0, false, fm);
+    pass(i++, lo + half, n - lo - half, stage, 1, half, side, fm);
+    b->n_passes = (uint32_t)i;
+}
+extern "C" int mbls_plan_batch(const mbls_limits* limits, uint64_t n, mbls_batch_plan* out) {
+    if (!limits || !out || !n) return MBLS_ERR_ARGUMENT;
+    plan_batch(*limits, n, false, false, out); return MBLS_OK;
+}
+extern "C" int mbls_ctx_get_limits(mbls_ctx* c, mbls_limits* out) {
+    if (!c || !out) return MBLS_ERR_ARGUMENT;
+    mbls_lock lk(c->mu); *out = ctx_limits(c); return MBLS_OK;
+}
 // A TRACK = what one pass of the pipeline owns besides the caller's stream: where its items start in the workspace (and in the status words / key staging that go
 // with it), the side streams of its front phases and the events that join them. Track 0 is the context's own set; verify_pipeline runs a second one beside it.
 struct track {
@@ -1014,15 +1102,17 @@ static int verify_pipeline_one(mbls_ctx* c, const uint8_t* d_sigs, const uint8_t
     if (!d_sigs || (!d_msgs && msg_len && !d_moff) || !d_results || (!have_keys && (k || d_off) && part != 1)) ARGFAIL(c, "null buffer");
     HIPCHK(c, hipSetDevice(c->device));
     const track tk = tkp ? *tkp : track0(c);
-    const uint64_t coop_max = tk.no_waves ? 0 : c->coop_max_items, coop_hash_max = tk.no_waves ? 0 : c->coop_hash_max_items;
-    const bool split = n > coop_max && n <= c->split_max_items && 2 * n <= c->round_items;     // two lanes per item in the Miller phase
-    // (a batch whose pairing check runs on waves but whose message phase does not takes the lane-pair message phase too: 2 n items of workspace)
-    const bool hash_pairs = split || (n <= coop_max && n > coop_hash_max && n <= c->split_max_items && 4 * n <= c->round_items);
-    int rc = mbls_ctx_reserve(c, tk.ws_off + (hash_pairs ? 2 * n : n)); if (rc) return rc;        // (a pass on a second track finds its space reserved: no growth under the first)
+    bool tm = c->timing;
+    // what this pass does is decided by plan_pass (the function mbls_plan_batch reports from): forms of the pairing check and of the message phase, workspace, forks
+    mbls_pass_plan pp; plan_pass(ctx_limits(c), n, tk.no_waves, tk.fork_max, part != 0, tm, &pp);
+    const bool on_waves = pp.pairing == MBLS_PAIRING_WAVE || pp.pairing == MBLS_PAIRING_WAVE_X2;
+    const bool split = pp.pairing == MBLS_PAIRING_LANES2 || pp.pairing == MBLS_PAIRING_LANES4;     // lane pairs / quads in the Miller phase, pairs in the final exponentiation
+    const bool hash_pairs = pp.workspace_items == 2 * n;
+    const int hform = pp.message == MBLS_MESSAGE_LANE ? HASH_FORM_LANE : pp.message == MBLS_MESSAGE_LANES2 ? HASH_FORM_PAIR : HASH_FORM_WAVE;
+    int rc = mbls_ctx_reserve(c, tk.ws_off + pp.workspace_items); if (rc) return rc;        // (a pass on a second track finds its space reserved: no growth under the first)
     mbls_ws ws; ws.w = c->d_w + tk.ws_off; ws.stride = c->cap;
     uint32_t* st = d_status ? d_status : c->d_status + tk.ws_off;
     unsigned g = nblk(n);
-    bool tm = c->timing;
     bool staged = !ks.indexed && (fmt == MBLS_PK_COMPRESSED) && !d_off && k > 1;   // lane-per-key decompression, then the per-item sums
     if (staged) { rc = reserve_keys(c, (tk.ws_off + n) * (uint64_t)k); if (rc) return rc; }
     uint32_t* const keys_xy = staged ? c->d_keys_xy + 24 * (uint64_t)k * tk.ws_off : nullptr;
@@ -1033,12 +1123,10 @@ static int verify_pipeline_one(mbls_ctx* c, const uint8_t* d_sigs, const uint8_t
     // part 1 / part 2 (host-buffer entry points): the signature and message phases are queued first (part 1, the keys may be
     // null), the caller then uploads the keys on another stream and makes this one wait, and part 2 queues the rest.
     const bool keys_later = part != 0;
-    const bool fused_sig = n > coop_max;     // one lane per item: the subgroup test of the signature comes out of the Miller loop, k_sig only decodes
-    const bool fork = !tm && n <= (tk.fork_max == ~0ull ? c->fork_max_items : tk.fork_max);
+    const bool fused_sig = pp.sig_subgroup_from_miller_loop != 0;     // the subgroup test of the signature comes out of the Miller loop, k_sig only decodes
+    const bool fork = pp.front != MBLS_FRONT_IN_A_ROW;
     // (host-buffer entries: hs_b carries the key upload, so their signature phase has a stream of its own)
-    // above a quarter of a round the three chains no longer fit the chip side by side (and the message phase runs on n lanes, its longest form): the
-    // signature phase -- the shortest -- then follows the key sum on the caller's stream, beside the message phase: 32 768 items 17.1 -> 16.5 ms
-    const bool sig_side = fork && (part != 0 || 4 * n <= c->round_items);
+    const bool sig_side = pp.front == MBLS_FRONT_ALL_BESIDE;
     hipStream_t s_sig = sig_side ? (part == 0 ? tk.sb : tk.sd) : s, s_msg = fork ? tk.sc : s;
     if (part != 2) {
         if (tk.ws_sync) { rc = ws_acquire(c, s); if (rc) return rc; }
@@ -1051,7 +1139,7 @@ static int verify_pipeline_one(mbls_ctx* c, const uint8_t* d_sigs, const uint8_t
     }
     if (part == 1) {
         hipLaunchKernelGGL(k_sig, dim3(g), dim3(WG), 0, s_sig, ws, d_sigs, st, n, fused_sig ? 0 : 1);
-        launch_hash(c, ws, d_msgs, msg_len, d_moff, st, n, s_msg, hash_pairs, hash_form(c, n, hash_pairs, tk.no_waves));
+        launch_hash(c, ws, d_msgs, msg_len, d_moff, st, n, s_msg, hash_pairs, hform);
         HIPCHK(c, hipGetLastError());
         return MBLS_OK;
     }
@@ -1067,19 +1155,19 @@ static int verify_pipeline_one(mbls_ctx* c, const uint8_t* d_sigs, const uint8_t
     if (tm) HIPCHK(c, hipEventRecord(c->ev[1], s));
     if (!keys_later) hipLaunchKernelGGL(k_sig, dim3(g), dim3(WG), 0, s_sig, ws, d_sigs, st, n, fused_sig ? 0 : 1);
     if (tm) HIPCHK(c, hipEventRecord(c->ev[2], s));
-    if (!keys_later) launch_hash(c, ws, d_msgs, msg_len, d_moff, st, n, s_msg, hash_pairs, hash_form(c, n, hash_pairs, tk.no_waves));
+    if (!keys_later) launch_hash(c, ws, d_msgs, msg_len, d_moff, st, n, s_msg, hash_pairs, hform);
     if (tm) HIPCHK(c, hipEventRecord(c->ev[3], s));
     if (fork) {      // join
         if (s_sig != s) { HIPCHK(c, hipEventRecord(tk.ev2, s_sig)); HIPCHK(c, hipStreamWaitEvent(s, tk.ev2, 0)); }
         HIPCHK(c, hipEventRecord(tk.ev3, s_msg)); HIPCHK(c, hipStreamWaitEvent(s, tk.ev3, 0));
     }
-    if (n <= coop_max) {
+    if (on_waves) {
         // small batch: one WAVE per item walks the Miller loop and the final exponentiation with its lanes side by side (mbls_coop.h)
-        coop_run(c, (n > c->coop_pack_min_items && n <= c->coop_pack_max_items) ? COOP_PAIRING2X2 : COOP_PAIRING2, ws, (uint64_t)0, (uint64_t)1, (uint64_t)0, n, st, d_results, COOP_RES_ITEM, s);
+        coop_run(c, pp.pairing == MBLS_PAIRING_WAVE_X2 ? COOP_PAIRING2X2 : COOP_PAIRING2, ws, (uint64_t)0, (uint64_t)1, (uint64_t)0, n, st, d_results, COOP_RES_ITEM, s);
         if (tm) { HIPCHK(c, hipEventRecord(c->ev[4], s)); HIPCHK(c, hipEventRecord(c->ev[5], s)); }
     } else {
         if (split) {
-            const int lpp = 4 * n <= c->round_items ? 2 : 1;         // a quarter of a round or less: two lanes per pair, products in pairs
+            const int lpp = pp.pairing == MBLS_PAIRING_LANES4 ? 2 : 1;         // a quarter of a round or less: two lanes per pair, products in pairs
             if (lpp == 2) hipLaunchKernelGGL(k_miller_split4, dim3(nblk(4 * n)), dim3(WG), 0, s, ws, n);
             else hipLaunchKernelGGL(k_miller_split, dim3(nblk(2 * n)), dim3(WG), 0, s, ws, n);
             hipLaunchKernelGGL(k_f12_tree_d, dim3(g), dim3(WG), 0, s, ws, 2 * n, n);
@@ -1113,47 +1201,36 @@ static int verify_pipeline_from(mbls_ctx* c, uint64_t lo, const uint8_t* d_sigs,
     return verify_pipeline_one(c, d_sigs + 96 * lo, (d_moff || !d_msgs) ? d_msgs : d_msgs + (uint64_t)msg_len * lo, msg_len, d_moff ? d_moff + lo : nullptr, t,
                                n - lo, k, mode, d_results + lo, d_bitmap ? d_bitmap + lo / 64 : nullptr, d_status ? d_status + lo : nullptr, s, 0, tk);
 }
-// The batch as the caller sees it. n = q rounds + r items (0 < r < round): the q rounds run as one launch per kernel, the r items afterwards
-// as a batch of their own, which takes the route of its size (one wave per item up to coop_max_items) -- 1 + T(r) / T(round) rounds
-// instead of 2. (The phase timers describe a single pass: no cut while they are on.)
-// TWO TRACKS (round 5): the last round and a remainder of at least tracks_min_rest items -- R + r items, which would cost a round and then the route of r items
-// (a second, mostly empty round when r is above half a round) -- run as two halves of (R + r) / 2 items SIDE BY SIDE instead, each on its own part of the workspace
-// and its own streams: their kernels are in different phases most of the time, and whichever SIMDs one half leaves idle take waves of the other. Measured with two
-// contexts (scripts/dbg/overlap_probe.py): 73 728 items 40.0 -> 36.2 ms, 100 000 items 51.6 -> 45.9, 98 304 items 42.7 -> 40.5; a remainder below ~6 000 items is
-// better off on the wave engine after the round (69 632 items: 35.3 either way).
+// The batch as the caller sees it: plan_batch decides (see there), this function carries the plan out. Passes of one stage run side by side -- track 0 on the
+// caller's stream, track 1 on the context's second set of streams, forked from and joined to the caller's stream --, stages one after the other.
 static int verify_pipeline(mbls_ctx* c, const uint8_t* d_sigs, const uint8_t* d_msgs, uint32_t msg_len, const uint64_t* d_moff, const keysrc& ks,
                            uint64_t n, uint32_t k, int mode, uint8_t* d_results, uint64_t* d_bitmap,
                            uint32_t* d_status, hipStream_t s, int part = 0) {
-    const uint64_t R = c ? c->round_items : 0;
-    if (!c || part != 0 || c->timing || !R || n <= R || n % R == 0)
+    if (!c || part != 0 || n == 0)
         return verify_pipeline_one(c, d_sigs, d_msgs, msg_len, d_moff, ks, n, k, mode, d_results, d_bitmap, d_status, s, part);
-    const uint64_t r = n % R;
-    const bool two = c->tracks_min_rest && r >= c->tracks_min_rest && (R + r) / 2 > c->split_max_items && (R + r) / 2 > c->coop_max_items;   // (halves that take one workspace item per item)
-    // SIDE mode (remainders up to tracks_side_max, default a quarter of a round): the last round on track 0 and the remainder -- on the lane-pair forms, whatever its
-    // size: no_waves -- on track 1 beside it, instead of two equal halves: 69 120 ... 76 000 items 33.7 ms against 34.5 ... 40 in a row and 36.9 as halves
-    // (scripts/dbg/rest_probe.py, rest_probe2.py); above a quarter of a round equal halves win
-    const bool side = two && r <= c->tracks_side_max && 4 * r <= R;
-    const uint64_t lo = two ? n - r - R : n - r;                 // the whole rounds in front: one launch per kernel
-    int rc;
-    if (!two) {
-        rc = mbls_ctx_reserve(c, lo); if (rc) return rc;         // one growth, not two
-        rc = verify_pipeline_one(c, d_sigs, d_msgs, msg_len, d_moff, ks, lo, k, mode, d_results, d_bitmap, d_status, s, 0); if (rc) return rc;
-        return verify_pipeline_from(c, lo, d_sigs, d_msgs, msg_len, d_moff, ks, n, k, mode, d_results, d_bitmap, d_status, s);
+    mbls_batch_plan bp; plan_batch(ctx_limits(c), n, c->timing, c->timing, &bp);
+    if (bp.mode == MBLS_BATCH_ONE_PASS)
+        return verify_pipeline_one(c, d_sigs, d_msgs, msg_len, d_moff, ks, n, k, mode, d_results, d_bitmap, d_status, s, 0);
+    // one growth of the workspace (and of the staging of decompressed keys) for the whole plan: nothing may be reallocated under a pass in flight
+    uint64_t need = 0;
+    for (uint32_t i = 0; i < bp.n_passes; i++) { const uint64_t e = bp.pass[i].workspace_first + bp.pass[i].workspace_items; if (e > need) need = e; }
+    int rc = mbls_ctx_reserve(c, need); if (rc) return rc;
+    if (!ks.indexed && ks.fmt == MBLS_PK_COMPRESSED && !ks.d_off && k > 1) { rc = reserve_keys(c, need * (uint64_t)k); if (rc) return rc; }
+    if (bp.mode == MBLS_BATCH_ROUNDS_THEN_REST) {
+        rc = verify_pipeline_one(c, d_sigs, d_msgs, msg_len, d_moff, ks, bp.pass[0].items, k, mode, d_results, d_bitmap, d_status, s, 0); if (rc) return rc;
+        return verify_pipeline_from(c, bp.pass[1].first_item, d_sigs, d_msgs, msg_len, d_moff, ks, n, k, mode, d_results, d_bitmap, d_status, s);
     }
-    // items [lo, mid) on track 0, [mid, n) on track 1 (cut at a bitmap word); track 1's part of the workspace starts at item `half`
-    const uint64_t half = side ? R : ((R + r) / 2 + WG - 1) / WG * WG, mid = lo + half;
-    const uint64_t need = side ? R + 2 * r : 2 * half;           // (a remainder on lane pairs takes two workspace items per item; halves above half a round take one)
-    rc = mbls_ctx_reserve(c, lo > need ? lo : need); if (rc) return rc;
-    if (!ks.indexed && ks.fmt == MBLS_PK_COMPRESSED && !ks.d_off && k > 1) { rc = reserve_keys(c, (lo > need ? lo : need) * (uint64_t)k); if (rc) return rc; }
-    if (lo) { rc = verify_pipeline_one(c, d_sigs, d_msgs, msg_len, d_moff, ks, lo, k, mode, d_results, d_bitmap, d_status, s, 0); if (rc) return rc; }
+    // two tracks: [rounds in front,] then two passes side by side
+    uint32_t i = 0;
+    if (bp.n_passes == 3) { rc = verify_pipeline_one(c, d_sigs, d_msgs, msg_len, d_moff, ks, bp.pass[0].items, k, mode, d_results, d_bitmap, d_status, s, 0); if (rc) return rc; i = 1; }
+    const mbls_pass_plan& pa = bp.pass[i]; const mbls_pass_plan& pb = bp.pass[i + 1];
+    const bool side = bp.mode == MBLS_BATCH_ROUND_BESIDE_REST;
+    const uint64_t fm = side ? ~0ull : (pa.front == MBLS_FRONT_IN_A_ROW ? 0 : c->fork_max_items);
     rc = ws_acquire(c, s); if (rc) return rc;
     HIPCHK(c, hipEventRecord(c->t1_ev, s)); HIPCHK(c, hipStreamWaitEvent(c->t1_s, c->t1_ev, 0));
-    track ta = track0(c); ta.ws_sync = false;
-    // the halves' front phases side by side only while a half is at most 19/32 of a round and no round runs in front (scripts/dbg/tracks_probe.py: r = 6 144 ... 10 240
-    // 36.7 against 37.7 ms; r = 18 432 ... 30 720 in a row 38.0 ... 40.1 against 38.8 ... 42.0; behind a round 64.4 against 67.1 at r = 10 240 ... 20 480); in side
-    // mode each part follows the rule of its own size
-    if (!side) ta.fork_max = (lo == 0 && half <= R / 32 * 19) ? c->fork_max_items : 0;
-    track tb; tb.no_waves = side; tb.fork_max = ta.fork_max; tb.ws_off = half; tb.sb = c->t1_b; tb.sc = c->t1_c; tb.sd = c->t1_b; tb.ev2 = c->t1_ev2; tb.ev3 = c->t1_ev3; tb.ws_sync = false;
+    track ta = track0(c); ta.ws_sync = false; ta.fork_max = fm;
+    track tb; tb.no_waves = side; tb.fork_max = fm; tb.ws_off = pb.workspace_first; tb.sb = c->t1_b; tb.sc = c->t1_c; tb.sd = c->t1_b; tb.ev2 = c->t1_ev2; tb.ev3 = c->t1_ev3; tb.ws_sync = false;
+    const uint64_t lo = pa.first_item, mid = pb.first_item;
     if (side) {          // the round first: its kernels fill the chip, the remainder's waves take what they leave between them
         rc = verify_pipeline_from(c, lo, d_sigs, d_msgs, msg_len, d_moff, ks, mid, k, mode, d_results, d_bitmap, d_status, s, &ta);
         if (!rc) rc = verify_pipeline_from(c, mid, d_sigs, d_msgs, msg_len, d_moff, ks, n, k, mode, d_results, d_bitmap, d_status, c->t1_s, &tb);

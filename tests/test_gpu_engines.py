@@ -184,6 +184,27 @@ def _device_call(N, ctx, dev, s, m, p, n, k, *, koff=None, moff=None, table=None
     return got, [x & 0xffffffff for x in d_st.cpu().tolist()], bits
 
 
+def test_context_limits_are_what_the_plan_is_made_from(mb):
+    """mbls_ctx_get_limits: the defaults follow the device's round (CUs x 4 x 64), the setters move them, and mbls_plan_batch on them is the plan the entries carry out
+    (tests/test_plan_cpu.py checks the plan itself at every boundary without a GPU)"""
+    import torch
+    from milagro_bls_amd import _native as N
+    ctx = N.default_context()
+    ctx.reset_tuning()
+    L = ctx.limits()
+    R = torch.cuda.get_device_properties(0).multi_processor_count * 4 * 64
+    D = N.default_limits(R)
+    assert [getattr(L, f) for f, _ in N.Limits._fields_] == [getattr(D, f) for f, _ in N.Limits._fields_]
+    try:
+        ctx.set_tracks(1000, 2000); ctx.set_coop_max_items(7); ctx.set_lane_shaping(100, 200)
+        L = ctx.limits()
+        assert (L.tracks_min_rest, L.tracks_side_max, L.coop_max_items, L.split_max_items, L.fork_max_items) == (1000, 2000, 7, 100, 200)
+        mode, ps = N.plan_batch(R + 1500, L)
+        assert mode == N.BATCH_ROUND_BESIDE_REST and ps[1]["items"] == 1500 and ps[1]["pairing"] == N.PAIRING_LANE      # split_max 100: the remainder on one lane per item
+    finally:
+        ctx.reset_tuning()
+
+
 def test_two_tracks_above_a_round_vs_oracle(mb, big):
     """n = q rounds + r with r >= mbls_ctx_set_tracks' limit (default 3 584): the last round and the remainder run on two tracks SIDE BY SIDE, each on its own part
     of the workspace and its own streams (verify_pipeline) -- the remainder beside the round up to a quarter of a round (73 728, 81 920 items; 150 000 with a whole
@@ -210,13 +231,13 @@ def test_two_tracks_above_a_round_vs_oracle(mb, big):
 
 def test_two_tracks_with_small_rounds_every_layout(mb, big):
     """the two-track cut on small numbers (rounds of 128 items, limit 1, one lane per item): n = 300 = one round in front + halves of 128 and 44 items; n = 200 =
-    halves of 128 and 72; the same with the remainder BESIDE the round (side mode: 44 items on lane pairs next to a round of 128) -- uniform keys, ragged keys + ragged messages through offset tables that do not start at 0, table indices, and 48-byte keys (the staged
+    halves of 128 and 72; n = 276 and 160 with the remainder BESIDE the round (side mode: 20 / 32 items on lane pairs next to a round of 128) -- uniform keys, ragged keys + ragged messages through offset tables that do not start at 0, table indices, and 48-byte keys (the staged
     decompression buffer is cut like the workspace) -- against the oracle."""
     import torch
     from milagro_bls_amd import _native as N
     ctx = N.default_context(); dev = torch.device("cuda:0")
     try:
-        for n, side_max in ((300, 0), (200, 0), (300, 64), (172, 64)):          # halves (128 + 44 behind a round; 128 + 72) / the remainder beside the round (44 items, behind a round and not)
+        for n, side_max in ((300, 0), (200, 0), (276, 64), (160, 64)):          # halves (128 + 44 behind a round; 128 + 72) / the remainder beside the round (20 items behind a round, 32 items)
             ctx.reset_tuning(); ctx.set_round_items(128); ctx.set_coop_max_items(0); ctx.set_coop_hash_max_items(0); ctx.set_tracks(1, side_max)
             s, m, p = prefix(big, n)
             got, st, bits = _device_call(N, ctx, dev, s, m, p, n, big.k)
@@ -232,7 +253,7 @@ def test_two_tracks_with_small_rounds_every_layout(mb, big):
             check(big, got, st, n); assert bits == [int(x) for x in got]
             tab.close()
         # 48-byte keys: a batch of its own (the big fixture holds 96-byte keys)
-        b = helpers.make_batch(300, 3, fmt=0, seed=77, nthreads=8)
+        b = helpers.make_batch(276, 3, fmt=0, seed=77, nthreads=8)
         want = orc.batch_fast_aggregate_verify(b.sigs, b.msgs, b.pks, b.n, b.k, 0, nthreads=8)
         assert want == b.expect
         for side_max in (0, 64):
