@@ -353,6 +353,12 @@ GKOFF = "s71"                       # run-time byte offset added to the address 
 VOFF = "v250"                       # slots of kind 'gv': the record is chosen PER LANE -- this register replaces LADDR as the lane offset
 
 
+# MBLS_GEN_TIMING_NO_STORES=1: a THROW-AWAY build for timing only -- every workspace store of the generated routines is left out (wrong results, same instruction
+# stream otherwise): what the write half of the workspace traffic costs (scripts/dbg/ab_gen.sh). Never committed: the freshness tests compare
+# the tracked file with the default generation.
+TIMING_NO_STORES = os.environ.get("MBLS_GEN_TIMING_NO_STORES", "0") == "1"
+
+
 def seq_gaddr(slot, koff=False):
     L = ["s_mul_i32 %s, %s, %d" % (GT0, GSTRIDE, 12 * slot), "s_mul_hi_u32 %s, %s, %d" % (GT1, GSTRIDE, 12 * slot),
          "s_add_u32 s74, s68, %s" % GT0, "s_addc_u32 s75, s69, %s" % GT1]
@@ -365,7 +371,8 @@ def seq_gstore(reg, slot, koff=False, lane=None):
     """12 packed words in reg(0)..reg(11) -> workspace slot (lane: a register that replaces LADDR as the lane's byte offset)"""
     L = seq_gaddr(slot, koff)
     for j in range(12):
-        L.append("global_store_dword %s, %s, %s" % (lane or LADDR, reg(j), GADDR))
+        if not TIMING_NO_STORES:
+            L.append("global_store_dword %s, %s, %s" % (lane or LADDR, reg(j), GADDR))
         if j < 11:
             L += ["s_add_u32 s74, s74, %s" % GSTRIDE, "s_addc_u32 s75, s75, 0"]
     return L
