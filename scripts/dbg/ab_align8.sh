@@ -1,0 +1,13 @@
+#!/bin/bash
+# A/B: every 8-byte instruction of the generated routines on an 8-byte boundary (MBLS_GEN_ALIGN8=1) against the tracked generation. Run on the GPU box; the three
+# generators are re-run for each variant and the tree ends as it began.
+cd "$(dirname "$0")/../.."
+for spec in "base" "align8 MBLS_GEN_ALIGN8=1" "base_again"; do
+    name=${spec%% *}; envs=""; [ "$spec" != "$name" ] && envs=${spec#* }
+    for g in gen_fp_asm gen_fpd_asm gen_tower_d; do env $envs python3 tools/$g.py > /dev/null; done
+    env $envs python3 -m milagro_bls_amd.build --force > /dev/null 2>&1
+    python3 bench.py --no-variants --no-cpu-baseline --steps 10 2> /dev/null | python3 -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1])
+print('$name', round(d['value']), round(d['ms_per_step'],3), {k:round(v,3) for k,v in d['phase_ms'].items()}, d['bitmap_matches_expectation'])"
+done

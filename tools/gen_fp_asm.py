@@ -12,6 +12,7 @@ Run:  python3 tools/gen_fp_asm.py   (output is committed; tests/test_asm_sim_cpu
 checks that the committed file is up to date)
 """
 import os
+import re
 P = 0x1a0111ea397fe69a4b1ba7b6434bacd764774b84f38512bf6730d2a0f6b0f6241eabfffeb153ffffb9feffffffffaaab
 NP0 = (-pow(P, -1, 1 << 32)) % (1 << 32)
 PL = [(P >> (32 * i)) & 0xFFFFFFFF for i in range(12)]
@@ -583,8 +584,104 @@ def fp_inv_gcd_body(unrolled=False):
     return L
 
 
+# MBLS_GEN_E32=1 (experiment, scripts/dbg/ab_gen.sh): plain operations in their 4-byte VOP1 / VOP2 encodings where the operands allow it instead of the 8-byte VOP3
+# forms the generators write -- same arithmetic, smaller code
+PREFER_E32 = os.environ.get("MBLS_GEN_E32", "0") == "1"
+
+
+def _is_v(x):
+    return re.fullmatch(r"v\d+", x) is not None
+
+
+def to_e32(line):
+    m = re.match(r"^(v_and_b32|v_add_u32|v_sub_u32|v_or_b32|v_xor_b32)_e64 (\S+), (\S+), (\S+)$", line)
+    if m:
+        op, d, a, b = m.groups(); a = a; d = d.rstrip(","); a = a.rstrip(",")
+        if _is_v(b):
+            return "%s_e32 %s, %s, %s" % (op, d, a, b)
+        if _is_v(a):
+            if op == "v_sub_u32":
+                return "v_subrev_u32_e32 %s, %s, %s" % (d, b, a)
+            return "%s_e32 %s, %s, %s" % (op, d, b, a)
+        return line
+    m = re.match(r"^(v_ashrrev_i32|v_lshlrev_b32|v_lshrrev_b32)_e64 (\S+), (\S+), (\S+)$", line)
+    if m:
+        op, d, a, b = m.groups(); d = d.rstrip(","); a = a.rstrip(",")
+        return "%s_e32 %s, %s, %s" % (op, d, a, b) if _is_v(b) else line
+    m = re.match(r"^(v_mov_b32|v_mov_b64)_e64 (.*)$", line)
+    if m:
+        return "%s_e32 %s" % (m.group(1), m.group(2))
+    return line
+
+
+# ---- instruction alignment (round 5). A lone wave fetches an 8-byte instruction that sits at an address = 4 mod 8 measurably slower than an aligned one (the
+# product routines are all 8-byte encodings behind a .p2align 6 and never misaligned; the bodies around them mix in 4-byte scalar instructions, and after an odd
+# number of those everything that follows is misaligned until the next one). Default (MBLS_GEN_ALIGN8=0 switches it off for an A/B): a post-pass over every emitted routine that keeps 8-byte
+# instructions on 8-byte boundaries by putting an `s_nop 0` in front of the first misaligned one of a run. Sizes: SOP* and VOP1 / VOP2 (_e32) encodings are 4
+# bytes, + 4 with a 32-bit literal or a relocation; everything else (VOP3, VOP3P, DS, FLAT) is 8.
+ALIGN8 = os.environ.get("MBLS_GEN_ALIGN8", "1") == "1"
+_INLINE_F = ("0.5", "-0.5", "1.0", "-1.0", "2.0", "-2.0", "4.0", "-4.0")
+
+
+def _is_literal(tok):
+    tok = tok.strip()
+    if "@rel32" in tok or re.search(r"\d+[fb]-\d+[fb]", tok) or re.fullmatch(r"\d+[fb]", tok):
+        return True                                  # relocations and label differences are assembled as 32-bit literals
+    if re.fullmatch(r"-?(0x[0-9a-fA-F]+|\d+)", tok):
+        v = int(tok, 0)
+        return not (-16 <= v <= 64)
+    return False
+
+
+def instr_size(line):
+    """bytes of one instruction line (0 for labels and directives)"""
+    l = line.strip()
+    if not l or l.endswith(":") or l.startswith("."):
+        return 0
+    op = l.split()[0]
+    args = l[len(op):]
+    toks = [t for t in re.split(r"[,\s]+", args) if t]
+    if op.startswith("s_"):
+        if op in ("s_waitcnt", "s_nop", "s_barrier", "s_endpgm") or op.startswith("s_cbranch") or op in ("s_setpc_b64", "s_getpc_b64", "s_swappc_b64"):
+            return 4
+        return 8 if any(_is_literal(t) for t in toks[1:]) else 4
+    if op.endswith("_e32"):
+        return 8 if any(_is_literal(t) for t in toks[1:]) else 4
+    return 8
+
+
+def align8(lines):
+    # (the compiler puts an s_waitcnt in front of an asm body that is a function of its own: the body is put on an 8-byte boundary first)
+    out, off = [".p2align 3"], 0
+    i = 0
+    while i < len(lines):
+        l = lines[i]
+        s = l.strip()
+        if s.startswith(".p2align"):
+            off = 0; out.append(l); i += 1; continue
+        sz = instr_size(l)
+        if sz == 0:
+            out.append(l); i += 1; continue
+        # a call through a relocation: s_getpc / s_add @rel32@lo+4 / s_addc @rel32@hi+12 / s_swappc -- the offsets in the relocations fix the distances, nothing may
+        # go between them: the group starts on an 8-byte boundary (its two 8-byte members then sit at 4 mod 8, the return address is aligned again)
+        if s.startswith("s_getpc_b64") and i + 1 < len(lines) and "@rel32" in lines[i + 1]:
+            if off % 8:
+                out.append("s_nop 0"); off += 4
+            for k in range(4):
+                out.append(lines[i + k]); off += instr_size(lines[i + k])
+            i += 4; continue
+        if sz == 8 and off % 8:
+            out.append("s_nop 0"); off += 4
+        out.append(l); off += sz; i += 1
+    return out
+
+
 def emit(name, lines):
     out = ["#define %s \\" % name]
+    if PREFER_E32:
+        lines = [to_e32(l) for l in lines]
+    if ALIGN8:
+        lines = align8(lines)
     for l in lines:
         out.append('    "%s\\n\\t" \\' % l)
     out.append('    ""')
