@@ -312,6 +312,18 @@ int mbls_verify_multiple_aggregate_signatures_device(mbls_ctx* ctx, const uint8_
                                               const uint8_t* d_msgs, uint32_t msg_len, const uint64_t* d_msg_offsets,
                                               const uint64_t* d_rands, uint64_t n, uint8_t* d_result, uint32_t* d_status,
                                               void* stream);
+/* The reference's own shape, generator included (src/aggregates.rs:261-316): its loop tests set i's signature for the subgroup
+ * (:272-275) BEFORE it draws rand[i] from the caller's rng (:280-287) and returns at the first signature outside G2, so a rejected
+ * batch leaves the rng after exactly as many draws as sets came before the bad one. This entry keeps that order in ONE call: the
+ * signatures are decoded and tested first (beside the message phase), the host reads the verdicts, `draw(user, out, count)` is
+ * called at most once for the `count` scalars of the sets in front of the first bad signature (count = n when there is none;
+ * not called for count = 0 or n = 0) and must fill out[0 .. count) with NONZERO scalars in set order; what follows does not repeat
+ * the subgroup test. Same bool as mbls_verify_multiple_aggregate_signatures with the same scalars. `draw` runs on the calling
+ * thread while the context is locked. include/milagro_bls.hpp, rust/src/lib.rs and milagro_bls_amd/api.py draw as :280-287 does. */
+typedef void (*mbls_scalar_source)(void* user, uint64_t* out, uint64_t count);
+int mbls_verify_multiple_aggregate_signatures_rng(mbls_ctx* ctx, const uint8_t* sigs96, const uint8_t* apks96,
+                                              const uint8_t* msgs, uint32_t msg_len, const uint64_t* msg_offsets,
+                                              size_t n, mbls_scalar_source draw, void* user);
 
 /* The same for sets given by their keys in wire format (BASELINE configs[3]: 2^14 sets x 128 keys): set i owns k keys
  * (or [pk_offsets[i], pk_offsets[i+1])), AggregatePublicKey::aggregate (src/aggregates.rs:29-39) runs on the device first. */

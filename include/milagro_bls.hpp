@@ -19,10 +19,12 @@
 #include <array>
 #include <cstdint>
 #include <cstring>
+#include <exception>
 #include <random>
 #include <stdexcept>
 #include <string>
 #include <tuple>
+#include <type_traits>
 #include <vector>
 #include "mbls.h"
 
@@ -236,7 +238,7 @@ struct AggregateSignature {
     bool fast_aggregate_verify_pre_aggregated(const Bytes& msg, const AggregatePublicKey& apk) const {
         return mbls_fast_aggregate_verify_pre_aggregated(detail::ctx(), point.data(), msg.data(), msg.size(), apk.point.data()) == 1;
     }
-    // rng(): one random byte per call. Blinding scalars drawn as at reference src/aggregates.rs:280-287 -- and in the reference's ORDER: its loop tests set i's
+    // (the multi-device form) rng(): one random byte per call. Blinding scalars drawn as at reference src/aggregates.rs:280-287 -- and in the reference's ORDER: its loop tests set i's
     // signature for the subgroup (:272-275) before it draws rand[i] and returns at the first signature outside G2, so a rejected batch leaves the caller's
     // generator where the reference would: one batched subgroup test up front (mbls_sig_check_batch) finds that set, scalars are drawn for the sets before it only.
     // -> false if a set was rejected before the pairing check (the buffers are then incomplete), true if the batch is ready
@@ -248,9 +250,7 @@ struct AggregateSignature {
         size_t n_ok = 0;
         while (n_ok < sets.size() && errs[n_ok] == MBLS_OK && in_g2[n_ok]) n_ok++;
         for (size_t i = 0; i < n_ok; i++) {
-            uint64_t r = 0;
-            while (r == 0) { uint64_t v = 0; for (int j = 0; j < 8; j++) v = (v << 8) | uint8_t(rng()); r = (v >> 63) ? (uint64_t(0) - v) : v; }      // i64::from_be_bytes(..).abs() as the release build wraps it
-            rands.push_back(r);
+            rands.push_back(draw_scalar(rng));
         }
         if (n_ok < sets.size()) return false;                              // :273-275
         for (auto& s : sets) {
@@ -260,12 +260,34 @@ struct AggregateSignature {
         }
         return true;
     }
+    // one scalar as at reference src/aggregates.rs:280-287: 8 random bytes, big-endian i64, absolute value (as the release build wraps it), again on zero
+    template <typename Rng> static uint64_t draw_scalar(Rng& rng) {
+        uint64_t r = 0;
+        while (r == 0) { uint64_t v = 0; for (int j = 0; j < 8; j++) v = (v << 8) | uint8_t(rng()); r = (v >> 63) ? (uint64_t(0) - v) : v; }
+        return r;
+    }
+    // One call (mbls_verify_multiple_aggregate_signatures_rng): the library tests the signatures first and asks for the scalars of the sets in front of the first
+    // bad one only -- the reference's order (see draw_in_reference_order) without a second subgroup test.
     template <typename Rng>
     static bool verify_multiple_aggregate_signatures(Rng&& rng, const std::vector<std::tuple<const AggregateSignature*, const AggregatePublicKey*, Bytes>>& sets) {
         if (sets.empty()) return mbls_verify_multiple_aggregate_signatures(detail::ctx(), nullptr, nullptr, nullptr, 0, nullptr, nullptr, 0) == 1;
-        Bytes sigs, apks, msgs; std::vector<uint64_t> rands, moff{0};
-        if (!draw_in_reference_order(rng, sets, sigs, apks, msgs, rands, moff)) return false;
-        return mbls_verify_multiple_aggregate_signatures(detail::ctx(), sigs.data(), apks.data(), msgs.data(), 0, moff.data(), rands.data(), sets.size()) == 1;
+        Bytes sigs, apks, msgs; std::vector<uint64_t> moff{0};
+        for (auto& s : sets) {
+            sigs.insert(sigs.end(), std::get<0>(s)->point.begin(), std::get<0>(s)->point.end());
+            apks.insert(apks.end(), std::get<1>(s)->point.begin(), std::get<1>(s)->point.end());
+            msgs.insert(msgs.end(), std::get<2>(s).begin(), std::get<2>(s).end());
+            moff.push_back(msgs.size());
+        }
+        using R = typename std::remove_reference<Rng>::type;
+        struct src { R* rng; std::exception_ptr err; } u{&rng, nullptr};
+        mbls_scalar_source draw = [](void* user, uint64_t* out, uint64_t count) {
+            src* p = static_cast<src*>(user);
+            try { for (uint64_t i = 0; i < count; i++) out[i] = draw_scalar(*p->rng); }
+            catch (...) { p->err = std::current_exception(); for (uint64_t i = 0; i < count; i++) out[i] = 0; }        // never unwind through the C frames
+        };
+        const bool ok = mbls_verify_multiple_aggregate_signatures_rng(detail::ctx(), sigs.data(), apks.data(), msgs.data(), 0, moff.data(), sets.size(), draw, &u) == 1;
+        if (u.err) std::rethrow_exception(u.err);
+        return ok;
     }
     // the same check with the sets cut into one shard per device of a multi-device handle (mbls_multi_create): same bool
     template <typename Rng>

@@ -67,6 +67,8 @@ def plan_batch(n, limits=None):
     return b.mode, [{f: getattr(b.passes[i], f) for f, _ in PassPlan._fields_} for i in range(b.n_passes)]
 
 
+# mbls_scalar_source (include/mbls.h): void draw(void* user, uint64_t* out, uint64_t count)
+SCALAR_SOURCE = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_uint64), C.c_uint64)
 SIGNATURES = {
     "mbls_ctx_create": (C.c_int, [C.POINTER(vp), C.c_int]),
     "mbls_ctx_destroy": (None, [vp]),
@@ -117,6 +119,7 @@ SIGNATURES = {
     "mbls_aggregate_verify": (C.c_int, [vp, vp, vp, vp, C.c_size_t, vp, C.c_size_t]),
     "mbls_verify_multiple_aggregate_signatures": (C.c_int, [vp, vp, vp, vp, C.c_uint32, vp, vp, C.c_size_t]),
     "mbls_verify_multiple_aggregate_signatures_device": (C.c_int, [vp, vp, vp, vp, C.c_uint32, vp, vp, C.c_uint64, vp, vp, vp]),
+    "mbls_verify_multiple_aggregate_signatures_rng": (C.c_int, [vp, vp, vp, vp, C.c_uint32, vp, C.c_size_t, SCALAR_SOURCE, vp]),
     "mbls_verify_multiple_sets_device": (C.c_int, [vp, vp, vp, C.c_int, vp, C.c_uint32, vp, C.c_uint32, vp, vp, C.c_uint64, vp, vp, vp]),
     "mbls_verify_multiple_sets_indexed_device": (C.c_int, [vp, vp, vp, vp, vp, C.c_uint32, vp, C.c_uint32, vp, vp, C.c_uint64, vp, vp, vp, vp]),
     "mbls_verify_multiple_partial_device": (C.c_int, [vp, vp, vp, vp, C.c_int, vp, C.c_uint32, vp, C.c_uint32, vp, vp, C.c_uint64, vp, vp]),

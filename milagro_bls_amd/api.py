@@ -296,32 +296,36 @@ class AggregateSignature:
         """reference src/aggregates.rs:261-316. `rng` must offer getrandbits (random.Random); the blinding scalars
         are drawn exactly as at :280-287: 8 random bytes, big-endian i64, absolute value, retry on zero -- and IN THE REFERENCE'S ORDER: its loop
         tests set i's signature for the subgroup (:272-275) before it draws rand[i], and returns at the first signature outside G2, so a rejected
-        batch leaves the caller's generator where the reference would (one batched subgroup test up front finds that first set; scalars are drawn
-        for the sets before it only). Messages may have any lengths (`&[u8]` per set in the reference): one buffer + an offset table."""
+        batch leaves the caller's generator where the reference would (mbls_verify_multiple_aggregate_signatures_rng tests the signatures first and
+        asks for the scalars of the sets in front of the first bad one only). Messages may have any lengths (`&[u8]` per set in the reference): one buffer + an offset table."""
         sets = list(signature_sets)
         if not sets:
             return bool(N.lib().mbls_verify_multiple_aggregate_signatures(_ctx().handle, None, None, None, 0, None, None, 0))
-        sigs = b"".join(s[0].point for s in sets)
-        errs, in_g2 = N.outbuf(len(sets)), N.outbuf(len(sets))
-        _raise(N.lib().mbls_sig_check_batch(_ctx().handle, N.cbuf(sigs), len(sets), errs, in_g2))
-        n_ok = next((i for i in range(len(sets)) if errs[i] or not in_g2[i]), len(sets))       # the sets the reference's loop reaches a draw for
-        rands = []
-        for _ in range(n_ok):
-            r = 0
-            while r == 0:
-                v = int.from_bytes(bytes(rng.getrandbits(8) for _ in range(8)), "big", signed=True)
-                r = abs(v) & 0xFFFFFFFFFFFFFFFF
-            rands.append(r)
-        if n_ok < len(sets):
-            return False                                                                       # :273-275
+        failed = []
+
+        def draw(_user, out, count):                    # src/aggregates.rs:280-287, for the sets the reference's loop reaches a draw for
+            try:
+                for i in range(count):
+                    r = 0
+                    while r == 0:
+                        v = int.from_bytes(bytes(rng.getrandbits(8) for _ in range(8)), "big", signed=True)
+                        r = abs(v) & 0xFFFFFFFFFFFFFFFF
+                    out[i] = r
+            except BaseException as e:                  # an exception must not unwind through the C frames: the batch fails, the error is raised afterwards
+                failed.append(e)
+                for i in range(count):
+                    out[i] = 0
         offs = [0]
         for s in sets:
             offs.append(offs[-1] + len(s[2]))
         moff = (C.c_uint64 * len(offs))(*offs)
-        rr = (C.c_uint64 * len(sets))(*rands)
-        return bool(N.lib().mbls_verify_multiple_aggregate_signatures(
-            _ctx().handle, N.cbuf(sigs), N.cbuf(b"".join(s[1].point for s in sets)),
-            N.cbuf(b"".join(bytes(s[2]) for s in sets)), 0, moff, rr, len(sets)))
+        cb = N.SCALAR_SOURCE(draw)
+        ok = bool(N.lib().mbls_verify_multiple_aggregate_signatures_rng(
+            _ctx().handle, N.cbuf(b"".join(s[0].point for s in sets)), N.cbuf(b"".join(s[1].point for s in sets)),
+            N.cbuf(b"".join(bytes(s[2]) for s in sets)), 0, moff, len(sets), cb, None))
+        if failed:
+            raise failed[0]
+        return ok
 
     @classmethod
     def from_bytes(cls, data):

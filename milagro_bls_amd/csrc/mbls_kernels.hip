@@ -308,15 +308,19 @@ __global__ void MBLS_LB k_blind_sig_d(mbls_ws ws, const uint8_t* sigs96, const u
     __shared__ uint32_t spill[154 * 64];
     uint64_t i = gid(); if (i >= n) return;
     uint32_t st = 0;
-    fp2 x, y; bool inf;
-    int e = g2_decode_compressed_t<true>(&x, &y, &inf, sigs96 + 96 * i);
-    if (e) { st |= MBLS_ST_BAD_SIG_ENCODING; inf = true; }
-    if (inf) { x = fp2_zero(); y = fp2_zero(); }
-    ws_st2(ws, MBLS_SLOT_SIG, i, x); ws_st2(ws, MBLS_SLOT_SIG + 2, i, y);
+    bool inf;
+    if (sigs96) {
+        fp2 x, y;
+        int e = g2_decode_compressed_t<true>(&x, &y, &inf, sigs96 + 96 * i);
+        if (e) { st |= MBLS_ST_BAD_SIG_ENCODING; inf = true; }
+        if (inf) { x = fp2_zero(); y = fp2_zero(); }
+        ws_st2(ws, MBLS_SLOT_SIG, i, x); ws_st2(ws, MBLS_SLOT_SIG + 2, i, y);
+    } else      // sigs96 == NULL: k_sig decoded AND tested the signatures already (they are in the slots; y = 0: infinity): only [r] sig is left to do
+        inf = fp2_is_zero(ws_ld2(ws, MBLS_SLOT_SIG + 2, i));
     const uint64_t r = rands[i];
     if (r == 0) st |= MBLS_ST_BAD_SCALAR;
     // an infinite (or undecodable) signature is (0, 0) in the slots: with the scalar 0 every window digit is 0 and the sum stays at infinity
-    const uint32_t fl = g2_blind_d_call(ws, i, (MBLS_LDS uint32_t*)spill, threadIdx.x, inf ? 0 : r);
+    const uint32_t fl = g2_blind_d_call(ws, i, (MBLS_LDS uint32_t*)spill, threadIdx.x, inf ? 0 : r, sigs96 ? 0u : 1u);
     if (!((fl & 1u) | inf)) st |= MBLS_ST_SIG_NOT_IN_G2;
     if (st) atomicOr(status + i, st);
 #endif
@@ -2038,7 +2042,10 @@ extern "C" int mbls_aggregate_verify_batch(mbls_ctx* c, const uint8_t* sigs, con
 }
 static int verify_multiple_impl(mbls_ctx* c, const uint8_t* d_sigs, const uint8_t* d_apks, const uint8_t* d_pks, int pk_format,
         const uint32_t* d_pk_offsets, uint32_t k, const uint8_t* d_msgs, uint32_t msg_len, const uint64_t* d_moff, const uint64_t* d_rands, uint64_t n,
-        uint8_t* d_result, uint32_t* d_status_or, void* stream, uint32_t* d_partial = nullptr, const mbls_keytable* tab = nullptr, const uint32_t* d_idx = nullptr) {
+        uint8_t* d_result, uint32_t* d_status_or, void* stream, uint32_t* d_partial = nullptr, const mbls_keytable* tab = nullptr, const uint32_t* d_idx = nullptr,
+        bool sigs_resident = false, bool hash_enqueued = false) {
+    // sigs_resident: k_sig (decode + subgroup test) has run over these signatures on this workspace and the host has seen every one pass: d_sigs is not read.
+    // hash_enqueued (batches whose chains run side by side only): the message phase is already on the context's message stream.
     if (!c || (!d_result && !d_partial)) return MBLS_ERR_ARGUMENT;
     mbls_lock lk(c->mu);
     hipStream_t s = (hipStream_t)stream;
@@ -2055,14 +2062,14 @@ static int verify_multiple_impl(mbls_ctx* c, const uint8_t* d_sigs, const uint8_
         return MBLS_OK;
     }
     if (!d_rands) ARGFAIL(c, "verify_multiple without blinding scalars is forgeable: rands must not be NULL");
-    if (!d_sigs || (!d_msgs && msg_len && !d_moff)) ARGFAIL(c, "null buffer");
+    if ((!d_sigs && !sigs_resident) || (!d_msgs && msg_len && !d_moff)) ARGFAIL(c, "null buffer");
     // batches of at most half a round: two lanes per message in the message phase (items [0, 2 n), slots no other chain touches)
     const bool pair_hash = n <= c->split_max_items && 2 * n <= c->round_items;
     int rc = mbls_ctx_reserve(c, pair_hash ? 2 * n : n); if (rc) return rc;
     mbls_ws ws; ws.w = c->d_w; ws.stride = c->cap;
     rc = ws_acquire(c, s); if (rc) return rc;
     HIPCHK(c, hipMemsetAsync(c->d_scalar, 0, 64, s));
-    HIPCHK(c, hipMemsetAsync(c->d_status, 0, 4 * n, s));
+    if (!sigs_resident) HIPCHK(c, hipMemsetAsync(c->d_status, 0, 4 * n, s));      // (resident: cleared before k_sig, and the message phase may be writing its bits)
     if (d_partial) HIPCHK(c, hipMemsetAsync(d_partial, 0, MBLS_VM_PARTIAL_BYTES, s));       // not a record until k_vm_export has spoken
     else HIPCHK(c, hipMemsetAsync(d_result, 0, 1, s));                      // false until the tail kernel has spoken (fail closed)
     // Three independent chains: keys (aggregate, [r]apk), signatures (decode, subgroup check, [r]sig, sum tree), messages (hash). Below
@@ -2078,7 +2085,7 @@ static int verify_multiple_impl(mbls_ctx* c, const uint8_t* d_sigs, const uint8_
     } else if (!d_apks)    // sets given by their wire-format keys: AggregatePublicKey::aggregate on the device first (src/aggregates.rs:29-39)
         launch_aggregate(ws, d_pks, d_pk_offsets, k, pk_format, MBLS_MODE_VERIFY, c->d_status, n, s);
     hipLaunchKernelGGL(k_blind_g1_d, dim3(nblk(n)), dim3(WG), 0, s, ws, tab ? (const uint8_t*)nullptr : d_apks, d_rands, c->d_status, n);
-    hipLaunchKernelGGL(k_blind_sig_d, dim3(nblk(n)), dim3(WG), 0, s_sig, ws, d_sigs, d_rands, c->d_status, n);
+    hipLaunchKernelGGL(k_blind_sig_d, dim3(nblk(n)), dim3(WG), 0, s_sig, ws, sigs_resident ? (const uint8_t*)nullptr : d_sigs, d_rands, c->d_status, n);
     const bool side_s_chain = !fork && s != c->hs_b;                  // the sum tree waits for the product tree's company (npairing_finish)
     if (!side_s_chain) g2_tree(c, ws, n, s_sig);
     if (fork) {     // S is complete: its Miller loop runs on one wave beside the other chains and the sets' Miller loops (most SIMDs are idle)
@@ -2087,7 +2094,7 @@ static int verify_multiple_impl(mbls_ctx* c, const uint8_t* d_sigs, const uint8_
             coop_run(c, COOP_SMILLER, ws, (uint64_t)0, (uint64_t)1, (uint64_t)0, (uint64_t)1, (uint32_t*)nullptr, (uint8_t*)nullptr, COOP_RES_ITEM, s_sig);
         HIPCHK(c, hipEventRecord(c->hs_ev, s_sig));                  // ... and its Miller value (awaited just before the tail)
     }
-    launch_hash(c, ws, d_msgs, msg_len, d_moff, c->d_status, n, s_msg, pair_hash);
+    if (!(hash_enqueued && fork)) launch_hash(c, ws, d_msgs, msg_len, d_moff, c->d_status, n, s_msg, pair_hash);
     if (fork) {      // the sets' Miller loops need the keys (this stream) and the messages; the signature chain is awaited before the tail (hs_ev)
         HIPCHK(c, hipEventRecord(c->hs_ev3, s_msg));
         HIPCHK(c, hipStreamWaitEvent(s, c->hs_ev3, 0));
@@ -2184,6 +2191,54 @@ extern "C" int mbls_verify_multiple_aggregate_signatures(mbls_ctx* c, const uint
                                                          moff ? dmo.as<uint64_t>() : nullptr, dr.as<uint64_t>(), n, dres.as<uint8_t>(), nullptr, c->hs_a)) return 0;
     uint8_t r = 0;
     if (hipStreamSynchronize(c->hs_a) != hipSuccess) return 0;
+    c->ws_pending = false;
+    if (dres.down(&r, 1) != hipSuccess) return 0;
+    return r;
+}
+// The reference's own shape (src/aggregates.rs:261-316): its loop tests set i's signature for the subgroup (:272-275) BEFORE it draws rand[i] from the caller's
+// generator (:280-287) and returns at the first signature outside G2 -- so a rejected batch leaves the generator after exactly as many draws as sets came before
+// the bad one. One call does the same: the signatures are decoded and tested first (k_sig, beside the message phase when the batch leaves room), the host reads
+// the verdicts, `draw` is asked for exactly the scalars the reference would have drawn, and what follows skips the second subgroup test (the points are in the slots).
+extern "C" int mbls_verify_multiple_aggregate_signatures_rng(mbls_ctx* c, const uint8_t* sigs96, const uint8_t* apks96, const uint8_t* msgs,
+        uint32_t msg_len, const uint64_t* moff, size_t n, mbls_scalar_source draw, void* user) {
+    if (!c) return 0;
+    if (n == 0) return 1;                                                   // empty iterator: true, the generator untouched
+    if (!draw) return 0;
+    if (moff && !msg_offsets_ok(moff, n)) return 0;
+    const uint64_t msg_first = moff ? moff[0] : 0;
+    const size_t msg_total = moff ? (size_t)(moff[n] - moff[0]) : (size_t)msg_len * n;
+    if (!sigs96 || !apks96 || (!msgs && msg_total)) return 0;
+    mbls_lock lk(c->mu);
+    if (hipSetDevice(c->device) != hipSuccess) return 0;
+    std::vector<uint64_t> rands; std::vector<uint32_t> st;
+    try { rands.resize(n); st.resize(n); } catch (...) { return 0; }
+    sbuf ds(c, 0), da(c, 1), dm(c, 2), dr(c, 3), dmo(c, 6), dres(c, 4);
+    if (ds.up(sigs96, 96 * n) != hipSuccess || da.up(apks96, 96 * n) != hipSuccess || dm.up(msgs ? msgs + msg_first : nullptr, msg_total) != hipSuccess ||
+        dr.alloc(8 * n) != hipSuccess || (moff && dmo.up(moff, 8 * (n + 1)) != hipSuccess) || dres.alloc(8) != hipSuccess) return 0;
+    const uint8_t* d_msgs = dm.as<uint8_t>() - msg_first; const uint64_t* d_moff = moff ? dmo.as<uint64_t>() : nullptr;
+    hipStream_t s = c->hs_a;
+    const bool pair_hash = n <= c->split_max_items && 2 * n <= c->round_items, fork = 2 * n <= c->round_items;       // as verify_multiple_impl decides
+    if (mbls_ctx_reserve(c, pair_hash ? 2 * n : n)) return 0;
+    mbls_ws ws; ws.w = c->d_w; ws.stride = c->cap;
+    if (ws_acquire(c, s)) return 0;
+    hipStream_t s_sig = fork ? c->hs_b : s;
+    auto fail = [&]() { (void)hipStreamSynchronize(c->hs_a); (void)hipStreamSynchronize(c->hs_b); (void)hipStreamSynchronize(c->hs_c); c->ws_pending = false; return 0; };
+    if (hipMemsetAsync(c->d_status, 0, 4 * n, s) != hipSuccess) return fail();
+    if (fork) { (void)hipEventRecord(c->hs_ev, s); (void)hipStreamWaitEvent(c->hs_b, c->hs_ev, 0); (void)hipStreamWaitEvent(c->hs_c, c->hs_ev, 0); }
+    hipLaunchKernelGGL(k_sig, dim3(nblk(n)), dim3(WG), 0, s_sig, ws, (const uint8_t*)ds.as<uint8_t>(), c->d_status, (uint64_t)n, 1);
+    if (fork) launch_hash(c, ws, d_msgs, msg_len, d_moff, c->d_status, n, c->hs_c, pair_hash);       // the message phase does not wait for the host
+    if (hipStreamSynchronize(s_sig) != hipSuccess || hipMemcpy(st.data(), c->d_status, 4 * n, hipMemcpyDeviceToHost) != hipSuccess) return fail();
+    size_t reached = n;                                                     // the sets the reference's loop draws a scalar for
+    for (size_t i = 0; i < n; i++)
+        if (st[i] & (MBLS_ST_BAD_SIG_ENCODING | MBLS_ST_SIG_NOT_IN_G2)) { reached = i; break; }
+    if (reached) draw(user, rands.data(), (uint64_t)reached);
+    if (reached < n) return fail();                                         // :273-275 (fail() only waits for the message phase)
+    if (dr.up(rands.data(), 8 * n) != hipSuccess) return fail();
+    std::fill(rands.begin(), rands.end(), 0);
+    if (verify_multiple_impl(c, nullptr, da.as<uint8_t>(), nullptr, 0, nullptr, 0, d_msgs, msg_len, d_moff, dr.as<uint64_t>(), n, dres.as<uint8_t>(), nullptr, s,
+                             nullptr, nullptr, nullptr, true, true)) return fail();
+    uint8_t r = 0;
+    if (hipStreamSynchronize(s) != hipSuccess) return fail();
     c->ws_pending = false;
     if (dres.down(&r, 1) != hipSuccess) return 0;
     return r;

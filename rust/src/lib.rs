@@ -17,6 +17,9 @@ extern crate zeroize;
 
 use rand::Rng;
 use std::os::raw::{c_char, c_int, c_void};
+
+/// `mbls_scalar_source` of include/mbls.h
+type MblsScalarSource = unsafe extern "C" fn(user: *mut c_void, out: *mut u64, count: u64);
 use std::sync::Once;
 use zeroize::Zeroize;
 
@@ -65,6 +68,8 @@ extern "C" {
     fn mbls_aggregate_verify(ctx: *mut MblsCtx, sig: *const u8, msgs: *const u8, msg_lens: *const usize, n_msgs: usize, pks96: *const u8, n_pks: usize) -> c_int;
     fn mbls_verify_multiple_aggregate_signatures(ctx: *mut MblsCtx, sigs96: *const u8, apks96: *const u8, msgs: *const u8, msg_len: u32, msg_offsets: *const u64,
                                                  rands: *const u64, n: usize) -> c_int;
+    fn mbls_verify_multiple_aggregate_signatures_rng(ctx: *mut MblsCtx, sigs96: *const u8, apks96: *const u8, msgs: *const u8, msg_len: u32, msg_offsets: *const u64,
+                                                     n: usize, draw: MblsScalarSource, user: *mut c_void) -> c_int;
     fn mbls_sig_check_batch(ctx: *mut MblsCtx, in96: *const u8, n: u64, errs: *mut u8, in_g2: *mut u8) -> c_int;
     fn mbls_fast_aggregate_verify_batch(ctx: *mut MblsCtx, sigs: *const u8, msgs: *const u8, msg_len: u32, msg_offsets: *const u64, pks: *const u8, pk_format: c_int,
                                         pk_offsets: *const u32, n: u64, k: u32, results: *mut u8, status: *mut u32) -> c_int;
@@ -507,8 +512,9 @@ impl AggregateSignature {
     /// `src/aggregates.rs:261-316`. The blinding scalars are drawn from `rng` exactly as the reference does (8 random bytes,
     /// big-endian i64, absolute value, retry on zero, `:280-287`) -- and in the reference's ORDER: its loop tests set i's signature for
     /// the subgroup (`:272-275`) before it draws `rand[i]` and returns at the first signature outside G2, so a rejected batch leaves the
-    /// caller's generator where the reference would. One batched subgroup test up front finds that set; scalars are drawn for the sets
-    /// before it only. (The iterator is collected first: the reference stops pulling from it at the rejected set.)
+    /// caller's generator where the reference would. `mbls_verify_multiple_aggregate_signatures_rng` tests the signatures first and asks
+    /// for the scalars of the sets before the first bad one only. (The iterator is collected first: the reference stops pulling from it
+    /// at the rejected set.)
     pub fn verify_multiple_aggregate_signatures<'a, R, I>(rng: &mut R, signature_sets: I) -> bool
     where
         R: Rng + ?Sized,
@@ -519,33 +525,32 @@ impl AggregateSignature {
         if n == 0 {
             return true; // e(infinity, -G1) = 1
         }
-        let sigs: Vec<u8> = sets.iter().flat_map(|s| s.0.point.iter().copied()).collect();
-        let (mut errs, mut in_g2) = (vec![0u8; n], vec![0u8; n]);
-        if unsafe { mbls_sig_check_batch(ctx(), sigs.as_ptr(), n as u64, errs.as_mut_ptr(), in_g2.as_mut_ptr()) } != 0 {
-            return false;
-        }
-        let n_ok = (0..n).find(|&i| errs[i] != 0 || in_g2[i] == 0).unwrap_or(n);
-        let mut rands = Vec::<u64>::with_capacity(n_ok);
-        for _ in 0..n_ok {
-            let mut rand = 0u64;
-            while rand == 0 {
-                let mut rand_bytes = [0u8; 8];
-                rng.fill(&mut rand_bytes);
-                rand = i64::from_be_bytes(rand_bytes).wrapping_abs() as u64;
-            }
-            rands.push(rand);
-        }
-        if n_ok < n {
-            return false; // `:273-275`
-        }
-        let (mut apks, mut msgs) = (Vec::new(), Vec::new());
+        let (mut sigs, mut apks, mut msgs) = (Vec::new(), Vec::new(), Vec::new());
         let mut moff: Vec<u64> = vec![0]; // messages of any length each (`&[u8]` per set): one buffer + an offset table
-        for (_, a, m) in &sets {
+        for (s, a, m) in &sets {
+            sigs.extend_from_slice(&s.point);
             apks.extend_from_slice(&a.point);
             msgs.extend_from_slice(m);
             moff.push(msgs.len() as u64);
         }
-        unsafe { mbls_verify_multiple_aggregate_signatures(ctx(), sigs.as_ptr(), apks.as_ptr(), msgs.as_ptr(), 0, moff.as_ptr(), rands.as_ptr(), n) == 1 }
+        // `draw` of mbls_verify_multiple_aggregate_signatures_rng: the scalars of the sets in front of the first bad signature, drawn as `:280-287` does
+        unsafe extern "C" fn draw<R: Rng + ?Sized>(user: *mut c_void, out: *mut u64, count: u64) {
+            let rng: &mut R = &mut **(user as *mut &mut R);
+            for i in 0..count as usize {
+                let mut rand = 0u64;
+                while rand == 0 {
+                    let mut rand_bytes = [0u8; 8];
+                    rng.fill(&mut rand_bytes);
+                    rand = i64::from_be_bytes(rand_bytes).wrapping_abs() as u64;
+                }
+                *out.add(i) = rand;
+            }
+        }
+        let mut rng_ref: &mut R = rng;
+        unsafe {
+            mbls_verify_multiple_aggregate_signatures_rng(ctx(), sigs.as_ptr(), apks.as_ptr(), msgs.as_ptr(), 0, moff.as_ptr(), n, draw::<R>,
+                                                          &mut rng_ref as *mut &mut R as *mut c_void) == 1
+        }
     }
     /// `src/aggregates.rs:319-322`
     pub fn from_bytes(bytes: &[u8]) -> Result<AggregateSignature, AmclError> {

@@ -145,7 +145,7 @@ def test_builds_without_the_generated_routines_are_refused(flag):
 
 # ---- the Rust facade (never compiled here: no toolchain) and the binding INTEGRATION.md shows must stay in lock-step with include/mbls.h
 _C2CANON = {"uint8_t": "u8", "uint32_t": "u32", "uint64_t": "u64", "size_t": "usize", "int": "c_int", "char": "c_char", "void": "c_void",
-            "mbls_ctx": "MblsCtx", "mbls_keytable": "MblsKeyTable", "mbls_multi": "MblsMulti", "mbls_multi_keytable": "MblsMultiKeyTable"}
+            "mbls_ctx": "MblsCtx", "mbls_keytable": "MblsKeyTable", "mbls_multi": "MblsMulti", "mbls_multi_keytable": "MblsMultiKeyTable", "mbls_scalar_source": "MblsScalarSource"}
 
 
 def _split_params(txt):

@@ -123,6 +123,85 @@ def test_verify_multiple_edge_members_vs_oracle(N, vectors):
     assert _vm_gpu(N, sigs, [bad_pk] + pks[1:], msgs, rands) is False
 
 
+def _vm_gpu_rng(N, sigs, apks, msgs, rands):
+    """mbls_verify_multiple_aggregate_signatures_rng with a source that hands out `rands` in order -> (bool, scalars asked for, calls)"""
+    asked = []
+
+    def draw(_user, out, count):
+        for i in range(count):
+            out[i] = rands[i]
+        asked.append(int(count))
+    cb = N.SCALAR_SOURCE(draw)
+    n = len(sigs)
+    got = N.lib().mbls_verify_multiple_aggregate_signatures_rng(N.default_context().handle, N.cbuf(b"".join(sigs)), N.cbuf(b"".join(apks)), N.cbuf(b"".join(msgs)),
+                                                                32, None, n, cb, None)
+    return bool(got), sum(asked), len(asked)
+
+
+@pytest.mark.usefixtures("engine")
+def test_verify_multiple_rng_entry_keeps_the_reference_order(N, vectors):
+    """reference src/aggregates.rs:261-316 in one call: the same bool as the entry that takes the scalars (and as the oracle), and the source is asked
+    exactly once for the scalars of the sets in front of the first signature outside G2 (:272-287) -- all of them when there is none."""
+    rnd = random.Random(41)
+    sks, pks, msgs, sigs, rands = _vm_sets(rnd, 9)
+    assert _vm_gpu_rng(N, sigs, pks, msgs, rands) == (True, 9, 1) and _vm_orc(sigs, pks, msgs, rands) is True
+    probe = bytes.fromhex(vectors["model"]["g2_subgroup_probes"][0]["compressed"])
+
+    def variant(f):
+        s, a, m = list(sigs), list(pks), list(msgs)
+        f(s, a, m)
+        got = _vm_gpu_rng(N, s, a, m, rands)
+        assert got[0] == _vm_gpu(N, s, a, m, rands) == bool(_vm_orc(s, a, m, rands)), got
+        return got
+    assert variant(lambda s, a, m: a.__setitem__(1, pks[0])) == (False, 9, 1)                       # rejected by the pairing check: every scalar drawn
+    assert variant(lambda s, a, m: s.__setitem__(8, sigs[7])) == (False, 9, 1)
+    assert variant(lambda s, a, m: s.__setitem__(5, probe)) == (False, 5, 1)                        # :274-276: sets 0..4 had their scalars drawn
+    assert variant(lambda s, a, m: (s.__setitem__(5, probe), s.__setitem__(7, probe))) == (False, 5, 1)
+    assert variant(lambda s, a, m: s.__setitem__(0, probe)) == (False, 0, 0)                        # nothing drawn, the source never called
+    assert variant(lambda s, a, m: s.__setitem__(2, helpers.G2_INF)) == (False, 9, 1)               # infinity is in G2 (passes :274), the pairing check rejects
+    assert variant(lambda s, a, m: (s.__setitem__(4, helpers.G2_INF), a.__setitem__(4, G1_INF_U))) == (True, 9, 1)
+    assert variant(lambda s, a, m: a.__setitem__(3, G1_INF_U)) == (False, 9, 1)
+    # bytes that do not decode stop the loop like a signature outside G2 (a reference caller could not have built the object)
+    bad_sig = bytes([sigs[3][0] & 0x7F]) + sigs[3][1:]
+    assert _vm_gpu_rng(N, sigs[:3] + [bad_sig] + sigs[4:], pks, msgs, rands) == (False, 3, 1)
+    # a zero from the source fails the batch (the mirrors draw until nonzero, :280-287); an empty batch is true and asks for nothing
+    assert _vm_gpu_rng(N, sigs, pks, msgs, rands[:4] + [0] + rands[5:]) == (False, 9, 1)
+    assert _vm_gpu_rng(N, [], [], [], []) == (True, 0, 0)
+    assert N.lib().mbls_verify_multiple_aggregate_signatures_rng(N.default_context().handle, N.cbuf(b"".join(sigs)), N.cbuf(b"".join(pks)), N.cbuf(b"".join(msgs)),
+                                                                 32, None, 9, N.SCALAR_SOURCE(0), None) == 0          # no source: refused
+    # any 64-bit nonzero scalars, messages behind an offset table
+    moff = (C.c_uint64 * 10)(*[32 * i for i in range(10)])
+    big = [(1 << 63), (1 << 64) - 1] + rands[2:]
+    cb = N.SCALAR_SOURCE(lambda _u, out, count: [out.__setitem__(i, big[i]) for i in range(count)] and None)
+    assert N.lib().mbls_verify_multiple_aggregate_signatures_rng(N.default_context().handle, N.cbuf(b"".join(sigs)), N.cbuf(b"".join(pks)), N.cbuf(b"".join(msgs)),
+                                                                 0, moff, 9, cb, None) == 1
+
+
+@pytest.mark.parametrize("n", [20000, 33000])
+def test_verify_multiple_rng_entry_large_batches(N, n):
+    """the same entry where the chains run side by side with two lanes per message (20 000 sets) and one after the other (33 000: more than half a round)"""
+    import torch, bench
+    ctx = N.default_context(); dev = torch.device("cuda:0")
+    d_sigs, d_msgs, d_pks, _ = bench.build_inputs(ctx, dev, n, 1, N.PK_UNCOMPRESSED, rank=5, negatives=False)
+    sigs, msgs, apks = bytes(d_sigs.cpu().numpy().tobytes()), bytes(d_msgs.cpu().numpy().tobytes()), bytes(d_pks.cpu().numpy().tobytes())
+    rnd = random.Random(n)
+    rands = [rnd.randrange(1, 1 << 64) for _ in range(n)]
+    rr = (C.c_uint64 * n)(*rands)
+    asked = []
+
+    def draw(_user, out, count):
+        C.memmove(out, rr, 8 * count); asked.append(int(count))
+    cb = N.SCALAR_SOURCE(draw)
+    call = lambda s: N.lib().mbls_verify_multiple_aggregate_signatures_rng(ctx.handle, N.cbuf(s), N.cbuf(apks), N.cbuf(msgs), 32, None, n, cb, None)
+    assert call(sigs) == 1 and asked == [n]
+    assert N.lib().mbls_verify_multiple_aggregate_signatures(ctx.handle, N.cbuf(sigs), N.cbuf(apks), N.cbuf(msgs), 32, None, rr, n) == 1
+    k = n - 7
+    swapped = sigs[:96 * k] + sigs[96 * (k - 1):96 * k] + sigs[96 * (k + 1):]                        # set k carries its neighbour's signature: in G2, wrong
+    asked.clear()
+    assert call(swapped) == 0 and asked == [n]
+    assert N.lib().mbls_verify_multiple_aggregate_signatures(ctx.handle, N.cbuf(swapped), N.cbuf(apks), N.cbuf(msgs), 32, None, rr, n) == 0
+
+
 def test_verify_multiple_scalar_requirements(N):
     """The blinding scalars are the security of the batch check: NULL is refused and a zero scalar fails the call (the reference
     draws until nonzero, src/aggregates.rs:280-287)."""
