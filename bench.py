@@ -683,12 +683,17 @@ def spawn_ranks(n, argv, stub=False, timeout_s=3600):
         return 6
     t0 = time.time()
     codes = [None] * n
+    t_failed, grace_s = None, 20.0
     while any(c is None for c in codes):
         for i, p in enumerate(procs):
             if codes[i] is None:
                 codes[i] = p.poll()
         failed = [c for c in codes if c not in (None, 0)]
-        if failed or time.time() - t0 > timeout_s:       # one rank is gone: the others would wait in a collective for ever
+        if failed and t_failed is None:
+            t_failed = time.time()
+        # one rank is gone: the others would wait in a collective for ever -- but a failure every rank has agreed on (a parity mismatch is reduced over the
+        # ranks, all of them then leave with the same code) ends them by itself within moments: they get a grace period before they are killed
+        if (t_failed is not None and time.time() - t_failed > grace_s) or time.time() - t0 > timeout_s:
             for i, p in enumerate(procs):
                 if codes[i] is None:
                     p.kill(); codes[i] = p.wait() or 9
