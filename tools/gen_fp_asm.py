@@ -676,8 +676,21 @@ def align8(lines):
     return out
 
 
+# MBLS_GEN_TIMING_NO_VMWAIT=1 / MBLS_GEN_TIMING_NO_LGKMWAIT=1: THROW-AWAY builds for timing only -- the three big routines without their waits for workspace
+# loads / for LDS reads (wrong results, same instruction stream otherwise): what the exposed memory latency of a lone wave costs (scripts/dbg/ab_gen.sh). Never
+# committed: the freshness tests compare the tracked files with the default generation.
+TIMING_NO_VMWAIT = os.environ.get("MBLS_GEN_TIMING_NO_VMWAIT", "0") == "1"
+TIMING_NO_LGKMWAIT = os.environ.get("MBLS_GEN_TIMING_NO_LGKMWAIT", "0") == "1"
+TIMING_ROUTINES = ("MBLS_MILLER_LOOP_D_ASM", "MBLS_FINAL_EXP_D_ASM", "MBLS_G2_HASH_TAIL_D_ASM")
+
+
 def emit(name, lines):
     out = ["#define %s \\" % name]
+    if name in TIMING_ROUTINES:
+        if TIMING_NO_VMWAIT:
+            lines = [l for l in lines if not l.startswith("s_waitcnt vmcnt")]
+        if TIMING_NO_LGKMWAIT:
+            lines = [l for l in lines if not l.startswith("s_waitcnt lgkmcnt")]
     if PREFER_E32:
         lines = [to_e32(l) for l in lines]
     if ALIGN8:
