@@ -325,6 +325,47 @@ __global__ void MBLS_LB k_blind_sig_d(mbls_ws ws, const uint8_t* sigs96, const u
     if (st) atomicOr(status + i, st);
 #endif
 }
+// The signature chain of SMALL verify_multiple batches (their Miller loops run on waves: the signatures are the critical path) with TWO lanes per signature:
+// lanes 2 j, 2 j + 1 of a workgroup = item 32 blockIdx + j; both decode, both walk the generated routine on identical values, products in pairs.
+// k_sig2 = k_sig with the subgroup test (the one-call entry's first phase); k_blind_sig2_d = k_blind_sig_d.
+__global__ void MBLS_LB k_sig2(mbls_ws ws, const uint8_t* sigs96, uint32_t* status, uint64_t n) {
+#if MBLS_DEVICE_ASM
+    __shared__ uint32_t spill[154 * 64];          // one column per ITEM: the two lanes of an item park identical values in it
+    const uint64_t t = gid(); if (t >= 2 * n) return;
+    const uint64_t i = t >> 1;
+    uint32_t st = 0;
+    fp2 x, y; bool inf;
+    int e = g2_decode_compressed_t<true>(&x, &y, &inf, sigs96 + 96 * i);
+    if (e) { st |= MBLS_ST_BAD_SIG_ENCODING; inf = true; }
+    if (inf) { x = fp2_zero(); y = fp2_zero(); }
+    ws_st2(ws, MBLS_SLOT_SIG, i, x); ws_st2(ws, MBLS_SLOT_SIG + 2, i, y);
+    const uint32_t fl = g2_subgroup2_d_call(ws, i, (MBLS_LDS uint32_t*)spill, threadIdx.x);
+    if (!((fl & 1u) | inf)) st |= MBLS_ST_SIG_NOT_IN_G2;
+    if (st && !(t & 1)) atomicOr(status + i, st);
+#endif
+}
+__global__ void MBLS_LB k_blind_sig2_d(mbls_ws ws, const uint8_t* sigs96, const uint64_t* rands, uint32_t* status, uint64_t n) {
+#if MBLS_DEVICE_ASM
+    __shared__ uint32_t spill[154 * 64];
+    const uint64_t t = gid(); if (t >= 2 * n) return;
+    const uint64_t i = t >> 1;
+    uint32_t st = 0;
+    bool inf;
+    if (sigs96) {
+        fp2 x, y;
+        int e = g2_decode_compressed_t<true>(&x, &y, &inf, sigs96 + 96 * i);
+        if (e) { st |= MBLS_ST_BAD_SIG_ENCODING; inf = true; }
+        if (inf) { x = fp2_zero(); y = fp2_zero(); }
+        ws_st2(ws, MBLS_SLOT_SIG, i, x); ws_st2(ws, MBLS_SLOT_SIG + 2, i, y);
+    } else
+        inf = fp2_is_zero(ws_ld2(ws, MBLS_SLOT_SIG + 2, i));
+    const uint64_t r = rands[i];
+    if (r == 0) st |= MBLS_ST_BAD_SCALAR;
+    const uint32_t fl = g2_blind2_d_call(ws, i, (MBLS_LDS uint32_t*)spill, threadIdx.x, inf ? 0 : r, sigs96 ? 0u : 1u);
+    if (!((fl & 1u) | inf)) st |= MBLS_ST_SIG_NOT_IN_G2;
+    if (st && !(t & 1)) atomicOr(status + i, st);
+#endif
+}
 // f_i = Miller(H_i, P_i) for i < n; lane n (if with_sig) computes Miller(S, -G1) with S read from slot S of item `s_item`.
 // The loop itself is the generated single-pair routine (mbls_pairing.h, miller_loop_single_d).
 template <int LPP> MBLS_FN void miller_single_body(const mbls_ws& ws, uint64_t n, int with_sig, uint64_t s_item, uint32_t* spill) {
@@ -2085,7 +2126,11 @@ static int verify_multiple_impl(mbls_ctx* c, const uint8_t* d_sigs, const uint8_
     } else if (!d_apks)    // sets given by their wire-format keys: AggregatePublicKey::aggregate on the device first (src/aggregates.rs:29-39)
         launch_aggregate(ws, d_pks, d_pk_offsets, k, pk_format, MBLS_MODE_VERIFY, c->d_status, n, s);
     hipLaunchKernelGGL(k_blind_g1_d, dim3(nblk(n)), dim3(WG), 0, s, ws, tab ? (const uint8_t*)nullptr : d_apks, d_rands, c->d_status, n);
-    hipLaunchKernelGGL(k_blind_sig_d, dim3(nblk(n)), dim3(WG), 0, s_sig, ws, sigs_resident ? (const uint8_t*)nullptr : d_sigs, d_rands, c->d_status, n);
+    // small batches (their Miller loops run one WAVE per pair, see npairing_finish): the signature chain is what the call waits for -- two lanes per signature
+    if (2 * n <= c->coop_max_items)
+        hipLaunchKernelGGL(k_blind_sig2_d, dim3(nblk(2 * n)), dim3(WG), 0, s_sig, ws, sigs_resident ? (const uint8_t*)nullptr : d_sigs, d_rands, c->d_status, n);
+    else
+        hipLaunchKernelGGL(k_blind_sig_d, dim3(nblk(n)), dim3(WG), 0, s_sig, ws, sigs_resident ? (const uint8_t*)nullptr : d_sigs, d_rands, c->d_status, n);
     const bool side_s_chain = !fork && s != c->hs_b;                  // the sum tree waits for the product tree's company (npairing_finish)
     if (!side_s_chain) g2_tree(c, ws, n, s_sig);
     if (fork) {     // S is complete: its Miller loop runs on one wave beside the other chains and the sets' Miller loops (most SIMDs are idle)
@@ -2225,7 +2270,8 @@ extern "C" int mbls_verify_multiple_aggregate_signatures_rng(mbls_ctx* c, const 
     auto fail = [&]() { (void)hipStreamSynchronize(c->hs_a); (void)hipStreamSynchronize(c->hs_b); (void)hipStreamSynchronize(c->hs_c); c->ws_pending = false; return 0; };
     if (hipMemsetAsync(c->d_status, 0, 4 * n, s) != hipSuccess) return fail();
     if (fork) { (void)hipEventRecord(c->hs_ev, s); (void)hipStreamWaitEvent(c->hs_b, c->hs_ev, 0); (void)hipStreamWaitEvent(c->hs_c, c->hs_ev, 0); }
-    hipLaunchKernelGGL(k_sig, dim3(nblk(n)), dim3(WG), 0, s_sig, ws, (const uint8_t*)ds.as<uint8_t>(), c->d_status, (uint64_t)n, 1);
+    if (2 * n <= c->coop_max_items) hipLaunchKernelGGL(k_sig2, dim3(nblk(2 * n)), dim3(WG), 0, s_sig, ws, (const uint8_t*)ds.as<uint8_t>(), c->d_status, (uint64_t)n);
+    else hipLaunchKernelGGL(k_sig, dim3(nblk(n)), dim3(WG), 0, s_sig, ws, (const uint8_t*)ds.as<uint8_t>(), c->d_status, (uint64_t)n, 1);
     if (fork) launch_hash(c, ws, d_msgs, msg_len, d_moff, c->d_status, n, c->hs_c, pair_hash);       // the message phase does not wait for the host
     if (hipStreamSynchronize(s_sig) != hipSuccess || hipMemcpy(st.data(), c->d_status, 4 * n, hipMemcpyDeviceToHost) != hipSuccess) return fail();
     size_t reached = n;                                                     // the sets the reference's loop draws a scalar for

@@ -281,6 +281,32 @@ MBLS_FN uint32_t g2_blind_d_call(const mbls_ws& ws, uint64_t i, MBLS_LDS uint32_
                  : MBLS_G2_BLIND_D_ASM_CLOBBERS);
     return fl;
 }
+// TWO LANES PER SIGNATURE (small batches of verify_multiple, where the signature chain is the critical path: k_sig2, k_blind_sig2_d): lanes 2 j and 2 j + 1
+// come with the same workspace item, the same LDS column and the same scalar, walk the routine on identical values and take the independent products of
+// every doubling / addition in pairs (g2_group_routine("sig", two_lane=True), g2_blind_routine(two_lane=True)). `lane` = threadIdx.x, `i` = THIS lane's item.
+extern "C" __device__ __attribute__((noinline, used, aligned(64))) void mbls_g2_subgroup2_d_asm_fn() { asm volatile(MBLS_G2_SUBGROUP2_D_ASM); }
+extern "C" __device__ __attribute__((noinline, used, aligned(64))) void mbls_g2_blind2_d_asm_fn() { asm volatile(MBLS_G2_BLIND2_D_ASM); }
+MBLS_FN uint32_t g2_subgroup2_d_call(const mbls_ws& ws, uint64_t i, MBLS_LDS uint32_t* spill, uint32_t lane) {
+    const uint32_t col = lane >> 1;
+    const uint32_t addr = (uint32_t)(uintptr_t)(spill + col);
+    const uint64_t gb = (uint64_t)(uintptr_t)ws.w + 4ull * (i - col) - (uint64_t)(uint32_t)(uintptr_t)spill;
+    const uint32_t gb_lo = __builtin_amdgcn_readfirstlane((uint32_t)gb), gb_hi = __builtin_amdgcn_readfirstlane((uint32_t)(gb >> 32));
+    const uint32_t st4 = __builtin_amdgcn_readfirstlane((uint32_t)(ws.stride * 4));
+    uint32_t fl = 0;
+    asm volatile(MBLS_ASM_CALL("mbls_g2_subgroup2_d_asm_fn") : "+{v251}"(fl) : "{v252}"(addr), "{s68}"(gb_lo), "{s69}"(gb_hi), "{s70}"(st4) : MBLS_G2_GROUP_D_ASM_CLOBBERS);
+    return fl;
+}
+MBLS_FN uint32_t g2_blind2_d_call(const mbls_ws& ws, uint64_t i, MBLS_LDS uint32_t* spill, uint32_t lane, uint64_t r, uint32_t skip_test = 0) {
+    const uint32_t col = lane >> 1;
+    const uint32_t addr = (uint32_t)(uintptr_t)(spill + col);
+    const uint64_t gb = (uint64_t)(uintptr_t)ws.w + 4ull * (i - col) - (uint64_t)(uint32_t)(uintptr_t)spill;
+    const uint32_t gb_lo = __builtin_amdgcn_readfirstlane((uint32_t)gb), gb_hi = __builtin_amdgcn_readfirstlane((uint32_t)(gb >> 32));
+    const uint32_t st4 = __builtin_amdgcn_readfirstlane((uint32_t)(ws.stride * 4));
+    uint32_t fl = skip_test, rlo = (uint32_t)r, rhi = (uint32_t)(r >> 32);
+    asm volatile(MBLS_ASM_CALL("mbls_g2_blind2_d_asm_fn") : "+{v251}"(fl), "+{v248}"(rlo), "+{v249}"(rhi) : "{v252}"(addr), "{s68}"(gb_lo), "{s69}"(gb_hi), "{s70}"(st4)
+                 : MBLS_G2_BLIND_D_ASM_CLOBBERS);
+    return fl;
+}
 #endif
 // hash_to_field: u0 -> workspace slots 31, 32, u1 -> 37, 38 (2^384 domain); the generated routine takes them from there. A function of
 // its own: its message schedule and digest arrays then stay out of the kernel's frame.

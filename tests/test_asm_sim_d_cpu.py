@@ -1169,11 +1169,34 @@ def test_paired_fp_products_and_squarings():
 
 
 # ---------------------------------------------------------------------------------------------- the blinding routines of verify_multiple
-def _blind_run(kind, r, ws_init, out_slots, ct=False):
+class _LanePair:
+    """the two lanes of one signature in the two-lane routines: two machines in lockstep (run_pair) with the same workspace item and, being
+    two lanes of one item, the same LDS column -- only `v`, `a`, the lane masks and the lane number are their own. Attribute reads go to the
+    even lane; `run` drives both."""
+
+    def __init__(self):
+        from asm_sim import run_pair
+        self._run_pair = run_pair
+        self.ma, self.mb = miller_machine(0), miller_machine(0)
+        self.mb.mem = self.ma.mem; self.mb.lds = self.ma.lds
+        for lane, mach in ((0, self.ma), (1, self.mb)):
+            mach.lane = 6 + lane; mach.model_exec = True
+
+    def run(self, lines):
+        self._run_pair(self.ma, self.mb, lines)
+
+    def both(self):
+        return (self.ma, self.mb)
+
+
+def _blind_run(kind, r, ws_init, out_slots, ct=False, two_lane=False, skip_test=False):
     """the instruction streams of g1_blind_routine / g2_blind_routine in their control order (the skeleton's loops mirrored here: table
-    of 1 P .. 8 P, top digit, sixteen windows of four doublings + one table addition), returning the words left in out_slots"""
-    full, pieces, st = t.g1_blind_routine() if kind == "g1" else t.g2_blind_routine(ct=ct)
+    of 1 P .. 8 P, top digit, sixteen windows of four doublings + one table addition), returning the words left in out_slots.
+    two_lane: the routine for lane pairs on two machines in lockstep; every check below then holds on BOTH lanes."""
+    full, pieces, st = t.g1_blind_routine() if kind == "g1" else t.g2_blind_routine(ct=ct, two_lane=two_lane)
     assert not any("scratch" in l or "buffer_" in l for l in full)
+    if two_lane:
+        return _blind_run_pair(pieces, st, r, ws_init, out_slots)
     if ct:      # constant-time table access: no memory instruction takes its lane offset from anything but the item's own (LADDR), no per-lane record offset
         mem = [l for l in full if l.startswith("global_")]
         assert mem and all(("%s, s[74:75]" % t.LADDR in l) or (l.startswith("global_store") and l.split()[1].rstrip(",") == t.LADDR) for l in mem)
@@ -1229,6 +1252,89 @@ def _blind_run(kind, r, ws_init, out_slots, ct=False):
         add("addt")
     m.run(pieces["epi"][:-1])
     return [ws_get(m, sl) for sl in out_slots], verdict
+
+
+def _blind_run_pair(pieces, st, r, ws_init, out_slots):
+    assert st["dbl"].get("pairs") == 3 and st["addt"].get("pairs") == 7 and st["madd"].get("pairs") == 5 and "pairs" not in st["fix"]
+    lp = _LanePair()
+    for m in lp.both():
+        m.v[248], m.v[249] = r & 0xFFFFFFFF, r >> 32
+    for slot, x in ws_init.items():
+        ws_put(lp.ma, slot, x)
+    lp.run(pieces["pro"])
+    assert (lp.ma.s[("pair", 94)], lp.mb.s[("pair", 94)]) == (0, 1)
+    rp = r + 0x8888888888888888
+    for m in lp.both():
+        assert (m.v[248] | (m.v[249] << 32), m.v[247]) == (rp & 0xFFFFFFFFFFFFFFFF, rp >> 64)
+    pr = lambda m, nm: m.s[("pair", int(nm[2:nm.index(":")]))]
+
+    def add(name):
+        lp.run(pieces[name])
+        flags = [(pr(m, t.M_H0), pr(m, t.M_R0), pr(m, t.M_INF1), pr(m, t.M_INF2)) for m in lp.both()]
+        assert flags[0] == flags[1], (name, flags)
+        h0, r0, i1, i2 = flags[0]
+        if h0 and r0 and not i1 and not i2:
+            lp.run(pieces["fix"])
+    lp.run(pieces["s_start"])
+    for ph, n_ in enumerate(t.RUNS):
+        for _ in range(n_):
+            lp.run(pieces["dbl"])
+        if ph < 5:
+            add("madd")
+    lp.run(pieces["s_compare"])
+    verdicts = []
+    for m in lp.both():
+        ex, ey, ia, ib = pr(m, t.M_H0), pr(m, t.M_R0), pr(m, t.M_INF1), pr(m, t.M_INF2)
+        verdicts.append(bool((ia and ib) or (not ia and not ib and ex and ey)))
+    assert verdicts[0] == verdicts[1]
+    lp.run(pieces["b_start"])
+    for m in lp.both():
+        m.s[71] = 0
+    lp.run(pieces["b_tab"]); lp.run(pieces["dbl"])
+    for m in lp.both():
+        m.s[71] = m.s[72]
+    lp.run(pieces["b_tab"])
+    for _ in range(6):
+        add("madd")
+        for m in lp.both():
+            m.s[71] += m.s[72]
+        lp.run(pieces["b_tab"])
+    lp.run(pieces["b_inf"]); lp.run(pieces["top"])
+    add("addt")
+    for shift in range(60, -4, -4):
+        for _ in range(4):
+            lp.run(pieces["dbl"])
+        for m in lp.both():
+            m.s[38] = shift
+        lp.run(pieces["digit"])
+        d = ((rp >> shift) & 15) - 8
+        for m in lp.both():
+            assert m.v[250] == LADDR + (max(abs(d), 1) - 1) * m.s[72]
+        add("addt")
+    lp.run(pieces["epi"][:-1])
+    return [ws_get(lp.ma, sl) for sl in out_slots], verdicts[0]
+
+
+def test_g2_blinding_routine_two_lanes_per_signature():
+    """k_blind_sig2_d's routine (small batches of verify_multiple): the two lanes of a signature -- same workspace item, same LDS column, same scalar -- walk
+    the subgroup test and the windowed [r] sig together, the products of every doubling / addition in pairs; same verdict and the same [r] sig as the model,
+    on both lanes, for a signature in G2 (random scalar, extreme digits) and a curve point outside it"""
+    M = _g2m()
+    rng = random.Random(34)
+    ri = pow(R384, -1, P)
+    inside = M.g2_mul(M.G2, rng.randrange(1, M.R))
+    while True:
+        x = (rng.randrange(P), rng.randrange(P))
+        y = M.f2_sqrt(M.f2_add(M.f2_mul(M.f2_sqr(x), x), M.B2))
+        if y is not None:
+            outside = (x, y)
+            break
+    for pt, r in ((inside, rng.randrange(1, 1 << 64)), (inside, 0x0807060504030201), (outside, 0xF00000000000000F)):
+        ws = {t.G2_SLOTS["SIG"] + i: c * R384 % P for i, c in enumerate((pt[0][0], pt[0][1], pt[1][0], pt[1][1]))}
+        out, verdict = _blind_run("g2", r, ws, range(t.BL_OUT, t.BL_OUT + 6), two_lane=True)
+        assert verdict == M.subgroup_check_g2(pt)
+        c = [w * ri % P for w in out]
+        assert jac2_affine(M, (c[0], c[1]), (c[2], c[3]), (c[4], c[5])) == M.g2_mul(pt, r), hex(r)
 
 
 def test_g1_blinding_routine():

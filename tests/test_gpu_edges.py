@@ -177,9 +177,10 @@ def test_verify_multiple_rng_entry_keeps_the_reference_order(N, vectors):
                                                                  0, moff, 9, cb, None) == 1
 
 
-@pytest.mark.parametrize("n", [20000, 33000])
+@pytest.mark.parametrize("n", [2560, 2561, 20000, 33000])
 def test_verify_multiple_rng_entry_large_batches(N, n):
-    """the same entry where the chains run side by side with two lanes per message (20 000 sets) and one after the other (33 000: more than half a round)"""
+    """the same entry at the last size whose signature chain runs on lane pairs (2 560 sets: k_sig2 / k_blind_sig2_d) and the first on single lanes, where the
+    chains run side by side with two lanes per message (20 000 sets), and one after the other (33 000: more than half a round)"""
     import torch, bench
     ctx = N.default_context(); dev = torch.device("cuda:0")
     d_sigs, d_msgs, d_pks, _ = bench.build_inputs(ctx, dev, n, 1, N.PK_UNCOMPRESSED, rank=5, negatives=False)

@@ -2627,7 +2627,7 @@ G2_SLOTS = dict(AD=19, P=31, T1=37, T2=13, T3=7, Q0=7, Q1=13, SIGAD=43, SIG=3, H
 BL_TAB, BL_OUT = 49, 25
 BL_SEL = 97                          # constant-time form (signing): the record the window selected, copied here by a scan over all eight (slots 97..102)
 BL_FREE_V = list(range(9, 17))       # block 17 (v238..v251) belongs to the shell: v[248:249] the scalar, v247 its top digit, v250 = VOFF, v251 status
-M_NEGQ, M_ZEROQ = "s[94:95]", "s[36:37]"
+M_NEGQ, M_ZEROQ = "s[90:91]", "s[36:37]"              # (not s[94:95]: that pair is PAIR_ROLE in the two-lane routines)
 
 
 def prog_g2_madd(ad_slot):
@@ -2896,9 +2896,9 @@ G1B_FREE_V = list(range(8, 17))
 # M_ZEROQ = it is zero, VOFF = lane offset of table record |digit| - 1.
 BLIND_RPRIME = ["v_add_co_u32_e32 v248, vcc, 0x88888888, v248", "v_mov_b32_e32 v247, 0x88888888", "v_addc_co_u32_e32 v249, vcc, v249, v247, vcc",
                 "v_cndmask_b32_e64 v247, 0, 1, vcc"]
-BLIND_TOP = ["s_mov_b64 %s, 0" % "s[94:95]", "v_cmp_eq_u32_e64 %s, 0, v247" % "s[36:37]", "v_mov_b32_e32 %s, %s" % (VOFF, LADDR)]
+BLIND_TOP = ["s_mov_b64 %s, 0" % M_NEGQ, "v_cmp_eq_u32_e64 %s, 0, v247" % M_ZEROQ, "v_mov_b32_e32 %s, %s" % (VOFF, LADDR)]
 BLIND_DIGIT = ["v_lshrrev_b64 v[246:247], s38, v[248:249]", "v_and_b32_e32 v246, 15, v246", "v_subrev_u32_e32 v246, 8, v246",          # d = e - 8 in [-8, 7]
-               "v_cmp_gt_i32_e64 %s, 0, v246" % "s[94:95]", "v_cmp_eq_u32_e64 %s, 0, v246" % "s[36:37]",
+               "v_cmp_gt_i32_e64 %s, 0, v246" % M_NEGQ, "v_cmp_eq_u32_e64 %s, 0, v246" % M_ZEROQ,
                "v_sub_u32_e32 v247, 0, v246", "v_max_i32_e32 v246, v246, v247", "v_max_i32_e32 v246, 1, v246", "v_subrev_u32_e32 v246, 1, v246",
                "v_mul_lo_u32 v246, v246, s72", "v_add_u32_e32 %s, %s, v246" % (VOFF, LADDR)]
 
@@ -3046,8 +3046,10 @@ def g1_blind_routine():
     return pro + main + expand_calls_d(epi) + ret + dbl4 + subs, pieces, st
 
 
-def g2_blind_routine(ct=False):
+def g2_blind_routine(ct=False, two_lane=False):
     """ct: the constant-time form used by signing (blind_scan_ct) -- same arithmetic, table records by scan + selection instead of by address.
+    two_lane (small batches of verify_multiple, k_blind_sig2_d): lanes 2 j and 2 j + 1 are ONE signature -- same workspace item, same LDS column, same
+    scalar --, both walk the whole routine on identical values and the independent products of a doubling / an addition go in pairs (pair_products).
     The signature phase of verify_multiple_aggregate_signatures (reference src/aggregates.rs:274-276, :303) as ONE routine: the subgroup
     test psi(P) = [x]P of the decoded signature, then [r] P for the lane's 64-bit blinding scalar r by signed 4-bit windows:
     r + 0x8888888888888888 = sum e_j 16^j (+ a carry digit), r = sum (e_j - 8) 16^j + carry 2^64; the table 1 P .. 8 P lives in workspace
@@ -3058,13 +3060,16 @@ def g2_blind_routine(ct=False):
     S = G2_SLOTS
     B, st = {}, {}
     for nm in ["madd", "addt", "dbl", "fix", "s_start", "s_compare", "b_tab", "b_start", "b_inf"]:
-        B[nm], st[nm] = build_g2("addt_ct" if (ct and nm == "addt") else nm, S["SIGAD"], free_v=BL_FREE_V)
+        B[nm], st[nm] = build_g2("addt_ct" if (ct and nm == "addt") else nm, S["SIGAD"], free_v=BL_FREE_V, pair_mode=(two_lane and nm != "fix"))
     top, digit = (BLIND_TOP_CT, BLIND_DIGIT_CT) if ct else (BLIND_TOP, BLIND_DIGIT)
     scan = blind_scan_ct() if ct else []
     X = lambda nm: expand_calls_d(B[nm])
     ADD, ADDT, LADDER, DBL4 = 50, 53, 52, 54
     pro = ["s_mov_b64 s[80:81], s[30:31]", "s_waitcnt vmcnt(0)"] + shell_constants() + ["s_mov_b64 %s, exec" % EXEC_ALL,
            "s_mul_i32 s72, %s, %d" % (GSTRIDE, 12 * 6)]
+    if two_lane:
+        assert PAIR_EXEC == EXEC_ALL and not ct
+        pro += pair_prologue()
     # r' = r + 0x8888888888888888, its carry is the 17th digit
     pro += BLIND_RPRIME
 
@@ -3170,6 +3175,12 @@ def main():
     full, pieces, st = g2_blind_routine()
     txt += emit("MBLS_G2_BLIND_D_ASM", full) + "\n"
     print("g2 blind routine", len(full), "lines; addt", len(pieces["addt"]), st["addt"])
+    full, pieces, st = g2_blind_routine(two_lane=True)
+    txt += emit("MBLS_G2_BLIND2_D_ASM", full) + "\n"
+    print("g2 blind routine, two lanes per signature:", len(full), "lines; dbl", st["dbl"].get("pairs"), "addt", st["addt"].get("pairs"), "madd", st["madd"].get("pairs"), "pairs")
+    full, pieces, st = g2_group_routine("sig", two_lane=True)
+    txt += emit("MBLS_G2_SUBGROUP2_D_ASM", full) + "\n"
+    print("g2 subgroup routine, two lanes per signature:", len(full), "lines")
     full, pieces, st = g2_blind_routine(ct=True)
     txt += emit("MBLS_G2_BLIND_CT_D_ASM", full) + "\n"
     print("g2 blind routine, constant-time table access:", len(full), "lines; scan", len(pieces["scan"]))
