@@ -1975,15 +1975,20 @@ extern "C" int mbls_aggregate_verify(mbls_ctx* c, const uint8_t sig[96], const u
     if (hipMemsetAsync(c->d_results, 0, 1, s) != hipSuccess) return 0;      // false until the tail kernel has spoken
     // three chains side by side: the signature (decode + subgroup test: k_sig on item 0's slots, then into slot S), the keys, the messages
     (void)hipEventRecord(c->hs_ev, s); (void)hipStreamWaitEvent(c->hs_b, c->hs_ev, 0); (void)hipStreamWaitEvent(c->hs_c, c->hs_ev, 0);
-    hipLaunchKernelGGL(k_sig, dim3(1), dim3(WG), 0, c->hs_b, ws, (const uint8_t*)dsig.as<uint8_t>(), c->d_status, (uint64_t)1, 1);
+    hipLaunchKernelGGL(k_sig2, dim3(1), dim3(WG), 0, c->hs_b, ws, (const uint8_t*)dsig.as<uint8_t>(), c->d_status, (uint64_t)1);      // (two lanes: the chain is latency)
     hipLaunchKernelGGL(k_sigslot_to_s, dim3(1), dim3(WG), 0, c->hs_b, ws, (uint64_t)0);
+    (void)hipEventRecord(c->hs_ev2, c->hs_b);                                   // the signature's status bits and S exist
+    // ... and its Miller loop (S, -G1) runs on one wave right away, beside the message phase (the longest chain) and the pairs' own loops: the tail then only
+    // multiplies and exponentiates (program vmfinal instead of vmtail)
+    coop_run(c, COOP_SMILLER, ws, (uint64_t)0, (uint64_t)1, (uint64_t)0, (uint64_t)1, (uint32_t*)nullptr, (uint8_t*)nullptr, COOP_RES_ITEM, c->hs_b);
+    (void)hipEventRecord(c->hs_ev, c->hs_b);
     hipLaunchKernelGGL(k_blind_g1, dim3(nblk(n)), dim3(WG), 0, s, ws, dp.as<uint8_t>(), (const uint64_t*)nullptr, c->d_status, n);   // r_i = 1: no blinding in AggregateVerify
     launch_hash(c, ws, dm.as<uint8_t>(), 0u, (const uint64_t*)doff.as<uint64_t>(), c->d_status, n, c->hs_c);
-    (void)hipEventRecord(c->hs_ev2, c->hs_b); (void)hipEventRecord(c->hs_ev3, c->hs_c);
+    (void)hipEventRecord(c->hs_ev3, c->hs_c);
     (void)hipStreamWaitEvent(s, c->hs_ev2, 0); (void)hipStreamWaitEvent(s, c->hs_ev3, 0);
     hipLaunchKernelGGL(k_status_or, dim3(nblk(n)), dim3(WG), 0, s, c->d_status, n, c->d_scalar);
     // a signature outside G2 or an undecodable member makes the tail answer false (reference src/aggregates.rs:137-139): no host round trip
-    if (npairing_finish(c, n, s, c->d_results)) return 0;
+    if (npairing_finish(c, n, s, c->d_results, c->hs_ev)) return 0;
     uint8_t r = 0;
     if (hipStreamSynchronize(s) != hipSuccess) return 0;
     c->ws_pending = false;
