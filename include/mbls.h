@@ -319,7 +319,8 @@ int mbls_verify_multiple_aggregate_signatures_device(mbls_ctx* ctx, const uint8_
  * called at most once for the `count` scalars of the sets in front of the first bad signature (count = n when there is none;
  * not called for count = 0 or n = 0) and must fill out[0 .. count) with NONZERO scalars in set order; what follows does not repeat
  * the subgroup test. Same bool as mbls_verify_multiple_aggregate_signatures with the same scalars. `draw` runs on the calling
- * thread while the context is locked. include/milagro_bls.hpp, rust/src/lib.rs and milagro_bls_amd/api.py draw as :280-287 does. */
+ * thread while the context is locked and the call's staging buffers are in use: it must not call back into the library with
+ * this context (another context is fine). include/milagro_bls.hpp, rust/src/lib.rs and milagro_bls_amd/api.py draw as :280-287 does. */
 typedef void (*mbls_scalar_source)(void* user, uint64_t* out, uint64_t count);
 int mbls_verify_multiple_aggregate_signatures_rng(mbls_ctx* ctx, const uint8_t* sigs96, const uint8_t* apks96,
                                               const uint8_t* msgs, uint32_t msg_len, const uint64_t* msg_offsets,
