@@ -681,6 +681,8 @@ def align8(lines):
 # committed: the freshness tests compare the tracked files with the default generation.
 TIMING_NO_VMWAIT = os.environ.get("MBLS_GEN_TIMING_NO_VMWAIT", "0") == "1"
 TIMING_NO_LGKMWAIT = os.environ.get("MBLS_GEN_TIMING_NO_LGKMWAIT", "0") == "1"
+TIMING_NO_LDS = os.environ.get("MBLS_GEN_TIMING_NO_LDS", "0") == "1"                # ... without their LDS instructions / their workspace loads: what ISSUING them costs
+TIMING_NO_GLOADS = os.environ.get("MBLS_GEN_TIMING_NO_GLOADS", "0") == "1"
 TIMING_ROUTINES = ("MBLS_MILLER_LOOP_D_ASM", "MBLS_FINAL_EXP_D_ASM", "MBLS_G2_HASH_TAIL_D_ASM")
 
 
@@ -691,6 +693,10 @@ def emit(name, lines):
             lines = [l for l in lines if not l.startswith("s_waitcnt vmcnt")]
         if TIMING_NO_LGKMWAIT:
             lines = [l for l in lines if not l.startswith("s_waitcnt lgkmcnt")]
+        if TIMING_NO_LDS:
+            lines = [l for l in lines if not l.startswith("ds_")]
+        if TIMING_NO_GLOADS:
+            lines = [l for l in lines if not l.startswith("global_load")]
     if PREFER_E32:
         lines = [to_e32(l) for l in lines]
     if ALIGN8:
