@@ -683,7 +683,32 @@ TIMING_NO_VMWAIT = os.environ.get("MBLS_GEN_TIMING_NO_VMWAIT", "0") == "1"
 TIMING_NO_LGKMWAIT = os.environ.get("MBLS_GEN_TIMING_NO_LGKMWAIT", "0") == "1"
 TIMING_NO_LDS = os.environ.get("MBLS_GEN_TIMING_NO_LDS", "0") == "1"                # ... without their LDS instructions / their workspace loads: what ISSUING them costs
 TIMING_NO_GLOADS = os.environ.get("MBLS_GEN_TIMING_NO_GLOADS", "0") == "1"
+TIMING_X4 = os.environ.get("MBLS_GEN_TIMING_X4", "0") == "1"                        # ... with every FOUR workspace words of a value moved by ONE 16-byte instruction
 TIMING_ROUTINES = ("MBLS_MILLER_LOOP_D_ASM", "MBLS_FINAL_EXP_D_ASM", "MBLS_G2_HASH_TAIL_D_ASM")
+
+
+def timing_x4(lines):
+    """timing only (scripts/dbg/ab_x4.sh): what a workspace of 16-byte vectors per lane would cost to access -- of the twelve dword loads / stores of a value the
+    1st, 5th and 9th become dwordx4 accesses at 16 bytes per lane (lane offset 4 x v252 in v102, a register no routine writes), the other nine go away. The
+    addresses stay inside the value's own rows; the data is garbage."""
+    out = []
+    for n, l in enumerate(lines):
+        m = re.match(r"global_load_dword v(\d+), v252, s\[74:75\]$", l)
+        if m:
+            r = int(m.group(1)); j = r % 14 - 2
+            if j % 4 == 0 and 0 <= j <= 8:
+                out.append("global_load_dwordx4 v[%d:%d], v102, s[74:75]" % (r, r + 3))
+            continue
+        m = re.match(r"global_store_dword v252, v(\d+), s\[74:75\]$", l)
+        if m:
+            r = int(m.group(1)); j = r % 14
+            if j % 4 == 0 and j <= 8:
+                out.append("global_store_dwordx4 v102, v[%d:%d], s[74:75]" % (r, r + 3))
+            continue
+        out.append(l)
+        if n == 0:
+            out.append("v_lshlrev_b32_e64 v102, 2, v252")
+    return out
 
 
 def emit(name, lines):
@@ -693,6 +718,8 @@ def emit(name, lines):
             lines = [l for l in lines if not l.startswith("s_waitcnt vmcnt")]
         if TIMING_NO_LGKMWAIT:
             lines = [l for l in lines if not l.startswith("s_waitcnt lgkmcnt")]
+        if TIMING_X4:
+            lines = timing_x4(lines)
         if TIMING_NO_LDS:
             lines = [l for l in lines if not l.startswith("ds_")]
         if TIMING_NO_GLOADS:
