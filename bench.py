@@ -593,6 +593,40 @@ def multi_handle_leg(lib, table, d_sigs, d_msgs, d_idx, expect, n, k, devices):
                               "gathered_bitmap_matches": gathered_ok}}
 
 
+def multi_leg_child(args):
+    """`bench.py --multi-leg G` (started by multi_leg_in_child): the same synthetic batch as rank 0's, the leg over devices 0 .. G-1, its JSON on stdout"""
+    protect_stdout()
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    ctx = N.Context(0); lib = N.lib()
+    n, k = args.items, args.keys
+    d_sigs, d_msgs, d_pks, expect, d_idx, table = build_inputs(ctx, dev, n, k, N.PK_UNCOMPRESSED, 0, return_indices=True)
+    devices = list(range(args.multi_leg))
+    if os.environ.get("MBLS_MULTI_LEG_DEVICES"):          # tests on a one-GPU box: "0,0" = two contexts on device 0 (host join: RCCL wants one rank per device)
+        devices = [int(x) for x in os.environ["MBLS_MULTI_LEG_DEVICES"].split(",")]
+    leg = multi_handle_leg(lib, table, d_sigs, d_msgs, d_idx, expect, n, k, devices)
+    emit_result(json.dumps(leg))
+    return 0
+
+
+def multi_leg_in_child(G, n, k, timeout_s=600):
+    cmd = [sys.executable, os.path.abspath(__file__), "--multi-leg", str(G), "--items", str(n), "--keys", str(k)]
+    try:
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout_s)
+    except subprocess.TimeoutExpired:
+        return {"devices": list(range(G)), "error": "no answer within %d s (child process ended)" % timeout_s}
+    except OSError as e:
+        return {"devices": list(range(G)), "error": "cannot start the child process: %s" % e}
+    for l in reversed(r.stdout.decode(errors="replace").splitlines()):
+        try:
+            d = json.loads(l)
+            if isinstance(d, dict) and "devices" in d:
+                return d
+        except ValueError:
+            pass
+    return {"devices": list(range(G)), "error": "child exit code %d: %s" % (r.returncode, r.stderr.decode(errors="replace")[-300:])}
+
+
 def config5_leg(ctx, lib, dev, sptr, rank, world, k):
     """2^17 items on this rank (2^20 over 8 GPUs) + the bitmap gather: 3 timed steps"""
     n = 1 << 17
@@ -839,11 +873,14 @@ def main():
                          "48-byte wire form, or indices into a resident key table")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-variants", action="store_true", help="skip the compressed-key and indexed-key legs")
+    ap.add_argument("--multi-leg", type=int, default=0, help=argparse.SUPPRESS)      # internal: run ONLY the in-process multi-device leg over this many devices, print it
     ap.add_argument("--stub", action="store_true", help="CPU test of the multi-rank plumbing only: gloo backend and a stand-in verifier; the line it prints is "
                                                          "labelled a stub and is not a measurement")
     args = ap.parse_args()
     protect_stdout()
 
+    if args.multi_leg:
+        sys.exit(multi_leg_child(args))
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # no launcher: this process only starts the ranks (before anything here has touched a GPU) and relays rank 0's line
         sys.exit(spawn_ranks(args.gpus, sys.argv[1:], args.stub))
@@ -979,9 +1016,11 @@ def main():
         for G in (1, 2, 4, 8):
             if G > have:
                 break
-            leg = multi_handle_leg(lib, table, d_sigs, d_msgs, d_idx, expect, n, k, list(range(G)))
+            # one device: here. More than one (RCCL between the devices of ONE process: never met hardware in the builder's runs): in a child process with a
+            # time limit, so that a hang or a crash there costs this leg and not the line; a leg that RAN and disagrees with the expectation still fails the run
+            leg = multi_handle_leg(lib, table, d_sigs, d_msgs, d_idx, expect, n, k, [0]) if G == 1 else multi_leg_in_child(G, n, k)
             multi_legs.append(leg)
-            ok = ok and leg["results_match"]
+            ok = ok and leg.get("results_match", True)
     vm_leg = None
     if n == (1 << 16) and not args.no_variants:
         vm_leg = sharded_verify_multiple_leg(ctx, lib, dev, sptr, rank, world, k)

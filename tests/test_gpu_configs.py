@@ -102,3 +102,19 @@ def test_bench_two_ranks_sharing_the_gpu_real_verifier():
     assert p.returncode == 0, p.stderr[-2000:]
     lines = [l for l in p.stdout.splitlines() if l.strip()]
     assert len(lines) == 1 and json.loads(lines[0])["n_gpus"] == 1
+
+
+def test_bench_multi_device_leg_in_a_child_process():
+    """the in-process multi-device legs over more than one device run in a child process with a time limit (bench.multi_leg_in_child): a hang or a crash
+    there costs that leg, not the line. On this box: the child with two contexts on device 0 (host join), and what a child that cannot answer leaves behind."""
+    import os
+    import bench
+    os.environ["MBLS_MULTI_LEG_DEVICES"] = "0,0"
+    try:
+        leg = bench.multi_leg_in_child(2, 2048, 4)
+    finally:
+        del os.environ["MBLS_MULTI_LEG_DEVICES"]
+    assert leg.get("results_match") is True and leg["devices"] == [0, 0] and leg["items"] == 4096, leg
+    assert leg["bitmap_gather"]["gathered_bitmap_matches"] is True
+    gone = bench.multi_leg_in_child(2, 2048, 4, timeout_s=0.01)
+    assert "error" in gone and "results_match" not in gone
