@@ -83,6 +83,25 @@ __global__ void MBLS_LB k_aggregate_indexed_d(mbls_ws ws, const uint32_t* recs, 
 }
 // one key per lane, nothing but a square root: with the 8-entry window table (112 AGPRs) the kernel fits 256 registers and two
 // waves share a SIMD -- the plain 32-bit third of the instruction stream then issues at twice the rate (profiles/r02_ubench.txt)
+// Small batches (the wave engine's: latency): the key sum of an item is cut into MBLS_KEY_SPLIT partial sums on lanes of their own (k_aggregate_raw_d /
+// k_aggregate_indexed_d over n * MBLS_KEY_SPLIT sub-items, whose keys lie back to back exactly like items of k / MBLS_KEY_SPLIT keys; their sums in the APK slots of
+// workspace items n + i * MBLS_KEY_SPLIT + q, their status words in st_sub) and this kernel adds the partial sums of item i -- AggregatePublicKey::aggregate
+// (reference src/aggregates.rs:29-39) sums from infinity in any order to the same point --, folds the status words and applies the apk = infinity test.
+#define MBLS_KEY_SPLIT 8u
+__global__ void MBLS_LB k_apk_combine(mbls_ws ws, uint64_t n, int mode, const uint32_t* st_sub, uint32_t* status) {
+    uint64_t i = gid(); if (i >= n) return;
+    const uint64_t t0 = n + i * MBLS_KEY_SPLIT;
+    g1j acc; acc.x = ws_ld(ws, MBLS_SLOT_APK, t0); acc.y = ws_ld(ws, MBLS_SLOT_APK + 1, t0); acc.z = ws_ld(ws, MBLS_SLOT_APK + 2, t0);
+    uint32_t st = st_sub[i * MBLS_KEY_SPLIT];
+    for (uint32_t q = 1; q < MBLS_KEY_SPLIT; q++) {
+        g1j p; p.x = ws_ld(ws, MBLS_SLOT_APK, t0 + q); p.y = ws_ld(ws, MBLS_SLOT_APK + 1, t0 + q); p.z = ws_ld(ws, MBLS_SLOT_APK + 2, t0 + q);
+        g1_add(&acc, &acc, &p);
+        st |= st_sub[i * MBLS_KEY_SPLIT + q];
+    }
+    if (mode == MBLS_MODE_FAST_AGGREGATE && g1_is_inf(&acc)) st |= MBLS_ST_APK_INFINITY;
+    ws_st(ws, MBLS_SLOT_APK, i, acc.x); ws_st(ws, MBLS_SLOT_APK + 1, i, acc.y); ws_st(ws, MBLS_SLOT_APK + 2, i, acc.z);
+    if (st) atomicOr(status + i, st);
+}
 __global__ void __launch_bounds__(WG, 2) k_pk_decompress(const uint8_t* pks48, uint64_t nkeys, uint32_t* keys_xy, uint8_t* flags) {
     uint64_t j = gid(); if (j >= nkeys) return;
     lane_pk_decompress(j, pks48, keys_xy, flags);
@@ -1154,11 +1173,17 @@ static int verify_pipeline_one(mbls_ctx* c, const uint8_t* d_sigs, const uint8_t
     const bool split = pp.pairing == MBLS_PAIRING_LANES2 || pp.pairing == MBLS_PAIRING_LANES4;     // lane pairs / quads in the Miller phase, pairs in the final exponentiation
     const bool hash_pairs = pp.workspace_items == 2 * n;
     const int hform = pp.message == MBLS_MESSAGE_LANE ? HASH_FORM_LANE : pp.message == MBLS_MESSAGE_LANES2 ? HASH_FORM_PAIR : HASH_FORM_WAVE;
-    int rc = mbls_ctx_reserve(c, tk.ws_off + pp.workspace_items); if (rc) return rc;        // (a pass on a second track finds its space reserved: no growth under the first)
+    bool staged = !ks.indexed && (fmt == MBLS_PK_COMPRESSED) && !d_off && k > 1;   // lane-per-key decompression, then the per-item sums
+    // batches on the wave engine are latency: the key sum of 128 keys is a 2 ms chain on one lane -- eight lanes take an eighth of the keys each (items of k / 8
+    // keys lie back to back just like that) and k_apk_combine adds their sums: 0.4 ms
+    const bool key_split = on_waves && !staged && !d_off && k >= 4 * MBLS_KEY_SPLIT && k % MBLS_KEY_SPLIT == 0 &&
+                           (ks.indexed || (fmt == MBLS_PK_UNCOMPRESSED && (((uintptr_t)ks.d_pks) & 3u) == 0));
+    const uint64_t nsub = key_split ? n * MBLS_KEY_SPLIT : 0;
+    const uint64_t ws_items = key_split && n + nsub > pp.workspace_items ? n + nsub : pp.workspace_items;
+    int rc = mbls_ctx_reserve(c, tk.ws_off + ws_items); if (rc) return rc;        // (a pass on a second track finds its space reserved: no growth under the first)
     mbls_ws ws; ws.w = c->d_w + tk.ws_off; ws.stride = c->cap;
     uint32_t* st = d_status ? d_status : c->d_status + tk.ws_off;
     unsigned g = nblk(n);
-    bool staged = !ks.indexed && (fmt == MBLS_PK_COMPRESSED) && !d_off && k > 1;   // lane-per-key decompression, then the per-item sums
     if (staged) { rc = reserve_keys(c, (tk.ws_off + n) * (uint64_t)k); if (rc) return rc; }
     uint32_t* const keys_xy = staged ? c->d_keys_xy + 24 * (uint64_t)k * tk.ws_off : nullptr;
     uint8_t* const key_flags = staged ? c->d_key_flags + (uint64_t)k * tk.ws_off : nullptr;
@@ -1182,15 +1207,31 @@ static int verify_pipeline_one(mbls_ctx* c, const uint8_t* d_sigs, const uint8_t
             HIPCHK(c, hipStreamWaitEvent(s_msg, tk.ev2, 0));
         }
     }
+    // batches on the wave engine are latency: their signature chain (decode + subgroup ladder, 2.1 ms on one lane) is the longest of the three front chains --
+    // two lanes per signature there (k_sig2: 1.6 ms)
+    auto launch_sig = [&]() {
+        if (on_waves && !fused_sig) hipLaunchKernelGGL(k_sig2, dim3(nblk(2 * n)), dim3(WG), 0, s_sig, ws, d_sigs, st, n);
+        else hipLaunchKernelGGL(k_sig, dim3(g), dim3(WG), 0, s_sig, ws, d_sigs, st, n, fused_sig ? 0 : 1);
+    };
     if (part == 1) {
-        hipLaunchKernelGGL(k_sig, dim3(g), dim3(WG), 0, s_sig, ws, d_sigs, st, n, fused_sig ? 0 : 1);
+        launch_sig();
         launch_hash(c, ws, d_msgs, msg_len, d_moff, st, n, s_msg, hash_pairs, hform);
         HIPCHK(c, hipGetLastError());
         return MBLS_OK;
     }
     if (tm) HIPCHK(c, hipEventRecord(c->ev[0], s));
     if (ks.indexed) { rc = table_acquire(c, ks.tab, s); if (rc) return rc; }
-    if (ks.indexed)
+    if (key_split) {
+        mbls_ws wsub = ws; wsub.w += n;                                  // sub-item t = workspace item n + t (APK slots only; nothing else uses them up there)
+        uint32_t* st_sub = c->d_status + tk.ws_off + n;                  // their status words: behind the items' own
+        HIPCHK(c, hipMemsetAsync(st_sub, 0, 4 * nsub, s));
+        if (ks.indexed)
+            hipLaunchKernelGGL(k_aggregate_indexed_d, dim3(nblk(nsub)), dim3(WG), 0, s, wsub, ks.d_recs, ks.tsize, ks.d_idx, (const uint32_t*)nullptr, k / MBLS_KEY_SPLIT,
+                               MBLS_MODE_VERIFY, st_sub, nsub);
+        else
+            hipLaunchKernelGGL(k_aggregate_raw_d, dim3(nblk(nsub)), dim3(WG), 0, s, wsub, ks.d_pks, (const uint32_t*)nullptr, k / MBLS_KEY_SPLIT, MBLS_MODE_VERIFY, st_sub, nsub);
+        hipLaunchKernelGGL(k_apk_combine, dim3(g), dim3(WG), 0, s, ws, n, mode, (const uint32_t*)st_sub, st);
+    } else if (ks.indexed)
         hipLaunchKernelGGL(k_aggregate_indexed_d, dim3(g), dim3(WG), 0, s, ws, ks.d_recs, ks.tsize, ks.d_idx, d_off, k, mode, st, n);
     else if (staged) {
         hipLaunchKernelGGL(k_pk_decompress, dim3(nblk(n * (uint64_t)k)), dim3(WG), 0, s, ks.d_pks, n * (uint64_t)k, keys_xy, key_flags);
@@ -1198,7 +1239,7 @@ static int verify_pipeline_one(mbls_ctx* c, const uint8_t* d_sigs, const uint8_t
     } else
         launch_aggregate(ws, ks.d_pks, d_off, k, fmt, mode, st, n, s);
     if (tm) HIPCHK(c, hipEventRecord(c->ev[1], s));
-    if (!keys_later) hipLaunchKernelGGL(k_sig, dim3(g), dim3(WG), 0, s_sig, ws, d_sigs, st, n, fused_sig ? 0 : 1);
+    if (!keys_later) launch_sig();
     if (tm) HIPCHK(c, hipEventRecord(c->ev[2], s));
     if (!keys_later) launch_hash(c, ws, d_msgs, msg_len, d_moff, st, n, s_msg, hash_pairs, hform);
     if (tm) HIPCHK(c, hipEventRecord(c->ev[3], s));

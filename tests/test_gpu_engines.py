@@ -72,6 +72,53 @@ def test_routing_boundaries_with_default_settings_vs_oracle(mb, big, n):
     check(big, got, st, n)
 
 
+@pytest.mark.parametrize("k", [24, 32, 40, 128])
+def test_wave_engine_batches_sum_their_keys_on_eight_lanes_vs_oracle(mb, k):
+    """small batches (the wave engine's) cut an item's key sum into eight partial sums on lanes of their own when k is a multiple of 8 and at least 32
+    (k_apk_combine adds them); 24 keys stay on one lane. Every item against the oracle -- the seven rejection classes (an aggregate key at infinity must still be
+    seen on the TOTAL, a key that does not decode in any of the eight parts), a key repeated within an item (a doubling inside a partial sum), a key and its
+    negative in different parts -- through byte keys and through a key table."""
+    from milagro_bls_amd import _native as N
+    N.default_context().reset_tuning()
+    n = 70
+    b = helpers.make_batch(n, k, fmt=1, seed=900 + k, pool_n=max(64, k + 8), nthreads=8)
+    keys = [b.pks[96 * k * i:96 * k * (i + 1)] for i in range(n)]
+    K = lambda i, j: keys[i][96 * j:96 * j + 96]
+    def put(i, j, key):
+        keys[i] = keys[i][:96 * j] + key + keys[i][96 * j + 96:]
+    put(0, 1, K(0, 0)); put(0, k - 1, K(0, 0))                                  # item 0: one key three times (parts 0 and 7)
+    put(4, k - 2, orc.g1_mul(K(4, 2), helpers.R - 1))                            # item 4: a key and its negative in different parts
+    per = max(k // 8, 1)
+    for j in range(k - per, k - 1, 2):                                           # item 8: the whole last part cancels (a partial sum at infinity; 3 keys: all but one)
+        put(8, j + 1, orc.g1_mul(K(8, j), helpers.R - 1))
+    pks = b"".join(keys)
+    want = orc.batch_fast_aggregate_verify(b.sigs, b.msgs, pks, n, k, 1, nthreads=8)
+    assert want[0] is False and want[4] is False and want[8] is False and want.count(True) > n // 2
+    got, st = mb.fast_aggregate_verify_batch(b.sigs, b.msgs, pks, n, k, pk_format=1)
+    assert got == want
+    for i, kind in enumerate(b.kinds):
+        if i not in (0, 4, 8) and FLAG.get(kind):
+            assert st[i] & FLAG[kind], (i, kind, hex(st[i]))
+    # the same items by table indices (keys that do not decode cannot enter a table: those items keep their other keys and are skipped in the comparison)
+    tab = N.KeyTable()
+    uniq = {}
+    idx = []
+    skip = set()
+    for i in range(n):
+        for j in range(k):
+            key = K(i, j)
+            if key not in uniq:
+                first, errs = tab.append(key, 1, pk_format=1, validate=False)
+                uniq[key] = None if errs[0] else first
+            if uniq[key] is None:
+                skip.add(i); idx.append(0)
+            else:
+                idx.append(uniq[key])
+    got_i, _ = mb.fast_aggregate_verify_batch_indexed(tab, b.sigs, b.msgs, idx, n, k)
+    assert [g for i, g in enumerate(got_i) if i not in skip] == [w for i, w in enumerate(want) if i not in skip] and len(skip) < n // 4
+    tab.close()
+
+
 def test_lane_kernels_20k_items_vs_oracle(mb, big):
     """the headline kernels (one lane per item; signature subgroup verdict out of the Miller loop) on 20 480 items, every one against the
     oracle: the two-pair loop k_miller forced (lane shaping off, front phases one after the other -- the shape of a full round), then the
