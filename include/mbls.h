@@ -109,7 +109,9 @@ int mbls_ctx_set_secret_ops(mbls_ctx* ctx, int variable_time);
  * Which kernels a batch of n items takes is decided by the limits above; mbls_plan_batch states the decision without running anything -- the SAME
  * function the verification entries call (verify_pipeline), so the table in DESIGN.md section 5 is checkable on a machine without a GPU
  * (tests/test_plan_cpu.py). mbls_default_limits fills the defaults for a device with round_items = CUs x 4 x 64 (65 536 on MI355X);
- * mbls_ctx_get_limits reads a context's current ones (setters and environment applied). */
+ * mbls_ctx_get_limits reads a context's current ones (setters and environment applied). The plan is a function of n alone; two forms follow from it and from
+ * the keys per item: with the pairing check on waves (MBLS_PAIRING_WAVE*) the signature phase runs on lane pairs (k_sig2), and an item's key sum of k >= 32
+ * keys, k a multiple of 8, uniform layout, as eight partial sums on lanes of their own (k_apk_combine; workspace n + 8 n items instead of workspace_items). */
 typedef struct mbls_limits {
     uint64_t round_items, coop_max_items, coop_hash_max_items, coop_pack_min_items, coop_pack_max_items, coop_hash_pack_min_items,
              split_max_items, fork_max_items, hash2_max_items, tracks_min_rest, tracks_side_max;
