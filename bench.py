@@ -220,6 +220,23 @@ def check_gathered(all_words, world, words_per_rank, own_words, rank):
     return bool(torch.equal(mine.cpu(), own_words.cpu()))
 
 
+def collective_figure(gather, world, sync, reps=20):
+    """What a SCALE record needs to check itself: the backend and the number of ranks the process group REALLY has (RCCL's own count under 'nccl'), and the time of
+    the one collective of a step -- the all-gather of the accept bitmap -- timed alone: `reps` gathers between two fences, MAX over ranks."""
+    if world == 1:
+        return None
+    for _ in range(2):
+        gather()
+    sync(); dist.barrier(); sync()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        gather()
+    sync()
+    ms = reduce_max((time.perf_counter() - t0) / reps * 1e3, world)
+    return {"backend": dist.get_backend(), "group_world_size": dist.get_world_size(), "group_rank_count_matches_n_gpus": dist.get_world_size() == world,
+            "all_gather_ms_per_step": ms, "reps": reps}
+
+
 # ---------------------------------------------------------------------------------------------- CPU baseline (the oracle)
 def _oracle_native():
     """oracle/bls_oracle.c built -O3 -march=native for THIS host (the shipped oracle/_build library is a portable build)"""
@@ -366,7 +383,12 @@ def valu_issue_figure(lib, ctx, phase_ms, n_items, agg_kernel="k_aggregate"):
         blend = total / (mad / rate["v_mad_u64_u32"] + (total - mad) / rate["plain_valu"])
         ceil = max(blend, r_loop)                                       # whichever calibration stream issues faster
         ns = 1e9 / ach                                                  # SIMD time per wave-instruction
+        # mac_frac = the MAC-only roofline the review asked for: multiply-accumulate wave-instructions / kernel time against the rate the SAME instruction reaches
+        # alone at 8 waves per SIMD (measured above) -- 1 - mac_frac is what everything that is not a multiply-accumulate (reduction masks and shifts, carry passes,
+        # additions between products, register moves, memory instructions, calls) and the one-wave issue rate cost together
+        mac_ach = mad * n_items / 64.0 / (phase_ms[phase] * 1e-3) / N_SIMD
         out["kernels"][kern] = {"valu_wave_instr_per_item": total, "of_which_v_mad_u64_u32": mad, "achieved": ach, "ceiling": ceil, "ceiling_blend": blend, "ceiling_product_loop": r_loop, "frac": ach / ceil,
+                                "mac_achieved": mac_ach, "mac_peak_8_waves": by_waves["v_mad_u64_u32@8w"], "mac_frac": mac_ach / by_waves["v_mad_u64_u32@8w"], "mac_share_of_valu": mad / float(total),
                                 "ns_per_valu_instr": ns, "clk_per_valu_instr": ns * PEAK_CLOCK_GHZ,
                                 "clk_note": "ns x %.1f GHz peak clock; the clock under this instruction mix is lower, see DESIGN.md section 4" % PEAK_CLOCK_GHZ}
     return out
@@ -765,12 +787,25 @@ def stub_rank(args, rank, world):
     bm = shard.pack_bits(res)
     d_all = torch.zeros(words * world, dtype=torch.int64)
 
+    calls = [0]
+
     def step():
         time.sleep(0.005 * (rank + 1))
+        calls[0] += 1
+        if os.environ.get("MBLS_STUB_DIE_RANK") == str(rank) and calls[0] == 2:
+            os._exit(17)                               # a rank that dies in the middle of the job (tests/test_bench_cpu.py): no line, a non-zero exit, no hang
         if world > 1:
             shard.all_gather_bitmap(bm, world, out=d_all)
     elapsed = timed_steps(step, args.steps, args.warmup, world, lambda: None)
     per_rank = gather_per_rank(LAST_OWN_ELAPSED[0] / args.steps * 1e3, world)
+    coll = collective_figure(lambda: shard.all_gather_bitmap(bm, world, out=d_all), world, lambda: None, reps=5)
+    # configs[4] as the real path times it at 8 ranks (config5_leg): the rank's own shard, then the gather -- here with the stand-in verifier
+    shard_leg = None
+    if world == 8:
+        e5 = timed_steps(step, 2, 0, world, lambda: None)
+        shard_leg = {"workload": "configs[4] (stub): %d items per rank over 8 ranks + the bitmap gather" % n, "value": n * world * 2 / e5, "unit": "fast_aggregate_verify/s",
+                     "ms_per_step": e5 / 2 * 1e3, "steps": 2,
+                     "bitmap_matches_expectation": reduce_all_ok(check_gathered(d_all, world, words, bm, rank), world)}
     ok = check_bitmap(res, bm, expect) and (world == 1 or check_gathered(d_all, world, words, bm, rank))
     # the exchange step of the sharded verify_multiple leg: one byte record per rank, gathered in rank order
     mine = torch.full((N.VM_PARTIAL_BYTES,), rank + 1, dtype=torch.uint8)
@@ -780,7 +815,8 @@ def stub_rank(args, rank, world):
     if rank == 0:
         emit_result(json.dumps({"metric": "fast_aggregate_verify/sec (128 pubkeys, 32B msg)", "stub": True, "value": n * world * args.steps / elapsed,
                           "unit": "fast_aggregate_verify/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-                          "ms_per_step_per_rank": per_rank, "bitmap_matches_expectation": ok}))
+                          "ms_per_step_per_rank": per_rank, "bitmap_matches_expectation": ok, "higher_is_better": True, "scaling": "weak",
+                          "collective": coll, "configs4_shard_leg": shard_leg}))
     if world > 1:
         dist.barrier(); dist.destroy_process_group()
     return 0 if ok else 3
@@ -997,6 +1033,10 @@ def main():
             ok = ok and ok2
 
     per_rank_ms = gather_per_rank(own_ms[args.pk_format], world)
+    coll = None
+    if world > 1:
+        _bm = torch.zeros(words, dtype=torch.int64, device=dev); _all = torch.zeros(words * world, dtype=torch.int64, device=dev)
+        coll = collective_figure(lambda: shard.all_gather_bitmap(_bm, world, out=_all), world, torch.cuda.synchronize)
     # one step = the kernels of one in-order stream (+ the gather): their event-timed sum against this rank's own step time, on every rank
     phase_sum_own = sum(phase_ms.values())
     phase_gap = abs(phase_sum_own - own_ms[args.pk_format]) / own_ms[args.pk_format]
@@ -1019,8 +1059,12 @@ def main():
             # one device: here. More than one (RCCL between the devices of ONE process: never met hardware in the builder's runs): in a child process with a
             # time limit, so that a hang or a crash there costs this leg and not the line; a leg that RAN and disagrees with the expectation still fails the run
             leg = multi_handle_leg(lib, table, d_sigs, d_msgs, d_idx, expect, n, k, [0]) if G == 1 else multi_leg_in_child(G, n, k)
+            # a leg that timed out, crashed or could not start carries 'error' and no 'results_match': it did NOT run -- said so per leg and in the line
+            # ('multi_legs_ok' below), never counted as a pass
+            leg["ran"] = "results_match" in leg
             multi_legs.append(leg)
-            ok = ok and leg.get("results_match", True)
+            if leg["ran"]:
+                ok = ok and bool(leg["results_match"])
     vm_leg = None
     if n == (1 << 16) and not args.no_variants:
         vm_leg = sharded_verify_multiple_leg(ctx, lib, dev, sptr, rank, world, k)
@@ -1067,7 +1111,10 @@ def main():
             "variants": variants,
             "other_configs": other,
             "multi_handle_leg": multi_legs,
+            # true only when every leg over the visible devices RAN and matched; false when one ran and disagreed (exit code 3) or produced no result at all
+            "multi_legs_ok": (all(l.get("ran") and l.get("results_match") for l in multi_legs) if multi_legs is not None else None),
             "configs4_shard_leg": shard_leg,
+            "collective": coll,
             "sharded_verify_multiple_leg": vm_leg,
             "input_build_s": t_in,
             "head": git_head(), "library_source_hash": library_source_hash(),

@@ -137,6 +137,11 @@ void mbls_default_limits(uint64_t round_items, mbls_limits* out);
 int mbls_ctx_get_limits(mbls_ctx* ctx, mbls_limits* out);
 /* the plan of mbls_fast_aggregate_verify_batch[_indexed]_device / mbls_verify_batch_device for n items (MBLS_ERR_ARGUMENT for n = 0 or null pointers) */
 int mbls_plan_batch(const mbls_limits* limits, uint64_t n, mbls_batch_plan* out);
+/* the workspace items that plan needs for items of k keys each -- split_layout != 0: uniform 96-byte keys (4-byte aligned) or key-table indices, the layouts whose
+ * key sums on the wave engine take eight lanes per item (n + 8 n items for such a pass instead of its workspace_items). This is what the verification entries
+ * reserve BEFORE they queue the first pass of a plan (no pass ever grows the workspace under another in flight); mbls_ctx_reserve(ctx, this) beforehand keeps
+ * every allocation out of the call. 0 for n = 0 or a null pointer. */
+uint64_t mbls_plan_workspace_items(const mbls_limits* limits, uint64_t n, uint32_t k, int split_layout);
 
 /* ---- the hot path -------------------------------------------------------------------------------------
  * Batch of n independent AggregateSignature::fast_aggregate_verify calls (reference src/aggregates.rs:177-215):
@@ -327,6 +332,11 @@ typedef void (*mbls_scalar_source)(void* user, uint64_t* out, uint64_t count);
 int mbls_verify_multiple_aggregate_signatures_rng(mbls_ctx* ctx, const uint8_t* sigs96, const uint8_t* apks96,
                                               const uint8_t* msgs, uint32_t msg_len, const uint64_t* msg_offsets,
                                               size_t n, mbls_scalar_source draw, void* user);
+/* The several-device form (mbls_multi_verify_multiple_aggregate_signatures) with the reference's RNG order and no second subgroup test (what mbls_verify_multiple_aggregate_signatures_rng is to one device): every device decodes and
+ * tests its shard's signatures first, the host finds the first bad signature of the WHOLE batch, `draw` is asked ONCE for the scalars of the sets in front of it
+ * (reference src/aggregates.rs:272-287) and -- every signature good -- the devices go on from the points they hold to their records, the exchange and the join. */
+int mbls_multi_verify_multiple_aggregate_signatures_rng(mbls_multi* m, const uint8_t* sigs96, const uint8_t* apks96, const uint8_t* msgs,
+                                                        uint32_t msg_len, const uint64_t* msg_offsets, size_t n, mbls_scalar_source draw, void* user);
 
 /* The same for sets given by their keys in wire format (BASELINE configs[3]: 2^14 sets x 128 keys): set i owns k keys
  * (or [pk_offsets[i], pk_offsets[i+1])), AggregatePublicKey::aggregate (src/aggregates.rs:29-39) runs on the device first. */

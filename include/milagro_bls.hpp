@@ -238,28 +238,6 @@ struct AggregateSignature {
     bool fast_aggregate_verify_pre_aggregated(const Bytes& msg, const AggregatePublicKey& apk) const {
         return mbls_fast_aggregate_verify_pre_aggregated(detail::ctx(), point.data(), msg.data(), msg.size(), apk.point.data()) == 1;
     }
-    // (the multi-device form) rng(): one random byte per call. Blinding scalars drawn as at reference src/aggregates.rs:280-287 -- and in the reference's ORDER: its loop tests set i's
-    // signature for the subgroup (:272-275) before it draws rand[i] and returns at the first signature outside G2, so a rejected batch leaves the caller's
-    // generator where the reference would: one batched subgroup test up front (mbls_sig_check_batch) finds that set, scalars are drawn for the sets before it only.
-    // -> false if a set was rejected before the pairing check (the buffers are then incomplete), true if the batch is ready
-    template <typename Rng, typename Sets>
-    static bool draw_in_reference_order(Rng&& rng, const Sets& sets, Bytes& sigs, Bytes& apks, Bytes& msgs, std::vector<uint64_t>& rands, std::vector<uint64_t>& moff) {
-        for (auto& s : sets) sigs.insert(sigs.end(), std::get<0>(s)->point.begin(), std::get<0>(s)->point.end());
-        std::vector<uint8_t> errs(sets.size()), in_g2(sets.size());
-        detail::check(mbls_sig_check_batch(detail::ctx(), sigs.data(), sets.size(), errs.data(), in_g2.data()));
-        size_t n_ok = 0;
-        while (n_ok < sets.size() && errs[n_ok] == MBLS_OK && in_g2[n_ok]) n_ok++;
-        for (size_t i = 0; i < n_ok; i++) {
-            rands.push_back(draw_scalar(rng));
-        }
-        if (n_ok < sets.size()) return false;                              // :273-275
-        for (auto& s : sets) {
-            apks.insert(apks.end(), std::get<1>(s)->point.begin(), std::get<1>(s)->point.end());
-            msgs.insert(msgs.end(), std::get<2>(s).begin(), std::get<2>(s).end());
-            moff.push_back(msgs.size());                                   // messages of any length each: one buffer + an offset table
-        }
-        return true;
-    }
     // one scalar as at reference src/aggregates.rs:280-287: 8 random bytes, big-endian i64, absolute value (as the release build wraps it), again on zero
     template <typename Rng> static uint64_t draw_scalar(Rng& rng) {
         uint64_t r = 0;
@@ -267,7 +245,8 @@ struct AggregateSignature {
         return r;
     }
     // One call (mbls_verify_multiple_aggregate_signatures_rng): the library tests the signatures first and asks for the scalars of the sets in front of the first
-    // bad one only -- the reference's order (see draw_in_reference_order) without a second subgroup test.
+    // bad one only -- the reference's order (its loop tests set i's signature for the subgroup, :272-275, BEFORE it draws rand[i] and returns at the first signature
+    // outside G2: a rejected batch leaves the caller's generator where the reference would) without a second subgroup test. rng(): one random byte per call.
     template <typename Rng>
     static bool verify_multiple_aggregate_signatures(Rng&& rng, const std::vector<std::tuple<const AggregateSignature*, const AggregatePublicKey*, Bytes>>& sets) {
         if (sets.empty()) return mbls_verify_multiple_aggregate_signatures(detail::ctx(), nullptr, nullptr, nullptr, 0, nullptr, nullptr, 0) == 1;
@@ -289,13 +268,28 @@ struct AggregateSignature {
         if (u.err) std::rethrow_exception(u.err);
         return ok;
     }
-    // the same check with the sets cut into one shard per device of a multi-device handle (mbls_multi_create): same bool
+    // the same check with the sets cut into one shard per device of a multi-device handle (mbls_multi_create): same bool, same RNG order, ONE call
+    // (mbls_multi_verify_multiple_aggregate_signatures_rng: every device tests its shard's signatures first, the scalars are asked for once)
     template <typename Rng>
     static bool verify_multiple_aggregate_signatures(mbls_multi* devices, Rng&& rng, const std::vector<std::tuple<const AggregateSignature*, const AggregatePublicKey*, Bytes>>& sets) {
         if (sets.empty()) return true;
-        Bytes sigs, apks, msgs; std::vector<uint64_t> rands, moff{0};
-        if (!draw_in_reference_order(rng, sets, sigs, apks, msgs, rands, moff)) return false;
-        return mbls_multi_verify_multiple_aggregate_signatures(devices, sigs.data(), apks.data(), msgs.data(), 0, moff.data(), rands.data(), sets.size()) == 1;
+        Bytes sigs, apks, msgs; std::vector<uint64_t> moff{0};
+        for (auto& s : sets) {
+            sigs.insert(sigs.end(), std::get<0>(s)->point.begin(), std::get<0>(s)->point.end());
+            apks.insert(apks.end(), std::get<1>(s)->point.begin(), std::get<1>(s)->point.end());
+            msgs.insert(msgs.end(), std::get<2>(s).begin(), std::get<2>(s).end());
+            moff.push_back(msgs.size());
+        }
+        using R = typename std::remove_reference<Rng>::type;
+        struct src { R* rng; std::exception_ptr err; } u{&rng, nullptr};
+        mbls_scalar_source draw = [](void* user, uint64_t* out, uint64_t count) {
+            src* p = static_cast<src*>(user);
+            try { for (uint64_t i = 0; i < count; i++) out[i] = draw_scalar(*p->rng); }
+            catch (...) { p->err = std::current_exception(); for (uint64_t i = 0; i < count; i++) out[i] = 0; }
+        };
+        const bool ok = mbls_multi_verify_multiple_aggregate_signatures_rng(devices, sigs.data(), apks.data(), msgs.data(), 0, moff.data(), sets.size(), draw, &u) == 1;
+        if (u.err) std::rethrow_exception(u.err);
+        return ok;
     }
     static AggregateSignature from_bytes(const Bytes& b) { AggregateSignature a; detail::check(mbls_sig_from_bytes(detail::ctx(), b.data(), b.size(), a.point.data())); return a; }
     std::array<uint8_t, 96> as_bytes() const { return point; }

@@ -67,6 +67,12 @@ def plan_batch(n, limits=None):
     return b.mode, [{f: getattr(b.passes[i], f) for f, _ in PassPlan._fields_} for i in range(b.n_passes)]
 
 
+def plan_workspace_items(n, k, split_layout=True, limits=None):
+    """workspace items the plan of n items of k keys needs (pure: no GPU); split_layout: uniform 96-byte keys or key-table indices"""
+    L = limits if limits is not None else default_limits()
+    return int(lib().mbls_plan_workspace_items(C.byref(L), n, k, 1 if split_layout else 0))
+
+
 # mbls_scalar_source (include/mbls.h): void draw(void* user, uint64_t* out, uint64_t count)
 SCALAR_SOURCE = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_uint64), C.c_uint64)
 SIGNATURES = {
@@ -85,6 +91,7 @@ SIGNATURES = {
     "mbls_default_limits": (None, [C.c_uint64, vp]),
     "mbls_ctx_get_limits": (C.c_int, [vp, vp]),
     "mbls_plan_batch": (C.c_int, [vp, C.c_uint64, vp]),
+    "mbls_plan_workspace_items": (C.c_uint64, [vp, C.c_uint64, C.c_uint32, C.c_int]),
     "mbls_last_error": (C.c_char_p, [vp]),
     "mbls_fast_aggregate_verify_batch_device": (C.c_int, [vp, vp, vp, C.c_uint32, vp, vp, C.c_int, vp, C.c_uint64, C.c_uint32, vp, vp, vp, vp]),
     "mbls_fast_aggregate_verify_batch": (C.c_int, [vp, vp, vp, C.c_uint32, vp, vp, C.c_int, vp, C.c_uint64, C.c_uint32, vp, vp]),
@@ -125,6 +132,7 @@ SIGNATURES = {
     "mbls_verify_multiple_partial_device": (C.c_int, [vp, vp, vp, vp, C.c_int, vp, C.c_uint32, vp, C.c_uint32, vp, vp, C.c_uint64, vp, vp]),
     "mbls_verify_multiple_finish_device": (C.c_int, [vp, vp, C.c_uint64, vp, vp, vp]),
     "mbls_multi_verify_multiple_aggregate_signatures": (C.c_int, [vp, vp, vp, vp, C.c_uint32, vp, vp, C.c_size_t]),
+    "mbls_multi_verify_multiple_aggregate_signatures_rng": (C.c_int, [vp, vp, vp, vp, C.c_uint32, vp, C.c_size_t, SCALAR_SOURCE, vp]),
     "mbls_pk_decode_batch": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_uint64, vp, vp]),
     "mbls_pk_compress_batch": (C.c_int, [vp, vp, C.c_uint64, vp, vp]),
     "mbls_sig_check_batch": (C.c_int, [vp, vp, C.c_uint64, vp, vp]),

@@ -292,8 +292,9 @@ class AggregateSignature:
                                                                        N.cbuf(aggregate_public_key.point)))
 
     @staticmethod
-    def verify_multiple_aggregate_signatures(rng, signature_sets):
-        """reference src/aggregates.rs:261-316. `rng` must offer getrandbits (random.Random); the blinding scalars
+    def verify_multiple_aggregate_signatures(rng, signature_sets, devices=None):
+        """reference src/aggregates.rs:261-316. devices (optional, not in the reference): a _native.MultiContext -- the sets are then cut into one shard per device
+        (mbls_multi_verify_multiple_aggregate_signatures_rng: same bool, same draws). `rng` must offer getrandbits (random.Random); the blinding scalars
         are drawn exactly as at :280-287: 8 random bytes, big-endian i64, absolute value, retry on zero -- and IN THE REFERENCE'S ORDER: its loop
         tests set i's signature for the subgroup (:272-275) before it draws rand[i], and returns at the first signature outside G2, so a rejected
         batch leaves the caller's generator where the reference would (mbls_verify_multiple_aggregate_signatures_rng tests the signatures first and
@@ -320,9 +321,10 @@ class AggregateSignature:
             offs.append(offs[-1] + len(s[2]))
         moff = (C.c_uint64 * len(offs))(*offs)
         cb = N.SCALAR_SOURCE(draw)
-        ok = bool(N.lib().mbls_verify_multiple_aggregate_signatures_rng(
-            _ctx().handle, N.cbuf(b"".join(s[0].point for s in sets)), N.cbuf(b"".join(s[1].point for s in sets)),
-            N.cbuf(b"".join(bytes(s[2]) for s in sets)), 0, moff, len(sets), cb, None))
+        entry, handle = ((N.lib().mbls_verify_multiple_aggregate_signatures_rng, _ctx().handle) if devices is None else
+                         (N.lib().mbls_multi_verify_multiple_aggregate_signatures_rng, devices.handle))
+        ok = bool(entry(handle, N.cbuf(b"".join(s[0].point for s in sets)), N.cbuf(b"".join(s[1].point for s in sets)),
+                        N.cbuf(b"".join(bytes(s[2]) for s in sets)), 0, moff, len(sets), cb, None))
         if failed:
             raise failed[0]
         return ok

@@ -13,6 +13,39 @@ DEPS = ["mbls_fp.h", "mbls_fp_asm.inc", "mbls_fpd_asm.inc", "mbls_towerd_asm.inc
 
 STAMP = LIB + ".srchash"
 
+# The one generated file that is NOT tracked: 25 MB of straight-line routines (tools/gen_tower_d.py, ~3 s). It is written into csrc/ (git-ignored, it still travels
+# to the GPU box with the snapshot like the built library) whenever it is missing or older than what the generator's sources say; tests/test_asm_sim_d_cpu.py still
+# compares it with a fresh run of the generator.
+ROOT = os.path.dirname(HERE)
+GENERATED = {"mbls_towerd_asm.inc": ("gen_tower_d.py", ["gen_tower_d.py", "gen_fp_asm.py", "gen_fpd_asm.py"])}
+
+
+def _gen_inputs_hash(inputs):
+    import hashlib
+    h = hashlib.sha256()
+    for f in inputs:
+        with open(os.path.join(ROOT, "tools", f), "rb") as fh:
+            h.update(f.encode() + b"\0" + fh.read())
+    return h.hexdigest()
+
+
+def ensure_generated(verbose=False):
+    """(re)generate the untracked generated sources when they are missing or stale against their generators"""
+    for name, (script, inputs) in GENERATED.items():
+        out, stamp = os.path.join(CSRC, name), os.path.join(CSRC, name + ".genhash")
+        want = _gen_inputs_hash(inputs)
+        if os.path.exists(out) and os.path.exists(stamp) and open(stamp).read().strip() == want:
+            continue
+        if os.path.exists(out) and not os.path.isdir(os.path.join(ROOT, "tools")):
+            continue                                    # a tree without the generators (never the repository): take the file as it is
+        cmd = [sys.executable, os.path.join(ROOT, "tools", script)]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        env = dict(os.environ); env.pop("MBLS_GEN_OUT_DIR", None)
+        subprocess.check_call(cmd, stdout=None if verbose else subprocess.DEVNULL, env=env)
+        with open(stamp, "w") as fh:
+            fh.write(want + "\n")
+
 
 def source_hash():
     """content hash of everything the library is built from (file times do not survive the copy to the GPU box)"""
@@ -27,6 +60,7 @@ def source_hash():
 def needs_build():
     if not os.path.exists(LIB) or not os.path.exists(STAMP):
         return True
+    ensure_generated()
     if os.environ.get("MBLS_TRUST_PREBUILT") == "1":
         return False
     with open(STAMP) as fh:
@@ -36,6 +70,7 @@ def needs_build():
 def build(force=False, verbose=False):
     if not force and not needs_build():
         return LIB
+    ensure_generated(verbose)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     extra = os.environ.get("MBLS_EXTRA_HIPCC_FLAGS", "").split()
     objs, procs = [], []

@@ -124,6 +124,14 @@ MBLS_FN void coop_from_words(int32_t* out, fp w) {
 // enough for two waves per SIMD).
 // LPI: lanes of a step one item uses -- 64: one item per wave, its slots in a static allocation (the latency path); 32 / 16: two / four
 // items per wave side by side, each with its own slots and flag words in the dynamic allocation (COOP_LDS_BYTES).
+#ifdef MBLS_COOP_PROFILE
+// dev build (-DMBLS_COOP_PROFILE, scripts/dbg/coop_prof.py): clocks per step kind and step part, summed by wave 0 of every launch: [kind][0] steps, [1] operands in
+// registers, [2] computed, [3] stored and past the barrier
+__device__ unsigned long long mbls_coop_prof[16 * 4];
+#define COOP_PROF_T(v) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); v = __builtin_readcyclecounter(); } while (0)
+#else
+#define COOP_PROF_T(v) do { } while (0)
+#endif
 template <bool POW, int LPI>
 __global__ void __launch_bounds__(64) k_coop_t(coop_prog pg, mbls_ws ws, uint64_t first_item, uint64_t item_step, uint64_t partner_step, uint64_t n_items,
                                              uint32_t* status, uint8_t* results, int res_mode) {
@@ -156,6 +164,9 @@ __global__ void __launch_bounds__(64) k_coop_t(coop_prog pg, mbls_ws ws, uint64_
     for (uint32_t step = 0;; step++) {
         const uint32_t kind = info & 0xFF, na = (info >> 8) & 0xF, nb = (info >> 12) & 0xF;
         if (kind == COOP_K_END) break;
+#ifdef MBLS_COOP_PROFILE
+        unsigned long long pt0 = 0, pt1 = 0, pt2 = 0, pt3 = 0; COOP_PROF_T(pt0); pt1 = pt2 = pt0;
+#endif
         const uint4 c0 = m0, c1 = m1;
         // the next step's microcode is requested before this step runs (the rows are shared by every wave: L2 hits)
         info = pg.steps[2 * (step + 1)]; row = pg.steps[2 * (step + 1) + 1];
@@ -186,7 +197,9 @@ __global__ void __launch_bounds__(64) k_coop_t(coop_prog pg, mbls_ws ws, uint64_
                     for (int j = 0; j < 14; j++) b[j] += cf[4 + t] * S[ix[4 + t] * COOP_SW + j];
                 }
             }
+            COOP_PROF_T(pt1);
             coop_mul(r, a, b);
+            COOP_PROF_T(pt2);
 #pragma unroll
             for (int j = 0; j < 14; j++) S[dst * COOP_SW + j] = r[j];
         } else if (kind == COOP_K_LIN) {
@@ -207,7 +220,9 @@ __global__ void __launch_bounds__(64) k_coop_t(coop_prog pg, mbls_ws ws, uint64_
                     for (int j = 0; j < 14; j++) s[j] += (int64_t)c * S[ix[4 + t] * COOP_SW + j];
                 }
             }
+            COOP_PROF_T(pt1);
             coop_reduce(r, s);
+            COOP_PROF_T(pt2);
 #pragma unroll
             for (int j = 0; j < 14; j++) S[dst * COOP_SW + j] = r[j];
         } else if (kind == COOP_K_INV) {
@@ -282,6 +297,13 @@ __global__ void __launch_bounds__(64) k_coop_t(coop_prog pg, mbls_ws ws, uint64_
             }
         }
         __syncthreads();
+#ifdef MBLS_COOP_PROFILE
+        COOP_PROF_T(pt3);
+        if (pt1 == pt0) pt1 = pt2 = pt3;
+        if (blockIdx.x == 0 && lane == 0) {
+            mbls_coop_prof[kind * 4 + 0] += 1; mbls_coop_prof[kind * 4 + 1] += pt1 - pt0; mbls_coop_prof[kind * 4 + 2] += pt2 - pt1; mbls_coop_prof[kind * 4 + 3] += pt3 - pt2;
+        }
+#endif
     }
 #endif
 }

@@ -17,7 +17,6 @@
 #include <vector>
 #include <dlfcn.h>
 #include <unistd.h>
-#include <rccl/rccl.h>        // types and enumerators only: the library itself is opened at run time (mbls_multi_create), never linked
 #include "mbls_ops.h"
 #include "mbls_coop.h"
 #include "../../include/mbls.h"
@@ -31,6 +30,16 @@
 #endif
 #if defined(__HIP_DEVICE_COMPILE__) && !MBLS_DEVICE_ASM
 #error "device pass without the generated routines"
+#endif
+
+// RCCL: the library is opened at run time (mbls_multi_create), never linked -- and its headers are not needed to BUILD either: the few opaque types and enumerators
+// the dlopen'ed entry points take are declared here when <rccl/rccl.h> is absent (values are RCCL's / NCCL's stable ABI: ncclSuccess = 0, ncclUint8 = 1)
+#if __has_include(<rccl/rccl.h>)
+#include <rccl/rccl.h>
+#else
+typedef struct ncclComm* ncclComm_t;
+typedef enum { ncclSuccess = 0 } ncclResult_t;
+typedef enum { ncclInt8 = 0, ncclChar = 0, ncclUint8 = 1 } ncclDataType_t;
 #endif
 
 #define MBLS_SLOT_S 25            // 6 Fp: Jacobian G2 accumulator for verify_multiple
@@ -1140,6 +1149,28 @@ extern "C" int mbls_plan_batch(const mbls_limits* limits, uint64_t n, mbls_batch
     if (!limits || !out || !n) return MBLS_ERR_ARGUMENT;
     plan_batch(*limits, n, false, false, out); return MBLS_OK;
 }
+// the workspace items the plan of n items needs when every item has k keys in a layout that allows the eight-lane key sum (see pass_key_split): what
+// verify_pipeline reserves before it queues the first pass -- mbls_ctx_reserve(ctx, this) beforehand keeps every allocation out of the call
+extern "C" uint64_t mbls_plan_workspace_items(const mbls_limits* limits, uint64_t n, uint32_t k, int split_layout) {
+    if (!limits || !n) return 0;
+    mbls_batch_plan bp; plan_batch(*limits, n, false, false, &bp);
+    uint64_t need = 0;
+    for (uint32_t i = 0; i < bp.n_passes; i++) {
+        const mbls_pass_plan& pp = bp.pass[i];
+        const bool on_waves = pp.pairing == MBLS_PAIRING_WAVE || pp.pairing == MBLS_PAIRING_WAVE_X2;
+        const bool ksplit = split_layout && on_waves && k >= 4 * MBLS_KEY_SPLIT && k % MBLS_KEY_SPLIT == 0;
+        const uint64_t w = ksplit && pp.items * (1 + MBLS_KEY_SPLIT) > pp.workspace_items ? pp.items * (1 + MBLS_KEY_SPLIT) : pp.workspace_items;
+        if (pp.workspace_first + w > need) need = pp.workspace_first + w;
+    }
+    return need;
+}
+#ifdef MBLS_COOP_PROFILE
+extern "C" int mbls_coop_profile_read(unsigned long long out[64], int reset) {     // dev builds only (not declared in mbls.h)
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(mbls_coop_prof), 64 * 8) != hipSuccess) return MBLS_ERR_DEVICE;
+    if (reset) { unsigned long long z[64] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(mbls_coop_prof), z, 64 * 8) != hipSuccess) return MBLS_ERR_DEVICE; }
+    return MBLS_OK;
+}
+#endif
 extern "C" int mbls_ctx_get_limits(mbls_ctx* c, mbls_limits* out) {
     if (!c || !out) return MBLS_ERR_ARGUMENT;
     mbls_lock lk(c->mu); *out = ctx_limits(c); return MBLS_OK;
@@ -1155,10 +1186,22 @@ struct track {
     bool no_waves = false;            // the pass stays on the lane kernels whatever its size (a remainder BESIDE a round: the wave engine's 40 KB-of-LDS waves would wait
                                       // for SIMDs the round's 512-register waves hold, and its latency advantage is worth nothing next to a 26 ms round)
 };
+// The eight-lane key sum of a pass on the wave engine (see verify_pipeline_one) and the workspace items the pass then needs: n items + 8 n partial sums. Both are
+// functions of the pass plan, the key source and the keys per item -- verify_pipeline sizes the workspace of a whole plan with them BEFORE the first pass is queued.
+static bool pass_key_split(const mbls_pass_plan& pp, const keysrc& ks, uint32_t k) {
+    const bool on_waves = pp.pairing == MBLS_PAIRING_WAVE || pp.pairing == MBLS_PAIRING_WAVE_X2;
+    const bool staged = !ks.indexed && ks.fmt == MBLS_PK_COMPRESSED && !ks.d_off && k > 1;
+    return on_waves && !staged && !ks.d_off && k >= 4 * MBLS_KEY_SPLIT && k % MBLS_KEY_SPLIT == 0 &&
+           (ks.indexed || (ks.fmt == MBLS_PK_UNCOMPRESSED && (((uintptr_t)ks.d_pks) & 3u) == 0));
+}
+static uint64_t pass_ws_items(const mbls_pass_plan& pp, const keysrc& ks, uint32_t k, uint64_t n) {
+    const uint64_t split = pass_key_split(pp, ks, k) ? n + n * MBLS_KEY_SPLIT : 0;
+    return split > pp.workspace_items ? split : pp.workspace_items;
+}
 static track track0(mbls_ctx* c) { track t; t.sb = c->hs_b; t.sc = c->hs_c; t.sd = c->hs_d; t.ev2 = c->hs_ev2; t.ev3 = c->hs_ev3; return t; }
 static int verify_pipeline_one(mbls_ctx* c, const uint8_t* d_sigs, const uint8_t* d_msgs, uint32_t msg_len, const uint64_t* d_moff, const keysrc& ks,
                                uint64_t n, uint32_t k, int mode, uint8_t* d_results, uint64_t* d_bitmap,
-                               uint32_t* d_status, hipStream_t s, int part = 0, const track* tkp = nullptr) {
+                               uint32_t* d_status, hipStream_t s, int part = 0, const track* tkp = nullptr, bool no_growth = false) {
     const int fmt = ks.fmt; const uint32_t* d_off = ks.d_off;
     if (!c || (fmt != MBLS_PK_COMPRESSED && fmt != MBLS_PK_UNCOMPRESSED)) return MBLS_ERR_ARGUMENT;
     if (n == 0) return MBLS_OK;
@@ -1176,10 +1219,13 @@ static int verify_pipeline_one(mbls_ctx* c, const uint8_t* d_sigs, const uint8_t
     bool staged = !ks.indexed && (fmt == MBLS_PK_COMPRESSED) && !d_off && k > 1;   // lane-per-key decompression, then the per-item sums
     // batches on the wave engine are latency: the key sum of 128 keys is a 2 ms chain on one lane -- eight lanes take an eighth of the keys each (items of k / 8
     // keys lie back to back just like that) and k_apk_combine adds their sums: 0.4 ms
-    const bool key_split = on_waves && !staged && !d_off && k >= 4 * MBLS_KEY_SPLIT && k % MBLS_KEY_SPLIT == 0 &&
-                           (ks.indexed || (fmt == MBLS_PK_UNCOMPRESSED && (((uintptr_t)ks.d_pks) & 3u) == 0));
+    // (pass_key_split: the same predicate verify_pipeline sizes the workspace of a several-pass plan with -- a pass that is not the first of its call finds its
+    // space reserved and never grows the workspace under a pass in flight: `no_growth` passes that would not fit fall back to the one-lane key sum)
+    bool key_split = pass_key_split(pp, ks, k);
+    if (key_split && no_growth && tk.ws_off + pass_ws_items(pp, ks, k, n) > c->cap) key_split = false;
     const uint64_t nsub = key_split ? n * MBLS_KEY_SPLIT : 0;
     const uint64_t ws_items = key_split && n + nsub > pp.workspace_items ? n + nsub : pp.workspace_items;
+    if (no_growth && tk.ws_off + ws_items > c->cap) ARGFAIL(c, "internal: a later pass of a plan would have to grow the workspace");
     int rc = mbls_ctx_reserve(c, tk.ws_off + ws_items); if (rc) return rc;        // (a pass on a second track finds its space reserved: no growth under the first)
     mbls_ws ws; ws.w = c->d_w + tk.ws_off; ws.stride = c->cap;
     uint32_t* st = d_status ? d_status : c->d_status + tk.ws_off;
@@ -1279,13 +1325,14 @@ static int verify_pipeline_one(mbls_ctx* c, const uint8_t* d_sigs, const uint8_t
 // Items [lo, n) of a batch as a batch of their own: uniform layouts advance the base pointers, offset tables are absolute (their slice goes
 // with the unmoved base); lo is a multiple of 64, so the bitmap advances by whole words.
 static int verify_pipeline_from(mbls_ctx* c, uint64_t lo, const uint8_t* d_sigs, const uint8_t* d_msgs, uint32_t msg_len, const uint64_t* d_moff, const keysrc& ks,
-                                uint64_t n, uint32_t k, int mode, uint8_t* d_results, uint64_t* d_bitmap, uint32_t* d_status, hipStream_t s, const track* tk = nullptr) {
+                                uint64_t n, uint32_t k, int mode, uint8_t* d_results, uint64_t* d_bitmap, uint32_t* d_status, hipStream_t s, const track* tk = nullptr,
+                                bool no_growth = false) {
     keysrc t = ks;
     const size_t unit = ks.fmt == MBLS_PK_COMPRESSED ? 48 : 96;
     if (ks.d_off) t.d_off = ks.d_off + lo;
     else { if (ks.d_pks) t.d_pks = ks.d_pks + unit * (uint64_t)k * lo; if (ks.d_idx) t.d_idx = ks.d_idx + (uint64_t)k * lo; }
     return verify_pipeline_one(c, d_sigs + 96 * lo, (d_moff || !d_msgs) ? d_msgs : d_msgs + (uint64_t)msg_len * lo, msg_len, d_moff ? d_moff + lo : nullptr, t,
-                               n - lo, k, mode, d_results + lo, d_bitmap ? d_bitmap + lo / 64 : nullptr, d_status ? d_status + lo : nullptr, s, 0, tk);
+                               n - lo, k, mode, d_results + lo, d_bitmap ? d_bitmap + lo / 64 : nullptr, d_status ? d_status + lo : nullptr, s, 0, tk, no_growth);
 }
 // The batch as the caller sees it: plan_batch decides (see there), this function carries the plan out. Passes of one stage run side by side -- track 0 on the
 // caller's stream, track 1 on the context's second set of streams, forked from and joined to the caller's stream --, stages one after the other.
@@ -1298,17 +1345,22 @@ static int verify_pipeline(mbls_ctx* c, const uint8_t* d_sigs, const uint8_t* d_
     if (bp.mode == MBLS_BATCH_ONE_PASS)
         return verify_pipeline_one(c, d_sigs, d_msgs, msg_len, d_moff, ks, n, k, mode, d_results, d_bitmap, d_status, s, 0);
     // one growth of the workspace (and of the staging of decompressed keys) for the whole plan: nothing may be reallocated under a pass in flight
-    uint64_t need = 0;
-    for (uint32_t i = 0; i < bp.n_passes; i++) { const uint64_t e = bp.pass[i].workspace_first + bp.pass[i].workspace_items; if (e > need) need = e; }
+    // (a pass on the wave engine may take the eight-lane key sum: n + 8 n items -- pass_ws_items, the figure the pass itself acts on; the staging of decompressed keys
+    // is indexed by ITEM, so it follows the items' extent, not the partial sums')
+    uint64_t need = 0, need_items = 0;
+    for (uint32_t i = 0; i < bp.n_passes; i++) {
+        const uint64_t e = bp.pass[i].workspace_first + pass_ws_items(bp.pass[i], ks, k, bp.pass[i].items); if (e > need) need = e;
+        const uint64_t ei = bp.pass[i].workspace_first + bp.pass[i].items; if (ei > need_items) need_items = ei;
+    }
     int rc = mbls_ctx_reserve(c, need); if (rc) return rc;
-    if (!ks.indexed && ks.fmt == MBLS_PK_COMPRESSED && !ks.d_off && k > 1) { rc = reserve_keys(c, need * (uint64_t)k); if (rc) return rc; }
+    if (!ks.indexed && ks.fmt == MBLS_PK_COMPRESSED && !ks.d_off && k > 1) { rc = reserve_keys(c, need_items * (uint64_t)k); if (rc) return rc; }
     if (bp.mode == MBLS_BATCH_ROUNDS_THEN_REST) {
-        rc = verify_pipeline_one(c, d_sigs, d_msgs, msg_len, d_moff, ks, bp.pass[0].items, k, mode, d_results, d_bitmap, d_status, s, 0); if (rc) return rc;
-        return verify_pipeline_from(c, bp.pass[1].first_item, d_sigs, d_msgs, msg_len, d_moff, ks, n, k, mode, d_results, d_bitmap, d_status, s);
+        rc = verify_pipeline_one(c, d_sigs, d_msgs, msg_len, d_moff, ks, bp.pass[0].items, k, mode, d_results, d_bitmap, d_status, s, 0, nullptr, true); if (rc) return rc;
+        return verify_pipeline_from(c, bp.pass[1].first_item, d_sigs, d_msgs, msg_len, d_moff, ks, n, k, mode, d_results, d_bitmap, d_status, s, nullptr, true);
     }
     // two tracks: [rounds in front,] then two passes side by side
     uint32_t i = 0;
-    if (bp.n_passes == 3) { rc = verify_pipeline_one(c, d_sigs, d_msgs, msg_len, d_moff, ks, bp.pass[0].items, k, mode, d_results, d_bitmap, d_status, s, 0); if (rc) return rc; i = 1; }
+    if (bp.n_passes == 3) { rc = verify_pipeline_one(c, d_sigs, d_msgs, msg_len, d_moff, ks, bp.pass[0].items, k, mode, d_results, d_bitmap, d_status, s, 0, nullptr, true); if (rc) return rc; i = 1; }
     const mbls_pass_plan& pa = bp.pass[i]; const mbls_pass_plan& pb = bp.pass[i + 1];
     const bool side = bp.mode == MBLS_BATCH_ROUND_BESIDE_REST;
     const uint64_t fm = side ? ~0ull : (pa.front == MBLS_FRONT_IN_A_ROW ? 0 : c->fork_max_items);
@@ -1318,11 +1370,11 @@ static int verify_pipeline(mbls_ctx* c, const uint8_t* d_sigs, const uint8_t* d_
     track tb; tb.no_waves = side; tb.fork_max = fm; tb.ws_off = pb.workspace_first; tb.sb = c->t1_b; tb.sc = c->t1_c; tb.sd = c->t1_b; tb.ev2 = c->t1_ev2; tb.ev3 = c->t1_ev3; tb.ws_sync = false;
     const uint64_t lo = pa.first_item, mid = pb.first_item;
     if (side) {          // the round first: its kernels fill the chip, the remainder's waves take what they leave between them
-        rc = verify_pipeline_from(c, lo, d_sigs, d_msgs, msg_len, d_moff, ks, mid, k, mode, d_results, d_bitmap, d_status, s, &ta);
-        if (!rc) rc = verify_pipeline_from(c, mid, d_sigs, d_msgs, msg_len, d_moff, ks, n, k, mode, d_results, d_bitmap, d_status, c->t1_s, &tb);
+        rc = verify_pipeline_from(c, lo, d_sigs, d_msgs, msg_len, d_moff, ks, mid, k, mode, d_results, d_bitmap, d_status, s, &ta, true);
+        if (!rc) rc = verify_pipeline_from(c, mid, d_sigs, d_msgs, msg_len, d_moff, ks, n, k, mode, d_results, d_bitmap, d_status, c->t1_s, &tb, true);
     } else {
-        rc = verify_pipeline_from(c, mid, d_sigs, d_msgs, msg_len, d_moff, ks, n, k, mode, d_results, d_bitmap, d_status, c->t1_s, &tb);
-        if (!rc) rc = verify_pipeline_from(c, lo, d_sigs, d_msgs, msg_len, d_moff, ks, mid, k, mode, d_results, d_bitmap, d_status, s, &ta);
+        rc = verify_pipeline_from(c, mid, d_sigs, d_msgs, msg_len, d_moff, ks, n, k, mode, d_results, d_bitmap, d_status, c->t1_s, &tb, true);
+        if (!rc) rc = verify_pipeline_from(c, lo, d_sigs, d_msgs, msg_len, d_moff, ks, mid, k, mode, d_results, d_bitmap, d_status, s, &ta, true);
     }
     // join: the caller's stream ends when both tracks have (also on an error path: nothing of the call stays in flight unordered)
     hipError_t e1 = hipEventRecord(c->t1_ev, c->t1_s), e2 = hipStreamWaitEvent(s, c->t1_ev, 0);
@@ -2166,6 +2218,10 @@ static int verify_multiple_impl(mbls_ctx* c, const uint8_t* d_sigs, const uint8_
     const bool fork = 2 * n <= c->round_items;
     hipStream_t s_sig = fork ? c->hs_b : s, s_msg = fork ? c->hs_c : s;
     if (fork) { HIPCHK(c, hipEventRecord(c->hs_ev, s)); HIPCHK(c, hipStreamWaitEvent(s_sig, c->hs_ev, 0)); HIPCHK(c, hipStreamWaitEvent(s_msg, c->hs_ev, 0)); }
+    // side by side, the message phase is the chain the sets' Miller loops wait for: it is ENQUEUED first (behind the ~20 launches of the signature chain's sum tree
+    // it started 0.26 ms late: 2^14 sets 9.47 -> 9.2 ms)
+    const bool hash_first = fork && !hash_enqueued;
+    if (hash_first) launch_hash(c, ws, d_msgs, msg_len, d_moff, c->d_status, n, s_msg, pair_hash);
     if (tab) {      // sets given by indices into a resident key table: the indexed key sum (the keys were decoded and validated once)
         rc = table_acquire(c, tab, s); if (rc) return rc;
         hipLaunchKernelGGL(k_aggregate_indexed_d, dim3(nblk(n)), dim3(WG), 0, s, ws, (const uint32_t*)tab->d_recs, tab->size, d_idx, d_pk_offsets, k, MBLS_MODE_VERIFY, c->d_status, n);
@@ -2185,7 +2241,7 @@ static int verify_multiple_impl(mbls_ctx* c, const uint8_t* d_sigs, const uint8_
             coop_run(c, COOP_SMILLER, ws, (uint64_t)0, (uint64_t)1, (uint64_t)0, (uint64_t)1, (uint32_t*)nullptr, (uint8_t*)nullptr, COOP_RES_ITEM, s_sig);
         HIPCHK(c, hipEventRecord(c->hs_ev, s_sig));                  // ... and its Miller value (awaited just before the tail)
     }
-    if (!(hash_enqueued && fork)) launch_hash(c, ws, d_msgs, msg_len, d_moff, c->d_status, n, s_msg, pair_hash);
+    if (!(hash_enqueued && fork) && !hash_first) launch_hash(c, ws, d_msgs, msg_len, d_moff, c->d_status, n, s_msg, pair_hash);
     if (fork) {      // the sets' Miller loops need the keys (this stream) and the messages; the signature chain is awaited before the tail (hs_ev)
         HIPCHK(c, hipEventRecord(c->hs_ev3, s_msg));
         HIPCHK(c, hipStreamWaitEvent(s, c->hs_ev3, 0));
@@ -2290,49 +2346,72 @@ extern "C" int mbls_verify_multiple_aggregate_signatures(mbls_ctx* c, const uint
 // generator (:280-287) and returns at the first signature outside G2 -- so a rejected batch leaves the generator after exactly as many draws as sets came before
 // the bad one. One call does the same: the signatures are decoded and tested first (k_sig, beside the message phase when the batch leaves room), the host reads
 // the verdicts, `draw` is asked for exactly the scalars the reference would have drawn, and what follows skips the second subgroup test (the points are in the slots).
+// The two halves of that call, shared with the several-device form (mbls_multi_verify_multiple_aggregate_signatures_rng): phase 1 stages a shard's sets, decodes and
+// tests its signatures (they stay in the workspace), starts the message phase and reads the verdicts back; phase 2 takes the scalars and runs the rest -- up to the
+// bool (d_partial == nullptr) or up to the shard's record. The caller holds the context's lock across both.
+struct vm_rng_stage {
+    sbuf ds, da, dm, dr, dmo, dout;
+    const uint8_t* d_msgs = nullptr; const uint64_t* d_moff = nullptr;
+    vm_rng_stage(mbls_ctx* c) : ds(c, 0), da(c, 1), dm(c, 2), dr(c, 3), dmo(c, 6), dout(c, 4) {}
+};
+static void vm_rng_drain(mbls_ctx* c) { (void)hipStreamSynchronize(c->hs_a); (void)hipStreamSynchronize(c->hs_b); (void)hipStreamSynchronize(c->hs_c); c->ws_pending = false; }
+// sigs96 / apks96: the shard's own sets; msgs: the buffer the (absolute) offsets of moff[0 .. n] point into, or n x msg_len bytes. -> MBLS_OK and st[0 .. n) (status words)
+static int vm_rng_phase1(mbls_ctx* c, vm_rng_stage& g, const uint8_t* sigs96, const uint8_t* apks96, const uint8_t* msgs, uint32_t msg_len, const uint64_t* moff, size_t n,
+                         size_t out_bytes, uint32_t* st) {
+    if (hipSetDevice(c->device) != hipSuccess) return MBLS_ERR_DEVICE;
+    if (g.dout.alloc(out_bytes) != hipSuccess) return MBLS_ERR_DEVICE;
+    if (n == 0) return MBLS_OK;
+    const uint64_t msg_first = moff ? moff[0] : 0;
+    const size_t msg_total = moff ? (size_t)(moff[n] - moff[0]) : (size_t)msg_len * n;
+    if (g.ds.up(sigs96, 96 * n) != hipSuccess || g.da.up(apks96, 96 * n) != hipSuccess || g.dm.up(msgs ? msgs + msg_first : nullptr, msg_total) != hipSuccess ||
+        g.dr.alloc(8 * n) != hipSuccess || (moff && g.dmo.up(moff, 8 * (n + 1)) != hipSuccess)) return MBLS_ERR_DEVICE;
+    g.d_msgs = g.dm.as<uint8_t>() - msg_first; g.d_moff = moff ? g.dmo.as<uint64_t>() : nullptr;
+    hipStream_t s = c->hs_a;
+    const bool pair_hash = n <= c->split_max_items && 2 * n <= c->round_items, fork = 2 * n <= c->round_items;       // as verify_multiple_impl decides
+    int rc = mbls_ctx_reserve(c, pair_hash ? 2 * n : n); if (rc) return rc;
+    mbls_ws ws; ws.w = c->d_w; ws.stride = c->cap;
+    rc = ws_acquire(c, s); if (rc) return rc;
+    hipStream_t s_sig = fork ? c->hs_b : s;
+    if (hipMemsetAsync(c->d_status, 0, 4 * n, s) != hipSuccess) { vm_rng_drain(c); return MBLS_ERR_DEVICE; }
+    if (fork) { (void)hipEventRecord(c->hs_ev, s); (void)hipStreamWaitEvent(c->hs_b, c->hs_ev, 0); (void)hipStreamWaitEvent(c->hs_c, c->hs_ev, 0); }
+    if (2 * n <= c->coop_max_items) hipLaunchKernelGGL(k_sig2, dim3(nblk(2 * n)), dim3(WG), 0, s_sig, ws, (const uint8_t*)g.ds.as<uint8_t>(), c->d_status, (uint64_t)n);
+    else hipLaunchKernelGGL(k_sig, dim3(nblk(n)), dim3(WG), 0, s_sig, ws, (const uint8_t*)g.ds.as<uint8_t>(), c->d_status, (uint64_t)n, 1);
+    if (fork) launch_hash(c, ws, g.d_msgs, msg_len, g.d_moff, c->d_status, n, c->hs_c, pair_hash);       // the message phase does not wait for the host
+    if (hipStreamSynchronize(s_sig) != hipSuccess || hipMemcpy(st, c->d_status, 4 * n, hipMemcpyDeviceToHost) != hipSuccess) { vm_rng_drain(c); return MBLS_ERR_DEVICE; }
+    return MBLS_OK;
+}
+// rands[0 .. n): the shard's scalars. d_partial == false: the bool is left in g.dout (1 byte); true: the shard's record (MBLS_VM_PARTIAL_BYTES). Enqueues on hs_a.
+static int vm_rng_phase2(mbls_ctx* c, vm_rng_stage& g, uint32_t msg_len, const uint64_t* rands, size_t n, bool partial) {
+    if (hipSetDevice(c->device) != hipSuccess) return MBLS_ERR_DEVICE;
+    if (n && g.dr.up(rands, 8 * n) != hipSuccess) return MBLS_ERR_DEVICE;
+    return verify_multiple_impl(c, nullptr, g.da.as<uint8_t>(), nullptr, 0, nullptr, 0, g.d_msgs, msg_len, g.d_moff, g.dr.as<uint64_t>(), n, partial ? nullptr : g.dout.as<uint8_t>(),
+                                nullptr, c->hs_a, partial ? g.dout.as<uint32_t>() : nullptr, nullptr, nullptr, true, true);
+}
 extern "C" int mbls_verify_multiple_aggregate_signatures_rng(mbls_ctx* c, const uint8_t* sigs96, const uint8_t* apks96, const uint8_t* msgs,
         uint32_t msg_len, const uint64_t* moff, size_t n, mbls_scalar_source draw, void* user) {
     if (!c) return 0;
     if (n == 0) return 1;                                                   // empty iterator: true, the generator untouched
     if (!draw) return 0;
     if (moff && !msg_offsets_ok(moff, n)) return 0;
-    const uint64_t msg_first = moff ? moff[0] : 0;
     const size_t msg_total = moff ? (size_t)(moff[n] - moff[0]) : (size_t)msg_len * n;
     if (!sigs96 || !apks96 || (!msgs && msg_total)) return 0;
     mbls_lock lk(c->mu);
-    if (hipSetDevice(c->device) != hipSuccess) return 0;
     std::vector<uint64_t> rands; std::vector<uint32_t> st;
     try { rands.resize(n); st.resize(n); } catch (...) { return 0; }
-    sbuf ds(c, 0), da(c, 1), dm(c, 2), dr(c, 3), dmo(c, 6), dres(c, 4);
-    if (ds.up(sigs96, 96 * n) != hipSuccess || da.up(apks96, 96 * n) != hipSuccess || dm.up(msgs ? msgs + msg_first : nullptr, msg_total) != hipSuccess ||
-        dr.alloc(8 * n) != hipSuccess || (moff && dmo.up(moff, 8 * (n + 1)) != hipSuccess) || dres.alloc(8) != hipSuccess) return 0;
-    const uint8_t* d_msgs = dm.as<uint8_t>() - msg_first; const uint64_t* d_moff = moff ? dmo.as<uint64_t>() : nullptr;
-    hipStream_t s = c->hs_a;
-    const bool pair_hash = n <= c->split_max_items && 2 * n <= c->round_items, fork = 2 * n <= c->round_items;       // as verify_multiple_impl decides
-    if (mbls_ctx_reserve(c, pair_hash ? 2 * n : n)) return 0;
-    mbls_ws ws; ws.w = c->d_w; ws.stride = c->cap;
-    if (ws_acquire(c, s)) return 0;
-    hipStream_t s_sig = fork ? c->hs_b : s;
-    auto fail = [&]() { (void)hipStreamSynchronize(c->hs_a); (void)hipStreamSynchronize(c->hs_b); (void)hipStreamSynchronize(c->hs_c); c->ws_pending = false; return 0; };
-    if (hipMemsetAsync(c->d_status, 0, 4 * n, s) != hipSuccess) return fail();
-    if (fork) { (void)hipEventRecord(c->hs_ev, s); (void)hipStreamWaitEvent(c->hs_b, c->hs_ev, 0); (void)hipStreamWaitEvent(c->hs_c, c->hs_ev, 0); }
-    if (2 * n <= c->coop_max_items) hipLaunchKernelGGL(k_sig2, dim3(nblk(2 * n)), dim3(WG), 0, s_sig, ws, (const uint8_t*)ds.as<uint8_t>(), c->d_status, (uint64_t)n);
-    else hipLaunchKernelGGL(k_sig, dim3(nblk(n)), dim3(WG), 0, s_sig, ws, (const uint8_t*)ds.as<uint8_t>(), c->d_status, (uint64_t)n, 1);
-    if (fork) launch_hash(c, ws, d_msgs, msg_len, d_moff, c->d_status, n, c->hs_c, pair_hash);       // the message phase does not wait for the host
-    if (hipStreamSynchronize(s_sig) != hipSuccess || hipMemcpy(st.data(), c->d_status, 4 * n, hipMemcpyDeviceToHost) != hipSuccess) return fail();
+    vm_rng_stage g(c);
+    if (vm_rng_phase1(c, g, sigs96, apks96, msgs, msg_len, moff, n, 8, st.data())) return 0;
     size_t reached = n;                                                     // the sets the reference's loop draws a scalar for
     for (size_t i = 0; i < n; i++)
         if (st[i] & (MBLS_ST_BAD_SIG_ENCODING | MBLS_ST_SIG_NOT_IN_G2)) { reached = i; break; }
     if (reached) draw(user, rands.data(), (uint64_t)reached);
-    if (reached < n) return fail();                                         // :273-275 (fail() only waits for the message phase)
-    if (dr.up(rands.data(), 8 * n) != hipSuccess) return fail();
+    if (reached < n) { vm_rng_drain(c); return 0; }                         // :273-275 (only the message phase is left to wait for)
+    const int rc = vm_rng_phase2(c, g, msg_len, rands.data(), n, false);
     std::fill(rands.begin(), rands.end(), 0);
-    if (verify_multiple_impl(c, nullptr, da.as<uint8_t>(), nullptr, 0, nullptr, 0, d_msgs, msg_len, d_moff, dr.as<uint64_t>(), n, dres.as<uint8_t>(), nullptr, s,
-                             nullptr, nullptr, nullptr, true, true)) return fail();
+    if (rc) { vm_rng_drain(c); return 0; }
     uint8_t r = 0;
-    if (hipStreamSynchronize(s) != hipSuccess) return fail();
+    if (hipStreamSynchronize(c->hs_a) != hipSuccess) { vm_rng_drain(c); return 0; }
     c->ws_pending = false;
-    if (dres.down(&r, 1) != hipSuccess) return 0;
+    if (g.dout.down(&r, 1) != hipSuccess) return 0;
     return r;
 }
 
@@ -2388,14 +2467,15 @@ static void multi_rccl_setup(mbls_multi* m, const int* device_ids, int G) {
     char why[160] = {};
     if (!rccl_open(&m->rccl, why, sizeof(why))) { snprintf(m->rccl_note, sizeof(m->rccl_note), "host join: %s", why); return; }
     m->comms.assign((size_t)G, nullptr);
-    // RCCL prints a version banner to the C stdout when the first communicator of a process is made. A verification library must not write to its host's
-    // stdout (a caller may be emitting a protocol there): descriptor 1 points at stderr while the communicator is set up, and what RCCL buffered is flushed there.
-    fflush(stdout);
-    const int saved = dup(1);
-    if (saved >= 0) (void)dup2(2, 1);
+    // RCCL may print a version banner to the C stdout when the first communicator of a process is made. The library does NOT touch the process-wide descriptor 1
+    // for that by default (another thread of the host may be writing there in that window): an application that emits a protocol on stdout protects it itself, as
+    // bench.py does (protect_stdout), or sets NCCL_DEBUG / RCCL's own switches. MBLS_MULTI_REDIRECT_STDOUT=1 opts a single-threaded host in to the old
+    // behaviour: descriptor 1 points at stderr while the communicator is set up.
+    const bool redirect = getenv("MBLS_MULTI_REDIRECT_STDOUT") != nullptr;
+    int saved = -1;
+    if (redirect) { fflush(stdout); saved = dup(1); if (saved >= 0) (void)dup2(2, 1); }
     const ncclResult_t r = m->rccl.CommInitAll(m->comms.data(), G, device_ids);
-    fflush(stdout);
-    if (saved >= 0) { (void)dup2(saved, 1); (void)close(saved); }
+    if (redirect) { fflush(stdout); if (saved >= 0) { (void)dup2(saved, 1); (void)close(saved); } }
     if (r != ncclSuccess) {
         snprintf(m->rccl_note, sizeof(m->rccl_note), "host join: ncclCommInitAll failed: %s", m->rccl.GetErrorString(r)); m->comms.clear(); return;
     }
@@ -2551,6 +2631,87 @@ extern "C" int mbls_multi_verify_multiple_aggregate_signatures(mbls_multi* m, co
     mbls_lock lk0(c->mu);
     if (hipSetDevice(c->device) != hipSuccess) return 0;
     sbuf dres(c, 4); uint8_t r = 0;
+    if (dres.alloc(8) != hipSuccess) return 0;
+    if (mbls_verify_multiple_finish_device(c, m->d_rec_all[0], G, dres.as<uint8_t>(), nullptr, c->hs_a)) { (void)hipStreamSynchronize(c->hs_a); c->ws_pending = false; return 0; }
+    if (hipStreamSynchronize(c->hs_a) != hipSuccess) return 0;
+    c->ws_pending = false;
+    if (dres.down(&r, 1) != hipSuccess) return 0;
+    return r;
+}
+// The same over several devices with the reference's RNG ORDER and without a second subgroup test (what mbls_verify_multiple_aggregate_signatures_rng is to one
+// device): every device decodes and tests its shard's signatures (they stay in its workspace) beside its message phase; the host reads the verdicts, finds the first
+// bad signature of the WHOLE batch, asks `draw` once for the scalars of the sets in front of it (reference src/aggregates.rs:272-287), and -- all signatures good --
+// every device goes on to its record, the records are exchanged (RCCL / host) and joined. One host thread per device holds its context across both phases.
+#include <condition_variable>
+extern "C" int mbls_multi_verify_multiple_aggregate_signatures_rng(mbls_multi* m, const uint8_t* sigs96, const uint8_t* apks96, const uint8_t* msgs,
+        uint32_t msg_len, const uint64_t* moff, size_t n, mbls_scalar_source draw, void* user) {
+    if (!m) return 0;
+    if (n == 0) return 1;                                                   // empty iterator: true, the generator untouched
+    if (!draw) return 0;
+    if (moff && !msg_offsets_ok(moff, n)) return 0;
+    if (!sigs96 || !apks96 || (!msgs && (moff ? moff[n] != moff[0] : msg_len != 0))) return 0;
+    std::lock_guard<std::mutex> lk(m->mu);
+    const uint64_t G = m->ctx.size();
+    std::vector<uint64_t> rands; std::vector<uint32_t> stw;
+    try { rands.resize(n); stw.resize(n); } catch (...) { return 0; }
+    std::vector<int> rcs(G, MBLS_OK); std::vector<std::thread> th;
+    std::vector<const void*> d_send(G, nullptr); std::vector<void*> d_recv(G, nullptr); std::vector<hipStream_t> st(G, nullptr);
+    std::mutex bm; std::condition_variable cv; uint64_t arrived = 0; int go = 0;             // go: 1 = run phase 2, -1 = stop (a bad signature, or a failed shard)
+    auto work = [&](uint64_t g) {
+        mbls_ctx* c = m->ctx[g];
+        const uint64_t lo = shard_lo(n, g, G), hi = shard_lo(n, g + 1, G), cnt = hi - lo;
+        mbls_lock lk2(c->mu);
+        vm_rng_stage sg(c);
+        if (hipSetDevice(c->device) != hipSuccess) rcs[g] = MBLS_ERR_DEVICE;
+        if (!rcs[g] && !m->d_rec_all[g] && hipMalloc(&m->d_rec_all[g], G * MBLS_VM_PARTIAL_BYTES) != hipSuccess) { m->d_rec_all[g] = nullptr; rcs[g] = MBLS_ERR_DEVICE; }
+        // (offset tables are absolute: phase 1 stages the shard's message bytes from its first offset on)
+        if (!rcs[g]) rcs[g] = vm_rng_phase1(c, sg, sigs96 + 96 * lo, apks96 + 96 * lo, moff ? msgs : (msgs ? msgs + (uint64_t)msg_len * lo : nullptr), msg_len,
+                                            moff ? moff + lo : nullptr, cnt, MBLS_VM_PARTIAL_BYTES, stw.data() + lo);
+        int mine;
+        {
+            std::unique_lock<std::mutex> ul(bm);
+            arrived++; cv.notify_all();
+            cv.wait(ul, [&] { return go != 0; });
+            mine = go;
+        }
+        if (mine < 0 || rcs[g]) { if (cnt) vm_rng_drain(c); return; }
+        rcs[g] = vm_rng_phase2(c, sg, msg_len, rands.data() + lo, cnt, true);
+        const bool synced = hipStreamSynchronize(c->hs_a) == hipSuccess;
+        (void)hipStreamSynchronize(c->hs_b); (void)hipStreamSynchronize(c->hs_c);
+        c->ws_pending = false;
+        if (!rcs[g] && !synced) rcs[g] = MBLS_ERR_DEVICE;
+        d_send[g] = sg.dout.p; d_recv[g] = m->d_rec_all[g]; st[g] = c->hs_a;       // the shard's record stays on its device: the exchange step follows
+    };
+    try { for (uint64_t g = 0; g < G; g++) th.emplace_back(work, g); }
+    catch (...) {
+        { std::lock_guard<std::mutex> gl(bm); go = -1; } cv.notify_all();
+        for (auto& t : th) t.join();
+        snprintf(m->err, sizeof(m->err), "cannot start a host thread"); return 0;
+    }
+    bool proceed = true;
+    {
+        std::unique_lock<std::mutex> ul(bm);
+        cv.wait(ul, [&] { return arrived == G; });
+    }
+    for (uint64_t g = 0; g < G; g++) if (rcs[g]) proceed = false;
+    size_t reached = n;
+    if (proceed) {
+        for (size_t i = 0; i < n; i++)
+            if (stw[i] & (MBLS_ST_BAD_SIG_ENCODING | MBLS_ST_SIG_NOT_IN_G2)) { reached = i; break; }
+        if (reached) draw(user, rands.data(), (uint64_t)reached);
+        if (reached < n) proceed = false;                                   // :273-275
+    }
+    { std::lock_guard<std::mutex> gl(bm); go = proceed ? 1 : -1; } cv.notify_all();
+    for (auto& t : th) t.join();
+    std::fill(rands.begin(), rands.end(), 0);
+    for (uint64_t g = 0; g < G; g++)
+        if (rcs[g]) { snprintf(m->err, sizeof(m->err), "device %d (shard %llu): %s", m->ctx[g]->device, (unsigned long long)g, m->ctx[g]->err); return 0; }
+    if (!proceed) return 0;
+    if (multi_allgather(m, d_send, d_recv, MBLS_VM_PARTIAL_BYTES, st)) return 0;
+    mbls_ctx* c = m->ctx[0];
+    mbls_lock lk0(c->mu);
+    if (hipSetDevice(c->device) != hipSuccess) return 0;
+    sbuf dres(c, 5); uint8_t r = 0;
     if (dres.alloc(8) != hipSuccess) return 0;
     if (mbls_verify_multiple_finish_device(c, m->d_rec_all[0], G, dres.as<uint8_t>(), nullptr, c->hs_a)) { (void)hipStreamSynchronize(c->hs_a); c->ws_pending = false; return 0; }
     if (hipStreamSynchronize(c->hs_a) != hipSuccess) return 0;

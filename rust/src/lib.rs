@@ -100,6 +100,8 @@ extern "C" {
                                                pk_format: c_int, pk_offsets: *const u32, n: u64, k: u32, bitmap: *mut u64, status: *mut u32) -> c_int;
     fn mbls_multi_verify_multiple_aggregate_signatures(m: *mut MblsMulti, sigs96: *const u8, apks96: *const u8, msgs: *const u8, msg_len: u32,
                                                        msg_offsets: *const u64, rands: *const u64, n: usize) -> c_int;
+    fn mbls_multi_verify_multiple_aggregate_signatures_rng(m: *mut MblsMulti, sigs96: *const u8, apks96: *const u8, msgs: *const u8, msg_len: u32,
+                                                           msg_offsets: *const u64, n: usize, draw: MblsScalarSource, user: *mut c_void) -> c_int;
 }
 const PK_COMPRESSED: c_int = 0;
 const PK_UNCOMPRESSED: c_int = 1;
@@ -534,23 +536,15 @@ impl AggregateSignature {
             moff.push(msgs.len() as u64);
         }
         // `draw` of mbls_verify_multiple_aggregate_signatures_rng: the scalars of the sets in front of the first bad signature, drawn as `:280-287` does
-        unsafe extern "C" fn draw<R: Rng + ?Sized>(user: *mut c_void, out: *mut u64, count: u64) {
-            let rng: &mut R = &mut **(user as *mut &mut R);
-            for i in 0..count as usize {
-                let mut rand = 0u64;
-                while rand == 0 {
-                    let mut rand_bytes = [0u8; 8];
-                    rng.fill(&mut rand_bytes);
-                    rand = i64::from_be_bytes(rand_bytes).wrapping_abs() as u64;
-                }
-                *out.add(i) = rand;
-            }
+        let mut st = DrawState { rng, panic: None };
+        let ok = unsafe {
+            mbls_verify_multiple_aggregate_signatures_rng(ctx(), sigs.as_ptr(), apks.as_ptr(), msgs.as_ptr(), 0, moff.as_ptr(), n, draw_scalars::<R>,
+                                                          &mut st as *mut DrawState<R> as *mut c_void) == 1
+        };
+        if let Some(payload) = st.panic.take() {
+            std::panic::resume_unwind(payload);
         }
-        let mut rng_ref: &mut R = rng;
-        unsafe {
-            mbls_verify_multiple_aggregate_signatures_rng(ctx(), sigs.as_ptr(), apks.as_ptr(), msgs.as_ptr(), 0, moff.as_ptr(), n, draw::<R>,
-                                                          &mut rng_ref as *mut &mut R as *mut c_void) == 1
-        }
+        ok
     }
     /// `src/aggregates.rs:319-322`
     pub fn from_bytes(bytes: &[u8]) -> Result<AggregateSignature, AmclError> {
@@ -561,6 +555,36 @@ impl AggregateSignature {
     /// `src/aggregates.rs:325-327`
     pub fn as_bytes(&self) -> [u8; G2_BYTES] {
         self.point
+    }
+}
+
+// The `draw` of mbls_[multi_]verify_multiple_aggregate_signatures_rng: the scalars of the sets in front of the first bad signature, drawn as `:280-287` does.
+// A panic must not unwind through the C frames of the library (the context mutex is held and GPU work is in flight): it is caught HERE, the scalars are
+// zeroed so that the batch fails closed (a zero scalar is rejected), and the payload is raised again once the FFI call has returned -- what the C++ and
+// Python mirrors do with an exception in their generator.
+struct DrawState<'r, R: Rng + ?Sized> {
+    rng: &'r mut R,
+    panic: Option<Box<dyn std::any::Any + Send + 'static>>,
+}
+unsafe extern "C" fn draw_scalars<R: Rng + ?Sized>(user: *mut c_void, out: *mut u64, count: u64) {
+    let st: &mut DrawState<R> = &mut *(user as *mut DrawState<R>);
+    let out = std::slice::from_raw_parts_mut(out, count as usize);
+    let r = std::panic::catch_unwind(std::panic::AssertUnwindSafe(|| {
+        for o in out.iter_mut() {
+            let mut rand = 0u64;
+            while rand == 0 {
+                let mut rand_bytes = [0u8; 8];
+                st.rng.fill(&mut rand_bytes);
+                rand = i64::from_be_bytes(rand_bytes).wrapping_abs() as u64;
+            }
+            *o = rand;
+        }
+    }));
+    if let Err(payload) = r {
+        for o in out.iter_mut() {
+            *o = 0;
+        }
+        st.panic = Some(payload);
     }
 }
 
@@ -729,26 +753,29 @@ impl MultiGpu {
         R: Rng + ?Sized,
         I: Iterator<Item = (&'a AggregateSignature, &'a AggregatePublicKey, &'a [u8])>,
     {
-        let (mut sigs, mut apks, mut msgs, mut rands) = (Vec::new(), Vec::new(), Vec::new(), Vec::<u64>::new());
+        let sets: Vec<(&AggregateSignature, &AggregatePublicKey, &[u8])> = signature_sets.collect();
+        let n = sets.len();
+        if n == 0 {
+            return true;
+        }
+        let (mut sigs, mut apks, mut msgs) = (Vec::new(), Vec::new(), Vec::new());
         let mut moff: Vec<u64> = vec![0];
-        for (s, a, m) in signature_sets {
-            let mut rand = 0u64;
-            while rand == 0 {
-                let mut rand_bytes = [0u8; 8];
-                rng.fill(&mut rand_bytes);
-                rand = i64::from_be_bytes(rand_bytes).wrapping_abs() as u64;
-            }
-            rands.push(rand);
+        for (s, a, m) in &sets {
             sigs.extend_from_slice(&s.point);
             apks.extend_from_slice(&a.point);
             msgs.extend_from_slice(m);
             moff.push(msgs.len() as u64);
         }
-        let n = rands.len();
-        if n == 0 {
-            return true;
+        // one call, the reference's RNG order (`src/aggregates.rs:272-287`): every device tests its shard's signatures first, the scalars are asked for once
+        let mut st = DrawState { rng, panic: None };
+        let ok = unsafe {
+            mbls_multi_verify_multiple_aggregate_signatures_rng(self.h, sigs.as_ptr(), apks.as_ptr(), msgs.as_ptr(), 0, moff.as_ptr(), n, draw_scalars::<R>,
+                                                                &mut st as *mut DrawState<R> as *mut c_void) == 1
+        };
+        if let Some(payload) = st.panic.take() {
+            std::panic::resume_unwind(payload);
         }
-        unsafe { mbls_multi_verify_multiple_aggregate_signatures(self.h, sigs.as_ptr(), apks.as_ptr(), msgs.as_ptr(), 0, moff.as_ptr(), rands.as_ptr(), n) == 1 }
+        ok
     }
 }
 impl Drop for MultiGpu {

@@ -13,6 +13,16 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_sessionstart(session):
+    # the untracked generated source (milagro_bls_amd/csrc/mbls_towerd_asm.inc, 25 MB: written by the build, milagro_bls_amd/build.py) exists before any test reads it;
+    # a tree that holds the file and its stamp is left alone (the GPU box)
+    try:
+        from milagro_bls_amd import build
+        build.ensure_generated()
+    except Exception as e:                                  # noqa: BLE001 -- the tests that need the file say so themselves
+        sys.stderr.write("conftest: ensure_generated failed: %r\n" % (e,))
+
+
 @pytest.fixture(scope="session")
 def vectors():
     import helpers

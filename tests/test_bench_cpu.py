@@ -121,3 +121,29 @@ def test_a_failing_rank_or_a_wrong_world_size_is_an_error_exit_not_a_one_gpu_lin
     if torch.cuda.device_count() < 2:
         rc, lines, err = _bench("--gpus", "2")
         assert rc == 4 and not lines and "visible" in err
+
+
+def test_eight_ranks_print_what_a_scale_record_needs():
+    """`bench.py --gpus 8 --stub`: the line a SCALE record is made from at N = 8 -- n_gpus, one ms_per_step per rank, the gathered bitmap checked on every rank, the
+    process group's own rank count and the time of the one collective, and configs[4]'s shard leg (timed at 8 ranks only)."""
+    rc, lines, err = _bench("--gpus", "8", "--steps", "2", "--warmup", "1", "--stub")
+    assert rc == 0, err
+    assert len(lines) == 1
+    d = lines[0]
+    assert d["n_gpus"] == 8 and d["stub"] is True and d["scaling"] == "weak" and d["bitmap_matches_expectation"] is True
+    assert len(d["ms_per_step_per_rank"]) == 8 and all(x > 0 for x in d["ms_per_step_per_rank"])
+    assert d["ms_per_step"] >= max(d["ms_per_step_per_rank"]) * 0.95           # the job's time is the slowest rank's
+    c = d["collective"]
+    assert c["backend"] == "gloo" and c["group_world_size"] == 8 and c["group_rank_count_matches_n_gpus"] is True and c["all_gather_ms_per_step"] > 0
+    leg = d["configs4_shard_leg"]
+    assert leg["bitmap_matches_expectation"] is True and leg["steps"] == 2 and leg["value"] > 0
+
+
+def test_a_rank_that_dies_ends_the_job_with_an_error_and_no_line():
+    """one of eight ranks exits in the middle of the timed region (fresh child processes only; nothing is re-executed): the others would wait in the gather for
+    ever -- the parent ends them after its grace period, prints no result line and leaves with a non-zero code"""
+    import time as _t
+    t0 = _t.time()
+    rc, lines, err = _bench("--gpus", "8", "--steps", "3", "--warmup", "0", "--stub", env={"MBLS_STUB_DIE_RANK": "5"})
+    assert rc != 0 and not lines
+    assert _t.time() - t0 < 240

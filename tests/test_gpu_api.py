@@ -319,6 +319,46 @@ def test_verify_multiple_draws_scalars_in_the_reference_order(api, vectors):
     assert api.AggregateSignature.verify_multiple_aggregate_signatures(rng, wrong) is False and rng.n == 5 * 8
 
 
+@pytest.mark.parametrize("devs", [[0], [0, 0], [0, 0, 0]])
+def test_verify_multiple_over_several_devices_draws_in_the_reference_order_too(api, vectors, devs):
+    """mbls_multi_verify_multiple_aggregate_signatures_rng (one context per listed device: {0} = an RCCL communicator of one rank, {0, 0} / {0, 0, 0} = the host join on
+    one GPU): every device tests its shard's signatures first, the scalars are asked for ONCE for the sets in front of the first bad signature of the whole batch --
+    same bool and the same number of random bytes as the one-device call, wherever the bad signature's shard lies; more devices than sets leave empty shards."""
+    from milagro_bls_amd import _native as N
+    rnd = random.Random(32)
+    sets = _sets(api, rnd, 7, 2)
+    probe = api.AggregateSignature.from_bytes(bytes.fromhex(vectors["model"]["g2_subgroup_probes"][0]["compressed"]))
+    m = N.MultiContext(devs)
+    try:
+        vm = lambda rng, s: api.AggregateSignature.verify_multiple_aggregate_signatures(rng, s, devices=m)
+        rng = _CountingRng(1)
+        assert vm(rng, sets) is True and rng.n == 7 * 8
+        rng = _CountingRng(2, zero_first=8)
+        assert vm(rng, sets) is True and rng.n == 8 * 8
+        for pos in (0, 2, 3, 6):                              # first / a middle shard / the last set
+            bad = list(sets); bad[pos] = (probe, sets[pos][1], sets[pos][2])
+            rng = _CountingRng(3)
+            assert vm(rng, bad) is False and rng.n == pos * 8, pos
+            one = _CountingRng(3)
+            assert api.AggregateSignature.verify_multiple_aggregate_signatures(one, bad) is False and one.n == rng.n
+        wrong = list(sets); wrong[5] = (sets[4][0], sets[5][1], sets[5][2])        # in G2, wrong signature: the pairing check rejects, every scalar was drawn
+        rng = _CountingRng(5)
+        assert vm(rng, wrong) is False and rng.n == 7 * 8
+        rng = _CountingRng(6)
+        assert vm(rng, sets[:2]) is True and rng.n == 2 * 8          # fewer sets than devices ({0, 0, 0}): an empty shard contributes (1, infinity)
+        assert vm(_CountingRng(7), []) is True
+        # a generator that raises: the batch fails closed and the exception comes out afterwards
+        class Boom(_CountingRng):
+            def getrandbits(self, k):
+                if self.n >= 20:
+                    raise RuntimeError("rng broke")
+                return super().getrandbits(k)
+        with pytest.raises(RuntimeError):
+            vm(Boom(8), sets)
+    finally:
+        m.close()
+
+
 @pytest.mark.usefixtures("engine")
 def test_aggregate_verify(api, vectors):
     # src/aggregates.rs:808-929

@@ -109,3 +109,20 @@ def test_limits_change_the_plan():
     assert mode == N.BATCH_TWO_HALVES and [(p["first_item"], p["items"]) for p in ps] == [(0, 128), (128, 128), (256, 44)]
     mode, ps = N.plan_batch(200, L)
     assert mode == N.BATCH_TWO_HALVES and [(p["first_item"], p["items"]) for p in ps] == [(0, 128), (128, 72)]
+
+
+def test_workspace_of_a_plan_counts_the_eight_lane_key_sum():
+    """a pass on the wave engine with k >= 32 keys (a multiple of 8) in a uniform layout sums its keys on eight lanes per item -- n + 8 n workspace items --, and
+    the entries reserve for the WHOLE plan before the first pass is queued (no pass grows the workspace under another in flight)"""
+    assert N.plan_workspace_items(1, 128) == 9 and N.plan_workspace_items(100, 128) == 900
+    assert N.plan_workspace_items(100, 128, split_layout=False) == 100          # ragged sets / 48-byte keys: one lane per item
+    assert N.plan_workspace_items(100, 24) == 100 and N.plan_workspace_items(100, 36) == 100      # below 32 keys / not a multiple of 8
+    assert N.plan_workspace_items(5120, 128) == 9 * 5120 and N.plan_workspace_items(5121, 128) == 2 * 5121
+    # a round, then a remainder on the wave engine: the remainder's 9 r items may exceed the round's own
+    assert N.plan_workspace_items(R + 100, 128) == R and N.plan_workspace_items(R + 3583, 128) == R
+    L = N.default_limits(8192)                   # a small device: round 8 192, remainders up to 5 120 on waves -> 9 r > round
+    L.tracks_min_rest = 0
+    assert N.plan_batch(8192 + 2000, L)[0] == N.BATCH_ROUNDS_THEN_REST
+    assert N.plan_workspace_items(8192 + 2000, 128, True, L) == 18000
+    assert N.plan_workspace_items(8192 + 2000, 128, False, L) == 8192
+    assert N.plan_workspace_items(0, 128) == 0
