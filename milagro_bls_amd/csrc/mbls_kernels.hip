@@ -550,11 +550,26 @@ __global__ void MBLS_LB k_sigslot_to_s(mbls_ws ws, uint64_t item) {
 __global__ void MBLS_LB k_g1_decode(const uint8_t* in, int fmt, int validate, uint64_t n, uint8_t* out96, uint8_t* err) { uint64_t i = gid(); if (i < n) op_g1_decode(i, in, fmt, validate, out96, err); }
 __global__ void MBLS_LB k_g1_key_validate(const uint8_t* in96, uint64_t n, uint8_t* ok) { uint64_t i = gid(); if (i < n) op_g1_key_validate(i, in96, ok); }
 __global__ void MBLS_LB k_g1_compress(const uint8_t* in96, uint64_t n, uint8_t* out48, uint8_t* err) { uint64_t i = gid(); if (i < n) op_g1_compress(i, in96, out48, err); }
-__global__ void MBLS_LB k_g2_check(const uint8_t* in96, uint64_t n, uint8_t* err, uint8_t* in_g2) { uint64_t i = gid(); if (i < n) op_g2_check(i, in96, err, in_g2); }
+// n x Signature::from_bytes (reference src/signature.rs:43-46) + the subgroup test verify performs (:29): the decoder inlined as in k_sig and the GENERATED subgroup
+// routine on the item's workspace slots (psi(P) = [x] P; no lane-private memory). err[i] = the decoder's code; in_g2 (optional): 1 for points of G2 and for infinity.
+__global__ void MBLS_LB k_g2_check(mbls_ws ws, const uint8_t* in96, uint64_t n, uint8_t* err, uint8_t* in_g2) {
+#if MBLS_DEVICE_ASM
+    __shared__ uint32_t spill[154 * 64];
+    uint64_t i = gid(); if (i >= n) return;
+    fp2 x, y; bool inf;
+    const int e = g2_decode_compressed_t<true>(&x, &y, &inf, in96 + 96 * i);
+    err[i] = (uint8_t)e;
+    if (!in_g2) return;                               // (uniform: a kernel argument)
+    if (e) inf = true;
+    if (inf) { x = fp2_zero(); y = fp2_zero(); }
+    ws_st2(ws, MBLS_SLOT_SIG, i, x); ws_st2(ws, MBLS_SLOT_SIG + 2, i, y);
+    const uint32_t fl = g2_group_d_call<false>(ws, i, (MBLS_LDS uint32_t*)spill, threadIdx.x);
+    in_g2[i] = (!e && ((fl & 1u) | (inf ? 1u : 0u))) ? 1 : 0;
+#endif
+}
 __global__ void MBLS_LB k_g2_add(const uint8_t* a, const uint8_t* b, uint64_t n, uint8_t* out, uint8_t* err) { uint64_t i = gid(); if (i < n) op_g2_add(i, a, b, out, err); }
 __global__ void MBLS_LB k_g1_add(const uint8_t* a, const uint8_t* b, uint64_t n, uint8_t* out, uint8_t* err) { uint64_t i = gid(); if (i < n) op_g1_add(i, a, b, out, err); }
 __global__ void MBLS_LB k_sk_to_pk(const uint8_t* sks, int fmt, uint64_t n, uint8_t* out) { uint64_t i = gid(); if (i < n) op_sk_to_pk(i, sks, fmt, out); }
-__global__ void MBLS_LB k_hash_to_g2(const uint8_t* msgs, uint32_t mlen, uint64_t n, uint8_t* out96) { uint64_t i = gid(); if (i < n) op_hash_to_g2(i, msgs, mlen, out96); }
 __global__ void MBLS_LB k_fp_mul(const uint8_t* a, const uint8_t* b, uint64_t n, uint8_t* out, int op) { uint64_t i = gid(); if (i < n) op_fp_mul(i, n, a, b, out, op); }
 // PublicKey::from_secret_key as a key sum: [sk] G1 = sum_j [d_j 16^j] G1 over the 64 hexadecimal digits of sk, every term a record of a
 // fixed 64 x 16 table (record 16 j + d; d = 0 is the point at infinity) -- the indexed key-sum routine does the rest, no doubling at all
@@ -607,26 +622,35 @@ __global__ void MBLS_LB k_apk_export(mbls_ws ws, uint64_t n, uint8_t* out96) { u
 // x = -y, y = 0xd201000000010000, and r = y^4 - y^2 + 1 < y^4: with sk mod r = a0 + a1 y + a2 y^2 + a3 y^3 (0 <= a_j < y < 2^64),
 // [sk] H = sum_j [a_j] (-1)^j psi^j(H) -- four 64-bit multiplications that run side by side on four lanes (items i, n + i, 2n + i, 3n + i)
 // with verify_multiple's windowed routine (g2_blind_routine without its subgroup test), then two levels of the G2 sum tree.
-MBLS_FN void scalar_base_y_digits(uint64_t a[4], const uint8_t* sk32) {
-    uint32_t k[8]; scalar_from_be32(k, sk32);
-    for (int rep = 0; rep < 4; rep++) {                            // any 32-byte value: 2^256 < 5 r, at most four subtractions
-        uint32_t d[8]; uint64_t bw = 0;
-        for (int j = 0; j < 8; j++) { uint64_t t = (uint64_t)k[j] - MBLS_ORDER[j] - bw; d[j] = (uint32_t)t; bw = (t >> 32) & 1u; }
-        for (int j = 0; j < 8; j++) k[j] = bw ? k[j] : d[j];
-    }
+// (64-bit limbs in named variables, every limb loop unrolled: nothing here is indexed at run time, so nothing lives in lane-private memory)
+MBLS_FN uint64_t div_step_y(uint64_t* rem, uint64_t limb) {       // (rem : limb) / y with rem < y: the quotient limb, the remainder left in *rem (restoring, one bit a step)
     const uint64_t y = MBLS_X_ABS;
-    for (int t = 0; t < 4; t++) {                                  // k <- k / y, a[t] = k mod y: restoring division, one bit a step
+    uint64_t r = *rem, q = 0;
+    for (int b = 63; b >= 0; b--) {
+        const uint64_t top = r >> 63;
+        r = (r << 1) | ((limb >> b) & 1u);
+        const bool ge = top | (r >= y);
+        r = ge ? r - y : r; q = (q << 1) | (ge ? 1u : 0u);
+    }
+    *rem = r; return q;
+}
+MBLS_FN void scalar_base_y_digits(uint64_t a[4], const uint8_t* sk32) {
+    uint64_t k3 = 0, k2 = 0, k1 = 0, k0 = 0;                        // big-endian bytes -> limbs, k0 the least significant
+#pragma unroll
+    for (int j = 0; j < 8; j++) { k3 = (k3 << 8) | sk32[j]; k2 = (k2 << 8) | sk32[8 + j]; k1 = (k1 << 8) | sk32[16 + j]; k0 = (k0 << 8) | sk32[24 + j]; }
+    const uint64_t r0 = 0xffffffff00000001ull, r1 = 0x53bda402fffe5bfeull, r2 = 0x3339d80809a1d805ull, r3 = 0x73eda753299d7d48ull;      // the group order
+#pragma unroll
+    for (int rep = 0; rep < 4; rep++) {                            // any 32-byte value: 2^256 < 5 r, at most four subtractions
+        const uint64_t d0 = k0 - r0; const uint64_t b0 = k0 < r0;
+        const uint64_t t1 = k1 - r1; const uint64_t d1 = t1 - b0; const uint64_t b1 = (k1 < r1) | (t1 < b0);
+        const uint64_t t2 = k2 - r2; const uint64_t d2 = t2 - b1; const uint64_t b2 = (k2 < r2) | (t2 < b1);
+        const uint64_t t3 = k3 - r3; const uint64_t d3 = t3 - b2; const uint64_t b3 = (k3 < r3) | (t3 < b2);
+        k0 = b3 ? k0 : d0; k1 = b3 ? k1 : d1; k2 = b3 ? k2 : d2; k3 = b3 ? k3 : d3;
+    }
+#pragma unroll
+    for (int t = 0; t < 4; t++) {                                  // k <- k / y, a[t] = k mod y
         uint64_t rem = 0;
-        for (int j = 7; j >= 0; j--) {
-            uint32_t q = 0;
-            for (int b = 31; b >= 0; b--) {
-                const uint32_t top = (uint32_t)(rem >> 63);
-                rem = (rem << 1) | ((k[j] >> b) & 1u);
-                const bool ge = top | (rem >= y);
-                rem = ge ? rem - y : rem; q = (q << 1) | (ge ? 1u : 0u);
-            }
-            k[j] = q;
-        }
+        k3 = div_step_y(&rem, k3); k2 = div_step_y(&rem, k2); k1 = div_step_y(&rem, k1); k0 = div_step_y(&rem, k0);
         a[t] = rem;
     }
 }
@@ -1629,8 +1653,11 @@ extern "C" int mbls_sig_check_batch(mbls_ctx* c, const uint8_t* in96, uint64_t n
     if (!n) return MBLS_OK;
     HIPCHK(c, hipSetDevice(c->device));
     sbuf di(c, 0), de(c, 1), dg(c, 2); HIPCHK(c, di.up(in96, 96 * n)); HIPCHK(c, de.alloc(n)); if (in_g2) HIPCHK(c, dg.alloc(n));
-    hipLaunchKernelGGL(k_g2_check, dim3(nblk(n)), dim3(WG), 0, c->hs_a, di.as<uint8_t>(), n, de.as<uint8_t>(), in_g2 ? dg.as<uint8_t>() : (uint8_t*)nullptr);
-    HIPCHK(c, hipStreamSynchronize(c->hs_a)); HIPCHK(c, de.down(errs, n)); if (in_g2) HIPCHK(c, dg.down(in_g2, n));
+    int rc = mbls_ctx_reserve(c, n); if (rc) return rc;               // the subgroup routine works on the items' workspace slots
+    mbls_ws ws; ws.w = c->d_w; ws.stride = c->cap;
+    rc = ws_acquire(c, c->hs_a); if (rc) return rc;
+    hipLaunchKernelGGL(k_g2_check, dim3(nblk(n)), dim3(WG), 0, c->hs_a, ws, di.as<uint8_t>(), n, de.as<uint8_t>(), in_g2 ? dg.as<uint8_t>() : (uint8_t*)nullptr);
+    HIPCHK(c, hipStreamSynchronize(c->hs_a)); c->ws_pending = false; HIPCHK(c, de.down(errs, n)); if (in_g2) HIPCHK(c, dg.down(in_g2, n));
     for (uint64_t i = 0; i < n; i++) errs[i] = (uint8_t)map_dec_err_g2(errs[i]);
     return MBLS_OK;
 }
@@ -1768,15 +1795,16 @@ extern "C" int mbls_hash_to_g2_batch_mode(mbls_ctx* c, const uint8_t* msgs, uint
     if (!n) return MBLS_OK;
     HIPCHK(c, hipSetDevice(c->device));
     sbuf dm(c, 0), dout(c, 1); HIPCHK(c, dm.up(msgs, (size_t)msg_len * n)); HIPCHK(c, dout.alloc(96 * n));
-    if (mode == 0)        // the stand-alone compiled lane body
-        hipLaunchKernelGGL(k_hash_to_g2, dim3(nblk(n)), dim3(WG), 0, c->hs_a, dm.as<uint8_t>(), msg_len, n, dout.as<uint8_t>());
-    else {                // the pipeline's message phase (mode 1: one lane per item, the generated routine; mode 2: one wave per item, program hashg2), then its H
-        int rc = mbls_ctx_reserve(c, mode == 3 ? 2 * n : n); if (rc) return rc;
+    {                     // the pipeline's message phase (mode 0: the form a batch of this size takes by itself; mode 1: one lane per item, the generated routine;
+                          // mode 2: one wave per item, program hashg2; mode 3: two lanes per item), then its H
+        const bool pair0 = mode == 0 && 2 * n <= c->round_items;
+        int rc = mbls_ctx_reserve(c, (mode == 3 || pair0) ? 2 * n : n); if (rc) return rc;
         mbls_ws ws; ws.w = c->d_w; ws.stride = c->cap;
         rc = ws_acquire(c, c->hs_a); if (rc) return rc;
         HIPCHK(c, hipMemsetAsync(c->d_status, 0, 4 * n, c->hs_a));
         // the form is named, not routed: mode 1 one lane per item, mode 2 one wave per item (four items per wave above the packing limit), mode 3 two lanes per item
-        launch_hash(c, ws, dm.as<uint8_t>(), msg_len, nullptr, c->d_status, n, c->hs_a, mode == 3, mode == 1 ? HASH_FORM_LANE : mode == 2 ? HASH_FORM_WAVE : HASH_FORM_PAIR);
+        launch_hash(c, ws, dm.as<uint8_t>(), msg_len, nullptr, c->d_status, n, c->hs_a, mode == 3 || pair0,
+                    mode == 0 ? HASH_FORM_AUTO : mode == 1 ? HASH_FORM_LANE : mode == 2 ? HASH_FORM_WAVE : HASH_FORM_PAIR);
         hipLaunchKernelGGL(k_h_export, dim3(nblk(n)), dim3(WG), 0, c->hs_a, ws, n, dout.as<uint8_t>());
     }
     HIPCHK(c, hipStreamSynchronize(c->hs_a)); c->ws_pending = false; HIPCHK(c, dout.down(out96, 96 * n)); return MBLS_OK;
