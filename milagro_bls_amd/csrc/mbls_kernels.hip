@@ -722,6 +722,29 @@ __global__ void __launch_bounds__(WG) k_valu_bench(uint32_t* sink, uint32_t iter
             // the same with the paired Fp product of the key-sum routines (8 x 923 instructions, 784 multiply-accumulates each)
             MBLS_REP4(asm volatile(MBLS_FP_MULPAIR_D_ASM MBLS_FP_MULPAIR_D_ASM ::: MBLS_VALU_BENCH_CLOBBERS);)
 #endif
+        } else if (mode == 4) {
+            // class model against mix, the experiment: 8 multiply-accumulates and 4 plain two-operand operations INTERLEAVED 2 : 1 (the kernels'
+            // proportion) ...
+            MBLS_REP16(asm volatile("v_mad_u64_u32 %0, vcc, %12, %13, %0\n v_mad_u64_u32 %1, s[20:21], %12, %13, %1\n v_add_u32_e32 %8, %12, %8\n"
+                                    "v_mad_u64_u32 %2, vcc, %12, %13, %2\n v_mad_u64_u32 %3, s[22:23], %12, %13, %3\n v_and_b32_e32 %9, %13, %9\n"
+                                    "v_mad_u64_u32 %4, vcc, %12, %13, %4\n v_mad_u64_u32 %5, s[20:21], %12, %13, %5\n v_add_u32_e32 %10, %13, %10\n"
+                                    "v_mad_u64_u32 %6, vcc, %12, %13, %6\n v_mad_u64_u32 %7, s[22:23], %12, %13, %7\n v_xor_b32_e32 %11, %12, %11\n"
+                                    : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3), "+v"(c4), "+v"(c5), "+v"(c6), "+v"(c7), "+v"(h0), "+v"(h1), "+v"(h2), "+v"(h3)
+                                    : "v"(a), "v"(b) : "vcc", "s20", "s21", "s22", "s23");)
+        } else if (mode == 5) {
+            // ... and the SAME twelve instructions in two homogeneous blocks (what a per-class model of the stream assumes)
+            MBLS_REP16(asm volatile("v_mad_u64_u32 %0, vcc, %12, %13, %0\n v_mad_u64_u32 %1, s[20:21], %12, %13, %1\n"
+                                    "v_mad_u64_u32 %2, vcc, %12, %13, %2\n v_mad_u64_u32 %3, s[22:23], %12, %13, %3\n"
+                                    "v_mad_u64_u32 %4, vcc, %12, %13, %4\n v_mad_u64_u32 %5, s[20:21], %12, %13, %5\n"
+                                    "v_mad_u64_u32 %6, vcc, %12, %13, %6\n v_mad_u64_u32 %7, s[22:23], %12, %13, %7\n"
+                                    "v_add_u32_e32 %8, %12, %8\n v_and_b32_e32 %9, %13, %9\n v_add_u32_e32 %10, %13, %10\n v_xor_b32_e32 %11, %12, %11\n"
+                                    : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3), "+v"(c4), "+v"(c5), "+v"(c6), "+v"(c7), "+v"(h0), "+v"(h1), "+v"(h2), "+v"(h3)
+                                    : "v"(a), "v"(b) : "vcc", "s20", "s21", "s22", "s23");)
+        } else if (mode == 6) {
+            // ... and the four plain operations alone
+            MBLS_REP16(asm volatile("v_add_u32_e32 %0, %4, %0\n v_and_b32_e32 %1, %5, %1\n v_add_u32_e32 %2, %5, %2\n v_xor_b32_e32 %3, %4, %3\n"
+                                    "v_add_u32_e32 %0, %5, %0\n v_and_b32_e32 %1, %4, %1\n v_add_u32_e32 %2, %4, %2\n v_xor_b32_e32 %3, %5, %3\n"
+                                    : "+v"(h0), "+v"(h1), "+v"(h2), "+v"(h3) : "v"(a), "v"(b));)
         } else {
             MBLS_REP16(asm volatile("v_add_co_u32_e64 %0, vcc, %4, %0\n v_add_co_u32_e64 %2, s[20:21], %5, %2\n v_addc_co_u32_e64 %1, vcc, %5, %1, vcc\n v_addc_co_u32_e64 %3, s[20:21], %4, %3, s[20:21]\n"
                                     "v_add_co_u32_e64 %0, vcc, %5, %0\n v_add_co_u32_e64 %2, s[20:21], %4, %2\n v_addc_co_u32_e64 %1, vcc, %4, %1, vcc\n v_addc_co_u32_e64 %3, s[20:21], %5, %3, s[20:21]\n"
@@ -1888,7 +1911,7 @@ extern "C" int mbls_fp_mul_bench(mbls_ctx* c, uint64_t n_lanes, uint32_t iters, 
 }
 
 extern "C" int mbls_valu_bench(mbls_ctx* c, int mode, uint32_t waves_per_simd, uint32_t iters, float* ms_out) {
-    if (!c || !ms_out || !waves_per_simd || waves_per_simd > 8 || mode < 0 || mode > 3) return MBLS_ERR_ARGUMENT;
+    if (!c || !ms_out || !waves_per_simd || waves_per_simd > 8 || mode < 0 || mode > 6) return MBLS_ERR_ARGUMENT;
     mbls_lock lk(c->mu);
     HIPCHK(c, hipSetDevice(c->device));
     hipDeviceProp_t prop; HIPCHK(c, hipGetDeviceProperties(&prop, c->device));

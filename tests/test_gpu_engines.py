@@ -7,6 +7,7 @@ Routing (milagro_bls_amd/csrc/mbls_kernels.hip, verify_pipeline / launch_hash): 
 k_final2 (two lanes per item: the compressed squarings split, the other products in pairs), (16384, 20480] k_hash2 + k_miller_split (two lanes per item) + k_final2, (20480, 32768] k_hash + k_miller_split + k_final2, above 32768 k_hash + k_miller (two-pair loop) + k_sig_verdict + k_final; in both lane forms the signature's subgroup test is read off the
 Miller loop's running point. Above a round (65 536 items) the remainder is routed as a batch of its own -- or, from 3 584 items up, the last round and the remainder run as two halves
 side by side on two tracks (device entries)."""
+import os
 import random
 
 import pytest
@@ -520,3 +521,38 @@ def test_aggregate_verify_batch_above_a_round_of_pairs(n, kp):
     ctx = N.default_context()
     r = bench.aggregate_verify_leg(ctx, N.lib(), torch.device("cuda:0"), None, n=n, kp=kp)
     assert r["correct"] is True, r
+
+
+def test_a_remainder_on_the_wave_engine_never_grows_the_workspace_under_the_round(mb):
+    """a pass on the wave engine with k >= 32 keys sums its keys on eight lanes per item (n + 8 n workspace items). In a rounds-then-remainder plan the
+    remainder's 9 r items can exceed everything the round needs: the entry now sizes the workspace for the WHOLE plan before the first pass is queued
+    (mbls_plan_workspace_items is that figure) and a later pass never reallocates -- on a FRESH context (nothing reserved), small rounds, against the oracle, byte keys
+    and table indices; the same with the workspace pre-reserved for what the passes' own workspace_items say (too small: the call grows it ONCE, up front)."""
+    import torch
+    from milagro_bls_amd import _native as N
+    nt = min(32, os.cpu_count() or 8)
+    n, k = 168, 32
+    b = helpers.make_batch(n, k, fmt=1, seed=77, pool_n=64, nthreads=nt)
+    want = orc.batch_fast_aggregate_verify(b.sigs, b.msgs, b.pks, b.n, b.k, 1, nthreads=nt)
+    assert want == b.expect
+    dev = torch.device("cuda:0")
+    for prereserve in (False, True):
+        ctx = N.Context(0)
+        try:
+            ctx.set_round_items(128); ctx.set_tracks(0); ctx.set_coop_max_items(100); ctx.set_coop_hash_max_items(100)
+            L = ctx.limits()
+            mode, ps = N.plan_batch(n, L)
+            assert mode == N.BATCH_ROUNDS_THEN_REST and ps[1]["items"] == 40 and ps[1]["pairing"] == N.PAIRING_WAVE and ps[0]["pairing"] != N.PAIRING_WAVE
+            assert N.plan_workspace_items(n, k, True, L) == 9 * 40 > max(p["workspace_first"] + p["workspace_items"] for p in ps)
+            if prereserve:
+                ctx.reserve(max(p["workspace_first"] + p["workspace_items"] for p in ps))
+            got, st, bits = _device_call(N, ctx, dev, b.sigs, b.msgs, b.pks, n, k)
+            assert got == want and bits == [int(x) for x in got]
+            tab = N.KeyTable(ctx, capacity_hint=n * k)
+            first, errs = tab.append(b.pks, n * k, pk_format=1, validate=False)
+            assert first == 0
+            got2, st2, bits2 = _device_call(N, ctx, dev, b.sigs, b.msgs, None, n, k, table=tab, idx=list(range(n * k)))
+            assert got2 == want and st2 == st
+            tab.close()
+        finally:
+            ctx.close()
