@@ -20,7 +20,7 @@ f(buf, 1)
 t = time.perf_counter(); run(); ms = (time.perf_counter() - t) * 1e3
 f(buf, 1)
 names = ["END", "MUL", "LIN", "INV", "ISZ", "FLG", "LOADW", "STOREW", "RES", "POW", "SGN"]
-print("one call: %.2f ms (profiled build; the columns are in 10-clock units: "ns/step" / 10 = clocks per step)" % ms)
+print("one call: %.2f ms (profiled build; clocks per step = the ns/step column / 10)" % ms)
 tot = 0
 for kd, nm in enumerate(names):
     c, a, b, d = buf[4 * kd:4 * kd + 4]
