@@ -348,7 +348,7 @@ def valu_issue_figure(lib, ctx, phase_ms, n_items, agg_kernel="k_aggregate"):
     with open(cf) as f:
         census = json.load(f)
     rate, by_waves = {}, {}
-    for mode, name in ((0, "v_mad_u64_u32"), (1, "plain_valu")):
+    for mode, name in ((0, "v_mad_u64_u32"), (1, "plain_valu"), (7, "v_mad_i64_i32")):
         best = 0.0
         for w in (1, 2, 4, 8):                                      # the best rate any occupancy reaches (two calls each, the faster one)
             r_w = 0.0
@@ -383,12 +383,15 @@ def valu_issue_figure(lib, ctx, phase_ms, n_items, agg_kernel="k_aggregate"):
         blend = total / (mad / rate["v_mad_u64_u32"] + (total - mad) / rate["plain_valu"])
         ceil = max(blend, r_loop)                                       # whichever calibration stream issues faster
         ns = 1e9 / ach                                                  # SIMD time per wave-instruction
-        # mac_frac = the MAC-only roofline the review asked for: multiply-accumulate wave-instructions / kernel time against the rate the SAME instruction reaches
-        # alone at 8 waves per SIMD (measured above) -- 1 - mac_frac is what everything that is not a multiply-accumulate (reduction masks and shifts, carry passes,
+        # mac_frac = the MAC-only roofline the review asked for: multiply-accumulate wave-instructions / kernel time against the best rate a bare stream of
+        # v_mad_u64_u32 / v_mad_i64_i32 reaches at any occupancy (measured above; mac_frac_vs_r02_ubench_0p571: against the 0.571 G wave-instructions/s/SIMD of
+        # profiles/r02_ubench.txt's "mad+addc dependent" row at 8 waves, the figure the round-5 review used) -- 1 - mac_frac is what everything that is not a multiply-accumulate (reduction masks and shifts, carry passes,
         # additions between products, register moves, memory instructions, calls) and the one-wave issue rate cost together
         mac_ach = mad * n_items / 64.0 / (phase_ms[phase] * 1e-3) / N_SIMD
+        mac_peak = max(max(by_waves["v_mad_u64_u32@%dw" % w], by_waves["v_mad_i64_i32@%dw" % w]) for w in (1, 2, 4, 8))       # the best any occupancy reaches, either opcode
         out["kernels"][kern] = {"valu_wave_instr_per_item": total, "of_which_v_mad_u64_u32": mad, "achieved": ach, "ceiling": ceil, "ceiling_blend": blend, "ceiling_product_loop": r_loop, "frac": ach / ceil,
-                                "mac_achieved": mac_ach, "mac_peak_8_waves": by_waves["v_mad_u64_u32@8w"], "mac_frac": mac_ach / by_waves["v_mad_u64_u32@8w"], "mac_share_of_valu": mad / float(total),
+                                "mac_achieved": mac_ach, "mac_peak": mac_peak, "mac_frac": mac_ach / mac_peak, "mac_share_of_valu": mad / float(total),
+                                "mac_frac_vs_r02_ubench_0p571": mac_ach / 0.571e9,
                                 "ns_per_valu_instr": ns, "clk_per_valu_instr": ns * PEAK_CLOCK_GHZ,
                                 "clk_note": "ns x %.1f GHz peak clock; the clock under this instruction mix is lower, see DESIGN.md section 4" % PEAK_CLOCK_GHZ}
     return out

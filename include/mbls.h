@@ -418,7 +418,8 @@ int mbls_fp_mul_bench(mbls_ctx* ctx, uint64_t n_lanes, uint32_t iters, float* ms
  * v_mad_u64_u32, mode 1: v_add_co/v_addc chains. Returns elapsed ms (rate = waves_per_simd * iters * 128 / ms per SIMD).
  * mode 2: `iters` x 8 calls' worth of the generated Fp2 product routine inlined back to back (8 x 1 281 instructions per iteration, 980
  * multiply-accumulates each; use waves_per_simd <= 4): the rate of a kernel made of nothing but products. mode 3: the same with the paired
- * Fp product of the key-sum routines (8 x 923 instructions, 784 multiply-accumulates each). */
+ * Fp product of the key-sum routines (8 x 923 instructions, 784 multiply-accumulates each). modes 4-6 (scripts/dbg/class_vs_mix.py): 8 multiply-accumulates + 4 plain
+ * operations interleaved / in two blocks (192 instructions per iteration), the plain operations alone (128); mode 7: v_mad_i64_i32 on eight accumulators (128). */
 int mbls_valu_bench(mbls_ctx* ctx, int mode, uint32_t waves_per_simd, uint32_t iters, float* ms_out);
 
 /* ---- instrumentation: per-kernel HIP-event timing of the last *_device verify call (ms), for bench.py ---- */

@@ -740,6 +740,11 @@ __global__ void __launch_bounds__(WG) k_valu_bench(uint32_t* sink, uint32_t iter
                                     "v_add_u32_e32 %8, %12, %8\n v_and_b32_e32 %9, %13, %9\n v_add_u32_e32 %10, %13, %10\n v_xor_b32_e32 %11, %12, %11\n"
                                     : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3), "+v"(c4), "+v"(c5), "+v"(c6), "+v"(c7), "+v"(h0), "+v"(h1), "+v"(h2), "+v"(h3)
                                     : "v"(a), "v"(b) : "vcc", "s20", "s21", "s22", "s23");)
+        } else if (mode == 7) {
+            // the scans' own instruction: v_mad_i64_i32 on eight accumulators (the peak of bench.py's mac_frac: whichever of mode 0 and this one issues faster)
+            MBLS_REP16(asm volatile("v_mad_i64_i32 %0, vcc, %8, %9, %0\n v_mad_i64_i32 %1, s[20:21], %8, %9, %1\n v_mad_i64_i32 %2, vcc, %8, %9, %2\n v_mad_i64_i32 %3, s[22:23], %8, %9, %3\n"
+                                    "v_mad_i64_i32 %4, vcc, %8, %9, %4\n v_mad_i64_i32 %5, s[20:21], %8, %9, %5\n v_mad_i64_i32 %6, vcc, %8, %9, %6\n v_mad_i64_i32 %7, s[22:23], %8, %9, %7\n"
+                                    : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3), "+v"(c4), "+v"(c5), "+v"(c6), "+v"(c7) : "v"(a), "v"(b) : "vcc", "s20", "s21", "s22", "s23");)
         } else if (mode == 6) {
             // ... and the four plain operations alone
             MBLS_REP16(asm volatile("v_add_u32_e32 %0, %4, %0\n v_and_b32_e32 %1, %5, %1\n v_add_u32_e32 %2, %5, %2\n v_xor_b32_e32 %3, %4, %3\n"
@@ -1911,7 +1916,7 @@ extern "C" int mbls_fp_mul_bench(mbls_ctx* c, uint64_t n_lanes, uint32_t iters, 
 }
 
 extern "C" int mbls_valu_bench(mbls_ctx* c, int mode, uint32_t waves_per_simd, uint32_t iters, float* ms_out) {
-    if (!c || !ms_out || !waves_per_simd || waves_per_simd > 8 || mode < 0 || mode > 6) return MBLS_ERR_ARGUMENT;
+    if (!c || !ms_out || !waves_per_simd || waves_per_simd > 8 || mode < 0 || mode > 7) return MBLS_ERR_ARGUMENT;
     mbls_lock lk(c->mu);
     HIPCHK(c, hipSetDevice(c->device));
     hipDeviceProp_t prop; HIPCHK(c, hipGetDeviceProperties(&prop, c->device));
