@@ -96,12 +96,19 @@ def test_bench_two_ranks_sharing_the_gpu_real_verifier():
     assert len(lines) == 1, lines
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["bitmap_matches_expectation"] is True and len(d["ms_per_step_per_rank"]) == 2 and "share_gpu_test" in d
+    # what makes a SCALE line check itself: the process group's own rank count against n_gpus and the time of the one collective, timed alone
+    c = d["collective"]
+    assert c["group_world_size"] == 2 and c["group_rank_count_matches_n_gpus"] is True and c["all_gather_ms_per_step"] > 0 and c["backend"] == "gloo"
     # one rank, with the in-process multi-device leg (it makes an RCCL communicator): still one line on stdout
     p = subprocess.run([sys.executable, os.path.join(helpers.ROOT, "bench.py"), "--steps", "1", "--warmup", "1", "--items", "4096", "--no-cpu-baseline"],
                        capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stderr[-2000:]
     lines = [l for l in p.stdout.splitlines() if l.strip()]
-    assert len(lines) == 1 and json.loads(lines[0])["n_gpus"] == 1
+    d1 = json.loads(lines[0])
+    assert len(lines) == 1 and d1["n_gpus"] == 1 and d1["collective"] is None
+    assert d1["multi_legs_ok"] is True and all(l["ran"] and l["results_match"] for l in d1["multi_handle_leg"])
+    k = d1["valu_issue"]["kernels"]["k_miller"]
+    assert 0 < k["mac_frac"] < 1.0 and 0.5 < k["mac_share_of_valu"] < 0.8 and k["mac_peak"] > 0          # (4 096 items: not the kernels' operating point; the keys are what is checked)
 
 
 def test_bench_multi_device_leg_in_a_child_process():
