@@ -1061,13 +1061,15 @@ def main():
                 break
             # one device: here. More than one (RCCL between the devices of ONE process: never met hardware in the builder's runs): in a child process with a
             # time limit, so that a hang or a crash there costs this leg and not the line; a leg that RAN and disagrees with the expectation still fails the run
-            leg = multi_handle_leg(lib, table, d_sigs, d_msgs, d_idx, expect, n, k, [0]) if G == 1 else multi_leg_in_child(G, n, k)
+            leg = multi_handle_leg(lib, table, d_sigs, d_msgs, d_idx, expect, n, k, [0]) if G == 1 else multi_leg_in_child(G, n, k, timeout_s=240)
             # a leg that timed out, crashed or could not start carries 'error' and no 'results_match': it did NOT run -- said so per leg and in the line
             # ('multi_legs_ok' below), never counted as a pass
             leg["ran"] = "results_match" in leg
             multi_legs.append(leg)
             if leg["ran"]:
                 ok = ok and bool(leg["results_match"])
+            else:
+                break                                      # a leg that could not run (time limit, crash): the larger ones are not tried -- the line must not wait for them
     vm_leg = None
     if n == (1 << 16) and not args.no_variants:
         vm_leg = sharded_verify_multiple_leg(ctx, lib, dev, sptr, rank, world, k)
